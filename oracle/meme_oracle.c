@@ -1,0 +1,519 @@
+/* TEST INFRASTRUCTURE ONLY -- see meme_oracle.h.  Plain C restatement of
+ *   (1) BWA-MEME learned-index seeding  (reference src/LearnedIndex_seeding.cpp, src/bwamem.cpp:1230-1413)
+ *   (2) banded Smith-Waterman extension (reference src/bandedSWA.cpp:116-260 == src/ksw.cpp:434-535)
+ *
+ * Seeding is restated at the level of its *semantic contract* (SURVEY.md Appendix B): every search of
+ * the reference ends in the triple (match_len, range_start, count) that depends only on the suffix
+ * array order and the text, never on the learned model or on the probe sequence.  The oracle therefore
+ * locates by a plain binary search over the whole suffix array on the 1-byte/base text and derives the
+ * triple from longest-common-prefix values; the per-read pivot state machines (rounds 1-3) are restated
+ * statement by statement because their order of searches *is* output-visible.
+ */
+#include "meme_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * compare: reference compare_read_and_ref_binary* (src/LearnedIndex_seeding.cpp:226-601).
+ *   ref_len = n - SA[slot];  L = min(valid_len, ref_len);  lcp = common prefix of q[0,L) and text.
+ *   lcp <  L              -> match_len = lcp,     result = text[SA+lcp] < q[lcp]
+ *   lcp == L <  ref_len   -> match_len = L, exact, result = true   (suffix continues past the query)
+ *   lcp == L == ref_len   -> match_len = ref_len, result = false   (text ends: sorts as T-padded)
+ * ------------------------------------------------------------------------------------------------ */
+int orc_compare(const orc_index* idx, uint64_t slot, const uint8_t* q, int64_t valid_len,
+                uint32_t* match_len, int* exact) {
+    uint64_t pos = idx->sa[slot];
+    int64_t ref_len = idx->n - (int64_t)pos;
+    int64_t L = valid_len < ref_len ? valid_len : ref_len;
+    const uint8_t* t = idx->text + pos;
+    int64_t l = 0;
+    while (l < L && t[l] == q[l]) ++l;
+    *exact = 0;
+    if (l < L) {
+        *match_len = (uint32_t)l;
+        return t[l] < q[l];
+    }
+    if (L < ref_len) {
+        *match_len = (uint32_t)L;
+        *exact = 1;
+        return 1;
+    }
+    *match_len = (uint32_t)ref_len;
+    return 0;
+}
+
+/* capped LCP of q with the suffix in SA slot j */
+static uint32_t lcp_at(const orc_index* idx, int64_t j, const uint8_t* q, int64_t valid_len) {
+    uint32_t m;
+    int ex;
+    orc_compare(idx, (uint64_t)j, q, valid_len, &m, &ex);
+    return m;
+}
+
+static int ge_at(const orc_index* idx, int64_t j, const uint8_t* q, uint32_t L) {
+    return lcp_at(idx, j, q, (int64_t)L) >= L;
+}
+
+/* lowest slot lo' <= lo such that every slot in [lo', lo] shares >= L bases with q (lo does) */
+static int64_t extend_down(const orc_index* idx, const uint8_t* q, uint32_t L, int64_t lo) {
+    int64_t step = 1, good = lo, bad = -1;
+    while (good > 0) {
+        int64_t probe = good - step;
+        if (probe < 0) probe = 0;
+        if (ge_at(idx, probe, q, L)) { good = probe; step <<= 1; }
+        else { bad = probe; break; }
+    }
+    /* invariant: good matches, bad (if >=0) does not, bad < good */
+    while (good - bad > 1 && bad >= 0) {
+        int64_t mid = bad + (good - bad) / 2;
+        if (ge_at(idx, mid, q, L)) good = mid; else bad = mid;
+    }
+    return good;
+}
+
+static int64_t extend_up(const orc_index* idx, const uint8_t* q, uint32_t L, int64_t hi) {
+    int64_t step = 1, good = hi, bad = idx->n;
+    while (good < idx->n - 1) {
+        int64_t probe = good + step;
+        if (probe > idx->n - 1) probe = idx->n - 1;
+        if (ge_at(idx, probe, q, L)) { good = probe; step <<= 1; }
+        else { bad = probe; break; }
+    }
+    while (bad - good > 1 && bad < idx->n) {
+        int64_t mid = good + (bad - good) / 2;
+        if (ge_at(idx, mid, q, L)) good = mid; else bad = mid;
+    }
+    return good;
+}
+
+/* locate (mem_search / right_smem_search up to the "iter_pos points to best exact matching position"
+ * comment, src/LearnedIndex_seeding.cpp:2262-2358, 2802-2894): boundary between compare()==true and
+ * ==false in SA order; best = larger LCP of the two boundary neighbours. */
+static uint32_t locate(const orc_index* idx, const uint8_t* q, int64_t valid_len, int64_t* best) {
+    int64_t lo = 0, hi = idx->n;
+    uint32_t m;
+    int ex;
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo) / 2;
+        if (orc_compare(idx, (uint64_t)mid, q, valid_len, &m, &ex)) lo = mid + 1; else hi = mid;
+    }
+    uint32_t m_lo = 0, m_hi = 0;
+    int have_lo = lo > 0, have_hi = lo < idx->n;
+    if (have_lo) m_lo = lcp_at(idx, lo - 1, q, valid_len);
+    if (have_hi) m_hi = lcp_at(idx, lo, q, valid_len);
+    if (have_lo && (!have_hi || m_lo >= m_hi)) { *best = lo - 1; return m_lo; }
+    *best = lo;
+    return m_hi;
+}
+
+/* Level search shared by right_smem_search (src/LearnedIndex_seeding.cpp:2359-2574), mem_search
+ * (:2898-2943, 3155-3196) and their ISA-seeded twins (:3417-3461 ...):
+ *   L = maxLCP; loop { [s,e] = maximal SA run around best with LCP >= L; if (e-s+1 >= min_intv) stop;
+ *                      L = max(LCP(s-1), LCP(e+1)) (0 beyond the array ends) }                      */
+uint32_t orc_search(const orc_index* idx, const uint8_t* q, int64_t valid_len, int32_t min_intv,
+                    int64_t* start, int64_t* count, orc_counters* ctr) {
+    int64_t best;
+    uint32_t L = locate(idx, q, valid_len, &best);
+    int64_t s = best, e = best;
+    if (ctr) ctr->searches++;
+    for (;;) {
+        s = extend_down(idx, q, L, s);
+        e = extend_up(idx, q, L, e);
+        if (ctr) ctr->level_steps++;
+        if (e - s + 1 >= (int64_t)min_intv) break;
+        uint32_t lm = s > 0 ? lcp_at(idx, s - 1, q, (int64_t)L) : 0;
+        uint32_t um = e < idx->n - 1 ? lcp_at(idx, e + 1, q, (int64_t)L) : 0;
+        L = um > lm ? um : lm;
+    }
+    *start = s;
+    *count = e - s + 1;
+    return L;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const orc_index* idx;
+    const uint8_t* fw;       /* read, codes 0..4           (unpacked_queue_buf)    */
+    uint8_t* rc;             /* reverse complement, N -> 4 (unpacked_rc_queue_buf) */
+    int l_seq;
+    int min_seed_len, min_intv_limit;
+    int pivot, l_pivot;
+    orc_mem_tl* smems;
+    int smem_cap, n_smems;
+    uint64_t* hits;
+    int64_t hit_cap, n_hits;
+    int overflow;
+    orc_counters* ctr;
+} rstate;
+
+static void set_pivot(rstate* r, int pivot) {   /* set_forward_pivot, :68-71 */
+    r->pivot = pivot;
+    r->l_pivot = r->l_seq - 1 - pivot;
+}
+
+/* first ambiguous base at/after `from` (Tokenization's *ambiguous_pos, :795-901) */
+static int first_n(const uint8_t* buf, int from, int l_seq) {
+    for (int i = from; i < l_seq; ++i)
+        if (buf[i] >= 4) return i;
+    return l_seq;
+}
+
+/* right_smem_search (:2131-2664): search to the right of pivot, emit an SMEM if long enough */
+static uint32_t right_smem(rstate* r) {
+    int amb = first_n(r->fw, r->pivot, r->l_seq);
+    int64_t valid = amb - r->pivot, s, c;
+    uint32_t L = orc_search(r->idx, r->fw + r->pivot, valid, r->min_intv_limit, &s, &c, r->ctr);
+    if ((int)L >= r->min_seed_len) {
+        if (r->n_smems >= r->smem_cap || r->n_hits + c > r->hit_cap) { r->overflow = 1; return L; }
+        orc_mem_tl* m = &r->smems[r->n_smems++];
+        m->start = r->pivot;
+        m->end = r->pivot + (int)L;
+        m->hitbeg = (int32_t)r->n_hits;
+        m->hitcount = (int32_t)c;
+        m->cache_refpos = r->idx->sa[s];
+        for (int64_t i = 0; i < c; ++i) r->hits[r->n_hits++] = r->idx->sa[s + i];
+        if (r->ctr) { r->ctr->smems++; r->ctr->hits += c; }
+    }
+    return L;
+}
+
+/* mem_search (:2667-3204): direction 1 = right of pivot on the read, 0 = left of pivot, i.e. to the
+ * right of l_pivot on the reverse-complemented read */
+static uint32_t mem_only(rstate* r, int right) {
+    int64_t s, c;
+    if (right) {
+        int amb = first_n(r->fw, r->pivot, r->l_seq);
+        return orc_search(r->idx, r->fw + r->pivot, amb - r->pivot, r->min_intv_limit, &s, &c, r->ctr);
+    }
+    int amb = first_n(r->rc, r->l_pivot, r->l_seq);
+    return orc_search(r->idx, r->rc + r->l_pivot, amb - r->l_pivot, r->min_intv_limit, &s, &c, r->ctr);
+}
+
+/* the zig-zag shared by step1 and OnePos: from search_pivot extend left to the MEM start, then right
+ * to the SMEM end; repeat until next_pivot is reached (:1724-1849, 1969-2084).  check_n: step1 skips
+ * ambiguous bases inside the loop (:1725-1736), OnePos cannot meet one. */
+static void zigzag(rstate* r, int next_pivot, int check_n) {
+    int search_pivot = r->pivot;
+    int guard = 0;
+    while (search_pivot < next_pivot) {
+        if (++guard > 4 * r->l_seq + 16) break;   /* the reference would spin; never seen */
+        if (check_n && r->fw[search_pivot] >= 4) {
+            if (r->l_seq - search_pivot < r->min_seed_len) {
+                set_pivot(r, r->l_seq);
+                search_pivot = r->l_seq;
+            } else {
+                search_pivot += 1;
+                set_pivot(r, r->pivot + 1);
+            }
+            continue;
+        }
+        uint32_t ss = mem_only(r, 0);
+        set_pivot(r, r->pivot - (int)ss + 1);
+        if (next_pivot - r->pivot < r->min_seed_len) break;
+        ss = right_smem(r);
+        search_pivot = r->pivot + (int)ss;
+        set_pivot(r, search_pivot);
+    }
+}
+
+/* Learned_getSMEMsOnePosOneThread_step1 (:1691-1894) */
+static void step1(rstate* r) {
+    int next_pivot;
+    if (r->fw[r->pivot] >= 4) {
+        if (r->l_seq - r->pivot < r->min_seed_len) set_pivot(r, r->l_seq);
+        else set_pivot(r, r->pivot + 1);
+        return;
+    }
+    if (r->pivot != 0 && r->fw[r->pivot - 1] < 4) {
+        next_pivot = r->l_seq;
+        zigzag(r, next_pivot, 1);
+    } else {
+        uint32_t L = right_smem(r);
+        next_pivot = r->pivot + (int)L;
+    }
+    set_pivot(r, next_pivot);
+}
+
+/* Learned_getSMEMsOnePosOneThread (:1897-2126) */
+static void one_pos(rstate* r) {
+    int next_pivot;
+    if (r->fw[r->pivot] >= 4) {
+        if (r->l_seq - r->pivot < r->min_seed_len) set_pivot(r, r->l_seq);
+        else set_pivot(r, r->pivot + 1);
+        return;
+    }
+    if (r->pivot != 0 && r->fw[r->pivot - 1] < 4) {
+        uint32_t L = mem_only(r, 1);
+        next_pivot = r->pivot + (int)L;
+        zigzag(r, next_pivot, 0);
+    } else {
+        uint32_t L = right_smem(r);
+        next_pivot = r->pivot + (int)L;
+    }
+    set_pivot(r, next_pivot);
+}
+
+/* Learned_getSMEMsAllPosOneThread (:913-972) / _step1only (:904-911) */
+static void all_pos(rstate* r, int split_len, int split_width, int with_round2) {
+    set_pivot(r, 0);
+    int guard = 0;
+    while (r->pivot < r->l_seq) {
+        if (++guard > 4 * r->l_seq + 16) break;
+        int before = r->n_smems;
+        step1(r);
+        int after = r->n_smems;
+        if (!with_round2) continue;
+        for (int k = before; k < after; ++k) {
+            int next_pivot = r->pivot;
+            int saved = r->min_intv_limit;
+            int qbeg = r->smems[k].start, qend = r->smems[k].end;
+            if (qend - qbeg < split_len || r->smems[k].hitcount > split_width) {
+                set_pivot(r, next_pivot);
+                continue;
+            }
+            set_pivot(r, (qbeg + qend) >> 1);
+            r->min_intv_limit = r->smems[k].hitcount + 1;
+            one_pos(r);
+            r->min_intv_limit = saved;
+            set_pivot(r, next_pivot);
+        }
+    }
+}
+
+/* Learned_bwtSeedStrategyAllPosOneThread (:974-1283) and its ISA twin (:1284-1466): from every pivot
+ * the shortest match of >= min_seed_len bases that occurs fewer than min_intv times. */
+static void seed_strategy(rstate* r) {
+    const orc_index* idx = r->idx;
+    const int min_intv = r->min_intv_limit, msl = r->min_seed_len;
+    set_pivot(r, 0);
+    while (r->pivot < r->l_seq - msl + 1) {
+        if (r->fw[r->pivot] >= 4) { set_pivot(r, r->pivot + 1); continue; }
+        int amb = first_n(r->fw, r->pivot, r->l_seq);
+        int valid = amb - r->pivot;
+        if (valid < msl) { set_pivot(r, r->pivot + valid); continue; }
+        const uint8_t* q = r->fw + r->pivot;
+        int64_t best;
+        uint32_t L = locate(idx, q, valid, &best);
+        if (r->ctr) r->ctr->searches++;
+        if ((int)L < msl) { set_pivot(r, r->pivot + msl); continue; }
+        int64_t s = best, e = best, last_s = best, last_cnt = 0, cnt, emit_s;
+        uint32_t match_len;
+        for (;;) {
+            s = extend_down(idx, q, L, s);
+            e = extend_up(idx, q, L, e);
+            if (r->ctr) r->ctr->level_steps++;
+            cnt = e - s + 1;
+            if (cnt >= min_intv) {            /* :1243-1251 */
+                cnt = last_cnt ? last_cnt : cnt;
+                emit_s = last_s;
+                match_len = L + 1;
+                break;
+            }
+            uint32_t lm = s > 0 ? lcp_at(idx, s - 1, q, (int64_t)L) : 0;
+            uint32_t um = e < idx->n - 1 ? lcp_at(idx, e + 1, q, (int64_t)L) : 0;
+            uint32_t nxt = um > lm ? um : lm;
+            if ((int)nxt < msl) {             /* :1252-1258 */
+                match_len = (uint32_t)msl;
+                emit_s = s;
+                break;
+            }
+            last_cnt = cnt;                   /* :1259-1262 */
+            last_s = s;
+            L = nxt;
+        }
+        if (cnt < min_intv) {                 /* :1265-1277 */
+            if ((int)match_len < msl) match_len = (uint32_t)msl;
+            if (r->n_smems >= r->smem_cap || r->n_hits + cnt > r->hit_cap) { r->overflow = 1; return; }
+            orc_mem_tl* m = &r->smems[r->n_smems++];
+            m->start = r->pivot;
+            m->end = r->pivot + (int)match_len;
+            m->hitbeg = (int32_t)r->n_hits;
+            m->hitcount = (int32_t)cnt;
+            m->cache_refpos = idx->sa[emit_s];
+            for (int64_t i = 0; i < cnt; ++i) r->hits[r->n_hits++] = idx->sa[emit_s + i];
+            if (r->ctr) { r->ctr->smems++; r->ctr->hits += cnt; }
+        }
+        set_pivot(r, r->pivot + (int)match_len);
+    }
+}
+
+/* per-read driver: the seeding part of mem_kernel1_core_Learned (src/bwamem.cpp:1249-1394) */
+int orc_seed_read(const orc_index* idx, const uint8_t* read, int32_t len, const orc_seed_params* p,
+                  orc_mem_tl* smems, int32_t smem_cap, int32_t* n_smems,
+                  uint64_t* hits, int64_t hit_cap, int64_t* n_hits, orc_counters* ctr) {
+    rstate r;
+    memset(&r, 0, sizeof(r));
+    uint8_t* rc = (uint8_t*)malloc((size_t)len + 1);
+    for (int i = 0; i < len; ++i) rc[len - 1 - i] = read[i] < 4 ? 3 - read[i] : 4;  /* :1277-1280 */
+    r.idx = idx; r.fw = read; r.rc = rc; r.l_seq = len;
+    r.min_seed_len = p->min_seed_len;
+    r.min_intv_limit = 1;
+    r.smems = smems; r.smem_cap = smem_cap; r.hits = hits; r.hit_cap = hit_cap; r.ctr = ctr;
+    if (len > 0) {
+        all_pos(&r, p->split_len, p->split_width, p->steps >= 2);
+        if (p->steps >= 3 && p->max_mem_intv > 0 && !r.overflow) {   /* :1385-1394 */
+            r.min_intv_limit = p->max_mem_intv;
+            r.min_seed_len = p->min_seed_len + 1;
+            seed_strategy(&r);
+        }
+    }
+    free(rc);
+    *n_smems = r.n_smems;
+    *n_hits = r.n_hits;
+    return r.overflow ? -1 : 0;
+}
+
+int orc_seed_batch(const orc_index* idx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                   const orc_seed_params* p, orc_mem_tl* smems, int32_t smem_cap, int32_t* n_smems,
+                   uint64_t* hits, int64_t hit_cap_per_read, int64_t* n_hits, orc_counters* ctr,
+                   int threads) {
+    int rc_all = 0;
+    orc_counters total;
+    memset(&total, 0, sizeof(total));
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+    {
+        orc_counters mine;
+        memset(&mine, 0, sizeof(mine));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 64)
+#endif
+        for (int64_t i = 0; i < nreads; ++i) {
+            int rc = orc_seed_read(idx, reads + read_off[i], (int32_t)(read_off[i + 1] - read_off[i]), p,
+                                   smems + i * smem_cap, smem_cap, &n_smems[i],
+                                   hits + i * hit_cap_per_read, hit_cap_per_read, &n_hits[i], &mine);
+            if (rc) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+                rc_all = -1;
+            }
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            total.searches += mine.searches; total.level_steps += mine.level_steps;
+            total.smems += mine.smems; total.hits += mine.hits;
+        }
+    }
+    if (ctr) *ctr = total;
+    return rc_all;
+}
+
+/* ================================================================================================
+ * Banded Smith-Waterman extension: scalarBandedSWA (reference src/bandedSWA.cpp:116-237), which is
+ * ksw_extend2 (src/ksw.cpp:434-535).  Rows = target (reference) bases, columns = query bases.
+ * eh[j] keeps { H(i-1,j-1), E(i,j) } exactly like the reference, *including* the stale entries it
+ * leaves outside the current band -- they are read again when the band re-grows, so they are part of
+ * the function's observable behaviour.
+ * ================================================================================================ */
+int orc_bsw_extend(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int w, int h0,
+                   const orc_bsw_params* p, int* _qle, int* _tle, int* _gtle, int* _gscore,
+                   int* _max_off, int64_t* cells) {
+    const int o_del = p->o_del, e_del = p->e_del, o_ins = p->o_ins, e_ins = p->e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int32_t* H = (int32_t*)calloc((size_t)qlen + 1, sizeof(int32_t));
+    int32_t* E = (int32_t*)calloc((size_t)qlen + 1, sizeof(int32_t));
+    /* scoring matrix of bwa_fill_scmat (src/bwa.cpp:262-270): a on the diagonal, -b off it, -1 with N */
+    int i, j, beg, end, max, max_i, max_j, max_ie, gscore, max_off;
+    int64_t ncell = 0;
+    /* first row (:143-145) */
+    H[0] = h0;
+    H[1] = h0 > oe_ins ? h0 - oe_ins : 0;
+    for (j = 2; j <= qlen && H[j - 1] > e_ins; ++j) H[j] = H[j - 1] - e_ins;
+    /* band cap from the best possible score (:148-156); max of the matrix is a (a>0) */
+    {
+        int mx = p->a > 0 ? p->a : 0;
+        int max_ins = (int)((double)(qlen * mx + p->end_bonus - o_ins) / e_ins + 1.);
+        if (max_ins < 1) max_ins = 1;
+        if (w > max_ins) w = max_ins;
+        int max_del = (int)((double)(qlen * mx + p->end_bonus - o_del) / e_del + 1.);
+        if (max_del < 1) max_del = 1;
+        if (w > max_del) w = max_del;
+    }
+    max = h0; max_i = max_j = -1; max_ie = -1; gscore = -1; max_off = 0;
+    beg = 0; end = qlen;
+    for (i = 0; i < tlen; ++i) {
+        int f = 0, h1, m = 0, mj = -1;
+        const int tb = target[i];
+        if (beg < i - w) beg = i - w;
+        if (end > i + w + 1) end = i + w + 1;
+        if (end > qlen) end = qlen;
+        if (beg == 0) {
+            h1 = h0 - (o_del + e_del * (i + 1));
+            if (h1 < 0) h1 = 0;
+        } else h1 = 0;
+        for (j = beg; j < end; ++j) {
+            int M = H[j], e = E[j], h, t;
+            int qb = query[j];
+            int sc = (tb > 3 || qb > 3) ? -1 : (tb == qb ? p->a : -p->b);
+            H[j] = h1;
+            M = M ? M + sc : 0;
+            h = M > e ? M : e;
+            h = h > f ? h : f;
+            h1 = h;
+            mj = m > h ? mj : j;
+            m = m > h ? m : h;
+            t = M - oe_del; t = t > 0 ? t : 0;
+            e -= e_del; e = e > t ? e : t;
+            E[j] = e;
+            t = M - oe_ins; t = t > 0 ? t : 0;
+            f -= e_ins; f = f > t ? f : t;
+            ++ncell;
+        }
+        H[end] = h1; E[end] = 0;
+        if (j == qlen) {
+            max_ie = gscore > h1 ? max_ie : i;
+            gscore = gscore > h1 ? gscore : h1;
+        }
+        if (m == 0) break;
+        if (m > max) {
+            max = m; max_i = i; max_j = mj;
+            int off = mj - i; if (off < 0) off = -off;
+            max_off = max_off > off ? max_off : off;
+        } else if (p->zdrop > 0) {
+            if (i - max_i > mj - max_j) {
+                if (max - m - ((i - max_i) - (mj - max_j)) * e_del > p->zdrop) break;
+            } else {
+                if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > p->zdrop) break;
+            }
+        }
+        for (j = beg; j < end && H[j] == 0 && E[j] == 0; ++j) {}
+        beg = j;
+        for (j = end; j >= beg && H[j] == 0 && E[j] == 0; --j) {}
+        end = j + 2 < qlen ? j + 2 : qlen;
+    }
+    free(H); free(E);
+    if (_qle) *_qle = max_j + 1;
+    if (_tle) *_tle = max_i + 1;
+    if (_gtle) *_gtle = max_ie + 1;
+    if (_gscore) *_gscore = gscore;
+    if (_max_off) *_max_off = max_off;
+    if (cells) *cells += ncell;
+    return max;
+}
+
+/* scalarBandedSWAWrapper (src/bandedSWA.cpp:242-260) -- also what getScores8/16 compute */
+void orc_bsw_batch(orc_seqpair* pairs, const uint8_t* ref, const uint8_t* qer, int32_t n, int32_t w,
+                   const orc_bsw_params* p, int threads, int64_t* cells) {
+    int64_t total = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : total)
+#endif
+    for (int32_t i = 0; i < n; ++i) {
+        orc_seqpair* s = &pairs[i];
+        int64_t c = 0;
+        s->score = orc_bsw_extend(s->len2, qer + s->idq, s->len1, ref + s->idr, w, s->h0, p, &s->qle,
+                                  &s->tle, &s->gtle, &s->gscore, &s->max_off, &c);
+        total += c;
+    }
+    if (cells) *cells = total;
+}

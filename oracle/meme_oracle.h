@@ -1,0 +1,93 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the BWA-MEME learned-index seeding
+ * path and of the banded Smith-Waterman seed extension.  Nothing under oracle/ is linked into,
+ * imported by or executed from the product path (bwa-meme_amd/, include/); only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this oracle against seed dumps and
+ * SeqPair dumps produced by the compiled reference (oracle/_ref, built from /root/reference by
+ * oracle/Makefile.ref; generator script tests/golden/make_golden.py), and tests/test_ref_live.py
+ * re-checks it against the reference binaries whenever oracle/_ref is present.
+ */
+#ifndef MEME_ORACLE_H
+#define MEME_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* = mem_tl, reference src/LearnedIndex_seeding.h:121-127 */
+typedef struct {
+    int32_t start, end;      /* [start,end) in the read */
+    int32_t hitbeg, hitcount;
+    uint64_t cache_refpos;   /* text position of the first hit */
+} orc_mem_tl;
+
+/* the index as plain arrays: fwd+rc text, 1 byte per base (".0123"), and the suffix array */
+typedef struct {
+    const uint8_t* text;
+    const uint64_t* sa;
+    int64_t n;               /* = 2*l_pac */
+} orc_index;
+
+typedef struct {
+    int32_t min_seed_len;    /* opt->min_seed_len (19) */
+    int32_t split_len;       /* (int)(min_seed_len*split_factor+.499) (28) */
+    int32_t split_width;     /* opt->split_width (10) */
+    int32_t max_mem_intv;    /* opt->max_mem_intv (20); 0 disables round 3 */
+    int32_t steps;           /* 1: round 1 only, 2: +re-seeding, 3: +round 3 (test harness "steps") */
+} orc_seed_params;
+
+/* work counters: the deterministic per-dataset figures of SURVEY.md section 8(d) */
+typedef struct {
+    int64_t searches;        /* locate operations (right/left, any round) */
+    int64_t level_steps;     /* interval (count) evaluations */
+    int64_t smems, hits;
+} orc_counters;
+
+/* Seeds one read (codes 0..3, >=4 = N).  Returns 0, or -1 if a capacity was exceeded. */
+int orc_seed_read(const orc_index* idx, const uint8_t* read, int32_t len, const orc_seed_params* p,
+                  orc_mem_tl* smems, int32_t smem_cap, int32_t* n_smems,
+                  uint64_t* hits, int64_t hit_cap, int64_t* n_hits, orc_counters* ctr);
+
+/* Batch driver (OpenMP over reads).  reads: concatenated codes, read_off[nreads+1].
+ * Outputs are per-read slots: smems[r*smem_cap ..], n_smems[r]; hits are written through
+ * hit_off (computed by a first counting pass inside): caller passes hits capacity. */
+int orc_seed_batch(const orc_index* idx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                   const orc_seed_params* p, orc_mem_tl* smems, int32_t smem_cap, int32_t* n_smems,
+                   uint64_t* hits, int64_t hit_cap_per_read, int64_t* n_hits, orc_counters* ctr,
+                   int threads);
+
+/* single primitives, exposed for unit tests */
+int orc_compare(const orc_index* idx, uint64_t sa_slot, const uint8_t* q, int64_t valid_len,
+                uint32_t* match_len, int* exact);
+/* locate + level search: returns match_len L = max l <= maxLCP with f(l) >= min_intv;
+ * *start,*count = SA interval of suffixes sharing >= L bases with q */
+uint32_t orc_search(const orc_index* idx, const uint8_t* q, int64_t valid_len, int32_t min_intv,
+                    int64_t* start, int64_t* count, orc_counters* ctr);
+
+/* ---- banded Smith-Waterman extension ---------------------------------------------------------- */
+typedef struct {
+    int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus, a, b;
+} orc_bsw_params;
+
+/* = SeqPair, reference src/bandedSWA.h:90-99 (56 bytes) */
+typedef struct {
+    int32_t idr, idq, id;
+    int32_t len1, len2;
+    int32_t h0;
+    int32_t seqid, regid;
+    int32_t score, tle, gtle, qle;
+    int32_t gscore, max_off;
+} orc_seqpair;
+
+int orc_bsw_extend(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int w, int h0,
+                   const orc_bsw_params* p, int* qle, int* tle, int* gtle, int* gscore, int* max_off,
+                   int64_t* cells);
+void orc_bsw_batch(orc_seqpair* pairs, const uint8_t* ref, const uint8_t* qer, int32_t n, int32_t w,
+                   const orc_bsw_params* p, int threads, int64_t* cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,137 @@
+"""ctypes access to the C oracle (oracle/_build/libmeme_oracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+
+class MemTl(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("hitbeg", C.c_int32),
+                ("hitcount", C.c_int32), ("cache_refpos", C.c_uint64)]
+
+
+MEM_TL_DTYPE = np.dtype([("start", "<i4"), ("end", "<i4"), ("hitbeg", "<i4"), ("hitcount", "<i4"),
+                         ("cache_refpos", "<u8")])
+SEQPAIR_DTYPE = np.dtype([(n, "<i4") for n in
+                          ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid", "score", "tle",
+                           "gtle", "qle", "gscore", "max_off")])
+assert MEM_TL_DTYPE.itemsize == 24 and SEQPAIR_DTYPE.itemsize == 56
+
+
+class OrcIndex(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("sa", C.c_void_p), ("n", C.c_int64)]
+
+
+class OrcSeedParams(C.Structure):
+    _fields_ = [("min_seed_len", C.c_int32), ("split_len", C.c_int32), ("split_width", C.c_int32),
+                ("max_mem_intv", C.c_int32), ("steps", C.c_int32)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [("searches", C.c_int64), ("level_steps", C.c_int64), ("smems", C.c_int64),
+                ("hits", C.c_int64)]
+
+
+class OrcBswParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("o_del", "e_del", "o_ins", "e_ins", "zdrop", "end_bonus", "a", "b")]
+
+
+def build():
+    subprocess.run(["make", "-s", "-f", "oracle/Makefile"], cwd=REPO, check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(REPO, "oracle", "_build", "libmeme_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_seed_batch.restype = C.c_int
+        _LIB.orc_bsw_batch.restype = None
+        _LIB.orc_search.restype = C.c_uint32
+    return _LIB
+
+
+def default_seed_params(steps=3):
+    return OrcSeedParams(19, 28, 10, 20, steps)
+
+
+def default_bsw_params(end_bonus=5):
+    # mem_opt_init (reference src/bwamem.cpp:126-162): a=1 b=4 o=6 e=1 zdrop=100 pen_clip=5
+    return OrcBswParams(6, 1, 6, 1, 100, end_bonus, 1, 4)
+
+
+class Index:
+    """text = fwd+rc codes (uint8), sa = uint64 suffix array"""
+
+    def __init__(self, text: np.ndarray, sa: np.ndarray):
+        self.text = np.ascontiguousarray(text, dtype=np.uint8)
+        self.sa = np.ascontiguousarray(sa, dtype=np.uint64)
+        assert self.text.shape[0] == self.sa.shape[0]
+        self.c = OrcIndex(self.text.ctypes.data, self.sa.ctypes.data, self.text.shape[0])
+
+
+def seed_batch(index: Index, reads: np.ndarray, read_off: np.ndarray, params=None, smem_cap=512,
+               hit_cap=1 << 16, threads=0):
+    """Returns (smems [nreads, smem_cap] structured, n_smems, hits [nreads, hit_cap], n_hits, counters)."""
+    params = params or default_seed_params()
+    reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    n = read_off.shape[0] - 1
+    smems = np.zeros((n, smem_cap), dtype=MEM_TL_DTYPE)
+    n_smems = np.zeros(n, dtype=np.int32)
+    hits = np.zeros((n, hit_cap), dtype=np.uint64)
+    n_hits = np.zeros(n, dtype=np.int64)
+    ctr = OrcCounters()
+    rc = lib().orc_seed_batch(C.byref(index.c), C.c_void_p(reads.ctypes.data), C.c_void_p(read_off.ctypes.data),
+                              C.c_int64(n), C.byref(params), C.c_void_p(smems.ctypes.data), C.c_int32(smem_cap),
+                              C.c_void_p(n_smems.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_int64(hit_cap),
+                              C.c_void_p(n_hits.ctypes.data), C.byref(ctr), C.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("oracle capacity exceeded (raise smem_cap / hit_cap)")
+    return smems, n_smems, hits, n_hits, ctr
+
+
+def bsw_batch(pairs: np.ndarray, ref: np.ndarray, qer: np.ndarray, w: int, params=None, threads=0):
+    """pairs: SEQPAIR_DTYPE array (modified in place). Returns number of DP cells evaluated."""
+    params = params or default_bsw_params()
+    assert pairs.dtype == SEQPAIR_DTYPE and pairs.flags.c_contiguous
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qer = np.ascontiguousarray(qer, dtype=np.uint8)
+    cells = C.c_int64(0)
+    lib().orc_bsw_batch(C.c_void_p(pairs.ctypes.data), C.c_void_p(ref.ctypes.data), C.c_void_p(qer.ctypes.data),
+                        C.c_int32(pairs.shape[0]), C.c_int32(w), C.byref(params), C.c_int(threads), C.byref(cells))
+    return cells.value
+
+
+def format_seed_dump(smems, n_smems, hits, first_id=0):
+    """The `steps=4` text dump of the reference harness (test/Learned_seeding_big_read.cpp:286-299):
+    per read "<id>:" then one "[start,end] [hit,hit,]" line per SMEM sorted by (start asc, end desc)."""
+    out = []
+    for r in range(n_smems.shape[0]):
+        out.append("%d:" % (r + first_id))
+        k = int(n_smems[r])
+        s = smems[r, :k] if smems.ndim == 2 else smems[r][:k]
+        order = sorted(range(k), key=lambda i: (int(s["start"][i]), -int(s["end"][i])))
+        for i in order:
+            hb, hc = int(s["hitbeg"][i]), int(s["hitcount"][i])
+            hv = hits[r][hb:hb + hc]
+            out.append("[%d,%d] [%s]" % (s["start"][i], s["end"][i], "".join("%d," % h for h in hv)))
+    return "\n".join(out) + "\n"
+
+
+def load_index_files(prefix: str) -> Index:
+    text = np.fromfile(prefix + ".0123", dtype=np.uint8)
+    raw = np.fromfile(prefix + ".pos_packed", dtype=np.uint8).reshape(-1, 5)
+    sa = (raw[:, :4].copy().view("<u4").reshape(-1).astype(np.uint64) << np.uint64(8)) | raw[:, 4].astype(np.uint64)
+    return Index(text, sa)

@@ -1,0 +1,66 @@
+"""ctypes / subprocess access to the *compiled reference* under oracle/_ref (TEST INFRASTRUCTURE ONLY).
+
+oracle/_ref is built from /root/reference by oracle/Makefile.ref in the build container; the binaries
+travel to the GPU box, the sources do not.  Everything here degrades to "not available" when the
+directory is missing or the host CPU cannot run the binaries (they are compiled for AVX-512 when the
+build host has it).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from oracle_py import SEQPAIR_DTYPE, OrcBswParams, REPO
+
+REF_DIR = os.path.join(REPO, "oracle", "_ref")
+_BSW = None
+
+
+def have(name: str) -> bool:
+    return os.path.exists(os.path.join(REF_DIR, name))
+
+
+def cpu_can_run() -> bool:
+    """The reference objects are built with the SIMD level recorded in oracle/_ref/SIMD."""
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    want = "avx512bw"
+    p = os.path.join(REF_DIR, "SIMD")
+    if os.path.exists(p):
+        want = open(p).read().strip().lstrip("-m") or want
+    return (want in flags) or want.startswith("sse")
+
+
+def bsw_lib():
+    global _BSW
+    if _BSW is None:
+        _BSW = C.CDLL(os.path.join(REF_DIR, "libbsw_ref.so"))
+        assert _BSW.ref_sizeof_seqpair() == SEQPAIR_DTYPE.itemsize
+    return _BSW
+
+
+def bsw_run(kind: int, pairs: np.ndarray, ref: np.ndarray, qer: np.ndarray, w: int, params: OrcBswParams):
+    """kind 0 = scalarBandedSWAWrapper, 16 = getScores16, 8 = getScores8 (reference src/bandedSWA.h).
+    Returns a copy of `pairs` with the six outputs filled by the reference."""
+    n = pairs.shape[0]
+    buf = np.zeros(n + 128, dtype=SEQPAIR_DTYPE)  # the SIMD wrappers pad past numPairs
+    buf[:n] = pairs
+    # the SIMD wrappers read sequence bytes of the padding pairs too -> keep slack in the buffers
+    ref = np.concatenate([np.ascontiguousarray(ref, dtype=np.uint8), np.zeros(1 << 16, np.uint8)])
+    qer = np.concatenate([np.ascontiguousarray(qer, dtype=np.uint8), np.zeros(1 << 16, np.uint8)])
+    rc = bsw_lib().ref_bsw_run(C.c_int(kind), C.c_void_p(buf.ctypes.data), C.c_void_p(ref.ctypes.data),
+                               C.c_void_p(qer.ctypes.data), C.c_int32(n), C.c_int32(w), C.byref(params))
+    assert rc == 0
+    return buf[:n].copy()
+
+
+def run_seed_dump(prefix: str, fastq: str, mode: int = 3, steps: int = 4, threads: int = 1, timeout=600) -> str:
+    exe = os.path.join(REF_DIR, "learned_seeding_mode%d" % mode)
+    out = subprocess.run([exe, prefix, fastq, "1000", str(threads), str(steps)], capture_output=True,
+                         timeout=timeout, check=True)
+    return out.stdout.decode()

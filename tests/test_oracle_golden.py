@@ -1,0 +1,51 @@
+"""Pins the C oracle (and our index builder) against golden vectors produced by the COMPILED
+REFERENCE (tests/golden/make_golden.py): seed dumps of learned_seeding_big_read and the six outputs of
+scalarBandedSWAWrapper.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import bsw_gen
+import oracle_py as O
+from common import GOLDEN, build_index, read_fastq_codes
+
+
+@pytest.fixture(scope="module")
+def g1_index():
+    return O.load_index_files(build_index(os.path.join(GOLDEN, "g1.fa")))
+
+
+@pytest.mark.parametrize("length", [150, 250, 60, 25])
+def test_oracle_seeds_equal_reference_dump(g1_index, length):
+    reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
+    sm, ns, hits, nh, _ = O.seed_batch(g1_index, reads, off, smem_cap=256, hit_cap=4096, threads=2)
+    dump = O.format_seed_dump(sm, ns, hits)
+    want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()
+    assert dump == want
+
+
+@pytest.mark.parametrize("w,eb", [(100, 5), (100, 0), (200, 5), (200, 0)])
+def test_oracle_bsw_equals_reference_scalar(w, eb):
+    z = np.load(os.path.join(GOLDEN, "bsw_golden.npz"))
+    pairs = z["pairs"].copy()
+    O.bsw_batch(pairs, z["ref"], z["qer"], w, O.default_bsw_params(end_bonus=eb), threads=2)
+    assert np.array_equal(bsw_gen.outputs(pairs), z["scalar_w%d_eb%d" % (w, eb)])
+
+
+def test_reference_simd16_agrees_with_scalar_where_it_matters():
+    """The reference's AVX-512 kernel deviates from its scalar twin only in (gtle, gscore) of pairs whose
+    end-to-end score cannot win; the values mem_chain2aln commits (src/bwamem.cpp:3020-3036: local vs
+    to-end decision, query/ref ends, truesc) are identical."""
+    z = np.load(os.path.join(GOLDEN, "bsw_golden.npz"))
+    a, b = z["scalar_w100_eb5"], z["simd16_w100_eb5"]
+    pen_clip = 5
+
+    def committed(o):
+        score, tle, gtle, qle, gscore = o[:, 0], o[:, 1], o[:, 2], o[:, 3], o[:, 4]
+        local = (gscore <= 0) | (gscore <= score - pen_clip)
+        return np.where(local, qle, -1), np.where(local, tle, gtle), np.where(local, score, gscore)
+
+    for x, y in zip(committed(a), committed(b)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[:, 0], b[:, 0]) and np.array_equal(a[:, 5], b[:, 5])
