@@ -1,0 +1,309 @@
+// Banded Smith-Waterman seed extension on MI355X.
+//
+// Replaces BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper (reference
+// src/bandedSWA.cpp:242-260, 1970-2261, 2664-2961), whose common semantics are scalarBandedSWA
+// (src/bandedSWA.cpp:116-237) == ksw_extend2 (src/ksw.cpp:434-535).
+//
+// Why row-synchronous and not anti-diagonal: the function's observable behaviour is defined row by row
+// -- the band [beg,end) of row i+1 is trimmed from the zero runs of row i (:217-221), the z-drop / m==0
+// exits (:206-216) and the max/gscore tie rules (:188-189, :202-205) are evaluated per row, and the
+// H/E array keeps *stale* cells outside the band that are read again when the band re-grows.  An
+// anti-diagonal sweep would have to replay those row-granular decisions anyway.  Instead each row is
+// computed across the 64 lanes of one wavefront: the only in-row dependency, the F (insertion) chain
+//   F(i,j+1) = max(0, M(i,j)-oe_ins, F(i,j)-e_ins)
+// is a max-plus prefix scan, F(i,j) = max(0, max_{k<j}(M(i,k) + k*e_ins) - oe_ins - (j-1)*e_ins),
+// done with wavefront shuffles.  H/E rows and the query live in LDS for the whole pair; the
+// reference window streams through registers.  Integer max-plus recurrences: MFMA does not apply.
+#include <limits.h>
+#include <string.h>
+
+#include "meme_common.h"
+
+namespace {
+
+constexpr int BSW_BLOCK = 256;            // 4 wavefronts = 4 pairs in flight per workgroup
+constexpr int WAVES = BSW_BLOCK / 64;
+constexpr int NEG = -(1 << 29);
+
+struct BswArgs {
+    meme_seqpair* pairs;
+    const uint8_t* ref;
+    const uint8_t* qer;
+    int npairs;
+    int w;
+    meme_bsw_opt o;
+    int qmax;                // LDS columns per wave (multiple of 64)
+    unsigned int* ticket;
+};
+
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(v, d);
+        if (lane >= d) v = v > y ? v : y;
+    }
+    return v;
+}
+
+__device__ __forceinline__ long long wave_max64(long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        long long y = __shfl_xor(v, d);
+        v = v > y ? v : y;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t per_wave = (size_t)(A.qmax + 2) * 8 + (size_t)A.qmax;
+    int* H = reinterpret_cast<int*>(lds_raw + per_wave * wid);
+    int* E = H + (A.qmax + 2);
+    uint8_t* Q = reinterpret_cast<uint8_t*>(E + (A.qmax + 2));
+    const int o_del = A.o.o_del, e_del = A.o.e_del, o_ins = A.o.o_ins, e_ins = A.o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = A.o.zdrop;
+    const int sa = A.o.a, sb = -A.o.b;
+
+    for (;;) {
+        unsigned int pi = 0;
+        if (lane == 0) pi = atomicAdd(A.ticket, 1u);
+        pi = __shfl(pi, 0);
+        if (pi >= (unsigned)A.npairs) break;
+        meme_seqpair* P = &A.pairs[pi];
+        const int qlen = P->len2, tlen = P->len1, h0 = P->h0;
+        const uint8_t* query = A.qer + P->idq;
+        const uint8_t* target = A.ref + P->idr;
+        if (qlen > A.qmax || qlen < 0 || tlen < 0) {      // cannot happen: the host sizes qmax from the batch
+            if (lane == 0) { P->score = INT_MIN; P->qle = P->tle = P->gtle = P->gscore = P->max_off = -1; }
+            continue;
+        }
+        // ---- first row (:143-145) and query staging ---------------------------------------------------
+        for (int j = lane; j <= qlen + 1; j += 64) {
+            int v = 0;
+            if (j == 0) v = h0;
+            else if (j <= qlen) {
+                // eh[1] = max(h0-oe_ins,0); eh[j] = eh[j-1]-e_ins while eh[j-1] > e_ins
+                int first = h0 > oe_ins ? h0 - oe_ins : 0;
+                int x = first - (j - 1) * e_ins;
+                // cell j is filled iff every predecessor 1..j-1 was > e_ins, i.e. eh[j-1] > e_ins
+                int prev = first - (j - 2) * e_ins;
+                v = (j == 1) ? first : (prev > e_ins ? x : 0);
+            }
+            H[j] = v;
+            E[j] = 0;
+            if (j < qlen) Q[j] = query[j];
+        }
+        // band cap (:148-156)
+        int w = A.w;
+        {
+            int mx = sa > 0 ? sa : 0;
+            int max_ins = (int)((double)(qlen * mx + A.o.end_bonus - o_ins) / e_ins + 1.);
+            if (max_ins < 1) max_ins = 1;
+            if (w > max_ins) w = max_ins;
+            int max_del = (int)((double)(qlen * mx + A.o.end_bonus - o_del) / e_del + 1.);
+            if (max_del < 1) max_del = 1;
+            if (w > max_del) w = max_del;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+        int tchunk = 0;                 // lane k holds target[64*(i/64) + k]: one coalesced load per 64 rows
+        for (int i = 0; i < tlen; ++i) {
+            if ((i & 63) == 0) tchunk = (i + lane < tlen) ? target[i + lane] : 4;
+            const int tb = __shfl(tchunk, i & 63);
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            int h1;
+            if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+            else h1 = 0;
+            int carry_g = NEG;          // running max of M(k) - oe_ins + k*e_ins over finished chunks
+            int left_h = h1;            // H(i, j0-1) for the first column of the chunk
+            long long best = -1;        // (m << 32) | mj, rightmost column among equal maxima
+            for (int j0 = beg; j0 < end; j0 += 64) {
+                const int j = j0 + lane;
+                const bool act = j < end;
+                int M = NEG, e = 0;
+                if (act) {
+                    M = H[j];
+                    e = E[j];
+                    const int qb = Q[j];
+                    const int sc = (tb > 3 || qb > 3) ? -1 : (tb == qb ? sa : sb);
+                    M = M ? M + sc : 0;   // :184
+                }
+                int g = act ? M - oe_ins + j * e_ins : NEG;
+                int gi = wave_incl_max(g, lane);
+                int gx = __shfl_up(gi, 1);
+                if (lane == 0) gx = NEG;
+                gx = gx > carry_g ? gx : carry_g;
+                int f = gx - (j - 1) * e_ins;
+                if (f < 0 || gx == NEG) f = 0;
+                int h = M > e ? M : e;
+                h = h > f ? h : f;
+                int hl = __shfl_up(h, 1);
+                if (lane == 0) hl = left_h;
+                if (act) {
+                    H[j] = hl;                             // H(i,j-1) for the next row (:183)
+                    int t = M - oe_del;
+                    t = t > 0 ? t : 0;
+                    e -= e_del;
+                    e = e > t ? e : t;
+                    E[j] = e;                              // E(i+1,j) (:190-194)
+                    long long key = ((long long)h << 32) | (unsigned)j;
+                    best = best > key ? best : key;
+                }
+                const int nact = end - j0 < 64 ? end - j0 : 64;
+                left_h = __shfl(h, nact - 1);
+                int cg = __shfl(gi, 63);
+                carry_g = carry_g > cg ? carry_g : cg;
+            }
+            best = wave_max64(best);
+            int m = 0, mj = -1;
+            if (best >= 0) { m = (int)(best >> 32); mj = (int)(best & 0xffffffffll); }
+            h1 = left_h;
+            if (lane == 0) { H[end] = h1; E[end] = 0; }    // :201
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((beg < end ? end : beg) == qlen) {          // "if (j == qlen)" after the column loop, :202-205
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+            if (m == 0) break;                             // :206
+            if (m > max) {
+                max = m; max_i = i; max_j = mj;
+                int off = mj - i;
+                if (off < 0) off = -off;
+                max_off = max_off > off ? max_off : off;
+            } else if (zdrop > 0) {
+                if (i - max_i > mj - max_j) {
+                    if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+                } else {
+                    if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+                }
+            }
+            // band trimming (:217-221): drop leading / trailing columns whose H and E are both zero
+            int nbeg = end;
+            for (int j0 = beg; j0 < end; j0 += 64) {
+                const int j = j0 + lane;
+                bool nz = j < end && ((H[j] | E[j]) != 0);
+                u64 b = __ballot(nz);
+                if (b) { nbeg = j0 + __ffsll((long long)b) - 1; break; }
+            }
+            int jl = nbeg - 1;
+            for (int hi = end; hi >= nbeg; hi -= 64) {
+                const int j = hi - 63 + lane;
+                bool nz = j >= nbeg && j <= hi && ((H[j] | E[j]) != 0);
+                u64 b = __ballot(nz);
+                if (b) { jl = hi - 63 + (63 - __clzll((long long)b)); break; }
+            }
+            beg = nbeg;
+            end = jl + 2 < qlen ? jl + 2 : qlen;
+        }
+        if (lane == 0) {
+            P->score = max;
+            P->qle = max_j + 1;
+            P->tle = max_i + 1;
+            P->gtle = max_ie + 1;
+            P->gscore = gscore;
+            P->max_off = max_off;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w,
+               const meme_bsw_opt* opt, int max_qlen) {
+    if (opt->e_ins <= 0 || opt->e_del <= 0) { meme_set_error("gap extension penalties must be positive"); return MEME_E_ARG; }
+    int qmax = ((max_qlen + 63) / 64) * 64;
+    if (qmax < 64) qmax = 64;
+    size_t per_wave = (size_t)(qmax + 2) * 8 + (size_t)qmax;
+    size_t lds = per_wave * WAVES;
+    if (lds > 160 * 1024) {
+        meme_set_error("query of %d bases exceeds the LDS-resident limit of this build", max_qlen);
+        return MEME_E_ARG;
+    }
+    int rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 4 * sizeof(unsigned long long)))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    int dev_cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+    i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : (i64)dev_cus * 4;
+    i64 want = (npairs + WAVES - 1) / WAVES;
+    if (blocks > want) blocks = want;
+    if (blocks < 1) blocks = 1;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bsw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    BswArgs A;
+    A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.npairs = npairs; A.w = w; A.o = *opt; A.qmax = qmax;
+    A.ticket = (unsigned int*)ctx->counters.p;
+    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    hipLaunchKernelGGL(k_bsw, dim3((unsigned)blocks), dim3(BSW_BLOCK), lds, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+    ctx->tm.bsw_kernel_ms = ms;
+    ctx->tm.bsw_launches = 1;
+    return MEME_OK;
+}
+
+__global__ void k_max_qlen(const meme_seqpair* pairs, int n, int* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int v = i < n ? pairs[i].len2 : 0;
+    for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(v, d); v = v > y ? v : y; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+}
+
+}  // namespace
+
+extern "C" int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer,
+                                     int32_t npairs, int32_t w, const meme_bsw_opt* opt) {
+    if (!ctx || !d_pairs || !d_ref || !d_qer || !opt || npairs < 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (npairs == 0) return MEME_OK;
+    int rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, 64))) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->scan_tmp.p, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_max_qlen, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pairs, npairs,
+                       (int*)ctx->scan_tmp.p);
+    int max_q = 0;
+    HIP_TRY(hipMemcpyAsync(&max_q, ctx->scan_tmp.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return launch_bsw(ctx, d_pairs, d_ref, d_qer, npairs, w, opt, max_q);
+}
+
+extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t* ref_buf, int64_t ref_bytes,
+                              const uint8_t* qer_buf, int64_t qer_bytes, int32_t npairs, int32_t w, const meme_bsw_opt* opt) {
+    if (!ctx || !pairs || !ref_buf || !qer_buf || !opt || npairs < 0 || ref_bytes < 0 || qer_bytes < 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (npairs == 0) return MEME_OK;
+    int max_q = 0;
+    for (int i = 0; i < npairs; ++i) {
+        const meme_seqpair& p = pairs[i];
+        if (p.len1 < 0 || p.len2 < 0 || p.idr < 0 || p.idq < 0 || (int64_t)p.idr + p.len1 > ref_bytes ||
+            (int64_t)p.idq + p.len2 > qer_bytes) {
+            meme_set_error("pair %d addresses bytes outside the sequence buffers", i);
+            return MEME_E_ARG;
+        }
+        if (p.len2 > max_q) max_q = p.len2;
+    }
+    int rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->pairs, (size_t)npairs * sizeof(meme_seqpair)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->refb, (size_t)ref_bytes + 16))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->qerb, (size_t)qer_bytes + 16))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->pairs.p, pairs, (size_t)npairs * sizeof(meme_seqpair), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->refb.p, ref_buf, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->qerb.p, qer_buf, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_bsw(ctx, (meme_seqpair*)ctx->pairs.p, (const uint8_t*)ctx->refb.p, (const uint8_t*)ctx->qerb.p, npairs, w,
+                    opt, max_q);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(pairs, ctx->pairs.p, (size_t)npairs * sizeof(meme_seqpair), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MEME_OK;
+}

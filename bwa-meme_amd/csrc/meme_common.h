@@ -1,0 +1,81 @@
+// Shared declarations of the HIP backend (gfx950 / MI355X only -- no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "meme_hip.h"
+
+typedef uint64_t u64;
+typedef int64_t i64;
+
+// ---- HBM layout of the index ---------------------------------------------------------------------
+// One suffix-array slot: the first 32 bases of the suffix as an integer whose unsigned order is the
+// lexicographic order (first base in bits 63..62, T-filled past the text end), plus the text position.
+// 16-byte aligned: one probe = one dwordx4 load = one 64-B HBM sector.
+struct __attribute__((aligned(16))) SaEnt {
+    u64 key;
+    u64 pos;
+};
+
+struct RmiRec {   // on-disk P-RMI record (reference src/LearnedIndex_seeding.cpp:197-206)
+    double icpt;
+    double slope;
+    u64 err;
+};
+
+struct DevIndex {
+    i64 n = 0;                 // sa_num = 2 * l_pac
+    const SaEnt* sa = nullptr;
+    const u64* pac = nullptr;  // 2-bit text, base i in bits (62 - 2*(i&31)) of word i>>5
+    const RmiRec* l2 = nullptr;
+    const RmiRec* l1 = nullptr;
+    i64 n_l2 = 0, n_l1 = 0;
+    int shift = 64;            // key >> shift = leaf index
+};
+
+struct DevBuf {   // growable device workspace
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct meme_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevIndex idx;
+    bool owns_index = false;
+    std::vector<void*> owned;          // device allocations of the index
+    // workspaces
+    DevBuf reads, read_off, slots, slot_cnt, slot_hits, smem_off, hit_off, smems, hits, scan_tmp, counters,
+           pairs, refb, qerb, pending;
+    // tuning
+    i64 seed_blocks = 0;               // 0 = auto
+    i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch
+    i64 bsw_blocks = 0;
+    // timings
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    meme_timings tm = {0, 0, 0, 0, 0};
+};
+
+void meme_set_error(const char* fmt, ...);
+int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes);
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            meme_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MEME_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------------------------
+// 32 bases starting at base offset s from a big-endian-within-word 2-bit array
+__device__ __forceinline__ u64 extract32(const u64* w, i64 s) {
+    i64 k = s >> 5;
+    int sh = (int)(s & 31) * 2;
+    u64 a = w[k], b = w[k + 1];
+    return sh ? (a << sh) | (b >> (64 - sh)) : a;
+}

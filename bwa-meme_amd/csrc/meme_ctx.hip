@@ -1,0 +1,299 @@
+// Context management and index staging for the MI355X backend.
+//
+// Replaces, on the device, the index part of memoryAllocLearned() (reference src/fastmap.cpp:422-617):
+// the 2-bit fwd+rc text image and the widening of the 5-byte suffix-array file into probe-ready
+// entries with their 64-bit keys are produced by two streaming HIP kernels instead of an OpenMP loop.
+#include <stdarg.h>
+#include <string.h>
+
+#include "meme_common.h"
+
+static thread_local char g_err[512] = "";
+
+void meme_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* meme_last_error(void) { return g_err; }
+
+int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return MEME_OK;
+    if (b.p) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.cap = want;
+    return MEME_OK;
+}
+
+extern "C" int meme_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" meme_ctx* meme_ctx_create(int device) {
+    int n = meme_device_count();
+    if (n <= 0) { meme_set_error("no HIP device visible: the MI355X backend has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= n) { meme_set_error("device %d out of range (0..%d)", device, n - 1); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { meme_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    meme_ctx* ctx = new meme_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        meme_set_error("hipStreamCreate failed");
+        delete ctx;
+        return nullptr;
+    }
+    for (auto& e : ctx->ev) {
+        if (hipEventCreate(&e) != hipSuccess) { meme_set_error("hipEventCreate failed"); delete ctx; return nullptr; }
+    }
+    return ctx;
+}
+
+static void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots, &ctx->slot_cnt, &ctx->slot_hits, &ctx->smem_off,
+                      &ctx->hit_off, &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs,
+                      &ctx->refb, &ctx->qerb, &ctx->pending};
+    for (DevBuf* b : bufs) free_buf(*b);
+    if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int meme_ctx_sync(meme_ctx* ctx) {
+    if (!ctx) return MEME_E_ARG;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MEME_OK;
+}
+
+extern "C" void* meme_ctx_stream(meme_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int meme_get_timings(meme_ctx* ctx, meme_timings* out) {
+    if (!ctx || !out) return MEME_E_ARG;
+    *out = ctx->tm;
+    return MEME_OK;
+}
+
+extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return MEME_E_ARG;
+    if (!strcmp(key, "seed_blocks")) ctx->seed_blocks = value;
+    else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
+    else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
+    else { meme_set_error("unknown tuning key %s", key); return MEME_E_ARG; }
+    return MEME_OK;
+}
+
+// ---- staging kernels ---------------------------------------------------------------------------------
+extern "C" int64_t meme_index_pac64_words(int64_t sa_num) { return ((sa_num + 31) >> 5) + 2; }
+
+// one thread per output word: 32 text bytes -> one u64, first base in the top bits; T past the end
+__global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ text, i64 n, u64* __restrict__ pac, i64 words) {
+    i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    i64 base = w << 5;
+    u64 v = 0;
+    if (base + 32 <= n) {
+        const uint4* p = reinterpret_cast<const uint4*>(text + base);   // 32-byte aligned chunks
+        uint4 a = p[0], b = p[1];
+        uint32_t q[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = q[k];   // little-endian: byte 0 is the earliest base
+            v = (v << 8) | ((u64)(x & 3) << 6) | ((u64)((x >> 8) & 3) << 4) | ((u64)((x >> 16) & 3) << 2) |
+                (u64)((x >> 24) & 3);
+        }
+    } else {
+        for (int r = 0; r < 32; ++r) {
+            i64 p = base + r;
+            u64 c = p < n ? (u64)(text[p] & 3) : 3ull;
+            v = (v << 2) | c;
+        }
+    }
+    pac[w] = v;
+}
+
+__global__ void __launch_bounds__(256) k_build_entries(const uint8_t* __restrict__ pos_packed, const u64* __restrict__ sa_u64,
+                                                        i64 n, const u64* __restrict__ pac, SaEnt* __restrict__ ent) {
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 pos;
+    if (sa_u64) pos = sa_u64[i];
+    else {
+        const uint8_t* p = pos_packed + i * 5;   // u32 LE (pos >> 8) then u8 (pos & 0xff)
+        pos = ((u64)p[0] << 8) | ((u64)p[1] << 16) | ((u64)p[2] << 24) | ((u64)p[3] << 32) | (u64)p[4];
+    }
+    SaEnt e;
+    e.key = extract32(pac, (i64)pos);   // the pad words make this "T-filled past the text end"
+    e.pos = pos;
+    ent[i] = e;
+}
+
+extern "C" int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text, int64_t n, void* d_pac64) {
+    if (!ctx || !d_text || !d_pac64 || n <= 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    i64 words = meme_index_pac64_words(n);
+    hipLaunchKernelGGL(k_pack_text, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_text, n,
+                       (u64*)d_pac64, words);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
+extern "C" int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t n, const void* d_pac64,
+                                        void* d_sa_ent) {
+    if (!ctx || !d_pos_packed || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_build_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_pos_packed,
+                       (const u64*)nullptr, n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
+extern "C" int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t n, const void* d_pac64,
+                                          void* d_sa_ent) {
+    if (!ctx || !d_sa || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_build_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)nullptr, (const u64*)d_sa, n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
+// ---- index objects ------------------------------------------------------------------------------------
+static int set_rmi(meme_ctx* ctx, i64 l2_records, i64 l1_records) {
+    if (l2_records <= 0 || (l2_records & (l2_records - 1)) != 0) {
+        // learned_index_load() requires num_model to be a power of two (src/LearnedIndex_seeding.cpp:113-119)
+        meme_set_error("L2 parameter table must hold a power-of-two number of 24-byte records (got %lld)",
+                       (long long)l2_records);
+        return MEME_E_IO;
+    }
+    int bits = 0;
+    while (((i64)1 << bits) < l2_records) ++bits;
+    ctx->idx.shift = 64 - bits;
+    ctx->idx.n_l2 = l2_records;
+    ctx->idx.n_l1 = l1_records;
+    return MEME_OK;
+}
+
+static void drop_index(meme_ctx* ctx) {
+    if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
+    ctx->owned.clear();
+    ctx->owns_index = false;
+    ctx->idx = DevIndex();
+}
+
+extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t n, const uint8_t* text,
+                                    const void* l1, int64_t l1_bytes, const void* l2, int64_t l2_bytes) {
+    if (!ctx || !pos_packed || !text || !l2 || n < 64 || l2_bytes < 24 || l2_bytes % 24 || l1_bytes % 24) {
+        meme_set_error("meme_index_load_host: bad argument (sa_num must be >= 64, parameter files multiples of 24 B)");
+        return MEME_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    drop_index(ctx);
+    int rc = set_rmi(ctx, l2_bytes / 24, l1_bytes / 24);
+    if (rc) return rc;
+    i64 words = meme_index_pac64_words(n);
+    void *d_ent = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_tmp = nullptr;
+    HIP_TRY(hipMalloc(&d_ent, (size_t)n * sizeof(SaEnt)));
+    ctx->owned.push_back(d_ent);
+    ctx->owns_index = true;
+    HIP_TRY(hipMalloc(&d_pac, (size_t)words * 8));
+    ctx->owned.push_back(d_pac);
+    HIP_TRY(hipMalloc(&d_l2, (size_t)l2_bytes));
+    ctx->owned.push_back(d_l2);
+    HIP_TRY(hipMalloc(&d_l1, (size_t)(l1_bytes > 0 ? l1_bytes : 24)));
+    ctx->owned.push_back(d_l1);
+    // staging buffer: the larger of the two images, reused
+    size_t tmp_bytes = (size_t)n * 5 + 64;
+    HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
+    HIP_TRY(hipMemcpyAsync(d_tmp, text, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac);
+    if (rc) { (void)hipFree(d_tmp); return rc; }
+    HIP_TRY(hipMemcpyAsync(d_tmp, pos_packed, (size_t)n * 5, hipMemcpyHostToDevice, ctx->stream));
+    rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent);
+    if (rc) { (void)hipFree(d_tmp); return rc; }
+    HIP_TRY(hipMemcpyAsync(d_l2, l2, (size_t)l2_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (l1_bytes > 0) HIP_TRY(hipMemcpyAsync(d_l1, l1, (size_t)l1_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_tmp));
+    ctx->idx.n = n;
+    ctx->idx.sa = (const SaEnt*)d_ent;
+    ctx->idx.pac = (const u64*)d_pac;
+    ctx->idx.l2 = (const RmiRec*)d_l2;
+    ctx->idx.l1 = (const RmiRec*)d_l1;
+    return MEME_OK;
+}
+
+static bool slurp(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize((size_t)sz);
+    size_t r = sz ? fread(out.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    return r == (size_t)sz;
+}
+
+extern "C" int meme_index_load_files(meme_ctx* ctx, const char* prefix) {
+    if (!ctx || !prefix) return MEME_E_ARG;
+    std::string p(prefix);
+    std::vector<uint8_t> pos, text, l1, l2;
+    // same file names memoryAllocLearned() opens (src/fastmap.cpp:425-470, 1496-1525)
+    if (!slurp(p + ".pos_packed", pos)) { meme_set_error("cannot read %s.pos_packed", prefix); return MEME_E_IO; }
+    if (!slurp(p + ".0123", text)) { meme_set_error("cannot read %s.0123", prefix); return MEME_E_IO; }
+    if (!slurp(p + ".suffixarray_uint64_L1_PARAMETERS", l1)) { meme_set_error("cannot read %s.suffixarray_uint64_L1_PARAMETERS", prefix); return MEME_E_IO; }
+    if (!slurp(p + ".suffixarray_uint64_L2_PARAMETERS", l2)) { meme_set_error("cannot read %s.suffixarray_uint64_L2_PARAMETERS", prefix); return MEME_E_IO; }
+    if (pos.size() % 5 || pos.size() / 5 != text.size()) {
+        meme_set_error("%s: .pos_packed (%zu B) and .0123 (%zu B) disagree on the suffix count", prefix, pos.size(), text.size());
+        return MEME_E_IO;
+    }
+    return meme_index_load_host(ctx, pos.data(), (int64_t)text.size(), text.data(), l1.data(), (int64_t)l1.size(),
+                                l2.data(), (int64_t)l2.size());
+}
+
+extern "C" int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* a) {
+    if (!ctx || !a || !a->d_sa_ent || !a->d_pac64 || !a->d_l2 || a->sa_num < 64) return MEME_E_ARG;
+    drop_index(ctx);
+    int rc = set_rmi(ctx, a->l2_records, a->l1_records);
+    if (rc) return rc;
+    ctx->idx.n = a->sa_num;
+    ctx->idx.sa = (const SaEnt*)a->d_sa_ent;
+    ctx->idx.pac = (const u64*)a->d_pac64;
+    ctx->idx.l2 = (const RmiRec*)a->d_l2;
+    ctx->idx.l1 = (const RmiRec*)a->d_l1;
+    return MEME_OK;
+}
+
+extern "C" int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out) {
+    if (!ctx || !out) return MEME_E_ARG;
+    if (!ctx->idx.sa) { meme_set_error("no index loaded"); return MEME_E_STATE; }
+    out->sa_num = ctx->idx.n;
+    out->d_sa_ent = (void*)ctx->idx.sa;
+    out->d_pac64 = (void*)ctx->idx.pac;
+    out->d_l2 = (void*)ctx->idx.l2;
+    out->l2_records = ctx->idx.n_l2;
+    out->d_l1 = (void*)ctx->idx.l1;
+    out->l1_records = ctx->idx.n_l1;
+    return MEME_OK;
+}
+
+extern "C" int meme_index_share(meme_ctx* ctx, meme_ctx* owner) {
+    if (!ctx || !owner || ctx->device != owner->device) return MEME_E_ARG;
+    if (!owner->idx.sa) { meme_set_error("owner has no index"); return MEME_E_STATE; }
+    drop_index(ctx);
+    ctx->idx = owner->idx;
+    return MEME_OK;
+}

@@ -1,0 +1,210 @@
+"""ctypes bindings of the C ABI in include/meme_hip.h (libmeme_hip.so, built in-tree by
+`make -C bwa-meme_amd hip`).  Fails loudly when the library or a HIP device is missing -- there is no
+CPU fallback on the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG, "libmeme_hip.so")
+
+MEM_TL = np.dtype([("start", "<i4"), ("end", "<i4"), ("hitbeg", "<i4"), ("hitcount", "<i4"),
+                   ("cache_refpos", "<u8")])
+SEQPAIR = np.dtype([(n, "<i4") for n in ("idr", "idq", "id", "len1", "len2", "h0", "seqid", "regid", "score",
+                                         "tle", "gtle", "qle", "gscore", "max_off")])
+
+
+class SeedOpt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("min_seed_len", "split_len", "split_width", "max_mem_intv", "rounds",
+                                         "hits_per_smem")]
+
+
+class BswOpt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("o_del", "e_del", "o_ins", "e_ins", "zdrop", "end_bonus", "a", "b")]
+
+
+class IndexArrays(C.Structure):
+    _fields_ = [("sa_num", C.c_int64), ("d_sa_ent", C.c_void_p), ("d_pac64", C.c_void_p), ("d_l2", C.c_void_p),
+                ("l2_records", C.c_int64), ("d_l1", C.c_void_p), ("l1_records", C.c_int64)]
+
+
+class SeedResult(C.Structure):
+    _fields_ = [("d_smems", C.c_void_p), ("d_smem_off", C.c_void_p), ("d_hits", C.c_void_p),
+                ("d_hit_off", C.c_void_p), ("total_smems", C.c_int64), ("total_hits", C.c_int64),
+                ("searches", C.c_int64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("seed_kernel_ms", C.c_float), ("seed_gather_ms", C.c_float), ("bsw_kernel_ms", C.c_float),
+                ("seed_launches", C.c_int64), ("bsw_launches", C.c_int64)]
+
+
+# every symbol include/meme_hip.h declares (tests/test_abi.py checks the library exports them all)
+EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_last_error", "meme_ctx_sync",
+           "meme_ctx_stream", "meme_index_load_host", "meme_index_load_files", "meme_index_pac64_words",
+           "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_stage_pack_text",
+           "meme_stage_build_entries", "meme_stage_entries_from_sa", "meme_seed_batch", "meme_seed_batch_device",
+           "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
+
+_lib = None
+
+
+def default_seed_opt(rounds=3, hits_per_smem=0):
+    # mem_opt_init (reference src/bwamem.cpp:126-162): min_seed_len 19, split_factor 1.5, split_width 10,
+    # max_mem_intv 20
+    return SeedOpt(19, 28, 10, 20, rounds, hits_per_smem)
+
+
+def default_bsw_opt(end_bonus=5):
+    return BswOpt(6, 1, 6, 1, 100, end_bonus, 1, 4)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C bwa-meme_amd hip` "
+                               "(or __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.meme_ctx_create.restype = C.c_void_p
+        L.meme_ctx_create.argtypes = [C.c_int]
+        L.meme_ctx_destroy.argtypes = [C.c_void_p]
+        L.meme_ctx_destroy.restype = None
+        L.meme_last_error.restype = C.c_char_p
+        L.meme_ctx_stream.restype = C.c_void_p
+        L.meme_ctx_stream.argtypes = [C.c_void_p]
+        L.meme_index_pac64_words.restype = C.c_int64
+        L.meme_index_pac64_words.argtypes = [C.c_int64]
+        _lib = L
+    return _lib
+
+
+class MemeError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise MemeError("meme_hip error %d: %s" % (rc, lib().meme_last_error().decode()))
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One HIP device + stream + workspaces (meme_ctx)."""
+
+    def __init__(self, device=0):
+        L = lib()
+        if L.meme_device_count() <= 0:
+            raise MemeError("no HIP device visible -- the MI355X backend has no CPU fallback")
+        self.h = L.meme_ctx_create(device)
+        if not self.h:
+            raise MemeError(L.meme_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().meme_ctx_destroy(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- index ---------------------------------------------------------------------------------------
+    def load_index_files(self, prefix):
+        _check(lib().meme_index_load_files(C.c_void_p(self.h), prefix.encode()))
+
+    def load_index_host(self, pos_packed, text, l1, l2):
+        pos_packed = np.ascontiguousarray(pos_packed, dtype=np.uint8)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        l1 = np.ascontiguousarray(l1).view(np.uint8)
+        l2 = np.ascontiguousarray(l2).view(np.uint8)
+        _check(lib().meme_index_load_host(C.c_void_p(self.h), _p(pos_packed), C.c_int64(text.shape[0]), _p(text),
+                                          _p(l1), C.c_int64(l1.shape[0]), _p(l2), C.c_int64(l2.shape[0])))
+
+    def attach_index(self, arrays: IndexArrays):
+        _check(lib().meme_index_attach(C.c_void_p(self.h), C.byref(arrays)))
+
+    def describe_index(self) -> IndexArrays:
+        a = IndexArrays()
+        _check(lib().meme_index_describe(C.c_void_p(self.h), C.byref(a)))
+        return a
+
+    def set_tuning(self, key, value):
+        _check(lib().meme_set_tuning(C.c_void_p(self.h), key.encode(), C.c_int64(value)))
+
+    def timings(self) -> Timings:
+        t = Timings()
+        _check(lib().meme_get_timings(C.c_void_p(self.h), C.byref(t)))
+        return t
+
+    def sync(self):
+        _check(lib().meme_ctx_sync(C.c_void_p(self.h)))
+
+    # ---- seeding (host buffers in, host buffers out) ----------------------------------------------------
+    def seed_batch(self, reads, read_off, opt=None, smem_capacity=None, hit_capacity=None):
+        opt = opt or default_seed_opt()
+        reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        n = read_off.shape[0] - 1
+        smem_capacity = smem_capacity or max(64 * n, 1024)
+        hit_capacity = hit_capacity or max(1024 * n, 1 << 16)
+        while True:
+            smems = np.zeros(smem_capacity, dtype=MEM_TL)
+            hits = np.zeros(hit_capacity, dtype=np.uint64)
+            smem_off = np.zeros(n + 1, dtype=np.int64)
+            hit_off = np.zeros(n + 1, dtype=np.int64)
+            ts, th = C.c_int64(0), C.c_int64(0)
+            rc = lib().meme_seed_batch(C.c_void_p(self.h), _p(reads), _p(read_off), C.c_int64(n), C.byref(opt),
+                                       _p(smems), C.c_int64(smem_capacity), _p(smem_off), _p(hits),
+                                       C.c_int64(hit_capacity), _p(hit_off), C.byref(ts), C.byref(th))
+            if rc == -4:  # MEME_E_CAPACITY: sizes were reported back
+                smem_capacity = max(smem_capacity, ts.value + 1)
+                hit_capacity = max(hit_capacity, th.value + 1)
+                continue
+            _check(rc)
+            return smems[:ts.value], smem_off, hits[:th.value], hit_off
+
+    def seed_batch_device(self, d_reads_ptr, d_read_off_ptr, nreads, total_bases, opt=None) -> SeedResult:
+        opt = opt or default_seed_opt()
+        res = SeedResult()
+        _check(lib().meme_seed_batch_device(C.c_void_p(self.h), C.c_void_p(d_reads_ptr), C.c_void_p(d_read_off_ptr),
+                                            C.c_int64(nreads), C.c_int64(total_bases), C.byref(opt), C.byref(res)))
+        return res
+
+    # ---- banded SW -------------------------------------------------------------------------------------------
+    def bsw_batch(self, pairs, ref, qer, w, opt=None):
+        opt = opt or default_bsw_opt()
+        assert pairs.dtype == SEQPAIR and pairs.flags.c_contiguous
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        qer = np.ascontiguousarray(qer, dtype=np.uint8)
+        _check(lib().meme_bsw_batch(C.c_void_p(self.h), _p(pairs), _p(ref), C.c_int64(ref.shape[0]), _p(qer),
+                                    C.c_int64(qer.shape[0]), C.c_int32(pairs.shape[0]), C.c_int32(w), C.byref(opt)))
+        return pairs
+
+    def bsw_batch_device(self, d_pairs_ptr, d_ref_ptr, d_qer_ptr, npairs, w, opt=None):
+        opt = opt or default_bsw_opt()
+        _check(lib().meme_bsw_batch_device(C.c_void_p(self.h), C.c_void_p(d_pairs_ptr), C.c_void_p(d_ref_ptr),
+                                           C.c_void_p(d_qer_ptr), C.c_int32(npairs), C.c_int32(w), C.byref(opt)))
+
+
+def smems_to_slots(smems, smem_off, hits, hit_off, smem_cap=None):
+    """Re-shape the flat batch output into the per-read layout the oracle's dump formatter takes."""
+    n = smem_off.shape[0] - 1
+    counts = np.diff(smem_off)
+    cap = int(smem_cap or max(1, counts.max() if n else 1))
+    out = np.zeros((n, cap), dtype=MEM_TL)
+    hl = []
+    for r in range(n):
+        k = int(counts[r])
+        out[r, :k] = smems[smem_off[r]:smem_off[r + 1]]
+        hl.append(hits[hit_off[r]:hit_off[r + 1]])
+    return out, counts.astype(np.int32), hl

@@ -1,0 +1,161 @@
+/* meme_hip.h -- C ABI of the MI355X (gfx950) backend for BWA-MEME's learned-index seeding and
+ * banded Smith-Waterman seed extension.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Each entry point
+ * names the reference interface it replaces (paths relative to the BWA-MEME source tree):
+ *
+ *   meme_index_load_host / _files   <- learned_index_load()            src/LearnedIndex_seeding.h:290
+ *                                      + index part of memoryAllocLearned()  src/fastmap.cpp:422-617
+ *   meme_seed_batch                 <- per-read loop of mem_kernel1_core_Learned()  src/bwamem.cpp:1249-1394
+ *                                      = Learned_getSMEMsAllPosOneThread()   src/LearnedIndex_seeding.h:265
+ *                                      + Learned_bwtSeedStrategyAllPosOneThread[_mem_tradeoff]() :241,:247
+ *                                      (outputs: mem_tl records + hit positions, the inputs of the unchanged
+ *                                       host consumer mem_chain_Learned(), src/bwamem.cpp:1122-1204)
+ *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
+ *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
+ *
+ * Threading: a meme_ctx owns one HIP device, one stream and its workspaces; calls on one ctx are
+ * serialised by the caller (one ctx per kt_for worker `tid`, or one submitter per phase).  Several
+ * ctxs may share one index through meme_index_share().
+ *
+ * Errors: every function returns 0 on success or a negative MEME_E_* code; meme_last_error() gives
+ * the message.  There is no CPU fallback: without a usable HIP device every call fails loudly.
+ */
+#ifndef MEME_HIP_H
+#define MEME_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MEME_OK 0
+#define MEME_E_HIP (-1)       /* HIP runtime error / no device */
+#define MEME_E_ARG (-2)       /* bad argument */
+#define MEME_E_IO (-3)        /* index file missing / malformed */
+#define MEME_E_CAPACITY (-4)  /* caller-provided output buffer too small (sizes reported back) */
+#define MEME_E_STATE (-5)     /* index not loaded etc. */
+
+typedef struct meme_ctx meme_ctx;
+
+/* = mem_tl, src/LearnedIndex_seeding.h:121-127 (24 bytes) */
+typedef struct {
+    int32_t start, end;       /* SMEM = read[start,end) */
+    int32_t hitbeg, hitcount; /* hits[hitbeg .. hitbeg+hitcount) relative to the read's first hit */
+    uint64_t cache_refpos;    /* text position of the first hit */
+} meme_mem_tl;
+
+/* = SeqPair, src/bandedSWA.h:90-99 (56 bytes) */
+typedef struct {
+    int32_t idr, idq, id;
+    int32_t len1, len2;
+    int32_t h0;
+    int32_t seqid, regid;
+    int32_t score, tle, gtle, qle;
+    int32_t gscore, max_off;
+} meme_seqpair;
+
+/* seeding options = the mem_opt_t fields the path reads (src/bwamem.cpp:126-162, 1348, 1358-1394) */
+typedef struct {
+    int32_t min_seed_len;   /* opt->min_seed_len, 19 */
+    int32_t split_len;      /* (int)(min_seed_len * split_factor + .499), 28 */
+    int32_t split_width;    /* opt->split_width, 10 */
+    int32_t max_mem_intv;   /* opt->max_mem_intv, 20; 0 disables the third round */
+    int32_t rounds;         /* 1: first round only (= ..._step1only), 2: + re-seeding, 3: + third round */
+    int32_t hits_per_smem;  /* 0: materialise every hit (reference behaviour); k>0: only the first k per SMEM */
+} meme_seed_opt;
+
+/* BandedPairWiseSW constructor arguments (src/bandedSWA.h:118-122); mat = bwa_fill_scmat(a, b) */
+typedef struct {
+    int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus, a, b;
+} meme_bsw_opt;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int meme_device_count(void);
+meme_ctx* meme_ctx_create(int device);
+void meme_ctx_destroy(meme_ctx* ctx);
+const char* meme_last_error(void);
+int meme_ctx_sync(meme_ctx* ctx);
+void* meme_ctx_stream(meme_ctx* ctx);          /* the hipStream_t every kernel of this ctx is launched on */
+
+/* ---- index staging ------------------------------------------------------------------------------
+ * Inputs are the reference's on-disk images: pos_packed = 5 B per SA slot,
+ * text0123 = 1 B per base fwd+rc, L1/L2 = 24-B P-RMI records.  The HBM layout is private:
+ *   sa_ent[n]   16 B {u64 key (32 bases, first base in the top bits, T-filled), u64 text position}
+ *   pac64[]     2-bit text, 32 bases per u64, first base in the top bits
+ *   l2[], l1[]  P-RMI records as on disk
+ * Keys are generated on the device (replaces the OpenMP loop of src/fastmap.cpp:549-613).          */
+int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t sa_num,
+                         const uint8_t* text0123, const void* l1_params, int64_t l1_bytes,
+                         const void* l2_params, int64_t l2_bytes);
+int meme_index_load_files(meme_ctx* ctx, const char* prefix);
+/* Device-resident variant for multi-GPU start-up: the caller owns the arrays (e.g. received through an
+ * RCCL broadcast) and they must outlive the ctx.  d_sa_ent may be NULL together with d_pos_packed !=
+ * NULL: then the entries are generated here from the 5-byte image. */
+typedef struct {
+    int64_t sa_num;
+    void* d_sa_ent;            /* sa_num * 16 B */
+    void* d_pac64;             /* meme_index_pac64_words(sa_num) * 8 B */
+    void* d_l2; int64_t l2_records;
+    void* d_l1; int64_t l1_records;
+} meme_index_arrays;
+int64_t meme_index_pac64_words(int64_t sa_num);
+int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* arrays);
+int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out);     /* device pointers of a loaded index */
+int meme_index_share(meme_ctx* ctx, meme_ctx* owner);               /* second ctx on the same device */
+/* staging kernels usable on caller-owned device buffers (used by the multi-GPU path and bench.py) */
+int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text0123, int64_t sa_num, void* d_pac64);
+int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t sa_num,
+                             const void* d_pac64, void* d_sa_ent);
+int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t sa_num, const void* d_pac64,
+                               void* d_sa_ent);
+
+/* ---- seeding ------------------------------------------------------------------------------------
+ * reads: concatenated base codes 0..3, >=4 = ambiguous (what mem_kernel1_core_Learned leaves in
+ * bseq1_t.seq, src/bwamem.cpp:1277-1279); read_off[nreads+1].
+ * Outputs, per read r: smems[smem_off[r] .. smem_off[r+1]) in emission order (the caller sorts them,
+ * src/bwamem.cpp:1397) and hits[hit_off[r] .. hit_off[r+1]) in ascending SA order per SMEM.          */
+int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                    const meme_seed_opt* opt,
+                    meme_mem_tl* smems, int64_t smem_capacity, int64_t* smem_off,
+                    uint64_t* hits, int64_t hit_capacity, int64_t* hit_off,
+                    int64_t* total_smems, int64_t* total_hits);
+
+/* Same with inputs and outputs resident in HBM (pointers valid until the next call on this ctx). */
+typedef struct {
+    const meme_mem_tl* d_smems;
+    const int64_t* d_smem_off;   /* nreads+1 */
+    const uint64_t* d_hits;
+    const int64_t* d_hit_off;    /* nreads+1 */
+    int64_t total_smems, total_hits;
+    int64_t searches;            /* locate operations issued (deterministic per data set) */
+} meme_seed_result;
+int meme_seed_batch_device(meme_ctx* ctx, const uint8_t* d_reads, const int64_t* d_read_off,
+                           int64_t nreads, int64_t total_bases, const meme_seed_opt* opt,
+                           meme_seed_result* out);
+
+/* ---- banded Smith-Waterman extension --------------------------------------------------------------
+ * Semantics of scalarBandedSWA == ksw_extend2 for every pair (the int8 / int16 / scalar classes of the
+ * reference compute the same function); results are written in place into
+ * pairs[i].{score,tle,gtle,qle,gscore,max_off}.                                                      */
+int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t* ref_buf, int64_t ref_bytes,
+                   const uint8_t* qer_buf, int64_t qer_bytes, int32_t npairs, int32_t w,
+                   const meme_bsw_opt* opt);
+int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer,
+                          int32_t npairs, int32_t w, const meme_bsw_opt* opt);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * HIP-event timings of the kernels of the last *_device call, measured on the ctx's stream.          */
+typedef struct {
+    float seed_kernel_ms;      /* SA-search kernel (rounds 1-3 state machine) */
+    float seed_gather_ms;      /* offsets scan + SMEM compaction + hit gather */
+    float bsw_kernel_ms;
+    int64_t seed_launches, bsw_launches;
+} meme_timings;
+int meme_get_timings(meme_ctx* ctx, meme_timings* out);
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* e.g. "seed_blocks", "smem_cap" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

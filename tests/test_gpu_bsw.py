@@ -1,0 +1,66 @@
+"""Parity of the HIP banded-SW kernel (through the C ABI) against the golden reference outputs and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import bsw_gen
+import oracle_py as O
+from common import GOLDEN
+from pymeme import hipapi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hipapi.Context(0)
+    yield c
+    c.close()
+
+
+def _opt(eb):
+    return hipapi.default_bsw_opt(end_bonus=eb)
+
+
+@pytest.mark.parametrize("w,eb", [(100, 5), (100, 0), (200, 5), (200, 0)])
+def test_hip_bsw_equals_reference_golden(ctx, w, eb):
+    z = np.load(os.path.join(GOLDEN, "bsw_golden.npz"))
+    pairs = z["pairs"].astype(hipapi.SEQPAIR).copy()
+    ctx.bsw_batch(pairs, z["ref"], z["qer"], w, _opt(eb))
+    assert np.array_equal(bsw_gen.outputs(pairs), z["scalar_w%d_eb%d" % (w, eb)])
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_q=300, sub=0.06, indel=0.02), dict(max_q=40), dict(max_q=500, h0_max=400),
+                                dict(max_q=150, sub=0.3, unrelated_frac=0.5), dict(max_q=1000, min_q=600, h0_max=50)])
+def test_hip_bsw_equals_oracle_random(ctx, kw):
+    pairs, ref, qer = bsw_gen.make_pairs(1500, seed=11, **kw)
+    for w in (100, 200, 7):
+        want = pairs.copy()
+        O.bsw_batch(want, ref, qer, w, O.default_bsw_params(5), threads=0)
+        got = pairs.copy()
+        ctx.bsw_batch(got, ref, qer, w, _opt(5))
+        assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want)), (kw, w)
+
+
+def test_hip_bsw_other_scoring(ctx):
+    pairs, ref, qer = bsw_gen.make_pairs(1500, seed=5, max_q=200)
+    o = hipapi.BswOpt(4, 2, 8, 1, 50, 7, 2, 5)
+    po = O.OrcBswParams(4, 2, 8, 1, 50, 7, 2, 5)
+    want = pairs.copy(); O.bsw_batch(want, ref, qer, 60, po)
+    got = pairs.copy(); ctx.bsw_batch(got, ref, qer, 60, o)
+    assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want))
+
+
+def test_hip_bsw_edge_cases(ctx):
+    # empty query / empty target / single bases / all-N / zero h0
+    pairs = np.zeros(6, dtype=hipapi.SEQPAIR)
+    ref = np.array([0, 1, 2, 3, 4, 4, 4, 0, 0, 0, 0, 0], np.uint8)
+    qer = np.array([0, 1, 2, 3, 4, 4, 4, 0, 0, 0, 0, 0], np.uint8)
+    spec = [(0, 0, 4, 0, 10), (0, 0, 0, 4, 10), (0, 0, 1, 1, 1), (4, 4, 3, 3, 20), (7, 7, 5, 5, 0), (0, 7, 4, 5, 3)]
+    for i, (idr, idq, l1, l2, h0) in enumerate(spec):
+        pairs[i]["idr"], pairs[i]["idq"], pairs[i]["len1"], pairs[i]["len2"], pairs[i]["h0"] = idr, idq, l1, l2, h0
+    want = pairs.copy(); O.bsw_batch(want, ref, qer, 100, O.default_bsw_params(5))
+    got = pairs.copy(); ctx.bsw_batch(got, ref, qer, 100, _opt(5))
+    assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want))
+    assert ctx.bsw_batch(np.zeros(0, hipapi.SEQPAIR), ref, qer, 100).shape[0] == 0

@@ -1,0 +1,134 @@
+"""Parity of the HIP seeding path (through the C ABI) against the oracle and the committed golden dumps."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from common import GOLDEN, build_index, read_fastq_codes
+from pymeme import hipapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hipapi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def g1(ctx):
+    prefix = build_index(os.path.join(GOLDEN, "g1.fa"))
+    ctx.load_index_files(prefix)
+    return prefix
+
+
+def _gpu_dump(ctx, reads, off, rounds=3):
+    smems, smem_off, hits, hit_off = ctx.seed_batch(reads, off, hipapi.default_seed_opt(rounds=rounds))
+    slots, counts, hl = hipapi.smems_to_slots(smems, smem_off, hits, hit_off)
+    return O.format_seed_dump(slots, counts, hl)
+
+
+@pytest.mark.parametrize("length", [150, 250, 60, 25])
+def test_hip_seeds_equal_reference_golden(ctx, g1, length):
+    reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
+    want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()
+    assert _gpu_dump(ctx, reads, off) == want
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3])
+def test_hip_seeds_equal_oracle_each_round(ctx, g1, rounds):
+    idx = O.load_index_files(g1)
+    for length in (150, 60):
+        reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
+        sm, ns, hits, nh, _ = O.seed_batch(idx, reads, off, O.default_seed_params(steps=rounds), smem_cap=256,
+                                           hit_cap=4096, threads=4)
+        assert _gpu_dump(ctx, reads, off, rounds) == O.format_seed_dump(sm, ns, hits)
+
+
+def _synthetic_case(tmp, n_bases, seed, **kw):
+    g = synth.make_genome(n_bases, seed=seed, **kw)
+    fa = os.path.join(tmp, "s%d.fa" % seed)
+    synth.write_fasta(fa, g, contigs=2)
+    return g, build_index(fa, bits=14)
+
+
+def test_hip_seeds_equal_oracle_repetitive_genome(tmp_path):
+    """Bigger, repeat-rich genome: large hit intervals (galloping edges), re-seeding, third round."""
+    g, prefix = _synthetic_case(str(tmp_path), 600_000, 31, repeat_frac=0.2, repeat_len=300, n_families=4,
+                                divergence=0.02, n_dups=10, dup_len=3000, poly_runs=8)
+    idx = O.load_index_files(prefix)
+    c = hipapi.Context(0)
+    try:
+        c.load_index_files(prefix)
+        for L, kw in ((150, dict(exact_frac=0.3, n_frac=0.05)), (250, dict(sub_rate=0.05, indel_rate=0.0075)),
+                      (40, dict(n_frac=0.3))):
+            reads, _, _ = synth.make_reads(g, 3000, L, seed=100 + L, **kw)
+            off = np.arange(0, (reads.shape[0] + 1) * L, L, dtype=np.int64)
+            sm, ns, hits, nh, _ = O.seed_batch(idx, reads, off, smem_cap=256, hit_cap=1 << 14, threads=0)
+            want = O.format_seed_dump(sm, ns, hits)
+            assert _gpu_dump(c, reads, off) == want
+    finally:
+        c.close()
+
+
+def test_edge_cases(ctx, g1):
+    idx = O.load_index_files(g1)
+    rng = np.random.default_rng(7)
+    text = idx.text
+    n = text.shape[0]
+    reads = []
+    reads.append(np.full(150, 4, np.uint8))                      # all N
+    reads.append(text[:150].copy())                              # text start
+    reads.append(text[n - 150:].copy())                          # text end (suffixes running off the text)
+    reads.append(text[n // 2 - 75:n // 2 + 75].copy())           # fwd/rc junction
+    reads.append(np.zeros(150, np.uint8))                        # poly-A
+    reads.append(np.full(150, 3, np.uint8))                      # poly-T (sorts at the T-padding end)
+    reads.append(rng.integers(0, 4, 150).astype(np.uint8))       # unrelated
+    reads.append(text[1000:1019].copy())                         # exactly min_seed_len
+    reads.append(text[1000:1018].copy())                         # shorter than min_seed_len
+    reads.append(text[2000:2001].copy())                         # 1 base
+    r = text[3000:3150].copy(); r[::20] = 4; reads.append(r)     # N every 20 bases
+    r = text[5000:5500].copy(); reads.append(r)                  # 500 bases (maximum)
+    off = np.zeros(len(reads) + 1, np.int64)
+    off[1:] = np.cumsum([x.shape[0] for x in reads])
+    flat = np.concatenate(reads)
+    sm, ns, hits, nh, _ = O.seed_batch(idx, flat, off, smem_cap=512, hit_cap=1 << 16, threads=2)
+    assert _gpu_dump(ctx, flat, off) == O.format_seed_dump(sm, ns, hits)
+
+
+def test_empty_batch(ctx, g1):
+    smems, smem_off, hits, hit_off = ctx.seed_batch(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert smems.shape[0] == 0 and hits.shape[0] == 0 and smem_off.tolist() == [0]
+
+
+def test_round_trip_property_large(ctx, g1):
+    """Size-independent properties on a larger batch: every SMEM really occurs at every reported hit,
+    hits of one SMEM are distinct, and results do not depend on batch composition."""
+    idx = O.load_index_files(g1)
+    g = idx.text[:idx.text.shape[0] // 2]
+    reads, _, _ = synth.make_reads(g, 20000, 150, seed=77)
+    off = np.arange(0, (reads.shape[0] + 1) * 150, 150, dtype=np.int64)
+    smems, smem_off, hits, hit_off = ctx.seed_batch(reads, off)
+    text = idx.text
+    rng = np.random.default_rng(1)
+    for r in rng.integers(0, reads.shape[0], 300):
+        for m in smems[smem_off[r]:smem_off[r + 1]]:
+            seg = reads[r, m["start"]:m["end"]]
+            hv = hits[hit_off[r] + m["hitbeg"]: hit_off[r] + m["hitbeg"] + m["hitcount"]]
+            assert len(set(hv.tolist())) == hv.shape[0]
+            for h in hv[:4]:
+                assert np.array_equal(text[int(h):int(h) + seg.shape[0]], seg)
+    # same reads in a different batch order give the same per-read answers
+    perm = rng.permutation(2000)
+    sub = reads[:2000][perm]
+    off2 = np.arange(0, 2001 * 150, 150, dtype=np.int64)
+    s2, so2, h2, ho2 = ctx.seed_batch(sub, off2)
+    for k in range(0, 2000, 97):
+        r = int(perm[k])
+        a = smems[smem_off[r]:smem_off[r + 1]]
+        b = s2[so2[k]:so2[k + 1]]
+        assert np.array_equal(a, b)
+        assert np.array_equal(hits[hit_off[r]:hit_off[r + 1]], h2[ho2[k]:ho2[k + 1]])
