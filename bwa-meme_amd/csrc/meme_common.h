@@ -48,8 +48,8 @@ struct meme_ctx {
     bool owns_index = false;
     std::vector<void*> owned;          // device allocations of the index
     // workspaces
-    DevBuf reads, read_off, slots, slot_cnt, slot_hits, smem_off, hit_off, smems, hits, scan_tmp, counters,
-           pairs, refb, qerb, pending;
+    DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
+           scan_tmp, counters, pairs, refb, qerb;
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
     i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch

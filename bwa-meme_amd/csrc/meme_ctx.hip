@@ -62,9 +62,9 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots, &ctx->slot_cnt, &ctx->slot_hits, &ctx->smem_off,
-                      &ctx->hit_off, &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs,
-                      &ctx->refb, &ctx->qerb, &ctx->pending};
+    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
+                      &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
+                      &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb};
     for (DevBuf* b : bufs) free_buf(*b);
     if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);

@@ -57,10 +57,18 @@ struct SeedArgs {
     SlotRec* slots;        // [nreads * cap]
     int* slot_cnt;         // [nreads]  SMEMs the read produced (may exceed cap -> overflow)
     i64* slot_hits;        // [nreads]  hits the read will materialise
-    const i64* pending;    // optional list of read ids to (re)process, else nullptr
-    int cap;
+    i64* slot_loc;         // [nreads]  (tier << 40) | block index inside that tier's slot array
+    const i64* pending;    // list of read ids to re-process in an overflow tier, else nullptr
+    i64* ovf_list;         // reads whose SMEMs did not fit this tier (re-run in the next tier)
+    int cap;               // SMEM slots per read in this tier
+    int lcap;              // LDS ring entries per read (SMEMs of the current first-round pass)
+    int tier;
     unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads
 };
+
+constexpr int N_TIERS = 3;
+constexpr int TIER_CAP[N_TIERS] = {64, 2048, 65536};   // tier 0 is tunable ("smem_cap")
+constexpr int LDS_RING_MAX = 512;                      // >= MAX_READ_LEN: one first-round pass cannot emit more
 
 struct GroupLds {
     u64 fw[MAXW + 1];
@@ -73,11 +81,14 @@ struct GroupLds {
 struct RState {
     const DevIndex* I;
     GroupLds* L;
-    int* sm_start;   // LDS mirror of this read's SMEM list (round 2 re-reads it)
+    int* sm_start;   // LDS ring: SMEMs of the current first-round pass (round 2 re-reads them)
     int* sm_end;
     int* sm_cnt;
     SlotRec* slots;  // global slots of this read
-    int cap;
+    int cap, lcap;
+    int sm_base;     // n_smems when the current first-round pass started
+    bool rec;        // record emissions in the LDS ring
+    bool lds_ovf;
     int l_seq;
     int min_seed_len, min_intv;
     int pivot, l_pivot;
@@ -407,17 +418,19 @@ __device__ __forceinline__ int first_n(const RState& R, const u64* mask, int fro
 }
 
 __device__ __forceinline__ void emit(RState& R, int start, int end, i64 sa_start, i64 count) {
-    if (R.n_smems < R.cap) {
-        int k = R.n_smems;
-        // group-uniform redundant LDS stores (same value from every lane): no cross-lane hand-off needed
-        R.sm_start[k] = start;
-        R.sm_end[k] = end;
-        R.sm_cnt[k] = count > (i64)INT_MAX ? INT_MAX : (int)count;
-        if (R.t == 0) {
-            SlotRec r;
-            r.start = start; r.end = end; r.sa_start = sa_start; r.count = count;
-            R.slots[k] = r;
-        }
+    if (R.n_smems < R.cap && R.t == 0) {
+        SlotRec r;
+        r.start = start; r.end = end; r.sa_start = sa_start; r.count = count;
+        R.slots[R.n_smems] = r;
+    }
+    if (R.rec) {
+        int k = R.n_smems - R.sm_base;
+        if (k < R.lcap) {
+            // group-uniform redundant LDS stores (same value from every lane): no cross-lane hand-off needed
+            R.sm_start[k] = start;
+            R.sm_end[k] = end;
+            R.sm_cnt[k] = count > (i64)INT_MAX ? INT_MAX : (int)count;
+        } else R.lds_ovf = true;
     }
     R.n_smems++;
     i64 h = count;
@@ -504,14 +517,17 @@ __device__ void all_pos(RState& R, int split_len, int split_width, bool round2) 
     while (R.pivot < R.l_seq) {
         if (++guard > 4 * R.l_seq + 16) break;
         int before = R.n_smems;
+        R.sm_base = before;
+        R.rec = true;
         step1(R);
+        R.rec = false;
         int after = R.n_smems;
         if (!round2) continue;
-        if (after > R.cap) after = R.cap;                 // overflowing reads are re-run by the host
+        if (R.lds_ovf) return;                             // re-run in the next tier (bigger LDS ring)
         for (int k = before; k < after; ++k) {
             int next_pivot = R.pivot;
             int saved = R.min_intv;
-            int qbeg = R.sm_start[k], qend = R.sm_end[k], cnt = R.sm_cnt[k];
+            int qbeg = R.sm_start[k - before], qend = R.sm_end[k - before], cnt = R.sm_cnt[k - before];
             if (qend - qbeg < split_len || cnt > split_width) { set_pivot(R, next_pivot); continue; }
             set_pivot(R, (qbeg + qend) >> 1);
             R.min_intv = cnt + 1;
@@ -577,10 +593,11 @@ __global__ void __launch_bounds__(BLOCK) k_seed(SeedArgs A) {
     RState R;
     R.I = &A.I;
     R.L = &lds[gib];
-    R.sm_start = sm_lists + (size_t)gib * 3 * A.cap;
-    R.sm_end = R.sm_start + A.cap;
-    R.sm_cnt = R.sm_end + A.cap;
+    R.sm_start = sm_lists + (size_t)gib * 3 * A.lcap;
+    R.sm_end = R.sm_start + A.lcap;
+    R.sm_cnt = R.sm_end + A.lcap;
     R.cap = A.cap;
+    R.lcap = A.lcap;
     R.t = threadIdx.x & (G - 1);
     R.gbase = lane & ~(G - 1);
     R.hits_per_smem = A.opt.hits_per_smem;
@@ -592,15 +609,18 @@ __global__ void __launch_bounds__(BLOCK) k_seed(SeedArgs A) {
         const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
         const i64 ro = A.read_off[rid];
         const int len = (int)(A.read_off[rid + 1] - ro);
-        R.slots = A.slots + rid * A.cap;
+        R.slots = A.slots + (i64)ticket * A.cap;
         R.l_seq = len;
+        R.rec = false;
+        R.lds_ovf = false;
+        R.sm_base = 0;
         R.n_smems = 0;
         R.n_hits = 0;
         R.searches = 0;
         if (len <= 0 || len > MAX_READ_LEN) {
             // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
             // here the read yields no seeds and is flagged through slot_cnt = -1
-            if (R.t == 0) { A.slot_cnt[rid] = len > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; }
+            if (R.t == 0) { A.slot_cnt[rid] = len > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0; }
             continue;
         }
         // ---- stage the read: both strands, 2 bits/base, first base in the top bits; N packed as A
@@ -653,10 +673,12 @@ __global__ void __launch_bounds__(BLOCK) k_seed(SeedArgs A) {
             seed_strategy(R);
         }
         if (R.t == 0) {
-            A.slot_cnt[rid] = R.n_smems;
-            A.slot_hits[rid] = R.n_hits;
-            atomicAdd(&A.counters[1], (unsigned long long)R.searches);
-            if (R.n_smems > R.cap) atomicAdd(&A.counters[2], 1ull);
+            const bool ovf = R.n_smems > R.cap || R.lds_ovf;
+            A.slot_cnt[rid] = ovf ? 0 : R.n_smems;
+            A.slot_hits[rid] = ovf ? 0 : R.n_hits;
+            A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
+            if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
+            else atomicAdd(&A.counters[1], (unsigned long long)R.searches);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -690,14 +712,14 @@ __device__ __forceinline__ i64 block_scan_excl(i64 v, i64* total) {
 
 // pass 1: per-tile sums of (smem count, hit count)
 __global__ void __launch_bounds__(SCAN_BLOCK) k_tile_sums(const int* __restrict__ cnt, const i64* __restrict__ hits, i64 n,
-                                                          int cap, i64* __restrict__ tile_sums) {
+                                                          i64* __restrict__ tile_sums) {
     i64 base = (i64)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     i64 a = 0, b = 0;
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         i64 i = base + k;
         if (i < n) {
             int c = cnt[i];
-            a += c < 0 ? 0 : (c > cap ? cap : c);
+            a += c < 0 ? 0 : c;
             b += hits[i];
         }
     }
@@ -724,7 +746,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(i64* __restrict__ til
 }
 
 // pass 3: per-read offsets
-__global__ void __launch_bounds__(SCAN_BLOCK) k_offsets(const int* __restrict__ cnt, const i64* __restrict__ hits, i64 n, int cap,
+__global__ void __launch_bounds__(SCAN_BLOCK) k_offsets(const int* __restrict__ cnt, const i64* __restrict__ hits, i64 n,
                                                         const i64* __restrict__ tile_sums, i64* __restrict__ smem_off,
                                                         i64* __restrict__ hit_off) {
     i64 base = (i64)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -734,7 +756,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_offsets(const int* __restrict__ 
         va[k] = vb[k] = 0;
         if (i < n) {
             int c = cnt[i];
-            va[k] = c < 0 ? 0 : (c > cap ? cap : c);
+            va[k] = c < 0 ? 0 : c;
             vb[k] = hits[i];
         }
         a += va[k];
@@ -753,8 +775,13 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_offsets(const int* __restrict__ 
 }
 
 // ---- compaction + hit gather: one 16-lane group per read --------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, const SlotRec* __restrict__ slots,
-                                                   const int* __restrict__ cnt, i64 n, int cap, int hits_per_smem,
+struct TierTable {
+    const SlotRec* base[N_TIERS];
+    int cap[N_TIERS];
+};
+
+__global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, TierTable tiers, const i64* __restrict__ slot_loc,
+                                                   const int* __restrict__ cnt, i64 n, int hits_per_smem,
                                                    const i64* __restrict__ smem_off, const i64* __restrict__ hit_off,
                                                    meme_mem_tl* __restrict__ smems, u64* __restrict__ hits) {
     const int t = threadIdx.x & (G - 1);
@@ -763,8 +790,9 @@ __global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, 
     for (i64 r = gid; r < n; r += ngroups) {
         int c = cnt[r];
         if (c <= 0) continue;
-        if (c > cap) c = cap;
-        const SlotRec* sl = slots + r * cap;
+        const i64 loc = slot_loc[r];
+        const int tier = (int)(loc >> 40);
+        const SlotRec* sl = tiers.base[tier] + (loc & ((1ll << 40) - 1)) * tiers.cap[tier];
         meme_mem_tl* out = smems + smem_off[r];
         u64* hout = hits + hit_off[r];
         i64 hb = 0;
@@ -789,35 +817,51 @@ __global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, 
 
 int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, const meme_seed_opt* opt,
                 meme_seed_result* out) {
-    const int cap0 = (int)ctx->smem_cap;
-    int cap = cap0;
     unsigned long long h_counters[4];
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->counters, 4 * sizeof(unsigned long long)))) return rc;
     int dev_cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
     float ms_total = 0.f;
-    i64 launches = 0;
-    for (;;) {
-        if ((rc = meme_buf_reserve(ctx, ctx->slots, (size_t)nreads * cap * sizeof(SlotRec)))) return rc;
+    i64 launches = 0, searches = 0;
+    TierTable tiers;
+    for (int t = 0; t < N_TIERS; ++t) { tiers.base[t] = nullptr; tiers.cap[t] = 0; }
+    i64 n_todo = nreads;
+    const i64* pending = nullptr;
+    for (int tier = 0;; ++tier) {
+        const int cap = tier == 0 ? (int)ctx->smem_cap : TIER_CAP[tier];
+        const int lcap = cap < LDS_RING_MAX ? cap : LDS_RING_MAX;
+        DevBuf& sb = ctx->slots[tier];
+        DevBuf& ob = ctx->ovf[tier & 1];
+        if ((rc = meme_buf_reserve(ctx, sb, (size_t)n_todo * cap * sizeof(SlotRec)))) return rc;
+        if ((rc = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc;
         HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
         SeedArgs A;
         A.I = ctx->idx;
         A.reads = d_reads;
         A.read_off = d_read_off;
-        A.nreads = nreads;
+        A.nreads = n_todo;
         A.opt = *opt;
-        A.slots = (SlotRec*)ctx->slots.p;
+        A.slots = (SlotRec*)sb.p;
         A.slot_cnt = (int*)ctx->slot_cnt.p;
         A.slot_hits = (i64*)ctx->slot_hits.p;
-        A.pending = nullptr;
+        A.slot_loc = (i64*)ctx->slot_loc.p;
+        A.pending = pending;
+        A.ovf_list = (i64*)ob.p;
         A.cap = cap;
+        A.lcap = lcap;
+        A.tier = tier;
         A.counters = (unsigned long long*)ctx->counters.p;
-        size_t lds = sizeof(GroupLds) * GROUPS_PER_BLOCK + (size_t)GROUPS_PER_BLOCK * 3 * cap * sizeof(int);
-        i64 want = (nreads + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
+        tiers.base[tier] = (const SlotRec*)sb.p;
+        tiers.cap[tier] = cap;
+        size_t lds = sizeof(GroupLds) * GROUPS_PER_BLOCK + (size_t)GROUPS_PER_BLOCK * 3 * lcap * sizeof(int);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        i64 want = (n_todo + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
         i64 blocks = ctx->seed_blocks > 0 ? ctx->seed_blocks : (i64)dev_cus * 4;
         if (blocks > want) blocks = want;
         if (blocks < 1) blocks = 1;
@@ -831,10 +875,17 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ms_total += ms;
         ++launches;
+        searches += (i64)h_counters[1];
         if (h_counters[2] == 0) break;
-        cap *= 4;   // some read produced more SMEMs than its slot: redo with larger slots (rare)
-        if (cap > 4096) { meme_set_error("a read produced more than 4096 SMEMs"); return MEME_E_CAPACITY; }
+        // some reads produced more SMEMs than their slots hold (pathological repeats): re-run only those
+        if (tier + 1 >= N_TIERS) {
+            meme_set_error("a read produced more than %d SMEMs", TIER_CAP[N_TIERS - 1]);
+            return MEME_E_CAPACITY;
+        }
+        n_todo = (i64)h_counters[2];
+        pending = (const i64*)ob.p;
     }
+    h_counters[1] = (unsigned long long)searches;
     ctx->tm.seed_kernel_ms = ms_total;
     ctx->tm.seed_launches = launches;
     // offsets
@@ -846,10 +897,10 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     i64* totals = tiles + 2 * ntiles;
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0, ctx->stream, (const int*)ctx->slot_cnt.p,
-                       (const i64*)ctx->slot_hits.p, nreads, cap, tiles);
+                       (const i64*)ctx->slot_hits.p, nreads, tiles);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, ctx->stream, tiles, ntiles, totals);
     hipLaunchKernelGGL(k_offsets, dim3((unsigned)ntiles), dim3(SCAN_BLOCK), 0, ctx->stream, (const int*)ctx->slot_cnt.p,
-                       (const i64*)ctx->slot_hits.p, nreads, cap, (const i64*)tiles, (i64*)ctx->smem_off.p,
+                       (const i64*)ctx->slot_hits.p, nreads, (const i64*)tiles, (i64*)ctx->smem_off.p,
                        (i64*)ctx->hit_off.p);
     HIP_TRY(hipGetLastError());
     i64 h_tot[2];
@@ -860,8 +911,8 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     i64 gblocks = (nreads + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK;
     if (gblocks > (i64)dev_cus * 8) gblocks = (i64)dev_cus * 8;
     if (gblocks < 1) gblocks = 1;
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)gblocks), dim3(BLOCK), 0, ctx->stream, ctx->idx.sa,
-                       (const SlotRec*)ctx->slots.p, (const int*)ctx->slot_cnt.p, nreads, cap, opt->hits_per_smem,
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)gblocks), dim3(BLOCK), 0, ctx->stream, ctx->idx.sa, tiers,
+                       (const i64*)ctx->slot_loc.p, (const int*)ctx->slot_cnt.p, nreads, opt->hits_per_smem,
                        (const i64*)ctx->smem_off.p, (const i64*)ctx->hit_off.p, (meme_mem_tl*)ctx->smems.p,
                        (u64*)ctx->hits.p);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,62 @@
+"""Synthetic workloads for bench.py / scale tests: genome + index (host builder) and device-resident reads."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+import time
+
+import numpy as np
+
+from . import synth
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_index_on_disk(genome: np.ndarray, workdir: str, bits: int = 0, threads: int = 0, contigs: int = 4,
+                        log=None) -> str:
+    """FASTA -> our meme-index (reference file formats).  Returns the index prefix."""
+    fa = os.path.join(workdir, "ref.fa")
+    t0 = time.time()
+    synth.write_fasta(fa, genome, contigs=contigs)
+    cmd = [os.path.join(PKG, "meme-index"), "build", fa]
+    if bits:
+        cmd += ["-b", str(bits)]
+    if threads:
+        cmd += ["-t", str(threads)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("meme-index failed: " + r.stderr[-2000:])
+    if log:
+        log("index build %.1f s: %s" % (time.time() - t0, r.stderr.strip().replace("\n", " | ")))
+    return fa
+
+
+def make_reads_fast(genome: np.ndarray, n_reads: int, read_len: int, seed: int, sub_rate=0.01, n_frac=0.02,
+                    indel_frac=0.15, chunk=1 << 20) -> np.ndarray:
+    """Vectorised read sampler for millions of reads: both strands, substitutions, one short indel in
+    `indel_frac` of the reads, one N in `n_frac` of the reads.  Returns codes [n_reads, read_len]."""
+    rng = np.random.default_rng(seed)
+    n = genome.shape[0]
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    span = read_len + 4
+    ar = np.arange(span)
+    for s in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - s)
+        pos = rng.integers(0, n - span, size=m)
+        frag = genome[pos[:, None] + ar[None, :]]
+        sub = rng.random((m, span)) < sub_rate
+        frag = np.where(sub, (frag + rng.integers(1, 4, size=(m, span), dtype=np.uint8)) & 3, frag).astype(np.uint8)
+        # deletion of 1..3 bases at a random column for a subset: shift the tail left
+        has = rng.random(m) < indel_frac
+        col = rng.integers(10, read_len - 10, size=m)
+        dl = rng.integers(1, 4, size=m)
+        idx = ar[None, :read_len] + np.where((ar[None, :read_len] >= col[:, None]) & has[:, None], dl[:, None], 0)
+        reads = np.take_along_axis(frag, idx, axis=1)
+        rcm = rng.random(m) < 0.5
+        reads[rcm] = 3 - reads[rcm][:, ::-1]
+        wn = np.nonzero(rng.random(m) < n_frac)[0]
+        reads[wn, rng.integers(0, read_len, size=wn.size)] = 4
+        out[s:s + m] = reads
+    return out

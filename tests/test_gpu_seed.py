@@ -95,7 +95,7 @@ def test_edge_cases(ctx, g1):
     off = np.zeros(len(reads) + 1, np.int64)
     off[1:] = np.cumsum([x.shape[0] for x in reads])
     flat = np.concatenate(reads)
-    sm, ns, hits, nh, _ = O.seed_batch(idx, flat, off, smem_cap=512, hit_cap=1 << 16, threads=2)
+    sm, ns, hits, nh, _ = O.seed_batch(idx, flat, off, smem_cap=8192, hit_cap=1 << 15, threads=2)
     assert _gpu_dump(ctx, flat, off) == O.format_seed_dump(sm, ns, hits)
 
 
