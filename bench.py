@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- learned-index seeding throughput of the MI355X backend (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the seeding hot path (P-RMI lookup -> SA last-mile search -> SMEM enumeration,
+all three rounds, hit gather included) over one batch of synthetic 150-bp reads that is already resident
+in HBM.  Reads shard across ranks with no data-path collective (weak scaling: every GPU gets its own
+batch); the index is built once by rank 0 and broadcast over RCCL.  One JSON line is printed by rank 0.
+
+Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 128), MEME_BENCH_READS (reads
+per GPU per step, default 2,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's
+rule), MEME_BENCH_CPU (0 disables the CPU-baseline leg), MEME_BENCH_CPU_READS (sample size, default 2M).
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "bwa-meme_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pymeme import hipapi, hostapi, synth, workload  # noqa: E402
+
+READ_LEN = 150
+
+
+def log(msg):
+    print("[bench r%s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
+
+def fastq_bytes(reads: np.ndarray) -> np.ndarray:
+    """Vectorised FASTQ image of fixed-length reads (constant name/quality; the harness ignores both)."""
+    n, L = reads.shape
+    row = np.empty((n, 3 + L + 3 + L + 1), dtype=np.uint8)
+    row[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+    row[:, 3:3 + L] = np.frombuffer(b"ACGTN", dtype=np.uint8)[reads]
+    row[:, 3 + L:6 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    row[:, 6 + L:6 + 2 * L] = ord("I")
+    row[:, 6 + 2 * L] = ord("\n")
+    return row
+
+
+def cpu_baseline_reference(fwd, text, sa, l1, l2, reads, cores):
+    """Times the COMPILED REFERENCE (oracle/_ref/learned_seeding_mode3 = test/Learned_seeding_big_read.cpp,
+    MODE=3, AVX-512 build) on the same index and a sample of the same reads.  Measurement only."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py as O
+    exe = os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")
+    tmp = tempfile.mkdtemp(prefix="meme_cpu_")
+    try:
+        prefix = os.path.join(tmp, "ref.fa")
+        t0 = time.time()
+        hostapi.write_index(prefix, fwd, text, sa, l1, l2, n_contigs=4)
+        fq = os.path.join(tmp, "sample.fq")
+        fastq_bytes(reads).tofile(fq)
+        log("cpu_baseline: index + FASTQ written in %.1f s" % (time.time() - t0))
+        hz = O.tsc_hz()
+        t0 = time.time()
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+        r = subprocess.run([exe, prefix, fq, "1000", str(cores), "3"], capture_output=True, text=True, env=env,
+                           timeout=1500)
+        wall = time.time() - t0
+        cyc = None
+        for line in r.stderr.splitlines():
+            if line.startswith("Consumed:"):
+                cyc = float(line.split()[1])
+        if r.returncode != 0 or cyc is None:
+            raise RuntimeError("reference harness failed: " + r.stderr[-500:])
+        secs = cyc / hz
+        log("cpu_baseline: reference seeded %d reads on %d threads in %.2f s (process wall %.1f s incl. index load)"
+            % (reads.shape[0], cores, secs, wall))
+        return {"value": reads.shape[0] / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
+                "sample": "%d of the benchmark's reads, same index; seeding region of test/Learned_seeding_big_read.cpp "
+                          "(MODE=3, AVX-512 build, steps=3) timed by its own rdtsc counter" % reads.shape[0]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline_port(text, sa, l1, l2, reads, cores):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py as O
+    idx = O.Index(text, sa)
+    off = np.arange(0, (reads.shape[0] + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    t0 = time.time()
+    O.refpath_seed_batch(idx, l1, l2, reads, off, threads=cores, keep_smems=False)
+    secs = time.time() - t0
+    return {"value": reads.shape[0] / secs, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "%d of the benchmark's reads; oracle/meme_refpath.c (restated MODE-2 probe sequence, OpenMP)"
+                      % reads.shape[0]}
+
+
+def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
+    """SURVEY 8(d) per-read figure from the instrumented restatement, on a sample of the same reads."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py as O
+    idx = O.Index(text, sa)
+    n = reads.shape[0]
+    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    _, _, ctr = O.refpath_seed_batch(idx, l1, l2, reads, off, threads=0, keep_smems=False)
+    return O.algorithmic_bytes(ctr, n * READ_LEN) / n, {k: v / n for k, v in ctr.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    mbp = float(os.environ.get("MEME_BENCH_MBP", "128"))
+    nreads = int(os.environ.get("MEME_BENCH_READS", "2000000"))
+    bits = int(os.environ.get("MEME_BENCH_BITS", "0"))
+    l_pac = int(mbp * 1e6) & ~1
+    n = 2 * l_pac
+
+    # ---- index: built on rank 0's host, staged on every GPU ----------------------------------------
+    meta = torch.zeros(4, dtype=torch.int64, device=dev)
+    fwd = text = sa = l1 = l2 = None
+    if rank == 0:
+        t0 = time.time()
+        fwd = synth.make_genome(l_pac, seed=11)
+        text, sa = hostapi.build_sa(fwd)
+        l1, l2 = hostapi.train_prmi(text, sa, bits=bits)
+        log("genome %.0f Mbp: suffix array + P-RMI (2^%d leaves, %d partial) built on host in %.1f s"
+            % (l_pac / 1e6, int(np.log2(l2.shape[0])), l1.shape[0], time.time() - t0))
+        meta[0], meta[1], meta[2] = n, l2.shape[0], l1.shape[0]
+    if world > 1:
+        dist.broadcast(meta, 0)
+    n_l2, n_l1 = int(meta[1]), int(meta[2])
+    t0 = time.time()
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    d_sa = torch.empty(n, dtype=torch.int64, device=dev)
+    d_l2 = torch.empty(n_l2 * 24, dtype=torch.uint8, device=dev)
+    d_l1 = torch.empty(max(n_l1, 1) * 24, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        d_text.copy_(torch.from_numpy(text))
+        d_sa.copy_(torch.from_numpy(sa.view(np.int64)))
+        d_l2.copy_(torch.from_numpy(l2.view(np.uint8).reshape(-1)))
+        if n_l1:
+            d_l1[:n_l1 * 24].copy_(torch.from_numpy(l1.view(np.uint8).reshape(-1)))
+    if world > 1:
+        # one-off RCCL broadcast of the index image over xGMI; no collective in steady state
+        for t in (d_text, d_sa, d_l2, d_l1):
+            dist.broadcast(t, 0)
+    torch.cuda.synchronize()
+    ctx = hipapi.Context(local)
+    words = hipapi.lib().meme_index_pac64_words(n)
+    d_pac = torch.empty(words, dtype=torch.int64, device=dev)
+    d_ent = torch.empty(2 * n, dtype=torch.int64, device=dev)
+    L = hipapi.lib()
+    import ctypes as C
+    hipapi._check(L.meme_stage_pack_text(C.c_void_p(ctx.h), C.c_void_p(d_text.data_ptr()), C.c_int64(n),
+                                         C.c_void_p(d_pac.data_ptr())))
+    hipapi._check(L.meme_stage_entries_from_sa(C.c_void_p(ctx.h), C.c_void_p(d_sa.data_ptr()), C.c_int64(n),
+                                               C.c_void_p(d_pac.data_ptr()), C.c_void_p(d_ent.data_ptr())))
+    ctx.sync()
+    arrays = hipapi.IndexArrays(n, d_ent.data_ptr(), d_pac.data_ptr(), d_l2.data_ptr(), n_l2, d_l1.data_ptr(), n_l1)
+    ctx.attach_index(arrays)
+    del d_sa, d_text
+    torch.cuda.empty_cache()
+    log("index staged in HBM in %.1f s (%.2f GB entries)" % (time.time() - t0, 16 * n / 1e9))
+
+    # ---- reads: every rank samples its own batch ------------------------------------------------------
+    genome_t = torch.empty(l_pac, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        genome_t.copy_(torch.from_numpy(fwd))
+    if world > 1:
+        dist.broadcast(genome_t, 0)
+    genome = fwd if rank == 0 else genome_t.cpu().numpy()
+    del genome_t
+    t0 = time.time()
+    reads = workload.make_reads_fast(genome, nreads, READ_LEN, seed=1000 + rank)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(0, (nreads + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    log("%d reads sampled and uploaded in %.1f s" % (nreads, time.time() - t0))
+    opt = hipapi.default_seed_opt(rounds=3)
+
+    def step():
+        return ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), nreads, nreads * READ_LEN, opt)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(a.warmup):
+        res = step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = step()
+        tm = ctx.timings()
+        kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms))
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+
+    if rank == 0:
+        k_ms = float(np.mean([k for k, _ in kernel_ms]))
+        g_ms = float(np.mean([g for _, g in kernel_ms]))
+        sample = reads[:20000]
+        bpr, per_read = algorithmic_bytes_per_read(text, sa, l1, l2, sample)
+        achieved = bpr * nreads / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "seeding_reads_per_sec", "value": world * nreads * a.steps / dt, "unit": "reads/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "learned-index seeding (rounds 1-3 + hit gather), %d bp SE reads vs %.0f Mbp synthetic "
+                                   "genome (fwd+rc suffix array of %d entries), index and reads resident in HBM"
+                                   % (READ_LEN, l_pac / 1e6, n),
+                       "genome_bp": l_pac, "sa_entries": n, "reads_per_gpu_per_step": nreads, "read_len": READ_LEN,
+                       "rmi_leaves_log2": int(np.log2(n_l2)), "sharding": "reads/%d ranks, index replicated by RCCL broadcast" % world,
+                       "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
+                       "searches_per_read": res.searches / nreads},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "k_seed", "kernel_ms": k_ms, "gather_ms": g_ms,
+                         "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
+        }
+        cpu = None
+        if world == 1 and os.environ.get("MEME_BENCH_CPU", "1") != "0":
+            cores = os.cpu_count() or 1
+            ns = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000")))
+            try:
+                if os.path.exists(os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")) and \
+                        "avx512bw" in open("/proc/cpuinfo").read():
+                    cpu = cpu_baseline_reference(fwd, text, sa, l1, l2, reads[:ns], cores)
+                else:
+                    cpu = cpu_baseline_port(text, sa, l1, l2, reads[:min(ns, 400000)], cores)
+            except Exception as e:  # the baseline is a reported extra, never the measured value
+                log("cpu_baseline leg failed: %r -- falling back to the port" % (e,))
+                cpu = cpu_baseline_port(text, sa, l1, l2, reads[:min(ns, 400000)], cores)
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

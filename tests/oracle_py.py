@@ -102,6 +102,50 @@ def seed_batch(index: Index, reads: np.ndarray, read_off: np.ndarray, params=Non
     return smems, n_smems, hits, n_hits, ctr
 
 
+REFPATH_COUNTERS = ("lookups", "partial_lookups", "compares", "extra_words", "hits", "smems", "searches")
+
+
+def refpath_seed_batch(index: Index, l1, l2, reads, read_off, params=None, smem_cap=512, threads=0, keep_smems=True):
+    """Instrumented restatement of the reference's probe sequence (oracle/meme_refpath.c).
+    Returns (smems or None, n_smems, dict of work counters)."""
+    params = params or default_seed_params()
+    reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    l1 = np.ascontiguousarray(l1)
+    l2 = np.ascontiguousarray(l2)
+    n = read_off.shape[0] - 1
+    smems = np.zeros((n, smem_cap), dtype=MEM_TL_DTYPE) if keep_smems else None
+    n_smems = np.zeros(n, dtype=np.int32)
+    ctr = np.zeros(7, dtype=np.int64)
+    rc = lib().rp_seed_batch(C.byref(index.c), C.c_void_p(l1.ctypes.data if l1.shape[0] else None),
+                             C.c_void_p(l2.ctypes.data), C.c_int64(l2.shape[0]), C.c_void_p(reads.ctypes.data),
+                             C.c_void_p(read_off.ctypes.data), C.c_int64(n), C.byref(params),
+                             C.c_void_p(smems.ctypes.data if keep_smems else None), C.c_int32(smem_cap),
+                             C.c_void_p(n_smems.ctypes.data), C.c_void_p(ctr.ctypes.data), C.c_int(threads))
+    if rc != 0:
+        raise RuntimeError("refpath capacity exceeded")
+    return smems, n_smems, dict(zip(REFPATH_COUNTERS, ctr.tolist()))
+
+
+def algorithmic_bytes(ctr, total_bases):
+    """lookups*24 (+24 per partial hop) + compares*13 + extra words*8 + hits*(5+8) +
+    SMEMs*24 + read bases (MODE 2/3 entry size 13 B; no ISA lookups in the restated MODE-2 path)."""
+    return (24 * ctr["lookups"] + 24 * ctr["partial_lookups"] + 13 * ctr["compares"] + 8 * ctr["extra_words"] +
+            13 * ctr["hits"] + 24 * ctr["smems"] + total_bases)
+
+
+def tsc_hz():
+    f = lib().orc_tsc_hz
+    f.restype = C.c_double
+    return f()
+
+
+def load_prmi_files(prefix):
+    dt = np.dtype([("icpt", "<f8"), ("slope", "<f8"), ("err", "<u8")])
+    return (np.fromfile(prefix + ".suffixarray_uint64_L1_PARAMETERS", dtype=dt),
+            np.fromfile(prefix + ".suffixarray_uint64_L2_PARAMETERS", dtype=dt))
+
+
 def bsw_batch(pairs: np.ndarray, ref: np.ndarray, qer: np.ndarray, w: int, params=None, threads=0):
     """pairs: SEQPAIR_DTYPE array (modified in place). Returns number of DP cells evaluated."""
     params = params or default_bsw_params()

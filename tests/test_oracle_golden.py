@@ -49,3 +49,19 @@ def test_reference_simd16_agrees_with_scalar_where_it_matters():
     for x, y in zip(committed(a), committed(b)):
         assert np.array_equal(x, y)
     assert np.array_equal(a[:, 0], b[:, 0]) and np.array_equal(a[:, 5], b[:, 5])
+
+
+@pytest.mark.parametrize("length", [150, 250, 60, 25])
+def test_refpath_restatement_agrees_with_semantic_oracle(g1_index, length):
+    """The instrumented probe-sequence restatement (work counters for the roofline) finds the same SMEMs."""
+    prefix = build_index(os.path.join(GOLDEN, "g1.fa"))
+    l1, l2 = O.load_prmi_files(prefix)
+    reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
+    sm, ns, hits, nh, _ = O.seed_batch(g1_index, reads, off, smem_cap=256, hit_cap=4096, threads=2)
+    rsm, rns, ctr = O.refpath_seed_batch(g1_index, l1, l2, reads, off, smem_cap=256, threads=2)
+    assert np.array_equal(ns, rns)
+    for r in range(ns.shape[0]):
+        k = ns[r]
+        for f in ("start", "end", "hitcount"):
+            assert np.array_equal(sm[r, :k][f], rsm[r, :k][f]), (r, f)
+    assert ctr["compares"] > ctr["lookups"] > 0 and ctr["smems"] == int(ns.sum())
