@@ -49,14 +49,16 @@ struct meme_ctx {
     std::vector<void*> owned;          // device allocations of the index
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb;
+           scan_tmp, counters, pairs, refb, qerb, packed;
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
-    i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch
+    i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch (tier 0)
+    i64 group_lanes = 16;              // lanes per read in the search kernel (4, 8, 16, 32)
+    i64 seed_blocks_per_cu = 4;
     i64 bsw_blocks = 0;
     // timings
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    meme_timings tm = {0, 0, 0, 0, 0};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    meme_timings tm = {0, 0, 0, 0, 0, 0, 0};
 };
 
 void meme_set_error(const char* fmt, ...);

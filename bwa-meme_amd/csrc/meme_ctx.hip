@@ -64,7 +64,8 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
-                      &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb};
+                      &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
+                      &ctx->packed};
     for (DevBuf* b : bufs) free_buf(*b);
     if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -91,6 +92,10 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "seed_blocks")) ctx->seed_blocks = value;
     else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
+    else if (!strcmp(key, "group_lanes")) {
+        if (value != 4 && value != 8 && value != 16 && value != 32) { meme_set_error("group_lanes must be 4, 8, 16 or 32"); return MEME_E_ARG; }
+        ctx->group_lanes = value;
+    } else if (!strcmp(key, "seed_blocks_per_cu")) ctx->seed_blocks_per_cu = value < 1 ? 1 : value;
     else { meme_set_error("unknown tuning key %s", key); return MEME_E_ARG; }
     return MEME_OK;
 }

@@ -1,0 +1,708 @@
+// Learned-index seeding kernels (device code), included by meme_seed.hip.
+//
+// Reference functions restated here (paths in the BWA-MEME tree):
+//   Learned_getSMEMsAllPosOneThread        src/LearnedIndex_seeding.cpp:913-972   (rounds 1 and 2)
+//     Learned_getSMEMsOnePosOneThread_step1                               :1691-1894
+//     Learned_getSMEMsOnePosOneThread                                     :1897-2126
+//   Learned_bwtSeedStrategyAllPosOneThread[_mem_tradeoff]                 :974-1466  (round 3)
+//   mem_search / right_smem_search [+ _tradeoff]                          :2131-4189
+//   learned_index_lookup                                                  :186-210
+//   compare_read_and_ref_binary*                                          :226-601
+//   read packing of mem_kernel1_core_Learned                              src/bwamem.cpp:1277-1344
+//
+// Design (MI355X-first, not a translation):
+//  * A read is owned by a group of G lanes (G = 4..32, 64/G reads per wavefront).  The pivot state
+//    machine is group-uniform scalar state replicated in the group's lanes; only suffix-array probes
+//    are lane-parallel.
+//  * The pivot logic of rounds 1-3 is flattened into an explicit state machine ("program counter"
+//    per read) around ONE search call site, so the 64/G reads of a wavefront execute the search body
+//    convergently and their memory requests are issued together -- instead of each read sitting in a
+//    different call site of a recursive-descent transcription of the CPU code.
+//  * The unit of memory traffic is a *window*: G consecutive 16-byte suffix-array entries, one
+//    coalesced load.  Each lane compares its entry's 64-bit key (and, only when all 32 bases agree,
+//    2-bit reference words) with the read; a wave ballot yields the partition point, the longest
+//    common prefix and -- from the same data -- the SMEM hit interval, so the reference's chain of
+//    ~log2(err)+linear dependent single-entry probes collapses to one window in the common case.
+//  * The learned model is a hint: when the partition point is outside the first
+//    window the group gallops away from the prediction and bisects with group-uniform single-entry
+//    probes (broadcast loads), then takes a final window.  Model error bounds are never needed, so
+//    any parameter file the reference loads is accepted.
+//  * Reads are packed once per batch by k_pack_reads (2 bits/base, both strands, first base in the
+//    top bits of each u64, plus N masks) and staged in LDS; a 32-base query word at any offset is a
+//    funnel shift of two LDS words, replacing the reference's 8 pre-shifted copies of every read.
+#pragma once
+#include <limits.h>
+
+#include "meme_common.h"
+
+namespace seedk {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_READ_LEN = 500;        // LEARNED_MAX_READ_LEN (reference src/bwamem.cpp:1259)
+
+struct SlotRec {          // search-kernel output, one per SMEM
+    int32_t start, end;
+    i64 sa_start;
+    i64 count;
+};
+
+constexpr int N_TIERS = 3;
+constexpr int TIER_CAP[N_TIERS] = {64, 2048, 65536};   // global SMEM slots per read; tier 0 is tunable
+constexpr int TIER_LCAP[N_TIERS] = {16, 512, 512};     // LDS ring: SMEMs of one first-round pass (<= read length)
+
+struct PackGeom {
+    int W;        // u64 words per strand (>= ceil(maxlen/32) + 2)
+    int MW;       // u64 N-mask words per strand
+    int stride;   // 2*W + 2*MW
+};
+
+struct SeedArgs {
+    DevIndex I;
+    const u64* packed;     // [nreads_total * stride]
+    const i64* read_off;
+    i64 nreads;
+    PackGeom geo;
+    meme_seed_opt opt;
+    SlotRec* slots;        // [nreads * cap] for this tier
+    int* slot_cnt;         // [all reads]
+    i64* slot_hits;
+    i64* slot_loc;         // (tier << 40) | block index inside the tier's slot array
+    const i64* pending;    // read ids to re-process in an overflow tier, else nullptr
+    i64* ovf_list;
+    int cap, lcap, tier;
+    unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads, [3] window loads
+};
+
+// ---- read packing -------------------------------------------------------------------------------------
+// one thread per output u64.  Layout per read: fw[W] rc[W] nfw[MW] nrc[MW].
+__global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ reads, const i64* __restrict__ read_off,
+                                                     i64 nreads, PackGeom g, u64* __restrict__ out) {
+    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 r = gid / g.stride;
+    if (r >= nreads) return;
+    int k = (int)(gid - r * g.stride);
+    const i64 ro = read_off[r];
+    int len = (int)(read_off[r + 1] - ro);
+    if (len > MAX_READ_LEN) len = 0;
+    const uint8_t* p = reads + ro;
+    u64 v = 0;
+    if (k < 2 * g.W) {
+        const bool rc = k >= g.W;
+        const int w = rc ? k - g.W : k;
+        for (int j = 0; j < 32; ++j) {
+            int i = 32 * w + j;
+            u64 c = 0;
+            if (i < len) {
+                uint8_t b = rc ? p[len - 1 - i] : p[i];
+                c = b < 4 ? (rc ? 3 - b : b) : 0;          // N packed as A (src/bwamem.cpp:1293-1294)
+            }
+            v = (v << 2) | c;
+        }
+    } else {
+        int m = k - 2 * g.W;
+        const bool rc = m >= g.MW;
+        if (rc) m -= g.MW;
+        for (int j = 0; j < 64; ++j) {
+            int i = 64 * m + j;
+            if (i < len) {
+                uint8_t b = rc ? p[len - 1 - i] : p[i];
+                if (b >= 4) v |= 1ull << j;
+            }
+        }
+    }
+    out[gid] = v;
+}
+
+// ---- per-read state ------------------------------------------------------------------------------------
+enum Pc : int {
+    PC_ALLPOS_TOP, PC_ZZ_TOP, PC_ZZ_RIGHT, PC_ZZ_END, PC_AFTER_STEP1, PC_R2_LOOP, PC_R2_AFTER, PC_R3_INIT,
+    PC_R3_TOP, PC_DONE
+};
+enum Kind : int { K_S1_RIGHT, K_ZZ_LEFT, K_ZZ_RIGHT, K_OP_MEM, K_OP_SMEM, K_R3 };
+
+struct Req {
+    int kind;
+    bool rc;          // query strand: reverse complement (left extension) or forward
+    int off, vlen;
+    int min_intv;
+    int mode;         // 0: match length only; 1: + interval with >= min_intv suffixes; 2: third-round levels
+};
+
+struct Res {
+    int L;            // match length (mode 2: the advance)
+    i64 start, count; // SA interval
+    bool emit;        // mode 2: an SMEM is to be emitted
+};
+
+template <int G>
+struct Grp {
+    static constexpr u64 FULL = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    const DevIndex* I;
+    const u64* fw;    // LDS
+    const u64* rc;
+    const u64* nfw;
+    const u64* nrc;
+    int t, gbase;
+    unsigned long long windows;
+
+    __device__ __forceinline__ u64 ballot(bool p) const { return (__ballot(p) >> gbase) & FULL; }
+    __device__ __forceinline__ int shfl(int v, int src) const { return __shfl(v, gbase + src); }
+};
+
+// ---- compare: compare_read_and_ref_binary* (:226-601) ---------------------------------------------------
+// L = min(cap, n - pos).  lcp < L: less = ref base < read base.  lcp == L: less = (L < ref_len)
+// ("exact": the suffix continues past the query and sorts before it; a suffix that ends first sorts
+// after it, as if followed by T-padding).
+__device__ __forceinline__ void cmp_entry(const DevIndex& I, const u64* s, int off, int cap, SaEnt e, int& lcp,
+                                          bool& less) {
+    i64 ref_len = I.n - (i64)e.pos;
+    int L = ref_len < (i64)cap ? (int)ref_len : cap;
+    u64 wr = e.key;
+    int l = 0, k = 0;
+    bool lt = false;
+    for (;;) {
+        u64 wq = extract32(s, off + 32 * k);
+        u64 x = wr ^ wq;
+        if (x) { l = 32 * k + (__clzll((long long)x) >> 1); lt = wr < wq; break; }
+        l = 32 * (k + 1);
+        if (l >= L) break;
+        ++k;
+        wr = extract32(I.pac, (i64)e.pos + 32 * k);
+    }
+    if (l >= L) { lcp = L; less = (i64)L < ref_len; }
+    else { lcp = l; less = lt; }
+}
+
+// ---- learned_index_lookup (:186-210): same arithmetic (FP64 FMA + clamp), used as a hint ------------------
+__device__ __forceinline__ i64 rmi_lookup(const DevIndex& I, u64 key) {
+    u64 m = I.shift >= 64 ? 0ull : key >> I.shift;
+    RmiRec r = I.l2[m];
+    double x = (double)key;
+    double f = fma(r.slope, x, r.icpt);
+    if (r.err >> 63) {
+        u64 ps = (r.err >> 32) & 0x7fffffffull;
+        double pn = (double)(r.err & 0xffffffffull) - 1.0;
+        double c = f < 0.0 ? 0.0 : (f > pn ? pn : f);
+        r = I.l1[ps + (u64)c];
+        f = fma(r.slope, x, r.icpt);
+    }
+    double top = (double)I.n - 1.0;
+    if (f < 0.0) return 0;
+    if (f > top) return I.n - 1;
+    return (i64)f;
+}
+
+template <int G>
+__device__ __forceinline__ void scan_window(Grp<G>& g, const u64* s, int off, int cap, i64 base, int& lcp, bool& less) {
+    SaEnt e = g.I->sa[base + g.t];
+    cmp_entry(*g.I, s, off, cap, e, lcp, less);
+    g.windows++;
+}
+
+// group-uniform single-slot probe: every lane loads the same entry (one broadcast sector)
+template <int G>
+__device__ __forceinline__ void probe(Grp<G>& g, const u64* s, int off, int cap, i64 slot, int& lcp, bool& less) {
+    SaEnt e = g.I->sa[slot];
+    cmp_entry(*g.I, s, off, cap, e, lcp, less);
+}
+
+// lowest slot s_edge <= cur with [s_edge, cur] all sharing >= L bases with the query (cur does, cur > 0);
+// nb = LCP of slot s_edge-1 (0 at the array start)
+template <int G>
+__device__ __noinline__ void edge_down(Grp<G>& g, const u64* s, int off, int L, i64 cur, i64& s_edge, int& nb) {
+    int iter = 0;
+    for (;;) {
+        i64 wb = cur - G;
+        if (wb < 0) wb = 0;
+        int lcp; bool less;
+        scan_window(g, s, off, L, wb, lcp, less);
+        u64 mm = g.ballot(lcp >= L);
+        int ncur = (int)(cur - wb);                       // lanes [0,ncur) lie below cur
+        u64 z = (~mm) & ((1ull << ncur) - 1ull);
+        if (z) {
+            int hz = 63 - __clzll((long long)z);
+            s_edge = wb + hz + 1;
+            nb = g.shfl(lcp, hz);
+            return;
+        }
+        cur = wb;
+        if (cur == 0) { s_edge = 0; nb = 0; return; }
+        if (++iter >= 2) break;
+    }
+    // large interval: gallop with single-slot probes, bisect, then one window for the exact edge
+    i64 good = cur, bad = -1, step = 4 * G;
+    for (;;) {
+        i64 p = good - step;
+        if (p < 0) p = 0;
+        int lcp; bool less;
+        probe(g, s, off, L, p, lcp, less);
+        if (lcp >= L) { good = p; if (p == 0) break; step <<= 1; }
+        else { bad = p; break; }
+    }
+    if (bad < 0) { s_edge = 0; nb = 0; return; }
+    while (good - bad > G) {
+        i64 mid = bad + (good - bad) / 2;
+        int lcp; bool less;
+        probe(g, s, off, L, mid, lcp, less);
+        if (lcp >= L) good = mid; else bad = mid;
+    }
+    {
+        i64 wb = good - G;                                // >= bad >= 0: window [wb, good) contains bad
+        if (wb < 0) wb = 0;
+        int lcp; bool less;
+        scan_window(g, s, off, L, wb, lcp, less);
+        int ncur = (int)(good - wb);
+        u64 z = (~g.ballot(lcp >= L)) & ((1ull << ncur) - 1ull);
+        int hz = 63 - __clzll((long long)z);
+        s_edge = wb + hz + 1;
+        nb = g.shfl(lcp, hz);
+    }
+}
+
+// highest slot e_edge >= cur with [cur, e_edge] all matching; nb = LCP of slot e_edge+1 (0 at the end)
+template <int G>
+__device__ __noinline__ void edge_up(Grp<G>& g, const u64* s, int off, int L, i64 cur, i64& e_edge, int& nb) {
+    const i64 n = g.I->n;
+    int iter = 0;
+    for (;;) {
+        i64 wb = cur + 1;                                 // window [wb, wb+G) clipped to the array
+        if (wb > n - G) wb = n - G;
+        int lcp; bool less;
+        scan_window(g, s, off, L, wb, lcp, less);
+        u64 mm = g.ballot(lcp >= L);
+        int first = (int)(cur + 1 - wb);                  // lanes [first, G) lie above cur
+        u64 z = (~mm) & Grp<G>::FULL & ~((1ull << first) - 1ull);
+        if (z) {
+            int lz = __ffsll((long long)z) - 1;
+            e_edge = wb + lz - 1;
+            nb = g.shfl(lcp, lz);
+            return;
+        }
+        cur = wb + G - 1;
+        if (cur == n - 1) { e_edge = n - 1; nb = 0; return; }
+        if (++iter >= 2) break;
+    }
+    i64 good = cur, bad = -1, step = 4 * G;
+    for (;;) {
+        i64 p = good + step;
+        if (p > n - 1) p = n - 1;
+        int lcp; bool less;
+        probe(g, s, off, L, p, lcp, less);
+        if (lcp >= L) { good = p; if (p == n - 1) break; step <<= 1; }
+        else { bad = p; break; }
+    }
+    if (bad < 0) { e_edge = n - 1; nb = 0; return; }
+    while (bad - good > G) {
+        i64 mid = good + (bad - good) / 2;
+        int lcp; bool less;
+        probe(g, s, off, L, mid, lcp, less);
+        if (lcp >= L) good = mid; else bad = mid;
+    }
+    {
+        i64 wb = good + 1;                                // window (good, good+G] contains bad
+        if (wb > n - G) wb = n - G;
+        int lcp; bool less;
+        scan_window(g, s, off, L, wb, lcp, less);
+        int first = (int)(good + 1 - wb);
+        u64 z = (~g.ballot(lcp >= L)) & Grp<G>::FULL & ~((1ull << first) - 1ull);
+        int lz = __ffsll((long long)z) - 1;
+        e_edge = wb + lz - 1;
+        nb = g.shfl(lcp, lz);
+    }
+}
+
+// partition point outside the first window: gallop away from the prediction, bisect, return the base of a
+// window that contains the partition point (or touches the array end it lies beyond)
+template <int G>
+__device__ __noinline__ i64 relocate(Grp<G>& g, const u64* s, int off, int vlen, i64 base, bool above) {
+    const i64 n = g.I->n;
+    if (above) {
+        i64 lo = base + G - 1, hi = -1, step = G;
+        for (;;) {
+            i64 p = lo + step;
+            if (p > n - 1) p = n - 1;
+            int l2; bool ls;
+            probe(g, s, off, vlen, p, l2, ls);
+            if (ls) { lo = p; if (p == n - 1) break; step <<= 1; }
+            else { hi = p; break; }
+        }
+        if (hi < 0) return n - G;
+        while (hi - lo >= G) {
+            i64 mid = lo + (hi - lo) / 2;
+            int l2; bool ls;
+            probe(g, s, off, vlen, mid, l2, ls);
+            if (ls) lo = mid; else hi = mid;
+        }
+        i64 b = hi - G + 1;
+        return b < 0 ? 0 : b;
+    }
+    i64 hi = base, lo = -1, step = G;
+    for (;;) {
+        i64 p = hi - step;
+        if (p < 0) p = 0;
+        int l2; bool ls;
+        probe(g, s, off, vlen, p, l2, ls);
+        if (!ls) { hi = p; if (p == 0) break; step <<= 1; }
+        else { lo = p; break; }
+    }
+    if (lo < 0) return 0;
+    while (hi - lo >= G) {
+        i64 mid = lo + (hi - lo) / 2;
+        int l2; bool ls;
+        probe(g, s, off, vlen, mid, l2, ls);
+        if (ls) lo = mid; else hi = mid;
+    }
+    return lo > n - G ? n - G : lo;
+}
+
+// The one search primitive.  Semantics of mem_search / right_smem_search (and the _tradeoff twins):
+//   maxLCP = longest prefix of the query (<= vlen bases) occurring in the text;
+//   mode 0: L = maxLCP.
+//   mode 1: L = largest l <= maxLCP whose SA interval holds >= min_intv suffixes; [start,count) = interval
+//           (:2365-2574, :2902-2942).
+//   mode 2: third round (:1199-1281): walk the levels maxLCP = L0 > L1 > ... until the interval holds
+//           >= min_intv suffixes or the next level is shorter than min_seed_len.
+template <int G>
+__device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
+    const DevIndex& I = *g.I;
+    const i64 n = I.n;
+    const u64* s = q.rc ? g.rc : g.fw;
+    const int off = q.off, vlen = q.vlen;
+    u64 key = extract32(s, off);
+    if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
+    i64 pos = rmi_lookup(I, key);
+    i64 base = pos - G / 2;
+    if (base < 0) base = 0;
+    if (base > n - G) base = n - G;
+    int lcp; bool less;
+    scan_window(g, s, off, vlen, base, lcp, less);
+    u64 m = g.ballot(less);
+    const bool above = (m == Grp<G>::FULL) && base + G < n;
+    const bool below = (m == 0) && base > 0;
+    if (above || below) {
+        base = relocate(g, s, off, vlen, base, above);
+        scan_window(g, s, off, vlen, base, lcp, less);
+        m = g.ballot(less);
+    }
+    // lanes [0,P) sort before the query; the longest match is at one of the two boundary neighbours
+    const int P = __popcll(m);
+    const int la = P > 0 ? g.shfl(lcp, P - 1) : -1;
+    const int lb = P < G ? g.shfl(lcp, P < G ? P : G - 1) : -1;
+    const int c = (la >= lb) ? P - 1 : P;
+    int L = la >= lb ? la : lb;
+    Res out;
+    out.L = L;
+    out.start = base + c;
+    out.count = 1;
+    out.emit = false;
+    if (q.mode == 0) return out;
+    if (q.mode == 2 && L < msl) return out;               // :1204-1208
+    // interval at level L from the window, extended beyond it when the run touches a window edge
+    i64 s_edge = base + c, e_edge = base + c;
+    int nb_lo = 0, nb_hi = 0;
+    {
+        u64 mm = g.ballot(lcp >= L);
+        u64 zb = (~mm) & ((1ull << c) - 1ull);
+        u64 za = (~mm) & Grp<G>::FULL & ~((2ull << c) - 1ull);
+        if (zb) {
+            int hz = 63 - __clzll((long long)zb);
+            s_edge = base + hz + 1;
+            nb_lo = g.shfl(lcp, hz);
+        } else if (base == 0) { s_edge = 0; nb_lo = 0; }
+        else edge_down(g, s, off, L, base, s_edge, nb_lo);
+        if (za) {
+            int lz = __ffsll((long long)za) - 1;
+            e_edge = base + lz - 1;
+            nb_hi = g.shfl(lcp, lz);
+        } else if (base + G >= n) { e_edge = n - 1; nb_hi = 0; }
+        else edge_up(g, s, off, L, base + G - 1, e_edge, nb_hi);
+    }
+    if (q.mode == 1) {
+        while (e_edge - s_edge + 1 < (i64)q.min_intv) {
+            L = nb_lo > nb_hi ? nb_lo : nb_hi;
+            if (nb_lo >= L && s_edge > 0) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
+            if (nb_hi >= L && e_edge < n - 1) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
+        }
+        out.L = L;
+        out.start = s_edge;
+        out.count = e_edge - s_edge + 1;
+        return out;
+    }
+    // mode 2
+    i64 last_s = s_edge, last_cnt = 0, cnt, emit_s;
+    int match_len;
+    for (;;) {
+        cnt = e_edge - s_edge + 1;
+        if (cnt >= (i64)q.min_intv) {                      // :1243-1251
+            cnt = last_cnt ? last_cnt : cnt;
+            emit_s = last_s;
+            match_len = L + 1;
+            break;
+        }
+        int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
+        if (nxt < msl) { match_len = msl; emit_s = s_edge; break; }   // :1252-1258
+        last_cnt = cnt;
+        last_s = s_edge;
+        L = nxt;
+        if (nb_lo >= L && s_edge > 0) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
+        if (nb_hi >= L && e_edge < n - 1) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
+    }
+    out.emit = cnt < (i64)q.min_intv;                      // :1265
+    if (match_len < msl) match_len = msl;
+    out.L = match_len;
+    out.start = emit_s;
+    out.count = cnt;
+    return out;
+}
+
+__device__ __forceinline__ bool is_n(const u64* mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
+
+// first ambiguous base at/after `from` (Tokenization's *ambiguous_pos, :795-901)
+__device__ __forceinline__ int first_n(const u64* mask, bool has_n, int from, int l_seq) {
+    if (!has_n) return l_seq;
+    int w = from >> 6;
+    u64 m = mask[w] & (~0ull << (from & 63));
+    const int nw = (l_seq + 63) >> 6;
+    for (;;) {
+        if (m) {
+            int p = w * 64 + __ffsll((long long)m) - 1;
+            return p < l_seq ? p : l_seq;
+        }
+        if (++w >= nw) return l_seq;
+        m = mask[w];
+    }
+}
+
+// ---- the search kernel ---------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(BLOCK) k_seed(SeedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int GROUPS = BLOCK / G;
+    const int lane = threadIdx.x & 63;
+    const int gib = threadIdx.x / G;
+    const int stride = A.geo.stride, W = A.geo.W, MW = A.geo.MW;
+    u64* rd = reinterpret_cast<u64*>(smem_raw) + (size_t)gib * stride;
+    int* ring = reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) + (size_t)gib * 3 * A.lcap;
+    int* sm_start = ring;
+    int* sm_end = ring + A.lcap;
+    int* sm_cnt = ring + 2 * A.lcap;
+    Grp<G> g;
+    g.I = &A.I;
+    g.fw = rd;
+    g.rc = rd + W;
+    g.nfw = rd + 2 * W;
+    g.nrc = rd + 2 * W + MW;
+    g.t = threadIdx.x & (G - 1);
+    g.gbase = lane & ~(G - 1);
+    const int cap = A.cap, lcap = A.lcap;
+    const int hits_per_smem = A.opt.hits_per_smem;
+    for (;;) {
+        unsigned long long ticket = 0;
+        if (g.t == 0) ticket = atomicAdd(&A.counters[0], 1ull);
+        ticket = __shfl(ticket, g.gbase);
+        if (ticket >= (unsigned long long)A.nreads) break;
+        const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
+        const int l_seq = (int)(A.read_off[rid + 1] - A.read_off[rid]);
+        SlotRec* slots = A.slots + (i64)ticket * cap;
+        if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
+            // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
+            // here such a read yields no seeds and is flagged through slot_cnt = -1
+            if (g.t == 0) { A.slot_cnt[rid] = l_seq > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0; }
+            continue;
+        }
+        // ---- stage the packed read in LDS (coalesced 8-byte loads) ------------------------------------
+        const u64* src = A.packed + rid * stride;
+        bool any_n = false;
+        for (int k = g.t; k < stride; k += G) {
+            u64 v = src[k];
+            rd[k] = v;
+            if (k >= 2 * W && k < 2 * W + MW) any_n |= (v != 0);
+        }
+        const bool has_n = g.ballot(any_n) != 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- per-read state (group-uniform) ----------------------------------------------------------------
+        int pivot = 0, l_pivot = l_seq - 1;
+        int msl = A.opt.min_seed_len, min_intv = 1;
+        int n_smems = 0, sm_base = 0;
+        i64 n_hits = 0;
+        bool rec = false, lds_ovf = false;
+        unsigned searches = 0;
+        g.windows = 0;
+        int pc = PC_ALLPOS_TOP;
+        int before = 0, after = 0, r2_k = 0, r2_next = 0, r2_saved = 1;
+        int zz_next = 0, zz_sp = 0, zz_guard = 0, ap_guard = 0;
+        bool zz_check = false, zz_ret_onepos = false;
+#define SET_PIVOT(p_) do { pivot = (p_); l_pivot = l_seq - 1 - pivot; } while (0)
+        for (;;) {
+            // ---- control: advance to the next search request -------------------------------------------------
+            Req q;
+            bool have = false;
+            while (!have && pc != PC_DONE) {
+                switch (pc) {
+                case PC_ALLPOS_TOP:   // Learned_getSMEMsAllPosOneThread loop head (:916) + step1 entry (:1691-1723)
+                    if (pivot >= l_seq || ++ap_guard > 4 * l_seq + 16) { pc = PC_R3_INIT; break; }
+                    before = n_smems; sm_base = before; rec = true;
+                    if (is_n(g.nfw, pivot)) {
+                        if (l_seq - pivot < msl) SET_PIVOT(l_seq); else SET_PIVOT(pivot + 1);
+                        pc = PC_AFTER_STEP1;
+                    } else if (pivot != 0 && !is_n(g.nfw, pivot - 1)) {
+                        zz_next = l_seq; zz_check = true; zz_ret_onepos = false; zz_sp = pivot; zz_guard = 0;
+                        pc = PC_ZZ_TOP;
+                    } else {
+                        q.kind = K_S1_RIGHT; q.rc = false; q.off = pivot;
+                        q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
+                        have = true;
+                    }
+                    break;
+                case PC_ZZ_TOP:       // zig-zag loop head (:1724-1737, :1969)
+                    if (zz_sp >= zz_next || ++zz_guard > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
+                    if (zz_check && is_n(g.nfw, zz_sp)) {
+                        if (l_seq - zz_sp < msl) { SET_PIVOT(l_seq); zz_sp = l_seq; }
+                        else { zz_sp += 1; SET_PIVOT(pivot + 1); }
+                        break;
+                    }
+                    q.kind = K_ZZ_LEFT; q.rc = true; q.off = l_pivot;
+                    q.vlen = first_n(g.nrc, has_n, l_pivot, l_seq) - l_pivot; q.min_intv = min_intv;
+                    q.mode = min_intv != 1 ? 1 : 0;
+                    have = true;
+                    break;
+                case PC_ZZ_RIGHT:
+                    q.kind = K_ZZ_RIGHT; q.rc = false; q.off = pivot;
+                    q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
+                    have = true;
+                    break;
+                case PC_ZZ_END:       // set_forward_pivot(raux, next_pivot) (:1893, :2125)
+                    SET_PIVOT(zz_next);
+                    pc = zz_ret_onepos ? PC_R2_AFTER : PC_AFTER_STEP1;
+                    break;
+                case PC_AFTER_STEP1:  // re-seeding loop entry (:921-923)
+                    rec = false;
+                    after = n_smems;
+                    if (A.opt.rounds < 2) { pc = PC_ALLPOS_TOP; break; }
+                    if (lds_ovf) { pc = PC_DONE; break; }   // re-run in the next tier (bigger LDS ring)
+                    r2_k = before;
+                    pc = PC_R2_LOOP;
+                    break;
+                case PC_R2_LOOP: {    // (:923-947) + OnePos entry (:1917-1930)
+                    if (r2_k >= after) { pc = PC_ALLPOS_TOP; break; }
+                    const int k = r2_k++ - before;
+                    r2_next = pivot; r2_saved = min_intv;
+                    const int qbeg = sm_start[k], qend = sm_end[k], cnt = sm_cnt[k];
+                    if (qend - qbeg < A.opt.split_len || cnt > A.opt.split_width) { SET_PIVOT(r2_next); break; }
+                    SET_PIVOT((qbeg + qend) >> 1);
+                    min_intv = cnt + 1;
+                    if (is_n(g.nfw, pivot)) {
+                        if (l_seq - pivot < msl) SET_PIVOT(l_seq); else SET_PIVOT(pivot + 1);
+                        pc = PC_R2_AFTER;
+                    } else if (pivot != 0 && !is_n(g.nfw, pivot - 1)) {
+                        q.kind = K_OP_MEM; q.rc = false; q.off = pivot;
+                        q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv;
+                        q.mode = min_intv != 1 ? 1 : 0;
+                        have = true;
+                    } else {
+                        q.kind = K_OP_SMEM; q.rc = false; q.off = pivot;
+                        q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
+                        have = true;
+                    }
+                    break;
+                }
+                case PC_R2_AFTER:     // (:945-946)
+                    min_intv = r2_saved;
+                    SET_PIVOT(r2_next);
+                    pc = PC_R2_LOOP;
+                    break;
+                case PC_R3_INIT:      // src/bwamem.cpp:1385-1394
+                    if (A.opt.rounds >= 3 && A.opt.max_mem_intv > 0 && !lds_ovf) {
+                        min_intv = A.opt.max_mem_intv;
+                        msl = A.opt.min_seed_len + 1;
+                        SET_PIVOT(0);
+                        pc = PC_R3_TOP;
+                    } else pc = PC_DONE;
+                    break;
+                case PC_R3_TOP: {     // Learned_bwtSeedStrategyAllPosOneThread loop head (:982-1012)
+                    if (!(pivot < l_seq - msl + 1)) { pc = PC_DONE; break; }
+                    if (is_n(g.nfw, pivot)) { SET_PIVOT(pivot + 1); break; }
+                    const int valid = first_n(g.nfw, has_n, pivot, l_seq) - pivot;
+                    if (valid < msl) { SET_PIVOT(pivot + valid); break; }
+                    q.kind = K_R3; q.rc = false; q.off = pivot; q.vlen = valid; q.min_intv = min_intv; q.mode = 2;
+                    have = true;
+                    break;
+                }
+                default: pc = PC_DONE; break;
+                }
+            }
+            if (!have) break;
+            // ---- the single search call site ----------------------------------------------------------------------
+            ++searches;
+            const Res r = do_search(g, q, msl);
+            // ---- apply -------------------------------------------------------------------------------------------
+            bool emit = false;
+            int e_start = pivot, e_end = pivot;
+            switch (q.kind) {
+            case K_S1_RIGHT:          // (:1852-1893)
+                emit = r.L >= msl; e_end = pivot + r.L;
+                break;
+            case K_ZZ_LEFT:           // (:1774-1777)
+                SET_PIVOT(pivot - r.L + 1);
+                pc = (zz_next - pivot < msl) ? PC_ZZ_END : PC_ZZ_RIGHT;
+                break;
+            case K_ZZ_RIGHT:          // (:1846-1848)
+                emit = r.L >= msl; e_end = pivot + r.L;
+                break;
+            case K_OP_MEM:            // (:1967-1969)
+                zz_next = pivot + r.L; zz_check = false; zz_ret_onepos = true; zz_sp = pivot; zz_guard = 0;
+                pc = PC_ZZ_TOP;
+                break;
+            case K_OP_SMEM:           // (:2093-2125)
+                emit = r.L >= msl; e_end = pivot + r.L;
+                break;
+            case K_R3:                // (:1204-1208, :1265-1281)
+                if (r.L < msl && !r.emit) { /* too short: advance by min_seed_len */ }
+                emit = r.emit; e_end = pivot + r.L;
+                break;
+            }
+            if (emit) {               // kv_push of mem_tl + hits (:2639-2657, :1266-1277)
+                if (n_smems < cap && g.t == 0) {
+                    SlotRec sr;
+                    sr.start = e_start; sr.end = e_end; sr.sa_start = r.start; sr.count = r.count;
+                    slots[n_smems] = sr;
+                }
+                if (rec) {
+                    const int k = n_smems - sm_base;
+                    if (k < lcap) {
+                        // group-uniform redundant LDS stores (every lane writes the same value): no hand-off needed
+                        sm_start[k] = e_start;
+                        sm_end[k] = e_end;
+                        sm_cnt[k] = r.count > (i64)INT_MAX ? INT_MAX : (int)r.count;
+                    } else lds_ovf = true;
+                }
+                ++n_smems;
+                i64 h = r.count;
+                if (hits_per_smem > 0 && h > hits_per_smem) h = hits_per_smem;
+                n_hits += h;
+            }
+            switch (q.kind) {
+            case K_S1_RIGHT: SET_PIVOT(pivot + r.L); pc = PC_AFTER_STEP1; break;
+            case K_ZZ_RIGHT: zz_sp = pivot + r.L; SET_PIVOT(zz_sp); pc = PC_ZZ_TOP; break;
+            case K_OP_SMEM: SET_PIVOT(pivot + r.L); pc = PC_R2_AFTER; break;
+            case K_R3: SET_PIVOT(pivot + (r.L < msl ? msl : r.L)); pc = PC_R3_TOP; break;
+            default: break;
+            }
+        }
+#undef SET_PIVOT
+        if (g.t == 0) {
+            const bool ovf = n_smems > cap || lds_ovf;
+            A.slot_cnt[rid] = ovf ? 0 : n_smems;
+            A.slot_hits[rid] = ovf ? 0 : n_hits;
+            A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
+            if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
+            else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], g.windows); }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace seedk

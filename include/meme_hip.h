@@ -151,9 +151,11 @@ typedef struct {
     float seed_gather_ms;      /* offsets scan + SMEM compaction + hit gather */
     float bsw_kernel_ms;
     int64_t seed_launches, bsw_launches;
+    float seed_pack_ms;        /* read packing kernel */
+    int64_t seed_windows;      /* suffix-array windows loaded by the SA-search kernel */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* e.g. "seed_blocks", "smem_cap" */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks" */
 
 #ifdef __cplusplus
 }

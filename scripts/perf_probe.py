@@ -22,6 +22,15 @@ t0 = time.time(); reads = workload.make_reads_fast(g, n, 150, seed=12); log("rea
 d_reads = torch.from_numpy(reads.reshape(-1)).cuda()
 d_off = torch.arange(0, (n + 1) * 150, 150, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
+import itertools
+configs = [(16,4),(8,4),(4,4),(8,8),(4,8),(16,8),(32,4)]
+for lanes, bpc in configs:
+    ctx.set_tuning("group_lanes", lanes); ctx.set_tuning("seed_blocks_per_cu", bpc)
+    for it in range(2):
+        res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * 150, hipapi.default_seed_opt(rounds=3))
+        tm = ctx.timings()
+    log("G=%d blocks/CU=%d: kernel %.1f ms pack %.2f ms gather %.1f ms -> %.2f M reads/s; windows/search %.2f" % (lanes, bpc, tm.seed_kernel_ms, tm.seed_pack_ms, tm.seed_gather_ms, n / tm.seed_kernel_ms / 1e3, tm.seed_windows / max(res.searches,1)))
+ctx.set_tuning("group_lanes", 16); ctx.set_tuning("seed_blocks_per_cu", 4)
 for rounds in (1, 2, 3):
     for it in range(2):
         t0 = time.time()

@@ -38,6 +38,20 @@ def test_hip_seeds_equal_reference_golden(ctx, g1, length):
     assert _gpu_dump(ctx, reads, off) == want
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32])
+def test_hip_seeds_equal_golden_for_every_group_width(g1, lanes):
+    c = hipapi.Context(0)
+    try:
+        c.load_index_files(g1)
+        c.set_tuning("group_lanes", lanes)
+        for length in (150, 250, 60, 25):
+            reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
+            want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()
+            assert _gpu_dump(c, reads, off) == want
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("rounds", [1, 2, 3])
 def test_hip_seeds_equal_oracle_each_round(ctx, g1, rounds):
     idx = O.load_index_files(g1)
