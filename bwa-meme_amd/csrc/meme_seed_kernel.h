@@ -157,17 +157,35 @@ __device__ __forceinline__ void cmp_entry(const DevIndex& I, const u64* s, int o
                                           bool& less) {
     i64 ref_len = I.n - (i64)e.pos;
     int L = ref_len < (i64)cap ? (int)ref_len : cap;
-    u64 wr = e.key;
-    int l = 0, k = 0;
+    u64 wq = extract32(s, off);
+    u64 x = e.key ^ wq;
+    int l;
     bool lt = false;
-    for (;;) {
-        u64 wq = extract32(s, off + 32 * k);
-        u64 x = wr ^ wq;
-        if (x) { l = 32 * k + (__clzll((long long)x) >> 1); lt = wr < wq; break; }
-        l = 32 * (k + 1);
-        if (l >= L) break;
-        ++k;
-        wr = extract32(I.pac, (i64)e.pos + 32 * k);
+    if (x) { l = __clzll((long long)x) >> 1; lt = e.key < wq; }
+    else {
+        l = 32;
+        if (l < L) {
+            // All 32 key bases agree: the rest comes from the 2-bit text.  Consecutive words are adjacent in
+            // memory (same sector), so four are fetched per round trip instead of one dependent load per word.
+            const i64 p0 = (i64)e.pos + 32;
+            const u64* pw = I.pac + (p0 >> 5);
+            const int sh = (int)(p0 & 31) * 2;
+            bool done = false;
+            for (int k = 1; !done; k += 4, pw += 4) {
+                u64 w[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) w[j] = pw[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (done) break;
+                    u64 wr = sh ? (w[j] << sh) | (w[j + 1] >> (64 - sh)) : w[j];
+                    u64 q = extract32(s, off + 32 * (k + j));
+                    u64 y = wr ^ q;
+                    if (y) { l += __clzll((long long)y) >> 1; lt = wr < q; done = true; }
+                    else { l += 32; if (l >= L) done = true; }
+                }
+            }
+        }
     }
     if (l >= L) { lcp = L; less = (i64)L < ref_len; }
     else { lcp = l; less = lt; }
@@ -475,7 +493,10 @@ __device__ __forceinline__ int first_n(const u64* mask, bool has_n, int from, in
 
 // ---- the search kernel ---------------------------------------------------------------------------------------
 template <int G>
-__global__ void __launch_bounds__(BLOCK) k_seed(SeedArgs A) {
+#ifndef SEED_MIN_WAVES
+#define SEED_MIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int GROUPS = BLOCK / G;
     const int lane = threadIdx.x & 63;
