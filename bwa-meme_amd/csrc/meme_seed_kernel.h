@@ -134,16 +134,30 @@ struct Res {
     bool emit;        // mode 2: an SMEM is to be emitted
 };
 
+// explicit address spaces: LDS (3) for the staged read, global (1) for the index.  Generic pointers would
+// compile to FLAT loads whose waits serialise LDS and HBM traffic.
+typedef const __attribute__((address_space(3))) u64* lds_u64;
+typedef const __attribute__((address_space(1))) u64* glb_u64;
+typedef const __attribute__((address_space(1))) SaEnt* glb_ent;
+typedef const __attribute__((address_space(1))) RmiRec* glb_rmi;
+
+__device__ __forceinline__ u64 ext_l(lds_u64 w, int s) {
+    int k = s >> 5, sh = (s & 31) * 2;
+    u64 a = w[k], b = w[k + 1];
+    return sh ? (a << sh) | (b >> (64 - sh)) : a;
+}
+
 template <int G>
 struct Grp {
     static constexpr u64 FULL = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    const DevIndex* I;
-    const u64* fw;    // LDS
-    const u64* rc;
-    const u64* nfw;
-    const u64* nrc;
+    glb_ent sa;
+    glb_u64 pac;
+    glb_rmi l2, l1;
+    i64 n;
+    int shift;
+    lds_u64 fw, rc, nfw, nrc;
     int t, gbase;
-    unsigned long long windows;
+    unsigned windows;
 
     __device__ __forceinline__ u64 ballot(bool p) const { return (__ballot(p) >> gbase) & FULL; }
     __device__ __forceinline__ int shfl(int v, int src) const { return __shfl(v, gbase + src); }
@@ -153,22 +167,23 @@ struct Grp {
 // L = min(cap, n - pos).  lcp < L: less = ref base < read base.  lcp == L: less = (L < ref_len)
 // ("exact": the suffix continues past the query and sorts before it; a suffix that ends first sorts
 // after it, as if followed by T-padding).
-__device__ __forceinline__ void cmp_entry(const DevIndex& I, const u64* s, int off, int cap, SaEnt e, int& lcp,
+template <int G>
+__device__ __forceinline__ void cmp_entry(const Grp<G>& g, lds_u64 s, int off, int cap, u64 ekey, u64 epos, int& lcp,
                                           bool& less) {
-    i64 ref_len = I.n - (i64)e.pos;
+    i64 ref_len = g.n - (i64)epos;
     int L = ref_len < (i64)cap ? (int)ref_len : cap;
-    u64 wq = extract32(s, off);
-    u64 x = e.key ^ wq;
+    u64 wq = ext_l(s, off);
+    u64 x = ekey ^ wq;
     int l;
     bool lt = false;
-    if (x) { l = __clzll((long long)x) >> 1; lt = e.key < wq; }
+    if (x) { l = __clzll((long long)x) >> 1; lt = ekey < wq; }
     else {
         l = 32;
         if (l < L) {
             // All 32 key bases agree: the rest comes from the 2-bit text.  Consecutive words are adjacent in
             // memory (same sector), so four are fetched per round trip instead of one dependent load per word.
-            const i64 p0 = (i64)e.pos + 32;
-            const u64* pw = I.pac + (p0 >> 5);
+            const i64 p0 = (i64)epos + 32;
+            glb_u64 pw = g.pac + (p0 >> 5);
             const int sh = (int)(p0 & 31) * 2;
             bool done = false;
             for (int k = 1; !done; k += 4, pw += 4) {
@@ -179,7 +194,7 @@ __device__ __forceinline__ void cmp_entry(const DevIndex& I, const u64* s, int o
                 for (int j = 0; j < 4; ++j) {
                     if (done) break;
                     u64 wr = sh ? (w[j] << sh) | (w[j + 1] >> (64 - sh)) : w[j];
-                    u64 q = extract32(s, off + 32 * (k + j));
+                    u64 q = ext_l(s, off + 32 * (k + j));
                     u64 y = wr ^ q;
                     if (y) { l += __clzll((long long)y) >> 1; lt = wr < q; done = true; }
                     else { l += 32; if (l >= L) done = true; }
@@ -192,42 +207,44 @@ __device__ __forceinline__ void cmp_entry(const DevIndex& I, const u64* s, int o
 }
 
 // ---- learned_index_lookup (:186-210): same arithmetic (FP64 FMA + clamp), used as a hint ------------------
-__device__ __forceinline__ i64 rmi_lookup(const DevIndex& I, u64 key) {
-    u64 m = I.shift >= 64 ? 0ull : key >> I.shift;
-    RmiRec r = I.l2[m];
+template <int G>
+__device__ __forceinline__ i64 rmi_lookup(const Grp<G>& g, u64 key) {
+    u64 m = g.shift >= 64 ? 0ull : key >> g.shift;
+    double icpt = g.l2[m].icpt, slope = g.l2[m].slope;
+    u64 err = g.l2[m].err;
     double x = (double)key;
-    double f = fma(r.slope, x, r.icpt);
-    if (r.err >> 63) {
-        u64 ps = (r.err >> 32) & 0x7fffffffull;
-        double pn = (double)(r.err & 0xffffffffull) - 1.0;
+    double f = fma(slope, x, icpt);
+    if (err >> 63) {
+        u64 ps = (err >> 32) & 0x7fffffffull;
+        double pn = (double)(err & 0xffffffffull) - 1.0;
         double c = f < 0.0 ? 0.0 : (f > pn ? pn : f);
-        r = I.l1[ps + (u64)c];
-        f = fma(r.slope, x, r.icpt);
+        u64 j = ps + (u64)c;
+        f = fma(g.l1[j].slope, x, g.l1[j].icpt);
     }
-    double top = (double)I.n - 1.0;
+    double top = (double)g.n - 1.0;
     if (f < 0.0) return 0;
-    if (f > top) return I.n - 1;
+    if (f > top) return g.n - 1;
     return (i64)f;
 }
 
 template <int G>
-__device__ __forceinline__ void scan_window(Grp<G>& g, const u64* s, int off, int cap, i64 base, int& lcp, bool& less) {
-    SaEnt e = g.I->sa[base + g.t];
-    cmp_entry(*g.I, s, off, cap, e, lcp, less);
+__device__ __forceinline__ void scan_window(Grp<G>& g, lds_u64 s, int off, int cap, i64 base, int& lcp, bool& less) {
+    u64 k = g.sa[base + g.t].key, p = g.sa[base + g.t].pos;
+    cmp_entry(g, s, off, cap, k, p, lcp, less);
     g.windows++;
 }
 
 // group-uniform single-slot probe: every lane loads the same entry (one broadcast sector)
 template <int G>
-__device__ __forceinline__ void probe(Grp<G>& g, const u64* s, int off, int cap, i64 slot, int& lcp, bool& less) {
-    SaEnt e = g.I->sa[slot];
-    cmp_entry(*g.I, s, off, cap, e, lcp, less);
+__device__ __forceinline__ void probe(Grp<G>& g, lds_u64 s, int off, int cap, i64 slot, int& lcp, bool& less) {
+    u64 k = g.sa[slot].key, p = g.sa[slot].pos;
+    cmp_entry(g, s, off, cap, k, p, lcp, less);
 }
 
 // lowest slot s_edge <= cur with [s_edge, cur] all sharing >= L bases with the query (cur does, cur > 0);
 // nb = LCP of slot s_edge-1 (0 at the array start)
 template <int G>
-__device__ __noinline__ void edge_down(Grp<G>& g, const u64* s, int off, int L, i64 cur, i64& s_edge, int& nb) {
+__device__ __forceinline__ void edge_down(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& s_edge, int& nb) {
     int iter = 0;
     for (;;) {
         i64 wb = cur - G;
@@ -279,8 +296,8 @@ __device__ __noinline__ void edge_down(Grp<G>& g, const u64* s, int off, int L, 
 
 // highest slot e_edge >= cur with [cur, e_edge] all matching; nb = LCP of slot e_edge+1 (0 at the end)
 template <int G>
-__device__ __noinline__ void edge_up(Grp<G>& g, const u64* s, int off, int L, i64 cur, i64& e_edge, int& nb) {
-    const i64 n = g.I->n;
+__device__ __forceinline__ void edge_up(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& e_edge, int& nb) {
+    const i64 n = g.n;
     int iter = 0;
     for (;;) {
         i64 wb = cur + 1;                                 // window [wb, wb+G) clipped to the array
@@ -332,45 +349,33 @@ __device__ __noinline__ void edge_up(Grp<G>& g, const u64* s, int off, int L, i6
 // partition point outside the first window: gallop away from the prediction, bisect, return the base of a
 // window that contains the partition point (or touches the array end it lies beyond)
 template <int G>
-__device__ __noinline__ i64 relocate(Grp<G>& g, const u64* s, int off, int vlen, i64 base, bool above) {
-    const i64 n = g.I->n;
-    if (above) {
-        i64 lo = base + G - 1, hi = -1, step = G;
-        for (;;) {
-            i64 p = lo + step;
-            if (p > n - 1) p = n - 1;
-            int l2; bool ls;
-            probe(g, s, off, vlen, p, l2, ls);
-            if (ls) { lo = p; if (p == n - 1) break; step <<= 1; }
-            else { hi = p; break; }
-        }
-        if (hi < 0) return n - G;
-        while (hi - lo >= G) {
-            i64 mid = lo + (hi - lo) / 2;
-            int l2; bool ls;
-            probe(g, s, off, vlen, mid, l2, ls);
-            if (ls) lo = mid; else hi = mid;
-        }
-        i64 b = hi - G + 1;
-        return b < 0 ? 0 : b;
-    }
-    i64 hi = base, lo = -1, step = G;
+__device__ __forceinline__ i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen, i64 base, bool above) {
+    const i64 n = g.n;
+    // one loop for both directions: `lo` is a slot known to sort before the query (-1: none yet),
+    // `hi` a slot known not to (n: none yet)
+    i64 lo = above ? base + G - 1 : -1, hi = above ? n : base, step = G;
     for (;;) {
-        i64 p = hi - step;
+        i64 p = above ? lo + step : hi - step;
+        if (p > n - 1) p = n - 1;
         if (p < 0) p = 0;
         int l2; bool ls;
         probe(g, s, off, vlen, p, l2, ls);
-        if (!ls) { hi = p; if (p == 0) break; step <<= 1; }
-        else { lo = p; break; }
+        if (ls) lo = p; else hi = p;
+        if (above ? (!ls || p == n - 1) : (ls || p == 0)) break;
+        step <<= 1;
     }
-    if (lo < 0) return 0;
+    if (hi == n) return n - G;            // every suffix sorts before the query
+    if (lo < 0) return 0;                 // none does
     while (hi - lo >= G) {
         i64 mid = lo + (hi - lo) / 2;
         int l2; bool ls;
         probe(g, s, off, vlen, mid, l2, ls);
         if (ls) lo = mid; else hi = mid;
     }
-    return lo > n - G ? n - G : lo;
+    i64 b = hi - G + 1;                   // window [b, hi] contains lo (hi - lo <= G-1)
+    if (b < 0) b = 0;
+    if (b > n - G) b = n - G;
+    return b;
 }
 
 // The one search primitive.  Semantics of mem_search / right_smem_search (and the _tradeoff twins):
@@ -382,13 +387,12 @@ __device__ __noinline__ i64 relocate(Grp<G>& g, const u64* s, int off, int vlen,
 //           >= min_intv suffixes or the next level is shorter than min_seed_len.
 template <int G>
 __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
-    const DevIndex& I = *g.I;
-    const i64 n = I.n;
-    const u64* s = q.rc ? g.rc : g.fw;
+    const i64 n = g.n;
+    lds_u64 s = q.rc ? g.rc : g.fw;
     const int off = q.off, vlen = q.vlen;
-    u64 key = extract32(s, off);
+    u64 key = ext_l(s, off);
     if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
-    i64 pos = rmi_lookup(I, key);
+    i64 pos = rmi_lookup(g, key);
     i64 base = pos - G / 2;
     if (base < 0) base = 0;
     if (base > n - G) base = n - G;
@@ -415,9 +419,10 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     out.emit = false;
     if (q.mode == 0) return out;
     if (q.mode == 2 && L < msl) return out;               // :1204-1208
-    // interval at level L from the window, extended beyond it when the run touches a window edge
-    i64 s_edge = base + c, e_edge = base + c;
+    // interval at level L from the window; extended beyond it only when the run touches a window edge
+    i64 s_edge = base + c, e_edge = base + c, cur_lo = base, cur_hi = base + G - 1;
     int nb_lo = 0, nb_hi = 0;
+    bool need_lo = false, need_hi = false;
     {
         u64 mm = g.ballot(lcp >= L);
         u64 zb = (~mm) & ((1ull << c) - 1ull);
@@ -426,57 +431,55 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
             int hz = 63 - __clzll((long long)zb);
             s_edge = base + hz + 1;
             nb_lo = g.shfl(lcp, hz);
-        } else if (base == 0) { s_edge = 0; nb_lo = 0; }
-        else edge_down(g, s, off, L, base, s_edge, nb_lo);
+        } else if (base == 0) s_edge = 0;
+        else need_lo = true;
         if (za) {
             int lz = __ffsll((long long)za) - 1;
             e_edge = base + lz - 1;
             nb_hi = g.shfl(lcp, lz);
-        } else if (base + G >= n) { e_edge = n - 1; nb_hi = 0; }
-        else edge_up(g, s, off, L, base + G - 1, e_edge, nb_hi);
+        } else if (base + G >= n) e_edge = n - 1;
+        else need_hi = true;
     }
-    if (q.mode == 1) {
-        while (e_edge - s_edge + 1 < (i64)q.min_intv) {
-            L = nb_lo > nb_hi ? nb_lo : nb_hi;
-            if (nb_lo >= L && s_edge > 0) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
-            if (nb_hi >= L && e_edge < n - 1) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
-        }
-        out.L = L;
-        out.start = s_edge;
-        out.count = e_edge - s_edge + 1;
-        return out;
-    }
-    // mode 2
-    i64 last_s = s_edge, last_cnt = 0, cnt, emit_s;
-    int match_len;
+    i64 last_s = s_edge, last_cnt = 0, cnt, emit_s = s_edge;
+    int match_len = L;
     for (;;) {
+        if (need_lo) edge_down(g, s, off, L, cur_lo, s_edge, nb_lo);
+        if (need_hi) edge_up(g, s, off, L, cur_hi, e_edge, nb_hi);
         cnt = e_edge - s_edge + 1;
-        if (cnt >= (i64)q.min_intv) {                      // :1243-1251
-            cnt = last_cnt ? last_cnt : cnt;
-            emit_s = last_s;
-            match_len = L + 1;
-            break;
+        const int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
+        if (q.mode == 1) {                                  // (:2568-2573, :2936-2940)
+            if (cnt >= (i64)q.min_intv) { emit_s = s_edge; match_len = L; break; }
+        } else {
+            if (cnt >= (i64)q.min_intv) {                   // :1243-1251
+                cnt = last_cnt ? last_cnt : cnt;
+                emit_s = last_s;
+                match_len = L + 1;
+                break;
+            }
+            if (nxt < msl) { match_len = msl; emit_s = s_edge; break; }   // :1252-1258
+            last_cnt = cnt;
+            last_s = s_edge;
         }
-        int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
-        if (nxt < msl) { match_len = msl; emit_s = s_edge; break; }   // :1252-1258
-        last_cnt = cnt;
-        last_s = s_edge;
         L = nxt;
-        if (nb_lo >= L && s_edge > 0) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
-        if (nb_hi >= L && e_edge < n - 1) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
+        need_lo = nb_lo >= L && s_edge > 0;
+        need_hi = nb_hi >= L && e_edge < n - 1;
+        cur_lo = s_edge;
+        cur_hi = e_edge;
     }
-    out.emit = cnt < (i64)q.min_intv;                      // :1265
-    if (match_len < msl) match_len = msl;
+    if (q.mode == 2) {
+        out.emit = cnt < (i64)q.min_intv;                  // :1265
+        if (match_len < msl) match_len = msl;
+    }
     out.L = match_len;
     out.start = emit_s;
     out.count = cnt;
     return out;
 }
 
-__device__ __forceinline__ bool is_n(const u64* mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
+__device__ __forceinline__ bool is_n(lds_u64 mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
 
 // first ambiguous base at/after `from` (Tokenization's *ambiguous_pos, :795-901)
-__device__ __forceinline__ int first_n(const u64* mask, bool has_n, int from, int l_seq) {
+__device__ __forceinline__ int first_n(lds_u64 mask, bool has_n, int from, int l_seq) {
     if (!has_n) return l_seq;
     int w = from >> 6;
     u64 m = mask[w] & (~0ull << (from & 63));
@@ -503,16 +506,22 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     const int gib = threadIdx.x / G;
     const int stride = A.geo.stride, W = A.geo.W, MW = A.geo.MW;
     u64* rd = reinterpret_cast<u64*>(smem_raw) + (size_t)gib * stride;
+    lds_u64 rdl = (lds_u64)rd;
     int* ring = reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) + (size_t)gib * 3 * A.lcap;
     int* sm_start = ring;
     int* sm_end = ring + A.lcap;
     int* sm_cnt = ring + 2 * A.lcap;
     Grp<G> g;
-    g.I = &A.I;
-    g.fw = rd;
-    g.rc = rd + W;
-    g.nfw = rd + 2 * W;
-    g.nrc = rd + 2 * W + MW;
+    g.sa = (glb_ent)A.I.sa;
+    g.pac = (glb_u64)A.I.pac;
+    g.l2 = (glb_rmi)A.I.l2;
+    g.l1 = (glb_rmi)A.I.l1;
+    g.n = A.I.n;
+    g.shift = A.I.shift;
+    g.fw = rdl;
+    g.rc = rdl + W;
+    g.nfw = rdl + 2 * W;
+    g.nrc = rdl + 2 * W + MW;
     g.t = threadIdx.x & (G - 1);
     g.gbase = lane & ~(G - 1);
     const int cap = A.cap, lcap = A.lcap;
@@ -720,7 +729,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             A.slot_hits[rid] = ovf ? 0 : n_hits;
             A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
             if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
-            else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], g.windows); }
+            else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], (unsigned long long)g.windows); }
         }
         __builtin_amdgcn_wave_barrier();
     }
