@@ -1,0 +1,56 @@
+"""End-to-end acceptance test of the drop-in (the reference's own acceptance criterion, README.md:81-92):
+the reference aligner with seeding and extension interposed by the HIP backend (oracle/_ref/bwa-meme_dropin =
+reference main + libbwa_pic.so + oracle/ref_dropin_shim.cpp over include/meme_hip.h) must write the same SAM
+as the unmodified reference binary (`mem -7`), apart from the @PG line that embeds the command line."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ref_py as R
+from common import build_index
+from pymeme import synth
+
+pytestmark = pytest.mark.gpu
+
+REF = R.REF_DIR
+
+
+def _sam(exe, prefix, fqs, env=None, threads=4):
+    cmd = [os.path.join(REF, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads), prefix] + fqs
+    r = subprocess.run(cmd, capture_output=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+@pytest.mark.parametrize("paired", [False, True])
+def test_sam_identical_to_reference(tmp_path, paired):
+    g = synth.make_genome(400_000, seed=41, repeat_frac=0.08, n_families=6, n_dups=6, dup_len=1500)
+    fa = str(tmp_path / "e2e.fa")
+    synth.write_fasta(fa, g, contigs=3)
+    prefix = build_index(fa, bits=14)
+    n = 6000
+    r1, pos, strand = synth.make_reads(g, n, 150, seed=42, n_frac=0.03, exact_frac=0.2)
+    fqs = [str(tmp_path / "r1.fq")]
+    synth.write_fastq(fqs[0], r1, prefix="p")
+    if paired:
+        # mates: reverse-complement reads ~350 bp downstream on the same fragment
+        rng = np.random.default_rng(43)
+        ins = rng.integers(300, 500, size=n)
+        p2 = np.clip(pos + ins - 150, 0, g.shape[0] - 160)
+        idx = p2[:, None] + np.arange(150)[None, :]
+        r2 = 3 - g[idx][:, ::-1]
+        sub = rng.random(r2.shape) < 0.01
+        r2 = np.where(sub, (r2 + 1) & 3, r2).astype(np.uint8)
+        # keep name pairing: same read names in both files
+        fqs.append(str(tmp_path / "r2.fq"))
+        synth.write_fastq(fqs[1], r2, prefix="p")
+    want = _sam("bwa-meme_mode3", prefix, fqs)
+    env = dict(os.environ, MEME_INDEX_PREFIX=prefix)
+    got = _sam("bwa-meme_dropin", prefix, fqs, env=env)
+    assert len(got) == len(want) and len(want) > n
+    diff = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
