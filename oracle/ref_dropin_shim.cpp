@@ -36,7 +36,20 @@ extern uint64_t tprof[LIM_R][LIM_C];
 #define dropin_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
 KSORT_INIT(meme_dropin_smem, mem_tl, dropin_smem_lt)
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#define TRACE(...) do { if (getenv("MEME_DROPIN_TRACE")) { fprintf(stderr, "[meme-dropin] " __VA_ARGS__); fputc('\n', stderr); } } while (0)
+
 namespace {
+
+void segv_handler(int sig) {
+    void* bt[64];
+    int n = backtrace(bt, 64);
+    fprintf(stderr, "[meme-dropin] signal %d, backtrace:\n", sig);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(139);
+}
 
 std::mutex g_mu;
 meme_ctx* g_ctx[1024];
@@ -64,7 +77,10 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
                              mem_chain_v* chain_ar, mem_seed_t* seedBuf, int64_t seedBufSize, uint8_t* sa_pos,
                              uint8_t* ref2sa, uint8_t* ref_string, mem_tlv* smems, u64v* hits, int tid) {
     (void)sa_pos; (void)ref2sa; (void)ref_string;
+    if (getenv("MEME_DROPIN_TRACE")) signal(SIGSEGV, segv_handler);
+    TRACE("seed batch tid=%d nseq=%d", tid, nseq);
     meme_ctx* ctx = ctx_for(tid);
+    TRACE("ctx ok");
     int64_t seedBufCount = 0;
     // base codes in place, as the reference leaves them for the later stages (src/bwamem.cpp:1277-1279)
     std::vector<int64_t> off((size_t)nseq + 1, 0);
@@ -93,6 +109,7 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
         if (rc) { fprintf(stderr, "[meme-dropin] meme_seed_batch: %s\n", meme_last_error()); exit(1); }
         break;
     }
+    TRACE("seeded: %lld smems %lld hits", (long long)ts, (long long)th);
     static_assert(sizeof(meme_mem_tl) == sizeof(mem_tl), "mem_tl layout");
     for (int l = 0; l < nseq; ++l) {
         const int64_t ns = smo[(size_t)l + 1] - smo[(size_t)l], nh = hto[(size_t)l + 1] - hto[(size_t)l];
@@ -111,6 +128,7 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
         chn->n = mem_chain_flt(opt, chn->n, chn->a, tid);
         mem_flt_chained_seeds(opt, bns, pac, seq_, chn->n, chn->a);
     }
+    TRACE("chained tid=%d", tid);
     return 1;
 }
 
@@ -118,6 +136,7 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
 namespace {
 void bsw_forward(const int8_t* mat, int o_del, int e_del, int o_ins, int e_ins, int zdrop, int end_bonus,
                  SeqPair* pairs, uint8_t* ref, uint8_t* qer, int n, int w) {
+    TRACE("bsw n=%d w=%d", n, w);
     if (n <= 0) return;
     // tid is not passed down to this level; extension runs on the ctx of slot 1023-... use a private pool
     static thread_local meme_ctx* ctx = nullptr;
