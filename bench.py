@@ -249,11 +249,12 @@ def main():
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
         }
         cpu = None
-        if world == 1 and os.environ.get("MEME_BENCH_CPU", "1") != "0":
+        cpu_mode = os.environ.get("MEME_BENCH_CPU", "1")
+        if world == 1 and cpu_mode != "0":
             cores = os.cpu_count() or 1
             ns = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000")))
             try:
-                if os.path.exists(os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")) and \
+                if cpu_mode != "port" and os.path.exists(os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")) and \
                         "avx512bw" in open("/proc/cpuinfo").read():
                     cpu = cpu_baseline_reference(fwd, text, sa, l1, l2, reads[:ns], cores)
                 else:

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG, "libmeme_hip.so")
+LIB_PATH = os.environ.get("MEME_HIP_LIB") or os.path.join(PKG, "libmeme_hip.so")
 
 MEM_TL = np.dtype([("start", "<i4"), ("end", "<i4"), ("hitbeg", "<i4"), ("hitcount", "<i4"),
                    ("cache_refpos", "<u8")])

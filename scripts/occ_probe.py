@@ -14,8 +14,9 @@ ctx.load_index_host(pp.reshape(-1), text, l1, l2)
 reads = workload.make_reads_fast(g, n, 150, seed=12)
 d_reads = torch.from_numpy(reads.reshape(-1)).cuda(); d_off = torch.arange(0, (n + 1) * 150, 150, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
-for lanes in (8, 16):
-    for bpc in (1, 2, 4):
+bl = [int(x) for x in os.environ.get("BPC", "1,2,4").split(",")]
+for lanes in [int(x) for x in os.environ.get("LANES", "8,16").split(",")]:
+    for bpc in bl:
         ctx.set_tuning("group_lanes", lanes); ctx.set_tuning("seed_blocks_per_cu", bpc)
         for it in range(2):
             res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * 150, hipapi.default_seed_opt(rounds=3))
