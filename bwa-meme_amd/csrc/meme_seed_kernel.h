@@ -136,7 +136,11 @@ struct Res {
 
 // explicit address spaces: LDS (3) for the staged read, global (1) for the index.  Generic pointers would
 // compile to FLAT loads whose waits serialise LDS and HBM traffic.
+#ifndef CMP_WORDS
+#define CMP_WORDS 2          // reference words fetched per round trip once the 32-base key matched
+#endif
 typedef const __attribute__((address_space(3))) u64* lds_u64;
+typedef __attribute__((address_space(3))) int* lds_int;
 typedef const __attribute__((address_space(1))) u64* glb_u64;
 typedef const __attribute__((address_space(1))) SaEnt* glb_ent;
 typedef const __attribute__((address_space(1))) RmiRec* glb_rmi;
@@ -147,6 +151,12 @@ __device__ __forceinline__ u64 ext_l(lds_u64 w, int s) {
     return sh ? (a << sh) | (b >> (64 - sh)) : a;
 }
 
+// cold per-read state kept in LDS (group-uniform redundant stores; every lane reads back what it wrote)
+enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_R2_SAVED, ST_ZZ_NEXT, ST_ZZ_SP, ST_ZZ_GUARD, ST_AP_GUARD,
+                   ST_SM_BASE, ST_N_SMEMS, ST_HITS_LO, ST_HITS_HI, ST_SEARCHES, ST_FLAGS, ST_LAST_CNT_LO, ST_LAST_CNT_HI,
+                   ST_LAST_S_LO, ST_LAST_S_HI, ST_WORDS };
+enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2, F_REC = 4, F_LDS_OVF = 8 };
+
 template <int G>
 struct Grp {
     static constexpr u64 FULL = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
@@ -156,6 +166,7 @@ struct Grp {
     i64 n;
     int shift;
     lds_u64 fw, rc, nfw, nrc;
+    lds_int st;
     int t, gbase;
     unsigned windows;
 
@@ -181,17 +192,17 @@ __device__ __forceinline__ void cmp_entry(const Grp<G>& g, lds_u64 s, int off, i
         l = 32;
         if (l < L) {
             // All 32 key bases agree: the rest comes from the 2-bit text.  Consecutive words are adjacent in
-            // memory (same sector), so four are fetched per round trip instead of one dependent load per word.
+            // memory (same sector), so CMP_WORDS are fetched per round trip instead of one dependent load per word.
             const i64 p0 = (i64)epos + 32;
             glb_u64 pw = g.pac + (p0 >> 5);
             const int sh = (int)(p0 & 31) * 2;
             bool done = false;
-            for (int k = 1; !done; k += 4, pw += 4) {
-                u64 w[5];
+            for (int k = 1; !done; k += CMP_WORDS, pw += CMP_WORDS) {
+                u64 w[CMP_WORDS + 1];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) w[j] = pw[j];
+                for (int j = 0; j < CMP_WORDS + 1; ++j) w[j] = pw[j];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < CMP_WORDS; ++j) {
                     if (done) break;
                     u64 wr = sh ? (w[j] << sh) | (w[j + 1] >> (64 - sh)) : w[j];
                     u64 q = ext_l(s, off + 32 * (k + j));
@@ -420,7 +431,7 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     if (q.mode == 0) return out;
     if (q.mode == 2 && L < msl) return out;               // :1204-1208
     // interval at level L from the window; extended beyond it only when the run touches a window edge
-    i64 s_edge = base + c, e_edge = base + c, cur_lo = base, cur_hi = base + G - 1;
+    i64 s_edge = base + c, e_edge = base + c;
     int nb_lo = 0, nb_hi = 0;
     bool need_lo = false, need_hi = false;
     {
@@ -432,39 +443,44 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
             s_edge = base + hz + 1;
             nb_lo = g.shfl(lcp, hz);
         } else if (base == 0) s_edge = 0;
-        else need_lo = true;
+        else { need_lo = true; s_edge = base; }             // provisional: every slot of [base, c] matches
         if (za) {
             int lz = __ffsll((long long)za) - 1;
             e_edge = base + lz - 1;
             nb_hi = g.shfl(lcp, lz);
         } else if (base + G >= n) e_edge = n - 1;
-        else need_hi = true;
+        else { need_hi = true; e_edge = base + G - 1; }
     }
-    i64 last_s = s_edge, last_cnt = 0, cnt, emit_s = s_edge;
+    // third-round bookkeeping (previous level's interval) lives in LDS: rarely touched, 4 registers saved
+    i64 cnt, emit_s = s_edge;
     int match_len = L;
+    bool have_last = false;
     for (;;) {
-        if (need_lo) edge_down(g, s, off, L, cur_lo, s_edge, nb_lo);
-        if (need_hi) edge_up(g, s, off, L, cur_hi, e_edge, nb_hi);
+        if (need_lo) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
+        if (need_hi) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
         cnt = e_edge - s_edge + 1;
         const int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
         if (q.mode == 1) {                                  // (:2568-2573, :2936-2940)
             if (cnt >= (i64)q.min_intv) { emit_s = s_edge; match_len = L; break; }
         } else {
             if (cnt >= (i64)q.min_intv) {                   // :1243-1251
-                cnt = last_cnt ? last_cnt : cnt;
-                emit_s = last_s;
+                if (have_last) {
+                    cnt = ((i64)g.st[ST_LAST_CNT_HI] << 32) | (u64)(unsigned)g.st[ST_LAST_CNT_LO];
+                    emit_s = ((i64)g.st[ST_LAST_S_HI] << 32) | (u64)(unsigned)g.st[ST_LAST_S_LO];
+                } else emit_s = s_edge;
                 match_len = L + 1;
                 break;
             }
             if (nxt < msl) { match_len = msl; emit_s = s_edge; break; }   // :1252-1258
-            last_cnt = cnt;
-            last_s = s_edge;
+            have_last = true;
+            g.st[ST_LAST_CNT_LO] = (int)(unsigned)(cnt & 0xffffffffll);
+            g.st[ST_LAST_CNT_HI] = (int)(cnt >> 32);
+            g.st[ST_LAST_S_LO] = (int)(unsigned)(s_edge & 0xffffffffll);
+            g.st[ST_LAST_S_HI] = (int)(s_edge >> 32);
         }
         L = nxt;
         need_lo = nb_lo >= L && s_edge > 0;
         need_hi = nb_hi >= L && e_edge < n - 1;
-        cur_lo = s_edge;
-        cur_hi = e_edge;
     }
     if (q.mode == 2) {
         out.emit = cnt < (i64)q.min_intv;                  // :1265
@@ -497,7 +513,7 @@ __device__ __forceinline__ int first_n(lds_u64 mask, bool has_n, int from, int l
 // ---- the search kernel ---------------------------------------------------------------------------------------
 template <int G>
 #ifndef SEED_MIN_WAVES
-#define SEED_MIN_WAVES 4
+#define SEED_MIN_WAVES 5
 #endif
 __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -507,11 +523,14 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     const int stride = A.geo.stride, W = A.geo.W, MW = A.geo.MW;
     u64* rd = reinterpret_cast<u64*>(smem_raw) + (size_t)gib * stride;
     lds_u64 rdl = (lds_u64)rd;
-    int* ring = reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) + (size_t)gib * 3 * A.lcap;
-    int* sm_start = ring;
-    int* sm_end = ring + A.lcap;
-    int* sm_cnt = ring + 2 * A.lcap;
+    // per group after the packed read: the SMEM ring (3 ints per entry) and the cold part of the read's state
+    lds_int ring = (lds_int)(reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) + (size_t)gib * (3 * A.lcap + ST_WORDS));
+    lds_int sm_start = ring;
+    lds_int sm_end = ring + A.lcap;
+    lds_int sm_cnt = ring + 2 * A.lcap;
+    lds_int st = ring + 3 * A.lcap;
     Grp<G> g;
+    g.st = st;
     g.sa = (glb_ent)A.I.sa;
     g.pac = (glb_u64)A.I.pac;
     g.l2 = (glb_rmi)A.I.l2;
@@ -554,18 +573,15 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // ---- per-read state (group-uniform) ----------------------------------------------------------------
-        int pivot = 0, l_pivot = l_seq - 1;
+        int pivot = 0;
         int msl = A.opt.min_seed_len, min_intv = 1;
-        int n_smems = 0, sm_base = 0;
-        i64 n_hits = 0;
-        bool rec = false, lds_ovf = false;
-        unsigned searches = 0;
         g.windows = 0;
         int pc = PC_ALLPOS_TOP;
-        int before = 0, after = 0, r2_k = 0, r2_next = 0, r2_saved = 1;
-        int zz_next = 0, zz_sp = 0, zz_guard = 0, ap_guard = 0;
-        bool zz_check = false, zz_ret_onepos = false;
-#define SET_PIVOT(p_) do { pivot = (p_); l_pivot = l_seq - 1 - pivot; } while (0)
+        for (int k = 0; k < ST_WORDS; ++k) st[k] = 0;
+#define SET_PIVOT(p_) do { pivot = (p_); } while (0)
+#define l_pivot (l_seq - 1 - pivot)
+#define FLAG(f_) ((st[ST_FLAGS] & (f_)) != 0)
+#define SETFLAG(f_, v_) do { st[ST_FLAGS] = (v_) ? (st[ST_FLAGS] | (f_)) : (st[ST_FLAGS] & ~(f_)); } while (0)
         for (;;) {
             // ---- control: advance to the next search request -------------------------------------------------
             Req q;
@@ -573,13 +589,13 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             while (!have && pc != PC_DONE) {
                 switch (pc) {
                 case PC_ALLPOS_TOP:   // Learned_getSMEMsAllPosOneThread loop head (:916) + step1 entry (:1691-1723)
-                    if (pivot >= l_seq || ++ap_guard > 4 * l_seq + 16) { pc = PC_R3_INIT; break; }
-                    before = n_smems; sm_base = before; rec = true;
+                    if (pivot >= l_seq || ++st[ST_AP_GUARD] > 4 * l_seq + 16) { pc = PC_R3_INIT; break; }
+                    st[ST_BEFORE] = st[ST_N_SMEMS]; st[ST_SM_BASE] = st[ST_BEFORE]; SETFLAG(F_REC, true);
                     if (is_n(g.nfw, pivot)) {
                         if (l_seq - pivot < msl) SET_PIVOT(l_seq); else SET_PIVOT(pivot + 1);
                         pc = PC_AFTER_STEP1;
                     } else if (pivot != 0 && !is_n(g.nfw, pivot - 1)) {
-                        zz_next = l_seq; zz_check = true; zz_ret_onepos = false; zz_sp = pivot; zz_guard = 0;
+                        st[ST_ZZ_NEXT] = l_seq; SETFLAG(F_ZZ_CHECK, true); SETFLAG(F_ZZ_RET_ONEPOS, false); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
                         pc = PC_ZZ_TOP;
                     } else {
                         q.kind = K_S1_RIGHT; q.rc = false; q.off = pivot;
@@ -588,10 +604,10 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     }
                     break;
                 case PC_ZZ_TOP:       // zig-zag loop head (:1724-1737, :1969)
-                    if (zz_sp >= zz_next || ++zz_guard > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
-                    if (zz_check && is_n(g.nfw, zz_sp)) {
-                        if (l_seq - zz_sp < msl) { SET_PIVOT(l_seq); zz_sp = l_seq; }
-                        else { zz_sp += 1; SET_PIVOT(pivot + 1); }
+                    if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
+                    if (FLAG(F_ZZ_CHECK) && is_n(g.nfw, st[ST_ZZ_SP])) {
+                        if (l_seq - st[ST_ZZ_SP] < msl) { SET_PIVOT(l_seq); st[ST_ZZ_SP] = l_seq; }
+                        else { st[ST_ZZ_SP] += 1; SET_PIVOT(pivot + 1); }
                         break;
                     }
                     q.kind = K_ZZ_LEFT; q.rc = true; q.off = l_pivot;
@@ -605,23 +621,23 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     have = true;
                     break;
                 case PC_ZZ_END:       // set_forward_pivot(raux, next_pivot) (:1893, :2125)
-                    SET_PIVOT(zz_next);
-                    pc = zz_ret_onepos ? PC_R2_AFTER : PC_AFTER_STEP1;
+                    SET_PIVOT(st[ST_ZZ_NEXT]);
+                    pc = FLAG(F_ZZ_RET_ONEPOS) ? PC_R2_AFTER : PC_AFTER_STEP1;
                     break;
                 case PC_AFTER_STEP1:  // re-seeding loop entry (:921-923)
-                    rec = false;
-                    after = n_smems;
+                    SETFLAG(F_REC, false);
+                    st[ST_AFTER] = st[ST_N_SMEMS];
                     if (A.opt.rounds < 2) { pc = PC_ALLPOS_TOP; break; }
-                    if (lds_ovf) { pc = PC_DONE; break; }   // re-run in the next tier (bigger LDS ring)
-                    r2_k = before;
+                    if (FLAG(F_LDS_OVF)) { pc = PC_DONE; break; }   // re-run in the next tier (bigger LDS ring)
+                    st[ST_R2_K] = st[ST_BEFORE];
                     pc = PC_R2_LOOP;
                     break;
                 case PC_R2_LOOP: {    // (:923-947) + OnePos entry (:1917-1930)
-                    if (r2_k >= after) { pc = PC_ALLPOS_TOP; break; }
-                    const int k = r2_k++ - before;
-                    r2_next = pivot; r2_saved = min_intv;
+                    if (st[ST_R2_K] >= st[ST_AFTER]) { pc = PC_ALLPOS_TOP; break; }
+                    const int k = st[ST_R2_K]++ - st[ST_BEFORE];
+                    st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
                     const int qbeg = sm_start[k], qend = sm_end[k], cnt = sm_cnt[k];
-                    if (qend - qbeg < A.opt.split_len || cnt > A.opt.split_width) { SET_PIVOT(r2_next); break; }
+                    if (qend - qbeg < A.opt.split_len || cnt > A.opt.split_width) { SET_PIVOT(st[ST_R2_NEXT]); break; }
                     SET_PIVOT((qbeg + qend) >> 1);
                     min_intv = cnt + 1;
                     if (is_n(g.nfw, pivot)) {
@@ -640,12 +656,12 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     break;
                 }
                 case PC_R2_AFTER:     // (:945-946)
-                    min_intv = r2_saved;
-                    SET_PIVOT(r2_next);
+                    min_intv = st[ST_R2_SAVED];
+                    SET_PIVOT(st[ST_R2_NEXT]);
                     pc = PC_R2_LOOP;
                     break;
                 case PC_R3_INIT:      // src/bwamem.cpp:1385-1394
-                    if (A.opt.rounds >= 3 && A.opt.max_mem_intv > 0 && !lds_ovf) {
+                    if (A.opt.rounds >= 3 && A.opt.max_mem_intv > 0 && !FLAG(F_LDS_OVF)) {
                         min_intv = A.opt.max_mem_intv;
                         msl = A.opt.min_seed_len + 1;
                         SET_PIVOT(0);
@@ -666,7 +682,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             }
             if (!have) break;
             // ---- the single search call site ----------------------------------------------------------------------
-            ++searches;
+            st[ST_SEARCHES] = st[ST_SEARCHES] + 1;
             const Res r = do_search(g, q, msl);
             // ---- apply -------------------------------------------------------------------------------------------
             bool emit = false;
@@ -677,13 +693,13 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                 break;
             case K_ZZ_LEFT:           // (:1774-1777)
                 SET_PIVOT(pivot - r.L + 1);
-                pc = (zz_next - pivot < msl) ? PC_ZZ_END : PC_ZZ_RIGHT;
+                pc = (st[ST_ZZ_NEXT] - pivot < msl) ? PC_ZZ_END : PC_ZZ_RIGHT;
                 break;
             case K_ZZ_RIGHT:          // (:1846-1848)
                 emit = r.L >= msl; e_end = pivot + r.L;
                 break;
             case K_OP_MEM:            // (:1967-1969)
-                zz_next = pivot + r.L; zz_check = false; zz_ret_onepos = true; zz_sp = pivot; zz_guard = 0;
+                st[ST_ZZ_NEXT] = pivot + r.L; SETFLAG(F_ZZ_CHECK, false); SETFLAG(F_ZZ_RET_ONEPOS, true); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
                 pc = PC_ZZ_TOP;
                 break;
             case K_OP_SMEM:           // (:2093-2125)
@@ -695,42 +711,50 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                 break;
             }
             if (emit) {               // kv_push of mem_tl + hits (:2639-2657, :1266-1277)
-                if (n_smems < cap && g.t == 0) {
+                if (st[ST_N_SMEMS] < cap && g.t == 0) {
                     SlotRec sr;
                     sr.start = e_start; sr.end = e_end; sr.sa_start = r.start; sr.count = r.count;
-                    slots[n_smems] = sr;
+                    slots[st[ST_N_SMEMS]] = sr;
                 }
-                if (rec) {
-                    const int k = n_smems - sm_base;
+                if (FLAG(F_REC)) {
+                    const int k = st[ST_N_SMEMS] - st[ST_SM_BASE];
                     if (k < lcap) {
                         // group-uniform redundant LDS stores (every lane writes the same value): no hand-off needed
                         sm_start[k] = e_start;
                         sm_end[k] = e_end;
                         sm_cnt[k] = r.count > (i64)INT_MAX ? INT_MAX : (int)r.count;
-                    } else lds_ovf = true;
+                    } else SETFLAG(F_LDS_OVF, true);
                 }
-                ++n_smems;
+                st[ST_N_SMEMS] = st[ST_N_SMEMS] + 1;
                 i64 h = r.count;
                 if (hits_per_smem > 0 && h > hits_per_smem) h = hits_per_smem;
-                n_hits += h;
+                h += ((i64)st[ST_HITS_HI] << 32) | (u64)(unsigned)st[ST_HITS_LO];
+                st[ST_HITS_LO] = (int)(unsigned)(h & 0xffffffffll);
+                st[ST_HITS_HI] = (int)(h >> 32);
             }
             switch (q.kind) {
             case K_S1_RIGHT: SET_PIVOT(pivot + r.L); pc = PC_AFTER_STEP1; break;
-            case K_ZZ_RIGHT: zz_sp = pivot + r.L; SET_PIVOT(zz_sp); pc = PC_ZZ_TOP; break;
+            case K_ZZ_RIGHT: st[ST_ZZ_SP] = pivot + r.L; SET_PIVOT(st[ST_ZZ_SP]); pc = PC_ZZ_TOP; break;
             case K_OP_SMEM: SET_PIVOT(pivot + r.L); pc = PC_R2_AFTER; break;
             case K_R3: SET_PIVOT(pivot + (r.L < msl ? msl : r.L)); pc = PC_R3_TOP; break;
             default: break;
             }
         }
 #undef SET_PIVOT
+#undef l_pivot
         if (g.t == 0) {
-            const bool ovf = n_smems > cap || lds_ovf;
+            const int n_smems = st[ST_N_SMEMS];
+            const unsigned searches = (unsigned)st[ST_SEARCHES];
+            const i64 n_hits = ((i64)st[ST_HITS_HI] << 32) | (u64)(unsigned)st[ST_HITS_LO];
+            const bool ovf = n_smems > cap || FLAG(F_LDS_OVF);
             A.slot_cnt[rid] = ovf ? 0 : n_smems;
             A.slot_hits[rid] = ovf ? 0 : n_hits;
             A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
             if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
             else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], (unsigned long long)g.windows); }
         }
+#undef FLAG
+#undef SETFLAG
         __builtin_amdgcn_wave_barrier();
     }
 }
