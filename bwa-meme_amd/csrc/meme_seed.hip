@@ -182,8 +182,6 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-    const int G = (int)ctx->group_lanes;
-    const int groups = BLOCK / G;
     float ms_total = 0.f;
     i64 launches = 0, searches = 0, windows = 0;
     TierTable tiers;
@@ -191,6 +189,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     i64 n_todo = nreads;
     const i64* pending = nullptr;
     for (int tier = 0;; ++tier) {
+        // overflow tiers hold a 512-entry SMEM ring per read in LDS: run them 32 lanes per read (8 reads per block)
+        const int G = tier == 0 ? (int)ctx->group_lanes : 32;
+        const int groups = BLOCK / G;
         const int cap = tier == 0 ? (int)ctx->smem_cap : TIER_CAP[tier];
         const int lcap = cap < TIER_LCAP[tier] ? cap : TIER_LCAP[tier];
         DevBuf& sb = ctx->slots[tier];
