@@ -9,10 +9,11 @@
 // exits (:206-216) and the max/gscore tie rules (:188-189, :202-205) are evaluated per row, and the
 // H/E array keeps *stale* cells outside the band that are read again when the band re-grows.  An
 // anti-diagonal sweep would have to replay those row-granular decisions anyway.  Instead each row is
-// computed across the 64 lanes of one wavefront: the only in-row dependency, the F (insertion) chain
+// computed across the LP lanes that own a pair (LP = 16 / 32 / 64 by query-length class, so 4 / 2 / 1 pairs
+// share a wavefront): the only in-row dependency, the F (insertion) chain
 //   F(i,j+1) = max(0, M(i,j)-oe_ins, F(i,j)-e_ins)
 // is a max-plus prefix scan, F(i,j) = max(0, max_{k<j}(M(i,k) + k*e_ins) - oe_ins - (j-1)*e_ins),
-// done with wavefront shuffles.  H/E rows and the query live in LDS for the whole pair; the
+// done with sub-wavefront shuffles.  H/E rows and the query live in LDS for the whole pair; the
 // reference window streams through registers.  Integer max-plus recurrences: MFMA does not apply.
 #include <limits.h>
 #include <string.h>
@@ -21,44 +22,53 @@
 
 namespace {
 
-constexpr int BSW_BLOCK = 256;            // 4 wavefronts = 4 pairs in flight per workgroup
-constexpr int WAVES = BSW_BLOCK / 64;
+constexpr int BSW_BLOCK = 256;            // 4 wavefronts = 4..16 pairs in flight per workgroup
 constexpr int NEG = -(1 << 29);
 
 struct BswArgs {
     meme_seqpair* pairs;
     const uint8_t* ref;
     const uint8_t* qer;
-    int npairs;
+    const int* order;        // pair indices of this length class
+    int npairs;              // pairs in this class
     int w;
     meme_bsw_opt o;
-    int qmax;                // LDS columns per wave (multiple of 64)
+    int qmax;                // LDS columns per pair (multiple of LP)
     unsigned int* ticket;
 };
 
-__device__ __forceinline__ int wave_incl_max(int v, int lane) {
+// LP lanes cooperate on one pair (64/LP pairs per wavefront): short extensions -- the common case, since most
+// reads carry one long SMEM -- would leave most of a 64-lane wavefront idle.
+template <int LP>
+__device__ __forceinline__ int grp_incl_max(int v, int gl) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(v, d);
-        if (lane >= d) v = v > y ? v : y;
+    for (int d = 1; d < LP; d <<= 1) {
+        int y = __shfl_up(v, d, LP);
+        if (gl >= d) v = v > y ? v : y;
     }
     return v;
 }
 
-__device__ __forceinline__ long long wave_max64(long long v) {
+template <int LP>
+__device__ __forceinline__ long long grp_max64(long long v) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        long long y = __shfl_xor(v, d);
+    for (int d = LP / 2; d >= 1; d >>= 1) {
+        long long y = __shfl_xor(v, d, LP);
         v = v > y ? v : y;
     }
     return v;
 }
 
+template <int LP>
 __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const size_t per_wave = (size_t)(A.qmax + 2) * 8 + (size_t)A.qmax;
-    int* H = reinterpret_cast<int*>(lds_raw + per_wave * wid);
+    constexpr u64 GMASK = LP == 64 ? ~0ull : ((1ull << LP) - 1ull);
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (LP - 1);              // lane within the pair's group
+    const int gbase = lane - gl;
+    const int gid = threadIdx.x / LP;            // group within the workgroup
+    const size_t per_grp = (size_t)(A.qmax + 2) * 8 + (size_t)((A.qmax + 7) & ~7);
+    int* H = reinterpret_cast<int*>(lds_raw + per_grp * gid);
     int* E = H + (A.qmax + 2);
     uint8_t* Q = reinterpret_cast<uint8_t*>(E + (A.qmax + 2));
     const int o_del = A.o.o_del, e_del = A.o.e_del, o_ins = A.o.o_ins, e_ins = A.o.e_ins;
@@ -66,27 +76,26 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
     const int sa = A.o.a, sb = -A.o.b;
 
     for (;;) {
-        unsigned int pi = 0;
-        if (lane == 0) pi = atomicAdd(A.ticket, 1u);
-        pi = __shfl(pi, 0);
-        if (pi >= (unsigned)A.npairs) break;
-        meme_seqpair* P = &A.pairs[pi];
+        unsigned int tk = 0;
+        if (gl == 0) tk = atomicAdd(A.ticket, 1u);
+        tk = __shfl(tk, 0, LP);
+        if (tk >= (unsigned)A.npairs) break;
+        meme_seqpair* P = &A.pairs[A.order ? A.order[tk] : (int)tk];
         const int qlen = P->len2, tlen = P->len1, h0 = P->h0;
         const uint8_t* query = A.qer + P->idq;
         const uint8_t* target = A.ref + P->idr;
-        if (qlen > A.qmax || qlen < 0 || tlen < 0) {      // cannot happen: the host sizes qmax from the batch
-            if (lane == 0) { P->score = INT_MIN; P->qle = P->tle = P->gtle = P->gscore = P->max_off = -1; }
+        if (qlen > A.qmax || qlen < 0 || tlen < 0) {      // cannot happen: the host sizes qmax per class
+            if (gl == 0) { P->score = INT_MIN; P->qle = P->tle = P->gtle = P->gscore = P->max_off = -1; }
             continue;
         }
         // ---- first row (:143-145) and query staging ---------------------------------------------------
-        for (int j = lane; j <= qlen + 1; j += 64) {
+        for (int j = gl; j <= qlen + 1; j += LP) {
             int v = 0;
             if (j == 0) v = h0;
             else if (j <= qlen) {
                 // eh[1] = max(h0-oe_ins,0); eh[j] = eh[j-1]-e_ins while eh[j-1] > e_ins
                 int first = h0 > oe_ins ? h0 - oe_ins : 0;
                 int x = first - (j - 1) * e_ins;
-                // cell j is filled iff every predecessor 1..j-1 was > e_ins, i.e. eh[j-1] > e_ins
                 int prev = first - (j - 2) * e_ins;
                 v = (j == 1) ? first : (prev > e_ins ? x : 0);
             }
@@ -110,10 +119,10 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
         int beg = 0, end = qlen;
-        int tchunk = 0;                 // lane k holds target[64*(i/64) + k]: one coalesced load per 64 rows
+        int tchunk = 0;                 // lane k of the group holds target[LP*(i/LP) + k]
         for (int i = 0; i < tlen; ++i) {
-            if ((i & 63) == 0) tchunk = (i + lane < tlen) ? target[i + lane] : 4;
-            const int tb = __shfl(tchunk, i & 63);
+            if ((i & (LP - 1)) == 0) tchunk = (i + gl < tlen) ? target[i + gl] : 4;
+            const int tb = __shfl(tchunk, i & (LP - 1), LP);
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
@@ -123,8 +132,8 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
             int carry_g = NEG;          // running max of M(k) - oe_ins + k*e_ins over finished chunks
             int left_h = h1;            // H(i, j0-1) for the first column of the chunk
             long long best = -1;        // (m << 32) | mj, rightmost column among equal maxima
-            for (int j0 = beg; j0 < end; j0 += 64) {
-                const int j = j0 + lane;
+            for (int j0 = beg; j0 < end; j0 += LP) {
+                const int j = j0 + gl;
                 const bool act = j < end;
                 int M = NEG, e = 0;
                 if (act) {
@@ -135,16 +144,16 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
                     M = M ? M + sc : 0;   // :184
                 }
                 int g = act ? M - oe_ins + j * e_ins : NEG;
-                int gi = wave_incl_max(g, lane);
-                int gx = __shfl_up(gi, 1);
-                if (lane == 0) gx = NEG;
+                int gi = grp_incl_max<LP>(g, gl);
+                int gx = __shfl_up(gi, 1, LP);
+                if (gl == 0) gx = NEG;
                 gx = gx > carry_g ? gx : carry_g;
                 int f = gx - (j - 1) * e_ins;
                 if (f < 0 || gx == NEG) f = 0;
                 int h = M > e ? M : e;
                 h = h > f ? h : f;
-                int hl = __shfl_up(h, 1);
-                if (lane == 0) hl = left_h;
+                int hl = __shfl_up(h, 1, LP);
+                if (gl == 0) hl = left_h;
                 if (act) {
                     H[j] = hl;                             // H(i,j-1) for the next row (:183)
                     int t = M - oe_del;
@@ -155,16 +164,16 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
                     long long key = ((long long)h << 32) | (unsigned)j;
                     best = best > key ? best : key;
                 }
-                const int nact = end - j0 < 64 ? end - j0 : 64;
-                left_h = __shfl(h, nact - 1);
-                int cg = __shfl(gi, 63);
+                const int nact = end - j0 < LP ? end - j0 : LP;
+                left_h = __shfl(h, nact - 1, LP);
+                int cg = __shfl(gi, LP - 1, LP);
                 carry_g = carry_g > cg ? carry_g : cg;
             }
-            best = wave_max64(best);
+            best = grp_max64<LP>(best);
             int m = 0, mj = -1;
             if (best >= 0) { m = (int)(best >> 32); mj = (int)(best & 0xffffffffll); }
             h1 = left_h;
-            if (lane == 0) { H[end] = h1; E[end] = 0; }    // :201
+            if (gl == 0) { H[end] = h1; E[end] = 0; }      // :201
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -187,23 +196,23 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
             }
             // band trimming (:217-221): drop leading / trailing columns whose H and E are both zero
             int nbeg = end;
-            for (int j0 = beg; j0 < end; j0 += 64) {
-                const int j = j0 + lane;
+            for (int j0 = beg; j0 < end; j0 += LP) {
+                const int j = j0 + gl;
                 bool nz = j < end && ((H[j] | E[j]) != 0);
-                u64 b = __ballot(nz);
+                u64 b = (__ballot(nz) >> gbase) & GMASK;
                 if (b) { nbeg = j0 + __ffsll((long long)b) - 1; break; }
             }
             int jl = nbeg - 1;
-            for (int hi = end; hi >= nbeg; hi -= 64) {
-                const int j = hi - 63 + lane;
+            for (int hi = end; hi >= nbeg; hi -= LP) {
+                const int j = hi - (LP - 1) + gl;
                 bool nz = j >= nbeg && j <= hi && ((H[j] | E[j]) != 0);
-                u64 b = __ballot(nz);
-                if (b) { jl = hi - 63 + (63 - __clzll((long long)b)); break; }
+                u64 b = (__ballot(nz) >> gbase) & GMASK;
+                if (b) { jl = hi - (LP - 1) + (63 - __clzll((long long)b)); break; }
             }
             beg = nbeg;
             end = jl + 2 < qlen ? jl + 2 : qlen;
         }
-        if (lane == 0) {
+        if (gl == 0) {
             P->score = max;
             P->qle = max_j + 1;
             P->tle = max_i + 1;
@@ -215,35 +224,74 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
     }
 }
 
-int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w,
-               const meme_bsw_opt* opt, int max_qlen) {
-    if (opt->e_ins <= 0 || opt->e_del <= 0) { meme_set_error("gap extension penalties must be positive"); return MEME_E_ARG; }
-    int qmax = ((max_qlen + 63) / 64) * 64;
-    if (qmax < 64) qmax = 64;
-    size_t per_wave = (size_t)(qmax + 2) * 8 + (size_t)qmax;
-    size_t lds = per_wave * WAVES;
+// length classes (the reference sorts pairs into int8 / int16 / scalar classes for its SIMD lanes,
+// sortPairsLenExt src/bwamem.cpp:2430-2527; here the class only decides how many lanes share a pair)
+constexpr int N_CLS = 3;
+constexpr int CLS_LIMIT[N_CLS] = {16, 32, 1 << 30};
+
+__global__ void __launch_bounds__(256) k_bsw_classify(const meme_seqpair* __restrict__ pairs, int n, int* __restrict__ order,
+                                                       int* __restrict__ cnt, int* __restrict__ maxq) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int q = pairs[i].len2;
+    const int c = q <= CLS_LIMIT[0] ? 0 : (q <= CLS_LIMIT[1] ? 1 : 2);
+    const int slot = atomicAdd(&cnt[c], 1);
+    order[(size_t)c * n + slot] = i;
+    if (c == 2) atomicMax(maxq, q);
+}
+
+template <int LP>
+int launch_cls(meme_ctx* ctx, BswArgs A, int qmax, i64 dev_cus) {
+    constexpr int GROUPS = BSW_BLOCK / LP;
+    size_t per_grp = (size_t)(qmax + 2) * 8 + (size_t)((qmax + 7) & ~7);
+    size_t lds = per_grp * GROUPS;
     if (lds > 160 * 1024) {
-        meme_set_error("query of %d bases exceeds the LDS-resident limit of this build", max_qlen);
+        meme_set_error("query of %d bases exceeds the LDS-resident limit of this build", qmax);
         return MEME_E_ARG;
     }
-    int rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 4 * sizeof(unsigned long long)))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
-    int dev_cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
-    i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : (i64)dev_cus * 4;
-    i64 want = (npairs + WAVES - 1) / WAVES;
+    i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 4;
+    i64 want = (A.npairs + GROUPS - 1) / GROUPS;
     if (blocks > want) blocks = want;
     if (blocks < 1) blocks = 1;
     if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_bsw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    BswArgs A;
-    A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.npairs = npairs; A.w = w; A.o = *opt; A.qmax = qmax;
-    A.ticket = (unsigned int*)ctx->counters.p;
-    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
-    hipLaunchKernelGGL(k_bsw, dim3((unsigned)blocks), dim3(BSW_BLOCK), lds, ctx->stream, A);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bsw<LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    A.qmax = qmax;
+    hipLaunchKernelGGL(k_bsw<LP>, dim3((unsigned)blocks), dim3(BSW_BLOCK), lds, ctx->stream, A);
     HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
+int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w,
+               const meme_bsw_opt* opt) {
+    if (opt->e_ins <= 0 || opt->e_del <= 0) { meme_set_error("gap extension penalties must be positive"); return MEME_E_ARG; }
+    int rc;
+    // counters: [0..2] class counts, [3] max qlen of the long class, [4..6] tickets
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 8 * sizeof(int) + 64))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->bsw_order, (size_t)N_CLS * npairs * sizeof(int)))) return rc;
+    int* cnt = (int*)ctx->counters.p;
+    HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    hipLaunchKernelGGL(k_bsw_classify, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pairs, npairs,
+                       (int*)ctx->bsw_order.p, cnt, cnt + 3);
+    HIP_TRY(hipGetLastError());
+    int h[4];
+    HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    i64 dev_cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+    BswArgs A;
+    A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
+    for (int c = 0; c < N_CLS; ++c) {
+        if (h[c] == 0) continue;
+        A.order = (const int*)ctx->bsw_order.p + (size_t)c * npairs;
+        A.npairs = h[c];
+        A.ticket = (unsigned int*)(cnt + 4 + c);
+        if (c == 0) rc = launch_cls<16>(ctx, A, 16, dev_cus);
+        else if (c == 1) rc = launch_cls<32>(ctx, A, 32, dev_cus);
+        else rc = launch_cls<64>(ctx, A, ((h[3] + 63) / 64) * 64, dev_cus);
+        if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -253,13 +301,6 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     return MEME_OK;
 }
 
-__global__ void k_max_qlen(const meme_seqpair* pairs, int n, int* out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int v = i < n ? pairs[i].len2 : 0;
-    for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(v, d); v = v > y ? v : y; }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
-}
-
 }  // namespace
 
 extern "C" int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer,
@@ -267,15 +308,7 @@ extern "C" int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const
     if (!ctx || !d_pairs || !d_ref || !d_qer || !opt || npairs < 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (npairs == 0) return MEME_OK;
-    int rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, 64))) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->scan_tmp.p, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_max_qlen, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pairs, npairs,
-                       (int*)ctx->scan_tmp.p);
-    int max_q = 0;
-    HIP_TRY(hipMemcpyAsync(&max_q, ctx->scan_tmp.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return launch_bsw(ctx, d_pairs, d_ref, d_qer, npairs, w, opt, max_q);
+    return launch_bsw(ctx, d_pairs, d_ref, d_qer, npairs, w, opt);
 }
 
 extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t* ref_buf, int64_t ref_bytes,
@@ -283,7 +316,6 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
     if (!ctx || !pairs || !ref_buf || !qer_buf || !opt || npairs < 0 || ref_bytes < 0 || qer_bytes < 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (npairs == 0) return MEME_OK;
-    int max_q = 0;
     for (int i = 0; i < npairs; ++i) {
         const meme_seqpair& p = pairs[i];
         if (p.len1 < 0 || p.len2 < 0 || p.idr < 0 || p.idq < 0 || (int64_t)p.idr + p.len1 > ref_bytes ||
@@ -291,7 +323,6 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
             meme_set_error("pair %d addresses bytes outside the sequence buffers", i);
             return MEME_E_ARG;
         }
-        if (p.len2 > max_q) max_q = p.len2;
     }
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->pairs, (size_t)npairs * sizeof(meme_seqpair)))) return rc;
@@ -301,7 +332,7 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
     HIP_TRY(hipMemcpyAsync(ctx->refb.p, ref_buf, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->qerb.p, qer_buf, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_bsw(ctx, (meme_seqpair*)ctx->pairs.p, (const uint8_t*)ctx->refb.p, (const uint8_t*)ctx->qerb.p, npairs, w,
-                    opt, max_q);
+                    opt);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pairs, ctx->pairs.p, (size_t)npairs * sizeof(meme_seqpair), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -49,7 +49,7 @@ struct meme_ctx {
     std::vector<void*> owned;          // device allocations of the index
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed;
+           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order;
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
     i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch (tier 0)

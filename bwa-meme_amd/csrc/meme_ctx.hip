@@ -65,7 +65,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
-                      &ctx->packed};
+                      &ctx->packed, &ctx->bsw_order};
     for (DevBuf* b : bufs) free_buf(*b);
     if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);

@@ -456,8 +456,38 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     int match_len = L;
     bool have_last = false;
     for (;;) {
-        if (need_lo) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
-        if (need_hi) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
+        // Lower levels usually still end inside the first window, whose LCPs (computed against the whole query)
+        // are still in registers: resolve the edge from them and touch memory only when the run leaves the window.
+        if (need_lo) {
+            bool solved = false;
+            if (s_edge > base && s_edge <= base + G) {
+                const int ncur = (int)(s_edge - base);          // lanes [0,ncur) lie below the current edge
+                const u64 z = (~g.ballot(lcp >= L)) & ((1ull << ncur) - 1ull);
+                if (z) {
+                    const int hz = 63 - __clzll((long long)z);
+                    s_edge = base + hz + 1;
+                    nb_lo = g.shfl(lcp, hz);
+                    solved = true;
+                } else if (base == 0) { s_edge = 0; nb_lo = 0; solved = true; }
+                else s_edge = base;
+            }
+            if (!solved) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
+        }
+        if (need_hi) {
+            bool solved = false;
+            if (e_edge >= base - 1 && e_edge < base + G - 1) {
+                const int first = (int)(e_edge + 1 - base);      // lanes [first,G) lie above the current edge
+                const u64 z = (~g.ballot(lcp >= L)) & Grp<G>::FULL & ~((1ull << first) - 1ull);
+                if (z) {
+                    const int lz = __ffsll((long long)z) - 1;
+                    e_edge = base + lz - 1;
+                    nb_hi = g.shfl(lcp, lz);
+                    solved = true;
+                } else if (base + G >= n) { e_edge = n - 1; nb_hi = 0; solved = true; }
+                else e_edge = base + G - 1;
+            }
+            if (!solved) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
+        }
         cnt = e_edge - s_edge + 1;
         const int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
         if (q.mode == 1) {                                  // (:2568-2573, :2936-2940)
