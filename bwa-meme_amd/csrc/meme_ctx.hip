@@ -100,13 +100,14 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     return MEME_OK;
 }
 
+static unsigned stage_blocks(i64 items);
 // ---- staging kernels ---------------------------------------------------------------------------------
 extern "C" int64_t meme_index_pac64_words(int64_t sa_num) { return ((sa_num + 31) >> 5) + 8; }
 
 // one thread per output word: 32 text bytes -> one u64, first base in the top bits; T past the end
 __global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ text, i64 n, u64* __restrict__ pac, i64 words) {
-    i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= words) return;
+  // grid-stride: a launch cannot carry more than 2^32 work-items, a GRCh38-sized index has 6.4 G slots
+  for (i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (i64)gridDim.x * blockDim.x) {
     i64 base = w << 5;
     u64 v = 0;
     if (base + 32 <= n) {
@@ -127,12 +128,12 @@ __global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ t
         }
     }
     pac[w] = v;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_build_entries(const uint8_t* __restrict__ pos_packed, const u64* __restrict__ sa_u64,
                                                         i64 n, const u64* __restrict__ pac, SaEnt* __restrict__ ent) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
     u64 pos;
     if (sa_u64) pos = sa_u64[i];
     else {
@@ -143,13 +144,14 @@ __global__ void __launch_bounds__(256) k_build_entries(const uint8_t* __restrict
     e.key = extract32(pac, (i64)pos);   // the pad words make this "T-filled past the text end"
     e.pos = pos;
     ent[i] = e;
+  }
 }
 
 extern "C" int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text, int64_t n, void* d_pac64) {
     if (!ctx || !d_text || !d_pac64 || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     i64 words = meme_index_pac64_words(n);
-    hipLaunchKernelGGL(k_pack_text, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_text, n,
+    hipLaunchKernelGGL(k_pack_text, dim3(stage_blocks(words)), dim3(256), 0, ctx->stream, d_text, n,
                        (u64*)d_pac64, words);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
@@ -159,7 +161,7 @@ extern "C" int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_pack
                                         void* d_sa_ent) {
     if (!ctx || !d_pos_packed || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_build_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_pos_packed,
+    hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream, d_pos_packed,
                        (const u64*)nullptr, n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
@@ -169,13 +171,19 @@ extern "C" int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, i
                                           void* d_sa_ent) {
     if (!ctx || !d_sa || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_build_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream,
                        (const uint8_t*)nullptr, (const u64*)d_sa, n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
 }
 
 // ---- index objects ------------------------------------------------------------------------------------
+static unsigned stage_blocks(i64 items) {
+    i64 b = (items + 255) / 256;
+    const i64 cap = 256 * 64;           // 64 workgroups per CU, grid-stride beyond that
+    return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap);
+}
+
 static int set_rmi(meme_ctx* ctx, i64 l2_records, i64 l1_records) {
     if (l2_records <= 0 || (l2_records & (l2_records - 1)) != 0) {
         // learned_index_load() requires num_model to be a power of two (src/LearnedIndex_seeding.cpp:113-119)

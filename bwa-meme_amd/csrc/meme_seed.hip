@@ -176,8 +176,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     if ((rc = meme_buf_reserve(ctx, ctx->packed, (size_t)nreads * geo.stride * 8))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
     {
-        i64 threads = nreads * geo.stride;
-        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_reads,
+        i64 threads = nreads * geo.stride, pblocks = (threads + 255) / 256;
+        if (pblocks > (i64)dev_cus * 64) pblocks = (i64)dev_cus * 64;   // grid-stride beyond that
+        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)pblocks), dim3(256), 0, ctx->stream, d_reads,
                            d_read_off, nreads, geo, (u64*)ctx->packed.p);
         HIP_TRY(hipGetLastError());
     }

@@ -77,9 +77,8 @@ struct SeedArgs {
 // one thread per output u64.  Layout per read: fw[W] rc[W] nfw[MW] nrc[MW].
 __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ reads, const i64* __restrict__ read_off,
                                                      i64 nreads, PackGeom g, u64* __restrict__ out) {
-    i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  for (i64 gid = (i64)blockIdx.x * blockDim.x + threadIdx.x; gid < nreads * g.stride; gid += (i64)gridDim.x * blockDim.x) {
     i64 r = gid / g.stride;
-    if (r >= nreads) return;
     int k = (int)(gid - r * g.stride);
     const i64 ro = read_off[r];
     int len = (int)(read_off[r + 1] - ro);
@@ -111,6 +110,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
         }
     }
     out[gid] = v;
+  }
 }
 
 // ---- per-read state ------------------------------------------------------------------------------------
