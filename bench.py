@@ -10,9 +10,14 @@ all three rounds, hit gather included) over one batch of synthetic 150-bp reads 
 in HBM.  Reads shard across ranks with no data-path collective (weak scaling: every GPU gets its own
 batch); the index is built once by rank 0 and broadcast over RCCL.  One JSON line is printed by rank 0.
 
-Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 128), MEME_BENCH_READS (reads
-per GPU per step, default 2,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's
-rule), MEME_BENCH_CPU (0 disables the CPU-baseline leg), MEME_BENCH_CPU_READS (sample size, default 2M).
+Default workload = BASELINE.json configs[1]: a GRCh38-sized (3.1 Gbp) synthetic genome -- 6.2 G suffixes, 99 GB of
+suffix-array entries in HBM -- and 10 M synthetic 150-bp single-end reads per GPU per step, seeding only.  The index
+is built on the host (about 4-6 minutes on the 256-thread box) and cached in /dev/shm for the next invocation.
+
+Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 3100), MEME_BENCH_READS (reads per GPU
+per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's rule),
+MEME_BENCH_LANES (lanes per read in the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the compiled
+reference up to 1 Gbp, the restated port above), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables).
 """
 import argparse
 import json
@@ -132,9 +137,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    mbp = float(os.environ.get("MEME_BENCH_MBP", "128"))
-    nreads = int(os.environ.get("MEME_BENCH_READS", "2000000"))
+    mbp = float(os.environ.get("MEME_BENCH_MBP", "3100"))
+    nreads = int(os.environ.get("MEME_BENCH_READS", "10000000"))
     bits = int(os.environ.get("MEME_BENCH_BITS", "0"))
+    # host RAM guard: the builder needs ~45 B per suffix (rank 0 only); shrink the genome rather than die
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        while mbp > 64 and 2 * mbp * 1e6 * 45 > 0.8 * avail:
+            mbp /= 2
+            log("host RAM too small for the configured genome: falling back to %.0f Mbp" % mbp)
+    except ImportError:
+        pass
+    gpu_free = torch.cuda.mem_get_info(local)[0]
+    while mbp > 64 and 2 * mbp * 1e6 * 28 + nreads * 2200 > 0.9 * gpu_free:
+        mbp /= 2
+        log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
     l_pac = int(mbp * 1e6) & ~1
     n = 2 * l_pac
 
@@ -144,10 +162,31 @@ def main():
     if rank == 0:
         t0 = time.time()
         fwd = synth.make_genome(l_pac, seed=11)
-        text, sa = hostapi.build_sa(fwd)
-        l1, l2 = hostapi.train_prmi(text, sa, bits=bits)
-        log("genome %.0f Mbp: suffix array + P-RMI (2^%d leaves, %d partial) built on host in %.1f s"
-            % (l_pac / 1e6, int(np.log2(l2.shape[0])), l1.shape[0], time.time() - t0))
+        cache = None
+        if os.environ.get("MEME_BENCH_CACHE", "1") != "0" and os.path.isdir("/dev/shm"):
+            cache = "/dev/shm/meme_bench_idx_%d_b%d" % (l_pac, bits)
+        if cache and os.path.exists(cache + ".ok"):
+            text = np.fromfile(cache + ".text", dtype=np.uint8)
+            sa = np.fromfile(cache + ".sa", dtype=np.uint64)
+            l1 = np.fromfile(cache + ".l1", dtype=hostapi.RMI_DTYPE)
+            l2 = np.fromfile(cache + ".l2", dtype=hostapi.RMI_DTYPE)
+            log("genome %.0f Mbp: index loaded from the /dev/shm cache in %.1f s" % (l_pac / 1e6, time.time() - t0))
+        else:
+            text, sa = hostapi.build_sa(fwd)
+            l1, l2 = hostapi.train_prmi(text, sa, bits=bits)
+            log("genome %.0f Mbp: suffix array + P-RMI (2^%d leaves, %d partial) built on host in %.1f s"
+                % (l_pac / 1e6, int(np.log2(l2.shape[0])), l1.shape[0], time.time() - t0))
+            if cache:
+                try:
+                    import glob
+                    for old in glob.glob("/dev/shm/meme_bench_idx_*"):
+                        if not old.startswith(cache + "."):
+                            os.remove(old)
+                    if shutil.disk_usage("/dev/shm").free > 1.2 * (text.nbytes + sa.nbytes + l1.nbytes + l2.nbytes):
+                        text.tofile(cache + ".text"); sa.tofile(cache + ".sa"); l1.tofile(cache + ".l1"); l2.tofile(cache + ".l2")
+                        open(cache + ".ok", "w").write("ok")
+                except OSError as e:
+                    log("index cache not written: %r" % (e,))
         meta[0], meta[1], meta[2] = n, l2.shape[0], l1.shape[0]
     if world > 1:
         dist.broadcast(meta, 0)
@@ -169,6 +208,8 @@ def main():
             dist.broadcast(t, 0)
     torch.cuda.synchronize()
     ctx = hipapi.Context(local)
+    if os.environ.get("MEME_BENCH_LANES"):
+        ctx.set_tuning("group_lanes", int(os.environ["MEME_BENCH_LANES"]))
     words = hipapi.lib().meme_index_pac64_words(n)
     d_pac = torch.empty(words, dtype=torch.int64, device=dev)
     d_ent = torch.empty(2 * n, dtype=torch.int64, device=dev)
@@ -249,10 +290,10 @@ def main():
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
         }
         cpu = None
-        cpu_mode = os.environ.get("MEME_BENCH_CPU", "1")
+        cpu_mode = os.environ.get("MEME_BENCH_CPU", "reference" if l_pac <= 1_000_000_000 else "port")
         if world == 1 and cpu_mode != "0":
             cores = os.cpu_count() or 1
-            ns = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000")))
+            ns = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000" if cpu_mode != "port" else "400000")))
             try:
                 if cpu_mode != "port" and os.path.exists(os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")) and \
                         "avx512bw" in open("/proc/cpuinfo").read():

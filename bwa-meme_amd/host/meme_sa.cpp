@@ -81,25 +81,32 @@ void build_suffix_array(const uint8_t* text, int64_t n, uint64_t* sa_out, int th
     // group boundaries
     std::vector<std::pair<int64_t, int64_t>> groups;  // unsorted groups [s,e)
     {
-        std::vector<uint8_t> head((size_t)N);
+        std::vector<uint8_t> head((size_t)N + 1);
+        head[(size_t)N] = 1;
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < N; ++i) {
             sa[(size_t)i] = kp[(size_t)i].pos;
             head[(size_t)i] = (i == 0) || kp[(size_t)i].key != kp[(size_t)i - 1].key;
         }
-        int64_t s = 0;
-        for (int64_t i = 1; i <= N; ++i) {
-            if (i == N || head[(size_t)i]) {
-                if (i - s > 1) groups.emplace_back(s, i);
-                s = i;
+        // ranks and the list of groups with more than one member, chunk-parallel: a thread owns the groups
+        // whose head lies in its chunk and follows the last one past the chunk end
+        const int nt = omp_get_max_threads();
+        std::vector<std::vector<std::pair<int64_t, int64_t>>> tl((size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            int64_t lo = N * t / nt, hi = N * (t + 1) / nt;
+            while (lo < hi && !head[(size_t)lo]) ++lo;     // first head in the chunk
+            int64_t i = lo;
+            while (i < hi) {                                // i is a head
+                int64_t e = i + 1;
+                while (!head[(size_t)e]) ++e;               // head[N] = 1 terminates
+                for (int64_t k = i; k < e; ++k) rank[(size_t)sa[(size_t)k]] = i;
+                if (e - i > 1) tl[(size_t)t].emplace_back(i, e);
+                i = e;
             }
         }
-        // ranks: sequential fill by group (cheap)
-        int64_t g = 0;
-        for (int64_t i = 0; i < N; ++i) {
-            if (head[(size_t)i]) g = i;
-            rank[(size_t)sa[(size_t)i]] = g;
-        }
+        for (auto& v : tl) groups.insert(groups.end(), v.begin(), v.end());
     }
     std::vector<KeyPos>().swap(kp);
 
@@ -147,10 +154,24 @@ void build_suffix_array(const uint8_t* text, int64_t n, uint64_t* sa_out, int th
         h *= 2;
     }
 
-    // ---- drop the padding suffixes --------------------------------------------------------
-    int64_t w = 0;
-    for (int64_t i = 0; i < N; ++i)
-        if ((int64_t)sa[(size_t)i] < n) sa_out[w++] = sa[(size_t)i];
+    // ---- drop the padding suffixes (stable, chunk-parallel compaction) -----------------------------
+    {
+        const int nt = omp_get_max_threads();
+        std::vector<int64_t> cnt((size_t)nt + 1, 0);
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            int64_t lo = N * t / nt, hi = N * (t + 1) / nt, c = 0;
+            for (int64_t i = lo; i < hi; ++i) c += (int64_t)sa[(size_t)i] < n;
+            cnt[(size_t)t + 1] = c;
+#pragma omp barrier
+#pragma omp single
+            for (int k = 0; k < nt; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+            int64_t w = cnt[(size_t)t];
+            for (int64_t i = lo; i < hi; ++i)
+                if ((int64_t)sa[(size_t)i] < n) sa_out[w++] = sa[(size_t)i];
+        }
+    }
 }
 
 }  // namespace meme
