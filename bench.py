@@ -135,25 +135,32 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+        # rank 0 builds the index on its host for several minutes while the others wait at the first broadcast
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=90))
 
     mbp = float(os.environ.get("MEME_BENCH_MBP", "3100"))
     nreads = int(os.environ.get("MEME_BENCH_READS", "10000000"))
     bits = int(os.environ.get("MEME_BENCH_BITS", "0"))
-    # host RAM guard: the builder needs ~45 B per suffix (rank 0 only); shrink the genome rather than die
-    try:
-        import psutil
-        avail = psutil.virtual_memory().available
-        while mbp > 64 and 2 * mbp * 1e6 * 45 > 0.8 * avail:
+    # host RAM / HBM guards, decided by rank 0 for everybody: the builder needs ~45 B of host RAM per suffix,
+    # the GPU ~28 B per suffix plus the batch; shrink the genome rather than die
+    if rank == 0:
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+            while mbp > 64 and 2 * mbp * 1e6 * 45 > 0.8 * avail:
+                mbp /= 2
+                log("host RAM too small for the configured genome: falling back to %.0f Mbp" % mbp)
+        except ImportError:
+            pass
+        gpu_free = torch.cuda.mem_get_info(local)[0]
+        while mbp > 64 and 2 * mbp * 1e6 * 28 + nreads * 2200 > 0.9 * gpu_free:
             mbp /= 2
-            log("host RAM too small for the configured genome: falling back to %.0f Mbp" % mbp)
-    except ImportError:
-        pass
-    gpu_free = torch.cuda.mem_get_info(local)[0]
-    while mbp > 64 and 2 * mbp * 1e6 * 28 + nreads * 2200 > 0.9 * gpu_free:
-        mbp /= 2
-        log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
-    l_pac = int(mbp * 1e6) & ~1
+            log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
+    l_pac_t = torch.tensor([int(mbp * 1e6) & ~1], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.broadcast(l_pac_t, 0)
+    l_pac = int(l_pac_t[0])
     n = 2 * l_pac
 
     # ---- index: built on rank 0's host, staged on every GPU ----------------------------------------
