@@ -63,7 +63,8 @@ def cpu_baseline_reference(fwd, text, sa, l1, l2, reads, cores):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_py as O
     exe = os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")
-    tmp = tempfile.mkdtemp(prefix="meme_cpu_")
+    big = text.nbytes > (1 << 31)
+    tmp = tempfile.mkdtemp(prefix="meme_cpu_", dir="/dev/shm" if big and os.path.isdir("/dev/shm") else None)
     try:
         prefix = os.path.join(tmp, "ref.fa")
         t0 = time.time()
@@ -75,7 +76,7 @@ def cpu_baseline_reference(fwd, text, sa, l1, l2, reads, cores):
         t0 = time.time()
         env = dict(os.environ, OMP_NUM_THREADS=str(cores))
         r = subprocess.run([exe, prefix, fq, "1000", str(cores), "3"], capture_output=True, text=True, env=env,
-                           timeout=1500)
+                           timeout=3000)
         wall = time.time() - t0
         cyc = None
         for line in r.stderr.splitlines():

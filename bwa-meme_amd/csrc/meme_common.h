@@ -53,7 +53,7 @@ struct meme_ctx {
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
     i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch (tier 0)
-    i64 group_lanes = 8;               // lanes per read in the search kernel (4, 8, 16, 32)
+    i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
     i64 bsw_blocks = 0;
     // timings
