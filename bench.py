@@ -262,12 +262,14 @@ def main():
     for _ in range(a.warmup):
         res = step()
     kernel_ms = []
+    windows = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         res = step()
         tm = ctx.timings()
-        kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms))
+        kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms))
+        windows = tm.seed_windows
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -292,7 +294,8 @@ def main():
                        "genome_bp": l_pac, "sa_entries": n, "reads_per_gpu_per_step": nreads, "read_len": READ_LEN,
                        "rmi_leaves_log2": int(np.log2(n_l2)), "sharding": "reads/%d ranks, index replicated by RCCL broadcast" % world,
                        "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
-                       "searches_per_read": res.searches / nreads},
+                       "searches_per_read": res.searches / nreads,
+                       "windows_per_search": windows / max(res.searches, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "k_seed", "kernel_ms": k_ms, "gather_ms": g_ms,
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},

@@ -113,38 +113,64 @@ __global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, 
                                                    const int* __restrict__ cnt, i64 n, int hits_per_smem,
                                                    const i64* __restrict__ smem_off, const i64* __restrict__ hit_off,
                                                    meme_mem_tl* __restrict__ smems, u64* __restrict__ hits) {
-    constexpr int G = 16;
-    const int t = threadIdx.x & (G - 1);
-    i64 gid = ((i64)blockIdx.x * BLOCK + threadIdx.x) / G;
-    const i64 ngroups = (i64)gridDim.x * BLOCK / G;
+    // one 16-lane group per read, one lane per SMEM: the slot reads, the first-hit lookups and the mem_tl stores of up
+    // to 16 SMEMs go out together; hit lists longer than a few entries are copied cooperatively afterwards
+    constexpr int GL = 16;
+    const int lane = threadIdx.x & 63;
+    const int t = lane & (GL - 1);
+    const int gbase = lane - t;
+    i64 gid = ((i64)blockIdx.x * BLOCK + threadIdx.x) / GL;
+    const i64 ngroups = (i64)gridDim.x * BLOCK / GL;
     for (i64 r = gid; r < n; r += ngroups) {
-        int c = cnt[r];
+        const int c = cnt[r];
         if (c <= 0) continue;
         const i64 loc = slot_loc[r];
         const int tier = (int)(loc >> 40);
         const SlotRec* sl = tiers.base[tier] + (loc & ((1ll << 40) - 1)) * tiers.cap[tier];
         meme_mem_tl* out = smems + smem_off[r];
         u64* hout = hits + hit_off[r];
-        i64 hb = 0;
-        for (int k = 0; k < c; ++k) {
-            SlotRec s = sl[k];
+        i64 hb0 = 0;                                   // hits before this chunk of SMEMs
+        for (int k0 = 0; k0 < c; k0 += GL) {
+            const int k = k0 + t;
+            const bool act = k < c;
+            SlotRec s;
+            s.start = s.end = 0; s.sa_start = 0; s.count = 0;
+            if (act) s = sl[k];
             i64 h = s.count;
             if (hits_per_smem > 0 && h > hits_per_smem) h = hits_per_smem;
-            if (t == 0) {
+            // exclusive prefix of h over the group's lanes
+            i64 incl = h;
+#pragma unroll
+            for (int d = 1; d < GL; d <<= 1) {
+                i64 y = __shfl_up(incl, d, GL);
+                if (t >= d) incl += y;
+            }
+            const i64 hb = hb0 + incl - h;
+            u64 first = 0;
+            if (act) {
+                first = sa[s.sa_start].pos;
                 meme_mem_tl m;
                 m.start = s.start;
                 m.end = s.end;
                 m.hitbeg = (int32_t)hb;
                 m.hitcount = s.count > (i64)INT_MAX ? INT_MAX : (int32_t)s.count;
-                m.cache_refpos = sa[s.sa_start].pos;
+                m.cache_refpos = first;
                 out[k] = m;
+                if (h > 0) hout[hb] = first;
+                for (i64 i = 1; i < h && i < 4; ++i) hout[hb + i] = sa[s.sa_start + i].pos;
             }
-            for (i64 i = t; i < h; i += G) hout[hb + i] = sa[s.sa_start + i].pos;
-            hb += h;
+            // long hit lists: all lanes of the group copy them together
+            u64 longmask = (__ballot(act && h > 4) >> gbase) & 0xffffull;
+            while (longmask) {
+                const int src = __ffsll((long long)longmask) - 1;
+                longmask &= longmask - 1;
+                const i64 lh = __shfl(h, src, GL), lhb = __shfl(hb, src, GL), lsa = __shfl(s.sa_start, src, GL);
+                for (i64 i = 4 + t; i < lh; i += GL) hout[lhb + i] = sa[lsa + i].pos;
+            }
+            hb0 += __shfl(incl, GL - 1, GL);
         }
     }
 }
-
 
 template <int G>
 int launch_k_seed(meme_ctx* ctx, const SeedArgs& A, size_t lds, i64 blocks) {
