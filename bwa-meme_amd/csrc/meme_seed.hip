@@ -198,7 +198,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     PackGeom geo;
     geo.W = (int)((max_len + 31) / 32) + 2;
     geo.MW = (int)((max_len + 63) / 64);
-    geo.stride = 2 * geo.W + 2 * geo.MW;
+    geo.stride = 2 * geo.W + 2 * geo.MW + 1;
     if ((rc = meme_buf_reserve(ctx, ctx->packed, (size_t)nreads * geo.stride * 8))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
     {

@@ -53,7 +53,7 @@ constexpr int TIER_LCAP[N_TIERS] = {16, 512, 512};     // LDS ring: SMEMs of one
 struct PackGeom {
     int W;        // u64 words per strand (>= ceil(maxlen/32) + 2)
     int MW;       // u64 N-mask words per strand
-    int stride;   // 2*W + 2*MW
+    int stride;   // 2*W + 2*MW + 1 (last word = read length)
 };
 
 struct SeedArgs {
@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
     int k = (int)(gid - r * g.stride);
     const i64 ro = read_off[r];
     int len = (int)(read_off[r + 1] - ro);
+    if (k == g.stride - 1) { out[gid] = (u64)(unsigned)len; continue; }   // length word
     if (len > MAX_READ_LEN) len = 0;
     const uint8_t* p = reads + ro;
     u64 v = 0;
@@ -575,13 +576,26 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     g.gbase = lane & ~(G - 1);
     const int cap = A.cap, lcap = A.lcap;
     const int hits_per_smem = A.opt.hits_per_smem;
+#ifndef SEED_STATIC_ASSIGN
+#define SEED_STATIC_ASSIGN 1
+#endif
+    // reads are dealt to groups round-robin (no ticket atomic, no dependent offset loads: the read length travels in
+    // the packed record); ~500 reads per group even out the per-read cost differences
+    const unsigned long long n_groups = (unsigned long long)gridDim.x * GROUPS;
+    unsigned long long next_ticket = (unsigned long long)blockIdx.x * GROUPS + gib;
     for (;;) {
         unsigned long long ticket = 0;
+#if SEED_STATIC_ASSIGN
+        ticket = next_ticket;
+        next_ticket += n_groups;
+#else
         if (g.t == 0) ticket = atomicAdd(&A.counters[0], 1ull);
         ticket = __shfl(ticket, g.gbase);
+#endif
         if (ticket >= (unsigned long long)A.nreads) break;
         const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
-        const int l_seq = (int)(A.read_off[rid + 1] - A.read_off[rid]);
+        const u64* src = A.packed + rid * stride;
+        const int l_seq = (int)src[stride - 1];          // k_pack_reads stores the length in the last word
         SlotRec* slots = A.slots + (i64)ticket * cap;
         if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
             // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
@@ -590,9 +604,8 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             continue;
         }
         // ---- stage the packed read in LDS (coalesced 8-byte loads) ------------------------------------
-        const u64* src = A.packed + rid * stride;
         bool any_n = false;
-        for (int k = g.t; k < stride; k += G) {
+        for (int k = g.t; k < stride - 1; k += G) {
             u64 v = src[k];
             rd[k] = v;
             if (k >= 2 * W && k < 2 * W + MW) any_n |= (v != 0);
