@@ -155,7 +155,7 @@ __device__ __forceinline__ u64 ext_l(lds_u64 w, int s) {
 // cold per-read state kept in LDS (group-uniform redundant stores; every lane reads back what it wrote)
 enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_R2_SAVED, ST_ZZ_NEXT, ST_ZZ_SP, ST_ZZ_GUARD, ST_AP_GUARD,
                    ST_SM_BASE, ST_N_SMEMS, ST_HITS_LO, ST_HITS_HI, ST_SEARCHES, ST_FLAGS, ST_LAST_CNT_LO, ST_LAST_CNT_HI,
-                   ST_LAST_S_LO, ST_LAST_S_HI, ST_WORDS };
+                   ST_LAST_S_LO, ST_LAST_S_HI, ST_WINDOWS, ST_WORDS };
 enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2, F_REC = 4, F_LDS_OVF = 8 };
 
 template <int G>
@@ -169,7 +169,6 @@ struct Grp {
     lds_u64 fw, rc, nfw, nrc;
     lds_int st;
     int t, gbase;
-    unsigned windows;
 
     __device__ __forceinline__ u64 ballot(bool p) const { return (__ballot(p) >> gbase) & FULL; }
     __device__ __forceinline__ int shfl(int v, int src) const { return __shfl(v, gbase + src); }
@@ -243,7 +242,7 @@ template <int G>
 __device__ __forceinline__ void scan_window(Grp<G>& g, lds_u64 s, int off, int cap, i64 base, int& lcp, bool& less) {
     u64 k = g.sa[base + g.t].key, p = g.sa[base + g.t].pos;
     cmp_entry(g, s, off, cap, k, p, lcp, less);
-    g.windows++;
+    g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
 }
 
 // group-uniform single-slot probe: every lane loads the same entry (one broadcast sector)
@@ -256,7 +255,7 @@ __device__ __forceinline__ void probe(Grp<G>& g, lds_u64 s, int off, int cap, i6
 // lowest slot s_edge <= cur with [s_edge, cur] all sharing >= L bases with the query (cur does, cur > 0);
 // nb = LCP of slot s_edge-1 (0 at the array start)
 template <int G>
-__device__ __forceinline__ void edge_down(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& s_edge, int& nb) {
+__device__ __forceinline__ void edge_down_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& s_edge, int& nb) {
     int iter = 0;
     for (;;) {
         i64 wb = cur - G;
@@ -308,7 +307,7 @@ __device__ __forceinline__ void edge_down(Grp<G>& g, lds_u64 s, int off, int L, 
 
 // highest slot e_edge >= cur with [cur, e_edge] all matching; nb = LCP of slot e_edge+1 (0 at the end)
 template <int G>
-__device__ __forceinline__ void edge_up(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& e_edge, int& nb) {
+__device__ __forceinline__ void edge_up_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& e_edge, int& nb) {
     const i64 n = g.n;
     int iter = 0;
     for (;;) {
@@ -361,7 +360,7 @@ __device__ __forceinline__ void edge_up(Grp<G>& g, lds_u64 s, int off, int L, i6
 // partition point outside the first window: gallop away from the prediction, bisect, return the base of a
 // window that contains the partition point (or touches the array end it lies beyond)
 template <int G>
-__device__ __forceinline__ i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen, i64 base, bool above) {
+__device__ __forceinline__ i64 relocate_impl(Grp<G>& g, lds_u64 s, int off, int vlen, i64 base, bool above) {
     const i64 n = g.n;
     // one loop for both directions: `lo` is a slot known to sort before the query (-1: none yet),
     // `hi` a slot known not to (n: none yet)
@@ -390,6 +389,32 @@ __device__ __forceinline__ i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen,
     return b;
 }
 
+// Cold paths (run for a minority of searches) are real function calls with by-value arguments and results: their
+// register needs stay out of the hot loop's allocation, which is what decides the kernel's occupancy.
+struct EdgeRes {
+    i64 edge;
+    int nb;
+};
+#ifndef COLD_ATTR
+#define COLD_ATTR __forceinline__   // real calls cost 3x (scratch frames): measured, keep the cold paths inline
+#endif
+template <int G>
+__device__ COLD_ATTR EdgeRes edge_down(Grp<G> g, lds_u64 s, int off, int L, i64 cur) {
+    EdgeRes r;
+    edge_down_impl(g, s, off, L, cur, r.edge, r.nb);
+    return r;
+}
+template <int G>
+__device__ COLD_ATTR EdgeRes edge_up(Grp<G> g, lds_u64 s, int off, int L, i64 cur) {
+    EdgeRes r;
+    edge_up_impl(g, s, off, L, cur, r.edge, r.nb);
+    return r;
+}
+template <int G>
+__device__ COLD_ATTR i64 relocate(Grp<G> g, lds_u64 s, int off, int vlen, i64 base, bool above) {
+    return relocate_impl(g, s, off, vlen, base, above);
+}
+
 // The one search primitive.  Semantics of mem_search / right_smem_search (and the _tradeoff twins):
 //   maxLCP = longest prefix of the query (<= vlen bases) occurring in the text;
 //   mode 0: L = maxLCP.
@@ -397,31 +422,74 @@ __device__ __forceinline__ i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen,
 //           (:2365-2574, :2902-2942).
 //   mode 2: third round (:1199-1281): walk the levels maxLCP = L0 > L1 > ... until the interval holds
 //           >= min_intv suffixes or the next level is shorter than min_seed_len.
+#ifndef WIN_E
+#define WIN_E 2      // suffix-array entries per lane in the first window: window = WIN_E * G slots
+#endif
+
+// value of a per-lane pair at window slot `idx` (slot j lives in lane j % G, register j / G)
+template <int G>
+__device__ __forceinline__ int win_at(const Grp<G>& g, const int (&v)[WIN_E], int idx) {
+    int r = g.shfl(v[0], idx & (G - 1));
+#pragma unroll
+    for (int e = 1; e < WIN_E; ++e) {
+        int y = g.shfl(v[e], idx & (G - 1));
+        if ((idx / G) == e) r = y;
+    }
+    return r;
+}
+
+template <int G>
+__device__ __forceinline__ u64 win_ballot(const Grp<G>& g, const bool (&p)[WIN_E]) {
+    u64 m = 0;
+#pragma unroll
+    for (int e = 0; e < WIN_E; ++e) m |= g.ballot(p[e]) << (e * G);
+    return m;
+}
+
 template <int G>
 __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
+    constexpr int W = WIN_E * G;                           // first-window width in slots
+    constexpr u64 WFULL = (W == 64) ? ~0ull : ((1ull << W) - 1ull);
     const i64 n = g.n;
     lds_u64 s = q.rc ? g.rc : g.fw;
     const int off = q.off, vlen = q.vlen;
     u64 key = ext_l(s, off);
     if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
     i64 pos = rmi_lookup(g, key);
-    i64 base = pos - G / 2;
+    i64 base = pos - W / 2;
     if (base < 0) base = 0;
-    if (base > n - G) base = n - G;
-    int lcp; bool less;
-    scan_window(g, s, off, vlen, base, lcp, less);
-    u64 m = g.ballot(less);
-    const bool above = (m == Grp<G>::FULL) && base + G < n;
+    if (base > n - W) base = n - W;
+    int lcp[WIN_E];
+    bool less[WIN_E];
+    // first window: WIN_E coalesced loads of G entries each, issued together
+    {
+        u64 ek[WIN_E], ep[WIN_E];
+#pragma unroll
+        for (int e = 0; e < WIN_E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
+#pragma unroll
+        for (int e = 0; e < WIN_E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
+        g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
+    }
+    u64 m = win_ballot(g, less);
+    const bool above = (m == WFULL) && base + W < n;
     const bool below = (m == 0) && base > 0;
     if (above || below) {
-        base = relocate(g, s, off, vlen, base, above);
-        scan_window(g, s, off, vlen, base, lcp, less);
-        m = g.ballot(less);
+        i64 b = relocate(g, s, off, vlen, above ? base + W - G : base, above);   // G slots containing the partition point
+        base = b - (W - G) / 2;
+        if (base < 0) base = 0;
+        if (base > n - W) base = n - W;
+        u64 ek[WIN_E], ep[WIN_E];
+#pragma unroll
+        for (int e = 0; e < WIN_E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
+#pragma unroll
+        for (int e = 0; e < WIN_E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
+        g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
+        m = win_ballot(g, less);
     }
-    // lanes [0,P) sort before the query; the longest match is at one of the two boundary neighbours
+    // slots [0,P) sort before the query; the longest match is at one of the two boundary neighbours
     const int P = __popcll(m);
-    const int la = P > 0 ? g.shfl(lcp, P - 1) : -1;
-    const int lb = P < G ? g.shfl(lcp, P < G ? P : G - 1) : -1;
+    const int la = P > 0 ? win_at(g, lcp, P - 1) : -1;
+    const int lb = P < W ? win_at(g, lcp, P < W ? P : W - 1) : -1;
     const int c = (la >= lb) ? P - 1 : P;
     int L = la >= lb ? la : lb;
     Res out;
@@ -434,60 +502,49 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     // interval at level L from the window; extended beyond it only when the run touches a window edge
     i64 s_edge = base + c, e_edge = base + c;
     int nb_lo = 0, nb_hi = 0;
-    bool need_lo = false, need_hi = false;
-    {
-        u64 mm = g.ballot(lcp >= L);
-        u64 zb = (~mm) & ((1ull << c) - 1ull);
-        u64 za = (~mm) & Grp<G>::FULL & ~((2ull << c) - 1ull);
-        if (zb) {
-            int hz = 63 - __clzll((long long)zb);
-            s_edge = base + hz + 1;
-            nb_lo = g.shfl(lcp, hz);
-        } else if (base == 0) s_edge = 0;
-        else { need_lo = true; s_edge = base; }             // provisional: every slot of [base, c] matches
-        if (za) {
-            int lz = __ffsll((long long)za) - 1;
-            e_edge = base + lz - 1;
-            nb_hi = g.shfl(lcp, lz);
-        } else if (base + G >= n) e_edge = n - 1;
-        else { need_hi = true; e_edge = base + G - 1; }
-    }
+    bool need_lo = true, need_hi = true;
     // third-round bookkeeping (previous level's interval) lives in LDS: rarely touched, 4 registers saved
     i64 cnt, emit_s = s_edge;
     int match_len = L;
     bool have_last = false;
     for (;;) {
-        // Lower levels usually still end inside the first window, whose LCPs (computed against the whole query)
-        // are still in registers: resolve the edge from them and touch memory only when the run leaves the window.
-        if (need_lo) {
-            bool solved = false;
-            if (s_edge > base && s_edge <= base + G) {
-                const int ncur = (int)(s_edge - base);          // lanes [0,ncur) lie below the current edge
-                const u64 z = (~g.ballot(lcp >= L)) & ((1ull << ncur) - 1ull);
-                if (z) {
-                    const int hz = 63 - __clzll((long long)z);
-                    s_edge = base + hz + 1;
-                    nb_lo = g.shfl(lcp, hz);
-                    solved = true;
-                } else if (base == 0) { s_edge = 0; nb_lo = 0; solved = true; }
-                else s_edge = base;
+        // Levels usually end inside the first window, whose LCPs (computed against the whole query) are still in
+        // registers: resolve the edge from them and touch memory only when the run leaves the window.
+        if (need_lo || need_hi) {
+            bool ge[WIN_E];
+#pragma unroll
+            for (int e = 0; e < WIN_E; ++e) ge[e] = lcp[e] >= L;
+            const u64 zm = (~win_ballot(g, ge)) & WFULL;       // slots of the window that do NOT reach level L
+            if (need_lo) {
+                bool solved = false;
+                if (s_edge > base && s_edge <= base + W) {
+                    const int ncur = (int)(s_edge - base);      // slots [0,ncur) lie below the current edge
+                    const u64 z = zm & ((ncur >= 64) ? ~0ull : ((1ull << ncur) - 1ull));
+                    if (z) {
+                        const int hz = 63 - __clzll((long long)z);
+                        s_edge = base + hz + 1;
+                        nb_lo = win_at(g, lcp, hz);
+                        solved = true;
+                    } else if (base == 0) { s_edge = 0; nb_lo = 0; solved = true; }
+                    else s_edge = base;
+                } else if (s_edge == 0) { nb_lo = 0; solved = true; }
+                if (!solved) { const EdgeRes er = edge_down(g, s, off, L, s_edge); s_edge = er.edge; nb_lo = er.nb; }
             }
-            if (!solved) edge_down(g, s, off, L, s_edge, s_edge, nb_lo);
-        }
-        if (need_hi) {
-            bool solved = false;
-            if (e_edge >= base - 1 && e_edge < base + G - 1) {
-                const int first = (int)(e_edge + 1 - base);      // lanes [first,G) lie above the current edge
-                const u64 z = (~g.ballot(lcp >= L)) & Grp<G>::FULL & ~((1ull << first) - 1ull);
-                if (z) {
-                    const int lz = __ffsll((long long)z) - 1;
-                    e_edge = base + lz - 1;
-                    nb_hi = g.shfl(lcp, lz);
-                    solved = true;
-                } else if (base + G >= n) { e_edge = n - 1; nb_hi = 0; solved = true; }
-                else e_edge = base + G - 1;
+            if (need_hi) {
+                bool solved = false;
+                if (e_edge >= base - 1 && e_edge < base + W - 1) {
+                    const int first = (int)(e_edge + 1 - base);  // slots [first,W) lie above the current edge
+                    const u64 z = zm & ~((1ull << first) - 1ull);
+                    if (z) {
+                        const int lz = __ffsll((long long)z) - 1;
+                        e_edge = base + lz - 1;
+                        nb_hi = win_at(g, lcp, lz);
+                        solved = true;
+                    } else if (base + W >= n) { e_edge = n - 1; nb_hi = 0; solved = true; }
+                    else e_edge = base + W - 1;
+                } else if (e_edge == n - 1) { nb_hi = 0; solved = true; }
+                if (!solved) { const EdgeRes er = edge_up(g, s, off, L, e_edge); e_edge = er.edge; nb_hi = er.nb; }
             }
-            if (!solved) edge_up(g, s, off, L, e_edge, e_edge, nb_hi);
         }
         cnt = e_edge - s_edge + 1;
         const int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
@@ -608,7 +665,6 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         // ---- per-read state (group-uniform) ----------------------------------------------------------------
         int pivot = 0;
         int msl = A.opt.min_seed_len, min_intv = 1;
-        g.windows = 0;
         int pc = PC_ALLPOS_TOP;
         for (int k = 0; k < ST_WORDS; ++k) st[k] = 0;
 #define SET_PIVOT(p_) do { pivot = (p_); } while (0)
@@ -784,7 +840,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             A.slot_hits[rid] = ovf ? 0 : n_hits;
             A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
             if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
-            else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], (unsigned long long)g.windows); }
+            else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], (unsigned long long)(unsigned)st[ST_WINDOWS]); }
         }
 #undef FLAG
 #undef SETFLAG

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the reference aligner with and without the HIP backend interposed
+(oracle/_ref/bwa-meme_mode3 vs oracle/_ref/bwa-meme_dropin): python scripts/e2e_bench.py [Mbp] [Mpairs] [threads]
+Prints wall time, reads/s and whether the SAM files are identical (minus @PG)."""
+import hashlib, os, subprocess, sys, tempfile, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "bwa-meme_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np
+from pymeme import hostapi, synth, workload
+mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 128
+npairs = int(float(sys.argv[2]) * 1e6) if len(sys.argv) > 2 else 1000000
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+log = lambda *a: print("[e2e]", *a, flush=True)
+d = tempfile.mkdtemp(prefix="e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+g = synth.make_genome(int(mbp * 1e6) & ~1, seed=11)
+t0 = time.time(); text, sa = hostapi.build_sa(g); l1, l2 = hostapi.train_prmi(text, sa)
+prefix = os.path.join(d, "ref.fa"); hostapi.write_index(prefix, g, text, sa, l1, l2, n_contigs=8); log("index %.1f s" % (time.time() - t0))
+rng = np.random.default_rng(5)
+pos = rng.integers(0, g.shape[0] - 700, size=npairs); ins = rng.integers(300, 500, size=npairs)
+ar = np.arange(150)
+def mut(x):
+    sub = rng.random(x.shape) < 0.01
+    return np.where(sub, (x + rng.integers(1, 4, size=x.shape, dtype=np.uint8)) & 3, x).astype(np.uint8)
+r1 = mut(g[pos[:, None] + ar[None, :]])
+r2 = mut(3 - g[(pos + ins - 150)[:, None] + ar[None, :]][:, ::-1])
+def fastq(reads, path):
+    n, L = reads.shape
+    names = np.char.add("@p", np.arange(n).astype(str)).astype("S")
+    with open(path, "wb") as fh:
+        alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+        seqs = alpha[reads]
+        q = b"I" * L
+        for i in range(n):
+            fh.write(names[i] + b"\n" + seqs[i].tobytes() + b"\n+\n" + q + b"\n")
+f1, f2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
+t0 = time.time(); fastq(r1, f1); fastq(r2, f2); log("fastq %.1f s" % (time.time() - t0))
+res = {}
+for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+    out = os.path.join(d, exe + ".sam")
+    env = dict(os.environ, MEME_INDEX_PREFIX=prefix)
+    t0 = time.time()
+    with open(out, "wb") as fh:
+        r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
+    wall = time.time() - t0
+    err = r.stderr.decode()
+    keys = [l for l in err.split("\n") if any(k in l for k in ("Runtime-build-index", "Total kernel", "LEARNED", "BSW time", "SAM Processing", "Overall time", "total time", "Loading"))]
+    h = hashlib.md5()
+    nlines = 0
+    with open(out, "rb") as fh:
+        for line in fh:
+            if not line.startswith(b"@PG"):
+                h.update(line); nlines += 1
+    res[exe] = (wall, h.hexdigest(), nlines)
+    log(exe, "rc", r.returncode, "wall %.1f s" % wall, "->", "%.0f reads/s (wall, incl. index load)" % (2 * npairs / wall), "sam lines", nlines)
+    for k in keys[-12:]: log("   ", k.strip())
+log("SAM identical:", res["bwa-meme_mode3"][1] == res["bwa-meme_dropin"][1])
+import shutil; shutil.rmtree(d, ignore_errors=True)
