@@ -427,28 +427,29 @@ __device__ COLD_ATTR i64 relocate(Grp<G> g, lds_u64 s, int off, int vlen, i64 ba
 #endif
 
 // value of a per-lane pair at window slot `idx` (slot j lives in lane j % G, register j / G)
-template <int G>
-__device__ __forceinline__ int win_at(const Grp<G>& g, const int (&v)[WIN_E], int idx) {
+template <int G, int E>
+__device__ __forceinline__ int win_at(const Grp<G>& g, const int (&v)[E], int idx) {
     int r = g.shfl(v[0], idx & (G - 1));
 #pragma unroll
-    for (int e = 1; e < WIN_E; ++e) {
+    for (int e = 1; e < E; ++e) {
         int y = g.shfl(v[e], idx & (G - 1));
         if ((idx / G) == e) r = y;
     }
     return r;
 }
 
-template <int G>
-__device__ __forceinline__ u64 win_ballot(const Grp<G>& g, const bool (&p)[WIN_E]) {
+template <int G, int E>
+__device__ __forceinline__ u64 win_ballot(const Grp<G>& g, const bool (&p)[E]) {
     u64 m = 0;
 #pragma unroll
-    for (int e = 0; e < WIN_E; ++e) m |= g.ballot(p[e]) << (e * G);
+    for (int e = 0; e < E; ++e) m |= g.ballot(p[e]) << (e * G);
     return m;
 }
 
 template <int G>
 __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
-    constexpr int W = WIN_E * G;                           // first-window width in slots
+    constexpr int E = (WIN_E * G > 64) ? 64 / G : WIN_E;   // entries per lane (the window mask is 64 bits)
+    constexpr int W = E * G;                               // first-window width in slots
     constexpr u64 WFULL = (W == 64) ? ~0ull : ((1ull << W) - 1ull);
     const i64 n = g.n;
     lds_u64 s = q.rc ? g.rc : g.fw;
@@ -459,15 +460,15 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     i64 base = pos - W / 2;
     if (base < 0) base = 0;
     if (base > n - W) base = n - W;
-    int lcp[WIN_E];
-    bool less[WIN_E];
+    int lcp[E];
+    bool less[E];
     // first window: WIN_E coalesced loads of G entries each, issued together
     {
-        u64 ek[WIN_E], ep[WIN_E];
+        u64 ek[E], ep[E];
 #pragma unroll
-        for (int e = 0; e < WIN_E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
+        for (int e = 0; e < E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
 #pragma unroll
-        for (int e = 0; e < WIN_E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
+        for (int e = 0; e < E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
         g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
     }
     u64 m = win_ballot(g, less);
@@ -478,11 +479,11 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
         base = b - (W - G) / 2;
         if (base < 0) base = 0;
         if (base > n - W) base = n - W;
-        u64 ek[WIN_E], ep[WIN_E];
+        u64 ek[E], ep[E];
 #pragma unroll
-        for (int e = 0; e < WIN_E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
+        for (int e = 0; e < E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
 #pragma unroll
-        for (int e = 0; e < WIN_E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
+        for (int e = 0; e < E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
         g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
         m = win_ballot(g, less);
     }
@@ -511,9 +512,9 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
         // Levels usually end inside the first window, whose LCPs (computed against the whole query) are still in
         // registers: resolve the edge from them and touch memory only when the run leaves the window.
         if (need_lo || need_hi) {
-            bool ge[WIN_E];
+            bool ge[E];
 #pragma unroll
-            for (int e = 0; e < WIN_E; ++e) ge[e] = lcp[e] >= L;
+            for (int e = 0; e < E; ++e) ge[e] = lcp[e] >= L;
             const u64 zm = (~win_ballot(g, ge)) & WFULL;       // slots of the window that do NOT reach level L
             if (need_lo) {
                 bool solved = false;
