@@ -181,7 +181,7 @@ int launch_k_seed(meme_ctx* ctx, const SeedArgs& A, size_t lds, i64 blocks) {
     return MEME_OK;
 }
 
-int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, i64 max_len,
+int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, i64 max_len, i64 total_bytes,
                 const meme_seed_opt* opt, meme_seed_result* out) {
     unsigned long long h_counters[4];
     int rc;
@@ -193,6 +193,8 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
     // ---- pack the reads: 2 bits/base, both strands, N masks (k_pack_reads) ---------------------------------
+    const i64 stage_len = max_len < 1 ? 1 : max_len;              // longest read as staged by the packing kernel
+    if (stage_len > 32768) { meme_set_error("read of %lld bases: not a short read", (long long)stage_len); return MEME_E_ARG; }
     if (max_len > MAX_READ_LEN) max_len = MAX_READ_LEN;
     if (max_len < 1) max_len = 1;
     PackGeom geo;
@@ -202,10 +204,14 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     if ((rc = meme_buf_reserve(ctx, ctx->packed, (size_t)nreads * geo.stride * 8))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
     {
-        i64 threads = nreads * geo.stride, pblocks = (threads + 255) / 256;
-        if (pblocks > (i64)dev_cus * 64) pblocks = (i64)dev_cus * 64;   // grid-stride beyond that
-        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)pblocks), dim3(256), 0, ctx->stream, d_reads,
-                           d_read_off, nreads, geo, (u64*)ctx->packed.p);
+        int rb = (int)((48 * 1024) / stage_len);                    // reads per workgroup: <= 48 KB of staged bytes
+        if (rb > 32) rb = 32;
+        if (rb < 1) rb = 1;
+        i64 pblocks = (nreads + rb - 1) / rb;
+        if (pblocks > (i64)dev_cus * 16) pblocks = (i64)dev_cus * 16;   // grid-stride beyond that
+        size_t plds = ((size_t)rb * (size_t)stage_len + 16 + 3) & ~(size_t)3;
+        hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)pblocks), dim3(256), plds, ctx->stream, d_reads,
+                           d_read_off, nreads, total_bytes, geo, rb, (u64*)ctx->packed.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
@@ -329,18 +335,29 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
 }
 
 // longest read of the batch (sizes the packed layout and the LDS tile)
-__global__ void k_max_len(const i64* __restrict__ off, i64 n, int* out) {
-    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    int v = i < n ? (int)(off[i + 1] - off[i]) : 0;
+__global__ void __launch_bounds__(256) k_max_len(const i64* __restrict__ off, i64 n, int* out) {
+    __shared__ int wmax[4];
+    int v = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        int l = (int)(off[i + 1] - off[i]);
+        v = v > l ? v : l;
+    }
     for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(v, d); v = v > y ? v : y; }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) v = v > wmax[k] ? v : wmax[k];
+        atomicMax(out, v);
+    }
 }
 
 int device_max_len(meme_ctx* ctx, const i64* d_read_off, i64 nreads, i64* max_len) {
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, 64))) return rc;
     HIP_TRY(hipMemsetAsync(ctx->scan_tmp.p, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_max_len, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, ctx->stream, d_read_off, nreads,
+    i64 mblocks = (nreads + 255) / 256;
+    if (mblocks > 1024) mblocks = 1024;
+    hipLaunchKernelGGL(k_max_len, dim3((unsigned)mblocks), dim3(256), 0, ctx->stream, d_read_off, nreads,
                        (int*)ctx->scan_tmp.p);
     int v = 0;
     HIP_TRY(hipMemcpyAsync(&v, ctx->scan_tmp.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -361,7 +378,6 @@ int check_opt(const meme_seed_opt* opt) {
 
 extern "C" int meme_seed_batch_device(meme_ctx* ctx, const uint8_t* d_reads, const int64_t* d_read_off, int64_t nreads,
                                       int64_t total_bases, const meme_seed_opt* opt, meme_seed_result* out) {
-    (void)total_bases;
     if (!ctx || !d_reads || !d_read_off || !out || nreads < 0) return MEME_E_ARG;
     int rc = check_opt(opt);
     if (rc) return rc;
@@ -370,7 +386,7 @@ extern "C" int meme_seed_batch_device(meme_ctx* ctx, const uint8_t* d_reads, con
     if (nreads == 0) { memset(out, 0, sizeof(*out)); return MEME_OK; }
     i64 max_len = 0;
     if ((rc = device_max_len(ctx, (const i64*)d_read_off, nreads, &max_len))) return rc;
-    return launch_seed(ctx, d_reads, (const i64*)d_read_off, nreads, max_len, opt, out);
+    return launch_seed(ctx, d_reads, (const i64*)d_read_off, nreads, max_len, total_bases, opt, out);
 }
 
 extern "C" int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
@@ -392,7 +408,7 @@ extern "C" int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_
     meme_seed_result res;
     i64 max_len = 0;
     for (i64 i = 0; i < nreads; ++i) max_len = read_off[i + 1] - read_off[i] > max_len ? read_off[i + 1] - read_off[i] : max_len;
-    rc = launch_seed(ctx, (const uint8_t*)ctx->reads.p, (const i64*)ctx->read_off.p, nreads, max_len, opt, &res);
+    rc = launch_seed(ctx, (const uint8_t*)ctx->reads.p, (const i64*)ctx->read_off.p, nreads, max_len, bases, opt, &res);
     if (rc) return rc;
     if (total_smems) *total_smems = res.total_smems;
     if (total_hits) *total_hits = res.total_hits;

@@ -121,7 +121,8 @@ int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off
                     uint64_t* hits, int64_t hit_capacity, int64_t* hit_off,
                     int64_t* total_smems, int64_t* total_hits);
 
-/* Same with inputs and outputs resident in HBM (pointers valid until the next call on this ctx). */
+/* Same with inputs and outputs resident in HBM (pointers valid until the next call on this ctx).
+ * d_reads must be 4-byte aligned (any hipMalloc'ed pointer is); total_bases = read_off[nreads] = bytes in d_reads. */
 typedef struct {
     const meme_mem_tl* d_smems;
     const int64_t* d_smem_off;   /* nreads+1 */
