@@ -155,6 +155,7 @@ struct Req {
     int off, vlen;
     int min_intv;
     int mode;         // 0: match length only; 1: + interval with >= min_intv suffixes; 2: third-round levels
+    bool exact;       // the interval at the final level is emitted: its edges must be exact
 };
 
 struct Res {
@@ -280,108 +281,159 @@ __device__ __forceinline__ void probe(Grp<G>& g, lds_u64 s, int off, int cap, i6
     cmp_entry(g, s, off, cap, k, p, lcp, less);
 }
 
+#ifndef EDGE_E
+#define EDGE_E 4     // entries per lane when an SMEM interval is followed beyond the first window
+#endif
+
+// value of a per-lane array at window slot `idx` (slot j lives in lane j % G, register j / G)
+template <int G, int E>
+__device__ __forceinline__ int win_at(const Grp<G>& g, const int (&v)[E], int idx) {
+    int r = g.shfl(v[0], idx & (G - 1));
+#pragma unroll
+    for (int e = 1; e < E; ++e) {
+        int y = g.shfl(v[e], idx & (G - 1));
+        if ((idx / G) == e) r = y;
+    }
+    return r;
+}
+
+template <int G, int E>
+__device__ __forceinline__ u64 win_ballot(const Grp<G>& g, const bool (&p)[E]) {
+    u64 m = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) m |= g.ballot(p[e]) << (e * G);
+    return m;
+}
+
+// E*G consecutive slots from `base`: E coalesced loads per lane issued together, then the compares
+template <int G, int E>
+__device__ __forceinline__ void scan_wide(Grp<G>& g, lds_u64 s, int off, int cap, i64 base, int (&lcp)[E], bool (&less)[E]) {
+    u64 ek[E], ep[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
+#pragma unroll
+    for (int e = 0; e < E; ++e) cmp_entry(g, s, off, cap, ek[e], ep[e], lcp[e], less[e]);
+    g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
+}
+
 // lowest slot s_edge <= cur with [s_edge, cur] all sharing >= L bases with the query (cur does, cur > 0);
-// nb = LCP of slot s_edge-1 (0 at the array start)
+// nb = LCP of slot s_edge-1 (0 at the array start).  `need`: the caller only wants to know whether at least
+// `need` more slots match (non-emitting searches, third round): stop extending once they do.
 template <int G>
-__device__ __forceinline__ void edge_down_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& s_edge, int& nb) {
+__device__ __forceinline__ void edge_down_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need, i64& s_edge, int& nb) {
+    constexpr int EE = (EDGE_E * G > 64) ? 64 / G : EDGE_E;
+    constexpr int WE = EE * G;
+    const i64 start = cur;
     int iter = 0;
     for (;;) {
-        i64 wb = cur - G;
+        i64 wb = cur - WE;
         if (wb < 0) wb = 0;
-        int lcp; bool less;
-        scan_window(g, s, off, L, wb, lcp, less);
-        u64 mm = g.ballot(lcp >= L);
-        int ncur = (int)(cur - wb);                       // lanes [0,ncur) lie below cur
-        u64 z = (~mm) & ((1ull << ncur) - 1ull);
+        int lcp[EE]; bool less[EE], ge[EE];
+        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
+#pragma unroll
+        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
+        const int ncur = (int)(cur - wb);                 // slots [0,ncur) lie below cur
+        const u64 z = (~win_ballot<G, EE>(g, ge)) & ((ncur >= 64) ? ~0ull : ((1ull << ncur) - 1ull));
         if (z) {
-            int hz = 63 - __clzll((long long)z);
+            const int hz = 63 - __clzll((long long)z);
             s_edge = wb + hz + 1;
-            nb = g.shfl(lcp, hz);
+            nb = win_at<G, EE>(g, lcp, hz);
             return;
         }
         cur = wb;
         if (cur == 0) { s_edge = 0; nb = 0; return; }
+        if (start - cur >= need) { s_edge = cur; nb = L; return; }
         if (++iter >= 2) break;
     }
     // large interval: gallop with single-slot probes, bisect, then one window for the exact edge
-    i64 good = cur, bad = -1, step = 4 * G;
+    i64 good = cur, bad = -1, step = 4 * WE;
     for (;;) {
         i64 p = good - step;
         if (p < 0) p = 0;
         int lcp; bool less;
         probe(g, s, off, L, p, lcp, less);
-        if (lcp >= L) { good = p; if (p == 0) break; step <<= 1; }
+        if (lcp >= L) { good = p; if (p == 0) break; if (start - good >= need) { s_edge = good; nb = L; return; } step <<= 1; }
         else { bad = p; break; }
     }
     if (bad < 0) { s_edge = 0; nb = 0; return; }
-    while (good - bad > G) {
+    while (good - bad > WE) {
         i64 mid = bad + (good - bad) / 2;
         int lcp; bool less;
         probe(g, s, off, L, mid, lcp, less);
         if (lcp >= L) good = mid; else bad = mid;
     }
     {
-        i64 wb = good - G;                                // >= bad >= 0: window [wb, good) contains bad
+        i64 wb = good - WE;                               // >= bad - ... : window [wb, good) contains bad
         if (wb < 0) wb = 0;
-        int lcp; bool less;
-        scan_window(g, s, off, L, wb, lcp, less);
-        int ncur = (int)(good - wb);
-        u64 z = (~g.ballot(lcp >= L)) & ((1ull << ncur) - 1ull);
-        int hz = 63 - __clzll((long long)z);
+        int lcp[EE]; bool less[EE], ge[EE];
+        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
+#pragma unroll
+        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
+        const int ncur = (int)(good - wb);
+        const u64 z = (~win_ballot<G, EE>(g, ge)) & ((ncur >= 64) ? ~0ull : ((1ull << ncur) - 1ull));
+        const int hz = 63 - __clzll((long long)z);
         s_edge = wb + hz + 1;
-        nb = g.shfl(lcp, hz);
+        nb = win_at<G, EE>(g, lcp, hz);
     }
 }
 
 // highest slot e_edge >= cur with [cur, e_edge] all matching; nb = LCP of slot e_edge+1 (0 at the end)
 template <int G>
-__device__ __forceinline__ void edge_up_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64& e_edge, int& nb) {
+__device__ __forceinline__ void edge_up_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need, i64& e_edge, int& nb) {
+    constexpr int EE = (EDGE_E * G > 64) ? 64 / G : EDGE_E;
+    constexpr int WE = EE * G;
+    constexpr u64 WEFULL = (WE == 64) ? ~0ull : ((1ull << WE) - 1ull);
     const i64 n = g.n;
+    const i64 start = cur;
     int iter = 0;
     for (;;) {
-        i64 wb = cur + 1;                                 // window [wb, wb+G) clipped to the array
-        if (wb > n - G) wb = n - G;
-        int lcp; bool less;
-        scan_window(g, s, off, L, wb, lcp, less);
-        u64 mm = g.ballot(lcp >= L);
-        int first = (int)(cur + 1 - wb);                  // lanes [first, G) lie above cur
-        u64 z = (~mm) & Grp<G>::FULL & ~((1ull << first) - 1ull);
+        i64 wb = cur + 1;                                 // window [wb, wb+WE) clipped to the array
+        if (wb > n - WE) wb = n - WE;
+        int lcp[EE]; bool less[EE], ge[EE];
+        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
+#pragma unroll
+        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
+        const int first = (int)(cur + 1 - wb);            // slots [first, WE) lie above cur
+        const u64 z = (~win_ballot<G, EE>(g, ge)) & WEFULL & ~((1ull << first) - 1ull);
         if (z) {
-            int lz = __ffsll((long long)z) - 1;
+            const int lz = __ffsll((long long)z) - 1;
             e_edge = wb + lz - 1;
-            nb = g.shfl(lcp, lz);
+            nb = win_at<G, EE>(g, lcp, lz);
             return;
         }
-        cur = wb + G - 1;
+        cur = wb + WE - 1;
         if (cur == n - 1) { e_edge = n - 1; nb = 0; return; }
+        if (cur - start >= need) { e_edge = cur; nb = L; return; }
         if (++iter >= 2) break;
     }
-    i64 good = cur, bad = -1, step = 4 * G;
+    i64 good = cur, bad = -1, step = 4 * WE;
     for (;;) {
         i64 p = good + step;
         if (p > n - 1) p = n - 1;
         int lcp; bool less;
         probe(g, s, off, L, p, lcp, less);
-        if (lcp >= L) { good = p; if (p == n - 1) break; step <<= 1; }
+        if (lcp >= L) { good = p; if (p == n - 1) break; if (good - start >= need) { e_edge = good; nb = L; return; } step <<= 1; }
         else { bad = p; break; }
     }
     if (bad < 0) { e_edge = n - 1; nb = 0; return; }
-    while (bad - good > G) {
+    while (bad - good > WE) {
         i64 mid = good + (bad - good) / 2;
         int lcp; bool less;
         probe(g, s, off, L, mid, lcp, less);
         if (lcp >= L) good = mid; else bad = mid;
     }
     {
-        i64 wb = good + 1;                                // window (good, good+G] contains bad
-        if (wb > n - G) wb = n - G;
-        int lcp; bool less;
-        scan_window(g, s, off, L, wb, lcp, less);
-        int first = (int)(good + 1 - wb);
-        u64 z = (~g.ballot(lcp >= L)) & Grp<G>::FULL & ~((1ull << first) - 1ull);
-        int lz = __ffsll((long long)z) - 1;
+        i64 wb = good + 1;                                // window (good, good+WE] contains bad
+        if (wb > n - WE) wb = n - WE;
+        int lcp[EE]; bool less[EE], ge[EE];
+        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
+#pragma unroll
+        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
+        const int first = (int)(good + 1 - wb);
+        const u64 z = (~win_ballot<G, EE>(g, ge)) & WEFULL & ~((1ull << first) - 1ull);
+        const int lz = __ffsll((long long)z) - 1;
         e_edge = wb + lz - 1;
-        nb = g.shfl(lcp, lz);
+        nb = win_at<G, EE>(g, lcp, lz);
     }
 }
 
@@ -427,19 +479,19 @@ struct EdgeRes {
 #define COLD_ATTR __forceinline__   // real calls cost 3x (scratch frames): measured, keep the cold paths inline
 #endif
 template <int G>
-__device__ COLD_ATTR EdgeRes edge_down(Grp<G> g, lds_u64 s, int off, int L, i64 cur) {
+__device__ COLD_ATTR EdgeRes edge_down(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need) {
     EdgeRes r;
-    edge_down_impl(g, s, off, L, cur, r.edge, r.nb);
+    edge_down_impl(g, s, off, L, cur, need, r.edge, r.nb);
     return r;
 }
 template <int G>
-__device__ COLD_ATTR EdgeRes edge_up(Grp<G> g, lds_u64 s, int off, int L, i64 cur) {
+__device__ COLD_ATTR EdgeRes edge_up(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need) {
     EdgeRes r;
-    edge_up_impl(g, s, off, L, cur, r.edge, r.nb);
+    edge_up_impl(g, s, off, L, cur, need, r.edge, r.nb);
     return r;
 }
 template <int G>
-__device__ COLD_ATTR i64 relocate(Grp<G> g, lds_u64 s, int off, int vlen, i64 base, bool above) {
+__device__ COLD_ATTR i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen, i64 base, bool above) {
     return relocate_impl(g, s, off, vlen, base, above);
 }
 
@@ -453,26 +505,6 @@ __device__ COLD_ATTR i64 relocate(Grp<G> g, lds_u64 s, int off, int vlen, i64 ba
 #ifndef WIN_E
 #define WIN_E 2      // suffix-array entries per lane in the first window: window = WIN_E * G slots
 #endif
-
-// value of a per-lane pair at window slot `idx` (slot j lives in lane j % G, register j / G)
-template <int G, int E>
-__device__ __forceinline__ int win_at(const Grp<G>& g, const int (&v)[E], int idx) {
-    int r = g.shfl(v[0], idx & (G - 1));
-#pragma unroll
-    for (int e = 1; e < E; ++e) {
-        int y = g.shfl(v[e], idx & (G - 1));
-        if ((idx / G) == e) r = y;
-    }
-    return r;
-}
-
-template <int G, int E>
-__device__ __forceinline__ u64 win_ballot(const Grp<G>& g, const bool (&p)[E]) {
-    u64 m = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) m |= g.ballot(p[e]) << (e * G);
-    return m;
-}
 
 template <int G>
 __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
@@ -491,14 +523,7 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     int lcp[E];
     bool less[E];
     // first window: WIN_E coalesced loads of G entries each, issued together
-    {
-        u64 ek[E], ep[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
-#pragma unroll
-        for (int e = 0; e < E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
-        g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
-    }
+    scan_wide<G, E>(g, s, off, vlen, base, lcp, less);
     u64 m = win_ballot(g, less);
     const bool above = (m == WFULL) && base + W < n;
     const bool below = (m == 0) && base > 0;
@@ -507,12 +532,7 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
         base = b - (W - G) / 2;
         if (base < 0) base = 0;
         if (base > n - W) base = n - W;
-        u64 ek[E], ep[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
-#pragma unroll
-        for (int e = 0; e < E; ++e) cmp_entry(g, s, off, vlen, ek[e], ep[e], lcp[e], less[e]);
-        g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
+        scan_wide<G, E>(g, s, off, vlen, base, lcp, less);
         m = win_ballot(g, less);
     }
     // slots [0,P) sort before the query; the longest match is at one of the two boundary neighbours
@@ -536,6 +556,9 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
     i64 cnt, emit_s = s_edge;
     int match_len = L;
     bool have_last = false;
+    // searches whose interval is never emitted at the level where the walk stops (left extensions, the third round)
+    // only need to know that the interval reached min_intv: following it further is wasted traffic
+    const i64 need_more = q.exact ? ((i64)1 << 62) : (i64)q.min_intv;
     for (;;) {
         // Levels usually end inside the first window, whose LCPs (computed against the whole query) are still in
         // registers: resolve the edge from them and touch memory only when the run leaves the window.
@@ -557,7 +580,7 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
                     } else if (base == 0) { s_edge = 0; nb_lo = 0; solved = true; }
                     else s_edge = base;
                 } else if (s_edge == 0) { nb_lo = 0; solved = true; }
-                if (!solved) { const EdgeRes er = edge_down(g, s, off, L, s_edge); s_edge = er.edge; nb_lo = er.nb; }
+                if (!solved) { const EdgeRes er = edge_down(g, s, off, L, s_edge, need_more - (e_edge - s_edge + 1)); s_edge = er.edge; nb_lo = er.nb; }
             }
             if (need_hi) {
                 bool solved = false;
@@ -572,7 +595,7 @@ __device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
                     } else if (base + W >= n) { e_edge = n - 1; nb_hi = 0; solved = true; }
                     else e_edge = base + W - 1;
                 } else if (e_edge == n - 1) { nb_hi = 0; solved = true; }
-                if (!solved) { const EdgeRes er = edge_up(g, s, off, L, e_edge); e_edge = er.edge; nb_hi = er.nb; }
+                if (!solved) { const EdgeRes er = edge_up(g, s, off, L, e_edge, need_more - (e_edge - s_edge + 1)); e_edge = er.edge; nb_hi = er.nb; }
             }
         }
         cnt = e_edge - s_edge + 1;
@@ -716,7 +739,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                         st[ST_ZZ_NEXT] = l_seq; SETFLAG(F_ZZ_CHECK, true); SETFLAG(F_ZZ_RET_ONEPOS, false); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
                         pc = PC_ZZ_TOP;
                     } else {
-                        q.kind = K_S1_RIGHT; q.rc = false; q.off = pivot;
+                        q.kind = K_S1_RIGHT; q.exact = true; q.rc = false; q.off = pivot;
                         q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
                         have = true;
                     }
@@ -728,13 +751,13 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                         else { st[ST_ZZ_SP] += 1; SET_PIVOT(pivot + 1); }
                         break;
                     }
-                    q.kind = K_ZZ_LEFT; q.rc = true; q.off = l_pivot;
+                    q.kind = K_ZZ_LEFT; q.exact = false; q.rc = true; q.off = l_pivot;
                     q.vlen = first_n(g.nrc, has_n, l_pivot, l_seq) - l_pivot; q.min_intv = min_intv;
                     q.mode = min_intv != 1 ? 1 : 0;
                     have = true;
                     break;
                 case PC_ZZ_RIGHT:
-                    q.kind = K_ZZ_RIGHT; q.rc = false; q.off = pivot;
+                    q.kind = K_ZZ_RIGHT; q.exact = true; q.rc = false; q.off = pivot;
                     q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
                     have = true;
                     break;
@@ -762,12 +785,12 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                         if (l_seq - pivot < msl) SET_PIVOT(l_seq); else SET_PIVOT(pivot + 1);
                         pc = PC_R2_AFTER;
                     } else if (pivot != 0 && !is_n(g.nfw, pivot - 1)) {
-                        q.kind = K_OP_MEM; q.rc = false; q.off = pivot;
+                        q.kind = K_OP_MEM; q.exact = false; q.rc = false; q.off = pivot;
                         q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv;
                         q.mode = min_intv != 1 ? 1 : 0;
                         have = true;
                     } else {
-                        q.kind = K_OP_SMEM; q.rc = false; q.off = pivot;
+                        q.kind = K_OP_SMEM; q.exact = true; q.rc = false; q.off = pivot;
                         q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
                         have = true;
                     }
@@ -791,7 +814,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     if (is_n(g.nfw, pivot)) { SET_PIVOT(pivot + 1); break; }
                     const int valid = first_n(g.nfw, has_n, pivot, l_seq) - pivot;
                     if (valid < msl) { SET_PIVOT(pivot + valid); break; }
-                    q.kind = K_R3; q.rc = false; q.off = pivot; q.vlen = valid; q.min_intv = min_intv; q.mode = 2;
+                    q.kind = K_R3; q.exact = false; q.rc = false; q.off = pivot; q.vlen = valid; q.min_intv = min_intv; q.mode = 2;
                     have = true;
                     break;
                 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 MBP=${1:-512}
-for v in "" _e3 _e4; do
+for v in "" _ee2; do
   lib=$PWD/bwa-meme_amd/libmeme_hip$v.so
   [ -f $lib ] || continue
   echo "== variant ${v:-default}"
