@@ -282,7 +282,7 @@ __device__ __forceinline__ void probe(Grp<G>& g, lds_u64 s, int off, int cap, i6
 }
 
 #ifndef EDGE_E
-#define EDGE_E 4     // entries per lane when an SMEM interval is followed beyond the first window
+#define EDGE_E 2     // entries per lane when an SMEM interval is followed beyond the first window
 #endif
 
 // value of a per-lane array at window slot `idx` (slot j lives in lane j % G, register j / G)
