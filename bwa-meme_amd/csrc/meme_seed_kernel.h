@@ -503,7 +503,7 @@ __device__ COLD_ATTR i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen, i64 b
 //   mode 2: third round (:1199-1281): walk the levels maxLCP = L0 > L1 > ... until the interval holds
 //           >= min_intv suffixes or the next level is shorter than min_seed_len.
 #ifndef WIN_E
-#define WIN_E 2      // suffix-array entries per lane in the first window: window = WIN_E * G slots
+#define WIN_E 3      // suffix-array entries per lane in the first window: window = WIN_E * G slots
 #endif
 
 template <int G>
