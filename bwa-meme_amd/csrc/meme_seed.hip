@@ -251,7 +251,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.counters = (unsigned long long*)ctx->counters.p;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
-        size_t lds = (size_t)groups * geo.stride * 8 + (size_t)groups * (3 * lcap + ST_WORDS) * sizeof(int);
+        size_t lds = seed_lds_bytes(G, geo, lcap);
         i64 want = (n_todo + groups - 1) / groups;
         i64 blocks = ctx->seed_blocks > 0 ? ctx->seed_blocks : (i64)dev_cus * ctx->seed_blocks_per_cu;
         if (blocks > want) blocks = want;

@@ -143,26 +143,19 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
 }
 
 // ---- per-read state ------------------------------------------------------------------------------------
+// Every read is a little machine with a "program counter" over the reference's pivot logic (rounds 1-3).  The
+// wavefront runs ONE loop whose body is: [control: advance reads that need a new search request] -> [window: load
+// E*G suffix-array slots and compare them with the query] -> [resolve: what the window means in the read's current
+// phase].  A read that finishes pulls the next one inside the same loop, so the 64/G reads of a wavefront never
+// wait for each other and the only heavy code (window load + compare) exists once in the kernel.
 enum Pc : int {
-    PC_ALLPOS_TOP, PC_ZZ_TOP, PC_ZZ_RIGHT, PC_ZZ_END, PC_AFTER_STEP1, PC_R2_LOOP, PC_R2_AFTER, PC_R3_INIT,
-    PC_R3_TOP, PC_DONE
+    PC_FETCH, PC_ALLPOS_TOP, PC_ZZ_TOP, PC_ZZ_RIGHT, PC_ZZ_END, PC_AFTER_STEP1, PC_R2_LOOP, PC_R2_AFTER, PC_R3_INIT,
+    PC_R3_TOP, PC_DONE, PC_EXIT
 };
 enum Kind : int { K_S1_RIGHT, K_ZZ_LEFT, K_ZZ_RIGHT, K_OP_MEM, K_OP_SMEM, K_R3 };
-
-struct Req {
-    int kind;
-    bool rc;          // query strand: reverse complement (left extension) or forward
-    int off, vlen;
-    int min_intv;
-    int mode;         // 0: match length only; 1: + interval with >= min_intv suffixes; 2: third-round levels
-    bool exact;       // the interval at the final level is emitted: its edges must be exact
-};
-
-struct Res {
-    int L;            // match length (mode 2: the advance)
-    i64 start, count; // SA interval
-    bool emit;        // mode 2: an SMEM is to be emitted
-};
+// what the next window is for: the partition point of the query (first window at the model's prediction, later ones
+// gallop/bisect), or the lower / upper end of the run of suffixes sharing >= L bases with it
+enum Phase : int { PH_CTRL, PH_PART, PH_EDGE_DN, PH_EDGE_UP };
 
 // explicit address spaces: LDS (3) for the staged read, global (1) for the index.  Generic pointers would
 // compile to FLAT loads whose waits serialise LDS and HBM traffic.
@@ -171,6 +164,7 @@ struct Res {
 #endif
 typedef const __attribute__((address_space(3))) u64* lds_u64;
 typedef __attribute__((address_space(3))) int* lds_int;
+typedef __attribute__((address_space(3))) unsigned short* lds_u16;
 typedef const __attribute__((address_space(1))) u64* glb_u64;
 typedef const __attribute__((address_space(1))) SaEnt* glb_ent;
 typedef const __attribute__((address_space(1))) RmiRec* glb_rmi;
@@ -181,77 +175,106 @@ __device__ __forceinline__ u64 ext_l(lds_u64 w, int s) {
     return sh ? (a << sh) | (b >> (64 - sh)) : a;
 }
 
+__device__ __forceinline__ u64 lowmask(int k) { return k >= 64 ? ~0ull : (k <= 0 ? 0ull : ((1ull << k) - 1ull)); }
+
 // cold per-read state kept in LDS (group-uniform redundant stores; every lane reads back what it wrote)
 enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_R2_SAVED, ST_ZZ_NEXT, ST_ZZ_SP, ST_ZZ_GUARD, ST_AP_GUARD,
                    ST_SM_BASE, ST_N_SMEMS, ST_HITS_LO, ST_HITS_HI, ST_SEARCHES, ST_FLAGS, ST_LAST_CNT_LO, ST_LAST_CNT_HI,
-                   ST_LAST_S_LO, ST_LAST_S_HI, ST_WINDOWS, ST_WORDS };
+                   ST_LAST_S_LO, ST_LAST_S_HI, ST_WINDOWS,
+                   // the level walk of the search in flight (do not survive a search)
+                   ST_L, ST_SE_LO, ST_SE_HI, ST_EE_LO, ST_EE_HI, ST_NB_LO, ST_NB_HI, ST_LF, ST_CB_LO, ST_CB_HI,
+                   ST_TICKET_LO, ST_TICKET_HI, ST_WORDS };
+// per-read words are cleared when a read is staged; the group's running totals live in registers
 enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2, F_REC = 4, F_LDS_OVF = 8 };
+enum LevelFlag : int { LF_NEED_LO = 1, LF_NEED_HI = 2, LF_HAVE_LAST = 4 };
 
-template <int G>
-struct Grp {
-    static constexpr u64 FULL = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-    glb_ent sa;
-    glb_u64 pac;
-    glb_rmi l2, l1;
-    i64 n;
-    int shift;
-    lds_u64 fw, rc, nfw, nrc;
-    lds_int st;
-    int t, gbase;
+#ifndef WIN_E
+#define WIN_E 3      // suffix-array entries per lane in a window: window = WIN_E * G slots (at most 64)
+#endif
+__host__ __device__ constexpr int win_entries(int G) { return (WIN_E * G > 64) ? 64 / G : WIN_E; }
 
-    __device__ __forceinline__ u64 ballot(bool p) const { return (__ballot(p) >> gbase) & FULL; }
-    __device__ __forceinline__ int shfl(int v, int src) const { return __shfl(v, gbase + src); }
-};
+// LDS bytes of one workgroup: per group the packed read, the SMEM ring of one first-round pass (2 ints per entry),
+// the cold state words and two windows of 16-bit LCPs (the partition window stays cached while edges are followed)
+constexpr int TICKET_CHUNK = 32;     // reads a wavefront draws from the global ticket counter at a time
+
+__host__ __device__ inline size_t seed_lds_group_bytes(int G, int stride, int lcap) {
+    const int groups = BLOCK / G;
+    const int W = win_entries(G) * G;
+    return (((size_t)groups * stride * 8 + (size_t)groups * (2 * lcap + ST_WORDS + W) * sizeof(int)) + 7) & ~(size_t)7;
+}
+// + per wavefront: the ticket chunk it is handing out (count, base)
+inline size_t seed_lds_bytes(int G, const PackGeom& geo, int lcap) {
+    return seed_lds_group_bytes(G, geo.stride, lcap) + (size_t)(BLOCK / 64) * 16;
+}
 
 // ---- compare: compare_read_and_ref_binary* (:226-601) ---------------------------------------------------
-// L = min(cap, n - pos).  lcp < L: less = ref base < read base.  lcp == L: less = (L < ref_len)
-// ("exact": the suffix continues past the query and sorts before it; a suffix that ends first sorts
-// after it, as if followed by T-padding).
-template <int G>
-__device__ __forceinline__ void cmp_entry(const Grp<G>& g, lds_u64 s, int off, int cap, u64 ekey, u64 epos, int& lcp,
-                                          bool& less) {
-    i64 ref_len = g.n - (i64)epos;
-    int L = ref_len < (i64)cap ? (int)ref_len : cap;
-    u64 wq = ext_l(s, off);
-    u64 x = ekey ^ wq;
-    int l;
-    bool lt = false;
-    if (x) { l = __clzll((long long)x) >> 1; lt = ekey < wq; }
-    else {
-        l = 32;
-        if (l < L) {
-            // All 32 key bases agree: the rest comes from the 2-bit text.  Consecutive words are adjacent in
-            // memory (same sector), so CMP_WORDS are fetched per round trip instead of one dependent load per word.
-            const i64 p0 = (i64)epos + 32;
-            glb_u64 pw = g.pac + (p0 >> 5);
-            const int sh = (int)(p0 & 31) * 2;
-            bool done = false;
-            for (int k = 1; !done; k += CMP_WORDS, pw += CMP_WORDS) {
-                u64 w[CMP_WORDS + 1];
+// For E suffix-array entries per lane: L = min(cap, n - pos).  lcp < L: less = ref base < read base.
+// lcp == L: less = (L < ref_len) ("exact": the suffix continues past the query and sorts before it; a suffix that
+// ends first sorts after it, as if followed by T-padding).
+// The 64-bit keys settle most entries; the ones whose 32 key bases all agree continue in the 2-bit text through ONE
+// loop instance shared by the lane's E entries (a wavefront usually has one such entry per read).
+template <int E>
+__device__ __forceinline__ void window_compare(glb_u64 pac, i64 n, lds_u64 s, int off, int cap, const u64 (&ek)[E],
+                                               const u64 (&ep)[E], int (&lcp)[E], bool (&less)[E]) {
+    const u64 wq = ext_l(s, off);
+    int l[E], Lc[E];
+    bool lt[E];
+    unsigned pend = 0;
 #pragma unroll
-                for (int j = 0; j < CMP_WORDS + 1; ++j) w[j] = pw[j];
+    for (int e = 0; e < E; ++e) {
+        const i64 ref_len = n - (i64)ep[e];
+        Lc[e] = ref_len < (i64)cap ? (int)ref_len : cap;
+        const u64 x = ek[e] ^ wq;
+        lt[e] = ek[e] < wq;
+        l[e] = x ? (__clzll((long long)x) >> 1) : 32;
+        if (!x && 32 < Lc[e]) pend |= 1u << e;
+    }
+    while (pend) {
+        const int es = __ffs((int)pend) - 1;
+        pend &= pend - 1;
+        u64 pos = ep[0];
+        int Ls = Lc[0];
 #pragma unroll
-                for (int j = 0; j < CMP_WORDS; ++j) {
-                    if (done) break;
-                    u64 wr = sh ? (w[j] << sh) | (w[j + 1] >> (64 - sh)) : w[j];
-                    u64 q = ext_l(s, off + 32 * (k + j));
-                    u64 y = wr ^ q;
-                    if (y) { l += __clzll((long long)y) >> 1; lt = wr < q; done = true; }
-                    else { l += 32; if (l >= L) done = true; }
-                }
+        for (int e = 1; e < E; ++e)
+            if (es == e) { pos = ep[e]; Ls = Lc[e]; }
+        // Consecutive text words are adjacent in memory (same sector), so CMP_WORDS are fetched per round trip
+        // instead of one dependent load per word.
+        const i64 p0 = (i64)pos + 32;
+        glb_u64 pw = pac + (p0 >> 5);
+        const int sh = (int)(p0 & 31) * 2;
+        int ll = 32;
+        bool llt = false, done = false;
+        for (int k = 1; !done; k += CMP_WORDS, pw += CMP_WORDS) {
+            u64 w[CMP_WORDS + 1];
+#pragma unroll
+            for (int j = 0; j < CMP_WORDS + 1; ++j) w[j] = pw[j];
+#pragma unroll
+            for (int j = 0; j < CMP_WORDS; ++j) {
+                if (done) break;
+                const u64 wr = sh ? (w[j] << sh) | (w[j + 1] >> (64 - sh)) : w[j];
+                const u64 q = ext_l(s, off + 32 * (k + j));
+                const u64 y = wr ^ q;
+                if (y) { ll += __clzll((long long)y) >> 1; llt = wr < q; done = true; }
+                else { ll += 32; if (ll >= Ls) done = true; }
             }
         }
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (es == e) { l[e] = ll; lt[e] = llt; }
     }
-    if (l >= L) { lcp = L; less = (i64)L < ref_len; }
-    else { lcp = l; less = lt; }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const i64 ref_len = n - (i64)ep[e];
+        if (l[e] >= Lc[e]) { lcp[e] = Lc[e]; less[e] = (i64)Lc[e] < ref_len; }
+        else { lcp[e] = l[e]; less[e] = lt[e]; }
+    }
 }
 
 // ---- learned_index_lookup (:186-210): same arithmetic (FP64 FMA + clamp), used as a hint ------------------
-template <int G>
-__device__ __forceinline__ i64 rmi_lookup(const Grp<G>& g, u64 key) {
-    u64 m = g.shift >= 64 ? 0ull : key >> g.shift;
-    double icpt = g.l2[m].icpt, slope = g.l2[m].slope;
-    u64 err = g.l2[m].err;
+__device__ __forceinline__ i64 rmi_lookup(glb_rmi l2, glb_rmi l1, int shift, i64 n, u64 key) {
+    u64 m = shift >= 64 ? 0ull : key >> shift;
+    double icpt = l2[m].icpt, slope = l2[m].slope;
+    u64 err = l2[m].err;
     double x = (double)key;
     double f = fma(slope, x, icpt);
     if (err >> 63) {
@@ -259,377 +282,12 @@ __device__ __forceinline__ i64 rmi_lookup(const Grp<G>& g, u64 key) {
         double pn = (double)(err & 0xffffffffull) - 1.0;
         double c = f < 0.0 ? 0.0 : (f > pn ? pn : f);
         u64 j = ps + (u64)c;
-        f = fma(g.l1[j].slope, x, g.l1[j].icpt);
+        f = fma(l1[j].slope, x, l1[j].icpt);
     }
-    double top = (double)g.n - 1.0;
+    double top = (double)n - 1.0;
     if (f < 0.0) return 0;
-    if (f > top) return g.n - 1;
+    if (f > top) return n - 1;
     return (i64)f;
-}
-
-template <int G>
-__device__ __forceinline__ void scan_window(Grp<G>& g, lds_u64 s, int off, int cap, i64 base, int& lcp, bool& less) {
-    u64 k = g.sa[base + g.t].key, p = g.sa[base + g.t].pos;
-    cmp_entry(g, s, off, cap, k, p, lcp, less);
-    g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
-}
-
-// group-uniform single-slot probe: every lane loads the same entry (one broadcast sector)
-template <int G>
-__device__ __forceinline__ void probe(Grp<G>& g, lds_u64 s, int off, int cap, i64 slot, int& lcp, bool& less) {
-    u64 k = g.sa[slot].key, p = g.sa[slot].pos;
-    cmp_entry(g, s, off, cap, k, p, lcp, less);
-}
-
-#ifndef EDGE_E
-#define EDGE_E 2     // entries per lane when an SMEM interval is followed beyond the first window
-#endif
-
-// value of a per-lane array at window slot `idx` (slot j lives in lane j % G, register j / G)
-template <int G, int E>
-__device__ __forceinline__ int win_at(const Grp<G>& g, const int (&v)[E], int idx) {
-    int r = g.shfl(v[0], idx & (G - 1));
-#pragma unroll
-    for (int e = 1; e < E; ++e) {
-        int y = g.shfl(v[e], idx & (G - 1));
-        if ((idx / G) == e) r = y;
-    }
-    return r;
-}
-
-template <int G, int E>
-__device__ __forceinline__ u64 win_ballot(const Grp<G>& g, const bool (&p)[E]) {
-    u64 m = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) m |= g.ballot(p[e]) << (e * G);
-    return m;
-}
-
-// E*G consecutive slots from `base`: E coalesced loads per lane issued together, then the compares
-template <int G, int E>
-__device__ __forceinline__ void scan_wide(Grp<G>& g, lds_u64 s, int off, int cap, i64 base, int (&lcp)[E], bool (&less)[E]) {
-    u64 ek[E], ep[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { ek[e] = g.sa[base + e * G + g.t].key; ep[e] = g.sa[base + e * G + g.t].pos; }
-#pragma unroll
-    for (int e = 0; e < E; ++e) cmp_entry(g, s, off, cap, ek[e], ep[e], lcp[e], less[e]);
-    g.st[ST_WINDOWS] = g.st[ST_WINDOWS] + 1;
-}
-
-// lowest slot s_edge <= cur with [s_edge, cur] all sharing >= L bases with the query (cur does, cur > 0);
-// nb = LCP of slot s_edge-1 (0 at the array start).  `need`: the caller only wants to know whether at least
-// `need` more slots match (non-emitting searches, third round): stop extending once they do.
-template <int G>
-__device__ __forceinline__ void edge_down_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need, i64& s_edge, int& nb) {
-    constexpr int EE = (EDGE_E * G > 64) ? 64 / G : EDGE_E;
-    constexpr int WE = EE * G;
-    const i64 start = cur;
-    int iter = 0;
-    for (;;) {
-        i64 wb = cur - WE;
-        if (wb < 0) wb = 0;
-        int lcp[EE]; bool less[EE], ge[EE];
-        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
-#pragma unroll
-        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
-        const int ncur = (int)(cur - wb);                 // slots [0,ncur) lie below cur
-        const u64 z = (~win_ballot<G, EE>(g, ge)) & ((ncur >= 64) ? ~0ull : ((1ull << ncur) - 1ull));
-        if (z) {
-            const int hz = 63 - __clzll((long long)z);
-            s_edge = wb + hz + 1;
-            nb = win_at<G, EE>(g, lcp, hz);
-            return;
-        }
-        cur = wb;
-        if (cur == 0) { s_edge = 0; nb = 0; return; }
-        if (start - cur >= need) { s_edge = cur; nb = L; return; }
-        if (++iter >= 2) break;
-    }
-    // large interval: gallop with single-slot probes, bisect, then one window for the exact edge
-    i64 good = cur, bad = -1, step = 4 * WE;
-    for (;;) {
-        i64 p = good - step;
-        if (p < 0) p = 0;
-        int lcp; bool less;
-        probe(g, s, off, L, p, lcp, less);
-        if (lcp >= L) { good = p; if (p == 0) break; if (start - good >= need) { s_edge = good; nb = L; return; } step <<= 1; }
-        else { bad = p; break; }
-    }
-    if (bad < 0) { s_edge = 0; nb = 0; return; }
-    while (good - bad > WE) {
-        i64 mid = bad + (good - bad) / 2;
-        int lcp; bool less;
-        probe(g, s, off, L, mid, lcp, less);
-        if (lcp >= L) good = mid; else bad = mid;
-    }
-    {
-        i64 wb = good - WE;                               // >= bad - ... : window [wb, good) contains bad
-        if (wb < 0) wb = 0;
-        int lcp[EE]; bool less[EE], ge[EE];
-        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
-#pragma unroll
-        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
-        const int ncur = (int)(good - wb);
-        const u64 z = (~win_ballot<G, EE>(g, ge)) & ((ncur >= 64) ? ~0ull : ((1ull << ncur) - 1ull));
-        const int hz = 63 - __clzll((long long)z);
-        s_edge = wb + hz + 1;
-        nb = win_at<G, EE>(g, lcp, hz);
-    }
-}
-
-// highest slot e_edge >= cur with [cur, e_edge] all matching; nb = LCP of slot e_edge+1 (0 at the end)
-template <int G>
-__device__ __forceinline__ void edge_up_impl(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need, i64& e_edge, int& nb) {
-    constexpr int EE = (EDGE_E * G > 64) ? 64 / G : EDGE_E;
-    constexpr int WE = EE * G;
-    constexpr u64 WEFULL = (WE == 64) ? ~0ull : ((1ull << WE) - 1ull);
-    const i64 n = g.n;
-    const i64 start = cur;
-    int iter = 0;
-    for (;;) {
-        i64 wb = cur + 1;                                 // window [wb, wb+WE) clipped to the array
-        if (wb > n - WE) wb = n - WE;
-        int lcp[EE]; bool less[EE], ge[EE];
-        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
-#pragma unroll
-        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
-        const int first = (int)(cur + 1 - wb);            // slots [first, WE) lie above cur
-        const u64 z = (~win_ballot<G, EE>(g, ge)) & WEFULL & ~((1ull << first) - 1ull);
-        if (z) {
-            const int lz = __ffsll((long long)z) - 1;
-            e_edge = wb + lz - 1;
-            nb = win_at<G, EE>(g, lcp, lz);
-            return;
-        }
-        cur = wb + WE - 1;
-        if (cur == n - 1) { e_edge = n - 1; nb = 0; return; }
-        if (cur - start >= need) { e_edge = cur; nb = L; return; }
-        if (++iter >= 2) break;
-    }
-    i64 good = cur, bad = -1, step = 4 * WE;
-    for (;;) {
-        i64 p = good + step;
-        if (p > n - 1) p = n - 1;
-        int lcp; bool less;
-        probe(g, s, off, L, p, lcp, less);
-        if (lcp >= L) { good = p; if (p == n - 1) break; if (good - start >= need) { e_edge = good; nb = L; return; } step <<= 1; }
-        else { bad = p; break; }
-    }
-    if (bad < 0) { e_edge = n - 1; nb = 0; return; }
-    while (bad - good > WE) {
-        i64 mid = good + (bad - good) / 2;
-        int lcp; bool less;
-        probe(g, s, off, L, mid, lcp, less);
-        if (lcp >= L) good = mid; else bad = mid;
-    }
-    {
-        i64 wb = good + 1;                                // window (good, good+WE] contains bad
-        if (wb > n - WE) wb = n - WE;
-        int lcp[EE]; bool less[EE], ge[EE];
-        scan_wide<G, EE>(g, s, off, L, wb, lcp, less);
-#pragma unroll
-        for (int e = 0; e < EE; ++e) ge[e] = lcp[e] >= L;
-        const int first = (int)(good + 1 - wb);
-        const u64 z = (~win_ballot<G, EE>(g, ge)) & WEFULL & ~((1ull << first) - 1ull);
-        const int lz = __ffsll((long long)z) - 1;
-        e_edge = wb + lz - 1;
-        nb = win_at<G, EE>(g, lcp, lz);
-    }
-}
-
-// partition point outside the first window: gallop away from the prediction, bisect, return the base of a
-// window that contains the partition point (or touches the array end it lies beyond)
-template <int G>
-__device__ __forceinline__ i64 relocate_impl(Grp<G>& g, lds_u64 s, int off, int vlen, i64 base, bool above) {
-    const i64 n = g.n;
-    // one loop for both directions: `lo` is a slot known to sort before the query (-1: none yet),
-    // `hi` a slot known not to (n: none yet)
-    i64 lo = above ? base + G - 1 : -1, hi = above ? n : base, step = G;
-    for (;;) {
-        i64 p = above ? lo + step : hi - step;
-        if (p > n - 1) p = n - 1;
-        if (p < 0) p = 0;
-        int l2; bool ls;
-        probe(g, s, off, vlen, p, l2, ls);
-        if (ls) lo = p; else hi = p;
-        if (above ? (!ls || p == n - 1) : (ls || p == 0)) break;
-        step <<= 1;
-    }
-    if (hi == n) return n - G;            // every suffix sorts before the query
-    if (lo < 0) return 0;                 // none does
-    while (hi - lo >= G) {
-        i64 mid = lo + (hi - lo) / 2;
-        int l2; bool ls;
-        probe(g, s, off, vlen, mid, l2, ls);
-        if (ls) lo = mid; else hi = mid;
-    }
-    i64 b = hi - G + 1;                   // window [b, hi] contains lo (hi - lo <= G-1)
-    if (b < 0) b = 0;
-    if (b > n - G) b = n - G;
-    return b;
-}
-
-// Cold paths (run for a minority of searches) are real function calls with by-value arguments and results: their
-// register needs stay out of the hot loop's allocation, which is what decides the kernel's occupancy.
-struct EdgeRes {
-    i64 edge;
-    int nb;
-};
-#ifndef COLD_ATTR
-#define COLD_ATTR __forceinline__   // real calls cost 3x (scratch frames): measured, keep the cold paths inline
-#endif
-template <int G>
-__device__ COLD_ATTR EdgeRes edge_down(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need) {
-    EdgeRes r;
-    edge_down_impl(g, s, off, L, cur, need, r.edge, r.nb);
-    return r;
-}
-template <int G>
-__device__ COLD_ATTR EdgeRes edge_up(Grp<G>& g, lds_u64 s, int off, int L, i64 cur, i64 need) {
-    EdgeRes r;
-    edge_up_impl(g, s, off, L, cur, need, r.edge, r.nb);
-    return r;
-}
-template <int G>
-__device__ COLD_ATTR i64 relocate(Grp<G>& g, lds_u64 s, int off, int vlen, i64 base, bool above) {
-    return relocate_impl(g, s, off, vlen, base, above);
-}
-
-// The one search primitive.  Semantics of mem_search / right_smem_search (and the _tradeoff twins):
-//   maxLCP = longest prefix of the query (<= vlen bases) occurring in the text;
-//   mode 0: L = maxLCP.
-//   mode 1: L = largest l <= maxLCP whose SA interval holds >= min_intv suffixes; [start,count) = interval
-//           (:2365-2574, :2902-2942).
-//   mode 2: third round (:1199-1281): walk the levels maxLCP = L0 > L1 > ... until the interval holds
-//           >= min_intv suffixes or the next level is shorter than min_seed_len.
-#ifndef WIN_E
-#define WIN_E 3      // suffix-array entries per lane in the first window: window = WIN_E * G slots
-#endif
-
-template <int G>
-__device__ __forceinline__ Res do_search(Grp<G>& g, const Req& q, int msl) {
-    constexpr int E = (WIN_E * G > 64) ? 64 / G : WIN_E;   // entries per lane (the window mask is 64 bits)
-    constexpr int W = E * G;                               // first-window width in slots
-    constexpr u64 WFULL = (W == 64) ? ~0ull : ((1ull << W) - 1ull);
-    const i64 n = g.n;
-    lds_u64 s = q.rc ? g.rc : g.fw;
-    const int off = q.off, vlen = q.vlen;
-    u64 key = ext_l(s, off);
-    if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
-    i64 pos = rmi_lookup(g, key);
-    i64 base = pos - W / 2;
-    if (base < 0) base = 0;
-    if (base > n - W) base = n - W;
-    int lcp[E];
-    bool less[E];
-    // first window: WIN_E coalesced loads of G entries each, issued together
-    scan_wide<G, E>(g, s, off, vlen, base, lcp, less);
-    u64 m = win_ballot(g, less);
-    const bool above = (m == WFULL) && base + W < n;
-    const bool below = (m == 0) && base > 0;
-    if (above || below) {
-        i64 b = relocate(g, s, off, vlen, above ? base + W - G : base, above);   // G slots containing the partition point
-        base = b - (W - G) / 2;
-        if (base < 0) base = 0;
-        if (base > n - W) base = n - W;
-        scan_wide<G, E>(g, s, off, vlen, base, lcp, less);
-        m = win_ballot(g, less);
-    }
-    // slots [0,P) sort before the query; the longest match is at one of the two boundary neighbours
-    const int P = __popcll(m);
-    const int la = P > 0 ? win_at(g, lcp, P - 1) : -1;
-    const int lb = P < W ? win_at(g, lcp, P < W ? P : W - 1) : -1;
-    const int c = (la >= lb) ? P - 1 : P;
-    int L = la >= lb ? la : lb;
-    Res out;
-    out.L = L;
-    out.start = base + c;
-    out.count = 1;
-    out.emit = false;
-    if (q.mode == 0) return out;
-    if (q.mode == 2 && L < msl) return out;               // :1204-1208
-    // interval at level L from the window; extended beyond it only when the run touches a window edge
-    i64 s_edge = base + c, e_edge = base + c;
-    int nb_lo = 0, nb_hi = 0;
-    bool need_lo = true, need_hi = true;
-    // third-round bookkeeping (previous level's interval) lives in LDS: rarely touched, 4 registers saved
-    i64 cnt, emit_s = s_edge;
-    int match_len = L;
-    bool have_last = false;
-    // searches whose interval is never emitted at the level where the walk stops (left extensions, the third round)
-    // only need to know that the interval reached min_intv: following it further is wasted traffic
-    const i64 need_more = q.exact ? ((i64)1 << 62) : (i64)q.min_intv;
-    for (;;) {
-        // Levels usually end inside the first window, whose LCPs (computed against the whole query) are still in
-        // registers: resolve the edge from them and touch memory only when the run leaves the window.
-        if (need_lo || need_hi) {
-            bool ge[E];
-#pragma unroll
-            for (int e = 0; e < E; ++e) ge[e] = lcp[e] >= L;
-            const u64 zm = (~win_ballot(g, ge)) & WFULL;       // slots of the window that do NOT reach level L
-            if (need_lo) {
-                bool solved = false;
-                if (s_edge > base && s_edge <= base + W) {
-                    const int ncur = (int)(s_edge - base);      // slots [0,ncur) lie below the current edge
-                    const u64 z = zm & ((ncur >= 64) ? ~0ull : ((1ull << ncur) - 1ull));
-                    if (z) {
-                        const int hz = 63 - __clzll((long long)z);
-                        s_edge = base + hz + 1;
-                        nb_lo = win_at(g, lcp, hz);
-                        solved = true;
-                    } else if (base == 0) { s_edge = 0; nb_lo = 0; solved = true; }
-                    else s_edge = base;
-                } else if (s_edge == 0) { nb_lo = 0; solved = true; }
-                if (!solved) { const EdgeRes er = edge_down(g, s, off, L, s_edge, need_more - (e_edge - s_edge + 1)); s_edge = er.edge; nb_lo = er.nb; }
-            }
-            if (need_hi) {
-                bool solved = false;
-                if (e_edge >= base - 1 && e_edge < base + W - 1) {
-                    const int first = (int)(e_edge + 1 - base);  // slots [first,W) lie above the current edge
-                    const u64 z = zm & ~((1ull << first) - 1ull);
-                    if (z) {
-                        const int lz = __ffsll((long long)z) - 1;
-                        e_edge = base + lz - 1;
-                        nb_hi = win_at(g, lcp, lz);
-                        solved = true;
-                    } else if (base + W >= n) { e_edge = n - 1; nb_hi = 0; solved = true; }
-                    else e_edge = base + W - 1;
-                } else if (e_edge == n - 1) { nb_hi = 0; solved = true; }
-                if (!solved) { const EdgeRes er = edge_up(g, s, off, L, e_edge, need_more - (e_edge - s_edge + 1)); e_edge = er.edge; nb_hi = er.nb; }
-            }
-        }
-        cnt = e_edge - s_edge + 1;
-        const int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
-        if (q.mode == 1) {                                  // (:2568-2573, :2936-2940)
-            if (cnt >= (i64)q.min_intv) { emit_s = s_edge; match_len = L; break; }
-        } else {
-            if (cnt >= (i64)q.min_intv) {                   // :1243-1251
-                if (have_last) {
-                    cnt = ((i64)g.st[ST_LAST_CNT_HI] << 32) | (u64)(unsigned)g.st[ST_LAST_CNT_LO];
-                    emit_s = ((i64)g.st[ST_LAST_S_HI] << 32) | (u64)(unsigned)g.st[ST_LAST_S_LO];
-                } else emit_s = s_edge;
-                match_len = L + 1;
-                break;
-            }
-            if (nxt < msl) { match_len = msl; emit_s = s_edge; break; }   // :1252-1258
-            have_last = true;
-            g.st[ST_LAST_CNT_LO] = (int)(unsigned)(cnt & 0xffffffffll);
-            g.st[ST_LAST_CNT_HI] = (int)(cnt >> 32);
-            g.st[ST_LAST_S_LO] = (int)(unsigned)(s_edge & 0xffffffffll);
-            g.st[ST_LAST_S_HI] = (int)(s_edge >> 32);
-        }
-        L = nxt;
-        need_lo = nb_lo >= L && s_edge > 0;
-        need_hi = nb_hi >= L && e_edge < n - 1;
-    }
-    if (q.mode == 2) {
-        out.emit = cnt < (i64)q.min_intv;                  // :1265
-        if (match_len < msl) match_len = msl;
-    }
-    out.L = match_len;
-    out.start = emit_s;
-    out.count = cnt;
-    return out;
 }
 
 __device__ __forceinline__ bool is_n(lds_u64 mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
@@ -651,6 +309,20 @@ __device__ __forceinline__ int first_n(lds_u64 mask, bool has_n, int from, int l
 }
 
 // ---- the search kernel ---------------------------------------------------------------------------------------
+// Search semantics (mem_search / right_smem_search and the _tradeoff twins, :2131-4189):
+//   maxLCP = longest prefix of the query (<= vlen bases) occurring in the text;
+//   mode 0: L = maxLCP.
+//   mode 1: L = largest l <= maxLCP whose SA interval holds >= min_intv suffixes; [start,count) = interval
+//           (:2365-2574, :2902-2942).
+//   mode 2: third round (:1199-1281): walk the levels maxLCP = L0 > L1 > ... until the interval holds
+//           >= min_intv suffixes or the next level is shorter than min_seed_len.
+// All of it reduces to one question asked of a window of W consecutive slots: where does a predicate that is
+// monotone over the suffix array flip from true to false?
+//   PH_PART     pred = suffix < query                  flip = partition point; its two neighbours carry maxLCP
+//   PH_EDGE_DN  pred = LCP(suffix, query) < L  (below the run)   flip = first slot of the level-L interval
+//   PH_EDGE_UP  pred = LCP(suffix, query) >= L (above the run)   flip = one past its last slot
+// [lo, hi] brackets the flip (lo: highest slot known true, hi: lowest known false); a window that does not
+// contain it moves the bracket and the next window gallops (step doubling) or bisects.
 template <int G>
 #ifndef SEED_MIN_WAVES
 #define SEED_MIN_WAVES 5
@@ -658,111 +330,131 @@ template <int G>
 __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int GROUPS = BLOCK / G;
+    constexpr int E = win_entries(G);                      // entries per lane (the window mask is 64 bits)
+    constexpr int W = E * G;                               // window width in slots
+    constexpr u64 GFULL = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
     const int lane = threadIdx.x & 63;
     const int gib = threadIdx.x / G;
-    const int stride = A.geo.stride, W = A.geo.W, MW = A.geo.MW;
-    u64* rd = reinterpret_cast<u64*>(smem_raw) + (size_t)gib * stride;
-    lds_u64 rdl = (lds_u64)rd;
-    // per group after the packed read: the SMEM ring (3 ints per entry) and the cold part of the read's state
-    lds_int ring = (lds_int)(reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) + (size_t)gib * (3 * A.lcap + ST_WORDS));
-    lds_int sm_start = ring;
-    lds_int sm_end = ring + A.lcap;
-    lds_int sm_cnt = ring + 2 * A.lcap;
-    lds_int st = ring + 3 * A.lcap;
-    Grp<G> g;
-    g.st = st;
-    g.sa = (glb_ent)A.I.sa;
-    g.pac = (glb_u64)A.I.pac;
-    g.l2 = (glb_rmi)A.I.l2;
-    g.l1 = (glb_rmi)A.I.l1;
-    g.n = A.I.n;
-    g.shift = A.I.shift;
-    g.fw = rdl;
-    g.rc = rdl + W;
-    g.nfw = rdl + 2 * W;
-    g.nrc = rdl + 2 * W + MW;
-    g.t = threadIdx.x & (G - 1);
-    g.gbase = lane & ~(G - 1);
+    const int t = threadIdx.x & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    const int stride = A.geo.stride, PW = A.geo.W, MW = A.geo.MW;
     const int cap = A.cap, lcap = A.lcap;
+    u64* rd = reinterpret_cast<u64*>(smem_raw) + (size_t)gib * stride;
+    const lds_u64 fw = (lds_u64)rd, rcs = fw + PW, nfw = fw + 2 * PW, nrc = nfw + MW;
+    // per group after the packed reads: SMEM ring (2 ints per entry), cold state, two windows of 16-bit LCPs
+    const lds_int ring = (lds_int)(reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) +
+                                   (size_t)gib * (2 * lcap + ST_WORDS + W));
+    const lds_int sm_se = ring;               // start | end << 16
+    const lds_int sm_cnt = ring + lcap;
+    const lds_int st = ring + 2 * lcap;
+    const lds_u16 wl = (lds_u16)(st + ST_WORDS);
+    // the wavefront's ticket chunk: [0] tickets handed out, [2..3] first ticket
+    const lds_int wv = (lds_int)(reinterpret_cast<int*>(smem_raw + seed_lds_group_bytes(G, stride, lcap)) + (threadIdx.x >> 6) * 4);
+    const glb_ent sa = (glb_ent)A.I.sa;
+    const glb_u64 pac = (glb_u64)A.I.pac;
+    const glb_rmi l2 = (glb_rmi)A.I.l2, l1 = (glb_rmi)A.I.l1;
+    const i64 n = A.I.n;
     const int hits_per_smem = A.opt.hits_per_smem;
-    // reads are pulled with one ticket atomic per read (measured 9 % faster than a static round-robin deal: reads differ
-    // 3x in cost); the read length travels in the packed record, so no dependent offset loads follow the ticket
-    for (;;) {
-        unsigned long long ticket = 0;
-        if (g.t == 0) ticket = atomicAdd(&A.counters[0], 1ull);
-        ticket = __shfl(ticket, g.gbase);
-        if (ticket >= (unsigned long long)A.nreads) break;
-        const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
-        const u64* src = A.packed + rid * stride;
-        const int l_seq = (int)src[stride - 1];          // k_pack_reads stores the length in the last word
-        SlotRec* slots = A.slots + (i64)ticket * cap;
-        if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
-            // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
-            // here such a read yields no seeds and is flagged through slot_cnt = -1
-            if (g.t == 0) { A.slot_cnt[rid] = l_seq > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0; }
-            continue;
-        }
-        // ---- stage the packed read in LDS (coalesced 8-byte loads) ------------------------------------
-        bool any_n = false;
-        for (int k = g.t; k < stride - 1; k += G) {
-            u64 v = src[k];
-            rd[k] = v;
-            if (k >= 2 * W && k < 2 * W + MW) any_n |= (v != 0);
-        }
-        const bool has_n = g.ballot(any_n) != 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- per-read state (group-uniform) ----------------------------------------------------------------
-        int pivot = 0;
-        int msl = A.opt.min_seed_len, min_intv = 1;
-        int pc = PC_ALLPOS_TOP;
-        for (int k = 0; k < ST_WORDS; ++k) st[k] = 0;
-#define SET_PIVOT(p_) do { pivot = (p_); } while (0)
-#define l_pivot (l_seq - 1 - pivot)
+#define GBALLOT(p_) ((__ballot(p_) >> gbase) & GFULL)
+#define LD64(lo_) (((i64)st[(lo_) + 1] << 32) | (u64)(unsigned)st[lo_])
+#define ST64(lo_, v_) do { const i64 v__ = (v_); st[lo_] = (int)(unsigned)(v__ & 0xffffffffll); st[(lo_) + 1] = (int)(v__ >> 32); } while (0)
 #define FLAG(f_) ((st[ST_FLAGS] & (f_)) != 0)
 #define SETFLAG(f_, v_) do { st[ST_FLAGS] = (v_) ? (st[ST_FLAGS] | (f_)) : (st[ST_FLAGS] & ~(f_)); } while (0)
-        for (;;) {
-            // ---- control: advance to the next search request -------------------------------------------------
-            Req q;
+#define LDS_HANDOFF() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+    // ---- per-read registers (group-uniform) ----------------------------------------------------------------------
+    int pc = PC_FETCH, phase = PH_CTRL;
+    int pivot = 0, l_seq = 0, msl = A.opt.min_seed_len, min_intv = 1;
+    bool has_n = false;
+    // the request in flight
+    int q_kind = 0, q_mode = 0, off = 0, vlen = 0, capc = 0;
+    bool q_rc = false, q_exact = false;
+    i64 base = 0, lo = -1, hi = n;
+    int stepk = 0;
+    unsigned acc_searches = 0, acc_windows = 0;             // of this group's completed reads
+    if (lane == 0) wv[0] = TICKET_CHUNK;                    // empty chunk
+    LDS_HANDOFF();
+
+    for (;;) {
+        // ================= control: reads without a request in flight produce the next one =========================
+        if (phase == PH_CTRL) {
             bool have = false;
-            while (!have && pc != PC_DONE) {
+            do {
                 switch (pc) {
+                case PC_FETCH: {      // pull the next read (reads differ 3x in cost: dynamic hand-out, no static deal)
+                    // One global atomic per TICKET_CHUNK reads: the wavefront keeps a chunk in LDS and its groups draw
+                    // from it with an LDS atomic.  (One global atomic per read on a single address caps the whole
+                    // kernel at ~30 M reads/s.)  The groups that are here together run in lockstep, so the refill
+                    // below cannot race with another draw of the same wavefront.
+                    int idx = TICKET_CHUNK;
+                    if (t == 0) idx = __hip_atomic_fetch_add(wv, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const u64 old_base = ((u64)(unsigned)wv[3] << 32) | (unsigned)wv[2];
+                    const bool over = t == 0 && idx >= TICKET_CHUNK;
+                    const unsigned long long mo = __ballot(over);
+                    unsigned long long ticket = old_base + (unsigned)idx;
+                    if (mo) {
+                        const int first = __ffsll((long long)mo) - 1;
+                        unsigned long long nb = 0;
+                        if (lane == first) {
+                            nb = atomicAdd(&A.counters[0], (unsigned long long)TICKET_CHUNK);
+                            wv[0] = __popcll(mo); wv[2] = (int)(unsigned)(nb & 0xffffffffull); wv[3] = (int)(nb >> 32);
+                        }
+                        nb = __shfl(nb, first);
+                        if (over) ticket = nb + (unsigned)__popcll(mo & ((1ull << lane) - 1ull));
+                    }
+                    ticket = __shfl(ticket, gbase);
+                    if (ticket >= (unsigned long long)A.nreads) { pc = PC_EXIT; break; }
+                    const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
+                    const u64* src = A.packed + rid * stride;
+                    l_seq = (int)src[stride - 1];          // k_pack_reads stores the length in the last word
+                    if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
+                        // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
+                        // here such a read yields no seeds and is flagged through slot_cnt = -1
+                        if (t == 0) { A.slot_cnt[rid] = l_seq > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0; }
+                        break;                              // stay in PC_FETCH
+                    }
+                    // stage the packed read in LDS (coalesced 8-byte loads) and clear the cold state
+                    bool any_n = false;
+                    for (int k = t; k < stride - 1; k += G) {
+                        u64 v = src[k];
+                        rd[k] = v;
+                        if (k >= 2 * PW && k < 2 * PW + MW) any_n |= (v != 0);
+                    }
+                    for (int k = t; k < ST_WORDS; k += G) st[k] = 0;
+                    has_n = GBALLOT(any_n) != 0;
+                    LDS_HANDOFF();
+                    st[ST_TICKET_LO] = (int)(unsigned)(ticket & 0xffffffffull);
+                    st[ST_TICKET_HI] = (int)(ticket >> 32);
+                    pivot = 0; msl = A.opt.min_seed_len; min_intv = 1;
+                    pc = PC_ALLPOS_TOP;
+                    break;
+                }
                 case PC_ALLPOS_TOP:   // Learned_getSMEMsAllPosOneThread loop head (:916) + step1 entry (:1691-1723)
                     if (pivot >= l_seq || ++st[ST_AP_GUARD] > 4 * l_seq + 16) { pc = PC_R3_INIT; break; }
                     st[ST_BEFORE] = st[ST_N_SMEMS]; st[ST_SM_BASE] = st[ST_BEFORE]; SETFLAG(F_REC, true);
-                    if (is_n(g.nfw, pivot)) {
-                        if (l_seq - pivot < msl) SET_PIVOT(l_seq); else SET_PIVOT(pivot + 1);
+                    if (is_n(nfw, pivot)) {
+                        pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
                         pc = PC_AFTER_STEP1;
-                    } else if (pivot != 0 && !is_n(g.nfw, pivot - 1)) {
+                    } else if (pivot != 0 && !is_n(nfw, pivot - 1)) {
                         st[ST_ZZ_NEXT] = l_seq; SETFLAG(F_ZZ_CHECK, true); SETFLAG(F_ZZ_RET_ONEPOS, false); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
                         pc = PC_ZZ_TOP;
-                    } else {
-                        q.kind = K_S1_RIGHT; q.exact = true; q.rc = false; q.off = pivot;
-                        q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
-                        have = true;
-                    }
+                    } else { q_kind = K_S1_RIGHT; have = true; }
                     break;
                 case PC_ZZ_TOP:       // zig-zag loop head (:1724-1737, :1969)
                     if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
-                    if (FLAG(F_ZZ_CHECK) && is_n(g.nfw, st[ST_ZZ_SP])) {
-                        if (l_seq - st[ST_ZZ_SP] < msl) { SET_PIVOT(l_seq); st[ST_ZZ_SP] = l_seq; }
-                        else { st[ST_ZZ_SP] += 1; SET_PIVOT(pivot + 1); }
+                    if (FLAG(F_ZZ_CHECK) && is_n(nfw, st[ST_ZZ_SP])) {
+                        if (l_seq - st[ST_ZZ_SP] < msl) { pivot = l_seq; st[ST_ZZ_SP] = l_seq; }
+                        else { st[ST_ZZ_SP] += 1; pivot = pivot + 1; }
                         break;
                     }
-                    q.kind = K_ZZ_LEFT; q.exact = false; q.rc = true; q.off = l_pivot;
-                    q.vlen = first_n(g.nrc, has_n, l_pivot, l_seq) - l_pivot; q.min_intv = min_intv;
-                    q.mode = min_intv != 1 ? 1 : 0;
-                    have = true;
+                    q_kind = K_ZZ_LEFT; have = true;
                     break;
                 case PC_ZZ_RIGHT:
-                    q.kind = K_ZZ_RIGHT; q.exact = true; q.rc = false; q.off = pivot;
-                    q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
-                    have = true;
+                    q_kind = K_ZZ_RIGHT; have = true;
                     break;
                 case PC_ZZ_END:       // set_forward_pivot(raux, next_pivot) (:1893, :2125)
-                    SET_PIVOT(st[ST_ZZ_NEXT]);
+                    pivot = st[ST_ZZ_NEXT];
                     pc = FLAG(F_ZZ_RET_ONEPOS) ? PC_R2_AFTER : PC_AFTER_STEP1;
                     break;
                 case PC_AFTER_STEP1:  // re-seeding loop entry (:921-923)
@@ -777,127 +469,283 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     if (st[ST_R2_K] >= st[ST_AFTER]) { pc = PC_ALLPOS_TOP; break; }
                     const int k = st[ST_R2_K]++ - st[ST_BEFORE];
                     st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
-                    const int qbeg = sm_start[k], qend = sm_end[k], cnt = sm_cnt[k];
-                    if (qend - qbeg < A.opt.split_len || cnt > A.opt.split_width) { SET_PIVOT(st[ST_R2_NEXT]); break; }
-                    SET_PIVOT((qbeg + qend) >> 1);
+                    const int se = sm_se[k], cnt = sm_cnt[k];
+                    const int qbeg = se & 0xffff, qend = (int)((unsigned)se >> 16);
+                    if (qend - qbeg < A.opt.split_len || cnt > A.opt.split_width) break;   // pivot stays (:929-931)
+                    pivot = (qbeg + qend) >> 1;
                     min_intv = cnt + 1;
-                    if (is_n(g.nfw, pivot)) {
-                        if (l_seq - pivot < msl) SET_PIVOT(l_seq); else SET_PIVOT(pivot + 1);
+                    if (is_n(nfw, pivot)) {
+                        pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
                         pc = PC_R2_AFTER;
-                    } else if (pivot != 0 && !is_n(g.nfw, pivot - 1)) {
-                        q.kind = K_OP_MEM; q.exact = false; q.rc = false; q.off = pivot;
-                        q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv;
-                        q.mode = min_intv != 1 ? 1 : 0;
-                        have = true;
-                    } else {
-                        q.kind = K_OP_SMEM; q.exact = true; q.rc = false; q.off = pivot;
-                        q.vlen = first_n(g.nfw, has_n, pivot, l_seq) - pivot; q.min_intv = min_intv; q.mode = 1;
-                        have = true;
-                    }
+                    } else if (pivot != 0 && !is_n(nfw, pivot - 1)) { q_kind = K_OP_MEM; have = true; }
+                    else { q_kind = K_OP_SMEM; have = true; }
                     break;
                 }
                 case PC_R2_AFTER:     // (:945-946)
                     min_intv = st[ST_R2_SAVED];
-                    SET_PIVOT(st[ST_R2_NEXT]);
+                    pivot = st[ST_R2_NEXT];
                     pc = PC_R2_LOOP;
                     break;
                 case PC_R3_INIT:      // src/bwamem.cpp:1385-1394
                     if (A.opt.rounds >= 3 && A.opt.max_mem_intv > 0 && !FLAG(F_LDS_OVF)) {
                         min_intv = A.opt.max_mem_intv;
                         msl = A.opt.min_seed_len + 1;
-                        SET_PIVOT(0);
+                        pivot = 0;
                         pc = PC_R3_TOP;
                     } else pc = PC_DONE;
                     break;
                 case PC_R3_TOP: {     // Learned_bwtSeedStrategyAllPosOneThread loop head (:982-1012)
                     if (!(pivot < l_seq - msl + 1)) { pc = PC_DONE; break; }
-                    if (is_n(g.nfw, pivot)) { SET_PIVOT(pivot + 1); break; }
-                    const int valid = first_n(g.nfw, has_n, pivot, l_seq) - pivot;
-                    if (valid < msl) { SET_PIVOT(pivot + valid); break; }
-                    q.kind = K_R3; q.exact = false; q.rc = false; q.off = pivot; q.vlen = valid; q.min_intv = min_intv; q.mode = 2;
-                    have = true;
+                    if (is_n(nfw, pivot)) { pivot = pivot + 1; break; }
+                    const int valid = first_n(nfw, has_n, pivot, l_seq) - pivot;
+                    if (valid < msl) { pivot = pivot + valid; break; }
+                    q_kind = K_R3; have = true;
+                    break;
+                }
+                case PC_DONE: {       // publish the read's SMEM count / hit count; its slots are already written
+                    const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
+                    if (t == 0) {
+                        const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
+                        const int n_smems = st[ST_N_SMEMS];
+                        const i64 n_hits = LD64(ST_HITS_LO);
+                        const bool ovf = n_smems > cap || FLAG(F_LDS_OVF);
+                        A.slot_cnt[rid] = ovf ? 0 : n_smems;
+                        A.slot_hits[rid] = ovf ? 0 : n_hits;
+                        A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
+                        if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
+                    }
+                    if (!(st[ST_N_SMEMS] > cap || FLAG(F_LDS_OVF))) { acc_searches += (unsigned)st[ST_SEARCHES]; acc_windows += (unsigned)st[ST_WINDOWS]; }
+                    pc = PC_FETCH;
                     break;
                 }
                 default: pc = PC_DONE; break;
                 }
+            } while (!have && pc != PC_EXIT);
+            if (pc == PC_EXIT) {
+                if (t == 0) { atomicAdd(&A.counters[1], (unsigned long long)acc_searches); atomicAdd(&A.counters[3], (unsigned long long)acc_windows); }
+                break;
             }
-            if (!have) break;
-            // ---- the single search call site ----------------------------------------------------------------------
+            // ---- the request: query = bases [off, off+vlen) of one strand; first window at the model's prediction
+            q_rc = q_kind == K_ZZ_LEFT;
+            off = q_rc ? l_seq - 1 - pivot : pivot;
+            vlen = first_n(q_rc ? nrc : nfw, has_n, off, l_seq) - off;
+            q_exact = q_kind == K_S1_RIGHT || q_kind == K_ZZ_RIGHT || q_kind == K_OP_SMEM;
+            q_mode = q_kind == K_R3 ? 2 : ((q_exact || min_intv != 1) ? 1 : 0);
             st[ST_SEARCHES] = st[ST_SEARCHES] + 1;
-            const Res r = do_search(g, q, msl);
-            // ---- apply -------------------------------------------------------------------------------------------
+            u64 key = ext_l(q_rc ? rcs : fw, off);
+            if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
+            const i64 pos = rmi_lookup(l2, l1, A.I.shift, n, key);
+            base = pos - W / 2;
+            if (base < 0) base = 0;
+            if (base > n - W) base = n - W;
+            lo = -1; hi = n; stepk = 0; capc = vlen;
+            phase = PH_PART;
+        }
+
+        // ================= window: E coalesced loads of G entries each, issued together, then the compares ===========
+        const lds_u64 s = q_rc ? rcs : fw;
+        int lcp[E];
+        bool less[E];
+        {
+            u64 ek[E], ep[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { ek[e] = sa[base + e * G + t].key; ep[e] = sa[base + e * G + t].pos; }
+            st[ST_WINDOWS] = st[ST_WINDOWS] + 1;
+            window_compare<E>(pac, n, s, off, capc, ek, ep, lcp, less);
+        }
+        u64 m = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool p = phase == PH_PART ? less[e] : ((lcp[e] >= capc) == (phase == PH_EDGE_UP));
+            m |= GBALLOT(p) << (e * G);
+        }
+        // slots <= lo are known true, slots >= hi known false (also removes the far side of a clipped edge window)
+        m = (m | lowmask((int)((lo - base + 1 > W) ? W : (lo - base + 1 < 0 ? 0 : lo - base + 1)))) &
+            lowmask((int)((hi - base > W) ? W : (hi - base < 0 ? 0 : hi - base)));
+        const int P = __popcll(m);
+        const bool at_lo = base == 0 || (phase == PH_EDGE_UP && base == lo + 1);
+        const bool at_hi = base + W == n || (phase == PH_EDGE_DN && base + W == hi);
+        const bool found = (P > 0 && P < W) || (P == 0 && at_lo) || (P == W && at_hi);
+
+        // ================= resolve ================================================================================
+        bool go_level = false, finished = false;
+        int L = 0, nb_lo = 0, nb_hi = 0, lf = 0;
+        i64 s_edge = 0, e_edge = 0, cb = base;
+        int r_L = 0;
+        i64 r_start = 0, r_count = 1;
+        bool r_emit = false;
+        if (found) {
+            // LCPs of the two slots around the flip, through LDS (region 0: partition window, kept for the level walk)
+            const int woff = phase == PH_PART ? 0 : W;
+#pragma unroll
+            for (int e = 0; e < E; ++e) wl[woff + e * G + t] = (unsigned short)lcp[e];
+            LDS_HANDOFF();
+            const int lm = P > 0 ? (int)wl[woff + P - 1] : -1;
+            const int lp = P < W ? (int)wl[woff + P] : -1;
+            if (phase == PH_PART) {
+                // slots [0,P) sort before the query; the longest match is at one of the two boundary neighbours
+                const int c = (lm >= lp) ? P - 1 : P;
+                L = lm >= lp ? lm : lp;
+                r_L = L; r_start = base + c; r_count = 1;
+                if (q_mode == 0 || (q_mode == 2 && L < msl)) finished = true;       // (:1204-1208)
+                else {
+                    s_edge = e_edge = base + c;
+                    lf = LF_NEED_LO | LF_NEED_HI;
+                    go_level = true;
+                }
+            } else {
+                L = st[ST_L]; nb_lo = st[ST_NB_LO]; nb_hi = st[ST_NB_HI]; lf = st[ST_LF];
+                s_edge = LD64(ST_SE_LO); e_edge = LD64(ST_EE_LO); cb = LD64(ST_CB_LO);
+                if (phase == PH_EDGE_DN) { s_edge = base + P; nb_lo = P > 0 ? lm : 0; lf &= ~LF_NEED_LO; }
+                else { e_edge = base + P - 1; nb_hi = P < W ? lp : 0; lf &= ~LF_NEED_HI; }
+                go_level = true;
+            }
+        } else {
+            if (P == W) lo = base + W - 1; else hi = base;
+            bool stop = false;
+            if (phase != PH_PART && !q_exact) {
+                // the interval is not emitted at the level where the walk stops (left extensions, third round): it is
+                // enough to know that it reached min_intv suffixes
+                s_edge = LD64(ST_SE_LO); e_edge = LD64(ST_EE_LO);
+                if (phase == PH_EDGE_DN ? (e_edge - hi + 1 >= (i64)min_intv) : (lo - s_edge + 1 >= (i64)min_intv)) {
+                    L = st[ST_L]; nb_lo = st[ST_NB_LO]; nb_hi = st[ST_NB_HI]; lf = st[ST_LF]; cb = LD64(ST_CB_LO);
+                    if (phase == PH_EDGE_DN) { s_edge = hi; nb_lo = L; lf &= ~LF_NEED_LO; }
+                    else { e_edge = lo; nb_hi = L; lf &= ~LF_NEED_HI; }
+                    stop = go_level = true;
+                }
+            }
+            if (!stop) {
+                if (lo < 0) { base = hi - ((i64)W << stepk); ++stepk; if (base < 0) base = 0; }                       // gallop down
+                else if (hi >= n) { base = lo + 1 + (((i64)W << stepk) - W); ++stepk; if (base > n - W) base = n - W; }  // gallop up
+                else if (hi - lo <= W - 1) { base = lo; if (base > n - W) base = n - W; }                            // final window
+                else base = lo + (hi - lo) / 2 - W / 2;                                                              // bisect
+            }
+        }
+        if (go_level) {
+            // walk the levels L0 > L1 > ...; an edge that leaves the cached partition window becomes an edge request
+            for (;;) {
+                if (lf & LF_NEED_LO) {
+                    i64 k = s_edge - cb;                          // cached slots [0,k) lie below the current edge
+                    if (k > 0 && k <= W) {
+                        int v = 0;
+                        while (k > 0 && (v = (int)wl[k - 1]) >= L) --k;
+                        s_edge = cb + k;
+                        if (k > 0) { nb_lo = v; lf &= ~LF_NEED_LO; }
+                        else if (cb == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; }
+                    } else if (s_edge == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; }
+                    if (lf & LF_NEED_LO) {
+                        phase = PH_EDGE_DN; lo = -1; hi = s_edge; stepk = 1;
+                        base = s_edge - W; if (base < 0) base = 0;
+                        break;
+                    }
+                }
+                if (lf & LF_NEED_HI) {
+                    i64 k = e_edge - cb;                          // cached slots (k,W) lie above the current edge
+                    if (k >= -1 && k < W - 1) {
+                        int v = 0;
+                        while (k < W - 1 && (v = (int)wl[k + 1]) >= L) ++k;
+                        e_edge = cb + k;
+                        if (k < W - 1) { nb_hi = v; lf &= ~LF_NEED_HI; }
+                        else if (cb + W >= n) { nb_hi = 0; lf &= ~LF_NEED_HI; }
+                    } else if (e_edge == n - 1) { nb_hi = 0; lf &= ~LF_NEED_HI; }
+                    if (lf & LF_NEED_HI) {
+                        phase = PH_EDGE_UP; lo = e_edge; hi = n; stepk = 1;
+                        base = e_edge + 1; if (base > n - W) base = n - W;
+                        break;
+                    }
+                }
+                const i64 cnt = e_edge - s_edge + 1;
+                const int nxt = nb_lo > nb_hi ? nb_lo : nb_hi;
+                if (q_mode == 1) {                                  // (:2568-2573, :2936-2940)
+                    if (cnt >= (i64)min_intv) { r_L = L; r_start = s_edge; r_count = cnt; finished = true; break; }
+                } else {
+                    if (cnt >= (i64)min_intv) {                     // :1243-1251
+                        if (lf & LF_HAVE_LAST) { r_count = LD64(ST_LAST_CNT_LO); r_start = LD64(ST_LAST_S_LO); }
+                        else { r_count = cnt; r_start = s_edge; }
+                        r_L = L + 1;
+                        finished = true;
+                        break;
+                    }
+                    if (nxt < msl) { r_L = msl; r_start = s_edge; r_count = cnt; finished = true; break; }   // :1252-1258
+                    lf |= LF_HAVE_LAST;
+                    ST64(ST_LAST_CNT_LO, cnt);
+                    ST64(ST_LAST_S_LO, s_edge);
+                }
+                L = nxt;
+                lf = (lf & LF_HAVE_LAST) | ((nb_lo >= L && s_edge > 0) ? LF_NEED_LO : 0) | ((nb_hi >= L && e_edge < n - 1) ? LF_NEED_HI : 0);
+            }
+            if (finished) {
+                if (q_mode == 2) {
+                    r_emit = r_count < (i64)min_intv;              // :1265
+                    if (r_L < msl) r_L = msl;
+                }
+            } else {
+                capc = L;
+                st[ST_L] = L; st[ST_NB_LO] = nb_lo; st[ST_NB_HI] = nb_hi; st[ST_LF] = lf;
+                ST64(ST_SE_LO, s_edge); ST64(ST_EE_LO, e_edge); ST64(ST_CB_LO, cb);
+            }
+        }
+        if (finished) {
+            // ---- apply the search result to the read's pivot logic ------------------------------------------------------
             bool emit = false;
-            int e_start = pivot, e_end = pivot;
-            switch (q.kind) {
+            const int e_start = pivot;
+            int e_end = pivot;
+            switch (q_kind) {
             case K_S1_RIGHT:          // (:1852-1893)
-                emit = r.L >= msl; e_end = pivot + r.L;
+            case K_ZZ_RIGHT:          // (:1846-1848)
+            case K_OP_SMEM:           // (:2093-2125)
+                emit = r_L >= msl; e_end = pivot + r_L;
                 break;
             case K_ZZ_LEFT:           // (:1774-1777)
-                SET_PIVOT(pivot - r.L + 1);
+                pivot = pivot - r_L + 1;
                 pc = (st[ST_ZZ_NEXT] - pivot < msl) ? PC_ZZ_END : PC_ZZ_RIGHT;
                 break;
-            case K_ZZ_RIGHT:          // (:1846-1848)
-                emit = r.L >= msl; e_end = pivot + r.L;
-                break;
             case K_OP_MEM:            // (:1967-1969)
-                st[ST_ZZ_NEXT] = pivot + r.L; SETFLAG(F_ZZ_CHECK, false); SETFLAG(F_ZZ_RET_ONEPOS, true); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
+                st[ST_ZZ_NEXT] = pivot + r_L; SETFLAG(F_ZZ_CHECK, false); SETFLAG(F_ZZ_RET_ONEPOS, true); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
                 pc = PC_ZZ_TOP;
                 break;
-            case K_OP_SMEM:           // (:2093-2125)
-                emit = r.L >= msl; e_end = pivot + r.L;
-                break;
-            case K_R3:                // (:1204-1208, :1265-1281)
-                if (r.L < msl && !r.emit) { /* too short: advance by min_seed_len */ }
-                emit = r.emit; e_end = pivot + r.L;
+            default:                  // K_R3 (:1204-1208, :1265-1281)
+                emit = r_emit; e_end = pivot + r_L;
                 break;
             }
             if (emit) {               // kv_push of mem_tl + hits (:2639-2657, :1266-1277)
-                if (st[ST_N_SMEMS] < cap && g.t == 0) {
+                const int ns = st[ST_N_SMEMS];
+                if (ns < cap && t == 0) {
+                    const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
                     SlotRec sr;
-                    sr.start = e_start; sr.end = e_end; sr.sa_start = r.start; sr.count = r.count;
-                    slots[st[ST_N_SMEMS]] = sr;
+                    sr.start = e_start; sr.end = e_end; sr.sa_start = r_start; sr.count = r_count;
+                    A.slots[(i64)ticket * cap + ns] = sr;
                 }
                 if (FLAG(F_REC)) {
-                    const int k = st[ST_N_SMEMS] - st[ST_SM_BASE];
+                    const int k = ns - st[ST_SM_BASE];
                     if (k < lcap) {
                         // group-uniform redundant LDS stores (every lane writes the same value): no hand-off needed
-                        sm_start[k] = e_start;
-                        sm_end[k] = e_end;
-                        sm_cnt[k] = r.count > (i64)INT_MAX ? INT_MAX : (int)r.count;
+                        sm_se[k] = e_start | (e_end << 16);
+                        sm_cnt[k] = r_count > (i64)INT_MAX ? INT_MAX : (int)r_count;
                     } else SETFLAG(F_LDS_OVF, true);
                 }
-                st[ST_N_SMEMS] = st[ST_N_SMEMS] + 1;
-                i64 h = r.count;
+                st[ST_N_SMEMS] = ns + 1;
+                i64 h = r_count;
                 if (hits_per_smem > 0 && h > hits_per_smem) h = hits_per_smem;
-                h += ((i64)st[ST_HITS_HI] << 32) | (u64)(unsigned)st[ST_HITS_LO];
-                st[ST_HITS_LO] = (int)(unsigned)(h & 0xffffffffll);
-                st[ST_HITS_HI] = (int)(h >> 32);
+                h += LD64(ST_HITS_LO);
+                ST64(ST_HITS_LO, h);
             }
-            switch (q.kind) {
-            case K_S1_RIGHT: SET_PIVOT(pivot + r.L); pc = PC_AFTER_STEP1; break;
-            case K_ZZ_RIGHT: st[ST_ZZ_SP] = pivot + r.L; SET_PIVOT(st[ST_ZZ_SP]); pc = PC_ZZ_TOP; break;
-            case K_OP_SMEM: SET_PIVOT(pivot + r.L); pc = PC_R2_AFTER; break;
-            case K_R3: SET_PIVOT(pivot + (r.L < msl ? msl : r.L)); pc = PC_R3_TOP; break;
+            switch (q_kind) {
+            case K_S1_RIGHT: pivot = pivot + r_L; pc = PC_AFTER_STEP1; break;
+            case K_ZZ_RIGHT: pivot = pivot + r_L; st[ST_ZZ_SP] = pivot; pc = PC_ZZ_TOP; break;
+            case K_OP_SMEM: pivot = pivot + r_L; pc = PC_R2_AFTER; break;
+            case K_R3: pivot = pivot + (r_L < msl ? msl : r_L); pc = PC_R3_TOP; break;
             default: break;
             }
+            phase = PH_CTRL;
         }
-#undef SET_PIVOT
-#undef l_pivot
-        if (g.t == 0) {
-            const int n_smems = st[ST_N_SMEMS];
-            const unsigned searches = (unsigned)st[ST_SEARCHES];
-            const i64 n_hits = ((i64)st[ST_HITS_HI] << 32) | (u64)(unsigned)st[ST_HITS_LO];
-            const bool ovf = n_smems > cap || FLAG(F_LDS_OVF);
-            A.slot_cnt[rid] = ovf ? 0 : n_smems;
-            A.slot_hits[rid] = ovf ? 0 : n_hits;
-            A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
-            if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
-            else { atomicAdd(&A.counters[1], (unsigned long long)searches); atomicAdd(&A.counters[3], (unsigned long long)(unsigned)st[ST_WINDOWS]); }
-        }
+    }
+#undef GBALLOT
+#undef LD64
+#undef ST64
 #undef FLAG
 #undef SETFLAG
-        __builtin_amdgcn_wave_barrier();
-    }
+#undef LDS_HANDOFF
 }
 
 }  // namespace seedk
