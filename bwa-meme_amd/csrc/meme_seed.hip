@@ -223,8 +223,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     const i64* pending = nullptr;
     for (int tier = 0;; ++tier) {
         // overflow tiers hold a 512-entry SMEM ring per read in LDS: run them 32 lanes per read (8 reads per block)
-        const int G = tier == 0 ? (int)ctx->group_lanes : 32;
-        const int groups = BLOCK / G;
+        int G = tier == 0 ? (int)ctx->group_lanes : 32;
         const int cap = tier == 0 ? (int)ctx->smem_cap : TIER_CAP[tier];
         const int lcap = cap < TIER_LCAP[tier] ? cap : TIER_LCAP[tier];
         DevBuf& sb = ctx->slots[tier];
@@ -251,6 +250,8 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.counters = (unsigned long long*)ctx->counters.p;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
+        while (G < 32 && seed_lds_bytes(G, geo, lcap) > (size_t)160 * 1024) G *= 2;   // long reads: fewer reads per workgroup
+        const int groups = BLOCK / G;
         size_t lds = seed_lds_bytes(G, geo, lcap);
         i64 want = (n_todo + groups - 1) / groups;
         i64 blocks = ctx->seed_blocks > 0 ? ctx->seed_blocks : (i64)dev_cus * ctx->seed_blocks_per_cu;
@@ -258,11 +259,13 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         if (blocks < 1) blocks = 1;
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         switch (G) {
+        case 1: rc = launch_k_seed<1>(ctx, A, lds, blocks); break;
+        case 2: rc = launch_k_seed<2>(ctx, A, lds, blocks); break;
         case 4: rc = launch_k_seed<4>(ctx, A, lds, blocks); break;
         case 8: rc = launch_k_seed<8>(ctx, A, lds, blocks); break;
         case 16: rc = launch_k_seed<16>(ctx, A, lds, blocks); break;
         case 32: rc = launch_k_seed<32>(ctx, A, lds, blocks); break;
-        default: meme_set_error("group_lanes must be 4, 8, 16 or 32"); return MEME_E_ARG;
+        default: meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG;
         }
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));

@@ -48,7 +48,10 @@ struct SlotRec {          // search-kernel output, one per SMEM
 
 constexpr int N_TIERS = 3;
 constexpr int TIER_CAP[N_TIERS] = {64, 2048, 65536};   // global SMEM slots per read; tier 0 is tunable
-constexpr int TIER_LCAP[N_TIERS] = {16, 512, 512};     // LDS ring: SMEMs of one first-round pass (<= read length)
+#ifndef LCAP0
+#define LCAP0 16
+#endif
+constexpr int TIER_LCAP[N_TIERS] = {LCAP0, 512, 512};     // LDS ring: SMEMs of one first-round pass (<= read length)
 
 struct PackGeom {
     int W;        // u64 words per strand (>= ceil(maxlen/32) + 2)
@@ -191,7 +194,10 @@ enum LevelFlag : int { LF_NEED_LO = 1, LF_NEED_HI = 2, LF_HAVE_LAST = 4 };
 #ifndef WIN_E
 #define WIN_E 3      // suffix-array entries per lane in a window: window = WIN_E * G slots (at most 64)
 #endif
-__host__ __device__ constexpr int win_entries(int G) { return (WIN_E * G > 64) ? 64 / G : WIN_E; }
+#ifndef WIN_SLOTS
+#define WIN_SLOTS 12  // ... but at least this many slots
+#endif
+__host__ __device__ constexpr int win_entries(int G) { return (WIN_E * G > 64) ? 64 / G : (WIN_E * G < WIN_SLOTS ? WIN_SLOTS / G : WIN_E); }
 
 // LDS bytes of one workgroup: per group the packed read, the SMEM ring of one first-round pass (2 ints per entry),
 // the cold state words and two windows of 16-bit LCPs (the partition window stays cached while edges are followed)
@@ -327,7 +333,7 @@ template <int G>
 #ifndef SEED_MIN_WAVES
 #define SEED_MIN_WAVES 5
 #endif
-__global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
+__global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(SeedArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int GROUPS = BLOCK / G;
     constexpr int E = win_entries(G);                      // entries per lane (the window mask is 64 bits)
@@ -379,10 +385,107 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     for (;;) {
         // ================= control: reads without a request in flight produce the next one =========================
         if (phase == PH_CTRL) {
+            // One pass over the states in the order reads usually flow through them, so a read takes several hops per
+            // pass (a switch in a loop costs the wavefront one full pass per hop of its slowest read); the outer
+            // loop only repeats for the rare backward hops.
             bool have = false;
+#define AT(pc_) (!have && pc == (pc_))
             do {
-                switch (pc) {
-                case PC_FETCH: {      // pull the next read (reads differ 3x in cost: dynamic hand-out, no static deal)
+                if (AT(PC_ZZ_TOP)) {       // zig-zag loop head (:1724-1737, :1969)
+                    if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) pc = PC_ZZ_END;
+                    else if (FLAG(F_ZZ_CHECK) && is_n(nfw, st[ST_ZZ_SP])) {
+                        if (l_seq - st[ST_ZZ_SP] < msl) { pivot = l_seq; st[ST_ZZ_SP] = l_seq; }
+                        else { st[ST_ZZ_SP] += 1; pivot = pivot + 1; }
+                    } else { q_kind = K_ZZ_LEFT; have = true; }
+                }
+                if (AT(PC_ZZ_RIGHT)) { q_kind = K_ZZ_RIGHT; have = true; }
+                if (AT(PC_ZZ_END)) {       // set_forward_pivot(raux, next_pivot) (:1893, :2125)
+                    pivot = st[ST_ZZ_NEXT];
+                    pc = FLAG(F_ZZ_RET_ONEPOS) ? PC_R2_AFTER : PC_AFTER_STEP1;
+                }
+                if (AT(PC_AFTER_STEP1)) {  // re-seeding loop entry (:921-923)
+                    SETFLAG(F_REC, false);
+                    st[ST_AFTER] = st[ST_N_SMEMS];
+                    if (A.opt.rounds < 2) pc = PC_ALLPOS_TOP;
+                    else if (FLAG(F_LDS_OVF)) pc = PC_DONE;          // re-run in the next tier (bigger LDS ring)
+                    else { st[ST_R2_K] = st[ST_BEFORE]; pc = PC_R2_LOOP; }
+                }
+                if (AT(PC_R2_AFTER)) {     // (:945-946)
+                    min_intv = st[ST_R2_SAVED];
+                    pivot = st[ST_R2_NEXT];
+                    pc = PC_R2_LOOP;
+                }
+                if (AT(PC_R2_LOOP)) {      // (:923-947) + OnePos entry (:1917-1930)
+                    int k = st[ST_R2_K];
+                    const int kb = st[ST_BEFORE], ke = st[ST_AFTER];
+                    int qbeg = 0, qend = 0, cnt = 0;
+                    bool take = false;
+                    while (k < ke) {        // SMEMs that are too short or too frequent are not re-seeded (:929-931)
+                        const int se = sm_se[k - kb];
+                        cnt = sm_cnt[k - kb];
+                        qbeg = se & 0xffff; qend = (int)((unsigned)se >> 16);
+                        ++k;
+                        if (!(qend - qbeg < A.opt.split_len || cnt > A.opt.split_width)) { take = true; break; }
+                    }
+                    st[ST_R2_K] = k;
+                    if (!take) pc = PC_ALLPOS_TOP;
+                    else {
+                        st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
+                        pivot = (qbeg + qend) >> 1;
+                        min_intv = cnt + 1;
+                        if (is_n(nfw, pivot)) {
+                            pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
+                            pc = PC_R2_AFTER;                         // backward hop (reads with N only)
+                        } else if (pivot != 0 && !is_n(nfw, pivot - 1)) { q_kind = K_OP_MEM; have = true; }
+                        else { q_kind = K_OP_SMEM; have = true; }
+                    }
+                }
+                if (AT(PC_ALLPOS_TOP)) {   // Learned_getSMEMsAllPosOneThread loop head (:916) + step1 entry (:1691-1723)
+                    if (pivot >= l_seq || ++st[ST_AP_GUARD] > 4 * l_seq + 16) pc = PC_R3_INIT;
+                    else {
+                        st[ST_BEFORE] = st[ST_N_SMEMS]; st[ST_SM_BASE] = st[ST_BEFORE]; SETFLAG(F_REC, true);
+                        if (is_n(nfw, pivot)) {
+                            pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
+                            pc = PC_AFTER_STEP1;                      // backward hop (reads with N only)
+                        } else if (pivot != 0 && !is_n(nfw, pivot - 1)) {
+                            // zig-zag entry: the loop head's checks pass trivially (sp = pivot < next = l_seq, no N here)
+                            st[ST_ZZ_NEXT] = l_seq; SETFLAG(F_ZZ_CHECK, true); SETFLAG(F_ZZ_RET_ONEPOS, false); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 1;
+                            q_kind = K_ZZ_LEFT; have = true;
+                        } else { q_kind = K_S1_RIGHT; have = true; }
+                    }
+                }
+                if (AT(PC_R3_INIT)) {      // src/bwamem.cpp:1385-1394
+                    if (A.opt.rounds >= 3 && A.opt.max_mem_intv > 0 && !FLAG(F_LDS_OVF)) {
+                        min_intv = A.opt.max_mem_intv;
+                        msl = A.opt.min_seed_len + 1;
+                        pivot = 0;
+                        pc = PC_R3_TOP;
+                    } else pc = PC_DONE;
+                }
+                if (AT(PC_R3_TOP)) {       // Learned_bwtSeedStrategyAllPosOneThread loop head (:982-1012)
+                    for (;;) {
+                        if (!(pivot < l_seq - msl + 1)) { pc = PC_DONE; break; }
+                        if (is_n(nfw, pivot)) { pivot = pivot + 1; continue; }
+                        const int valid = first_n(nfw, has_n, pivot, l_seq) - pivot;
+                        if (valid < msl) { pivot = pivot + valid; continue; }
+                        q_kind = K_R3; have = true;
+                        break;
+                    }
+                }
+                if (AT(PC_DONE)) {         // publish the read's SMEM count / hit count; its slots are already written
+                    const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
+                    const bool ovf = st[ST_N_SMEMS] > cap || FLAG(F_LDS_OVF);
+                    if (t == 0) {
+                        const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
+                        A.slot_cnt[rid] = ovf ? 0 : st[ST_N_SMEMS];
+                        A.slot_hits[rid] = ovf ? 0 : LD64(ST_HITS_LO);
+                        A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
+                        if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
+                    }
+                    if (!ovf) { acc_searches += (unsigned)st[ST_SEARCHES]; acc_windows += (unsigned)st[ST_WINDOWS]; }
+                    pc = PC_FETCH;
+                }
+                if (AT(PC_FETCH)) {        // pull the next read (reads differ 3x in cost: dynamic hand-out, no static deal)
                     // One global atomic per TICKET_CHUNK reads: the wavefront keeps a chunk in LDS and its groups draw
                     // from it with an LDS atomic.  (One global atomic per read on a single address caps the whole
                     // kernel at ~30 M reads/s.)  The groups that are here together run in lockstep, so the refill
@@ -394,133 +497,57 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     const unsigned long long mo = __ballot(over);
                     unsigned long long ticket = old_base + (unsigned)idx;
                     if (mo) {
+                        // k groups need tickets from a fresh chunk; a wavefront may hold more groups than a chunk
                         const int first = __ffsll((long long)mo) - 1;
+                        const int kreq = __popcll(mo), alloc = kreq > TICKET_CHUNK ? kreq : TICKET_CHUNK;
                         unsigned long long nb = 0;
                         if (lane == first) {
-                            nb = atomicAdd(&A.counters[0], (unsigned long long)TICKET_CHUNK);
-                            wv[0] = __popcll(mo); wv[2] = (int)(unsigned)(nb & 0xffffffffull); wv[3] = (int)(nb >> 32);
+                            nb = atomicAdd(&A.counters[0], (unsigned long long)alloc);
+                            const unsigned long long wb = nb + (unsigned)(alloc - TICKET_CHUNK);
+                            wv[0] = kreq - (alloc - TICKET_CHUNK); wv[2] = (int)(unsigned)(wb & 0xffffffffull); wv[3] = (int)(wb >> 32);
                         }
                         nb = __shfl(nb, first);
                         if (over) ticket = nb + (unsigned)__popcll(mo & ((1ull << lane) - 1ull));
                     }
                     ticket = __shfl(ticket, gbase);
-                    if (ticket >= (unsigned long long)A.nreads) { pc = PC_EXIT; break; }
-                    const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
-                    const u64* src = A.packed + rid * stride;
-                    l_seq = (int)src[stride - 1];          // k_pack_reads stores the length in the last word
-                    if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
-                        // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
-                        // here such a read yields no seeds and is flagged through slot_cnt = -1
-                        if (t == 0) { A.slot_cnt[rid] = l_seq > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0; }
-                        break;                              // stay in PC_FETCH
-                    }
-                    // stage the packed read in LDS (coalesced 8-byte loads) and clear the cold state
-                    bool any_n = false;
-                    for (int k = t; k < stride - 1; k += G) {
-                        u64 v = src[k];
-                        rd[k] = v;
-                        if (k >= 2 * PW && k < 2 * PW + MW) any_n |= (v != 0);
-                    }
-                    for (int k = t; k < ST_WORDS; k += G) st[k] = 0;
-                    has_n = GBALLOT(any_n) != 0;
-                    LDS_HANDOFF();
-                    st[ST_TICKET_LO] = (int)(unsigned)(ticket & 0xffffffffull);
-                    st[ST_TICKET_HI] = (int)(ticket >> 32);
-                    pivot = 0; msl = A.opt.min_seed_len; min_intv = 1;
-                    pc = PC_ALLPOS_TOP;
-                    break;
-                }
-                case PC_ALLPOS_TOP:   // Learned_getSMEMsAllPosOneThread loop head (:916) + step1 entry (:1691-1723)
-                    if (pivot >= l_seq || ++st[ST_AP_GUARD] > 4 * l_seq + 16) { pc = PC_R3_INIT; break; }
-                    st[ST_BEFORE] = st[ST_N_SMEMS]; st[ST_SM_BASE] = st[ST_BEFORE]; SETFLAG(F_REC, true);
-                    if (is_n(nfw, pivot)) {
-                        pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
-                        pc = PC_AFTER_STEP1;
-                    } else if (pivot != 0 && !is_n(nfw, pivot - 1)) {
-                        st[ST_ZZ_NEXT] = l_seq; SETFLAG(F_ZZ_CHECK, true); SETFLAG(F_ZZ_RET_ONEPOS, false); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
-                        pc = PC_ZZ_TOP;
-                    } else { q_kind = K_S1_RIGHT; have = true; }
-                    break;
-                case PC_ZZ_TOP:       // zig-zag loop head (:1724-1737, :1969)
-                    if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
-                    if (FLAG(F_ZZ_CHECK) && is_n(nfw, st[ST_ZZ_SP])) {
-                        if (l_seq - st[ST_ZZ_SP] < msl) { pivot = l_seq; st[ST_ZZ_SP] = l_seq; }
-                        else { st[ST_ZZ_SP] += 1; pivot = pivot + 1; }
-                        break;
-                    }
-                    q_kind = K_ZZ_LEFT; have = true;
-                    break;
-                case PC_ZZ_RIGHT:
-                    q_kind = K_ZZ_RIGHT; have = true;
-                    break;
-                case PC_ZZ_END:       // set_forward_pivot(raux, next_pivot) (:1893, :2125)
-                    pivot = st[ST_ZZ_NEXT];
-                    pc = FLAG(F_ZZ_RET_ONEPOS) ? PC_R2_AFTER : PC_AFTER_STEP1;
-                    break;
-                case PC_AFTER_STEP1:  // re-seeding loop entry (:921-923)
-                    SETFLAG(F_REC, false);
-                    st[ST_AFTER] = st[ST_N_SMEMS];
-                    if (A.opt.rounds < 2) { pc = PC_ALLPOS_TOP; break; }
-                    if (FLAG(F_LDS_OVF)) { pc = PC_DONE; break; }   // re-run in the next tier (bigger LDS ring)
-                    st[ST_R2_K] = st[ST_BEFORE];
-                    pc = PC_R2_LOOP;
-                    break;
-                case PC_R2_LOOP: {    // (:923-947) + OnePos entry (:1917-1930)
-                    if (st[ST_R2_K] >= st[ST_AFTER]) { pc = PC_ALLPOS_TOP; break; }
-                    const int k = st[ST_R2_K]++ - st[ST_BEFORE];
-                    st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
-                    const int se = sm_se[k], cnt = sm_cnt[k];
-                    const int qbeg = se & 0xffff, qend = (int)((unsigned)se >> 16);
-                    if (qend - qbeg < A.opt.split_len || cnt > A.opt.split_width) break;   // pivot stays (:929-931)
-                    pivot = (qbeg + qend) >> 1;
-                    min_intv = cnt + 1;
-                    if (is_n(nfw, pivot)) {
-                        pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
-                        pc = PC_R2_AFTER;
-                    } else if (pivot != 0 && !is_n(nfw, pivot - 1)) { q_kind = K_OP_MEM; have = true; }
-                    else { q_kind = K_OP_SMEM; have = true; }
-                    break;
-                }
-                case PC_R2_AFTER:     // (:945-946)
-                    min_intv = st[ST_R2_SAVED];
-                    pivot = st[ST_R2_NEXT];
-                    pc = PC_R2_LOOP;
-                    break;
-                case PC_R3_INIT:      // src/bwamem.cpp:1385-1394
-                    if (A.opt.rounds >= 3 && A.opt.max_mem_intv > 0 && !FLAG(F_LDS_OVF)) {
-                        min_intv = A.opt.max_mem_intv;
-                        msl = A.opt.min_seed_len + 1;
-                        pivot = 0;
-                        pc = PC_R3_TOP;
-                    } else pc = PC_DONE;
-                    break;
-                case PC_R3_TOP: {     // Learned_bwtSeedStrategyAllPosOneThread loop head (:982-1012)
-                    if (!(pivot < l_seq - msl + 1)) { pc = PC_DONE; break; }
-                    if (is_n(nfw, pivot)) { pivot = pivot + 1; break; }
-                    const int valid = first_n(nfw, has_n, pivot, l_seq) - pivot;
-                    if (valid < msl) { pivot = pivot + valid; break; }
-                    q_kind = K_R3; have = true;
-                    break;
-                }
-                case PC_DONE: {       // publish the read's SMEM count / hit count; its slots are already written
-                    const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
-                    if (t == 0) {
+                    if (ticket >= (unsigned long long)A.nreads) pc = PC_EXIT;
+                    else {
                         const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
-                        const int n_smems = st[ST_N_SMEMS];
-                        const i64 n_hits = LD64(ST_HITS_LO);
-                        const bool ovf = n_smems > cap || FLAG(F_LDS_OVF);
-                        A.slot_cnt[rid] = ovf ? 0 : n_smems;
-                        A.slot_hits[rid] = ovf ? 0 : n_hits;
-                        A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
-                        if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
+                        const u64* src = A.packed + rid * stride;
+                        // stage the packed read in LDS (coalesced 8-byte loads; the length word travels in the same
+                        // batch of loads) and clear the cold state
+                        bool any_n = false;
+                        const int lw = (stride - 1) % G;               // the lane that loads the length word
+                        u64 lenw = 0;
+                        for (int k = t; k < stride; k += G) {
+                            u64 v = src[k];
+                            rd[k] = v;
+                            if (k >= 2 * PW && k < 2 * PW + MW) any_n |= (v != 0);
+                            if (k == stride - 1) lenw = v;
+                        }
+                        l_seq = (int)__shfl((int)lenw, gbase + lw);    // k_pack_reads stores the length in the last word
+                        for (int k = t; k < ST_WORDS; k += G) st[k] = 0;
+                        has_n = GBALLOT(any_n) != 0;
+                        LDS_HANDOFF();
+                        if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
+                            // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
+                            // here such a read yields no seeds and is flagged through slot_cnt = -1
+                            if (t == 0) { A.slot_cnt[rid] = l_seq > MAX_READ_LEN ? -1 : 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0; }
+                            // stays in PC_FETCH
+                        } else {
+                            st[ST_TICKET_LO] = (int)(unsigned)(ticket & 0xffffffffull);
+                            st[ST_TICKET_HI] = (int)(ticket >> 32);
+                            pivot = 0; msl = A.opt.min_seed_len; min_intv = 1;
+                            pc = PC_ALLPOS_TOP;
+                            if (!is_n(nfw, 0)) {                       // first step of PC_ALLPOS_TOP at pivot 0, inlined
+                                st[ST_AP_GUARD] = 1; SETFLAG(F_REC, true);
+                                q_kind = K_S1_RIGHT; have = true;
+                            }
+                        }
                     }
-                    if (!(st[ST_N_SMEMS] > cap || FLAG(F_LDS_OVF))) { acc_searches += (unsigned)st[ST_SEARCHES]; acc_windows += (unsigned)st[ST_WINDOWS]; }
-                    pc = PC_FETCH;
-                    break;
-                }
-                default: pc = PC_DONE; break;
                 }
             } while (!have && pc != PC_EXIT);
+#undef AT
             if (pc == PC_EXIT) {
                 if (t == 0) { atomicAdd(&A.counters[1], (unsigned long long)acc_searches); atomicAdd(&A.counters[3], (unsigned long long)acc_windows); }
                 break;

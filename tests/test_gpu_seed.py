@@ -38,7 +38,7 @@ def test_hip_seeds_equal_reference_golden(ctx, g1, length):
     assert _gpu_dump(ctx, reads, off) == want
 
 
-@pytest.mark.parametrize("lanes", [4, 8, 16, 32])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32])
 def test_hip_seeds_equal_golden_for_every_group_width(g1, lanes):
     c = hipapi.Context(0)
     try:
