@@ -118,6 +118,44 @@ def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
     return O.algorithmic_bytes(ctr, n * READ_LEN) / n, {k: v / n for k, v in ctr.items()}
 
 
+def bsw_leg(ctx, dev, world):
+    """Second kernel of the path: banded seed extension on rank 0's GPU, pairs resident in HBM.
+    Reported beside the headline metric: pairs/s, GCUPS (DP cells from the CPU restatement's counter) and the
+    CPU restatement on all host cores for the same pairs."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py
+    npairs = int(os.environ.get("MEME_BENCH_BSW_PAIRS", "2000000"))
+    pairs, ref, qer, base = workload.make_bsw_pairs(npairs, seed=77, read_len=READ_LEN)
+    d_pairs = torch.from_numpy(pairs.view(np.uint8)).to(dev)
+    d_ref = torch.from_numpy(ref).to(dev)
+    d_qer = torch.from_numpy(qer).to(dev)
+    torch.cuda.synchronize()
+    ms = []
+    for it in range(4):
+        ctx.bsw_batch_device(d_pairs.data_ptr(), d_ref.data_ptr(), d_qer.data_ptr(), npairs, 100)
+        ctx.sync()
+        if it:
+            ms.append(ctx.timings().bsw_kernel_ms)
+    k_ms = float(np.mean(ms))
+    got = d_pairs.cpu().numpy().view(hipapi.SEQPAIR)[:base]
+    # cells and the CPU figure from the restatement of scalarBandedSWA (the oracle): checker + baseline only
+    chk = pairs[:base].copy().view(oracle_py.SEQPAIR_DTYPE)
+    cells = oracle_py.bsw_batch(chk, ref, qer, 100, threads=0)
+    same = all(np.array_equal(got[f], chk[f]) for f in ("score", "tle", "gtle", "qle", "gscore", "max_off"))
+    reps = npairs / base
+    cores = os.cpu_count() or 1
+    big = np.tile(pairs[:base], max(1, int(400000 // base)))
+    big_chk = big.copy().view(oracle_py.SEQPAIR_DTYPE)
+    t0 = time.perf_counter()
+    oracle_py.bsw_batch(big_chk, ref, qer, 100, threads=cores)
+    cpu_dt = time.perf_counter() - t0
+    return {"metric": "bsw_pairs_per_sec", "value": npairs / (k_ms * 1e-3), "unit": "pairs/s", "per": "gpu",
+            "pairs": npairs, "band_w": 100, "kernel_ms": k_ms, "cells_per_pair": cells / base,
+            "gcups": cells * reps / (k_ms * 1e-3) / 1e9, "matches_oracle": bool(same),
+            "cpu_baseline": {"value": big.shape[0] / cpu_dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                             "sample": "%d pairs, scalar restatement of scalarBandedSWA on %d threads" % (big.shape[0], cores)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +353,12 @@ def main():
                 log("cpu_baseline leg failed: %r -- falling back to the port" % (e,))
                 cpu = cpu_baseline_port(text, sa, l1, l2, reads[:min(ns, 400000)], cores)
         out["cpu_baseline"] = cpu
+        if os.environ.get("MEME_BENCH_BSW", "1") != "0":
+            try:
+                out["bsw"] = bsw_leg(ctx, dev, world)
+            except Exception as e:  # a secondary measurement: never lose the headline line over it
+                log("bsw leg failed: %r" % (e,))
+                out["bsw"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -183,12 +183,12 @@ int launch_k_seed(meme_ctx* ctx, const SeedArgs& A, size_t lds, i64 blocks) {
 
 int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, i64 max_len, i64 total_bytes,
                 const meme_seed_opt* opt, meme_seed_result* out) {
-    unsigned long long h_counters[4];
+    unsigned long long h_counters[12];
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 12 * sizeof(unsigned long long)))) return rc;
     int dev_cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
@@ -230,7 +230,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         DevBuf& ob = ctx->ovf[tier & 1];
         if ((rc = meme_buf_reserve(ctx, sb, (size_t)n_todo * cap * sizeof(SlotRec)))) return rc;
         if ((rc = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 12 * sizeof(unsigned long long), ctx->stream));
         SeedArgs A;
         A.I = ctx->idx;
         A.packed = (const u64*)ctx->packed.p;
@@ -276,6 +276,15 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         ms_total += ms;
         ++launches;
         searches += (i64)h_counters[1];
+#ifdef SEED_PROF
+        {
+            double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)h_counters[4 + k];
+            fprintf(stderr, "[seed prof] tier %d:", tier);
+            const char* nm[6] = {"control", "request+rmi", "window+compare", "resolve", "level", "apply"};
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)h_counters[4 + k] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "\n");
+        }
+#endif
         windows += (i64)h_counters[3];
         if (h_counters[2] == 0) break;
         // some reads produced more SMEMs than their slots hold (pathological repeats): re-run only those

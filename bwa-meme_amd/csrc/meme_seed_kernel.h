@@ -206,7 +206,7 @@ constexpr int TICKET_CHUNK = 32;     // reads a wavefront draws from the global 
 __host__ __device__ inline size_t seed_lds_group_bytes(int G, int stride, int lcap) {
     const int groups = BLOCK / G;
     const int W = win_entries(G) * G;
-    return (((size_t)groups * stride * 8 + (size_t)groups * (2 * lcap + ST_WORDS + W) * sizeof(int)) + 7) & ~(size_t)7;
+    return (((size_t)groups * stride * 8 + (size_t)groups * (2 * lcap + ST_WORDS + (W + 1) / 2) * sizeof(int)) + 7) & ~(size_t)7;
 }
 // + per wavefront: the ticket chunk it is handing out (count, base)
 inline size_t seed_lds_bytes(int G, const PackGeom& geo, int lcap) {
@@ -226,10 +226,11 @@ __device__ __forceinline__ void window_compare(glb_u64 pac, i64 n, lds_u64 s, in
     int l[E], Lc[E];
     bool lt[E];
     unsigned pend = 0;
+    const u64 nlimit = (u64)(n - (i64)cap);          // suffixes starting beyond it are shorter than cap (rare)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const i64 ref_len = n - (i64)ep[e];
-        Lc[e] = ref_len < (i64)cap ? (int)ref_len : cap;
+        Lc[e] = cap;
+        if (ep[e] > nlimit) Lc[e] = (int)(n - (i64)ep[e]);
         const u64 x = ek[e] ^ wq;
         lt[e] = ek[e] < wq;
         l[e] = x ? (__clzll((long long)x) >> 1) : 32;
@@ -270,8 +271,8 @@ __device__ __forceinline__ void window_compare(glb_u64 pac, i64 n, lds_u64 s, in
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const i64 ref_len = n - (i64)ep[e];
-        if (l[e] >= Lc[e]) { lcp[e] = Lc[e]; less[e] = (i64)Lc[e] < ref_len; }
+        // Lc == cap < ref_len unless the suffix was clamped above (then Lc == ref_len) or starts exactly at nlimit
+        if (l[e] >= Lc[e]) { lcp[e] = Lc[e]; less[e] = ep[e] < nlimit; }
         else { lcp[e] = l[e]; less[e] = lt[e]; }
     }
 }
@@ -294,6 +295,32 @@ __device__ __forceinline__ i64 rmi_lookup(glb_rmi l2, glb_rmi l1, int shift, i64
     if (f < 0.0) return 0;
     if (f > top) return n - 1;
     return (i64)f;
+}
+
+// OR-reduction over the G lanes of a group without touching LDS: DPP lane permutations inside a 16-lane row
+// (quad swaps, then mirrored halves / rows); only groups of 32 need a cross-row exchange.
+template <int G>
+__device__ __forceinline__ int group_or(int v) {
+    if constexpr (G >= 2) v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    if constexpr (G >= 16) v |= __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    if constexpr (G >= 32) v |= __shfl_xor(v, 16);
+    return v;
+}
+
+// values of a per-lane array of window slots (slot j lives in lane j % G, register j / G) at slots ia and ib, packed
+// (ia's value << 16) | ib's value; an index outside [0, E*G) yields 0
+template <int G, int E>
+__device__ __forceinline__ int slot_pair(const int (&v)[E], int t, int ia, int ib) {
+    int x = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = e * G + t;
+        x |= (j == ia) ? (v[e] << 16) : 0;
+        x |= (j == ib) ? v[e] : 0;
+    }
+    return group_or<G>(x);
 }
 
 __device__ __forceinline__ bool is_n(lds_u64 mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
@@ -339,6 +366,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     constexpr int E = win_entries(G);                      // entries per lane (the window mask is 64 bits)
     constexpr int W = E * G;                               // window width in slots
     constexpr u64 GFULL = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+    constexpr u64 WFULL = (W == 64) ? ~0ull : ((1ull << W) - 1ull);
     const int lane = threadIdx.x & 63;
     const int gib = threadIdx.x / G;
     const int t = threadIdx.x & (G - 1);
@@ -349,7 +377,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     const lds_u64 fw = (lds_u64)rd, rcs = fw + PW, nfw = fw + 2 * PW, nrc = nfw + MW;
     // per group after the packed reads: SMEM ring (2 ints per entry), cold state, two windows of 16-bit LCPs
     const lds_int ring = (lds_int)(reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) +
-                                   (size_t)gib * (2 * lcap + ST_WORDS + W));
+                                   (size_t)gib * (2 * lcap + ST_WORDS + (W + 1) / 2));
     const lds_int sm_se = ring;               // start | end << 16
     const lds_int sm_cnt = ring + lcap;
     const lds_int st = ring + 2 * lcap;
@@ -382,8 +410,18 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     if (lane == 0) wv[0] = TICKET_CHUNK;                    // empty chunk
     LDS_HANDOFF();
 
+#ifdef SEED_PROF
+    // diagnostic build: wall-clock ticks (100 MHz) a wavefront spends in each section of the loop body, summed over
+    // groups into counters[4..]; marks sit at points every lane still in the loop passes
+    unsigned prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = wall_clock64();
+#define PROF_MARK(i_) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now__ = wall_clock64(); prof[i_] += (unsigned)(now__ - prof_t); prof_t = now__; } while (0)
+#else
+#define PROF_MARK(i_) do { } while (0)
+#endif
     for (;;) {
         // ================= control: reads without a request in flight produce the next one =========================
+        bool newreq = false;
         if (phase == PH_CTRL) {
             // One pass over the states in the order reads usually flow through them, so a read takes several hops per
             // pass (a switch in a loop costs the wavefront one full pass per hop of its slowest read); the outer
@@ -549,9 +587,18 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             } while (!have && pc != PC_EXIT);
 #undef AT
             if (pc == PC_EXIT) {
-                if (t == 0) { atomicAdd(&A.counters[1], (unsigned long long)acc_searches); atomicAdd(&A.counters[3], (unsigned long long)acc_windows); }
+                if (t == 0) {
+                    atomicAdd(&A.counters[1], (unsigned long long)acc_searches); atomicAdd(&A.counters[3], (unsigned long long)acc_windows);
+#ifdef SEED_PROF
+                    for (int k = 0; k < 8; ++k) atomicAdd(&A.counters[4 + k], (unsigned long long)prof[k]);
+#endif
+                }
                 break;
             }
+            newreq = true;
+        }
+        PROF_MARK(0);
+        if (newreq) {
             // ---- the request: query = bases [off, off+vlen) of one strand; first window at the model's prediction
             q_rc = q_kind == K_ZZ_LEFT;
             off = q_rc ? l_seq - 1 - pivot : pivot;
@@ -568,6 +615,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             lo = -1; hi = n; stepk = 0; capc = vlen;
             phase = PH_PART;
         }
+        PROF_MARK(1);
 
         // ================= window: E coalesced loads of G entries each, issued together, then the compares ===========
         const lds_u64 s = q_rc ? rcs : fw;
@@ -580,6 +628,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             st[ST_WINDOWS] = st[ST_WINDOWS] + 1;
             window_compare<E>(pac, n, s, off, capc, ek, ep, lcp, less);
         }
+        PROF_MARK(2);
         u64 m = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -587,8 +636,9 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             m |= GBALLOT(p) << (e * G);
         }
         // slots <= lo are known true, slots >= hi known false (also removes the far side of a clipped edge window)
-        m = (m | lowmask((int)((lo - base + 1 > W) ? W : (lo - base + 1 < 0 ? 0 : lo - base + 1)))) &
-            lowmask((int)((hi - base > W) ? W : (hi - base < 0 ? 0 : hi - base)));
+        if (stepk != 0)                  // not the first window of a partition search: a bracket exists
+            m = (m | lowmask((int)((lo - base + 1 > W) ? W : (lo - base + 1 < 0 ? 0 : lo - base + 1)))) &
+                lowmask((int)((hi - base > W) ? W : (hi - base < 0 ? 0 : hi - base)));
         const int P = __popcll(m);
         const bool at_lo = base == 0 || (phase == PH_EDGE_UP && base == lo + 1);
         const bool at_hi = base + W == n || (phase == PH_EDGE_DN && base + W == hi);
@@ -601,14 +651,13 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         int r_L = 0;
         i64 r_start = 0, r_count = 1;
         bool r_emit = false;
+        int cl[E];                       // LCPs of the cached partition window (this lane's slots)
+        bool cache_in_lds = phase != PH_PART;
         if (found) {
-            // LCPs of the two slots around the flip, through LDS (region 0: partition window, kept for the level walk)
-            const int woff = phase == PH_PART ? 0 : W;
-#pragma unroll
-            for (int e = 0; e < E; ++e) wl[woff + e * G + t] = (unsigned short)lcp[e];
-            LDS_HANDOFF();
-            const int lm = P > 0 ? (int)wl[woff + P - 1] : -1;
-            const int lp = P < W ? (int)wl[woff + P] : -1;
+            // LCPs of the two slots around the flip
+            const int v2 = slot_pair<G, E>(lcp, t, P - 1, P);
+            const int lm = P > 0 ? (v2 >> 16) : -1;
+            const int lp = P < W ? (v2 & 0xffff) : -1;
             if (phase == PH_PART) {
                 // slots [0,P) sort before the query; the longest match is at one of the two boundary neighbours
                 const int c = (lm >= lp) ? P - 1 : P;
@@ -648,33 +697,45 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 else base = lo + (hi - lo) / 2 - W / 2;                                                              // bisect
             }
         }
+        PROF_MARK(3);
         if (go_level) {
-            // walk the levels L0 > L1 > ...; an edge that leaves the cached partition window becomes an edge request
+            // Walk the levels L0 > L1 > ... on the partition window's LCPs, held in registers (fresh from the compare, or
+            // re-loaded from LDS after an edge request): per level one ballot mask, two bit scans and one DPP
+            // reduction -- no LDS round trip.  An edge that leaves the cached window becomes an edge request.
+#pragma unroll
+            for (int e = 0; e < E; ++e) cl[e] = cache_in_lds ? (int)wl[e * G + t] : lcp[e];
             for (;;) {
-                if (lf & LF_NEED_LO) {
-                    i64 k = s_edge - cb;                          // cached slots [0,k) lie below the current edge
-                    if (k > 0 && k <= W) {
-                        int v = 0;
-                        while (k > 0 && (v = (int)wl[k - 1]) >= L) --k;
-                        s_edge = cb + k;
-                        if (k > 0) { nb_lo = v; lf &= ~LF_NEED_LO; }
-                        else if (cb == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; }
-                    } else if (s_edge == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; }
+                if (lf & (LF_NEED_LO | LF_NEED_HI)) {
+                    u64 ge = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ge |= GBALLOT(cl[e] >= L) << (e * G);
+                    const u64 nz = ~ge & WFULL;                       // cached slots that do not reach level L
+                    const i64 klo = s_edge - cb;                      // cached slots [0,klo) lie below the current edge
+                    const i64 khi = e_edge - cb;                      // cached slots (khi,W) lie above it
+                    const bool in_lo = (lf & LF_NEED_LO) && klo > 0 && klo <= W;
+                    const bool in_hi = (lf & LF_NEED_HI) && khi >= -1 && khi < W - 1;
+                    const u64 zlo = in_lo ? (nz & lowmask((int)klo)) : 0ull;
+                    const u64 zhi = in_hi ? (nz & ~lowmask((int)khi + 1)) : 0ull;
+                    const int hz = zlo ? 63 - __clzll((long long)zlo) : -1;
+                    const int lz = zhi ? __ffsll((long long)zhi) - 1 : -1;
+                    const int nb2 = slot_pair<G, E>(cl, t, hz, lz);
                     if (lf & LF_NEED_LO) {
+                        if (in_lo) {
+                            if (zlo) { s_edge = cb + hz + 1; nb_lo = nb2 >> 16; lf &= ~LF_NEED_LO; }
+                            else { s_edge = cb; if (cb == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; } }
+                        } else if (s_edge == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; }
+                    }
+                    if (lf & LF_NEED_HI) {
+                        if (in_hi) {
+                            if (zhi) { e_edge = cb + lz - 1; nb_hi = nb2 & 0xffff; lf &= ~LF_NEED_HI; }
+                            else { e_edge = cb + W - 1; if (cb + W >= n) { nb_hi = 0; lf &= ~LF_NEED_HI; } }
+                        } else if (e_edge == n - 1) { nb_hi = 0; lf &= ~LF_NEED_HI; }
+                    }
+                    if (lf & LF_NEED_LO) {                            // the run leaves the cached window: edge request
                         phase = PH_EDGE_DN; lo = -1; hi = s_edge; stepk = 1;
                         base = s_edge - W; if (base < 0) base = 0;
                         break;
                     }
-                }
-                if (lf & LF_NEED_HI) {
-                    i64 k = e_edge - cb;                          // cached slots (k,W) lie above the current edge
-                    if (k >= -1 && k < W - 1) {
-                        int v = 0;
-                        while (k < W - 1 && (v = (int)wl[k + 1]) >= L) ++k;
-                        e_edge = cb + k;
-                        if (k < W - 1) { nb_hi = v; lf &= ~LF_NEED_HI; }
-                        else if (cb + W >= n) { nb_hi = 0; lf &= ~LF_NEED_HI; }
-                    } else if (e_edge == n - 1) { nb_hi = 0; lf &= ~LF_NEED_HI; }
                     if (lf & LF_NEED_HI) {
                         phase = PH_EDGE_UP; lo = e_edge; hi = n; stepk = 1;
                         base = e_edge + 1; if (base > n - W) base = n - W;
@@ -710,8 +771,13 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 capc = L;
                 st[ST_L] = L; st[ST_NB_LO] = nb_lo; st[ST_NB_HI] = nb_hi; st[ST_LF] = lf;
                 ST64(ST_SE_LO, s_edge); ST64(ST_EE_LO, e_edge); ST64(ST_CB_LO, cb);
+                if (!cache_in_lds) {                              // first edge request of this search: park the cache
+#pragma unroll
+                    for (int e = 0; e < E; ++e) wl[e * G + t] = (unsigned short)cl[e];
+                }
             }
         }
+        PROF_MARK(4);
         if (finished) {
             // ---- apply the search result to the read's pivot logic ------------------------------------------------------
             bool emit = false;
@@ -766,7 +832,9 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             }
             phase = PH_CTRL;
         }
+        PROF_MARK(5);
     }
+#undef PROF_MARK
 #undef GBALLOT
 #undef LD64
 #undef ST64

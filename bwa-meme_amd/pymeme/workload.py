@@ -60,3 +60,42 @@ def make_reads_fast(genome: np.ndarray, n_reads: int, read_len: int, seed: int, 
         reads[wn, rng.integers(0, read_len, size=wn.size)] = 4
         out[s:s + m] = reads
     return out
+
+
+def make_bsw_pairs(n_pairs: int, seed: int, read_len: int = 150, base: int = 8192, sub=0.01, indel=0.0015,
+                   amb=0.001):
+    """Seed-extension jobs shaped like the ones mem_chain2aln_across_reads_V2 builds for `read_len`-bp reads
+    (reference src/bwamem.cpp:2777-2798, 2893-2898): the query is the part of the read left or right of a seed
+    (1 .. read_len-19 bases), the target the same stretch of the reference plus the gap allowance, h0 the
+    seed's score.  `base` distinct pairs are generated and tiled to n_pairs (the work per pair is what matters).
+    Returns (pairs[SEQPAIR], ref bytes, query bytes)."""
+    from .hipapi import SEQPAIR
+    rng = np.random.default_rng(seed)
+    base = min(base, n_pairs)
+    pairs = np.zeros(base, dtype=SEQPAIR)
+    refs, qers = [], []
+    ro = qo = 0
+    for i in range(base):
+        ql = int(rng.integers(1, read_len - 19 + 1))
+        q = rng.integers(0, 4, size=ql).astype(np.uint8)
+        t = q.copy()
+        sm = rng.random(ql) < sub
+        t[sm] = (t[sm] + rng.integers(1, 4, size=int(sm.sum()))) & 3
+        if rng.random() < indel * ql:                       # one short indel
+            p = int(rng.integers(0, ql))
+            k = int(rng.integers(1, 4))
+            t = np.concatenate([t[:p], t[p + k:]]) if rng.random() < 0.5 else \
+                np.concatenate([t[:p], rng.integers(0, 4, size=k).astype(np.uint8), t[p:]])
+        gap = int(rng.integers(10, 60))                     # cal_max_gap allowance (src/bwamem.cpp:85-95)
+        t = np.concatenate([t, rng.integers(0, 4, size=gap).astype(np.uint8)])
+        t[rng.random(t.shape[0]) < amb] = 4
+        pairs[i]["idr"], pairs[i]["idq"] = ro, qo
+        pairs[i]["len1"], pairs[i]["len2"] = t.shape[0], ql
+        pairs[i]["h0"] = int(read_len - ql) if rng.random() < 0.7 else int(rng.integers(19, read_len))
+        refs.append(t); qers.append(q)
+        ro += t.shape[0]; qo += ql
+    reps = (n_pairs + base - 1) // base
+    out = np.tile(pairs, reps)[:n_pairs].copy()
+    out["id"] = np.arange(n_pairs, dtype=np.int32)
+    out["seqid"] = out["id"]
+    return out, np.concatenate(refs), np.concatenate(qers), base
