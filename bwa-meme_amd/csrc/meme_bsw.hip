@@ -4,13 +4,18 @@
 // src/bandedSWA.cpp:242-260, 1970-2261, 2664-2961), whose common semantics are scalarBandedSWA
 // (src/bandedSWA.cpp:116-237) == ksw_extend2 (src/ksw.cpp:434-535).
 //
-// Why row-synchronous and not anti-diagonal: the function's observable behaviour is defined row by row
+// Two kernels, one semantics:
+//  * k_bsw_lane -- one pair per lane (64 pairs per wavefront, pairs counting-sorted by query length so the lanes finish
+//    together): the inter-task parallelism of the reference's own SIMD code at wavefront width.  Takes every pair whose
+//    query fits the LDS classes (<= 600 bases) and whose scores fit 14 bits -- all short-read extensions.
+//  * k_bsw<64>  -- 64 lanes per pair for the rest (long queries, huge h0).
+//
+// Why row-synchronous and not anti-diagonal (k_bsw): the function's observable behaviour is defined row by row
 // -- the band [beg,end) of row i+1 is trimmed from the zero runs of row i (:217-221), the z-drop / m==0
 // exits (:206-216) and the max/gscore tie rules (:188-189, :202-205) are evaluated per row, and the
 // H/E array keeps *stale* cells outside the band that are read again when the band re-grows.  An
 // anti-diagonal sweep would have to replay those row-granular decisions anyway.  Instead each row is
-// computed across the LP lanes that own a pair (LP = 16 / 32 / 64 by query-length class, so 4 / 2 / 1 pairs
-// share a wavefront): the only in-row dependency, the F (insertion) chain
+// computed across the LP lanes that own a pair: the only in-row dependency, the F (insertion) chain
 //   F(i,j+1) = max(0, M(i,j)-oe_ins, F(i,j)-e_ins)
 // is a max-plus prefix scan, F(i,j) = max(0, max_{k<j}(M(i,k) + k*e_ins) - oe_ins - (j-1)*e_ins),
 // done with sub-wavefront shuffles.  H/E rows and the query live in LDS for the whole pair; the
@@ -224,20 +229,204 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
     }
 }
 
-// length classes (the reference sorts pairs into int8 / int16 / scalar classes for its SIMD lanes,
-// sortPairsLenExt src/bwamem.cpp:2430-2527; here the class only decides how many lanes share a pair)
-constexpr int N_CLS = 3;
-constexpr int CLS_LIMIT[N_CLS] = {16, 32, 1 << 30};
+// ---- lane-per-pair kernel ---------------------------------------------------------------------------------------------
+// The same inter-task parallelism the reference's SIMD code uses (one pair per SIMD lane, pairs sorted by length so that
+// the lanes of a vector finish together: sortPairsLenExt, src/bwamem.cpp:2430-2527), at wavefront width: each of the 64
+// lanes runs scalarBandedSWA on its own pair.  No cross-lane traffic at all; per DP cell a lane issues one LDS read,
+// one LDS write and ~16 integer ops.  The row state {H(i-1,j-1), E(i,j)} and the query base of column j share one
+// 32-bit LDS word (14 + 14 + 3 bits), laid out [column][lane] so every access is bank-conflict free whatever column
+// each lane is at.  Pairs whose scores could exceed 14 bits or whose query exceeds LANE_QMAX go to the
+// lanes-per-pair kernel above.
+constexpr int LANE_QMAX = 600;
+constexpr int LANE_SCORE_LIMIT = 1 << 14;
+constexpr int N_LANE_CLS = 4;
+constexpr int LANE_CLS_Q[N_LANE_CLS] = {62, 158, 318, LANE_QMAX};    // LDS = (q + 2) * 256 B per wavefront
+constexpr int SORT_KEYS = 1024;                                      // key = query length, SORT_KEYS-1 = not eligible
 
-__global__ void __launch_bounds__(256) k_bsw_classify(const meme_seqpair* __restrict__ pairs, int n, int* __restrict__ order,
-                                                       int* __restrict__ cnt, int* __restrict__ maxq) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int q = pairs[i].len2;
-    const int c = q <= CLS_LIMIT[0] ? 0 : (q <= CLS_LIMIT[1] ? 1 : 2);
-    const int slot = atomicAdd(&cnt[c], 1);
-    order[(size_t)c * n + slot] = i;
-    if (c == 2) atomicMax(maxq, q);
+struct LaneArgs {
+    meme_seqpair* pairs;
+    const uint8_t* ref;
+    const uint8_t* qer;
+    const int* order;        // pair indices sorted by query length; this launch covers [first, first + count)
+    int first, count;
+    int w;
+    meme_bsw_opt o;
+    unsigned int* ticket;
+};
+
+__device__ __forceinline__ unsigned he_pack(int h, int e, unsigned qbits) { return (unsigned)h | ((unsigned)e << 14) | qbits; }
+
+__global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int he_raw[];
+    typedef __attribute__((address_space(3))) unsigned int* lds_u32;
+    const int lane = threadIdx.x;
+    const lds_u32 he = (lds_u32)he_raw + lane;           // column j of this lane's pair: he[j * 64]
+    const int o_del = A.o.o_del, e_del = A.o.e_del, o_ins = A.o.o_ins, e_ins = A.o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = A.o.zdrop;
+    const int sa = A.o.a, sb = -A.o.b;
+    constexpr unsigned HE_MASK = (1u << 28) - 1u, QMASK = 7u << 28;
+    for (;;) {
+        unsigned int tk = 0;
+        if (lane == 0) tk = atomicAdd(A.ticket, 64u);
+        tk = __shfl(tk, 0);
+        if (tk >= (unsigned)A.count) break;
+        const bool active = tk + lane < (unsigned)A.count;
+        meme_seqpair* P = &A.pairs[A.order[A.first + (active ? tk + lane : tk)]];
+        const int qlen = active ? P->len2 : 0, tlen = active ? P->len1 : 0, h0 = P->h0;
+        const uint8_t* query = A.qer + P->idq;
+        const uint8_t* target = A.ref + P->idr;
+        // ---- first row (:143-145) with the query bases folded in -----------------------------------------
+        {
+            const int first = h0 > oe_ins ? h0 - oe_ins : 0;
+            for (int j = 0; j <= qlen; ++j) {
+                int v;
+                if (j == 0) v = h0;
+                else if (j == 1) v = first;
+                else { const int prev = first - (j - 2) * e_ins; v = prev > e_ins ? prev - e_ins : 0; }
+                const unsigned qb = j < qlen ? (unsigned)query[j] : 0u;
+                he[j * 64] = he_pack(v, 0, (qb > 4u ? 4u : qb) << 28);
+            }
+        }
+        // band cap (:148-156)
+        int w = A.w;
+        {
+            const int mx = sa > 0 ? sa : 0;
+            int max_ins = (int)((double)(qlen * mx + A.o.end_bonus - o_ins) / e_ins + 1.);
+            if (max_ins < 1) max_ins = 1;
+            if (w > max_ins) w = max_ins;
+            int max_del = (int)((double)(qlen * mx + A.o.end_bonus - o_del) / e_del + 1.);
+            if (max_del < 1) max_del = 1;
+            if (w > max_del) w = max_del;
+        }
+        int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+        int tb_next = tlen > 0 ? (int)target[0] : 4;
+        for (int i = 0; i < tlen; ++i) {
+            const int tb = tb_next;
+            if (i + 1 < tlen) tb_next = target[i + 1];        // in flight during the row
+            int f = 0, h1, m = 0, mj = -1;
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+            else h1 = 0;
+            const int s_eq = tb > 3 ? -1 : sa, s_ne = tb > 3 ? -1 : sb;
+            unsigned word = beg < end ? he[beg * 64] : 0u;
+            for (int j = beg; j < end; ++j) {
+                const unsigned cur = word;
+                if (j + 1 < end) word = he[(j + 1) * 64];      // next column's state, in flight during this cell
+                int M = (int)(cur & 0x3fffu), e = (int)((cur >> 14) & 0x3fffu);
+                const int qb = (int)(cur >> 28);
+                const int sc = qb > 3 ? -1 : (qb == tb ? s_eq : s_ne);
+                M = M ? M + sc : 0;                            // :184
+                int h = M > e ? M : e;
+                h = h > f ? h : f;
+                mj = m > h ? mj : j;                           // rightmost column among equal maxima (:188-189)
+                m = m > h ? m : h;
+                int t = M - oe_del;
+                t = t > 0 ? t : 0;
+                e -= e_del;
+                e = e > t ? e : t;                             // E(i+1,j) (:190-194)
+                he[j * 64] = he_pack(h1, e, cur & QMASK);      // H(i,j-1) for the next row (:183)
+                h1 = h;
+                t = M - oe_ins;
+                t = t > 0 ? t : 0;
+                f -= e_ins;
+                f = f > t ? f : t;                             // F(i,j+1) (:195-198)
+            }
+            he[end * 64] = he_pack(h1, 0, he[end * 64] & QMASK);    // :201
+            if ((beg < end ? end : beg) == qlen) {             // "if (j == qlen)" after the column loop, :202-205
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+            if (m == 0) break;                                 // :206
+            if (m > max) {
+                max = m; max_i = i; max_j = mj;
+                int off = mj - i;
+                if (off < 0) off = -off;
+                max_off = max_off > off ? max_off : off;
+            } else if (zdrop > 0) {
+                if (i - max_i > mj - max_j) {
+                    if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+                } else {
+                    if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+                }
+            }
+            // band trimming (:217-221): drop leading / trailing columns whose H and E are both zero
+            int j = beg;
+            while (j < end && (he[j * 64] & HE_MASK) == 0u) ++j;
+            beg = j;
+            j = end;
+            while (j >= beg && (he[j * 64] & HE_MASK) == 0u) --j;
+            end = j + 2 < qlen ? j + 2 : qlen;
+        }
+        if (active) {
+            P->score = max;
+            P->qle = max_j + 1;
+            P->tle = max_i + 1;
+            P->gtle = max_ie + 1;
+            P->gscore = gscore;
+            P->max_off = max_off;
+        }
+    }
+}
+
+// ---- counting sort of the pairs by query length (the lanes of a wavefront should finish together) -------------------------
+__device__ __forceinline__ int lane_key(const meme_seqpair& p, int a) {
+    const long long bound = (long long)p.h0 + (long long)p.len2 * (a > 0 ? a : 0) + 1;
+    const bool ok = p.len2 >= 0 && p.len2 <= LANE_QMAX && p.len1 >= 0 && p.h0 >= 0 && bound < LANE_SCORE_LIMIT;
+    return ok ? p.len2 : SORT_KEYS - 1;
+}
+
+__global__ void __launch_bounds__(256) k_bsw_hist(const meme_seqpair* __restrict__ pairs, int n, int a, int* __restrict__ hist,
+                                                   int* __restrict__ maxq) {
+    __shared__ int lh[SORT_KEYS];
+    for (int k = threadIdx.x; k < SORT_KEYS; k += 256) lh[k] = 0;
+    __syncthreads();
+    int mq = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int key = lane_key(pairs[i], a);
+        atomicAdd(&lh[key], 1);
+        if (key == SORT_KEYS - 1) mq = mq > pairs[i].len2 ? mq : pairs[i].len2;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < SORT_KEYS; k += 256) if (lh[k]) atomicAdd(&hist[k], lh[k]);
+    if (mq) atomicMax(maxq, mq);
+}
+
+__global__ void __launch_bounds__(SORT_KEYS) k_bsw_scan(const int* __restrict__ hist, int* __restrict__ offs, int* __restrict__ cursor) {
+    __shared__ int tmp[SORT_KEYS];
+    const int k = threadIdx.x;
+    tmp[k] = hist[k];
+    __syncthreads();
+    for (int d = 1; d < SORT_KEYS; d <<= 1) {
+        const int v = k >= d ? tmp[k - d] : 0;
+        __syncthreads();
+        tmp[k] += v;
+        __syncthreads();
+    }
+    const int excl = tmp[k] - hist[k];
+    offs[k] = excl;
+    cursor[k] = excl;
+    if (k == SORT_KEYS - 1) offs[SORT_KEYS] = tmp[k];
+}
+
+__global__ void __launch_bounds__(256) k_bsw_scatter(const meme_seqpair* __restrict__ pairs, int n, int a, int* __restrict__ cursor,
+                                                      int* __restrict__ order) {
+    __shared__ int lh[SORT_KEYS];
+    __shared__ int lbase[SORT_KEYS];
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        for (int k = threadIdx.x; k < SORT_KEYS; k += 256) lh[k] = 0;
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        int key = 0, r = 0;
+        if (i < n) { key = lane_key(pairs[i], a); r = atomicAdd(&lh[key], 1); }
+        __syncthreads();
+        for (int k = threadIdx.x; k < SORT_KEYS; k += 256) if (lh[k]) lbase[k] = atomicAdd(&cursor[k], lh[k]);
+        __syncthreads();
+        if (i < n) order[lbase[key] + r] = i;
+        __syncthreads();
+    }
 }
 
 template <int LP>
@@ -265,32 +454,65 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
                const meme_bsw_opt* opt) {
     if (opt->e_ins <= 0 || opt->e_del <= 0) { meme_set_error("gap extension penalties must be positive"); return MEME_E_ARG; }
     int rc;
-    // counters: [0..2] class counts, [3] max qlen of the long class, [4..6] tickets
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 8 * sizeof(int) + 64))) return rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->bsw_order, (size_t)N_CLS * npairs * sizeof(int)))) return rc;
-    int* cnt = (int*)ctx->counters.p;
-    HIP_TRY(hipMemsetAsync(cnt, 0, 8 * sizeof(int), ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
-    hipLaunchKernelGGL(k_bsw_classify, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_pairs, npairs,
-                       (int*)ctx->bsw_order.p, cnt, cnt + 3);
-    HIP_TRY(hipGetLastError());
-    int h[4];
-    HIP_TRY(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // counters (ints): [0..SORT_KEYS) histogram by query length, [SORT_KEYS..2*SORT_KEYS] exclusive offsets (+ total),
+    // then the scatter cursors, the longest query of the pairs the lane kernel cannot take, and the kernels' tickets
+    const size_t n_ints = 3 * (size_t)SORT_KEYS + 16;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, n_ints * sizeof(int)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->bsw_order, (size_t)npairs * sizeof(int)))) return rc;
+    int* hist = (int*)ctx->counters.p;
+    int* offs = hist + SORT_KEYS;
+    int* cursor = offs + SORT_KEYS + 1;
+    int* maxq = cursor + SORT_KEYS;
+    unsigned int* tickets = (unsigned int*)(maxq + 1);
+    int* order = (int*)ctx->bsw_order.p;
     i64 dev_cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
-    BswArgs A;
-    A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
-    for (int c = 0; c < N_CLS; ++c) {
-        if (h[c] == 0) continue;
-        A.order = (const int*)ctx->bsw_order.p + (size_t)c * npairs;
-        A.npairs = h[c];
-        A.ticket = (unsigned int*)(cnt + 4 + c);
-        if (c == 0) rc = launch_cls<16>(ctx, A, 16, dev_cus);
-        else if (c == 1) rc = launch_cls<32>(ctx, A, 32, dev_cus);
-        else rc = launch_cls<64>(ctx, A, ((h[3] + 63) / 64) * 64, dev_cus);
-        if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(hist, 0, n_ints * sizeof(int), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    {
+        i64 sblocks = ((i64)npairs + 255) / 256;
+        if (sblocks > dev_cus * 8) sblocks = dev_cus * 8;
+        hipLaunchKernelGGL(k_bsw_hist, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, opt->a, hist, maxq);
+        hipLaunchKernelGGL(k_bsw_scan, dim3(1), dim3(SORT_KEYS), 0, ctx->stream, hist, offs, cursor);
+        hipLaunchKernelGGL(k_bsw_scatter, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, opt->a, cursor, order);
+        HIP_TRY(hipGetLastError());
+    }
+    int h_local[SORT_KEYS + 2];
+    HIP_TRY(hipMemcpyAsync(h_local, offs, (SORT_KEYS + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h_local + SORT_KEYS + 1, maxq, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // ---- lane-per-pair kernel, one launch per LDS size class (pairs are sorted by query length) --------------------------
+    int qlo = 0;
+    for (int c = 0; c < N_LANE_CLS; ++c) {
+        const int qhi = LANE_CLS_Q[c];                       // class = query lengths [qlo, qhi]
+        const int first = h_local[qlo], last = h_local[qhi + 1];
+        qlo = qhi + 1;
+        if (last <= first) continue;
+        LaneArgs L;
+        L.pairs = d_pairs; L.ref = d_ref; L.qer = d_qer; L.order = order; L.first = first; L.count = last - first;
+        L.w = w; L.o = *opt; L.ticket = tickets + c;
+        const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        i64 want = ((i64)L.count + 63) / 64;
+        i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 16;
+        if (blocks > want) blocks = want;
+        hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- the rest (long queries, scores beyond 14 bits): lanes-per-pair kernel ------------------------------------------
+    {
+        const int first = h_local[SORT_KEYS - 1], last = h_local[SORT_KEYS];
+        if (last > first) {
+            BswArgs A;
+            A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
+            A.order = order + first;
+            A.npairs = last - first;
+            A.ticket = tickets + N_LANE_CLS;
+            const int mq = h_local[SORT_KEYS + 1] < 1 ? 1 : h_local[SORT_KEYS + 1];
+            if ((rc = launch_cls<64>(ctx, A, ((mq + 63) / 64) * 64, dev_cus))) return rc;
+        }
     }
     HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

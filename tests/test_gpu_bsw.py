@@ -64,3 +64,29 @@ def test_hip_bsw_edge_cases(ctx):
     got = pairs.copy(); ctx.bsw_batch(got, ref, qer, 100, _opt(5))
     assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want))
     assert ctx.bsw_batch(np.zeros(0, hipapi.SEQPAIR), ref, qer, 100).shape[0] == 0
+
+
+@pytest.mark.parametrize("q", [1, 62, 63, 158, 159, 318, 319, 600, 601])
+def test_hip_bsw_length_class_boundaries(ctx, q):
+    # the lane-per-pair kernel is launched per LDS size class (query <= 62 / 158 / 318 / 600); longer queries and scores
+    # beyond 14 bits take the lanes-per-pair kernel: every boundary, with a wavefront that is not full
+    pairs, ref, qer = bsw_gen.make_pairs(130, seed=100 + q, min_q=q, max_q=q, h0_max=60)
+    want = pairs.copy()
+    O.bsw_batch(want, ref, qer, 100, O.default_bsw_params(5), threads=0)
+    got = pairs.copy()
+    ctx.bsw_batch(got, ref, qer, 100, _opt(5))
+    assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want))
+
+
+def test_hip_bsw_scores_beyond_14_bits_and_mixed_lengths(ctx):
+    a, ra, qa = bsw_gen.make_pairs(300, seed=21, max_q=120, h0_max=30000)      # h0 + qlen >= 2^14 for most pairs
+    b, rb, qb = bsw_gen.make_pairs(300, seed=22, max_q=700)                     # both kernels in one batch
+    b = b.copy(); b["idr"] += ra.shape[0]; b["idq"] += qa.shape[0]
+    pairs = np.concatenate([a, b]); ref = np.concatenate([ra, rb]); qer = np.concatenate([qa, qb])
+    order = np.random.default_rng(3).permutation(pairs.shape[0])
+    pairs = pairs[order].copy()
+    want = pairs.copy()
+    O.bsw_batch(want, ref, qer, 100, O.default_bsw_params(5), threads=0)
+    got = pairs.copy()
+    ctx.bsw_batch(got, ref, qer, 100, _opt(5))
+    assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want))
