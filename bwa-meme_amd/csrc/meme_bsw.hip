@@ -239,8 +239,8 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
 // lanes-per-pair kernel above.
 constexpr int LANE_QMAX = 600;
 constexpr int LANE_SCORE_LIMIT = 1 << 14;
-constexpr int N_LANE_CLS = 4;
-constexpr int LANE_CLS_Q[N_LANE_CLS] = {62, 158, 318, LANE_QMAX};    // LDS = (q + 2) * 256 B per wavefront
+constexpr int N_LANE_CLS = 8;                                        // LDS = (q + 2) * 256 B per wavefront: 8 KB ... 150 KB
+constexpr int LANE_CLS_Q[N_LANE_CLS] = {30, 62, 94, 126, 158, 222, 318, LANE_QMAX};
 constexpr int SORT_KEYS = 1024;                                      // key = query length, SORT_KEYS-1 = not eligible
 
 struct LaneArgs {
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
             unsigned word = beg < end ? he[beg * 64] : 0u;
             for (int j = beg; j < end; ++j) {
                 const unsigned cur = word;
-                if (j + 1 < end) word = he[(j + 1) * 64];      // next column's state, in flight during this cell
+                word = he[(j + 1) * 64];                       // next column's state, in flight during this cell (j+1 <= qlen)
                 int M = (int)(cur & 0x3fffu), e = (int)((cur >> 14) & 0x3fffu);
                 const int qb = (int)(cur >> 28);
                 const int sc = qb > 3 ? -1 : (qb == tb ? s_eq : s_ne);
@@ -456,7 +456,7 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     int rc;
     // counters (ints): [0..SORT_KEYS) histogram by query length, [SORT_KEYS..2*SORT_KEYS] exclusive offsets (+ total),
     // then the scatter cursors, the longest query of the pairs the lane kernel cannot take, and the kernels' tickets
-    const size_t n_ints = 3 * (size_t)SORT_KEYS + 16;
+    const size_t n_ints = 3 * (size_t)SORT_KEYS + 32;
     if ((rc = meme_buf_reserve(ctx, ctx->counters, n_ints * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->bsw_order, (size_t)npairs * sizeof(int)))) return rc;
     int* hist = (int*)ctx->counters.p;

@@ -66,9 +66,9 @@ def test_hip_bsw_edge_cases(ctx):
     assert ctx.bsw_batch(np.zeros(0, hipapi.SEQPAIR), ref, qer, 100).shape[0] == 0
 
 
-@pytest.mark.parametrize("q", [1, 62, 63, 158, 159, 318, 319, 600, 601])
+@pytest.mark.parametrize("q", [1, 30, 31, 62, 63, 94, 95, 126, 127, 158, 159, 222, 223, 318, 319, 600, 601])
 def test_hip_bsw_length_class_boundaries(ctx, q):
-    # the lane-per-pair kernel is launched per LDS size class (query <= 62 / 158 / 318 / 600); longer queries and scores
+    # the lane-per-pair kernel is launched per LDS size class (query <= 30 / 62 / 94 / 126 / 158 / 222 / 318 / 600); longer queries and scores
     # beyond 14 bits take the lanes-per-pair kernel: every boundary, with a wavefront that is not full
     pairs, ref, qer = bsw_gen.make_pairs(130, seed=100 + q, min_q=q, max_q=q, h0_max=60)
     want = pairs.copy()
