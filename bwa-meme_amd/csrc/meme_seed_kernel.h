@@ -56,7 +56,7 @@ constexpr int TIER_LCAP[N_TIERS] = {LCAP0, 512, 512};     // LDS ring: SMEMs of 
 struct PackGeom {
     int W;        // u64 words per strand (>= ceil(maxlen/32) + 2)
     int MW;       // u64 N-mask words per strand
-    int stride;   // 2*W + 2*MW + 1 (last word = read length)
+    int stride;   // 2*W + 2*MW + 1 (last word = read length | has-N flag << 31)
 };
 
 struct SeedArgs {
@@ -111,8 +111,14 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
             const i64 ro = read_off[r];
             int len = (int)(read_off[r + 1] - ro);
             u64 v = 0;
-            if (k == g.stride - 1) v = (u64)(unsigned)len;     // length word
-            else {
+            if (k == g.stride - 1) {                            // length word: length | (read has an N) << 31
+                bool any_n = false;
+                if (len <= MAX_READ_LEN) {
+                    const uint8_t* p = sb + shift + (int)(ro - b0);
+                    for (int i = 0; i < len; ++i) any_n |= p[i] >= 4;
+                }
+                v = (u64)(unsigned)len | (any_n ? (1ull << 31) : 0ull);
+            } else {
                 if (len > MAX_READ_LEN) len = 0;
                 const uint8_t* p = sb + shift + (int)(ro - b0);
                 if (k < 2 * g.W) {
@@ -172,7 +178,21 @@ typedef const __attribute__((address_space(1))) u64* glb_u64;
 typedef const __attribute__((address_space(1))) SaEnt* glb_ent;
 typedef const __attribute__((address_space(1))) RmiRec* glb_rmi;
 
-__device__ __forceinline__ u64 ext_l(lds_u64 w, int s) {
+// Where a search reads its query words from.  1 (default): the read's packed record is staged in LDS when the read is
+// pulled.  0: straight from the packed-read array in global memory (the 168 B record stays L2-resident for the ~60
+// searches of its lifetime); the per-read LDS footprint shrinks to the state words so twice as many reads fit a CU,
+// which lifts 2 lanes/read from 81 to 113 M reads/s (512 Mbp probe) but costs 4 lanes/read 5 % (118 -> 112): one more
+// dependent L2 round trip per search.  Measured, kept as a build option.
+#ifndef SEED_QUERY_LDS
+#define SEED_QUERY_LDS 1
+#endif
+#if SEED_QUERY_LDS
+typedef lds_u64 q_u64;
+#else
+typedef const __attribute__((address_space(1))) u64* q_u64;
+#endif
+
+__device__ __forceinline__ u64 ext_l(q_u64 w, int s) {
     int k = s >> 5, sh = (s & 31) * 2;
     u64 a = w[k], b = w[k + 1];
     return sh ? (a << sh) | (b >> (64 - sh)) : a;
@@ -206,7 +226,7 @@ constexpr int TICKET_CHUNK = 32;     // reads a wavefront draws from the global 
 __host__ __device__ inline size_t seed_lds_group_bytes(int G, int stride, int lcap) {
     const int groups = BLOCK / G;
     const int W = win_entries(G) * G;
-    return (((size_t)groups * stride * 8 + (size_t)groups * (2 * lcap + ST_WORDS + (W + 1) / 2) * sizeof(int)) + 7) & ~(size_t)7;
+    return (((size_t)groups * (SEED_QUERY_LDS ? stride * 8 : 0) + (size_t)groups * (2 * lcap + ST_WORDS + (W + 1) / 2) * sizeof(int)) + 7) & ~(size_t)7;
 }
 // + per wavefront: the ticket chunk it is handing out (count, base)
 inline size_t seed_lds_bytes(int G, const PackGeom& geo, int lcap) {
@@ -220,9 +240,8 @@ inline size_t seed_lds_bytes(int G, const PackGeom& geo, int lcap) {
 // The 64-bit keys settle most entries; the ones whose 32 key bases all agree continue in the 2-bit text through ONE
 // loop instance shared by the lane's E entries (a wavefront usually has one such entry per read).
 template <int E>
-__device__ __forceinline__ void window_compare(glb_u64 pac, i64 n, lds_u64 s, int off, int cap, const u64 (&ek)[E],
+__device__ __forceinline__ void window_compare(glb_u64 pac, i64 n, q_u64 s, u64 wq, int off, int cap, const u64 (&ek)[E],
                                                const u64 (&ep)[E], int (&lcp)[E], bool (&less)[E]) {
-    const u64 wq = ext_l(s, off);
     int l[E], Lc[E];
     bool lt[E];
     unsigned pend = 0;
@@ -323,10 +342,10 @@ __device__ __forceinline__ int slot_pair(const int (&v)[E], int t, int ia, int i
     return group_or<G>(x);
 }
 
-__device__ __forceinline__ bool is_n(lds_u64 mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
+__device__ __forceinline__ bool is_n(q_u64 mask, int i) { return (mask[i >> 6] >> (i & 63)) & 1ull; }
 
 // first ambiguous base at/after `from` (Tokenization's *ambiguous_pos, :795-901)
-__device__ __forceinline__ int first_n(lds_u64 mask, bool has_n, int from, int l_seq) {
+__device__ __forceinline__ int first_n(q_u64 mask, bool has_n, int from, int l_seq) {
     if (!has_n) return l_seq;
     int w = from >> 6;
     u64 m = mask[w] & (~0ull << (from & 63));
@@ -373,10 +392,17 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     const int gbase = lane & ~(G - 1);
     const int stride = A.geo.stride, PW = A.geo.W, MW = A.geo.MW;
     const int cap = A.cap, lcap = A.lcap;
+#if SEED_QUERY_LDS
     u64* rd = reinterpret_cast<u64*>(smem_raw) + (size_t)gib * stride;
-    const lds_u64 fw = (lds_u64)rd, rcs = fw + PW, nfw = fw + 2 * PW, nrc = nfw + MW;
+    const q_u64 fw = (lds_u64)rd;
+#else
+    q_u64 fw = (q_u64)A.packed;                          // the current read's record: fw[PW] rc[PW] nfw[MW] nrc[MW] len
+#endif
+#define rcs (fw + PW)
+#define nfw (fw + 2 * PW)
+#define nrc (fw + 2 * PW + MW)
     // per group after the packed reads: SMEM ring (2 ints per entry), cold state, two windows of 16-bit LCPs
-    const lds_int ring = (lds_int)(reinterpret_cast<int*>(smem_raw + (size_t)GROUPS * stride * 8) +
+    const lds_int ring = (lds_int)(reinterpret_cast<int*>(smem_raw + (SEED_QUERY_LDS ? (size_t)GROUPS * stride * 8 : 0)) +
                                    (size_t)gib * (2 * lcap + ST_WORDS + (W + 1) / 2));
     const lds_int sm_se = ring;               // start | end << 16
     const lds_int sm_cnt = ring + lcap;
@@ -406,6 +432,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     bool q_rc = false, q_exact = false;
     i64 base = 0, lo = -1, hi = n;
     int stepk = 0;
+    u64 wq = 0;
     unsigned acc_searches = 0, acc_windows = 0;             // of this group's completed reads
     if (lane == 0) wv[0] = TICKET_CHUNK;                    // empty chunk
     LDS_HANDOFF();
@@ -431,7 +458,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             do {
                 if (AT(PC_ZZ_TOP)) {       // zig-zag loop head (:1724-1737, :1969)
                     if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) pc = PC_ZZ_END;
-                    else if (FLAG(F_ZZ_CHECK) && is_n(nfw, st[ST_ZZ_SP])) {
+                    else if (FLAG(F_ZZ_CHECK) && has_n && is_n(nfw, st[ST_ZZ_SP])) {
                         if (l_seq - st[ST_ZZ_SP] < msl) { pivot = l_seq; st[ST_ZZ_SP] = l_seq; }
                         else { st[ST_ZZ_SP] += 1; pivot = pivot + 1; }
                     } else { q_kind = K_ZZ_LEFT; have = true; }
@@ -471,10 +498,10 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
                         pivot = (qbeg + qend) >> 1;
                         min_intv = cnt + 1;
-                        if (is_n(nfw, pivot)) {
+                        if (has_n && is_n(nfw, pivot)) {
                             pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
                             pc = PC_R2_AFTER;                         // backward hop (reads with N only)
-                        } else if (pivot != 0 && !is_n(nfw, pivot - 1)) { q_kind = K_OP_MEM; have = true; }
+                        } else if (pivot != 0 && !(has_n && is_n(nfw, pivot - 1))) { q_kind = K_OP_MEM; have = true; }
                         else { q_kind = K_OP_SMEM; have = true; }
                     }
                 }
@@ -482,10 +509,10 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                     if (pivot >= l_seq || ++st[ST_AP_GUARD] > 4 * l_seq + 16) pc = PC_R3_INIT;
                     else {
                         st[ST_BEFORE] = st[ST_N_SMEMS]; st[ST_SM_BASE] = st[ST_BEFORE]; SETFLAG(F_REC, true);
-                        if (is_n(nfw, pivot)) {
+                        if (has_n && is_n(nfw, pivot)) {
                             pivot = (l_seq - pivot < msl) ? l_seq : pivot + 1;
                             pc = PC_AFTER_STEP1;                      // backward hop (reads with N only)
-                        } else if (pivot != 0 && !is_n(nfw, pivot - 1)) {
+                        } else if (pivot != 0 && !(has_n && is_n(nfw, pivot - 1))) {
                             // zig-zag entry: the loop head's checks pass trivially (sp = pivot < next = l_seq, no N here)
                             st[ST_ZZ_NEXT] = l_seq; SETFLAG(F_ZZ_CHECK, true); SETFLAG(F_ZZ_RET_ONEPOS, false); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 1;
                             q_kind = K_ZZ_LEFT; have = true;
@@ -503,7 +530,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 if (AT(PC_R3_TOP)) {       // Learned_bwtSeedStrategyAllPosOneThread loop head (:982-1012)
                     for (;;) {
                         if (!(pivot < l_seq - msl + 1)) { pc = PC_DONE; break; }
-                        if (is_n(nfw, pivot)) { pivot = pivot + 1; continue; }
+                        if (has_n && is_n(nfw, pivot)) { pivot = pivot + 1; continue; }
                         const int valid = first_n(nfw, has_n, pivot, l_seq) - pivot;
                         if (valid < msl) { pivot = pivot + valid; continue; }
                         q_kind = K_R3; have = true;
@@ -552,20 +579,25 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                     else {
                         const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
                         const u64* src = A.packed + rid * stride;
+#if SEED_QUERY_LDS
                         // stage the packed read in LDS (coalesced 8-byte loads; the length word travels in the same
                         // batch of loads) and clear the cold state
-                        bool any_n = false;
                         const int lw = (stride - 1) % G;               // the lane that loads the length word
                         u64 lenw = 0;
                         for (int k = t; k < stride; k += G) {
                             u64 v = src[k];
                             rd[k] = v;
-                            if (k >= 2 * PW && k < 2 * PW + MW) any_n |= (v != 0);
                             if (k == stride - 1) lenw = v;
                         }
-                        l_seq = (int)__shfl((int)lenw, gbase + lw);    // k_pack_reads stores the length in the last word
+                        lenw = (u64)(unsigned)__shfl((int)lenw, gbase + lw);
+#else
+                        // the searches read the record in place; only its last word (length, "has an N" flag) is needed now
+                        fw = (q_u64)src;
+                        const u64 lenw = fw[stride - 1];
+#endif
+                        l_seq = (int)(lenw & 0x7fffffffull);           // k_pack_reads: length | has-N flag << 31
+                        has_n = ((lenw >> 31) & 1ull) != 0;
                         for (int k = t; k < ST_WORDS; k += G) st[k] = 0;
-                        has_n = GBALLOT(any_n) != 0;
                         LDS_HANDOFF();
                         if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
                             // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262);
@@ -577,7 +609,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                             st[ST_TICKET_HI] = (int)(ticket >> 32);
                             pivot = 0; msl = A.opt.min_seed_len; min_intv = 1;
                             pc = PC_ALLPOS_TOP;
-                            if (!is_n(nfw, 0)) {                       // first step of PC_ALLPOS_TOP at pivot 0, inlined
+                            if (!(has_n && is_n(nfw, 0))) {                       // first step of PC_ALLPOS_TOP at pivot 0, inlined
                                 st[ST_AP_GUARD] = 1; SETFLAG(F_REC, true);
                                 q_kind = K_S1_RIGHT; have = true;
                             }
@@ -606,7 +638,8 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             q_exact = q_kind == K_S1_RIGHT || q_kind == K_ZZ_RIGHT || q_kind == K_OP_SMEM;
             q_mode = q_kind == K_R3 ? 2 : ((q_exact || min_intv != 1) ? 1 : 0);
             st[ST_SEARCHES] = st[ST_SEARCHES] + 1;
-            u64 key = ext_l(q_rc ? rcs : fw, off);
+            wq = ext_l(q_rc ? rcs : fw, off);                 // first 32 bases of the query: every window compares against it
+            u64 key = wq;
             if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
             const i64 pos = rmi_lookup(l2, l1, A.I.shift, n, key);
             base = pos - W / 2;
@@ -618,7 +651,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         PROF_MARK(1);
 
         // ================= window: E coalesced loads of G entries each, issued together, then the compares ===========
-        const lds_u64 s = q_rc ? rcs : fw;
+        const q_u64 s = q_rc ? rcs : fw;
         int lcp[E];
         bool less[E];
         {
@@ -626,7 +659,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
 #pragma unroll
             for (int e = 0; e < E; ++e) { ek[e] = sa[base + e * G + t].key; ep[e] = sa[base + e * G + t].pos; }
             st[ST_WINDOWS] = st[ST_WINDOWS] + 1;
-            window_compare<E>(pac, n, s, off, capc, ek, ep, lcp, less);
+            window_compare<E>(pac, n, s, wq, off, capc, ek, ep, lcp, less);
         }
         PROF_MARK(2);
         u64 m = 0;
@@ -835,6 +868,9 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         PROF_MARK(5);
     }
 #undef PROF_MARK
+#undef rcs
+#undef nfw
+#undef nrc
 #undef GBALLOT
 #undef LD64
 #undef ST64
