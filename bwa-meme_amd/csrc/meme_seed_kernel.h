@@ -86,12 +86,14 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char pk_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(pk_raw);
     const uint8_t* sb = pk_raw;
+    __shared__ int has_n[64];                                   // per read of the group (PACK_RB <= 64)
     for (i64 r0 = (i64)blockIdx.x * PACK_RB; r0 < nreads; r0 += (i64)gridDim.x * PACK_RB) {
         const int nr = (int)(nreads - r0 < PACK_RB ? nreads - r0 : PACK_RB);
         const i64 b0 = read_off[r0], b1 = read_off[r0 + nr];
         const i64 a0 = b0 & ~3ll;                              // dword-aligned start (reads + a0 is 4-byte aligned)
         const int ndw = (int)((b1 - a0 + 3) >> 2);
         __syncthreads();                                       // previous iteration's readers are done
+        if (threadIdx.x < 64) has_n[threadIdx.x] = 0;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(reads + a0);
         for (int k = threadIdx.x; k < ndw; k += blockDim.x) {
             uint32_t v;
@@ -105,48 +107,47 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
         }
         __syncthreads();
         const int shift = (int)(b0 - a0);
-        for (int wk = threadIdx.x; wk < nr * g.stride; wk += blockDim.x) {
-            const int rr = wk / g.stride, k = wk - rr * g.stride;
+        const int nw = g.stride - 1;                            // data words per read; the length word follows them
+        for (int wk = threadIdx.x; wk < nr * nw; wk += blockDim.x) {
+            const int rr = wk / nw, k = wk - rr * nw;
             const i64 r = r0 + rr;
             const i64 ro = read_off[r];
             int len = (int)(read_off[r + 1] - ro);
             u64 v = 0;
-            if (k == g.stride - 1) {                            // length word: length | (read has an N) << 31
-                bool any_n = false;
-                if (len <= MAX_READ_LEN) {
-                    const uint8_t* p = sb + shift + (int)(ro - b0);
-                    for (int i = 0; i < len; ++i) any_n |= p[i] >= 4;
+            if (len > MAX_READ_LEN) len = 0;
+            const uint8_t* p = sb + shift + (int)(ro - b0);
+            if (k < 2 * g.W) {
+                const bool rc = k >= g.W;
+                const int w = rc ? k - g.W : k;
+                for (int j = 0; j < 32; ++j) {
+                    const int i = 32 * w + j;
+                    u64 c = 0;
+                    if (i < len) {
+                        const uint8_t bb = rc ? p[len - 1 - i] : p[i];
+                        c = bb < 4 ? (rc ? 3 - bb : bb) : 0;   // N packed as A (src/bwamem.cpp:1293-1294)
+                    }
+                    v = (v << 2) | c;
                 }
-                v = (u64)(unsigned)len | (any_n ? (1ull << 31) : 0ull);
             } else {
-                if (len > MAX_READ_LEN) len = 0;
-                const uint8_t* p = sb + shift + (int)(ro - b0);
-                if (k < 2 * g.W) {
-                    const bool rc = k >= g.W;
-                    const int w = rc ? k - g.W : k;
-                    for (int j = 0; j < 32; ++j) {
-                        const int i = 32 * w + j;
-                        u64 c = 0;
-                        if (i < len) {
-                            const uint8_t bb = rc ? p[len - 1 - i] : p[i];
-                            c = bb < 4 ? (rc ? 3 - bb : bb) : 0;   // N packed as A (src/bwamem.cpp:1293-1294)
-                        }
-                        v = (v << 2) | c;
-                    }
-                } else {
-                    int m = k - 2 * g.W;
-                    const bool rc = m >= g.MW;
-                    if (rc) m -= g.MW;
-                    for (int j = 0; j < 64; ++j) {
-                        const int i = 64 * m + j;
-                        if (i < len) {
-                            const uint8_t bb = rc ? p[len - 1 - i] : p[i];
-                            if (bb >= 4) v |= 1ull << j;
-                        }
+                int m = k - 2 * g.W;
+                const bool rc = m >= g.MW;
+                if (rc) m -= g.MW;
+                for (int j = 0; j < 64; ++j) {
+                    const int i = 64 * m + j;
+                    if (i < len) {
+                        const uint8_t bb = rc ? p[len - 1 - i] : p[i];
+                        if (bb >= 4) v |= 1ull << j;
                     }
                 }
+                if (v) has_n[rr] = 1;                           // benign race: every writer stores 1
             }
             out[r * g.stride + k] = v;
+        }
+        __syncthreads();
+        for (int rr = threadIdx.x; rr < nr; rr += blockDim.x) {  // length word: length | (read has an N) << 31
+            const i64 r = r0 + rr;
+            const int len = (int)(read_off[r + 1] - read_off[r]);
+            out[r * g.stride + nw] = (u64)(unsigned)len | (has_n[rr] ? (1ull << 31) : 0ull);
         }
     }
 }
