@@ -93,7 +93,6 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
         const i64 a0 = b0 & ~3ll;                              // dword-aligned start (reads + a0 is 4-byte aligned)
         const int ndw = (int)((b1 - a0 + 3) >> 2);
         __syncthreads();                                       // previous iteration's readers are done
-        if (threadIdx.x < 64) has_n[threadIdx.x] = 0;
         const uint32_t* src = reinterpret_cast<const uint32_t*>(reads + a0);
         for (int k = threadIdx.x; k < ndw; k += blockDim.x) {
             uint32_t v;
@@ -108,6 +107,25 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
         __syncthreads();
         const int shift = (int)(b0 - a0);
         const int nw = g.stride - 1;                            // data words per read; the length word follows them
+        // does the read contain an ambiguous base?  (dword-wide scan of the staged bytes; almost always "no", and then
+        // its N-mask words are zero without looking at the bases again)
+        for (int rr = threadIdx.x; rr < nr; rr += blockDim.x) {
+            const i64 ro = read_off[r0 + rr];
+            const int len = (int)(read_off[r0 + rr + 1] - ro);
+            uint32_t acc = 0;
+            if (len > 0 && len <= MAX_READ_LEN) {
+                const int o = shift + (int)(ro - b0), last = o + len - 1;
+                const int d0 = o >> 2, d1 = last >> 2;
+                for (int d = d0; d <= d1; ++d) {
+                    uint32_t m = 0xFCFCFCFCu;
+                    if (d == d0) m &= 0xFFFFFFFFu << (8 * (o & 3));
+                    if (d == d1) m &= 0xFFFFFFFFu >> (8 * (3 - (last & 3)));
+                    acc |= stage[d] & m;
+                }
+            }
+            has_n[rr] = acc != 0;
+        }
+        __syncthreads();
         for (int wk = threadIdx.x; wk < nr * nw; wk += blockDim.x) {
             const int rr = wk / nw, k = wk - rr * nw;
             const i64 r = r0 + rr;
@@ -119,6 +137,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
             if (k < 2 * g.W) {
                 const bool rc = k >= g.W;
                 const int w = rc ? k - g.W : k;
+#pragma unroll 16
                 for (int j = 0; j < 32; ++j) {
                     const int i = 32 * w + j;
                     u64 c = 0;
@@ -128,7 +147,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
                     }
                     v = (v << 2) | c;
                 }
-            } else {
+            } else if (has_n[rr]) {
                 int m = k - 2 * g.W;
                 const bool rc = m >= g.MW;
                 if (rc) m -= g.MW;
@@ -139,7 +158,6 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
                         if (bb >= 4) v |= 1ull << j;
                     }
                 }
-                if (v) has_n[rr] = 1;                           // benign race: every writer stores 1
             }
             out[r * g.stride + k] = v;
         }
