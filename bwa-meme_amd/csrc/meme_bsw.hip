@@ -278,13 +278,21 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
         // ---- first row (:143-145) with the query bases folded in -----------------------------------------
         {
             const int first = h0 > oe_ins ? h0 - oe_ins : 0;
-            for (int j = 0; j <= qlen; ++j) {
-                int v;
-                if (j == 0) v = h0;
-                else if (j == 1) v = first;
-                else { const int prev = first - (j - 2) * e_ins; v = prev > e_ins ? prev - e_ins : 0; }
-                const unsigned qb = j < qlen ? (unsigned)query[j] : 0u;
-                he[j * 64] = he_pack(v, 0, (qb > 4u ? 4u : qb) << 28);
+            // query bytes in batches of 8 independent loads (a lane's bytes are consecutive: same cache line)
+            for (int j0 = 0; j0 <= qlen; j0 += 8) {
+                unsigned qb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) qb[u] = j0 + u < qlen ? (unsigned)query[j0 + u] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+                    if (j > qlen) break;
+                    int v;
+                    if (j == 0) v = h0;
+                    else if (j == 1) v = first;
+                    else { const int prev = first - (j - 2) * e_ins; v = prev > e_ins ? prev - e_ins : 0; }
+                    he[j * 64] = he_pack(v, 0, (qb[u] > 4u ? 4u : qb[u]) << 28);
+                }
             }
         }
         // band cap (:148-156)
