@@ -8,7 +8,8 @@
 //  * k_bsw_lane -- one pair per lane (64 pairs per wavefront, pairs counting-sorted by query length so the lanes finish
 //    together): the inter-task parallelism of the reference's own SIMD code at wavefront width.  Takes every pair whose
 //    query fits the LDS classes (<= 600 bases) and whose scores fit 14 bits -- all short-read extensions.
-//  * k_bsw<64>  -- 64 lanes per pair for the rest (long queries, huge h0).
+//  * k_bsw<LP>  -- 16 / 32 / 64 lanes per pair (by query length) for the rest (long queries, huge h0) and for small
+//    batches, where latency matters: a lone pair takes milliseconds on one lane (see bsw_lane_min_pairs).
 //
 // Why row-synchronous and not anti-diagonal (k_bsw): the function's observable behaviour is defined row by row
 // -- the band [beg,end) of row i+1 is trimmed from the zero runs of row i (:217-221), the z-drop / m==0
@@ -380,8 +381,11 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
 }
 
 // ---- counting sort of the pairs by query length (the lanes of a wavefront should finish together) -------------------------
+// a >= 0: key for the lane-per-pair kernel (query length, or SORT_KEYS-1 when the pair is not eligible);
+// a < 0: plain query-length key (clipped), used when the whole batch goes to the lanes-per-pair kernel
 __device__ __forceinline__ int lane_key(const meme_seqpair& p, int a) {
-    const long long bound = (long long)p.h0 + (long long)p.len2 * (a > 0 ? a : 0) + 1;
+    if (a < 0) return p.len2 < 0 ? 0 : (p.len2 < SORT_KEYS - 1 ? p.len2 : SORT_KEYS - 1);
+    const long long bound = (long long)p.h0 + (long long)p.len2 * a + 1;
     const bool ok = p.len2 >= 0 && p.len2 <= LANE_QMAX && p.len1 >= 0 && p.h0 >= 0 && bound < LANE_SCORE_LIMIT;
     return ok ? p.len2 : SORT_KEYS - 1;
 }
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(256) k_bsw_hist(const meme_seqpair* __restrict
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int key = lane_key(pairs[i], a);
         atomicAdd(&lh[key], 1);
-        if (key == SORT_KEYS - 1) mq = mq > pairs[i].len2 ? mq : pairs[i].len2;
+        if (key == SORT_KEYS - 1 || a < 0) mq = mq > pairs[i].len2 ? mq : pairs[i].len2;
     }
     __syncthreads();
     for (int k = threadIdx.x; k < SORT_KEYS; k += 256) if (lh[k]) atomicAdd(&hist[k], lh[k]);
@@ -478,47 +482,61 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
     HIP_TRY(hipMemsetAsync(hist, 0, n_ints * sizeof(int), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+    // big batches: one pair per lane (throughput).  Small batches (the reference's 512-read call granularity): 16-64
+    // lanes per pair, because a lone pair on one lane takes milliseconds.
+    const bool use_lane = (i64)npairs >= ctx->bsw_lane_min_pairs;
+    const int key_a = use_lane ? (opt->a > 0 ? opt->a : 0) : -1;
     {
         i64 sblocks = ((i64)npairs + 255) / 256;
         if (sblocks > dev_cus * 8) sblocks = dev_cus * 8;
-        hipLaunchKernelGGL(k_bsw_hist, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, opt->a, hist, maxq);
+        hipLaunchKernelGGL(k_bsw_hist, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, key_a, hist, maxq);
         hipLaunchKernelGGL(k_bsw_scan, dim3(1), dim3(SORT_KEYS), 0, ctx->stream, hist, offs, cursor);
-        hipLaunchKernelGGL(k_bsw_scatter, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, opt->a, cursor, order);
+        hipLaunchKernelGGL(k_bsw_scatter, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, key_a, cursor, order);
         HIP_TRY(hipGetLastError());
     }
     int h_local[SORT_KEYS + 2];
     HIP_TRY(hipMemcpyAsync(h_local, offs, (SORT_KEYS + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(h_local + SORT_KEYS + 1, maxq, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    // ---- lane-per-pair kernel, one launch per LDS size class (pairs are sorted by query length) --------------------------
-    int qlo = 0;
-    for (int c = 0; c < N_LANE_CLS; ++c) {
-        const int qhi = LANE_CLS_Q[c];                       // class = query lengths [qlo, qhi]
-        const int first = h_local[qlo], last = h_local[qhi + 1];
-        qlo = qhi + 1;
-        if (last <= first) continue;
-        LaneArgs L;
-        L.pairs = d_pairs; L.ref = d_ref; L.qer = d_qer; L.order = order; L.first = first; L.count = last - first;
-        L.w = w; L.o = *opt; L.ticket = tickets + c;
-        const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
-        if (lds > 64 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        i64 want = ((i64)L.count + 63) / 64;
-        i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 16;
-        if (blocks > want) blocks = want;
-        hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
-        HIP_TRY(hipGetLastError());
+    if (use_lane) {
+        // ---- lane-per-pair kernel, one launch per LDS size class (pairs are sorted by query length) ----------------------
+        int qlo = 0;
+        for (int c = 0; c < N_LANE_CLS; ++c) {
+            const int qhi = LANE_CLS_Q[c];                       // class = query lengths [qlo, qhi]
+            const int first = h_local[qlo], last = h_local[qhi + 1];
+            qlo = qhi + 1;
+            if (last <= first) continue;
+            LaneArgs L;
+            L.pairs = d_pairs; L.ref = d_ref; L.qer = d_qer; L.order = order; L.first = first; L.count = last - first;
+            L.w = w; L.o = *opt; L.ticket = tickets + c;
+            const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
+            if (lds > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            i64 want = ((i64)L.count + 63) / 64;
+            i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 16;
+            if (blocks > want) blocks = want;
+            hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
+            HIP_TRY(hipGetLastError());
+        }
     }
-    // ---- the rest (long queries, scores beyond 14 bits): lanes-per-pair kernel ------------------------------------------
+    // ---- lanes-per-pair kernel: the pairs the lane kernel cannot take (long queries, scores beyond 14 bits), or the whole
+    // batch when it is small; 16 / 32 / 64 lanes per pair by query length (4 / 2 / 1 pairs per wavefront)
     {
-        const int first = h_local[SORT_KEYS - 1], last = h_local[SORT_KEYS];
-        if (last > first) {
-            BswArgs A;
-            A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
-            A.order = order + first;
-            A.npairs = last - first;
-            A.ticket = tickets + N_LANE_CLS;
-            const int mq = h_local[SORT_KEYS + 1] < 1 ? 1 : h_local[SORT_KEYS + 1];
+        const int rest0 = use_lane ? h_local[SORT_KEYS - 1] : 0, total = h_local[SORT_KEYS];
+        const int mq = h_local[SORT_KEYS + 1] < 1 ? 1 : h_local[SORT_KEYS + 1];
+        const int cut16 = use_lane ? rest0 : h_local[17], cut32 = use_lane ? rest0 : h_local[33];
+        BswArgs A;
+        A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
+        if (cut16 > rest0) {
+            A.order = order + rest0; A.npairs = cut16 - rest0; A.ticket = tickets + N_LANE_CLS;
+            if ((rc = launch_cls<16>(ctx, A, 16, dev_cus))) return rc;
+        }
+        if (cut32 > cut16) {
+            A.order = order + cut16; A.npairs = cut32 - cut16; A.ticket = tickets + N_LANE_CLS + 1;
+            if ((rc = launch_cls<32>(ctx, A, 32, dev_cus))) return rc;
+        }
+        if (total > cut32) {
+            A.order = order + cut32; A.npairs = total - cut32; A.ticket = tickets + N_LANE_CLS + 2;
             if ((rc = launch_cls<64>(ctx, A, ((mq + 63) / 64) * 64, dev_cus))) return rc;
         }
     }

@@ -56,6 +56,8 @@ struct meme_ctx {
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
     i64 bsw_blocks = 0;
+    i64 bsw_lane_min_pairs = 131072;   // batches at least this big use the lane-per-pair kernel (throughput); smaller ones the
+                                       // lanes-per-pair kernel (latency: a lone pair takes ~6 ms on one lane, ~0.3 ms on 64)
     // timings
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     meme_timings tm = {0, 0, 0, 0, 0, 0, 0};

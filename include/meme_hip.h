@@ -156,7 +156,7 @@ typedef struct {
     int64_t seed_windows;      /* suffix-array windows loaded by the SA-search kernel */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks" */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs" */
 
 #ifdef __cplusplus
 }

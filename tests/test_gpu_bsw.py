@@ -12,9 +12,11 @@ from pymeme import hipapi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[0, 1 << 30], ids=["lane-per-pair", "lanes-per-pair"])
+def ctx(request):
+    # big batches take the lane-per-pair kernel, small ones the lanes-per-pair kernel: force each for every test
     c = hipapi.Context(0)
+    c.set_tuning("bsw_lane_min_pairs", request.param)
     yield c
     c.close()
 
