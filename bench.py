@@ -152,6 +152,11 @@ def bsw_leg(ctx, dev, world):
     return {"metric": "bsw_pairs_per_sec", "value": npairs / (k_ms * 1e-3), "unit": "pairs/s", "per": "gpu",
             "pairs": npairs, "band_w": 100, "kernel_ms": k_ms, "cells_per_pair": cells / base,
             "gcups": cells * reps / (k_ms * 1e-3) / 1e9, "matches_oracle": bool(same),
+            # integer-VALU roofline of the lane-per-pair kernel: 35 VALU instructions per DP cell in its inner loop (ISA count),
+            # against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz int32 lane-ops/s
+            "roofline": {"bound": "valu-int32", "ops_per_cell": 35, "peak": 39.3, "unit": "Tops/s",
+                         "achieved": 35 * cells * reps / (k_ms * 1e-3) / 1e12,
+                         "frac": 35 * cells * reps / (k_ms * 1e-3) / 1e12 / 39.3},
             "cpu_baseline": {"value": big.shape[0] / cpu_dt, "unit": "pairs/s", "cores": cores, "kind": "port",
                              "sample": "%d pairs, scalar restatement of scalarBandedSWA on %d threads" % (big.shape[0], cores)}}
 
@@ -233,6 +238,11 @@ def main():
                         open(cache + ".ok", "w").write("ok")
                 except OSError as e:
                     log("index cache not written: %r" % (e,))
+                    for ext in (".text", ".sa", ".l1", ".l2", ".ok"):
+                        try:
+                            os.remove(cache + ext)
+                        except OSError:
+                            pass
         meta[0], meta[1], meta[2] = n, l2.shape[0], l1.shape[0]
     if world > 1:
         dist.broadcast(meta, 0)
