@@ -52,6 +52,7 @@ for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
                 h.update(line); nlines += 1
     res[exe] = (wall, h.hexdigest(), nlines)
     log(exe, "rc", r.returncode, "wall %.1f s" % wall, "->", "%.0f reads/s (wall, incl. index load)" % (2 * npairs / wall), "sam lines", nlines)
-    for k in keys[-12:]: log("   ", k.strip())
+    for k in err.split("\n")[-45:]:
+        if k.strip(): log("   ", k.strip())
 log("SAM identical:", res["bwa-meme_mode3"][1] == res["bwa-meme_dropin"][1])
 import shutil; shutil.rmtree(d, ignore_errors=True)

@@ -49,8 +49,11 @@ def test_sam_identical_to_reference(tmp_path, paired):
         fqs.append(str(tmp_path / "r2.fq"))
         synth.write_fastq(fqs[1], r2, prefix="p")
     want = _sam("bwa-meme_mode3", prefix, fqs)
-    env = dict(os.environ, MEME_INDEX_PREFIX=prefix)
-    got = _sam("bwa-meme_dropin", prefix, fqs, env=env)
-    assert len(got) == len(want) and len(want) > n
-    diff = [(a, b) for a, b in zip(got, want) if a != b]
-    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+    # the binding either combines the concurrent calls of the reference's workers into one backend call (default) or
+    # forwards every call on its own: same SAM both ways
+    for combine in ("1", "0"):
+        env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_COMBINE=combine)
+        got = _sam("bwa-meme_dropin", prefix, fqs, env=env)
+        assert len(got) == len(want) and len(want) > n
+        diff = [(a, b) for a, b in zip(got, want) if a != b]
+        assert not diff, "combine=%s, first differing SAM line:\n%s\n%s" % ((combine,) + diff[0])
