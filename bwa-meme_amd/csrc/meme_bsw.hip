@@ -320,29 +320,44 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
             if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
             else h1 = 0;
             const int s_eq = tb > 3 ? -1 : sa, s_ne = tb > 3 ? -1 : sb;
-            unsigned word = beg < end ? he[beg * 64] : 0u;
-            for (int j = beg; j < end; ++j) {
-                const unsigned cur = word;
-                word = he[(j + 1) * 64];                       // next column's state, in flight during this cell (j+1 <= qlen)
-                int M = (int)(cur & 0x3fffu), e = (int)((cur >> 14) & 0x3fffu);
-                const int qb = (int)(cur >> 28);
-                const int sc = qb > 3 ? -1 : (qb == tb ? s_eq : s_ne);
-                M = M ? M + sc : 0;                            // :184
-                int h = M > e ? M : e;
-                h = h > f ? h : f;
-                mj = m > h ? mj : j;                           // rightmost column among equal maxima (:188-189)
-                m = m > h ? m : h;
-                int t = M - oe_del;
-                t = t > 0 ? t : 0;
-                e -= e_del;
-                e = e > t ? e : t;                             // E(i+1,j) (:190-194)
-                he[j * 64] = he_pack(h1, e, cur & QMASK);      // H(i,j-1) for the next row (:183)
-                h1 = h;
-                t = M - oe_ins;
-                t = t > 0 ? t : 0;
-                f -= e_ins;
-                f = f > t ? f : t;                             // F(i,j+1) (:195-198)
+            // Four cells per trip with rotating registers for the column state: the next column's LDS word is
+            // requested before the current cell is computed and first touched a whole cell later (a single rotating
+            // register made the compiler wait for the prefetch in the middle of the cell).
+#define BSW_CELL(cur_, nxt_, j_)                                                                              \
+            {                                                                                                  \
+                nxt_ = he[((j_) + 1) * 64];                    /* (j+1 <= qlen: inside the row) */              \
+                int M = (int)(cur_ & 0x3fffu), e = (int)((cur_ >> 14) & 0x3fffu);                               \
+                const int qb = (int)(cur_ >> 28);                                                              \
+                const int sc = qb > 3 ? -1 : (qb == tb ? s_eq : s_ne);                                         \
+                M = M ? M + sc : 0;                            /* :184 */                                      \
+                int h = M > e ? M : e;                                                                         \
+                h = h > f ? h : f;                                                                             \
+                mj = m > h ? mj : (j_);                        /* rightmost column among equal maxima */       \
+                m = m > h ? m : h;                                                                             \
+                int t = M - oe_del;                                                                            \
+                t = t > 0 ? t : 0;                                                                             \
+                e -= e_del;                                                                                    \
+                e = e > t ? e : t;                             /* E(i+1,j) (:190-194) */                       \
+                he[(j_) * 64] = he_pack(h1, e, cur_ & QMASK);  /* H(i,j-1) for the next row (:183) */          \
+                h1 = h;                                                                                        \
+                t = M - oe_ins;                                                                                \
+                t = t > 0 ? t : 0;                                                                             \
+                f -= e_ins;                                                                                    \
+                f = f > t ? f : t;                             /* F(i,j+1) (:195-198) */                       \
             }
+            unsigned wa = beg < end ? he[beg * 64] : 0u, wb = 0u, wc = 0u, wd = 0u;
+            int j = beg;
+            for (; j + 3 < end; j += 4) {
+                BSW_CELL(wa, wb, j)
+                BSW_CELL(wb, wc, j + 1)
+                BSW_CELL(wc, wd, j + 2)
+                BSW_CELL(wd, wa, j + 3)
+            }
+            for (; j < end; ++j) {
+                BSW_CELL(wa, wb, j)
+                wa = wb;
+            }
+#undef BSW_CELL
             he[end * 64] = he_pack(h1, 0, he[end * 64] & QMASK);    // :201
             if ((beg < end ? end : beg) == qlen) {             // "if (j == qlen)" after the column loop, :202-205
                 max_ie = gscore > h1 ? max_ie : i;
@@ -362,12 +377,12 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
                 }
             }
             // band trimming (:217-221): drop leading / trailing columns whose H and E are both zero
-            int j = beg;
-            while (j < end && (he[j * 64] & HE_MASK) == 0u) ++j;
-            beg = j;
-            j = end;
-            while (j >= beg && (he[j * 64] & HE_MASK) == 0u) --j;
-            end = j + 2 < qlen ? j + 2 : qlen;
+            int jt = beg;
+            while (jt < end && (he[jt * 64] & HE_MASK) == 0u) ++jt;
+            beg = jt;
+            jt = end;
+            while (jt >= beg && (he[jt * 64] & HE_MASK) == 0u) --jt;
+            end = jt + 2 < qlen ? jt + 2 : qlen;
         }
         if (active) {
             P->score = max;
