@@ -45,24 +45,39 @@ struct BswArgs {
 
 // LP lanes cooperate on one pair (64/LP pairs per wavefront): short extensions -- the common case, since most
 // reads carry one long SMEM -- would leave most of a 64-lane wavefront idle.
+// Cross-lane primitives of the lanes-per-pair kernel as DPP / readlane operations (register file only): the ds_bpermute
+// shuffles they replace each cost an LDS round trip on the row's dependent chain (~20 per row).
+#define BSW_DPP(old_, src_, ctrl_, rowmask_) __builtin_amdgcn_update_dpp((old_), (src_), (ctrl_), (rowmask_), 0xF, false)
+
+// inclusive max-scan over the LP lanes of a group (identity NEG): row_shr 1/2/4/8, then row_bcast15 / row_bcast31
 template <int LP>
-__device__ __forceinline__ int grp_incl_max(int v, int gl) {
-#pragma unroll
-    for (int d = 1; d < LP; d <<= 1) {
-        int y = __shfl_up(v, d, LP);
-        if (gl >= d) v = v > y ? v : y;
-    }
+__device__ __forceinline__ int grp_incl_max(int v) {
+    int y;
+    y = BSW_DPP(NEG, v, 0x111, 0xF); v = v > y ? v : y;
+    y = BSW_DPP(NEG, v, 0x112, 0xF); v = v > y ? v : y;
+    y = BSW_DPP(NEG, v, 0x114, 0xF); v = v > y ? v : y;
+    y = BSW_DPP(NEG, v, 0x118, 0xF); v = v > y ? v : y;
+    if constexpr (LP >= 32) { y = BSW_DPP(NEG, v, 0x142, 0xA); v = v > y ? v : y; }   // rows 1,3 <- lane 15 of rows 0,2
+    if constexpr (LP >= 64) { y = BSW_DPP(NEG, v, 0x143, 0xC); v = v > y ? v : y; }   // rows 2,3 <- lane 31
     return v;
 }
 
+// value of the previous lane (lane 0 of the wavefront gets `first`; group heads are overridden by the caller)
+__device__ __forceinline__ int lane_shr1(int v, int first) { return BSW_DPP(first, v, 0x138, 0xF); }   // wave_shr:1
+
+// value held by lane `k` of the caller's group, k uniform over the wavefront
 template <int LP>
-__device__ __forceinline__ long long grp_max64(long long v) {
-#pragma unroll
-    for (int d = LP / 2; d >= 1; d >>= 1) {
-        long long y = __shfl_xor(v, d, LP);
-        v = v > y ? v : y;
+__device__ __forceinline__ int grp_bcast(int v, int k, int lane) {
+    k = __builtin_amdgcn_readfirstlane(k);
+    if constexpr (LP == 64) return __builtin_amdgcn_readlane(v, k);
+    else if constexpr (LP == 32) {
+        const int a = __builtin_amdgcn_readlane(v, k), b = __builtin_amdgcn_readlane(v, 32 + k);
+        return lane < 32 ? a : b;
+    } else {
+        const int a = __builtin_amdgcn_readlane(v, k), b = __builtin_amdgcn_readlane(v, 16 + k);
+        const int c = __builtin_amdgcn_readlane(v, 32 + k), d = __builtin_amdgcn_readlane(v, 48 + k);
+        return lane < 32 ? (lane < 16 ? a : b) : (lane < 48 ? c : d);
     }
-    return v;
 }
 
 template <int LP>
@@ -128,7 +143,7 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
         int tchunk = 0;                 // lane k of the group holds target[LP*(i/LP) + k]
         for (int i = 0; i < tlen; ++i) {
             if ((i & (LP - 1)) == 0) tchunk = (i + gl < tlen) ? target[i + gl] : 4;
-            const int tb = __shfl(tchunk, i & (LP - 1), LP);
+            const int tb = grp_bcast<LP>(tchunk, i & (LP - 1), lane);   // all groups of a wavefront are at the same row
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
@@ -137,7 +152,7 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
             else h1 = 0;
             int carry_g = NEG;          // running max of M(k) - oe_ins + k*e_ins over finished chunks
             int left_h = h1;            // H(i, j0-1) for the first column of the chunk
-            long long best = -1;        // (m << 32) | mj, rightmost column among equal maxima
+            int bh = -1, bj = -1;       // this lane's best cell of the row: score, rightmost column among equal scores
             for (int j0 = beg; j0 < end; j0 += LP) {
                 const int j = j0 + gl;
                 const bool act = j < end;
@@ -150,15 +165,15 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
                     M = M ? M + sc : 0;   // :184
                 }
                 int g = act ? M - oe_ins + j * e_ins : NEG;
-                int gi = grp_incl_max<LP>(g, gl);
-                int gx = __shfl_up(gi, 1, LP);
+                int gi = grp_incl_max<LP>(g);
+                int gx = lane_shr1(gi, NEG);
                 if (gl == 0) gx = NEG;
                 gx = gx > carry_g ? gx : carry_g;
                 int f = gx - (j - 1) * e_ins;
                 if (f < 0 || gx == NEG) f = 0;
                 int h = M > e ? M : e;
                 h = h > f ? h : f;
-                int hl = __shfl_up(h, 1, LP);
+                int hl = lane_shr1(h, 0);
                 if (gl == 0) hl = left_h;
                 if (act) {
                     H[j] = hl;                             // H(i,j-1) for the next row (:183)
@@ -167,17 +182,17 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
                     e -= e_del;
                     e = e > t ? e : t;
                     E[j] = e;                              // E(i+1,j) (:190-194)
-                    long long key = ((long long)h << 32) | (unsigned)j;
-                    best = best > key ? best : key;
+                    if (h >= bh) { bh = h; bj = j; }
                 }
                 const int nact = end - j0 < LP ? end - j0 : LP;
                 left_h = __shfl(h, nact - 1, LP);
-                int cg = __shfl(gi, LP - 1, LP);
+                int cg = grp_bcast<LP>(gi, LP - 1, lane);
                 carry_g = carry_g > cg ? carry_g : cg;
             }
-            best = grp_max64<LP>(best);
-            int m = 0, mj = -1;
-            if (best >= 0) { m = (int)(best >> 32); mj = (int)(best & 0xffffffffll); }
+            // row maximum and its rightmost column: two max-scans, each total read off the group's last lane
+            int m = grp_bcast<LP>(grp_incl_max<LP>(bh), LP - 1, lane), mj = -1;
+            if (m < 0) m = 0;
+            else mj = grp_bcast<LP>(grp_incl_max<LP>(bh == m ? bj : -1), LP - 1, lane);
             h1 = left_h;
             if (gl == 0) { H[end] = h1; E[end] = 0; }      // :201
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
