@@ -330,6 +330,17 @@ def main():
         g_ms = float(np.mean([g for _, g in kernel_ms]))
         sample = reads[:20000]
         bpr, per_read = algorithmic_bytes_per_read(text, sa, l1, l2, sample)
+        # parity at the benchmark's own size (index of n suffixes): the GPU seeds the same sample on its own and must
+        # emit exactly as many SMEMs and hits as the CPU restatement counted (the restatement is only the checker here)
+        ns = sample.shape[0]
+        d_s = torch.from_numpy(sample.reshape(-1)).to(dev)
+        d_so = torch.arange(0, (ns + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
+        rs = ctx.seed_batch_device(d_s.data_ptr(), d_so.data_ptr(), ns, ns * READ_LEN, opt)
+        sample_parity = (rs.total_smems == int(round(per_read["smems"] * ns)) and
+                         rs.total_hits == int(round(per_read["hits"] * ns)))
+        if not sample_parity:
+            log("PARITY MISMATCH on the %d-read sample: GPU %d SMEMs / %d hits, restatement %d / %d"
+                % (ns, rs.total_smems, rs.total_hits, round(per_read["smems"] * ns), round(per_read["hits"] * ns)))
         achieved = bpr * nreads / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "seeding_reads_per_sec", "value": world * nreads * a.steps / dt, "unit": "reads/s",
@@ -343,7 +354,8 @@ def main():
                        "rmi_leaves_log2": int(np.log2(n_l2)), "sharding": "reads/%d ranks, index replicated by RCCL broadcast" % world,
                        "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
                        "searches_per_read": res.searches / nreads,
-                       "windows_per_search": windows / max(res.searches, 1)},
+                       "windows_per_search": windows / max(res.searches, 1),
+                       "sample_parity_with_cpu_restatement": bool(sample_parity)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "k_seed", "kernel_ms": k_ms, "gather_ms": g_ms,
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
