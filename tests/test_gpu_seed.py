@@ -146,3 +146,23 @@ def test_round_trip_property_large(ctx, g1):
         b = s2[so2[k]:so2[k + 1]]
         assert np.array_equal(a, b)
         assert np.array_equal(hits[hit_off[r]:hit_off[r + 1]], h2[ho2[k]:ho2[k + 1]])
+
+
+def test_hip_seeds_equal_oracle_midsize_default_model(tmp_path):
+    """16 Mbp repeat-rich genome with the trainer's default leaf count (partial third layer in use), 6 000 reads of three
+    lengths: the model, window and gallop paths at a size where predictions are no longer near-exact."""
+    from pymeme import workload
+    g = synth.make_genome(16_000_000, seed=91, repeat_frac=0.05, repeat_len=400, n_families=8, divergence=0.03,
+                          n_dups=20, dup_len=5000, poly_runs=6)
+    prefix = workload.build_index_on_disk(g, str(tmp_path), bits=0)
+    idx = O.load_index_files(prefix)
+    c = hipapi.Context(0)
+    try:
+        c.load_index_files(prefix)
+        for L, kw in ((150, dict(n_frac=0.02)), (250, dict(sub_rate=0.05, indel_rate=0.0075)), (76, dict(exact_frac=0.5))):
+            reads, _, _ = synth.make_reads(g, 2000, L, seed=300 + L, **kw)
+            off = np.arange(0, (reads.shape[0] + 1) * L, L, dtype=np.int64)
+            sm, ns, hits, nh, _ = O.seed_batch(idx, reads, off, smem_cap=512, hit_cap=1 << 15, threads=0)
+            assert _gpu_dump(c, reads, off) == O.format_seed_dump(sm, ns, hits), L
+    finally:
+        c.close()
