@@ -23,16 +23,17 @@ lib = os.environ.get("MEME_HIP_LIB", "")
 ctx = hipapi.Context(0)
 ctx.load_index_files(prefix)
 n = int(mreads * 1e6)
-reads = workload.make_reads_fast(g, n, 150, seed=12)
+RL = int(os.environ.get("PROBE_READ_LEN", "150")); SUB = float(os.environ.get("PROBE_SUB_RATE", "0.01"))
+reads = workload.make_reads_fast(g, n, RL, seed=12, sub_rate=SUB)
 d_reads = torch.from_numpy(reads.reshape(-1)).cuda()
-d_off = torch.arange(0, (n + 1) * 150, 150, dtype=torch.int64, device="cuda")
+d_off = torch.arange(0, (n + 1) * RL, RL, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 for lanes in lanes_list:
     ctx.set_tuning("group_lanes", lanes)
     for rounds in (1, 3):
         for it in range(2):
-            res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * 150, hipapi.default_seed_opt(rounds=rounds))
+            res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * RL, hipapi.default_seed_opt(rounds=rounds))
             tm = ctx.timings()
-        log("%s G=%d rounds=%d: kernel %.1f ms -> %.2f M reads/s; searches/read %.1f windows/search %.3f smems %d hits %d" % (
-            os.path.basename(lib), lanes, rounds, tm.seed_kernel_ms, n / tm.seed_kernel_ms / 1e3, res.searches / n,
+        log("%s len=%d sub=%.3f G=%d rounds=%d: kernel %.1f ms -> %.2f M reads/s; searches/read %.1f windows/search %.3f smems %d hits %d" % (
+            os.path.basename(lib), RL, SUB, lanes, rounds, tm.seed_kernel_ms, n / tm.seed_kernel_ms / 1e3, res.searches / n,
             tm.seed_windows / max(res.searches, 1), res.total_smems, res.total_hits))
