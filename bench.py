@@ -360,6 +360,23 @@ def main():
                          "traffic": None, "kernel": "k_seed", "kernel_ms": k_ms, "gather_ms": g_ms,
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
         }
+        # HBM traffic per launch from the committed PMC passes of this very configuration (rocprofv3 counters cannot be
+        # collected inside a timed run): FETCH_SIZE doubled as the gfx950 guide prescribes (128-byte line fills are
+        # tallied at 64 B; cross-checked against TCC_MISS x 128 B) + WRITE_SIZE
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_named.json")))
+            c = pmc["config"]
+            if not (c["genome_bp"] == l_pac and c["reads_per_step"] == nreads and c["read_len"] == READ_LEN and
+                    c["rmi_leaves_log2"] == int(np.log2(n_l2))):
+                pmc = None
+        except (OSError, ValueError, KeyError):
+            pmc = None
+        if pmc:
+            out["roofline"]["traffic"] = (2 * pmc["fetch_size_kb_per_launch"] + pmc["write_size_kb_per_launch"]) * 1024.0
+            out["roofline"]["traffic_source"] = pmc["source"]
+            out["roofline"]["l2_miss_lines_per_s"] = pmc["tcc_miss_lines_per_launch"] / (k_ms * 1e-3)
+            out["roofline"]["random_line_roofline_lines_per_s"] = 50e9     # scripts/microbench/gather_roofline.hip
         cpu = None
         cpu_mode = os.environ.get("MEME_BENCH_CPU", "reference" if l_pac <= 1_000_000_000 else "port")
         if world == 1 and cpu_mode != "0":
@@ -374,6 +391,8 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never the measured value
                 log("cpu_baseline leg failed: %r -- falling back to the port" % (e,))
                 cpu = cpu_baseline_port(text, sa, l1, l2, reads[:min(ns, 400000)], cores)
+        if cpu is not None and cpu.get("kind") == "port" and pmc:
+            cpu["reference_on_this_configuration"] = pmc["reference_cpu"]   # measured once (3 min of index load): see its source
         out["cpu_baseline"] = cpu
         if os.environ.get("MEME_BENCH_BSW", "1") != "0":
             try:
