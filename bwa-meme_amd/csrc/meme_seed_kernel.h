@@ -11,25 +11,25 @@
 //   read packing of mem_kernel1_core_Learned                              src/bwamem.cpp:1277-1344
 //
 // Design (MI355X-first, not a translation):
-//  * A read is owned by a group of G lanes (G = 4..32, 64/G reads per wavefront).  The pivot state
-//    machine is group-uniform scalar state replicated in the group's lanes; only suffix-array probes
-//    are lane-parallel.
-//  * The pivot logic of rounds 1-3 is flattened into an explicit state machine ("program counter"
-//    per read) around ONE search call site, so the 64/G reads of a wavefront execute the search body
-//    convergently and their memory requests are issued together -- instead of each read sitting in a
-//    different call site of a recursive-descent transcription of the CPU code.
-//  * The unit of memory traffic is a *window*: G consecutive 16-byte suffix-array entries, one
-//    coalesced load.  Each lane compares its entry's 64-bit key (and, only when all 32 bases agree,
-//    2-bit reference words) with the read; a wave ballot yields the partition point, the longest
-//    common prefix and -- from the same data -- the SMEM hit interval, so the reference's chain of
-//    ~log2(err)+linear dependent single-entry probes collapses to one window in the common case.
-//  * The learned model is a hint: when the partition point is outside the first
-//    window the group gallops away from the prediction and bisects with group-uniform single-entry
-//    probes (broadcast loads), then takes a final window.  Model error bounds are never needed, so
-//    any parameter file the reference loads is accepted.
-//  * Reads are packed once per batch by k_pack_reads (2 bits/base, both strands, first base in the
-//    top bits of each u64, plus N masks) and staged in LDS; a 32-base query word at any offset is a
-//    funnel shift of two LDS words, replacing the reference's 8 pre-shifted copies of every read.
+//  * A read is owned by a group of G lanes (G = 1..32, default 4: 16 reads per wavefront).  The pivot logic is
+//    group-uniform scalar state replicated in the group's lanes; only suffix-array windows are lane-parallel.
+//  * ONE flat loop per wavefront: every read is a small machine with a program counter over the pivot logic of
+//    rounds 1-3; the loop body is  control -> window -> resolve -> level walk -> apply.  A read that finishes pulls
+//    the next one inside the same loop, so reads never wait for each other, and the heavy code (window load +
+//    compare + reference-word loop) exists exactly once in the kernel.
+//  * The unit of memory traffic is a *window*: E*G consecutive 16-byte suffix-array entries (12 slots = 192 B at G=4),
+//    E coalesced loads per lane issued together.  Each lane compares its entries' 64-bit keys (and, only when all 32
+//    bases agree, 2-bit reference words) with the read; ballots yield the partition point, the longest common prefix
+//    and -- from the same data -- the SMEM hit interval, so the reference's chain of ~log2(err)+linear dependent
+//    single-entry probes collapses to one window in the common case.
+//  * Partition point, lower and upper interval edge are all "where does a monotone predicate flip?": a window that
+//    does not contain the flip moves a bracket [lo, hi] and the next window gallops or bisects -- relocations and
+//    edge scans are just more trips through the same loop.
+//  * The learned model is a hint: model error bounds are never needed, so any parameter file the
+//    reference loads is accepted.
+//  * Reads are packed once per batch by k_pack_reads (2 bits/base, both strands, first base in the top bits of each
+//    u64, plus N masks) and staged in LDS when pulled; a 32-base query word at any offset is a funnel shift of two
+//    LDS words, replacing the reference's 8 pre-shifted copies of every read.
 #pragma once
 #include <limits.h>
 
