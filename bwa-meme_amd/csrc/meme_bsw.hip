@@ -257,7 +257,9 @@ constexpr int LANE_QMAX = 600;
 constexpr int LANE_SCORE_LIMIT = 1 << 14;
 constexpr int N_LANE_CLS = 8;                                        // LDS = (q + 2) * 256 B per wavefront: 8 KB ... 150 KB
 constexpr int LANE_CLS_Q[N_LANE_CLS] = {30, 62, 94, 126, 158, 222, 318, LANE_QMAX};
-constexpr int SORT_KEYS = 1024;                                      // key = query length, SORT_KEYS-1 = not eligible
+constexpr int TL_BUCKETS = 8;                                        // sub-key: (target length - query length) / 8
+constexpr int SORT_KEYS = (LANE_QMAX + 1) * TL_BUCKETS + 1;          // key = query length * 8 + sub-key; last key = the rest
+#define QKEY(q_) ((q_) * TL_BUCKETS)
 
 struct LaneArgs {
     meme_seqpair* pairs;
@@ -411,13 +413,18 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
 }
 
 // ---- counting sort of the pairs by query length (the lanes of a wavefront should finish together) -------------------------
-// a >= 0: key for the lane-per-pair kernel (query length, or SORT_KEYS-1 when the pair is not eligible);
-// a < 0: plain query-length key (clipped), used when the whole batch goes to the lanes-per-pair kernel
+// Sort key: query length first (LDS size class, column-loop length), then the surplus of target rows over query columns
+// in steps of 8, so that the 64 pairs of a wavefront also run about the same number of rows.
+// a >= 0: keys for the lane-per-pair kernel (the last key collects the pairs it cannot take);
+// a < 0: the whole batch goes to the lanes-per-pair kernels (queries beyond LANE_QMAX collect in the last key)
 __device__ __forceinline__ int lane_key(const meme_seqpair& p, int a) {
-    if (a < 0) return p.len2 < 0 ? 0 : (p.len2 < SORT_KEYS - 1 ? p.len2 : SORT_KEYS - 1);
-    const long long bound = (long long)p.h0 + (long long)p.len2 * a + 1;
-    const bool ok = p.len2 >= 0 && p.len2 <= LANE_QMAX && p.len1 >= 0 && p.h0 >= 0 && bound < LANE_SCORE_LIMIT;
-    return ok ? p.len2 : SORT_KEYS - 1;
+    const long long bound = (long long)p.h0 + (long long)p.len2 * (a > 0 ? a : 0) + 1;
+    const bool ok = p.len2 >= 0 && p.len2 <= LANE_QMAX && p.len1 >= 0 &&
+                    (a < 0 || (p.h0 >= 0 && bound < LANE_SCORE_LIMIT));
+    if (!ok) return p.len2 < 0 ? 0 : SORT_KEYS - 1;
+    int sub = (p.len1 - p.len2) >> 3;
+    sub = sub < 0 ? 0 : (sub > TL_BUCKETS - 1 ? TL_BUCKETS - 1 : sub);
+    return QKEY(p.len2) + sub;
 }
 
 __global__ void __launch_bounds__(256) k_bsw_hist(const meme_seqpair* __restrict__ pairs, int n, int a, int* __restrict__ hist,
@@ -436,21 +443,24 @@ __global__ void __launch_bounds__(256) k_bsw_hist(const meme_seqpair* __restrict
     if (mq) atomicMax(maxq, mq);
 }
 
-__global__ void __launch_bounds__(SORT_KEYS) k_bsw_scan(const int* __restrict__ hist, int* __restrict__ offs, int* __restrict__ cursor) {
-    __shared__ int tmp[SORT_KEYS];
-    const int k = threadIdx.x;
-    tmp[k] = hist[k];
+__global__ void __launch_bounds__(1024) k_bsw_scan(const int* __restrict__ hist, int* __restrict__ offs, int* __restrict__ cursor) {
+    // exclusive scan of SORT_KEYS counts: every thread owns a run of consecutive keys, the run totals are scanned in LDS
+    constexpr int PER = (SORT_KEYS + 1023) / 1024;
+    __shared__ int tmp[1024];
+    const int t = threadIdx.x, k0 = t * PER;
+    int sum = 0;
+    for (int k = k0; k < k0 + PER && k < SORT_KEYS; ++k) sum += hist[k];
+    tmp[t] = sum;
     __syncthreads();
-    for (int d = 1; d < SORT_KEYS; d <<= 1) {
-        const int v = k >= d ? tmp[k - d] : 0;
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? tmp[t - d] : 0;
         __syncthreads();
-        tmp[k] += v;
+        tmp[t] += v;
         __syncthreads();
     }
-    const int excl = tmp[k] - hist[k];
-    offs[k] = excl;
-    cursor[k] = excl;
-    if (k == SORT_KEYS - 1) offs[SORT_KEYS] = tmp[k];
+    int run = tmp[t] - sum;
+    for (int k = k0; k < k0 + PER && k < SORT_KEYS; ++k) { offs[k] = run; cursor[k] = run; run += hist[k]; }
+    if (t == 1023) offs[SORT_KEYS] = tmp[t];
 }
 
 __global__ void __launch_bounds__(256) k_bsw_scatter(const meme_seqpair* __restrict__ pairs, int n, int a, int* __restrict__ cursor,
@@ -520,11 +530,11 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
         i64 sblocks = ((i64)npairs + 255) / 256;
         if (sblocks > dev_cus * 8) sblocks = dev_cus * 8;
         hipLaunchKernelGGL(k_bsw_hist, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, key_a, hist, maxq);
-        hipLaunchKernelGGL(k_bsw_scan, dim3(1), dim3(SORT_KEYS), 0, ctx->stream, hist, offs, cursor);
+        hipLaunchKernelGGL(k_bsw_scan, dim3(1), dim3(1024), 0, ctx->stream, hist, offs, cursor);
         hipLaunchKernelGGL(k_bsw_scatter, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, key_a, cursor, order);
         HIP_TRY(hipGetLastError());
     }
-    int h_local[SORT_KEYS + 2];
+    static thread_local int h_local[SORT_KEYS + 2];
     HIP_TRY(hipMemcpyAsync(h_local, offs, (SORT_KEYS + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(h_local + SORT_KEYS + 1, maxq, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -533,7 +543,7 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
         int qlo = 0;
         for (int c = 0; c < N_LANE_CLS; ++c) {
             const int qhi = LANE_CLS_Q[c];                       // class = query lengths [qlo, qhi]
-            const int first = h_local[qlo], last = h_local[qhi + 1];
+            const int first = h_local[QKEY(qlo)], last = h_local[QKEY(qhi + 1)];
             qlo = qhi + 1;
             if (last <= first) continue;
             LaneArgs L;
@@ -554,7 +564,7 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     {
         const int rest0 = use_lane ? h_local[SORT_KEYS - 1] : 0, total = h_local[SORT_KEYS];
         const int mq = h_local[SORT_KEYS + 1] < 1 ? 1 : h_local[SORT_KEYS + 1];
-        const int cut16 = use_lane ? rest0 : h_local[17], cut32 = use_lane ? rest0 : h_local[33];
+        const int cut16 = use_lane ? rest0 : h_local[QKEY(17)], cut32 = use_lane ? rest0 : h_local[QKEY(33)];
         BswArgs A;
         A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
         if (cut16 > rest0) {
