@@ -205,6 +205,10 @@ typedef const __attribute__((address_space(1))) RmiRec* glb_rmi;
 #ifndef SEED_QUERY_LDS
 #define SEED_QUERY_LDS 1
 #endif
+// 1: the model's error bounds place the first window (asymmetric bounds -> asymmetric window); 0: centred on the prediction
+#ifndef SEED_USE_ERR
+#define SEED_USE_ERR 1
+#endif
 #if SEED_QUERY_LDS
 typedef lds_u64 q_u64;
 #else
@@ -316,7 +320,9 @@ __device__ __forceinline__ void window_compare(glb_u64 pac, i64 n, q_u64 s, u64 
 }
 
 // ---- learned_index_lookup (:186-210): same arithmetic (FP64 FMA + clamp), used as a hint ------------------
-__device__ __forceinline__ i64 rmi_lookup(glb_rmi l2, glb_rmi l1, int shift, i64 n, u64 key) {
+// `err_out`: the record's error word (bits 61..32 = how far the true position can lie below the prediction, bits 30..0
+// above), used only to place the first window -- a wrong or loose bound costs a second window, never a wrong answer.
+__device__ __forceinline__ i64 rmi_lookup(glb_rmi l2, glb_rmi l1, int shift, i64 n, u64 key, u64& err_out) {
     u64 m = shift >= 64 ? 0ull : key >> shift;
     double icpt = l2[m].icpt, slope = l2[m].slope;
     u64 err = l2[m].err;
@@ -328,7 +334,9 @@ __device__ __forceinline__ i64 rmi_lookup(glb_rmi l2, glb_rmi l1, int shift, i64
         double c = f < 0.0 ? 0.0 : (f > pn ? pn : f);
         u64 j = ps + (u64)c;
         f = fma(l1[j].slope, x, l1[j].icpt);
+        err = l1[j].err;
     }
+    err_out = err;
     double top = (double)n - 1.0;
     if (f < 0.0) return 0;
     if (f > top) return n - 1;
@@ -660,8 +668,17 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             wq = ext_l(q_rc ? rcs : fw, off);                 // first 32 bases of the query: every window compares against it
             u64 key = wq;
             if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
-            const i64 pos = rmi_lookup(l2, l1, A.I.shift, n, key);
+            u64 err;
+            const i64 pos = rmi_lookup(l2, l1, A.I.shift, n, key, err);
+#if SEED_USE_ERR
+            // the partition point lies in [pos - below, pos + above]; the window has to hold it and its left neighbour.
+            // If that span fits, centre it; else split the window in the proportion of the two bounds.
+            const i64 below = (i64)((err >> 32) & 0x3fffffffull) + 1, above = (i64)(err & 0x7fffffffull);
+            const i64 span = below + above + 1;
+            base = span <= W ? pos - below - (W - span) / 2 : pos - (below * W) / span;
+#else
             base = pos - W / 2;
+#endif
             if (base < 0) base = 0;
             if (base > n - W) base = n - W;
             lo = -1; hi = n; stepk = 0; capc = vlen;

@@ -8,4 +8,4 @@ for lib in bwa-meme_amd/libmeme_hip_*.so; do
   [ -f $lib ] || continue
   MEME_HIP_LIB=$PWD/$lib timeout 600 python bench.py --steps 3 --warmup 1 2>/dev/null | pr $(basename $lib)
 done
-MEME_BENCH_BITS=30 timeout 900 python bench.py --steps 3 --warmup 1 2>/dev/null | pr bits30
+[ -n "$WITH_BITS30" ] && MEME_BENCH_BITS=30 timeout 900 python bench.py --steps 3 --warmup 1 2>/dev/null | pr bits30
