@@ -1,0 +1,430 @@
+// Reference-side binding of the MI355X backend (what INTEGRATION.md describes), written against the *reference's own
+// headers* and linked into the reference aligner (oracle/Makefile.ref target bwa-meme_dropin).  The reference objects
+// are built position-independent into libbwa_pic.so; the definitions below live in the executable and therefore win
+// symbol resolution (ELF interposition) -- no reference source is modified or copied, the calls below go to functions
+// the reference exports.  A maintainer integrating the backend would put the same code behind an #ifdef at the four
+// places named here:
+//
+//   memoryAllocLearned()            src/fastmap.cpp:351-641   worker buffers as before, but the index goes to HBM
+//                                   (meme_index_load_files + meme_index_replicate per extra GPU) instead of being
+//                                   expanded on the host (13-byte suffix-array entries + ISA, ~100 s / ~120 GB at GRCh38)
+//   mem_process_seqs()              src/bwamem.cpp:1920-1972  ONE meme_seed_batch_host() per -K chunk (split over the
+//                                   visible GPUs) before kt_for(worker_bwt); the reference's own body then runs unchanged
+//   mem_kernel1_core_Learned()      src/bwamem.cpp:1230-1413  per 512-read batch: takes the chunk's precomputed SMEMs and
+//                                   hits, then the reference's ks_introsort / mem_chain_Learned / mem_chain_flt /
+//                                   mem_flt_chained_seeds
+//   BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper   src/bandedSWA.cpp:242-260,1970-,2664-
+//                                   -> meme_bsw_batch(); the concurrent calls of the kt_for workers are combined into one
+//                                   backend call per GPU (group commit), staged through pinned buffers
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "fastmap.h"             // reference headers (-I$(REF)/src): ktp_aux_t, worker_t, mem_opt_t, bseq1_t ...
+#include "bandedSWA.h"
+#include "ksort.h"
+
+#include "meme_hip.h"            // our C ABI (-Iinclude)
+
+// reference functions used unchanged
+void mem_chain_Learned(const mem_opt_t* opt, const bntseq_t* bns, int len, mem_tlv* smems, mem_chain_v* chain,
+                       int seqid, u64v* hits, mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid);
+int mem_chain_flt(const mem_opt_t* opt, int n_chn_, mem_chain_t* a_, int tid);
+void mem_flt_chained_seeds(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int n_chn,
+                           mem_chain_t* a);
+
+#define dropin_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
+KSORT_INIT(meme_dropin_smem, mem_tl, dropin_smem_lt)
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+[[noreturn]] void die(const char* what) {
+    fprintf(stderr, "[meme-dropin] %s: %s\n", what, meme_last_error());
+    exit(1);
+}
+bool verbose() { static const bool v = getenv("MEME_DROPIN_VERBOSE") != nullptr; return v; }
+
+// ---- devices -------------------------------------------------------------------------------------------------
+struct Device {
+    meme_ctx* seed = nullptr;     // owns (device 0) or holds a replica of the index
+    meme_ctx* bsw = nullptr;
+};
+std::vector<Device> g_dev;
+std::mutex g_mu;
+std::atomic<double> g_t_seed{0}, g_t_bsw{0};
+std::atomic<int64_t> g_n_bsw_calls{0}, g_n_bsw_pairs{0}, g_n_seed_reads{0};
+
+void init_devices(const char* prefix) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_dev.empty()) return;
+    int n = meme_device_count();
+    if (n <= 0) die("no HIP device");
+    if (getenv("MEME_DROPIN_DEVICES")) { int want = atoi(getenv("MEME_DROPIN_DEVICES")); if (want >= 1 && want < n) n = want; }
+    g_dev.resize((size_t)n);
+    const double t0 = now_s();
+    for (int d = 0; d < n; ++d) {
+        if (!(g_dev[(size_t)d].seed = meme_ctx_create(d))) die("meme_ctx_create");
+        if (!(g_dev[(size_t)d].bsw = meme_ctx_create(d))) die("meme_ctx_create");
+        // small combined calls keep the lanes-per-pair kernels; combined calls of the whole thread team are big enough
+        // for the lane-per-pair kernel much earlier than a lone caller's
+        if (getenv("MEME_DROPIN_BSW_LANE_MIN")) meme_set_tuning(g_dev[(size_t)d].bsw, "bsw_lane_min_pairs", atoll(getenv("MEME_DROPIN_BSW_LANE_MIN")));
+    }
+    if (meme_index_load_files(g_dev[0].seed, prefix)) die("meme_index_load_files");
+    const double t1 = now_s();
+    std::vector<std::thread> th;
+    for (int d = 1; d < n; ++d)                                 // device-to-device over xGMI, all replicas at once
+        th.emplace_back([d] { if (meme_index_replicate(g_dev[(size_t)d].seed, g_dev[0].seed)) die("meme_index_replicate"); });
+    for (auto& t : th) t.join();
+    fprintf(stderr, "[meme-dropin] index staged in HBM in %.2f s, replicated to %d more GPU(s) in %.2f s\n", t1 - t0, n - 1,
+            now_s() - t1);
+}
+
+// ---- memoryAllocLearned (src/fastmap.cpp:351-641) ----------------------------------------------------------------
+// Worker buffers exactly as the reference sizes them (they are indexed by the kt_for thread id all over
+// mem_chain2aln_across_reads_V2 and freed by process(), src/fastmap.cpp:1098-1110); the host-side index expansion is gone.
+uint8_t bitrev8(uint8_t b) {
+    b = (uint8_t)(((b & 0xF0) >> 4) | ((b & 0x0F) << 4));
+    b = (uint8_t)(((b & 0xCC) >> 2) | ((b & 0x33) << 2));
+    return (uint8_t)(((b & 0xAA) >> 1) | ((b & 0x55) << 1));
+}
+
+}  // namespace
+
+void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nthreads, char* idx_prefix) {
+    const double t0 = now_s();
+    const int64_t memSize = nreads;
+    w.regs = (mem_alnreg_v*)calloc((size_t)memSize, sizeof(mem_alnreg_v));
+    w.chain_ar = (mem_chain_v*)malloc((size_t)memSize * sizeof(mem_chain_v));
+    w.seedBuf = (mem_seed_t*)calloc(sizeof(mem_seed_t), (size_t)memSize * AVG_SEEDS_PER_READ);
+    if (!w.regs || !w.chain_ar || !w.seedBuf) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+    w.seedBufSize = BATCH_SIZE * AVG_SEEDS_PER_READ;
+    const int64_t wsize = BATCH_SIZE * SEEDS_PER_READ;
+    for (int l = 0; l < nthreads; ++l) {
+        w.mmc.seqBufLeftRef[l * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64);
+        w.mmc.seqBufLeftQer[l * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_QER + MAX_LINE_LEN, 64);
+        w.mmc.seqBufRightRef[l * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64);
+        w.mmc.seqBufRightQer[l * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_QER + MAX_LINE_LEN, 64);
+        w.mmc.wsize_buf_ref[l * CACHE_LINE] = wsize * MAX_SEQ_LEN_REF;
+        w.mmc.wsize_buf_qer[l * CACHE_LINE] = wsize * MAX_SEQ_LEN_QER;
+        w.mmc.seqPairArrayAux[l] = (SeqPair*)malloc((size_t)(wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+        w.mmc.seqPairArrayLeft128[l] = (SeqPair*)malloc((size_t)(wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+        w.mmc.seqPairArrayRight128[l] = (SeqPair*)malloc((size_t)(wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+        w.mmc.wsize[l] = wsize;
+        w.mmc.lim[l] = (int32_t*)_mm_malloc((BATCH_SIZE + 32) * sizeof(int32_t), 64);
+        if (!w.mmc.seqBufLeftRef[l * CACHE_LINE] || !w.mmc.seqBufLeftQer[l * CACHE_LINE] || !w.mmc.seqBufRightRef[l * CACHE_LINE] ||
+            !w.mmc.seqBufRightQer[l * CACHE_LINE] || !w.mmc.seqPairArrayAux[l] || !w.mmc.seqPairArrayLeft128[l] ||
+            !w.mmc.seqPairArrayRight128[l] || !w.mmc.lim[l]) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+    }
+    // forward + reverse-complement 2-bit text in the byte order the reference's seeding code uses (src/fastmap.cpp:441-457).
+    // The reference hands this array -- not idx->pac -- to mem_flt_chained_seeds (src/bwamem.cpp:1407, 1768), so the
+    // binding has to provide the very same bytes for the SAM output to be identical.
+    const int64_t l_pac = aux->fmi->idx->bns->l_pac;
+    const int64_t ll_pac = (l_pac * 2 + 3) / 4 * 4;
+    w.rc_pac = (uint8_t*)malloc((size_t)(ll_pac / 4));
+    if (!w.rc_pac) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+    const uint8_t* pac = aux->fmi->idx->pac;
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < ll_pac / 4; ++k) {
+        uint8_t b = 0;
+        for (int j = 0; j < 4; ++j) {
+            const int64_t p = 4 * k + j;
+            int c = 0;
+            if (p < l_pac) c = pac[p >> 2] >> ((~p & 3) << 1) & 3;
+            else if (p < 2 * l_pac) { const int64_t q = 2 * l_pac - 1 - p; c = 3 - (pac[q >> 2] >> ((~q & 3) << 1) & 3); }
+            b = (uint8_t)(b | (c << ((~j & 3) << 1)));
+        }
+        w.rc_pac[k] = bitrev8(b);
+    }
+    w.sa_position = nullptr;                                   // the suffix array lives in HBM
+    w.ref2sa = nullptr;
+    w.smemBufSize = MAX_LINE_LEN * sizeof(mem_tlv);
+    w.l_smems = (mem_tlv*)malloc((size_t)nthreads * w.smemBufSize);
+    w.hitBufSize = MAX_LINE_LEN * sizeof(u64v);
+    w.hits_ar = (u64v*)malloc((size_t)nthreads * w.hitBufSize);
+    if (!w.l_smems || !w.hits_ar) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+    for (int i = 0; i < nthreads; ++i) {
+        kv_init_base(mem_tl, w.l_smems[i * MAX_LINE_LEN], BATCH_MUL * READ_LEN);
+        kv_init_base(uint64_t, w.hits_ar[i * MAX_LINE_LEN], 65536);
+    }
+    w.useErt = 0;
+    w.useLearned = 1;
+    const double t1 = now_s();
+    const char* prefix = getenv("MEME_INDEX_PREFIX") ? getenv("MEME_INDEX_PREFIX") : idx_prefix;
+    init_devices(prefix);
+    fprintf(stderr, "[meme-dropin] worker buffers + fwd/rc text %.2f s, HBM index %.2f s (no host-side index expansion)\n",
+            t1 - t0, now_s() - t1);
+}
+
+// ---- chunk-level seeding ----------------------------------------------------------------------------------------------
+namespace {
+
+struct ChunkPart {                     // the slice of a chunk one GPU seeded
+    int64_t first = 0, count = 0;
+    meme_seed_host_result res;
+    uint8_t* flat = nullptr; int64_t flat_cap = 0;       // pinned staging (grow-only)
+    int64_t* off = nullptr; int64_t off_cap = 0;
+};
+struct Chunk {
+    const bseq1_t* seqs = nullptr;
+    int64_t n = 0;
+    std::vector<ChunkPart> part;
+} g_chunk;
+
+meme_seed_opt seed_opt_of(const mem_opt_t* opt) {
+    meme_seed_opt so;
+    so.min_seed_len = opt->min_seed_len;
+    so.split_len = (int)(opt->min_seed_len * opt->split_factor + .499);   // src/bwamem.cpp:1348
+    so.split_width = opt->split_width;
+    so.max_mem_intv = opt->max_mem_intv;
+    so.rounds = 3;
+    so.hits_per_smem = 0;
+    return so;
+}
+
+void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
+    if (P.count + 1 > P.off_cap) { meme_host_free(P.off); P.off_cap = P.count + P.count / 4 + 64; if (!(P.off = (int64_t*)meme_host_alloc(P.off_cap * 8))) die("meme_host_alloc"); }
+    int64_t bytes = 0;
+    for (int64_t i = 0; i < P.count; ++i) { P.off[i] = bytes; bytes += seqs[P.first + i].l_seq; }
+    P.off[P.count] = bytes;
+    if (bytes + 16 > P.flat_cap) { meme_host_free(P.flat); P.flat_cap = bytes + bytes / 4 + 4096; if (!(P.flat = (uint8_t*)meme_host_alloc(P.flat_cap))) die("meme_host_alloc"); }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < P.count; ++i) {
+        // base codes in place, as the reference leaves them for the later stages (src/bwamem.cpp:1277-1279)
+        bseq1_t& s = seqs[P.first + i];
+        uint8_t* dst = P.flat + P.off[i];
+        for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
+    }
+    const meme_seed_opt so = seed_opt_of(opt);
+    if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
+}
+
+void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n) {
+    const double t0 = now_s();
+    const int nd = (int)g_dev.size();
+    g_chunk.seqs = seqs;
+    g_chunk.n = n;
+    if (g_chunk.part.size() != (size_t)nd) g_chunk.part.resize((size_t)nd);
+    // consecutive 512-read batches of the chunk go to consecutive GPUs: contiguous ranges, batch-aligned
+    const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
+    std::vector<std::thread> th;
+    for (int d = 0; d < nd; ++d) {
+        ChunkPart& P = g_chunk.part[(size_t)d];
+        const int64_t b0 = nb * d / nd, b1 = nb * (d + 1) / nd;
+        P.first = b0 * BATCH_SIZE;
+        P.count = (b1 * BATCH_SIZE < n ? b1 * BATCH_SIZE : n) - P.first;
+        if (P.count < 0) P.count = 0;
+        if (d + 1 < nd) th.emplace_back(seed_part, d, opt, seqs, std::ref(P));
+        else seed_part(d, opt, seqs, P);
+    }
+    for (auto& t : th) t.join();
+    g_t_seed = g_t_seed + (now_s() - t0);
+    g_n_seed_reads += n;
+    if (verbose()) fprintf(stderr, "[meme-dropin] chunk of %lld reads seeded on %d GPU(s) in %.3f s\n", (long long)n, nd, now_s() - t0);
+}
+
+int g_team = 1;                        // kt_for worker threads of the run (opt->n_threads)
+
+typedef void (*process_fn)(mem_opt_t*, int64_t, int, bseq1_t*, const mem_pestat_t*, worker_t&);
+
+}  // namespace
+
+void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs, const mem_pestat_t* pes0, worker_t& w) {
+    static process_fn next = nullptr;
+    if (!next) {
+        next = (process_fn)dlsym(RTLD_NEXT, "_Z16mem_process_seqsP9mem_opt_tliP7bseq1_tPK12mem_pestat_tR8worker_t");
+        if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_process_seqs was not found: %s\n", dlerror()); exit(1); }
+    }
+    g_team = opt->n_threads > 0 ? opt->n_threads : 1;
+    if (w.useLearned) seed_chunk(opt, seqs, n);
+    next(opt, n_processed, n, seqs, pes0, w);
+    g_chunk.seqs = nullptr;
+    if (verbose())
+        fprintf(stderr, "[meme-dropin] totals: seeding %.3f s for %lld reads; bsw %lld calls, %lld pairs, %.3f s inside the backend\n",
+                (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs, (double)g_t_bsw);
+}
+
+int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
+                             mem_chain_v* chain_ar, mem_seed_t* seedBuf, int64_t seedBufSize, uint8_t* sa_pos,
+                             uint8_t* ref2sa, uint8_t* ref_string, mem_tlv* smems, u64v* hits, int tid) {
+    (void)sa_pos; (void)ref2sa; (void)ref_string;
+    static_assert(sizeof(meme_mem_tl) == sizeof(mem_tl), "mem_tl layout");
+    const int64_t g0 = seq_ - g_chunk.seqs;                   // this batch's position in the chunk seeded above
+    if (!g_chunk.seqs || g0 < 0 || g0 + nseq > g_chunk.n) { fprintf(stderr, "[meme-dropin] batch outside the seeded chunk\n"); exit(1); }
+    int64_t seedBufCount = 0;
+    for (int l = 0; l < nseq; ++l) {
+        const int64_t g = g0 + l;
+        const ChunkPart* P = nullptr;
+        for (const ChunkPart& c : g_chunk.part) if (g >= c.first && g < c.first + c.count) { P = &c; break; }
+        const int64_t r = g - P->first;
+        const int64_t s0 = P->res.smem_off[r], ns = P->res.smem_off[r + 1] - s0;
+        const int64_t h0 = P->res.hit_off[r], nh = P->res.hit_off[r + 1] - h0;
+        smems->n = 0;
+        hits->n = 0;
+        if ((int64_t)smems->m < ns) kv_resize(mem_tl, *smems, (size_t)ns);
+        if ((int64_t)hits->m < nh) kv_resize(uint64_t, *hits, (size_t)nh);
+        if (ns) memcpy(smems->a, P->res.smems + s0, (size_t)ns * sizeof(mem_tl));
+        if (nh) memcpy(hits->a, P->res.hits + h0, (size_t)nh * sizeof(uint64_t));
+        smems->n = (size_t)ns;
+        hits->n = (size_t)nh;
+        ks_introsort(meme_dropin_smem, smems->n, smems->a);            // src/bwamem.cpp:1397
+        kv_init(chain_ar[l]);
+        mem_chain_Learned(opt, bns, seq_[l].l_seq, smems, &chain_ar[l], l, hits, seedBuf, seedBufSize, seedBufCount, tid);
+        mem_chain_v* chn = &chain_ar[l];
+        chn->n = mem_chain_flt(opt, chn->n, chn->a, tid);
+        mem_flt_chained_seeds(opt, bns, pac, seq_, chn->n, chn->a);
+    }
+    return 1;
+}
+
+// ---- banded SW: the three entry points of the reference class forward to the HIP batch call -------------------------------
+namespace {
+
+struct BswReq {
+    SeqPair* pairs; const uint8_t* ref; const uint8_t* qer; int n; int w; meme_bsw_opt o; int64_t rb, qb;
+    bool done = false;
+};
+
+// Group commit: the first worker to arrive becomes the leader, takes everything queued so far (after a short wait for
+// the rest of the team), issues ONE backend call and hands the results back.  While a call is in flight the other
+// workers' requests pile up for the next leader.  One combiner per GPU; worker threads are spread over them.
+struct Combiner {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<BswReq*> queue;
+    bool busy = false;
+    int device = 0;
+    // pinned staging, leader-only
+    meme_seqpair* pairs = nullptr; int64_t pairs_cap = 0;
+    uint8_t* ref = nullptr; int64_t ref_cap = 0;
+    uint8_t* qer = nullptr; int64_t qer_cap = 0;
+
+    void exec(std::vector<BswReq*>& batch);
+    void submit(BswReq* r, int expected) {
+        std::unique_lock<std::mutex> lk(m);
+        queue.push_back(r);
+        cv.notify_all();
+        for (;;) {
+            if (r->done) return;
+            if (busy) { cv.wait(lk); continue; }
+            busy = true;
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(150);
+            while ((int)queue.size() < expected && cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+            std::vector<BswReq*> batch;
+            batch.swap(queue);
+            lk.unlock();
+            exec(batch);
+            lk.lock();
+            for (BswReq* b : batch) b->done = true;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+};
+
+template <class T>
+void grow(T*& p, int64_t& cap, int64_t want) {
+    if (want <= cap) return;
+    meme_host_free(p);
+    cap = want + want / 2 + 4096;
+    if (!(p = (T*)meme_host_alloc(cap * (int64_t)sizeof(T)))) die("meme_host_alloc");
+}
+
+void Combiner::exec(std::vector<BswReq*>& batch) {
+    const double t0 = now_s();
+    meme_ctx* ctx = g_dev[(size_t)device].bsw;
+    std::vector<char> used(batch.size(), 0);
+    for (size_t k0 = 0; k0 < batch.size(); ++k0) {
+        if (used[k0]) continue;
+        // requests with the same band and penalties share one call; SeqPair offsets are 32-bit, so a call is also cut
+        // when the combined sequence buffers would pass 2 GB
+        size_t k = k0;
+        while (k < batch.size()) {
+            int64_t n = 0, rb = 0, qb = 0;
+            std::vector<size_t> grp;
+            for (; k < batch.size(); ++k) {
+                if (used[k] || batch[k]->w != batch[k0]->w || memcmp(&batch[k]->o, &batch[k0]->o, sizeof(meme_bsw_opt))) continue;
+                if (!grp.empty() && (rb + batch[k]->rb >= INT32_MAX || qb + batch[k]->qb >= INT32_MAX || n + batch[k]->n >= INT32_MAX)) break;
+                grp.push_back(k); used[k] = 1;
+                n += batch[k]->n; rb += batch[k]->rb; qb += batch[k]->qb;
+            }
+            if (grp.empty()) break;
+            grow(pairs, pairs_cap, n); grow(ref, ref_cap, rb + 16); grow(qer, qer_cap, qb + 16);
+            int64_t pn = 0, pr = 0, pq = 0;
+            for (size_t g : grp) {
+                BswReq* r = batch[g];
+                memcpy(ref + pr, r->ref, (size_t)r->rb);
+                memcpy(qer + pq, r->qer, (size_t)r->qb);
+                memcpy(pairs + pn, r->pairs, (size_t)r->n * sizeof(meme_seqpair));
+                for (int i = 0; i < r->n; ++i) { pairs[pn + i].idr += (int32_t)pr; pairs[pn + i].idq += (int32_t)pq; }
+                pn += r->n; pr += r->rb; pq += r->qb;
+            }
+            if (meme_bsw_batch(ctx, pairs, ref, rb, qer, qb, (int)n, batch[k0]->w, &batch[k0]->o)) die("meme_bsw_batch");
+            pn = 0;
+            for (size_t g : grp) {
+                BswReq* r = batch[g];
+                for (int i = 0; i < r->n; ++i) {
+                    const meme_seqpair& s = pairs[pn + i];
+                    SeqPair& p = r->pairs[i];
+                    p.score = s.score; p.tle = s.tle; p.gtle = s.gtle; p.qle = s.qle; p.gscore = s.gscore; p.max_off = s.max_off;
+                }
+                pn += r->n;
+            }
+            g_n_bsw_calls += 1;
+            g_n_bsw_pairs += n;
+        }
+    }
+    g_t_bsw = g_t_bsw + (now_s() - t0);
+}
+
+Combiner* g_comb = nullptr;
+std::once_flag g_comb_once;
+std::atomic<int> g_thread_seq{0};
+
+void bsw_forward(const int8_t* mat, int o_del, int e_del, int o_ins, int e_ins, int zdrop, int end_bonus, SeqPair* pairs,
+                 uint8_t* ref, uint8_t* qer, int n, int w) {
+    if (n <= 0) return;
+    static_assert(sizeof(meme_seqpair) == sizeof(SeqPair), "SeqPair layout");
+    if (g_dev.empty()) { fprintf(stderr, "[meme-dropin] banded SW called before the devices were set up\n"); exit(1); }
+    std::call_once(g_comb_once, [] {
+        g_comb = new Combiner[g_dev.size()];
+        for (size_t d = 0; d < g_dev.size(); ++d) g_comb[d].device = (int)d;
+    });
+    BswReq rq;
+    rq.pairs = pairs; rq.ref = ref; rq.qer = qer; rq.n = n; rq.w = w;
+    memset(&rq.o, 0, sizeof(rq.o));
+    rq.o.o_del = o_del; rq.o.e_del = e_del; rq.o.o_ins = o_ins; rq.o.e_ins = e_ins; rq.o.zdrop = zdrop; rq.o.end_bonus = end_bonus;
+    rq.o.a = mat[0]; rq.o.b = -mat[1];                        // mat = bwa_fill_scmat(a, b)
+    rq.rb = rq.qb = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((int64_t)pairs[i].idr + pairs[i].len1 > rq.rb) rq.rb = (int64_t)pairs[i].idr + pairs[i].len1;
+        if ((int64_t)pairs[i].idq + pairs[i].len2 > rq.qb) rq.qb = (int64_t)pairs[i].idq + pairs[i].len2;
+    }
+    // the kt_for thread id is not passed down to this level: number the calling threads as they show up
+    static thread_local int my = g_thread_seq++;
+    const int nd = (int)g_dev.size();
+    const int per = (g_team + nd - 1) / nd;
+    g_comb[my % nd].submit(&rq, per);
+}
+}  // namespace
+
+void BandedPairWiseSW::scalarBandedSWAWrapper(SeqPair* p, uint8_t* r, uint8_t* q, int n, int nthreads, int32_t w) {
+    (void)nthreads;
+    bsw_forward(mat, o_del, e_del, o_ins, e_ins, zdrop, end_bonus, p, r, q, n, w);
+}
+void BandedPairWiseSW::getScores16(SeqPair* p, uint8_t* r, uint8_t* q, int32_t n, uint16_t nthreads, int32_t w) {
+    (void)nthreads;
+    bsw_forward(mat, o_del, e_del, o_ins, e_ins, zdrop, end_bonus, p, r, q, n, w);
+}
+void BandedPairWiseSW::getScores8(SeqPair* p, uint8_t* r, uint8_t* q, int32_t n, uint16_t nthreads, int32_t w) {
+    (void)nthreads;
+    bsw_forward(mat, o_del, e_del, o_ins, e_ins, zdrop, end_bonus, p, r, q, n, w);
+}

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "meme_hip.h"
@@ -46,10 +47,12 @@ struct meme_ctx {
     hipStream_t stream = nullptr;
     DevIndex idx;
     bool owns_index = false;
-    std::vector<void*> owned;          // device allocations of the index
+    std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
            scan_tmp, counters, pairs, refb, qerb, packed, bsw_order;
+    // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
+    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc;
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
     i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch (tier 0)
@@ -65,6 +68,7 @@ struct meme_ctx {
 
 void meme_set_error(const char* fmt, ...);
 int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes);
+int meme_hostbuf_reserve(meme_ctx* ctx, meme_ctx::HostBuf& b, size_t bytes);
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \

@@ -28,6 +28,24 @@ int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes) {
     return MEME_OK;
 }
 
+int meme_hostbuf_reserve(meme_ctx* ctx, meme_ctx::HostBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return MEME_OK;
+    if (b.p) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    b.cap = want;
+    return MEME_OK;
+}
+
+// pinned host memory for the caller's staging buffers: copies from / to it are true asynchronous DMA transfers
+extern "C" void* meme_host_alloc(int64_t bytes) {
+    void* p = nullptr;
+    if (bytes <= 0) return nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) { meme_set_error("hipHostMalloc(%lld) failed", (long long)bytes); return nullptr; }
+    return p;
+}
+extern "C" void meme_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int meme_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -67,7 +85,9 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
                       &ctx->packed, &ctx->bsw_order};
     for (DevBuf* b : bufs) free_buf(*b);
-    if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
+    if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
+    for (meme_ctx::HostBuf* h : {&ctx->h_smems, &ctx->h_hits, &ctx->h_smem_off, &ctx->h_hit_off, &ctx->h_misc})
+        if (h->p) (void)hipHostFree(h->p);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -102,6 +122,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
 }
 
 static unsigned stage_blocks(i64 items);
+extern "C" int meme_index_share(meme_ctx* ctx, meme_ctx* owner);
 // ---- staging kernels ---------------------------------------------------------------------------------
 extern "C" int64_t meme_index_pac64_words(int64_t sa_num) { return ((sa_num + 31) >> 5) + 8; }
 
@@ -201,7 +222,7 @@ static int set_rmi(meme_ctx* ctx, i64 l2_records, i64 l1_records) {
 }
 
 static void drop_index(meme_ctx* ctx) {
-    if (ctx->owns_index) for (void* p : ctx->owned) (void)hipFree(p);
+    if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     ctx->owned.clear();
     ctx->owns_index = false;
     ctx->idx = DevIndex();
@@ -220,14 +241,14 @@ extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, in
     i64 words = meme_index_pac64_words(n);
     void *d_ent = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_tmp = nullptr;
     HIP_TRY(hipMalloc(&d_ent, (size_t)n * sizeof(SaEnt)));
-    ctx->owned.push_back(d_ent);
+    ctx->owned.push_back({d_ent, (size_t)n * sizeof(SaEnt)});
     ctx->owns_index = true;
     HIP_TRY(hipMalloc(&d_pac, (size_t)words * 8));
-    ctx->owned.push_back(d_pac);
+    ctx->owned.push_back({d_pac, (size_t)words * 8});
     HIP_TRY(hipMalloc(&d_l2, (size_t)l2_bytes));
-    ctx->owned.push_back(d_l2);
+    ctx->owned.push_back({d_l2, (size_t)l2_bytes});
     HIP_TRY(hipMalloc(&d_l1, (size_t)(l1_bytes > 0 ? l1_bytes : 24)));
-    ctx->owned.push_back(d_l1);
+    ctx->owned.push_back({d_l1, (size_t)(l1_bytes > 0 ? l1_bytes : 24)});
     // staging buffer: the larger of the two images, reused
     size_t tmp_bytes = (size_t)n * 5 + 64;
     HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
@@ -301,6 +322,36 @@ extern "C" int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out) {
     out->l2_records = ctx->idx.n_l2;
     out->d_l1 = (void*)ctx->idx.l1;
     out->l1_records = ctx->idx.n_l1;
+    return MEME_OK;
+}
+
+// Multi-GPU start-up: copy a staged index to a ctx on another device, device to device over xGMI (no host round trip,
+// no re-staging).  Equivalent of the RCCL broadcast of bench.py for hosts that drive all GPUs from one process (the
+// reference's kt_for threads).
+extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
+    if (!dst || !src || dst == src) return MEME_E_ARG;
+    if (!src->idx.sa) { meme_set_error("meme_index_replicate: source has no index"); return MEME_E_STATE; }
+    if (dst->device == src->device) return meme_index_share(dst, src);
+    if (!src->owns_index) { meme_set_error("meme_index_replicate: the source ctx must own its index (load_host / load_files)"); return MEME_E_STATE; }
+    HIP_TRY(hipSetDevice(dst->device));
+    drop_index(dst);
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, dst->device, src->device);
+    if (can) { hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0; (void)hipGetLastError(); }
+    DevIndex I = src->idx;
+    dst->owns_index = true;
+    for (auto& o : src->owned) {
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, o.second));
+        dst->owned.push_back({d, o.second});
+        HIP_TRY(hipMemcpyPeerAsync(d, dst->device, o.first, src->device, o.second, dst->stream));
+        if ((const void*)I.sa == o.first) I.sa = (const SaEnt*)d;
+        if ((const void*)I.pac == o.first) I.pac = (const u64*)d;
+        if ((const void*)I.l2 == o.first) I.l2 = (const RmiRec*)d;
+        if ((const void*)I.l1 == o.first) I.l1 = (const RmiRec*)d;
+    }
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    dst->idx = I;
     return MEME_OK;
 }
 

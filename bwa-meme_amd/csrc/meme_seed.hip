@@ -194,8 +194,11 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
     // ---- pack the reads: 2 bits/base, both strands, N masks (k_pack_reads) ---------------------------------
     const i64 stage_len = max_len < 1 ? 1 : max_len;              // longest read as staged by the packing kernel
-    if (stage_len > 32768) { meme_set_error("read of %lld bases: not a short read", (long long)stage_len); return MEME_E_ARG; }
-    if (max_len > MAX_READ_LEN) max_len = MAX_READ_LEN;
+    // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262): fail loudly, never seed part of a batch
+    if (max_len > MAX_READ_LEN) {
+        meme_set_error("read of %lld bases exceeds the learned-index limit of %d (LEARNED_MAX_READ_LEN)", (long long)max_len, MAX_READ_LEN);
+        return MEME_E_ARG;
+    }
     if (max_len < 1) max_len = 1;
     PackGeom geo;
     geo.W = (int)((max_len + 31) / 32) + 2;
@@ -435,5 +438,46 @@ extern "C" int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_
     HIP_TRY(hipMemcpyAsync(smems, res.d_smems, (size_t)res.total_smems * sizeof(meme_mem_tl), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(hits, res.d_hits, (size_t)res.total_hits * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MEME_OK;
+}
+
+// Host-pointer variant whose results land in pinned buffers owned by the ctx (valid until the next seeding call on it):
+// no capacity negotiation, and the device-to-host copies are plain DMA transfers.  `reads` / `read_off` may be pageable or
+// pinned (meme_host_alloc).  This is the call a chunk-level binding issues once per -K chunk.
+extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                                    const meme_seed_opt* opt, meme_seed_host_result* out) {
+    if (!ctx || !reads || !read_off || !out || nreads < 0) return MEME_E_ARG;
+    int rc = check_opt(opt);
+    if (rc) return rc;
+    if (!ctx->idx.sa) { meme_set_error("meme_seed_batch_host: no index loaded"); return MEME_E_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smem_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
+    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hit_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
+    out->smem_off = (const int64_t*)ctx->h_smem_off.p;
+    out->hit_off = (const int64_t*)ctx->h_hit_off.p;
+    if (nreads == 0) { ((i64*)ctx->h_smem_off.p)[0] = 0; ((i64*)ctx->h_hit_off.p)[0] = 0; return MEME_OK; }
+    if (read_off[0] != 0) { meme_set_error("read_off[0] must be 0"); return MEME_E_ARG; }
+    const i64 bases = read_off[nreads];
+    if ((rc = meme_buf_reserve(ctx, ctx->reads, (size_t)bases + 16))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->read_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->reads.p, reads, (size_t)bases, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->read_off.p, read_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyHostToDevice, ctx->stream));
+    i64 max_len = 0;
+    for (i64 i = 0; i < nreads; ++i) max_len = read_off[i + 1] - read_off[i] > max_len ? read_off[i + 1] - read_off[i] : max_len;
+    meme_seed_result res;
+    rc = launch_seed(ctx, (const uint8_t*)ctx->reads.p, (const i64*)ctx->read_off.p, nreads, max_len, bases, opt, &res);
+    if (rc) return rc;
+    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smems, (size_t)(res.total_smems + 1) * sizeof(meme_mem_tl)))) return rc;
+    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hits, (size_t)(res.total_hits + 1) * sizeof(u64)))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->h_smem_off.p, res.d_smem_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_hit_off.p, res.d_hit_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_smems.p, res.d_smems, (size_t)res.total_smems * sizeof(meme_mem_tl), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_hits.p, res.d_hits, (size_t)res.total_hits * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->smems = (const meme_mem_tl*)ctx->h_smems.p;
+    out->hits = (const uint64_t*)ctx->h_hits.p;
+    out->total_smems = res.total_smems;
+    out->total_hits = res.total_hits;
     return MEME_OK;
 }

@@ -103,6 +103,13 @@ int64_t meme_index_pac64_words(int64_t sa_num);
 int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* arrays);
 int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out);     /* device pointers of a loaded index */
 int meme_index_share(meme_ctx* ctx, meme_ctx* owner);               /* second ctx on the same device */
+/* Multi-GPU: copy src's staged index to dst (a ctx on another device) device-to-device over xGMI.  The counterpart,
+ * for a host that drives all GPUs from one process (the reference's kt_for threads, src/kthread.cpp:79-114), of the
+ * RCCL broadcast a one-process-per-GPU launcher uses.  Same device: behaves like meme_index_share. */
+int meme_index_replicate(meme_ctx* dst, meme_ctx* src);
+/* Pinned host memory for staging buffers handed to the batch calls (their copies then run as asynchronous DMA). */
+void* meme_host_alloc(int64_t bytes);
+void meme_host_free(void* p);
 /* staging kernels usable on caller-owned device buffers (used by the multi-GPU path and bench.py) */
 int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text0123, int64_t sa_num, void* d_pac64);
 int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t sa_num,
@@ -112,7 +119,8 @@ int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t sa_n
 
 /* ---- seeding ------------------------------------------------------------------------------------
  * reads: concatenated base codes 0..3, >=4 = ambiguous (what mem_kernel1_core_Learned leaves in
- * bseq1_t.seq, src/bwamem.cpp:1277-1279); read_off[nreads+1].
+ * bseq1_t.seq, src/bwamem.cpp:1277-1279); read_off[nreads+1].  A read longer than 500 bases
+ * (LEARNED_MAX_READ_LEN; the reference exits, src/bwamem.cpp:1259-1262) fails the whole call with MEME_E_ARG.
  * Outputs, per read r: smems[smem_off[r] .. smem_off[r+1]) in emission order (the caller sorts them,
  * src/bwamem.cpp:1397) and hits[hit_off[r] .. hit_off[r+1]) in ascending SA order per SMEM.          */
 int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
@@ -120,6 +128,18 @@ int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off
                     meme_mem_tl* smems, int64_t smem_capacity, int64_t* smem_off,
                     uint64_t* hits, int64_t hit_capacity, int64_t* hit_off,
                     int64_t* total_smems, int64_t* total_hits);
+
+/* Same, results in pinned host buffers owned by the ctx (valid until its next seeding call): the form a chunk-level
+ * binding uses -- one call per -K chunk of mem_process_seqs (src/bwamem.cpp:1920-1972), no capacity negotiation. */
+typedef struct {
+    const meme_mem_tl* smems;
+    const int64_t* smem_off;     /* nreads+1 */
+    const uint64_t* hits;
+    const int64_t* hit_off;      /* nreads+1 */
+    int64_t total_smems, total_hits;
+} meme_seed_host_result;
+int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                         const meme_seed_opt* opt, meme_seed_host_result* out);
 
 /* Same with inputs and outputs resident in HBM (pointers valid until the next call on this ctx).
  * d_reads must be 4-byte aligned (any hipMalloc'ed pointer is); total_bases = read_off[nreads] = bytes in d_reads. */
