@@ -16,7 +16,7 @@ is built on the host (about 4-6 minutes on the 256-thread box) and cached in /de
 
 Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 3100), MEME_BENCH_READS (reads per GPU
 per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's rule),
-MEME_BENCH_LANES (lanes per read in the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the compiled
+MEME_BENCH_WAVES (resident wavefronts per CU of the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the compiled
 reference up to 1 Gbp, the restated port above), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables).
 """
 import argparse
@@ -198,7 +198,7 @@ def main():
         except ImportError:
             pass
         gpu_free = torch.cuda.mem_get_info(local)[0]
-        while mbp > 64 and 2 * mbp * 1e6 * 28 + nreads * 2200 > 0.9 * gpu_free:
+        while mbp > 64 and 2 * mbp * 1e6 * 30 + nreads * 2200 > 0.9 * gpu_free:
             mbp /= 2
             log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
     l_pac_t = torch.tensor([int(mbp * 1e6) & ~1], dtype=torch.int64, device=dev)
@@ -248,39 +248,34 @@ def main():
         dist.broadcast(meta, 0)
     n_l2, n_l1 = int(meta[1]), int(meta[2])
     t0 = time.time()
+    ctx = hipapi.Context(local)
+    if os.environ.get("MEME_BENCH_WAVES"):
+        ctx.set_tuning("seed_waves_per_cu", int(os.environ["MEME_BENCH_WAVES"]))
+    L = hipapi.lib()
     d_text = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_sa = torch.empty(n, dtype=torch.int64, device=dev)
+    d_pos5 = torch.zeros(L.meme_index_pos5_bytes(n), dtype=torch.uint8, device=dev)
     d_l2 = torch.empty(n_l2 * 24, dtype=torch.uint8, device=dev)
     d_l1 = torch.empty(max(n_l1, 1) * 24, dtype=torch.uint8, device=dev)
     if rank == 0:
         d_text.copy_(torch.from_numpy(text))
-        d_sa.copy_(torch.from_numpy(sa.view(np.int64)))
+        # the host builder holds the suffix array as u64; the GPU index (and the broadcast) use the reference's 5-byte image
+        d_sa = torch.from_numpy(sa.view(np.int64)).to(dev)
+        d_pos5 = hipapi.pos5_from_sa_torch(ctx, d_sa, n)
+        del d_sa
+        torch.cuda.empty_cache()
         d_l2.copy_(torch.from_numpy(l2.view(np.uint8).reshape(-1)))
         if n_l1:
             d_l1[:n_l1 * 24].copy_(torch.from_numpy(l1.view(np.uint8).reshape(-1)))
     if world > 1:
-        # one-off RCCL broadcast of the index image over xGMI; no collective in steady state
-        for t in (d_text, d_sa, d_l2, d_l1):
+        # one-off RCCL broadcast of the raw index images over xGMI (5 B per suffix + 1 B per base + the model tables);
+        # no collective in steady state
+        for t in (d_text, d_pos5, d_l2, d_l1):
             dist.broadcast(t, 0)
     torch.cuda.synchronize()
-    ctx = hipapi.Context(local)
-    if os.environ.get("MEME_BENCH_LANES"):
-        ctx.set_tuning("group_lanes", int(os.environ["MEME_BENCH_LANES"]))
-    words = hipapi.lib().meme_index_pac64_words(n)
-    d_pac = torch.empty(words, dtype=torch.int64, device=dev)
-    d_ent = torch.empty(2 * n, dtype=torch.int64, device=dev)
-    L = hipapi.lib()
-    import ctypes as C
-    hipapi._check(L.meme_stage_pack_text(C.c_void_p(ctx.h), C.c_void_p(d_text.data_ptr()), C.c_int64(n),
-                                         C.c_void_p(d_pac.data_ptr())))
-    hipapi._check(L.meme_stage_entries_from_sa(C.c_void_p(ctx.h), C.c_void_p(d_sa.data_ptr()), C.c_int64(n),
-                                               C.c_void_p(d_pac.data_ptr()), C.c_void_p(d_ent.data_ptr())))
-    ctx.sync()
-    arrays = hipapi.IndexArrays(n, d_ent.data_ptr(), d_pac.data_ptr(), d_l2.data_ptr(), n_l2, d_l1.data_ptr(), n_l1)
-    ctx.attach_index(arrays)
-    del d_sa, d_text
+    keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, n_l2, d_l1, n_l1)
+    del d_text, d_l2, d_l1
     torch.cuda.empty_cache()
-    log("index staged in HBM in %.1f s (%.2f GB entries)" % (time.time() - t0, 16 * n / 1e9))
+    log("index staged in HBM in %.1f s (%.2f GB keys + %.2f GB positions)" % (time.time() - t0, 8 * n / 1e9, 5 * n / 1e9))
 
     # ---- reads: every rank samples its own batch ------------------------------------------------------
     genome_t = torch.empty(l_pac, dtype=torch.uint8, device=dev)

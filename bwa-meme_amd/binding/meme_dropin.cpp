@@ -60,7 +60,7 @@ struct Device {
 };
 std::vector<Device> g_dev;
 std::mutex g_mu;
-std::atomic<double> g_t_seed{0}, g_t_bsw{0};
+std::atomic<double> g_t_seed{0}, g_t_bsw_gather{0}, g_t_bsw_call{0}, g_t_bsw_kernel{0};
 std::atomic<int64_t> g_n_bsw_calls{0}, g_n_bsw_pairs{0}, g_n_seed_reads{0};
 
 void init_devices(const char* prefix) {
@@ -248,8 +248,10 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
     if (verbose())
-        fprintf(stderr, "[meme-dropin] totals: seeding %.3f s for %lld reads; bsw %lld calls, %lld pairs, %.3f s inside the backend\n",
-                (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs, (double)g_t_bsw);
+        fprintf(stderr, "[meme-dropin] totals: seeding %.3f s for %lld reads; bsw %lld calls, %lld pairs "
+                "(copy-in thread-seconds %.3f, backend calls %.3f s of which kernels %.3f s)\n",
+                (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs,
+                (double)g_t_bsw_gather, (double)g_t_bsw_call, (double)g_t_bsw_kernel);
 }
 
 int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
@@ -290,100 +292,123 @@ namespace {
 
 struct BswReq {
     SeqPair* pairs; const uint8_t* ref; const uint8_t* qer; int n; int w; meme_bsw_opt o; int64_t rb, qb;
+    int64_t pn = 0, pr = 0, pq = 0;      // where this request sits in the staging buffers
     bool done = false;
 };
 
-// Group commit: the first worker to arrive becomes the leader, takes everything queued so far (after a short wait for
-// the rest of the team), issues ONE backend call and hands the results back.  While a call is in flight the other
-// workers' requests pile up for the next leader.  One combiner per GPU; worker threads are spread over them.
+// Group commit with double-buffered pinned staging.  A worker reserves room for its request in the open staging buffer
+// (under the lock), copies its pairs and sequences in by itself (all workers copy in parallel, outside the lock) and
+// waits; the first waiter that finds no call in flight becomes the leader: it closes the buffer, lets new arrivals
+// fill the other one, issues ONE backend call for everything in it and wakes the owners, which copy their own
+// results out.  While a call is in flight the next batch assembles itself.  One combiner per GPU.
+struct Staging {
+    meme_seqpair* pairs = nullptr; uint8_t* ref = nullptr; uint8_t* qer = nullptr;     // pinned, fixed capacity
+    int64_t n = 0, rb = 0, qb = 0;
+    int w = 0; meme_bsw_opt o; bool has_key = false;
+    std::vector<BswReq*> reqs;
+    int copying = 0, reading = 0;
+    bool closed = false;
+};
+
 struct Combiner {
-    std::mutex m;
+    static constexpr int64_t CAP_PAIRS = 1 << 20, CAP_REF = 384ll << 20, CAP_QER = 192ll << 20;
+    std::mutex m, ctx_mu;
     std::condition_variable cv;
-    std::vector<BswReq*> queue;
+    Staging st[2];
+    int open = 0;
     bool busy = false;
     int device = 0;
-    // pinned staging, leader-only
-    meme_seqpair* pairs = nullptr; int64_t pairs_cap = 0;
-    uint8_t* ref = nullptr; int64_t ref_cap = 0;
-    uint8_t* qer = nullptr; int64_t qer_cap = 0;
 
-    void exec(std::vector<BswReq*>& batch);
-    void submit(BswReq* r, int expected) {
-        std::unique_lock<std::mutex> lk(m);
-        queue.push_back(r);
+    void init() {
+        for (Staging& S : st) {
+            S.pairs = (meme_seqpair*)meme_host_alloc(CAP_PAIRS * (int64_t)sizeof(meme_seqpair));
+            S.ref = (uint8_t*)meme_host_alloc(CAP_REF + 64);
+            S.qer = (uint8_t*)meme_host_alloc(CAP_QER + 64);
+            if (!S.pairs || !S.ref || !S.qer) die("meme_host_alloc");
+        }
+    }
+    static bool same_key(const Staging& S, const BswReq* r) { return S.w == r->w && !memcmp(&S.o, &r->o, sizeof(meme_bsw_opt)); }
+    static bool fits(const Staging& S, const BswReq* r) {
+        return S.n + r->n <= CAP_PAIRS && S.rb + r->rb <= CAP_REF && S.qb + r->qb <= CAP_QER;
+    }
+
+    // called with the lock held and busy == false: run everything reserved in S
+    void lead(std::unique_lock<std::mutex>& lk, Staging& S, int expected) {
+        busy = true;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
+        while ((int)S.reqs.size() < expected && S.n < CAP_PAIRS / 2 && cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+        S.closed = true;
+        Staging& other = st[&S == &st[0] ? 1 : 0];
+        while (other.closed) cv.wait(lk);                   // its owners are still copying the previous results out
+        open = &S == &st[0] ? 1 : 0;
+        while (S.copying > 0) cv.wait(lk);
+        lk.unlock();
+        const double t0 = now_s();
+        {
+            std::lock_guard<std::mutex> cl(ctx_mu);
+            if (meme_bsw_batch(g_dev[(size_t)device].bsw, S.pairs, S.ref, S.rb, S.qer, S.qb, (int)S.n, S.w, &S.o)) die("meme_bsw_batch");
+            if (verbose()) { meme_timings tm; if (!meme_get_timings(g_dev[(size_t)device].bsw, &tm)) g_t_bsw_kernel = g_t_bsw_kernel + tm.bsw_kernel_ms * 1e-3; }
+        }
+        g_t_bsw_call = g_t_bsw_call + (now_s() - t0);
+        g_n_bsw_calls += 1;
+        g_n_bsw_pairs += S.n;
+        lk.lock();
+        S.reading = (int)S.reqs.size();
+        for (BswReq* b : S.reqs) b->done = true;
+        busy = false;
         cv.notify_all();
+    }
+
+    void submit(BswReq* r, int expected) {
+        if (r->n > CAP_PAIRS || r->rb > CAP_REF || r->qb > CAP_QER) {      // a request bigger than the staging area: on its own
+            std::lock_guard<std::mutex> cl(ctx_mu);
+            if (meme_bsw_batch(g_dev[(size_t)device].bsw, (meme_seqpair*)r->pairs, r->ref, r->rb, r->qer, r->qb, r->n, r->w, &r->o)) die("meme_bsw_batch");
+            return;
+        }
+        std::unique_lock<std::mutex> lk(m);
+        Staging* S;
         for (;;) {
-            if (r->done) return;
-            if (busy) { cv.wait(lk); continue; }
-            busy = true;
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(150);
-            while ((int)queue.size() < expected && cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
-            std::vector<BswReq*> batch;
-            batch.swap(queue);
-            lk.unlock();
-            exec(batch);
-            lk.lock();
-            for (BswReq* b : batch) b->done = true;
-            busy = false;
+            S = &st[open];
+            if (!S->closed && (!S->has_key || same_key(*S, r)) && fits(*S, r)) break;
+            if (!busy && !S->closed && S->n > 0) { lead(lk, *S, 0); continue; }   // flush what blocks the way
+            cv.wait(lk);
+        }
+        if (!S->has_key) { S->w = r->w; S->o = r->o; S->has_key = true; }
+        r->pn = S->n; r->pr = S->rb; r->pq = S->qb;
+        S->n += r->n; S->rb += r->rb; S->qb += r->qb;
+        S->reqs.push_back(r);
+        S->copying++;
+        cv.notify_all();
+        lk.unlock();
+        const double t0 = now_s();
+        memcpy(S->ref + r->pr, r->ref, (size_t)r->rb);
+        memcpy(S->qer + r->pq, r->qer, (size_t)r->qb);
+        for (int i = 0; i < r->n; ++i) {
+            meme_seqpair p;
+            memcpy(&p, &r->pairs[i], sizeof(p));
+            p.idr += (int32_t)r->pr; p.idq += (int32_t)r->pq;
+            S->pairs[r->pn + i] = p;
+        }
+        g_t_bsw_gather = g_t_bsw_gather + (now_s() - t0);
+        lk.lock();
+        if (--S->copying == 0) cv.notify_all();
+        while (!r->done) {
+            if (!busy && !S->closed) lead(lk, *S, expected);
+            else cv.wait(lk);
+        }
+        lk.unlock();
+        for (int i = 0; i < r->n; ++i) {
+            const meme_seqpair& g = S->pairs[r->pn + i];
+            SeqPair& p = r->pairs[i];
+            p.score = g.score; p.tle = g.tle; p.gtle = g.gtle; p.qle = g.qle; p.gscore = g.gscore; p.max_off = g.max_off;
+        }
+        lk.lock();
+        if (--S->reading == 0) {                              // last owner out: the buffer can be filled again
+            S->n = S->rb = S->qb = 0; S->has_key = false; S->closed = false; S->reqs.clear();
             cv.notify_all();
         }
     }
 };
-
-template <class T>
-void grow(T*& p, int64_t& cap, int64_t want) {
-    if (want <= cap) return;
-    meme_host_free(p);
-    cap = want + want / 2 + 4096;
-    if (!(p = (T*)meme_host_alloc(cap * (int64_t)sizeof(T)))) die("meme_host_alloc");
-}
-
-void Combiner::exec(std::vector<BswReq*>& batch) {
-    const double t0 = now_s();
-    meme_ctx* ctx = g_dev[(size_t)device].bsw;
-    std::vector<char> used(batch.size(), 0);
-    for (size_t k0 = 0; k0 < batch.size(); ++k0) {
-        if (used[k0]) continue;
-        // requests with the same band and penalties share one call; SeqPair offsets are 32-bit, so a call is also cut
-        // when the combined sequence buffers would pass 2 GB
-        size_t k = k0;
-        while (k < batch.size()) {
-            int64_t n = 0, rb = 0, qb = 0;
-            std::vector<size_t> grp;
-            for (; k < batch.size(); ++k) {
-                if (used[k] || batch[k]->w != batch[k0]->w || memcmp(&batch[k]->o, &batch[k0]->o, sizeof(meme_bsw_opt))) continue;
-                if (!grp.empty() && (rb + batch[k]->rb >= INT32_MAX || qb + batch[k]->qb >= INT32_MAX || n + batch[k]->n >= INT32_MAX)) break;
-                grp.push_back(k); used[k] = 1;
-                n += batch[k]->n; rb += batch[k]->rb; qb += batch[k]->qb;
-            }
-            if (grp.empty()) break;
-            grow(pairs, pairs_cap, n); grow(ref, ref_cap, rb + 16); grow(qer, qer_cap, qb + 16);
-            int64_t pn = 0, pr = 0, pq = 0;
-            for (size_t g : grp) {
-                BswReq* r = batch[g];
-                memcpy(ref + pr, r->ref, (size_t)r->rb);
-                memcpy(qer + pq, r->qer, (size_t)r->qb);
-                memcpy(pairs + pn, r->pairs, (size_t)r->n * sizeof(meme_seqpair));
-                for (int i = 0; i < r->n; ++i) { pairs[pn + i].idr += (int32_t)pr; pairs[pn + i].idq += (int32_t)pq; }
-                pn += r->n; pr += r->rb; pq += r->qb;
-            }
-            if (meme_bsw_batch(ctx, pairs, ref, rb, qer, qb, (int)n, batch[k0]->w, &batch[k0]->o)) die("meme_bsw_batch");
-            pn = 0;
-            for (size_t g : grp) {
-                BswReq* r = batch[g];
-                for (int i = 0; i < r->n; ++i) {
-                    const meme_seqpair& s = pairs[pn + i];
-                    SeqPair& p = r->pairs[i];
-                    p.score = s.score; p.tle = s.tle; p.gtle = s.gtle; p.qle = s.qle; p.gscore = s.gscore; p.max_off = s.max_off;
-                }
-                pn += r->n;
-            }
-            g_n_bsw_calls += 1;
-            g_n_bsw_pairs += n;
-        }
-    }
-    g_t_bsw = g_t_bsw + (now_s() - t0);
-}
 
 Combiner* g_comb = nullptr;
 std::once_flag g_comb_once;
@@ -396,7 +421,7 @@ void bsw_forward(const int8_t* mat, int o_del, int e_del, int o_ins, int e_ins, 
     if (g_dev.empty()) { fprintf(stderr, "[meme-dropin] banded SW called before the devices were set up\n"); exit(1); }
     std::call_once(g_comb_once, [] {
         g_comb = new Combiner[g_dev.size()];
-        for (size_t d = 0; d < g_dev.size(); ++d) g_comb[d].device = (int)d;
+        for (size_t d = 0; d < g_dev.size(); ++d) { g_comb[d].device = (int)d; g_comb[d].init(); }
     });
     BswReq rq;
     rq.pairs = pairs; rq.ref = ref; rq.qer = qer; rq.n = n; rq.w = w;

@@ -41,6 +41,8 @@ struct BswArgs {
     meme_bsw_opt o;
     int qmax;                // LDS columns per pair (multiple of LP)
     unsigned int* ticket;
+    const int* offs;         // != nullptr: the class is order[offs[key_first] .. offs[key_last]) (exclusive scan of the sort keys,
+    int key_first, key_last; // read on the device: no host round trip between the sort and the DP kernels)
 };
 
 // LP lanes cooperate on one pair (64/LP pairs per wavefront): short extensions -- the common case, since most
@@ -96,6 +98,7 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = A.o.zdrop;
     const int sa = A.o.a, sb = -A.o.b;
 
+    if (A.offs) { const int f = A.offs[A.key_first]; A.order += f; A.npairs = A.offs[A.key_last] - f; }
     for (;;) {
         unsigned int tk = 0;
         if (gl == 0) tk = atomicAdd(A.ticket, 1u);
@@ -270,6 +273,8 @@ struct LaneArgs {
     int w;
     meme_bsw_opt o;
     unsigned int* ticket;
+    const int* offs;         // != nullptr: first/count come from the device-side scan, keys [key_first, key_last)
+    int key_first, key_last;
 };
 
 __device__ __forceinline__ unsigned he_pack(int h, int e, unsigned qbits) { return (unsigned)h | ((unsigned)e << 14) | qbits; }
@@ -283,6 +288,7 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = A.o.zdrop;
     const int sa = A.o.a, sb = -A.o.b;
     constexpr unsigned HE_MASK = (1u << 28) - 1u, QMASK = 7u << 28;
+    if (A.offs) { A.first = A.offs[A.key_first]; A.count = A.offs[A.key_last] - A.first; }
     for (;;) {
         unsigned int tk = 0;
         if (lane == 0) tk = atomicAdd(A.ticket, 64u);
@@ -491,7 +497,7 @@ int launch_cls(meme_ctx* ctx, BswArgs A, int qmax, i64 dev_cus) {
         return MEME_E_ARG;
     }
     i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 4;
-    i64 want = (A.npairs + GROUPS - 1) / GROUPS;
+    i64 want = (A.npairs + GROUPS - 1) / GROUPS;        // (upper bound when the class range is read on the device)
     if (blocks > want) blocks = want;
     if (blocks < 1) blocks = 1;
     if (lds > 64 * 1024)
@@ -502,8 +508,10 @@ int launch_cls(meme_ctx* ctx, BswArgs A, int qmax, i64 dev_cus) {
     return MEME_OK;
 }
 
+// `host_maxq`: longest query of the batch when the caller knows it (host API), else -1: then the class boundaries and the
+// longest query of the pairs the lane kernel cannot take are read back from the device before the DP kernels are sized.
 int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w,
-               const meme_bsw_opt* opt) {
+               const meme_bsw_opt* opt, int host_maxq) {
     if (opt->e_ins <= 0 || opt->e_del <= 0) { meme_set_error("gap extension penalties must be positive"); return MEME_E_ARG; }
     int rc;
     // counters (ints): [0..SORT_KEYS) histogram by query length, [SORT_KEYS..2*SORT_KEYS] exclusive offsets (+ total),
@@ -517,9 +525,7 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     int* maxq = cursor + SORT_KEYS;
     unsigned int* tickets = (unsigned int*)(maxq + 1);
     int* order = (int*)ctx->bsw_order.p;
-    i64 dev_cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) dev_cus = prop.multiProcessorCount;
+    const i64 dev_cus = ctx->n_cus;
     HIP_TRY(hipMemsetAsync(hist, 0, n_ints * sizeof(int), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
     // big batches: one pair per lane (throughput).  Small batches (the reference's 512-read call granularity): 16-64
@@ -534,25 +540,30 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
         hipLaunchKernelGGL(k_bsw_scatter, dim3((unsigned)sblocks), dim3(256), 0, ctx->stream, d_pairs, npairs, key_a, cursor, order);
         HIP_TRY(hipGetLastError());
     }
-    static thread_local int h_local[SORT_KEYS + 2];
-    HIP_TRY(hipMemcpyAsync(h_local, offs, (SORT_KEYS + 1) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(h_local + SORT_KEYS + 1, maxq, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int mq = host_maxq;
+    if (mq < 0) {
+        int h_mq = 0;
+        HIP_TRY(hipMemcpyAsync(&h_mq, maxq, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        mq = h_mq;
+    }
+    if (mq < 1) mq = 1;
     if (use_lane) {
-        // ---- lane-per-pair kernel, one launch per LDS size class (pairs are sorted by query length) ----------------------
+        // ---- lane-per-pair kernel, one launch per LDS size class (pairs are sorted by query length); a class finds its
+        // range in the device-side scan and leaves at once when it is empty
         int qlo = 0;
         for (int c = 0; c < N_LANE_CLS; ++c) {
             const int qhi = LANE_CLS_Q[c];                       // class = query lengths [qlo, qhi]
-            const int first = h_local[QKEY(qlo)], last = h_local[QKEY(qhi + 1)];
-            qlo = qhi + 1;
-            if (last <= first) continue;
             LaneArgs L;
-            L.pairs = d_pairs; L.ref = d_ref; L.qer = d_qer; L.order = order; L.first = first; L.count = last - first;
+            L.pairs = d_pairs; L.ref = d_ref; L.qer = d_qer; L.order = order; L.first = 0; L.count = 0;
             L.w = w; L.o = *opt; L.ticket = tickets + c;
+            L.offs = offs; L.key_first = QKEY(qlo); L.key_last = QKEY(qhi + 1);
+            qlo = qhi + 1;
+            if (host_maxq >= 0 && L.key_first > QKEY(host_maxq) ) continue;    // no query of the batch is that long
             const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            i64 want = ((i64)L.count + 63) / 64;
+            i64 want = ((i64)npairs + 63) / 64;
             i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 16;
             if (blocks > want) blocks = want;
             hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
@@ -562,30 +573,32 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     // ---- lanes-per-pair kernel: the pairs the lane kernel cannot take (long queries, scores beyond 14 bits), or the whole
     // batch when it is small; 16 / 32 / 64 lanes per pair by query length (4 / 2 / 1 pairs per wavefront)
     {
-        const int rest0 = use_lane ? h_local[SORT_KEYS - 1] : 0, total = h_local[SORT_KEYS];
-        const int mq = h_local[SORT_KEYS + 1] < 1 ? 1 : h_local[SORT_KEYS + 1];
-        const int cut16 = use_lane ? rest0 : h_local[QKEY(17)], cut32 = use_lane ? rest0 : h_local[QKEY(33)];
         BswArgs A;
-        A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0;
-        if (cut16 > rest0) {
-            A.order = order + rest0; A.npairs = cut16 - rest0; A.ticket = tickets + N_LANE_CLS;
+        A.pairs = d_pairs; A.ref = d_ref; A.qer = d_qer; A.w = w; A.o = *opt; A.qmax = 0; A.order = order; A.npairs = npairs;
+        A.offs = offs;
+        if (!use_lane) {
+            A.key_first = 0; A.key_last = QKEY(17); A.ticket = tickets + N_LANE_CLS;
             if ((rc = launch_cls<16>(ctx, A, 16, dev_cus))) return rc;
+            if (mq > 16) {
+                A.key_first = QKEY(17); A.key_last = QKEY(33); A.ticket = tickets + N_LANE_CLS + 1;
+                if ((rc = launch_cls<32>(ctx, A, 32, dev_cus))) return rc;
+            }
         }
-        if (cut32 > cut16) {
-            A.order = order + cut16; A.npairs = cut32 - cut16; A.ticket = tickets + N_LANE_CLS + 1;
-            if ((rc = launch_cls<32>(ctx, A, 32, dev_cus))) return rc;
-        }
-        if (total > cut32) {
-            A.order = order + cut32; A.npairs = total - cut32; A.ticket = tickets + N_LANE_CLS + 2;
+        if (use_lane || mq > 32) {
+            A.key_first = use_lane ? SORT_KEYS - 1 : QKEY(33); A.key_last = SORT_KEYS; A.ticket = tickets + N_LANE_CLS + 2;
             if ((rc = launch_cls<64>(ctx, A, ((mq + 63) / 64) * 64, dev_cus))) return rc;
         }
     }
     HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->tm.bsw_launches = 1;
+    return MEME_OK;
+}
+
+int finish_bsw(meme_ctx* ctx) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
     ctx->tm.bsw_kernel_ms = ms;
-    ctx->tm.bsw_launches = 1;
     return MEME_OK;
 }
 
@@ -596,7 +609,9 @@ extern "C" int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const
     if (!ctx || !d_pairs || !d_ref || !d_qer || !opt || npairs < 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (npairs == 0) return MEME_OK;
-    return launch_bsw(ctx, d_pairs, d_ref, d_qer, npairs, w, opt);
+    int rc = launch_bsw(ctx, d_pairs, d_ref, d_qer, npairs, w, opt, -1);
+    if (rc) return rc;
+    return finish_bsw(ctx);
 }
 
 extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t* ref_buf, int64_t ref_bytes,
@@ -604,6 +619,7 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
     if (!ctx || !pairs || !ref_buf || !qer_buf || !opt || npairs < 0 || ref_bytes < 0 || qer_bytes < 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (npairs == 0) return MEME_OK;
+    int maxq = 0;
     for (int i = 0; i < npairs; ++i) {
         const meme_seqpair& p = pairs[i];
         if (p.len1 < 0 || p.len2 < 0 || p.idr < 0 || p.idq < 0 || (int64_t)p.idr + p.len1 > ref_bytes ||
@@ -611,6 +627,7 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
             meme_set_error("pair %d addresses bytes outside the sequence buffers", i);
             return MEME_E_ARG;
         }
+        maxq = p.len2 > maxq ? p.len2 : maxq;
     }
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->pairs, (size_t)npairs * sizeof(meme_seqpair)))) return rc;
@@ -619,10 +636,10 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
     HIP_TRY(hipMemcpyAsync(ctx->pairs.p, pairs, (size_t)npairs * sizeof(meme_seqpair), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->refb.p, ref_buf, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->qerb.p, qer_buf, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // one host synchronisation per call: the class ranges stay on the device (the host knows the longest query)
     rc = launch_bsw(ctx, (meme_seqpair*)ctx->pairs.p, (const uint8_t*)ctx->refb.p, (const uint8_t*)ctx->qerb.p, npairs, w,
-                    opt);
+                    opt, maxq);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(pairs, ctx->pairs.p, (size_t)npairs * sizeof(meme_seqpair), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return MEME_OK;
+    return finish_bsw(ctx);
 }

@@ -59,6 +59,7 @@ extern "C" meme_ctx* meme_ctx_create(int device) {
     if (hipSetDevice(device) != hipSuccess) { meme_set_error("hipSetDevice(%d) failed", device); return nullptr; }
     meme_ctx* ctx = new meme_ctx();
     ctx->device = device;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount; }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         meme_set_error("hipStreamCreate failed");
         delete ctx;
@@ -80,7 +81,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
+    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->slots[3], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
                       &ctx->packed, &ctx->bsw_order};
@@ -113,10 +114,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
-    else if (!strcmp(key, "group_lanes")) {
-        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) { meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG; }
-        ctx->group_lanes = value;
-    } else if (!strcmp(key, "seed_blocks_per_cu")) ctx->seed_blocks_per_cu = value < 1 ? 1 : value;
+    else if (!strcmp(key, "seed_waves_per_cu")) ctx->seed_waves_per_cu = value < 0 ? 0 : value;
     else { meme_set_error("unknown tuning key %s", key); return MEME_E_ARG; }
     return MEME_OK;
 }
@@ -125,6 +123,9 @@ static unsigned stage_blocks(i64 items);
 extern "C" int meme_index_share(meme_ctx* ctx, meme_ctx* owner);
 // ---- staging kernels ---------------------------------------------------------------------------------
 extern "C" int64_t meme_index_pac64_words(int64_t sa_num) { return ((sa_num + 31) >> 5) + 8; }
+extern "C" int64_t meme_index_key_words(int64_t sa_num) { return ((sa_num + 15) & ~(int64_t)15) + 16; }
+extern "C" int64_t meme_index_pos5_bytes(int64_t sa_num) { return sa_num * 5 + 16; }
+extern "C" int64_t meme_index_special_bytes(void) { return (int64_t)SPECIAL_SLOTS * 4; }
 
 // one thread per output word: 32 text bytes -> one u64, first base in the top bits; T past the end
 __global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ text, i64 n, u64* __restrict__ pac, i64 words) {
@@ -153,19 +154,46 @@ __global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ t
   }
 }
 
-__global__ void __launch_bounds__(256) k_build_entries(const uint8_t* __restrict__ pos_packed, const u64* __restrict__ sa_u64,
-                                                        i64 n, const u64* __restrict__ pac, SaEnt* __restrict__ ent) {
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
-    u64 pos;
-    if (sa_u64) pos = sa_u64[i];
-    else {
-        const uint8_t* p = pos_packed + i * 5;   // u32 LE (pos >> 8) then u8 (pos & 0xff)
-        pos = ((u64)p[0] << 8) | ((u64)p[1] << 16) | ((u64)p[2] << 24) | ((u64)p[3] << 32) | (u64)p[4];
+// key array + the hash set of "special" window lines, from the 5-byte position image (replaces the OpenMP expansion loop
+// of src/fastmap.cpp:549-613: 13-byte entries + inverse suffix array on the host)
+__global__ void __launch_bounds__(256) k_build_keys(const uint8_t* __restrict__ pos5, i64 n, i64 key_words, const u64* __restrict__ pac,
+                                                     u64* __restrict__ keys, uint32_t* __restrict__ special) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < key_words; i += (i64)gridDim.x * blockDim.x) {
+    u64 key = ~0ull;
+    if (i < n) {
+        const u64 pos = load_pos5(pos5, i);
+        key = extract32(pac, (i64)pos);   // the pad words make this "T-filled past the text end"
+        if ((i64)pos > n - SPECIAL_SPAN) {
+            const uint32_t line = (uint32_t)(i >> 4);
+            uint32_t h = (line * 2654435761u) >> 20;
+            for (;;) {
+                const uint32_t old = atomicCAS(&special[h], 0u, line + 1u);
+                if (old == 0u || old == line + 1u) break;
+                h = (h + 1u) & (uint32_t)(SPECIAL_SLOTS - 1);
+            }
+        }
     }
-    SaEnt e;
-    e.key = extract32(pac, (i64)pos);   // the pad words make this "T-filled past the text end"
-    e.pos = pos;
-    ent[i] = e;
+    keys[i] = key;
+  }
+}
+
+// 8-byte suffix array -> the 5-byte on-disk image (hosts that hold the array as u64, e.g. bench.py's builder)
+__global__ void __launch_bounds__(256) k_pos5_from_sa(const u64* __restrict__ sa, i64 n, uint8_t* __restrict__ pos5) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const u64 pos = sa[i];
+    uint8_t* p = pos5 + i * 5;
+    const uint32_t hi = (uint32_t)(pos >> 8);
+    p[0] = (uint8_t)hi; p[1] = (uint8_t)(hi >> 8); p[2] = (uint8_t)(hi >> 16); p[3] = (uint8_t)(hi >> 24); p[4] = (uint8_t)(pos & 0xff);
+  }
+}
+
+// 24-byte on-disk P-RMI records -> 32-byte records (a lookup never straddles a 128-byte line)
+__global__ void __launch_bounds__(256) k_rmi32(const RmiRec* __restrict__ in, i64 n, Rmi32* __restrict__ out) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const RmiRec r = in[i];
+    Rmi32 o;
+    o.icpt = r.icpt; o.slope = r.slope; o.err = r.err; o.pad = 0;
+    out[i] = o;
   }
 }
 
@@ -179,22 +207,31 @@ extern "C" int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text, int64_
     return MEME_OK;
 }
 
-extern "C" int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t n, const void* d_pac64,
-                                        void* d_sa_ent) {
-    if (!ctx || !d_pos_packed || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
+extern "C" int meme_stage_build_keys(meme_ctx* ctx, const uint8_t* d_pos5, int64_t n, const void* d_pac64, void* d_keys,
+                                     void* d_special) {
+    if (!ctx || !d_pos5 || !d_pac64 || !d_keys || !d_special || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream, d_pos_packed,
-                       (const u64*)nullptr, n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
+    HIP_TRY(hipMemsetAsync(d_special, 0, (size_t)SPECIAL_SLOTS * 4, ctx->stream));
+    const i64 kw = meme_index_key_words(n);
+    hipLaunchKernelGGL(k_build_keys, dim3(stage_blocks(kw)), dim3(256), 0, ctx->stream, d_pos5, (i64)n, kw,
+                       (const u64*)d_pac64, (u64*)d_keys, (uint32_t*)d_special);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
 }
 
-extern "C" int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t n, const void* d_pac64,
-                                          void* d_sa_ent) {
-    if (!ctx || !d_sa || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
+extern "C" int meme_stage_pos5_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t n, void* d_pos5) {
+    if (!ctx || !d_sa || !d_pos5 || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream,
-                       (const uint8_t*)nullptr, (const u64*)d_sa, n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
+    hipLaunchKernelGGL(k_pos5_from_sa, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream, (const u64*)d_sa, (i64)n, (uint8_t*)d_pos5);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
+extern "C" int meme_stage_rmi32(meme_ctx* ctx, const void* d_rmi24, int64_t records, void* d_rmi32) {
+    if (!ctx || !d_rmi32 || records < 0 || (records > 0 && !d_rmi24)) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (records == 0) return MEME_OK;
+    hipLaunchKernelGGL(k_rmi32, dim3(stage_blocks(records)), dim3(256), 0, ctx->stream, (const RmiRec*)d_rmi24, (i64)records, (Rmi32*)d_rmi32);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
 }
@@ -228,6 +265,13 @@ static void drop_index(meme_ctx* ctx) {
     ctx->idx = DevIndex();
 }
 
+static int own_alloc(meme_ctx* ctx, void** p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes));
+    ctx->owned.push_back({*p, bytes});
+    ctx->owns_index = true;
+    return MEME_OK;
+}
+
 extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t n, const uint8_t* text,
                                     const void* l1, int64_t l1_bytes, const void* l2, int64_t l2_bytes) {
     if (!ctx || !pos_packed || !text || !l2 || n < 64 || l2_bytes < 24 || l2_bytes % 24 || l1_bytes % 24) {
@@ -238,35 +282,42 @@ extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, in
     drop_index(ctx);
     int rc = set_rmi(ctx, l2_bytes / 24, l1_bytes / 24);
     if (rc) return rc;
-    i64 words = meme_index_pac64_words(n);
-    void *d_ent = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_tmp = nullptr;
-    HIP_TRY(hipMalloc(&d_ent, (size_t)n * sizeof(SaEnt)));
-    ctx->owned.push_back({d_ent, (size_t)n * sizeof(SaEnt)});
-    ctx->owns_index = true;
-    HIP_TRY(hipMalloc(&d_pac, (size_t)words * 8));
-    ctx->owned.push_back({d_pac, (size_t)words * 8});
-    HIP_TRY(hipMalloc(&d_l2, (size_t)l2_bytes));
-    ctx->owned.push_back({d_l2, (size_t)l2_bytes});
-    HIP_TRY(hipMalloc(&d_l1, (size_t)(l1_bytes > 0 ? l1_bytes : 24)));
-    ctx->owned.push_back({d_l1, (size_t)(l1_bytes > 0 ? l1_bytes : 24)});
-    // staging buffer: the larger of the two images, reused
-    size_t tmp_bytes = (size_t)n * 5 + 64;
+    const i64 words = meme_index_pac64_words(n), kw = meme_index_key_words(n);
+    const i64 n_l2 = l2_bytes / 24, n_l1 = l1_bytes / 24;
+    void *d_keys = nullptr, *d_pos5 = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_spec = nullptr, *d_tmp = nullptr;
+    if ((rc = own_alloc(ctx, &d_keys, (size_t)kw * 8))) return rc;
+    if ((rc = own_alloc(ctx, &d_pos5, (size_t)meme_index_pos5_bytes(n)))) return rc;
+    if ((rc = own_alloc(ctx, &d_pac, (size_t)words * 8))) return rc;
+    if ((rc = own_alloc(ctx, &d_l2, (size_t)n_l2 * 32))) return rc;
+    if ((rc = own_alloc(ctx, &d_l1, (size_t)(n_l1 > 0 ? n_l1 : 1) * 32))) return rc;
+    if ((rc = own_alloc(ctx, &d_spec, (size_t)SPECIAL_SLOTS * 4))) return rc;
+    // staging buffer for the text bytes and the 24-byte parameter records
+    size_t tmp_bytes = (size_t)n + 64;
+    if ((size_t)l2_bytes > tmp_bytes) tmp_bytes = (size_t)l2_bytes;
+    if ((size_t)l1_bytes > tmp_bytes) tmp_bytes = (size_t)l1_bytes;
     HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
-    HIP_TRY(hipMemcpyAsync(d_tmp, text, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac);
-    if (rc) { (void)hipFree(d_tmp); return rc; }
-    HIP_TRY(hipMemcpyAsync(d_tmp, pos_packed, (size_t)n * 5, hipMemcpyHostToDevice, ctx->stream));
-    rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent);
-    if (rc) { (void)hipFree(d_tmp); return rc; }
-    HIP_TRY(hipMemcpyAsync(d_l2, l2, (size_t)l2_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (l1_bytes > 0) HIP_TRY(hipMemcpyAsync(d_l1, l1, (size_t)l1_bytes, hipMemcpyHostToDevice, ctx->stream));
+    auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d_tmp); return code; };
+    if (hipMemcpyAsync(d_tmp, text, (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac))) return fail(rc);
+    if (hipMemcpyAsync(d_pos5, pos_packed, (size_t)n * 5, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if (hipMemsetAsync((uint8_t*)d_pos5 + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = meme_stage_build_keys(ctx, (const uint8_t*)d_pos5, n, d_pac, d_keys, d_spec))) return fail(rc);
+    if (hipMemcpyAsync(d_tmp, l2, (size_t)l2_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l2, d_l2))) return fail(rc);
+    if (n_l1 > 0) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);   // d_tmp is reused
+        if (hipMemcpyAsync(d_tmp, l1, (size_t)l1_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+        if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l1, d_l1))) return fail(rc);
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_tmp));
     ctx->idx.n = n;
-    ctx->idx.sa = (const SaEnt*)d_ent;
+    ctx->idx.keys = (const u64*)d_keys;
+    ctx->idx.pos5 = (const uint8_t*)d_pos5;
     ctx->idx.pac = (const u64*)d_pac;
-    ctx->idx.l2 = (const RmiRec*)d_l2;
-    ctx->idx.l1 = (const RmiRec*)d_l1;
+    ctx->idx.l2 = (const Rmi32*)d_l2;
+    ctx->idx.l1 = (const Rmi32*)d_l1;
+    ctx->idx.special = (const uint32_t*)d_spec;
     return MEME_OK;
 }
 
@@ -300,28 +351,32 @@ extern "C" int meme_index_load_files(meme_ctx* ctx, const char* prefix) {
 }
 
 extern "C" int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* a) {
-    if (!ctx || !a || !a->d_sa_ent || !a->d_pac64 || !a->d_l2 || a->sa_num < 64) return MEME_E_ARG;
+    if (!ctx || !a || !a->d_keys || !a->d_pos5 || !a->d_pac64 || !a->d_l2 || !a->d_special || a->sa_num < 64) return MEME_E_ARG;
     drop_index(ctx);
     int rc = set_rmi(ctx, a->l2_records, a->l1_records);
     if (rc) return rc;
     ctx->idx.n = a->sa_num;
-    ctx->idx.sa = (const SaEnt*)a->d_sa_ent;
+    ctx->idx.keys = (const u64*)a->d_keys;
+    ctx->idx.pos5 = (const uint8_t*)a->d_pos5;
     ctx->idx.pac = (const u64*)a->d_pac64;
-    ctx->idx.l2 = (const RmiRec*)a->d_l2;
-    ctx->idx.l1 = (const RmiRec*)a->d_l1;
+    ctx->idx.l2 = (const Rmi32*)a->d_l2;
+    ctx->idx.l1 = (const Rmi32*)a->d_l1;
+    ctx->idx.special = (const uint32_t*)a->d_special;
     return MEME_OK;
 }
 
 extern "C" int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out) {
     if (!ctx || !out) return MEME_E_ARG;
-    if (!ctx->idx.sa) { meme_set_error("no index loaded"); return MEME_E_STATE; }
+    if (!ctx->idx.keys) { meme_set_error("no index loaded"); return MEME_E_STATE; }
     out->sa_num = ctx->idx.n;
-    out->d_sa_ent = (void*)ctx->idx.sa;
+    out->d_keys = (void*)ctx->idx.keys;
+    out->d_pos5 = (void*)ctx->idx.pos5;
     out->d_pac64 = (void*)ctx->idx.pac;
     out->d_l2 = (void*)ctx->idx.l2;
     out->l2_records = ctx->idx.n_l2;
     out->d_l1 = (void*)ctx->idx.l1;
     out->l1_records = ctx->idx.n_l1;
+    out->d_special = (void*)ctx->idx.special;
     return MEME_OK;
 }
 
@@ -330,25 +385,26 @@ extern "C" int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out) {
 // reference's kt_for threads).
 extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
     if (!dst || !src || dst == src) return MEME_E_ARG;
-    if (!src->idx.sa) { meme_set_error("meme_index_replicate: source has no index"); return MEME_E_STATE; }
+    if (!src->idx.keys) { meme_set_error("meme_index_replicate: source has no index"); return MEME_E_STATE; }
     if (dst->device == src->device) return meme_index_share(dst, src);
     if (!src->owns_index) { meme_set_error("meme_index_replicate: the source ctx must own its index (load_host / load_files)"); return MEME_E_STATE; }
     HIP_TRY(hipSetDevice(dst->device));
     drop_index(dst);
     int can = 0;
     (void)hipDeviceCanAccessPeer(&can, dst->device, src->device);
-    if (can) { hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0; (void)hipGetLastError(); }
+    if (can) { hipError_t e = hipDeviceEnablePeerAccess(src->device, 0); (void)e; (void)hipGetLastError(); }
     DevIndex I = src->idx;
-    dst->owns_index = true;
     for (auto& o : src->owned) {
         void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, o.second));
-        dst->owned.push_back({d, o.second});
+        int rc = own_alloc(dst, &d, o.second);
+        if (rc) return rc;
         HIP_TRY(hipMemcpyPeerAsync(d, dst->device, o.first, src->device, o.second, dst->stream));
-        if ((const void*)I.sa == o.first) I.sa = (const SaEnt*)d;
+        if ((const void*)I.keys == o.first) I.keys = (const u64*)d;
+        if ((const void*)I.pos5 == o.first) I.pos5 = (const uint8_t*)d;
         if ((const void*)I.pac == o.first) I.pac = (const u64*)d;
-        if ((const void*)I.l2 == o.first) I.l2 = (const RmiRec*)d;
-        if ((const void*)I.l1 == o.first) I.l1 = (const RmiRec*)d;
+        if ((const void*)I.l2 == o.first) I.l2 = (const Rmi32*)d;
+        if ((const void*)I.l1 == o.first) I.l1 = (const Rmi32*)d;
+        if ((const void*)I.special == o.first) I.special = (const uint32_t*)d;
     }
     HIP_TRY(hipStreamSynchronize(dst->stream));
     dst->idx = I;
@@ -357,7 +413,7 @@ extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
 
 extern "C" int meme_index_share(meme_ctx* ctx, meme_ctx* owner) {
     if (!ctx || !owner || ctx->device != owner->device) return MEME_E_ARG;
-    if (!owner->idx.sa) { meme_set_error("owner has no index"); return MEME_E_STATE; }
+    if (!owner->idx.keys) { meme_set_error("owner has no index"); return MEME_E_STATE; }
     drop_index(ctx);
     ctx->idx = owner->idx;
     return MEME_OK;

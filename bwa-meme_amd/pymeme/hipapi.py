@@ -27,8 +27,14 @@ class BswOpt(C.Structure):
 
 
 class IndexArrays(C.Structure):
-    _fields_ = [("sa_num", C.c_int64), ("d_sa_ent", C.c_void_p), ("d_pac64", C.c_void_p), ("d_l2", C.c_void_p),
-                ("l2_records", C.c_int64), ("d_l1", C.c_void_p), ("l1_records", C.c_int64)]
+    _fields_ = [("sa_num", C.c_int64), ("d_keys", C.c_void_p), ("d_pos5", C.c_void_p), ("d_pac64", C.c_void_p),
+                ("d_l2", C.c_void_p), ("l2_records", C.c_int64), ("d_l1", C.c_void_p), ("l1_records", C.c_int64),
+                ("d_special", C.c_void_p)]
+
+
+class SeedHostResult(C.Structure):
+    _fields_ = [("smems", C.c_void_p), ("smem_off", C.c_void_p), ("hits", C.c_void_p), ("hit_off", C.c_void_p),
+                ("total_smems", C.c_int64), ("total_hits", C.c_int64)]
 
 
 class SeedResult(C.Structure):
@@ -40,14 +46,16 @@ class SeedResult(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("seed_kernel_ms", C.c_float), ("seed_gather_ms", C.c_float), ("bsw_kernel_ms", C.c_float),
                 ("seed_launches", C.c_int64), ("bsw_launches", C.c_int64), ("seed_pack_ms", C.c_float),
-                ("seed_windows", C.c_int64)]
+                ("seed_windows", C.c_int64), ("seed_text_compares", C.c_int64)]
 
 
 # every symbol include/meme_hip.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_last_error", "meme_ctx_sync",
            "meme_ctx_stream", "meme_index_load_host", "meme_index_load_files", "meme_index_pac64_words",
-           "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_stage_pack_text",
-           "meme_stage_build_entries", "meme_stage_entries_from_sa", "meme_seed_batch", "meme_seed_batch_device",
+           "meme_index_key_words", "meme_index_pos5_bytes", "meme_index_special_bytes",
+           "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
+           "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_keys",
+           "meme_stage_rmi32", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -77,8 +85,14 @@ def lib():
         L.meme_last_error.restype = C.c_char_p
         L.meme_ctx_stream.restype = C.c_void_p
         L.meme_ctx_stream.argtypes = [C.c_void_p]
-        L.meme_index_pac64_words.restype = C.c_int64
-        L.meme_index_pac64_words.argtypes = [C.c_int64]
+        for f in ("meme_index_pac64_words", "meme_index_key_words", "meme_index_pos5_bytes"):
+            getattr(L, f).restype = C.c_int64
+            getattr(L, f).argtypes = [C.c_int64]
+        L.meme_index_special_bytes.restype = C.c_int64
+        L.meme_host_alloc.restype = C.c_void_p
+        L.meme_host_alloc.argtypes = [C.c_int64]
+        L.meme_host_free.argtypes = [C.c_void_p]
+        L.meme_host_free.restype = None
         _lib = L
     return _lib
 
@@ -174,6 +188,24 @@ class Context:
             _check(rc)
             return smems[:ts.value], smem_off, hits[:th.value], hit_off
 
+    def seed_batch_host(self, reads, read_off, opt=None):
+        """meme_seed_batch_host: results come back in pinned buffers owned by the ctx (copied out here)."""
+        opt = opt or default_seed_opt()
+        reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        n = read_off.shape[0] - 1
+        res = SeedHostResult()
+        _check(lib().meme_seed_batch_host(C.c_void_p(self.h), _p(reads), _p(read_off), C.c_int64(n), C.byref(opt),
+                                          C.byref(res)))
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return (view(res.smems, res.total_smems, MEM_TL), view(res.smem_off, n + 1, np.int64),
+                view(res.hits, res.total_hits, np.uint64), view(res.hit_off, n + 1, np.int64))
+
     def seed_batch_device(self, d_reads_ptr, d_read_off_ptr, nreads, total_bases, opt=None) -> SeedResult:
         opt = opt or default_seed_opt()
         res = SeedResult()
@@ -209,3 +241,38 @@ def smems_to_slots(smems, smem_off, hits, hit_off, smem_cap=None):
         out[r, :k] = smems[smem_off[r]:smem_off[r + 1]]
         hl.append(hits[hit_off[r]:hit_off[r + 1]])
     return out, counts.astype(np.int32), hl
+
+
+def stage_index_torch(ctx, n, d_text, d_pos5, d_l2_24, n_l2, d_l1_24, n_l1):
+    """Multi-GPU / bench start-up: the raw images (text0123 bytes, 5-byte position image, 24-byte P-RMI records) are
+    already in HBM as torch uint8 tensors (uploaded, or received through an RCCL broadcast); run the staging kernels
+    into torch-owned buffers and attach them.  Returns the tensors that must outlive the ctx."""
+    import torch
+    L = lib()
+    dev = d_text.device
+    d_pac = torch.empty(L.meme_index_pac64_words(n), dtype=torch.int64, device=dev)
+    d_keys = torch.empty(L.meme_index_key_words(n), dtype=torch.int64, device=dev)
+    d_l2 = torch.empty(n_l2 * 32, dtype=torch.uint8, device=dev)
+    d_l1 = torch.empty(max(n_l1, 1) * 32, dtype=torch.uint8, device=dev)
+    d_spec = torch.empty(L.meme_index_special_bytes(), dtype=torch.uint8, device=dev)
+    h = C.c_void_p(ctx.h)
+    _check(L.meme_stage_pack_text(h, C.c_void_p(d_text.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr())))
+    _check(L.meme_stage_build_keys(h, C.c_void_p(d_pos5.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr()),
+                                   C.c_void_p(d_keys.data_ptr()), C.c_void_p(d_spec.data_ptr())))
+    _check(L.meme_stage_rmi32(h, C.c_void_p(d_l2_24.data_ptr()), C.c_int64(n_l2), C.c_void_p(d_l2.data_ptr())))
+    _check(L.meme_stage_rmi32(h, C.c_void_p(d_l1_24.data_ptr()), C.c_int64(n_l1), C.c_void_p(d_l1.data_ptr())))
+    ctx.sync()
+    ctx.attach_index(IndexArrays(n, d_keys.data_ptr(), d_pos5.data_ptr(), d_pac.data_ptr(), d_l2.data_ptr(), n_l2,
+                                 d_l1.data_ptr(), n_l1, d_spec.data_ptr()))
+    return d_pac, d_keys, d_l2, d_l1, d_spec, d_pos5
+
+
+def pos5_from_sa_torch(ctx, d_sa, n):
+    """u64 suffix array in HBM -> the 5-byte .pos_packed image (torch uint8 tensor)."""
+    import torch
+    L = lib()
+    d_pos5 = torch.zeros(L.meme_index_pos5_bytes(n), dtype=torch.uint8, device=d_sa.device)
+    _check(L.meme_stage_pos5_from_sa(C.c_void_p(ctx.h), C.c_void_p(d_sa.data_ptr()), C.c_int64(n),
+                                     C.c_void_p(d_pos5.data_ptr())))
+    ctx.sync()
+    return d_pos5

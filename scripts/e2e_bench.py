@@ -9,7 +9,7 @@ import numpy as np
 from pymeme import hostapi, synth, workload
 mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 128
 npairs = int(float(sys.argv[2]) * 1e6) if len(sys.argv) > 2 else 1000000
-threads = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+threads = int(sys.argv[3]) if len(sys.argv) > 3 else min(256, os.cpu_count() or 64)
 log = lambda *a: print("[e2e]", *a, flush=True)
 d = tempfile.mkdtemp(prefix="e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 g = synth.make_genome(int(mbp * 1e6) & ~1, seed=11)
@@ -37,13 +37,13 @@ t0 = time.time(); fastq(r1, f1); fastq(r2, f2); log("fastq %.1f s" % (time.time(
 res = {}
 for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
     out = os.path.join(d, exe + ".sam")
-    env = dict(os.environ, MEME_INDEX_PREFIX=prefix)
+    env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1")
     t0 = time.time()
     with open(out, "wb") as fh:
         r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
     wall = time.time() - t0
     err = r.stderr.decode()
-    keys = [l for l in err.split("\n") if any(k in l for k in ("Runtime-build-index", "Total kernel", "LEARNED", "BSW time", "SAM Processing", "Overall time", "total time", "Loading"))]
+    keys = [l for l in err.split("\n") if any(k in l for k in ("Runtime-build-index", "Total kernel", "LEARNED", "BSW time", "SAM Processing", "Overall time", "total time", "Loading", "meme-dropin"))]
     h = hashlib.md5()
     nlines = 0
     with open(out, "rb") as fh:

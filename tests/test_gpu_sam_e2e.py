@@ -1,6 +1,6 @@
 """End-to-end acceptance test of the drop-in (the reference's own acceptance criterion, README.md:81-92):
 the reference aligner with seeding and extension interposed by the HIP backend (oracle/_ref/bwa-meme_dropin =
-reference main + libbwa_pic.so + oracle/ref_dropin_shim.cpp over include/meme_hip.h) must write the same SAM
+reference main + libbwa_pic.so + bwa-meme_amd/binding/meme_dropin.cpp over include/meme_hip.h) must write the same SAM
 as the unmodified reference binary (`mem -7`), apart from the @PG line that embeds the command line."""
 import os
 import subprocess
@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 REF = R.REF_DIR
 
 
-def _sam(exe, prefix, fqs, env=None, threads=4):
-    cmd = [os.path.join(REF, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads), prefix] + fqs
+def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000):
+    cmd = [os.path.join(REF, exe), "mem", "-7", "-Y", "-K", str(chunk), "-t", str(threads), prefix] + fqs
     r = subprocess.run(cmd, capture_output=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     return [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
@@ -49,11 +49,33 @@ def test_sam_identical_to_reference(tmp_path, paired):
         fqs.append(str(tmp_path / "r2.fq"))
         synth.write_fastq(fqs[1], r2, prefix="p")
     want = _sam("bwa-meme_mode3", prefix, fqs)
-    # the binding either combines the concurrent calls of the reference's workers into one backend call (default) or
-    # forwards every call on its own: same SAM both ways
-    for combine in ("1", "0"):
-        env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_COMBINE=combine)
-        got = _sam("bwa-meme_dropin", prefix, fqs, env=env)
-        assert len(got) == len(want) and len(want) > n
-        diff = [(a, b) for a, b in zip(got, want) if a != b]
-        assert not diff, "combine=%s, first differing SAM line:\n%s\n%s" % ((combine,) + diff[0])
+    # chunk-level seeding + combined extension calls: the SAM must not depend on how many worker threads feed the
+    # combiner, nor on the -K chunk size (several chunks per run, the last one ragged)
+    for threads, chunk in ((4, 100000000), (16, 400000)):
+        env = dict(os.environ, MEME_INDEX_PREFIX=prefix)
+        got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
+        ref = want if chunk == 100000000 else _sam("bwa-meme_mode3", prefix, fqs, threads=threads, chunk=chunk)
+        assert len(got) == len(ref) and len(ref) > n
+        diff = [(a, b) for a, b in zip(got, ref) if a != b]
+        assert not diff, "threads=%d chunk=%d, first differing SAM line:\n%s\n%s" % ((threads, chunk) + diff[0])
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
+    """BASELINE.json configs[0]: an E. coli K-12 sized reference (4.64 Mbp, one contig) and 100 k synthetic 150-bp
+    single-end reads through `mem -7`: SAM diff == empty."""
+    g = synth.make_genome(4_641_652, seed=7, repeat_frac=0.03, n_families=8, n_dups=7, dup_len=1200)
+    fa = str(tmp_path / "ecoli_sized.fa")
+    synth.write_fasta(fa, g, contigs=1)
+    prefix = build_index(fa, bits=18, threads=min(32, os.cpu_count() or 4))
+    n = 100_000
+    r1, _, _ = synth.make_reads(g, n, 150, seed=8, n_frac=0.01, exact_frac=0.2)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, r1, prefix="e")
+    threads = min(32, os.cpu_count() or 4)
+    want = _sam("bwa-meme_mode3", prefix, [fq], threads=threads)
+    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix), threads=threads)
+    assert len(got) == len(want) and len(want) > n
+    diff = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]

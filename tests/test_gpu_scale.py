@@ -1,0 +1,73 @@
+"""Parity at the size the headline number is quoted on: an index of more than 2^32 suffixes (64-bit slot arithmetic in
+the search kernel, grid-stride staging kernels, the 5-byte position image above 4 G entries), full seed dump against
+the pinned oracle.  Takes a few minutes: the suffix array of 4.3 G suffixes is built on the host first."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from pymeme import hipapi, hostapi, synth, workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _enough_memory():
+    try:
+        import psutil
+        return psutil.virtual_memory().available > 300e9
+    except ImportError:
+        return True
+
+
+@pytest.mark.skipif(os.environ.get("MEME_SKIP_SCALE_TEST") == "1" or not _enough_memory(),
+                    reason="needs ~300 GB of host memory for the suffix-array builder")
+def test_seeds_equal_oracle_above_2_pow_32_suffixes():
+    import torch
+    l_pac = 2_150_000_000
+    n = 2 * l_pac
+    assert n > 1 << 32
+    g = synth.make_genome(l_pac, seed=11)
+    text, sa = hostapi.build_sa(g)
+    l1, l2 = hostapi.train_prmi(text, sa, bits=24)
+    dev = torch.device("cuda", 0)
+    ctx = hipapi.Context(0)
+    try:
+        d_text = torch.from_numpy(text).to(dev)
+        d_sa = torch.from_numpy(sa.view(np.int64)).to(dev)
+        d_pos5 = hipapi.pos5_from_sa_torch(ctx, d_sa, n)
+        # the 5-byte image equals the reference's on-disk encoding, also above 2^32 entries
+        for lo in (0, (1 << 32) - 500, n - 1000):
+            chunk = d_pos5[lo * 5:(lo + 1000) * 5].cpu().numpy().reshape(-1, 5)
+            pos = (chunk[:, :4].copy().view("<u4")[:, 0].astype(np.uint64) << np.uint64(8)) | chunk[:, 4].astype(np.uint64)
+            assert np.array_equal(pos, sa[lo:lo + 1000]), lo
+        del d_sa
+        torch.cuda.empty_cache()
+        d_l2 = torch.from_numpy(l2.view(np.uint8).reshape(-1)).to(dev)
+        d_l1 = torch.zeros(max(l1.shape[0], 1) * 24, dtype=torch.uint8, device=dev)
+        if l1.shape[0]:
+            d_l1[:l1.shape[0] * 24].copy_(torch.from_numpy(np.ascontiguousarray(l1).view(np.uint8).reshape(-1)))
+        keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, l2.shape[0], d_l1, l1.shape[0])
+        d_keys = keep[1]
+        # keys: sorted, and the first 32 bases of the suffix each slot points to (sampled around 2^32 and at the ends)
+        tp = np.concatenate([text[-64:], np.full(64, 3, np.uint8)])
+        for lo in (0, (1 << 32) - 500, n - 1000):
+            k = d_keys[lo:lo + 1000].cpu().numpy().view(np.uint64)
+            assert np.all(k[1:] >= k[:-1]), lo
+            for i in (0, 499, 999):
+                p = int(sa[lo + i])
+                s32 = text[p:p + 32] if p + 32 <= n else np.concatenate([text[p:], np.full(32 - (n - p), 3, np.uint8)])
+                want = 0
+                for b in s32:
+                    want = (want << 2) | int(b & 3)
+                assert int(k[i]) == want, (lo, i)
+        idx = O.Index(text, sa)
+        for L, nreads, kw in ((150, 3000, {}), (250, 600, dict(sub_rate=0.05))):
+            reads = workload.make_reads_fast(g, nreads, L, seed=12 + L, **kw)
+            off = np.arange(0, (nreads + 1) * L, L, dtype=np.int64)
+            smems, so, hits, ho = ctx.seed_batch(reads, off)
+            slots, counts, hl = hipapi.smems_to_slots(smems, so, hits, ho)
+            sm, ns, oh, nh, _ = O.seed_batch(idx, reads, off, smem_cap=4096, hit_cap=1 << 17, threads=0)
+            assert O.format_seed_dump(slots, counts, hl) == O.format_seed_dump(sm, ns, oh), L
+    finally:
+        ctx.close()

@@ -38,18 +38,51 @@ def test_hip_seeds_equal_reference_golden(ctx, g1, length):
     assert _gpu_dump(ctx, reads, off) == want
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32])
-def test_hip_seeds_equal_golden_for_every_group_width(g1, lanes):
+@pytest.mark.parametrize("waves", [1, 4, 0])
+def test_hip_seeds_equal_golden_at_every_occupancy(g1, waves):
+    """Results must not depend on how many wavefronts share a CU (read hand-out order, ticket chunks)."""
     c = hipapi.Context(0)
     try:
         c.load_index_files(g1)
-        c.set_tuning("group_lanes", lanes)
+        c.set_tuning("seed_waves_per_cu", waves)
         for length in (150, 250, 60, 25):
             reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
             want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()
             assert _gpu_dump(c, reads, off) == want
     finally:
         c.close()
+
+
+def test_overflow_tiers_give_the_same_seeds(g1):
+    """With 8 SMEM slots per read in the first pass most 150/250-bp reads overflow and are re-run in the bigger tiers
+    (the pending / overflow-list ping-pong, slot locators of several tiers in one gather): same dump."""
+    c = hipapi.Context(0)
+    try:
+        c.load_index_files(g1)
+        c.set_tuning("smem_cap", 8)
+        for length in (150, 250):
+            reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
+            want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()
+            assert _gpu_dump(c, reads, off) == want
+            assert c.timings().seed_launches >= 2
+    finally:
+        c.close()
+
+
+def test_host_result_variant_equals_capacity_variant(ctx, g1):
+    reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_150.fq"))
+    a = ctx.seed_batch(reads, off)
+    b = ctx.seed_batch_host(reads, off)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_read_longer_than_500_bases_is_rejected(ctx, g1):
+    """The reference exits on such reads (src/bwamem.cpp:1259-1262); the backend fails the call, loudly."""
+    reads = np.zeros(150 + 501, np.uint8)
+    off = np.array([0, 150, 651], np.int64)
+    with pytest.raises(hipapi.MemeError, match="exceeds the learned-index limit"):
+        ctx.seed_batch(reads, off)
 
 
 @pytest.mark.parametrize("rounds", [1, 2, 3])
