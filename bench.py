@@ -14,10 +14,16 @@ Default workload = BASELINE.json configs[1]: a GRCh38-sized (3.1 Gbp) synthetic 
 suffix-array entries in HBM -- and 10 M synthetic 150-bp single-end reads per GPU per step, seeding only.  The index
 is built on the host (about 4-6 minutes on the 256-thread box) and cached in /dev/shm for the next invocation.
 
+Besides the headline line's `roofline` and `cpu_baseline` objects, rank 0 at N=1 adds `bsw` (the banded-SW kernel on 2 M
+distinct extension jobs) and `e2e` (BASELINE.json's second metric: paired-end `mem -7` through the reference aligner
+with the HIP backend bound in, next to the unmodified reference on the same host cores, SAM md5 compared).
+
 Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 3100), MEME_BENCH_READS (reads per GPU
 per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's rule),
-MEME_BENCH_WAVES (resident wavefronts per CU of the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the compiled
-reference up to 1 Gbp, the restated port above), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables).
+MEME_BENCH_WAVES (resident wavefronts per CU of the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the
+compiled reference, timed in this run), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables the /dev/shm caches),
+MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
+2,000,000), MEME_BENCH_BUDGET_S (wall budget in seconds after which optional legs are skipped, default 1500).
 """
 import argparse
 import json
@@ -39,6 +45,8 @@ import torch.distributed as dist  # noqa: E402
 from pymeme import hipapi, hostapi, synth, workload  # noqa: E402
 
 READ_LEN = 150
+BSW_VALU_PER_CELL = 35.0     # updated from profiles/r02_bsw.md (SQ_INSTS_VALU x 64 / DP cells of the bench's 2 M distinct pairs)
+T_START = time.time()
 
 
 def log(msg):
@@ -57,21 +65,39 @@ def fastq_bytes(reads: np.ndarray) -> np.ndarray:
     return row
 
 
-def cpu_baseline_reference(fwd, text, sa, l1, l2, reads, cores):
+def reference_index_on_disk(fwd, text, sa, l1, l2, l_pac, bits):
+    """The benchmark index in the reference's own file formats (what `bwa-meme index` + the trainer write), kept next to
+    the suffix-array cache in /dev/shm: the compiled reference binaries (cpu_baseline and e2e legs) load it from there."""
+    root = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d = os.path.join(root, "meme_bench_ref_%d_b%d" % (l_pac, bits))
+    prefix = os.path.join(d, "ref.fa")
+    if os.path.exists(os.path.join(d, "ok")):
+        return prefix
+    need = 7.3 * 2 * l_pac + 24.0 * l2.shape[0]
+    if shutil.disk_usage(root).free < 1.15 * need:
+        raise RuntimeError("not enough room in %s for the reference-format index (%.0f GB)" % (root, need / 1e9))
+    import glob
+    for old in glob.glob(os.path.join(root, "meme_bench_ref_*")):
+        if old != d:
+            shutil.rmtree(old, ignore_errors=True)
+    os.makedirs(d, exist_ok=True)
+    t0 = time.time()
+    hostapi.write_index(prefix, fwd, text, sa, l1, l2, n_contigs=4)
+    open(os.path.join(d, "ok"), "w").write("ok")
+    log("reference-format index written to %s in %.1f s" % (d, time.time() - t0))
+    return prefix
+
+
+def cpu_baseline_reference(prefix, reads, cores):
     """Times the COMPILED REFERENCE (oracle/_ref/learned_seeding_mode3 = test/Learned_seeding_big_read.cpp,
     MODE=3, AVX-512 build) on the same index and a sample of the same reads.  Measurement only."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_py as O
     exe = os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")
-    big = text.nbytes > (1 << 31)
-    tmp = tempfile.mkdtemp(prefix="meme_cpu_", dir="/dev/shm" if big and os.path.isdir("/dev/shm") else None)
+    tmp = tempfile.mkdtemp(prefix="meme_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
-        prefix = os.path.join(tmp, "ref.fa")
-        t0 = time.time()
-        hostapi.write_index(prefix, fwd, text, sa, l1, l2, n_contigs=4)
         fq = os.path.join(tmp, "sample.fq")
         fastq_bytes(reads).tofile(fq)
-        log("cpu_baseline: index + FASTQ written in %.1f s" % (time.time() - t0))
         hz = O.tsc_hz()
         t0 = time.time()
         env = dict(os.environ, OMP_NUM_THREADS=str(cores))
@@ -89,7 +115,8 @@ def cpu_baseline_reference(fwd, text, sa, l1, l2, reads, cores):
             % (reads.shape[0], cores, secs, wall))
         return {"value": reads.shape[0] / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
                 "sample": "%d of the benchmark's reads, same index; seeding region of test/Learned_seeding_big_read.cpp "
-                          "(MODE=3, AVX-512 build, steps=3) timed by its own rdtsc counter" % reads.shape[0]}
+                          "(MODE=3, AVX-512 build, steps=3) timed by its own rdtsc counter in this run" % reads.shape[0],
+                "process_wall_s": wall}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -120,12 +147,13 @@ def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
 
 def bsw_leg(ctx, dev, world):
     """Second kernel of the path: banded seed extension on rank 0's GPU, pairs resident in HBM.
-    Reported beside the headline metric: pairs/s, GCUPS (DP cells from the CPU restatement's counter) and the
-    CPU restatement on all host cores for the same pairs."""
+    Every pair is distinct (no tiling): lengths, targets and errors differ from pair to pair as in a real batch, so the
+    lanes of a wavefront diverge the way they do in production.  Reported beside the headline metric: pairs/s, GCUPS
+    (DP cells from the CPU restatement's counter on a sample) and the CPU restatement on all host cores."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_py
     npairs = int(os.environ.get("MEME_BENCH_BSW_PAIRS", "2000000"))
-    pairs, ref, qer, base = workload.make_bsw_pairs(npairs, seed=77, read_len=READ_LEN)
+    pairs, ref, qer = workload.make_bsw_pairs_distinct(npairs, seed=77, read_len=READ_LEN)
     d_pairs = torch.from_numpy(pairs.view(np.uint8)).to(dev)
     d_ref = torch.from_numpy(ref).to(dev)
     d_qer = torch.from_numpy(qer).to(dev)
@@ -137,28 +165,110 @@ def bsw_leg(ctx, dev, world):
         if it:
             ms.append(ctx.timings().bsw_kernel_ms)
     k_ms = float(np.mean(ms))
-    got = d_pairs.cpu().numpy().view(hipapi.SEQPAIR)[:base]
     # cells and the CPU figure from the restatement of scalarBandedSWA (the oracle): checker + baseline only
-    chk = pairs[:base].copy().view(oracle_py.SEQPAIR_DTYPE)
-    cells = oracle_py.bsw_batch(chk, ref, qer, 100, threads=0)
-    same = all(np.array_equal(got[f], chk[f]) for f in ("score", "tle", "gtle", "qle", "gscore", "max_off"))
-    reps = npairs / base
+    ns = min(npairs, 400000)
+    got = d_pairs.cpu().numpy().view(hipapi.SEQPAIR)[:ns]
+    chk = pairs[:ns].copy().view(oracle_py.SEQPAIR_DTYPE)
     cores = os.cpu_count() or 1
-    big = np.tile(pairs[:base], max(1, int(400000 // base)))
-    big_chk = big.copy().view(oracle_py.SEQPAIR_DTYPE)
     t0 = time.perf_counter()
-    oracle_py.bsw_batch(big_chk, ref, qer, 100, threads=cores)
+    cells = oracle_py.bsw_batch(chk, ref, qer, 100, threads=cores)
     cpu_dt = time.perf_counter() - t0
+    same = all(np.array_equal(got[f], chk[f]) for f in ("score", "tle", "gtle", "qle", "gscore", "max_off"))
+    cells_per_pair = cells / ns
+    gcups = cells_per_pair * npairs / (k_ms * 1e-3) / 1e9
     return {"metric": "bsw_pairs_per_sec", "value": npairs / (k_ms * 1e-3), "unit": "pairs/s", "per": "gpu",
-            "pairs": npairs, "band_w": 100, "kernel_ms": k_ms, "cells_per_pair": cells / base,
-            "gcups": cells * reps / (k_ms * 1e-3) / 1e9, "matches_oracle": bool(same),
-            # integer-VALU roofline of the lane-per-pair kernel: 35 VALU instructions per DP cell in its inner loop (ISA count),
-            # against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz int32 lane-ops/s
-            "roofline": {"bound": "valu-int32", "ops_per_cell": 35, "peak": 39.3, "unit": "Tops/s",
-                         "achieved": 35 * cells * reps / (k_ms * 1e-3) / 1e12,
-                         "frac": 35 * cells * reps / (k_ms * 1e-3) / 1e12 / 39.3},
-            "cpu_baseline": {"value": big.shape[0] / cpu_dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-                             "sample": "%d pairs, scalar restatement of scalarBandedSWA on %d threads" % (big.shape[0], cores)}}
+            "pairs": npairs, "distinct_pairs": npairs, "band_w": 100, "kernel_ms": k_ms, "cells_per_pair": cells_per_pair,
+            "gcups": gcups, "matches_oracle": bool(same), "checked_pairs": ns,
+            # integer-VALU roofline of the lane-per-pair kernel: VALU instructions per DP cell from the committed counter pass
+            # (profiles/r02_bsw.md, SQ_INSTS_VALU / cells), against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz int32 lane-ops/s
+            "roofline": {"bound": "valu-int32", "peak": 39.3, "unit": "Tops/s", "ops_per_cell": BSW_VALU_PER_CELL,
+                         "ops_per_cell_source": "SQ_INSTS_VALU x 64 lanes / DP cells, profiles/r02_bsw.md",
+                         "achieved": BSW_VALU_PER_CELL * gcups / 1e3, "frac": BSW_VALU_PER_CELL * gcups / 1e3 / 39.3},
+            "cpu_baseline": {"value": ns / cpu_dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                             "sample": "%d pairs, scalar restatement of scalarBandedSWA on %d threads" % (ns, cores)}}
+
+
+def sam_md5(path):
+    import hashlib
+    h = hashlib.md5()
+    nlines = 0
+    with open(path, "rb") as fh:
+        for line in fh:
+            if not line.startswith(b"@PG"):
+                h.update(line)
+                nlines += 1
+    return h.hexdigest(), nlines
+
+
+def e2e_leg(prefix, genome, npairs, threads):
+    """BASELINE.json's end-to-end metric: `mem -7` on paired-end 150-bp reads through the reference aligner with the HIP
+    backend bound in (oracle/_ref/bwa-meme_dropin = reference main + reference objects + bwa-meme_amd/binding) and
+    through the unmodified reference (oracle/_ref/bwa-meme_mode3, AVX-512) on the same host cores, same index files,
+    same FASTQ; SAM files compared by md5 (minus @PG).  Walls include index loading; `process_s` sums the reference's own
+    per-chunk "Processed N reads in X real sec" lines (seeding + chaining + extension + SAM formation, no I/O)."""
+    import re
+    ref_dir = os.path.join(REPO, "oracle", "_ref")
+    for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+        if not os.path.exists(os.path.join(ref_dir, exe)):
+            raise RuntimeError("%s not built" % exe)
+    d = tempfile.mkdtemp(prefix="meme_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        rng = np.random.default_rng(5)
+        pos = rng.integers(0, genome.shape[0] - 700, size=npairs)
+        ins = rng.integers(300, 500, size=npairs)
+        ar = np.arange(READ_LEN)
+
+        def mut(x):
+            sub = rng.random(x.shape) < 0.01
+            return np.where(sub, (x + rng.integers(1, 4, size=x.shape, dtype=np.uint8)) & 3, x).astype(np.uint8)
+        fqs = []
+        for k in range(2):
+            if k == 0:
+                r = mut(genome[pos[:, None] + ar[None, :]])
+            else:
+                r = mut(3 - genome[(pos + ins - READ_LEN)[:, None] + ar[None, :]][:, ::-1])
+            f = os.path.join(d, "r%d.fq" % (k + 1))
+            workload.write_fastq_fast(f, r, prefix="p")
+            fqs.append(f)
+            del r
+        out = {}
+        for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+            sam = os.path.join(d, exe + ".sam")
+            env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1")
+            t0 = time.time()
+            with open(sam, "wb") as fh:
+                r = subprocess.run([os.path.join(ref_dir, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads),
+                                    prefix] + fqs, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=3000)
+            wall = time.time() - t0
+            err = r.stderr.decode(errors="replace")
+            if r.returncode != 0:
+                raise RuntimeError("%s failed: %s" % (exe, err[-800:]))
+            proc = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
+            md5, nlines = sam_md5(sam)
+            os.remove(sam)
+            info = {"wall_s": wall, "process_s": proc, "reads_per_s_wall": 2 * npairs / wall,
+                    "reads_per_s_process": 2 * npairs / proc if proc > 0 else None, "sam_md5": md5, "sam_lines": nlines}
+            m = re.search(r"Runtime-build-index took ([0-9.]+) sec", err)
+            if m:
+                info["host_index_expansion_s"] = float(m.group(1))
+            m = re.search(r"index staged in HBM in ([0-9.]+) s", err)
+            if m:
+                info["hbm_index_staging_s"] = float(m.group(1))
+            for m in re.finditer(r"totals: seeding ([0-9.]+) s for (\d+) reads; bsw (\d+) calls, (\d+) pairs \(copy-in thread-seconds "
+                                 r"([0-9.]+), backend calls ([0-9.]+) s of which kernels ([0-9.]+) s\)", err):
+                info["backend"] = {"seeding_s": float(m.group(1)), "bsw_calls": int(m.group(3)), "bsw_pairs": int(m.group(4)),
+                                   "bsw_backend_s": float(m.group(6)), "bsw_kernel_s": float(m.group(7))}
+            out[exe] = info
+            log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
+        ref, drop = out["bwa-meme_mode3"], out["bwa-meme_dropin"]
+        return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
+                "workload": "mem -7 -t %d, %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the benchmark "
+                            "genome (%d bp), wall time incl. index loading" % (threads, npairs, READ_LEN, genome.shape[0]),
+                "threads": threads, "pairs": npairs, "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]),
+                "dropin": drop, "reference": ref, "speedup_wall": ref["wall_s"] / drop["wall_s"],
+                "speedup_process": (ref["process_s"] / drop["process_s"]) if drop["process_s"] > 0 else None}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -305,7 +415,8 @@ def main():
     for _ in range(a.warmup):
         res = step()
     kernel_ms = []
-    windows = 0
+    windows = text_compares = 0
+    rc_exit = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -313,6 +424,7 @@ def main():
         tm = ctx.timings()
         kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms))
         windows = tm.seed_windows
+        text_compares = tm.seed_text_compares
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -325,20 +437,24 @@ def main():
         g_ms = float(np.mean([g for _, g in kernel_ms]))
         sample = reads[:20000]
         bpr, per_read = algorithmic_bytes_per_read(text, sa, l1, l2, sample)
-        # parity at the benchmark's own size (index of n suffixes): the GPU seeds the same sample on its own and must
-        # emit exactly as many SMEMs and hits as the CPU restatement counted (the restatement is only the checker here)
+        # parity at the benchmark's own size (index of n suffixes), by CONTENT: the GPU seeds the sample on its own and its
+        # full seed dump (every SMEM, every hit position, the harness's dump format) must equal the pinned oracle's
+        # (oracle/meme_oracle.c orc_seed_batch; the checker only -- nothing timed goes through it)
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        import oracle_py as O
         ns = sample.shape[0]
-        d_s = torch.from_numpy(sample.reshape(-1)).to(dev)
-        d_so = torch.arange(0, (ns + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
-        rs = ctx.seed_batch_device(d_s.data_ptr(), d_so.data_ptr(), ns, ns * READ_LEN, opt)
-        sample_parity = (rs.total_smems == int(round(per_read["smems"] * ns)) and
-                         rs.total_hits == int(round(per_read["hits"] * ns)))
+        s_off = np.arange(0, (ns + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+        g_sm, g_so, g_h, g_ho = ctx.seed_batch(sample, s_off, opt)
+        g_slots, g_counts, g_hl = hipapi.smems_to_slots(g_sm, g_so, g_h, g_ho)
+        o_sm, o_ns, o_h, o_nh, _ = O.seed_batch(O.Index(text, sa), sample, s_off, smem_cap=1024, hit_cap=1 << 15, threads=0)
+        sample_parity = O.format_seed_dump(g_slots, g_counts, g_hl) == O.format_seed_dump(o_sm, o_ns, o_h)
+        del g_sm, g_h, g_slots, g_hl, o_sm, o_h
         if not sample_parity:
-            log("PARITY MISMATCH on the %d-read sample: GPU %d SMEMs / %d hits, restatement %d / %d"
-                % (ns, rs.total_smems, rs.total_hits, round(per_read["smems"] * ns), round(per_read["hits"] * ns)))
+            log("PARITY MISMATCH on the %d-read sample: the GPU seed dump differs from the oracle's" % ns)
         achieved = bpr * nreads / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "seeding_reads_per_sec", "value": world * nreads * a.steps / dt, "unit": "reads/s",
+            "metric": "seeding_reads_per_sec", "value": (world * nreads * a.steps / dt) if sample_parity else None,
+            "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
@@ -350,7 +466,9 @@ def main():
                        "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
                        "searches_per_read": res.searches / nreads,
                        "windows_per_search": windows / max(res.searches, 1),
-                       "sample_parity_with_cpu_restatement": bool(sample_parity)},
+                       "text_compares_per_search": text_compares / max(res.searches, 1),
+                       "sample_parity_with_oracle": bool(sample_parity),
+                       "sample_parity_check": "full seed dump of %d of the benchmark's reads vs orc_seed_batch" % ns},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "kernel": "k_seed", "kernel_ms": k_ms, "gather_ms": g_ms,
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
@@ -370,40 +488,72 @@ def main():
         if pmc:
             try:
                 out["roofline"]["traffic"] = (2 * pmc["fetch_size_kb_per_launch"] + pmc["write_size_kb_per_launch"]) * 1024.0
-                out["roofline"]["traffic_source"] = pmc["source"]
+                out["roofline"]["traffic_source"] = "committed PMC pass, not this run: " + pmc["source"]
                 out["roofline"]["l2_miss_lines_per_s"] = pmc["tcc_miss_lines_per_launch"] / (k_ms * 1e-3)
                 out["roofline"]["random_line_roofline_lines_per_s"] = 50e9     # scripts/microbench/gather_roofline.hip
             except Exception as e:  # never lose the headline line over an annotation
                 log("pmc annotation skipped: %r" % (e,))
-                pmc = None
-        cpu = None
-        cpu_mode = os.environ.get("MEME_BENCH_CPU", "reference" if l_pac <= 1_000_000_000 else "port")
-        if world == 1 and cpu_mode != "0":
-            cores = os.cpu_count() or 1
-            ns = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000" if cpu_mode != "port" else "400000")))
+        budget = float(os.environ.get("MEME_BENCH_BUDGET_S", "1500"))
+        single = world == 1
+        cores = min(256, os.cpu_count() or 1)
+        # ---- the reference's own file formats on disk, for the two legs that run compiled reference binaries ----------
+        ref_prefix = None
+        want_ref = single and (os.environ.get("MEME_BENCH_CPU", "reference") == "reference" or
+                               os.environ.get("MEME_BENCH_E2E", "1") != "0")
+        have_avx512 = "avx512bw" in open("/proc/cpuinfo").read()
+        if want_ref and have_avx512 and os.path.exists(os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")):
             try:
-                if cpu_mode != "port" and os.path.exists(os.path.join(REPO, "oracle", "_ref", "learned_seeding_mode3")) and \
-                        "avx512bw" in open("/proc/cpuinfo").read():
-                    cpu = cpu_baseline_reference(fwd, text, sa, l1, l2, reads[:ns], cores)
-                else:
-                    cpu = cpu_baseline_port(text, sa, l1, l2, reads[:min(ns, 400000)], cores)
-            except Exception as e:  # the baseline is a reported extra, never the measured value
-                log("cpu_baseline leg failed: %r -- falling back to the port" % (e,))
-                cpu = cpu_baseline_port(text, sa, l1, l2, reads[:min(ns, 400000)], cores)
-        if cpu is not None and cpu.get("kind") == "port" and pmc:
-            cpu["reference_on_this_configuration"] = pmc["reference_cpu"]   # measured once (3 min of index load): see its source
+                ref_prefix = reference_index_on_disk(fwd, text, sa, l1, l2, l_pac, bits)
+            except Exception as e:
+                log("reference-format index not available: %r" % (e,))
+        # ---- cpu_baseline: the compiled reference timed in this run (fallback: the restated port) ------------------------
+        cpu = None
+        cpu_mode = os.environ.get("MEME_BENCH_CPU", "reference")
+        if single and cpu_mode != "0":
+            nsamp = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000")))
+            if cpu_mode == "reference" and ref_prefix and time.time() - T_START < budget - 400:
+                try:
+                    cpu = cpu_baseline_reference(ref_prefix, reads[:nsamp], os.cpu_count() or 1)
+                except Exception as e:  # the baseline is a reported extra, never the measured value
+                    log("cpu_baseline (reference) failed: %r -- falling back to the port" % (e,))
+            port = cpu_baseline_port(text, sa, l1, l2, reads[:min(nsamp, 400000)], os.cpu_count() or 1)
+            if cpu is None:
+                cpu = port
+            else:
+                cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
         out["cpu_baseline"] = cpu
-        if os.environ.get("MEME_BENCH_BSW", "1") != "0":
+        if single and os.environ.get("MEME_BENCH_BSW", "1") != "0":
             try:
                 out["bsw"] = bsw_leg(ctx, dev, world)
             except Exception as e:  # a secondary measurement: never lose the headline line over it
                 log("bsw leg failed: %r" % (e,))
                 out["bsw"] = None
+        # ---- e2e: BASELINE.json's second metric, the drop-in next to the unmodified reference (last: it needs the HBM) --------
+        if single and os.environ.get("MEME_BENCH_E2E", "1") != "0":
+            if not ref_prefix:
+                out["e2e"] = {"skipped": "compiled reference / reference-format index not available on this box"}
+            elif time.time() - T_START > budget - 500:
+                out["e2e"] = {"skipped": "wall budget (%d s) nearly used up after %.0f s" % (budget, time.time() - T_START)}
+            else:
+                try:
+                    del text, sa
+                    ctx.close()
+                    ctx = None
+                    del keep, d_reads, d_off, d_pos5
+                    torch.cuda.empty_cache()
+                    out["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_E2E_PAIRS", "2000000")), cores)
+                except Exception as e:
+                    log("e2e leg failed: %r" % (e,))
+                    out["e2e"] = {"failed": repr(e)[:300]}
         print(json.dumps(out), flush=True)
+        if not sample_parity:
+            rc_exit = 1
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
+    sys.exit(rc_exit)
 
 
 if __name__ == "__main__":

@@ -23,6 +23,8 @@
 // reference window streams through registers.  Integer max-plus recurrences: MFMA does not apply.
 #include <limits.h>
 #include <string.h>
+#include <stdlib.h>
+#include <chrono>
 
 #include "meme_common.h"
 
@@ -43,6 +45,7 @@ struct BswArgs {
     unsigned int* ticket;
     const int* offs;         // != nullptr: the class is order[offs[key_first] .. offs[key_last]) (exclusive scan of the sort keys,
     int key_first, key_last; // read on the device: no host round trip between the sort and the DP kernels)
+    unsigned char* gws;      // != nullptr: H/E rows and the staged query live here (queries too long for LDS), per_grp bytes per group
 };
 
 // LP lanes cooperate on one pair (64/LP pairs per wavefront): short extensions -- the common case, since most
@@ -91,7 +94,9 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
     const int gbase = lane - gl;
     const int gid = threadIdx.x / LP;            // group within the workgroup
     const size_t per_grp = (size_t)(A.qmax + 2) * 8 + (size_t)((A.qmax + 7) & ~7);
-    int* H = reinterpret_cast<int*>(lds_raw + per_grp * gid);
+    // queries of up to ~4.5 k bases keep their rows in LDS; longer ones (the reference's 16-bit class reaches 32 k) in HBM
+    unsigned char* rows = A.gws ? A.gws + per_grp * ((size_t)blockIdx.x * (BSW_BLOCK / LP) + gid) : lds_raw + per_grp * gid;
+    int* H = reinterpret_cast<int*>(rows);
     int* E = H + (A.qmax + 2);
     uint8_t* Q = reinterpret_cast<uint8_t*>(E + (A.qmax + 2));
     const int o_del = A.o.o_del, e_del = A.o.e_del, o_ins = A.o.o_ins, e_ins = A.o.e_ins;
@@ -146,7 +151,8 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
         int tchunk = 0;                 // lane k of the group holds target[LP*(i/LP) + k]
         for (int i = 0; i < tlen; ++i) {
             if ((i & (LP - 1)) == 0) tchunk = (i + gl < tlen) ? target[i + gl] : 4;
-            const int tb = grp_bcast<LP>(tchunk, i & (LP - 1), lane);   // all groups of a wavefront are at the same row
+            // the row index is per group (groups of one wavefront may be at different rows after a divergent exit)
+            const int tb = __builtin_amdgcn_ds_bpermute((gbase + (i & (LP - 1))) << 2, tchunk);
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
@@ -492,14 +498,20 @@ int launch_cls(meme_ctx* ctx, BswArgs A, int qmax, i64 dev_cus) {
     constexpr int GROUPS = BSW_BLOCK / LP;
     size_t per_grp = (size_t)(qmax + 2) * 8 + (size_t)((qmax + 7) & ~7);
     size_t lds = per_grp * GROUPS;
-    if (lds > 160 * 1024) {
-        meme_set_error("query of %d bases exceeds the LDS-resident limit of this build", qmax);
-        return MEME_E_ARG;
-    }
     i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 4;
     i64 want = (A.npairs + GROUPS - 1) / GROUPS;        // (upper bound when the class range is read on the device)
     if (blocks > want) blocks = want;
     if (blocks < 1) blocks = 1;
+    A.gws = nullptr;
+    if (lds > 160 * 1024) {
+        // BandedPairWiseSW's 16-bit class takes sequences below 32768 bases (src/bandedSWA.h:47-86): rows in an HBM workspace
+        if (qmax > 32768) { meme_set_error("query of %d bases: beyond the 32768 the reference's banded SW accepts", qmax); return MEME_E_ARG; }
+        if (blocks > dev_cus * 2) blocks = dev_cus * 2;
+        int rc = meme_buf_reserve(ctx, ctx->bsw_ws, per_grp * GROUPS * (size_t)blocks);
+        if (rc) return rc;
+        A.gws = (unsigned char*)ctx->bsw_ws.p;
+        lds = 0;
+    }
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_bsw<LP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     A.qmax = qmax;
@@ -619,6 +631,9 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
     if (!ctx || !pairs || !ref_buf || !qer_buf || !opt || npairs < 0 || ref_bytes < 0 || qer_bytes < 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (npairs == 0) return MEME_OK;
+    static const bool trace = getenv("MEME_BSW_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0;
     int maxq = 0;
     for (int i = 0; i < npairs; ++i) {
         const meme_seqpair& p = pairs[i];
@@ -630,6 +645,7 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
         maxq = p.len2 > maxq ? p.len2 : maxq;
     }
     int rc;
+    const double t1 = trace ? now() : 0;
     if ((rc = meme_buf_reserve(ctx, ctx->pairs, (size_t)npairs * sizeof(meme_seqpair)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->refb, (size_t)ref_bytes + 16))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->qerb, (size_t)qer_bytes + 16))) return rc;
@@ -637,9 +653,16 @@ extern "C" int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t*
     HIP_TRY(hipMemcpyAsync(ctx->refb.p, ref_buf, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->qerb.p, qer_buf, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
     // one host synchronisation per call: the class ranges stay on the device (the host knows the longest query)
+    const double t2 = trace ? now() : 0;
     rc = launch_bsw(ctx, (meme_seqpair*)ctx->pairs.p, (const uint8_t*)ctx->refb.p, (const uint8_t*)ctx->qerb.p, npairs, w,
                     opt, maxq);
     if (rc) return rc;
+    const double t3 = trace ? now() : 0;
     HIP_TRY(hipMemcpyAsync(pairs, ctx->pairs.p, (size_t)npairs * sizeof(meme_seqpair), hipMemcpyDeviceToHost, ctx->stream));
-    return finish_bsw(ctx);
+    rc = finish_bsw(ctx);
+    if (trace)
+        fprintf(stderr, "[meme bsw] %d pairs, %.1f MB in: validate %.2f ms, reserve + H2D enqueue %.2f ms, launches %.2f ms, D2H + wait %.2f ms (GPU %.2f ms)\n",
+                npairs, (ref_bytes + qer_bytes + (double)npairs * sizeof(meme_seqpair)) / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3,
+                (now() - t3) * 1e3, ctx->tm.bsw_kernel_ms);
+    return rc;
 }

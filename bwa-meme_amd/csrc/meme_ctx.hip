@@ -84,7 +84,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->slots[3], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
-                      &ctx->packed, &ctx->bsw_order};
+                      &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws};
     for (DevBuf* b : bufs) free_buf(*b);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     for (meme_ctx::HostBuf* h : {&ctx->h_smems, &ctx->h_hits, &ctx->h_smem_off, &ctx->h_hit_off, &ctx->h_misc})

@@ -175,12 +175,12 @@ __global__ void __launch_bounds__(GATHER_BLOCK) k_gather(const uint8_t* __restri
 
 int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, i64 max_len, i64 total_bytes,
                 const meme_seed_opt* opt, meme_seed_result* out) {
-    unsigned long long h_counters[12];
+    unsigned long long h_counters[16];
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 12 * sizeof(unsigned long long)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long)))) return rc;
     const int dev_cus = ctx->n_cus;
     // ---- pack the reads: 2 bits/base, forward strand, N masks (k_pack_reads) ---------------------------------
     // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262): fail loudly, never seed part of a batch
@@ -190,9 +190,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     }
     if (max_len < 1) max_len = 1;
     PackGeom geo;
-    geo.W = (int)((max_len + 31) / 32) + 1;
+    geo.W = (int)((max_len + 31) / 32);
     geo.MW = (int)((max_len + 63) / 64);
-    geo.stride = geo.W + geo.MW + 1;
+    geo.stride = 1 + geo.W + geo.MW;
     if ((rc = meme_buf_reserve(ctx, ctx->packed, (size_t)nreads * geo.stride * 8))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
     {
@@ -238,7 +238,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         }
         if ((rc = meme_buf_reserve(ctx, sb, need))) return rc;
         if ((rc = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 12 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
         SeedArgs A;
         A.I = ctx->idx;
         A.packed = (const u64*)ctx->packed.p;
@@ -273,6 +273,15 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         searches += (i64)h_counters[1];
         windows += (i64)h_counters[3];
         deep += (i64)h_counters[4];
+#ifdef SEED_PROF
+        {
+            double tot = 0; for (int k = 0; k < 10; ++k) tot += (double)h_counters[5 + k];
+            const char* nm[10] = {"control", "hand-out", "round1 (model|pos|read)", "round2 issue+keys", "text finish", "fresh", "evaluate", "apply", "-", "loop"};
+            fprintf(stderr, "[seed prof] tier %d:", tier);
+            for (int k = 0; k < 10; ++k) if (h_counters[5 + k]) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)h_counters[5 + k] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "\n");
+        }
+#endif
         if (h_counters[2] == 0) break;
         // some reads produced more SMEMs than their slots hold (pathological repeats): re-run only those
         if (tier + 1 >= N_TIERS) {

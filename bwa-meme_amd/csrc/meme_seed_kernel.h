@@ -55,9 +55,9 @@ constexpr int N_TIERS = 4;
 constexpr int TIER_CAP[N_TIERS] = {64, 512, 8192, 65536};   // SMEM slots per read; tier 0 is tunable
 
 struct PackGeom {
-    int W;        // u64 words of the forward strand (>= ceil(maxlen/32) + 1: one zero pad word)
+    int W;        // u64 words of the forward strand (ceil(maxlen/32))
     int MW;       // u64 N-mask words
-    int stride;   // W + MW + 1 (last word = read length | has-N flag << 31)
+    int stride;   // 1 + W + MW (first word = read length | has-N flag << 31)
 };
 
 struct SeedArgs {
@@ -77,7 +77,7 @@ struct SeedArgs {
 };
 
 // ---- read packing -------------------------------------------------------------------------------------
-// Layout per read: fw[W] nfw[MW] len.  A workgroup packs PACK_RB consecutive reads: their bytes are contiguous in the
+// Layout per read: len fw[W] nfw[MW].  A workgroup packs PACK_RB consecutive reads: their bytes are contiguous in the
 // input, so they are staged in LDS with aligned, coalesced dword loads and the 2-bit words are assembled from LDS bytes.
 __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ reads, const i64* __restrict__ read_off,
                                                      i64 nreads, i64 total_bytes, PackGeom g, int PACK_RB,
@@ -151,13 +151,13 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
                     if (i < len && p[i] >= 4) v |= 1ull << j;
                 }
             }
-            out[r * g.stride + k] = v;
+            out[r * g.stride + 1 + k] = v;
         }
         __syncthreads();
         for (int rr = threadIdx.x; rr < nr; rr += blockDim.x) {  // length word: length | (read has an N) << 31
             const i64 r = r0 + rr;
             const int len = (int)(read_off[r + 1] - read_off[r]);
-            out[r * g.stride + nw] = (u64)(unsigned)len | (has_n[rr] ? (1ull << 31) : 0ull);
+            out[r * g.stride] = (u64)(unsigned)len | (has_n[rr] ? (1ull << 31) : 0ull);
         }
     }
 }
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
 // ---- per-read state ------------------------------------------------------------------------------------
 enum Pc : int {
     PC_FETCH, PC_ALLPOS_TOP, PC_ZZ_TOP, PC_ZZ_RIGHT, PC_ZZ_END, PC_AFTER_STEP1, PC_R2_LOOP, PC_R2_AFTER, PC_R3_INIT,
-    PC_R3_TOP, PC_DONE, PC_EXIT
+    PC_R3_TOP, PC_DONE, PC_LOAD, PC_EXIT
 };
 enum Kind : int { K_S1_RIGHT, K_ZZ_LEFT, K_ZZ_RIGHT, K_OP_MEM, K_OP_SMEM, K_R3 };
 // what the next window is for: the partition point of the query (first window at the model's prediction, later ones
@@ -185,6 +185,8 @@ enum Phase : int { PH_CTRL, PH_PART, PH_EDGE_DN, PH_EDGE_UP };
 typedef __attribute__((address_space(3))) u64* lds_u64;
 typedef __attribute__((address_space(3))) int* lds_int;
 typedef __attribute__((address_space(3))) unsigned short* lds_u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4;
 typedef const __attribute__((address_space(1))) u64* glb_u64;
 typedef const __attribute__((address_space(1))) uint8_t* glb_u8;
 typedef const __attribute__((address_space(1))) uint32_t* glb_u32;
@@ -193,10 +195,12 @@ typedef const __attribute__((address_space(1))) Rmi32* glb_rmi;
 __device__ __forceinline__ u64 lowmask(int k) { return k >= 64 ? ~0ull : (k <= 0 ? 0ull : ((1ull << k) - 1ull)); }
 
 // cold per-read state in LDS, [word][lane]
-enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_ZZ_NEXT, ST_ZZ_SP, ST_ZZ_GUARD, ST_AP_GUARD, ST_N_SMEMS,
-                   ST_HITS_LO, ST_HITS_HI, ST_TICKET_LO, ST_TICKET_HI,
+enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_ZZ /* zig-zag start | next pivot << 16 */, ST_GUARDS /* zig-zag | all-pos << 16 */, ST_N_SMEMS,
+                   ST_HITS_LO, ST_HITS_HI, ST_TICKET,
+                   ST_RING_SE0, ST_RING_C0, ST_RING_SE1, ST_RING_C1,   // the first two SMEMs of the current first-round pass
                    // the level walk of the search in flight (written when an edge request parks it)
-                   ST_L, ST_SE_LO, ST_SE_HI, ST_EE_LO, ST_EE_HI, ST_NB, ST_LF, ST_CB_LO, ST_CB_HI, ST_CACHE, ST_LAST_CNT_LO,
+                   ST_WALK /* L | lf << 10 | cache array << 16 | cache slots << 17 | cache at text end << 22 */, ST_SE_LO, ST_SE_HI, ST_EE_LO, ST_EE_HI,
+                   ST_NB, ST_CB_LO, ST_CB_HI, ST_LAST_CNT_LO,
                    ST_LAST_CNT_HI, ST_LAST_S_LO, ST_LAST_S_HI, ST_WORDS };
 enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2 };
 enum LevelFlag : int { LF_NEED_LO = 1, LF_NEED_HI = 2, LF_HAVE_LAST = 4 };
@@ -209,7 +213,10 @@ __host__ __device__ inline size_t seed_lds_bytes(int W) {
 
 constexpr int TICKET_CHUNK = 64;     // reads a wavefront draws from the global ticket counter at a time
 #ifndef TXT_WORDS
-#define TXT_WORDS 5                  // text words compared per round trip of a tie compare (160 bases: one trip for 150-bp reads)
+#define TXT_WORDS 3                  // text words compared per round trip of a tie compare (32 key bases + 96 per trip)
+#endif
+#ifndef LD_WORDS
+#define LD_WORDS 10                  // words of a packed read fetched per round trip (a 150-bp record: 6 + 3 + 1)
 #endif
 // per-search bookkeeping word `tx`
 enum TxBits : unsigned { TX_PEND = 1u, TX_FRESH = 2u, TX_SPEC = 4u, TX_W_SHIFT = 3, TX_W_MASK = 1u << 3, TX_S_SHIFT = 4,
@@ -282,6 +289,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     int pc = PC_FETCH, phase = PH_CTRL;
     int pivot = 0, l_seq = 0, msl = A.opt.min_seed_len, min_intv = 1, flags = 0;
     bool has_n = false;
+    int nn = 0;                                              // first two N positions of the read (see is_n)
     i64 rid = 0;
     // the request in flight
     int q_kind = 0, q_mode = 0, off = 0, vlen = 0, capc = 0;
@@ -295,22 +303,22 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
     // tk0: 32-base words of the pending text compare already known equal
     unsigned km = 0, lessm = 0, tx = 0;
     int tk0 = 1;
-    unsigned rd_searches = 0, rd_windows = 0, acc_searches = 0, acc_windows = 0, acc_deep = 0;
+    unsigned acc_searches = 0, acc_windows = 0, acc_deep = 0;   // (reads re-run in an overflow tier are counted in both runs)
     // the wavefront's ticket chunk (wave-uniform values)
-    unsigned long long w_next = 0;
+    unsigned long long w_next = 0, ld_ticket = 0;
     int w_remain = 0;
 
     // 32 query bases at offset s of the forward strand (s may reach past the read: zero words follow it in LDS)
     auto ext_fw = [&](int s) -> u64 {
         int k = s >> 5;
         const int sh = (s & 31) * 2;
-        if (k > PW - 2) k = PW - 2;                          // (only for offsets beyond the read; the value is not used)
-        const u64 a = Q(k), b = Q(k + 1);
+        if (k > PW - 1) k = PW - 1;                          // (only for offsets beyond the read; the value is not used)
+        const u64 a = Q(k), b = k + 1 < PW ? Q(k + 1) : 0ull; // zero bases follow the read
         return sh ? (a << sh) | (b >> (64 - sh)) : a;
     };
     // ... of the strand the current request searches: the reverse complement is derived from the forward words
     auto ext_q = [&](int s) -> u64 {
-        if (!q_rc) return ext_fw(s < 32 * (PW - 1) ? s : 32 * (PW - 1));
+        if (!q_rc) return ext_fw(s);
         const int s0 = l_seq - s - 32;                       // forward bases [s0, s0 + 32) reversed and complemented
         u64 w;
         if (s0 >= 0) w = ext_fw(s0);
@@ -318,12 +326,21 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         else w = (ext_fw(0) >> (2 * -s0)) | (~0ull << (64 - 2 * -s0));   // bases before the read: T, complemented to 0
         return revcomp32(w);
     };
-    // N masks live in the packed record in global memory (reads with an N are rare)
-    auto nmask = [&](int w) -> u64 { return ((glb_u64)A.packed)[rid * stride + PW + w]; };
-    auto is_n = [&](int i) -> bool { return (nmask(i >> 6) >> (i & 63)) & 1ull; };
+    // Ambiguous bases: the positions of a read's first two N live in the register `nn` (n0 | n1 << 10 | count << 20,
+    // count 3 = "more than two": only then the N masks of the packed record in global memory are consulted)
+    auto nmask = [&](int w) -> u64 { return ((glb_u64)A.packed)[rid * stride + 1 + PW + w]; };
+    auto is_n = [&](int i) -> bool {
+        const int c = nn >> 20;
+        if (c == 3) return (nmask(i >> 6) >> (i & 63)) & 1ull;
+        return (c >= 1 && i == (nn & 1023)) || (c == 2 && i == ((nn >> 10) & 1023));
+    };
     // first ambiguous base at/after `from` on the forward strand (Tokenization's *ambiguous_pos, :795-901)
     auto first_n_fw = [&](int from) -> int {
         if (!has_n) return l_seq;
+        if ((nn >> 20) != 3) {
+            const int n0 = nn & 1023, n1 = (nn >> 10) & 1023;
+            return n0 >= from ? n0 : (((nn >> 20) == 2 && n1 >= from) ? n1 : l_seq);
+        }
         int w = from >> 6;
         u64 m = nmask(w) & (~0ull << (from & 63));
         const int nw = (l_seq + 63) >> 6;
@@ -338,6 +355,11 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         if (!has_n) return l_seq;
         const int p = l_seq - 1 - from;                      // last forward position of interest
         if (p < 0) return l_seq;
+        if ((nn >> 20) != 3) {
+            const int n0 = nn & 1023, n1 = (nn >> 10) & 1023;
+            if ((nn >> 20) == 2 && n1 <= p) return l_seq - 1 - n1;
+            return n0 <= p ? l_seq - 1 - n0 : l_seq;
+        }
         int w = p >> 6;
         u64 m = nmask(w) & lowmask((p & 63) + 1);
         for (;;) {
@@ -384,28 +406,36 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         else { lcp_out = ll; less_out = llt; }
     };
 
+#ifdef SEED_PROF
+    // diagnostic build: shader cycles a wavefront spends in each section of the loop body, summed into counters[5..]
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+#define PROF_MARK(i_) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now__ = __builtin_amdgcn_s_memtime(); prof[i_] += now__ - prof_t; prof_t = now__; } while (0)
+#else
+#define PROF_MARK(i_) do { } while (0)
+#endif
     for (;;) {
         // ================= control: reads without a request in flight produce the next one =========================
         bool newreq = false;
-        for (;;) {
-        if (phase == PH_CTRL && pc != PC_EXIT && pc != PC_FETCH && !newreq) {
+        PROF_MARK(9);
+        if (phase == PH_CTRL && pc != PC_EXIT && pc != PC_FETCH && pc != PC_LOAD) {
             // One pass over the states in the order reads usually flow through them, so a read takes several hops per
             // pass; the inner loop only repeats for the rare backward hops.
             bool have = false;
 #define AT(pc_) (!have && pc == (pc_))
             do {
                 if (AT(PC_ZZ_TOP)) {       // zig-zag loop head (:1724-1737, :1969)
-                    const int sp = ST(ST_ZZ_SP), guard = ST(ST_ZZ_GUARD) + 1;
-                    ST(ST_ZZ_GUARD) = guard;
-                    if (sp >= ST(ST_ZZ_NEXT) || guard > 4 * l_seq + 16) pc = PC_ZZ_END;
+                    const int zz = ST(ST_ZZ), sp = zz & 0xffff, gw = ST(ST_GUARDS) + 1, guard = gw & 0xffff;
+                    ST(ST_GUARDS) = gw;
+                    if (sp >= (zz >> 16) || guard > 4 * l_seq + 16) pc = PC_ZZ_END;
                     else if ((flags & F_ZZ_CHECK) && has_n && is_n(sp)) {
-                        if (l_seq - sp < msl) { pivot = l_seq; ST(ST_ZZ_SP) = l_seq; }
-                        else { ST(ST_ZZ_SP) = sp + 1; pivot = pivot + 1; }
+                        if (l_seq - sp < msl) { pivot = l_seq; ST(ST_ZZ) = (zz & ~0xffff) | l_seq; }
+                        else { ST(ST_ZZ) = zz + 1; pivot = pivot + 1; }
                     } else { q_kind = K_ZZ_LEFT; have = true; }
                 }
                 if (AT(PC_ZZ_RIGHT)) { q_kind = K_ZZ_RIGHT; have = true; }
                 if (AT(PC_ZZ_END)) {       // set_forward_pivot(raux, next_pivot) (:1893, :2125)
-                    pivot = ST(ST_ZZ_NEXT);
+                    pivot = ST(ST_ZZ) >> 16;
                     pc = (flags & F_ZZ_RET_ONEPOS) ? PC_R2_AFTER : PC_AFTER_STEP1;
                 }
                 if (AT(PC_AFTER_STEP1)) {  // re-seeding loop entry (:921-923)
@@ -425,14 +455,23 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     const int ke = ST(ST_AFTER);
                     int qbeg = 0, qend = 0, cnt = 0;
                     bool take = false;
-                    // the SMEMs of this first-round pass are read back from the read's own slots (written by this lane)
-                    const unsigned long long ticket = ((unsigned long long)(unsigned)ST(ST_TICKET_HI) << 32) | (unsigned)ST(ST_TICKET_LO);
+                    // the first two SMEMs of this first-round pass are at hand in LDS; further ones are read back from the
+                    // read's own slots (written by this lane)
+                    const int kb = ST(ST_BEFORE);
+                    const unsigned long long ticket = (unsigned long long)(unsigned)ST(ST_TICKET);
                     const SlotRec* mine = A.slots + (i64)ticket * cap;
                     while (k < ke) {        // SMEMs that are too short or too frequent are not re-seeded (:929-931)
-                        const u64 se = __hip_atomic_load((const u64*)&mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const i64 c64 = (i64)__hip_atomic_load((const u64*)&mine[k].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        cnt = c64 > (i64)INT_MAX ? INT_MAX : (int)c64;
-                        qbeg = (int)(unsigned)(se & 0xffffffffull); qend = (int)(unsigned)(se >> 32);
+                        const int d = k - kb;
+                        if (d < 2) {
+                            const int se = ST(d ? ST_RING_SE1 : ST_RING_SE0);
+                            cnt = ST(d ? ST_RING_C1 : ST_RING_C0);
+                            qbeg = se & 0xffff; qend = (int)((unsigned)se >> 16);
+                        } else {
+                            const u64 se = __hip_atomic_load((const u64*)&mine[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const i64 c64 = (i64)__hip_atomic_load((const u64*)&mine[k].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            cnt = c64 > (i64)INT_MAX ? INT_MAX : (int)c64;
+                            qbeg = (int)(unsigned)(se & 0xffffffffull); qend = (int)(unsigned)(se >> 32);
+                        }
                         ++k;
                         if (!(qend - qbeg < A.opt.split_len || cnt > A.opt.split_width)) { take = true; break; }
                     }
@@ -450,8 +489,8 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     }
                 }
                 if (AT(PC_ALLPOS_TOP)) {   // Learned_getSMEMsAllPosOneThread loop head (:916) + step1 entry (:1691-1723)
-                    const int guard = ST(ST_AP_GUARD) + 1;
-                    ST(ST_AP_GUARD) = guard;
+                    const int gw = ST(ST_GUARDS) + 0x10000, guard = (int)((unsigned)gw >> 16);
+                    ST(ST_GUARDS) = gw;
                     if (pivot >= l_seq || guard > 4 * l_seq + 16) pc = PC_R3_INIT;
                     else {
                         ST(ST_BEFORE) = ST(ST_N_SMEMS);
@@ -460,7 +499,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                             pc = PC_AFTER_STEP1;                      // backward hop (reads with N only)
                         } else if (pivot != 0 && !(has_n && is_n(pivot - 1))) {
                             // zig-zag entry: the loop head's checks pass trivially (sp = pivot < next = l_seq, no N here)
-                            ST(ST_ZZ_NEXT) = l_seq; flags = F_ZZ_CHECK; ST(ST_ZZ_SP) = pivot; ST(ST_ZZ_GUARD) = 1;
+                            ST(ST_ZZ) = pivot | (l_seq << 16); flags = F_ZZ_CHECK; ST(ST_GUARDS) = (gw & ~0xffff) | 1;
                             q_kind = K_ZZ_LEFT; have = true;
                         } else { q_kind = K_S1_RIGHT; have = true; }
                     }
@@ -484,64 +523,48 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     }
                 }
                 if (AT(PC_DONE)) {         // publish the read's SMEM count / hit count; its slots are already written
-                    const unsigned long long ticket = ((unsigned long long)(unsigned)ST(ST_TICKET_HI) << 32) | (unsigned)ST(ST_TICKET_LO);
+                    const unsigned long long ticket = (unsigned long long)(unsigned)ST(ST_TICKET);
                     const int ns = ST(ST_N_SMEMS);
                     const bool ovf = ns > cap;
                     A.slot_cnt[rid] = ovf ? 0 : ns;
                     A.slot_hits[rid] = ovf ? 0 : LD64(ST_HITS_LO);
                     A.slot_loc[rid] = ((i64)A.tier << 40) | (i64)ticket;
                     if (ovf) A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = rid;
-                    else { acc_searches += rd_searches; acc_windows += rd_windows; }
                     pc = PC_FETCH;
                 }
             } while (!have && pc != PC_EXIT && pc != PC_FETCH);
 #undef AT
             newreq = have;
         }
+        PROF_MARK(0);
         // hand-out of new reads (reads differ 3x in cost: dynamic, no static deal).  Every lane of the wavefront passes
         // here together: the wavefront keeps a chunk of TICKET_CHUNK tickets (w_next, w_remain are wave-uniform) and
         // refills it with ONE global atomic (one atomic per read on a single address caps the kernel at ~30 M reads/s).
+        // The read itself is fetched in memory round 1 below, next to the other lanes' model records.
         {
             const bool want = phase == PH_CTRL && pc == PC_FETCH;
             const unsigned long long mw = __ballot(want);
-            if (!mw) break;
-            const int k = __popcll(mw);
-            const int rank = __popcll(mw & ((1ull << lane) - 1ull));
-            unsigned long long ticket = w_next + (unsigned)rank;
-            if (k > w_remain) {
-                unsigned long long nb = 0;
-                const int first = __ffsll((long long)mw) - 1;
-                if (lane == first) nb = atomicAdd(&A.counters[0], (unsigned long long)TICKET_CHUNK);
-                nb = ((unsigned long long)(unsigned)__shfl((int)(nb >> 32), first) << 32) | (unsigned)__shfl((int)(nb & 0xffffffffull), first);
-                if (rank >= w_remain) ticket = nb + (unsigned)(rank - w_remain);
-                w_next = nb + (unsigned)(k - w_remain);
-                w_remain = TICKET_CHUNK - (k - w_remain);
-            } else { w_next += (unsigned)k; w_remain -= k; }
-            if (want) {
-                if (ticket >= (unsigned long long)A.nreads) pc = PC_EXIT;
-                else {
-                    rid = A.pending ? A.pending[ticket] : (i64)ticket;
-                    const glb_u64 src = (glb_u64)A.packed + rid * stride;
-                    for (int k2 = 0; k2 < PW; ++k2) Q(k2) = src[k2];       // stage the forward strand in LDS
-                    const u64 lenw = src[stride - 1];
-                    l_seq = (int)(lenw & 0x7fffffffull);           // k_pack_reads: length | has-N flag << 31
-                    has_n = ((lenw >> 31) & 1ull) != 0;
-                    for (int k2 = 0; k2 < ST_WORDS; ++k2) ST(k2) = 0;
-                    rd_searches = rd_windows = 0;
-                    if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
-                        // empty read (longer ones are rejected by the host before the launch): no seeds; stays in PC_FETCH
-                        A.slot_cnt[rid] = 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0;
-                    } else {
-                        ST(ST_TICKET_LO) = (int)(unsigned)(ticket & 0xffffffffull);
-                        ST(ST_TICKET_HI) = (int)(ticket >> 32);
-                        pivot = 0; msl = A.opt.min_seed_len; min_intv = 1; flags = 0;
-                        pc = PC_ALLPOS_TOP;
-                    }
+            if (mw) {
+                const int k = __popcll(mw);
+                const int rank = __popcll(mw & ((1ull << lane) - 1ull));
+                unsigned long long ticket = w_next + (unsigned)rank;
+                if (k > w_remain) {
+                    unsigned long long nb = 0;
+                    const int first = __ffsll((long long)mw) - 1;
+                    if (lane == first) nb = atomicAdd(&A.counters[0], (unsigned long long)TICKET_CHUNK);
+                    nb = ((unsigned long long)(unsigned)__shfl((int)(nb >> 32), first) << 32) | (unsigned)__shfl((int)(nb & 0xffffffffull), first);
+                    if (rank >= w_remain) ticket = nb + (unsigned)(rank - w_remain);
+                    w_next = nb + (unsigned)(k - w_remain);
+                    w_remain = TICKET_CHUNK - (k - w_remain);
+                } else { w_next += (unsigned)k; w_remain -= k; }
+                if (want) {
+                    if (ticket >= (unsigned long long)A.nreads) pc = PC_EXIT;
+                    else { ld_ticket = ticket; pc = PC_LOAD; }
                 }
             }
         }
-        }
         if (!__ballot(pc != PC_EXIT)) break;                 // every read of the batch has been handed out and finished
+        PROF_MARK(1);
 
         // ================= memory round 1: model record (new requests) | position of a tied slot (text compares) =========
         // Every lane does at most TWO dependent memory rounds per iteration -- (model, keys) for a new request, (-, keys)
@@ -559,7 +582,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             vlen = (q_rc ? first_n_rc(off) : first_n_fw(off)) - off;
             q_exact = q_kind == K_S1_RIGHT || q_kind == K_ZZ_RIGHT || q_kind == K_OP_SMEM;
             q_mode = q_kind == K_R3 ? 2 : ((q_exact || min_intv != 1) ? 1 : 0);
-            ++rd_searches;
+            ++acc_searches;
             wq = ext_q(off);                                     // first 32 bases of the query: every window compares against it
             key = wq;
             if (vlen < 32) key |= (~0ull) >> (2 * vlen);          // T-pad short queries like Tokenization (:813-817)
@@ -579,6 +602,64 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             t_two = (u64)pd[0] | ((u64)pd[1] << 32);
             t_two = (t_two >> (8 * (int)(bo & 3))) & 0xffffffffffull;
         }
+        // a lane that drew a ticket fetches its packed read now (LD_WORDS words per round; a 150-bp record is 10 words) and
+        // runs its control pass in the next iteration
+        const bool do_load = live && pc == PC_LOAD;
+        u64 ld_w[LD_WORDS];
+        glb_u64 ld_src = (glb_u64)A.packed;
+        if (do_load) {
+            rid = A.pending ? A.pending[ld_ticket] : (i64)ld_ticket;
+            ld_src = (glb_u64)A.packed + rid * stride;
+#pragma unroll
+            for (int j = 0; j < LD_WORDS; ++j) ld_w[j] = ld_src[j < stride ? j : stride - 1];
+        }
+        if (do_load) {
+            // stage the forward strand in LDS, note the first two N positions (only reads that have one), clear the cold state
+            nn = 0;
+            const u64 lenw = ld_w[0];
+            const bool any_n = ((lenw >> 31) & 1ull) != 0;
+            for (int k0 = 0; k0 < stride; k0 += LD_WORDS) {
+                if (k0) {                                        // longer records: further rounds of LD_WORDS words
+#pragma unroll
+                    for (int j = 0; j < LD_WORDS; ++j) ld_w[j] = ld_src[k0 + j < stride ? k0 + j : stride - 1];
+                }
+#pragma unroll
+                for (int j = 0; j < LD_WORDS; ++j) {
+                    const int k2 = k0 + j - 1;                   // word k2 of the record's data (the length word is word -1)
+                    if (k2 >= 0 && k2 < PW) Q(k2) = ld_w[j];
+                }
+                if (any_n) {
+#pragma unroll
+                    for (int j = 0; j < LD_WORDS; ++j) {
+                        const int k2 = k0 + j - 1;
+                        if (k2 >= PW && k2 < stride - 1) {
+                            u64 mw2 = ld_w[j];
+                            for (int it = 0; it < 3 && mw2; ++it) {
+                                const int pn = 64 * (k2 - PW) + __ffsll((long long)mw2) - 1;
+                                const int c = nn >> 20;
+                                if (c == 0) nn = pn | (1 << 20);
+                                else if (c == 1) nn = (nn & 1023) | (pn << 10) | (2 << 20);
+                                else nn = (nn & 0xfffff) | (3 << 20);
+                                mw2 &= mw2 - 1;
+                            }
+                        }
+                    }
+                }
+            }
+            l_seq = (int)(lenw & 0x7fffffffull);               // k_pack_reads: length | has-N flag << 31
+            has_n = ((lenw >> 31) & 1ull) != 0;
+            for (int k2 = 0; k2 < ST_WORDS; ++k2) ST(k2) = 0;
+            if (l_seq <= 0 || l_seq > MAX_READ_LEN) {
+                // empty read (longer ones are rejected by the host before the launch): no seeds; draws the next ticket
+                A.slot_cnt[rid] = 0; A.slot_hits[rid] = 0; A.slot_loc[rid] = 0;
+                pc = PC_FETCH;
+            } else {
+                ST(ST_TICKET) = (int)(unsigned)ld_ticket;          // (a launch hands out fewer than 2^32 tickets)
+                pivot = 0; msl = A.opt.min_seed_len; min_intv = 1; flags = 0;
+                pc = PC_ALLPOS_TOP;
+            }
+        }
+
         if (newreq) {
             // learned_index_lookup (:186-210): same arithmetic (FP64 FMA + clamp, partial third layer), used as a hint
             const double x = (double)key;
@@ -607,6 +688,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             tx = TX_FRESH;
         }
 
+        PROF_MARK(2);
         // ================= memory round 2: window keys (four sub-passes, the quad works for its k-th owner) | text words ======
         const bool fresh = live && phase != PH_CTRL && (tx & TX_FRESH) != 0;
         // does this window's line hold one of the few suffixes near the end of the text?  (L1-resident 16 KB table)
@@ -626,16 +708,15 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         }
         int cnt_lt = 0, cnt_tie = 0;
         {
-            // request word broadcast to the quad: base (16-aligned) | LCP array << 1 | active
-            const u64 breq = fresh ? ((u64)base | ((u64)which << 1) | 1ull) : 0ull;
+            // request word broadcast to the quad: window line (base >> 4) << 2 | LCP array << 1 | active
+            const int breq = fresh ? (int)(((unsigned)(base >> 4) << 2) | ((unsigned)which << 1) | 1u) : 0;
             const int cl = capc > 32 ? 33 : capc;                // lanes only need to know whether capc reaches past the key
             u64 kk[4][4];
-            u64 rq[4], rw[4];
-            int rc[4];
+            int rq[4];
 #define SUB_LOAD(K_)                                                                                   \
-            rq[K_] = quad_bcast64<K_>(breq); rw[K_] = quad_bcast64<K_>(wq); rc[K_] = quad_bcast<K_>(cl);           \
-            if (rq[K_] & 1ull) {                                                                                     \
-                const glb_u64 kp = keys + (i64)(rq[K_] & ~15ull) + t;                                                \
+            rq[K_] = quad_bcast<K_>(breq);                                                                           \
+            if (rq[K_] & 1) {                                                                                        \
+                const glb_u64 kp = keys + ((i64)((unsigned)rq[K_] >> 2) << 4) + t;                                   \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) kk[K_][e] = kp[4 * e];                              \
             }
             SUB_LOAD(0) SUB_LOAD(1) SUB_LOAD(2) SUB_LOAD(3)
@@ -643,19 +724,21 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
 #define SUB_CMP(K_)                                                                                    \
             {                                                                                                        \
                 int c = 0;                                                                                           \
-                if (rq[K_] & 1ull) {                                                                                 \
+                const u64 rw = quad_bcast64<K_>(wq);                                                                 \
+                const int rc = quad_bcast<K_>(cl);                                                                   \
+                if (rq[K_] & 1) {                                                                                    \
                     unsigned short lv[4];                                                                            \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                               \
-                        const u64 xx = kk[K_][e] ^ rw[K_];                                                           \
+                        const u64 xx = kk[K_][e] ^ rw;                                                               \
                         int l = xx ? (__clzll((long long)xx) >> 1) : 32;                                             \
-                        const bool full = l >= rc[K_];        /* the whole query matched inside the key */           \
+                        const bool full = l >= rc;            /* the whole query matched inside the key */           \
                         const bool tie = !full && xx == 0;   /* 32 bases equal and the query goes on */             \
-                        if (full) l = rc[K_];                                                                        \
-                        c += tie ? 32 : ((full || kk[K_][e] < rw[K_]) ? 1 : 0);                                      \
+                        if (full) l = rc;                                                                            \
+                        c += tie ? 32 : ((full || kk[K_][e] < rw) ? 1 : 0);                                          \
                         lv[e] = (unsigned short)l;                                                                   \
                     }                                                                                                \
                     const int owner = (lane & ~3) + K_;                                                              \
-                    const int wsel = (int)((rq[K_] >> 1) & 1ull);                                                    \
+                    const int wsel = (rq[K_] >> 1) & 1;                                                              \
                     *(__attribute__((address_space(3))) u64*)&LCb[(((wsel * 64) + owner) << 4) + (t << 2)] =         \
                         (u64)lv[0] | ((u64)lv[1] << 16) | ((u64)lv[2] << 32) | ((u64)lv[3] << 48);                   \
                 }                                                                                                    \
@@ -670,6 +753,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        PROF_MARK(3);
         bool need_eval = false;
         if (do_txt) {
             // ---- finish the text compare (compare_read_and_ref_binary*, :226-601).  L = min(capc, n - pos).
@@ -701,9 +785,10 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                 need_eval = true;
             }
         }
+        PROF_MARK(4);
         const int valid = (n - base) < WIN ? (int)(n - base) : WIN;
         if (fresh) {
-            ++rd_windows;
+            ++acc_windows;
             tx &= ~(unsigned)TX_FRESH;
             // ---- this window in numbers: slots [0, t0) sort below the query by their keys, [t0, t1) tie with it
             // (their order and prefix length need the text), [t1, valid) sort above.  km bits 0..15: slots whose exact
@@ -737,6 +822,7 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             need_eval = true;
         }
 
+        PROF_MARK(5);
         // ================= evaluate: what does the window (or the cached partition window) say now? ======================
         // Runs to the end and commits, or stops at the first slot whose prefix length is still unknown (a key tie): that slot
         // goes to the text compare of the next iteration and the evaluation simply starts over -- it is a pure function of
@@ -747,84 +833,85 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
         bool r_emit = false;
         if (need_eval) {
             const bool spec = (tx & TX_SPEC) != 0;
-            const int t0 = (int)((tx >> TX_T0_SHIFT) & 31u), t1 = (int)((tx >> TX_T1_SHIFT) & 31u);
             const int wcur = which;
             int need_w = -1, need_s = 0;
-            unsigned known = km & 0xffffu;
-            // exact prefix length of slot s of window array w (bookkeeping mask kn); an unknown slot is noted as needed
-            auto slot_lcp = [&](int w, unsigned kn, int s) -> int {
-                if (!((kn >> s) & 1u)) {
-                    if (need_w < 0) { need_w = w; need_s = s; }
-                    return 32;
+            const unsigned known = km & 0xffffu, vmask = (unsigned)lowmask(valid);
+            // The 16 prefix lengths of a window live in LDS in position order (position 4t+e = slot 4e+t); one 32-byte read
+            // brings them into registers, and every question below is answered with 16-bit masks over the slots.
+            unsigned dcur[8];
+            {
+                const lds_u32x4 lp4 = (lds_u32x4)&LCb[((wcur * 64 + lane) << 4)];
+                const u32x4 x0 = lp4[0], x1 = lp4[1];
+                dcur[0] = x0.x; dcur[1] = x0.y; dcur[2] = x0.z; dcur[3] = x0.w; dcur[4] = x1.x; dcur[5] = x1.y; dcur[6] = x1.z; dcur[7] = x1.w;
+            }
+            // slots whose stored prefix length is >= L (an unknown slot stores 32: a key tie shares at least 32 bases)
+            auto ge16 = [&](const unsigned (&d)[8], int L) -> unsigned {
+                unsigned m = 0;
+                const unsigned uL = (unsigned)L;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int p0 = 2 * i, p1 = 2 * i + 1;
+                    const int s0 = 4 * (p0 & 3) + (p0 >> 2), s1 = 4 * (p1 & 3) + (p1 >> 2);
+                    m |= ((d[i] & 0xffffu) >= uL ? (1u << s0) : 0u) | ((d[i] >> 16) >= uL ? (1u << s1) : 0u);
                 }
-                return (int)LCP_AT(w, s);
+                return m;
             };
-            // first slot z in [a, b] such that every slot of [z, b) has a prefix length >= L.  Lengths are non-decreasing
-            // towards the partition point, so this is a binary search; `linear` (windows at the end of the text, where
-            // the T-padding convention can break monotony) walks down from b like the reference's slot-by-slot logic.
-            auto first_ge = [&](int w, unsigned kn, int a, int b, int L, bool linear) -> int {
-                if (linear) { while (b > a && slot_lcp(w, kn, b - 1) >= L) --b; return b; }
-                while (a < b) {
-                    const int mid = (a + b) >> 1;
-                    // an unresolved tie shares at least 32 bases: no text compare needed for levels within the key
-                    const bool ge = (!((kn >> mid) & 1u) && L <= 32) ? true : slot_lcp(w, kn, mid) >= L;
-                    if (ge) b = mid; else a = mid + 1;
-                }
-                return a;
-            };
-            // ... first slot z in [a, b] such that every slot of [a, z) has a prefix length >= L (non-increasing side)
-            auto first_lt = [&](int w, unsigned kn, int a, int b, int L, bool linear) -> int {
-                if (linear) { while (a < b && slot_lcp(w, kn, a) >= L) ++a; return a; }
-                while (a < b) {
-                    const int mid = (a + b) >> 1;
-                    const bool ge = (!((kn >> mid) & 1u) && L <= 32) ? true : slot_lcp(w, kn, mid) >= L;
-                    if (ge) a = mid + 1; else b = mid;
-                }
-                return a;
+            auto lcp_at = [&](int w, int s) -> int { return (int)LCP_AT(w, s); };
+            // the unknown slot of a range to look up first: the one nearest to the middle (the range halves every time)
+            auto pick = [&](unsigned um, int a, int b) -> int {
+                const int mid = (a + b - 1) >> 1;
+                const unsigned up = um >> mid;
+                return up ? mid + (__ffs((int)up) - 1) : 31 - __clz((int)(um & (unsigned)lowmask(mid)));
             };
 
-            // number of slots of the window for which the phase's predicate holds (they come first)
-            int P;
+            // ---- number of slots of the window for which the phase's predicate holds (they come first) -----------------
             const int wlo = (lo - base + 1 > valid) ? valid : (lo - base + 1 < 0 ? 0 : (int)(lo - base + 1));   // slots < wlo known true
             const int whi = (hi - base > valid) ? valid : (hi - base < 0 ? 0 : (int)(hi - base));              // slots >= whi known false
+            const unsigned brk_lo = (unsigned)lowmask(wlo), brk_hi = (unsigned)lowmask(whi);
+            unsigned tru, unk;                                   // slots known true; slots whose answer needs the text
+            if (phase == PH_PART) { tru = lessm; unk = ~known & vmask; }
+            else {
+                const unsigned g = ge16(dcur, capc);
+                const bool deep = capc > 32 && !spec;            // an unknown slot only matters for levels beyond the key
+                unk = deep ? (~known & vmask) : 0u;
+                tru = phase == PH_EDGE_DN ? (~g & vmask & ~unk) : (g & ~unk);
+            }
+            int P;
             if (spec) {
-                P = wlo;
-                for (int s2 = wlo; s2 < whi; ++s2)
-                    P += phase == PH_PART ? (int)((lessm >> s2) & 1u) : (((int)LCP_AT(wcur, s2) >= capc) == (phase == PH_EDGE_UP) ? 1 : 0);
-            } else if (phase == PH_PART) {
-                // ties sort by the text: first tie that is not below the query (order is monotone over the array)
-                int a = t0 < wlo ? wlo : t0, b = t1 < whi ? t1 : whi;
-                if (b < a) b = a;
-                while (a < b) {
-                    const int mid = (a + b) >> 1;
-                    (void)slot_lcp(wcur, known, mid);
-                    if ((lessm >> mid) & 1u) a = mid + 1; else b = mid;
-                }
-                P = a;
-                if (t0 >= whi) P = whi;                          // (the bracket already says so)
-                if (P < wlo) P = wlo;
-            } else if (phase == PH_EDGE_DN) P = first_ge(wcur, known, wlo, whi, capc, false);
-            else P = first_lt(wcur, known, wlo, whi, capc, false);
+                // windows at the end of the text: every slot is known; count like the reference's slot-by-slot compare would
+                P = wlo + __popc(tru & ~brk_lo & brk_hi);
+            } else {
+                const unsigned T = (tru | brk_lo) & brk_hi, U = unk & ~brk_lo & brk_hi;
+                const int p_lo = __ffs((int)~T) - 1, p_hi = __ffs((int)~(T | U)) - 1;     // (bit 16 and above are zero: <= 16)
+                if (p_lo != p_hi) { need_w = wcur; need_s = pick(U, p_lo, p_hi); }
+                P = p_lo;
+            }
 
             // is the flip pinned down?  slot f-1 must be known true and slot f known false
             const i64 f = base + P;
             const bool lo_ok = P > 0 || base == 0 || lo == base - 1;
             const bool hi_ok = P < valid || base + valid >= n || hi == base + valid;
             const bool found = lo_ok && hi_ok;
+            // exact prefix length of a slot of the current window (noting it as needed when it is still unknown)
+            auto cur_lcp = [&](int s) -> int {
+                if (!((known >> s) & 1u) && need_w < 0) { need_w = wcur; need_s = s; }
+                return lcp_at(wcur, s);
+            };
 
             // ---- resolve (into temporaries: nothing is committed before the evaluation is known to be complete) ----------
-            bool go_level = false, c_finished = false, c_park = false, c_moved = false;
+            bool go_level = false, c_finished = false, c_park = false;
             int L = 0, nb_lo = 0, nb_hi = 0, lf = 0;
             i64 s_edge = 0, e_edge = 0, cb = base;
             unsigned cknown = known;                             // the cached partition window's bookkeeping
             int cwhich = wcur, cvalid = valid;
-            bool cspec = spec;
+            bool cspec = spec, same_cache = true;
             i64 n_lo = lo, n_hi = hi, n_base = base;
             int n_lo_lcp = lo_lcp, n_hi_lcp = hi_lcp, n_stepk = stepk, n_phase = phase;
             if (found) {
                 // prefix lengths of the two slots around the flip (in the window, or remembered with the bracket)
-                const int lm = P > 0 ? slot_lcp(wcur, known, P - 1) : (f > 0 ? lo_lcp : -1);
-                const int lp = P < valid ? slot_lcp(wcur, known, P) : (f < n ? hi_lcp : -1);
+                const int lm = P > 0 ? cur_lcp(P - 1) : (f > 0 ? lo_lcp : -1);
+                const int lp = P < valid ? cur_lcp(P) : (f < n ? hi_lcp : -1);
                 if (phase == PH_PART) {
                     // slots below f sort before the query; the longest match is at one of the two boundary neighbours
                     L = lm >= lp ? lm : lp;
@@ -837,29 +924,28 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                         go_level = true;
                     }
                 } else {
-                    L = ST(ST_L); lf = ST(ST_LF);
+                    { const int cc = ST(ST_WALK); L = cc & 1023; lf = (cc >> 10) & 7; cwhich = (cc >> 16) & 1; cvalid = (cc >> 17) & 31; cspec = (cc >> 22) & 1; }
                     { const int nb = ST(ST_NB); nb_lo = nb & 0xffff; nb_hi = (int)((unsigned)nb >> 16); }
                     s_edge = LD64(ST_SE_LO); e_edge = LD64(ST_EE_LO); cb = LD64(ST_CB_LO);
-                    { const int cc = ST(ST_CACHE); cwhich = (cc >> 16) & 1; cvalid = (cc >> 17) & 31; cspec = (cc >> 22) & 1; }
-                    cknown = km >> 16;
+                    cknown = km >> 16; same_cache = false;
                     if (phase == PH_EDGE_DN) { s_edge = f; nb_lo = f > 0 ? lm : 0; lf &= ~LF_NEED_LO; }
                     else { e_edge = f - 1; nb_hi = f < n ? lp : 0; lf &= ~LF_NEED_HI; }
                     go_level = true;
                 }
             } else {
                 // move the bracket, remembering the prefix length of its new end
-                if (P == valid) { n_lo = base + valid - 1; n_lo_lcp = slot_lcp(wcur, known, valid - 1); }
-                else { n_hi = base; n_hi_lcp = slot_lcp(wcur, known, 0); }
+                if (P == valid) { n_lo = base + valid - 1; n_lo_lcp = cur_lcp(valid - 1); }
+                else { n_hi = base; n_hi_lcp = cur_lcp(0); }
                 bool stop = false;
                 if (phase != PH_PART && !q_exact) {
                     // the interval is not emitted at the level where the walk stops (left extensions, third round): it is
                     // enough to know that it reached min_intv suffixes
                     s_edge = LD64(ST_SE_LO); e_edge = LD64(ST_EE_LO);
                     if (phase == PH_EDGE_DN ? (e_edge - n_hi + 1 >= (i64)min_intv) : (n_lo - s_edge + 1 >= (i64)min_intv)) {
-                        L = ST(ST_L); lf = ST(ST_LF); cb = LD64(ST_CB_LO);
+                        cb = LD64(ST_CB_LO);
+                        { const int cc = ST(ST_WALK); L = cc & 1023; lf = (cc >> 10) & 7; cwhich = (cc >> 16) & 1; cvalid = (cc >> 17) & 31; cspec = (cc >> 22) & 1; }
                         { const int nb = ST(ST_NB); nb_lo = nb & 0xffff; nb_hi = (int)((unsigned)nb >> 16); }
-                        { const int cc = ST(ST_CACHE); cwhich = (cc >> 16) & 1; cvalid = (cc >> 17) & 31; cspec = (cc >> 22) & 1; }
-                        cknown = km >> 16;
+                        cknown = km >> 16; same_cache = false;
                         if (phase == PH_EDGE_DN) { s_edge = n_hi; nb_lo = L; lf &= ~LF_NEED_LO; }
                         else { e_edge = n_lo; nb_hi = L; lf &= ~LF_NEED_HI; }
                         stop = go_level = true;
@@ -871,33 +957,48 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                     else if (n_hi >= n) { tgt = n_lo + 1 + (((i64)WIN << stepk) - WIN); n_stepk = stepk + 1; if (tgt > n - 1) tgt = n - 1; }   // gallop up
                     else tgt = n_lo + (n_hi - n_lo) / 2;                                                                       // bisect (hi - lo >= 2 here)
                     n_base = tgt & ~(i64)(WIN - 1);
-                    c_moved = true;
                 }
             }
-            if (go_level) {
+            if (go_level && need_w < 0) {
                 // Walk the levels L0 > L1 > ... on the cached partition window [cb, cb + cvalid): the run of slots sharing
-                // >= L bases with the query is contiguous around the partition point and the lengths are monotone on
-                // either side of it, so every step is a binary search over at most 16 cached lengths.  An edge that leaves
-                // the cached window becomes an edge request.
-                while (need_w < 0) {
+                // >= L bases with the query is contiguous around the partition point, so an edge is the nearest slot on that
+                // side that does not reach the level -- one mask, one bit scan.  An edge that leaves the cached window
+                // becomes an edge request.
+                unsigned dc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dc[i] = dcur[i];
+                if (!same_cache) {
+                    const lds_u32x4 lp4 = (lds_u32x4)&LCb[((cwhich * 64 + lane) << 4)];
+                    const u32x4 x0 = lp4[0], x1 = lp4[1];
+                    dc[0] = x0.x; dc[1] = x0.y; dc[2] = x0.z; dc[3] = x0.w; dc[4] = x1.x; dc[5] = x1.y; dc[6] = x1.z; dc[7] = x1.w;
+                }
+                const unsigned cvm = (unsigned)lowmask(cvalid), cunk = ~cknown & cvm;
+                for (;;) {
                     if (lf & (LF_NEED_LO | LF_NEED_HI)) {
+                        const unsigned gp = ge16(dc, L);                     // pessimistic: an unknown tie does not reach L > 32
+                        const unsigned go = L > 32 ? (gp | cunk) : gp;       // optimistic
                         if (lf & LF_NEED_LO) {
                             const i64 klo = s_edge - cb;              // cached slots [0, klo) lie below the current edge
                             if (klo > 0 && klo <= cvalid) {
-                                const int z = first_ge(cwhich, cknown, 0, (int)klo, L, cspec);
-                                if (z > 0) { s_edge = cb + z; nb_lo = slot_lcp(cwhich, cknown, z - 1); lf &= ~LF_NEED_LO; }
+                                const unsigned below = (unsigned)lowmask((int)klo);
+                                const unsigned mp = ~gp & below, mo = ~go & below;
+                                const int zp = mp ? 32 - __clz((int)mp) : 0, zo = mo ? 32 - __clz((int)mo) : 0;
+                                if (zp != zo) { need_w = cwhich; need_s = pick(cunk & below, zo, zp); break; }
+                                if (zp > 0) { s_edge = cb + zp; nb_lo = lcp_at(cwhich, zp - 1); lf &= ~LF_NEED_LO; }
                                 else { s_edge = cb; if (cb == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; } }
                             } else if (s_edge == 0) { nb_lo = 0; lf &= ~LF_NEED_LO; }
                         }
                         if (lf & LF_NEED_HI) {
                             const i64 khi = e_edge - cb;              // cached slots (khi, cvalid) lie above it
                             if (khi >= -1 && khi < cvalid - 1) {
-                                const int z = first_lt(cwhich, cknown, (int)khi + 1, cvalid, L, cspec);
-                                if (z < cvalid) { e_edge = cb + z - 1; nb_hi = slot_lcp(cwhich, cknown, z); lf &= ~LF_NEED_HI; }
+                                const unsigned above = cvm & ~(unsigned)lowmask((int)khi + 1);
+                                const unsigned mp = ~gp & above, mo = ~go & above;
+                                const int zp = mp ? __ffs((int)mp) - 1 : cvalid, zo = mo ? __ffs((int)mo) - 1 : cvalid;
+                                if (zp != zo) { need_w = cwhich; need_s = pick(cunk & above, zp, zo); break; }
+                                if (zp < cvalid) { e_edge = cb + zp - 1; nb_hi = lcp_at(cwhich, zp); lf &= ~LF_NEED_HI; }
                                 else { e_edge = cb + cvalid - 1; if (cb + cvalid >= n) { nb_hi = 0; lf &= ~LF_NEED_HI; } }
                             } else if (e_edge == n - 1) { nb_hi = 0; lf &= ~LF_NEED_HI; }
                         }
-                        if (need_w >= 0) break;
                         if (lf & LF_NEED_LO) {                            // the run leaves the cached window: edge request
                             n_phase = PH_EDGE_DN; n_lo = -1; n_hi = s_edge; n_hi_lcp = L; n_stepk = 1;
                             n_base = (s_edge - 1) & ~(i64)(WIN - 1);
@@ -946,21 +1047,19 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                 lo = n_lo; hi = n_hi; lo_lcp = n_lo_lcp; hi_lcp = n_hi_lcp; stepk = n_stepk; base = n_base;
                 tx |= TX_FRESH;                                   // the next iteration loads the window at `base`
                 if (c_park) {
-                    // park the walk; the edge windows go to the other LCP array, the cache stays
+                    // park the walk; the edge windows go to the other LCP array, the cache stays.  The cache's bookkeeping
+                    // mask lives in km bits 16..31 while edges are followed.
                     phase = n_phase;
                     capc = L;
-                    ST(ST_L) = L; ST(ST_NB) = (nb_lo & 0xffff) | (nb_hi << 16); ST(ST_LF) = lf;
+                    ST(ST_NB) = (nb_lo & 0xffff) | (nb_hi << 16);
                     ST64(ST_SE_LO, s_edge); ST64(ST_EE_LO, e_edge); ST64(ST_CB_LO, cb);
-                    ST(ST_CACHE) = (cwhich << 16) | (cvalid << 17) | ((cspec ? 1 : 0) << 22);
-                    if (cwhich == wcur && phase != PH_CTRL && (km >> 16) != cknown) {}   // (bookkeeping below)
-                    // the cache's bookkeeping mask lives in km bits 16..31 while edges are followed
+                    ST(ST_WALK) = L | (lf << 10) | (cwhich << 16) | (cvalid << 17) | ((cspec ? 1 : 0) << 22);
                     km = (km & 0xffffu) | (cknown << 16);
                     which = cwhich ^ 1;
-                } else if (!c_moved) {
-                    // (unreachable: an evaluation either finishes, parks, moves the window or needs a text compare)
                 }
             }
         }
+        PROF_MARK(6);
         if (finished) {
             // ---- apply the search result to the read's pivot logic ------------------------------------------------------
             bool emit = false;
@@ -974,10 +1073,10 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
                 break;
             case K_ZZ_LEFT:           // (:1774-1777)
                 pivot = pivot - r_L + 1;
-                pc = (ST(ST_ZZ_NEXT) - pivot < msl) ? PC_ZZ_END : PC_ZZ_RIGHT;
+                pc = ((ST(ST_ZZ) >> 16) - pivot < msl) ? PC_ZZ_END : PC_ZZ_RIGHT;
                 break;
             case K_OP_MEM:            // (:1967-1969)
-                ST(ST_ZZ_NEXT) = pivot + r_L; flags = F_ZZ_RET_ONEPOS; ST(ST_ZZ_SP) = pivot; ST(ST_ZZ_GUARD) = 0;
+                ST(ST_ZZ) = pivot | ((pivot + r_L) << 16); flags = F_ZZ_RET_ONEPOS; ST(ST_GUARDS) = ST(ST_GUARDS) & ~0xffff;
                 pc = PC_ZZ_TOP;
                 break;
             default:                  // K_R3 (:1204-1208, :1265-1281)
@@ -987,12 +1086,18 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             if (emit) {               // kv_push of mem_tl + hits (:2639-2657, :1266-1277)
                 const int ns = ST(ST_N_SMEMS);
                 if (ns < cap) {
-                    const unsigned long long ticket = ((unsigned long long)(unsigned)ST(ST_TICKET_HI) << 32) | (unsigned)ST(ST_TICKET_LO);
+                    const unsigned long long ticket = (unsigned long long)(unsigned)ST(ST_TICKET);
                     SlotRec sr;
                     sr.start = e_start; sr.end = e_end; sr.sa_start = r_start; sr.count = r_count;
                     A.slots[(i64)ticket * cap + ns] = sr;
                 }
                 ST(ST_N_SMEMS) = ns + 1;
+                {
+                    const int d = ns - ST(ST_BEFORE);
+                    const int cc = r_count > (i64)INT_MAX ? INT_MAX : (int)r_count;
+                    if (d == 0) { ST(ST_RING_SE0) = e_start | (e_end << 16); ST(ST_RING_C0) = cc; }
+                    else if (d == 1) { ST(ST_RING_SE1) = e_start | (e_end << 16); ST(ST_RING_C1) = cc; }
+                }
                 i64 h = r_count;
                 if (hits_per_smem > 0 && h > hits_per_smem) h = hits_per_smem;
                 h += LD64(ST_HITS_LO);
@@ -1000,14 +1105,19 @@ __global__ void __launch_bounds__(BLOCK, SEED_MIN_WAVES) k_seed(SeedArgs A) {
             }
             switch (q_kind) {
             case K_S1_RIGHT: pivot = pivot + r_L; pc = PC_AFTER_STEP1; break;
-            case K_ZZ_RIGHT: pivot = pivot + r_L; ST(ST_ZZ_SP) = pivot; pc = PC_ZZ_TOP; break;
+            case K_ZZ_RIGHT: pivot = pivot + r_L; ST(ST_ZZ) = (ST(ST_ZZ) & ~0xffff) | pivot; pc = PC_ZZ_TOP; break;
             case K_OP_SMEM: pivot = pivot + r_L; pc = PC_R2_AFTER; break;
             case K_R3: pivot = pivot + (r_L < msl ? msl : r_L); pc = PC_R3_TOP; break;
             default: break;
             }
             phase = PH_CTRL;
         }
+        PROF_MARK(7);
     }
+#ifdef SEED_PROF
+    if (lane == 0) for (int k = 0; k < 10; ++k) atomicAdd(&A.counters[5 + k], prof[k]);
+#endif
+#undef PROF_MARK
     for (int d = 32; d >= 1; d >>= 1) {
         acc_searches += (unsigned)__shfl_xor((int)acc_searches, d);
         acc_windows += (unsigned)__shfl_xor((int)acc_windows, d);

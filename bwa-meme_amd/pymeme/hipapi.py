@@ -153,6 +153,10 @@ class Context:
         _check(lib().meme_index_describe(C.c_void_p(self.h), C.byref(a)))
         return a
 
+    def replicate_index_from(self, src: "Context"):
+        """meme_index_replicate: device-to-device copy of src's staged index (same device: shared)."""
+        _check(lib().meme_index_replicate(C.c_void_p(self.h), C.c_void_p(src.h)))
+
     def set_tuning(self, key, value):
         _check(lib().meme_set_tuning(C.c_void_p(self.h), key.encode(), C.c_int64(value)))
 
@@ -250,6 +254,7 @@ def stage_index_torch(ctx, n, d_text, d_pos5, d_l2_24, n_l2, d_l1_24, n_l1):
     import torch
     L = lib()
     dev = d_text.device
+    torch.cuda.synchronize(dev)     # the images were filled on torch's stream; the staging kernels run on the ctx's own stream
     d_pac = torch.empty(L.meme_index_pac64_words(n), dtype=torch.int64, device=dev)
     d_keys = torch.empty(L.meme_index_key_words(n), dtype=torch.int64, device=dev)
     d_l2 = torch.empty(n_l2 * 32, dtype=torch.uint8, device=dev)
@@ -272,6 +277,7 @@ def pos5_from_sa_torch(ctx, d_sa, n):
     import torch
     L = lib()
     d_pos5 = torch.zeros(L.meme_index_pos5_bytes(n), dtype=torch.uint8, device=d_sa.device)
+    torch.cuda.synchronize(d_sa.device)     # (the zero fill and the upload of d_sa ran on torch's stream, the kernel runs on the ctx's)
     _check(L.meme_stage_pos5_from_sa(C.c_void_p(ctx.h), C.c_void_p(d_sa.data_ptr()), C.c_int64(n),
                                      C.c_void_p(d_pos5.data_ptr())))
     ctx.sync()

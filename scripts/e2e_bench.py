@@ -38,12 +38,15 @@ res = {}
 for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
     out = os.path.join(d, exe + ".sam")
     env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1")
+    if os.environ.get("E2E_BSW_TRACE"): env["MEME_BSW_TRACE"] = "1"
     t0 = time.time()
     with open(out, "wb") as fh:
         r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
     wall = time.time() - t0
     err = r.stderr.decode()
-    keys = [l for l in err.split("\n") if any(k in l for k in ("Runtime-build-index", "Total kernel", "LEARNED", "BSW time", "SAM Processing", "Overall time", "total time", "Loading", "meme-dropin"))]
+    if os.environ.get("E2E_STDERR_DIR"):
+        open(os.path.join(os.environ["E2E_STDERR_DIR"], exe + ".stderr"), "w").write(err)
+    keys = [l for l in err.split("\n") if any(k in l for k in ("Runtime-build-index", "Total kernel", "LEARNED", "BSW time", "SAM Processing", "Overall time", "total time", "Loading", "meme-dropin", "meme bsw"))]
     h = hashlib.md5()
     nlines = 0
     with open(out, "rb") as fh:

@@ -92,3 +92,18 @@ def test_hip_bsw_scores_beyond_14_bits_and_mixed_lengths(ctx):
     got = pairs.copy()
     ctx.bsw_batch(got, ref, qer, 100, _opt(5))
     assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want))
+
+
+def test_hip_bsw_queries_beyond_the_lds_resident_limit(ctx):
+    """getScores16's class reaches 32 k bases (src/bandedSWA.h:47-86): queries of 5-9 k bases keep their DP rows in an HBM
+    workspace instead of LDS; a mixed batch (short pairs alongside) exercises both storage modes of one launch sequence."""
+    a, ra, qa = bsw_gen.make_pairs(6, seed=31, min_q=5000, max_q=9000, h0_max=100)
+    b, rb, qb = bsw_gen.make_pairs(200, seed=32, max_q=300)
+    b = b.copy(); b["idr"] += ra.shape[0]; b["idq"] += qa.shape[0]
+    pairs = np.concatenate([a, b]); ref = np.concatenate([ra, rb]); qer = np.concatenate([qa, qb])
+    for w in (100, 500):
+        want = pairs.copy()
+        O.bsw_batch(want, ref, qer, w, O.default_bsw_params(5), threads=0)
+        got = pairs.copy()
+        ctx.bsw_batch(got, ref, qer, w, _opt(5))
+        assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want)), w
