@@ -20,7 +20,7 @@ with the HIP backend bound in, next to the unmodified reference on the same host
 
 Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 3100), MEME_BENCH_READS (reads per GPU
 per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's rule),
-MEME_BENCH_WAVES (resident wavefronts per CU of the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the
+MEME_BENCH_LANES (lanes per read in the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the
 compiled reference, timed in this run), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables the /dev/shm caches),
 MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
 2,000,000), MEME_BENCH_BUDGET_S (wall budget in seconds after which optional legs are skipped, default 1500).
@@ -308,7 +308,7 @@ def main():
         except ImportError:
             pass
         gpu_free = torch.cuda.mem_get_info(local)[0]
-        while mbp > 64 and 2 * mbp * 1e6 * 30 + nreads * 2200 > 0.9 * gpu_free:
+        while mbp > 64 and 2 * mbp * 1e6 * 33 + nreads * 2200 > 0.9 * gpu_free:
             mbp /= 2
             log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
     l_pac_t = torch.tensor([int(mbp * 1e6) & ~1], dtype=torch.int64, device=dev)
@@ -359,8 +359,8 @@ def main():
     n_l2, n_l1 = int(meta[1]), int(meta[2])
     t0 = time.time()
     ctx = hipapi.Context(local)
-    if os.environ.get("MEME_BENCH_WAVES"):
-        ctx.set_tuning("seed_waves_per_cu", int(os.environ["MEME_BENCH_WAVES"]))
+    if os.environ.get("MEME_BENCH_LANES"):
+        ctx.set_tuning("group_lanes", int(os.environ["MEME_BENCH_LANES"]))
     L = hipapi.lib()
     d_text = torch.empty(n, dtype=torch.uint8, device=dev)
     d_pos5 = torch.zeros(L.meme_index_pos5_bytes(n), dtype=torch.uint8, device=dev)
@@ -383,9 +383,9 @@ def main():
             dist.broadcast(t, 0)
     torch.cuda.synchronize()
     keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, n_l2, d_l1, n_l1)
-    del d_text, d_l2, d_l1
+    del d_text, d_l2, d_l1, d_pos5
     torch.cuda.empty_cache()
-    log("index staged in HBM in %.1f s (%.2f GB keys + %.2f GB positions)" % (time.time() - t0, 8 * n / 1e9, 5 * n / 1e9))
+    log("index staged in HBM in %.1f s (%.2f GB entries)" % (time.time() - t0, 16 * n / 1e9))
 
     # ---- reads: every rank samples its own batch ------------------------------------------------------
     genome_t = torch.empty(l_pac, dtype=torch.uint8, device=dev)
@@ -415,7 +415,7 @@ def main():
     for _ in range(a.warmup):
         res = step()
     kernel_ms = []
-    windows = text_compares = 0
+    windows = 0
     rc_exit = 0
     barrier()
     t0 = time.perf_counter()
@@ -424,7 +424,6 @@ def main():
         tm = ctx.timings()
         kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms))
         windows = tm.seed_windows
-        text_compares = tm.seed_text_compares
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -466,7 +465,6 @@ def main():
                        "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
                        "searches_per_read": res.searches / nreads,
                        "windows_per_search": windows / max(res.searches, 1),
-                       "text_compares_per_search": text_compares / max(res.searches, 1),
                        "sample_parity_with_oracle": bool(sample_parity),
                        "sample_parity_check": "full seed dump of %d of the benchmark's reads vs orc_seed_batch" % ns},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -539,7 +537,7 @@ def main():
                     del text, sa
                     ctx.close()
                     ctx = None
-                    del keep, d_reads, d_off, d_pos5
+                    del keep, d_reads, d_off
                     torch.cuda.empty_cache()
                     out["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_E2E_PAIRS", "2000000")), cores)
                 except Exception as e:

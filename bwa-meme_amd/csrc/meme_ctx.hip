@@ -81,7 +81,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->slots[3], &ctx->ovf[0],
+    DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
                       &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws};
@@ -114,7 +114,10 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
-    else if (!strcmp(key, "seed_waves_per_cu")) ctx->seed_waves_per_cu = value < 0 ? 0 : value;
+    else if (!strcmp(key, "group_lanes")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) { meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG; }
+        ctx->group_lanes = value;
+    } else if (!strcmp(key, "seed_blocks_per_cu")) ctx->seed_blocks_per_cu = value < 1 ? 1 : value;
     else { meme_set_error("unknown tuning key %s", key); return MEME_E_ARG; }
     return MEME_OK;
 }
@@ -123,9 +126,7 @@ static unsigned stage_blocks(i64 items);
 extern "C" int meme_index_share(meme_ctx* ctx, meme_ctx* owner);
 // ---- staging kernels ---------------------------------------------------------------------------------
 extern "C" int64_t meme_index_pac64_words(int64_t sa_num) { return ((sa_num + 31) >> 5) + 8; }
-extern "C" int64_t meme_index_key_words(int64_t sa_num) { return ((sa_num + 15) & ~(int64_t)15) + 16; }
 extern "C" int64_t meme_index_pos5_bytes(int64_t sa_num) { return sa_num * 5 + 16; }
-extern "C" int64_t meme_index_special_bytes(void) { return (int64_t)SPECIAL_SLOTS * 4; }
 
 // one thread per output word: 32 text bytes -> one u64, first base in the top bits; T past the end
 __global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ text, i64 n, u64* __restrict__ pac, i64 words) {
@@ -154,30 +155,21 @@ __global__ void __launch_bounds__(256) k_pack_text(const uint8_t* __restrict__ t
   }
 }
 
-// key array + the hash set of "special" window lines, from the 5-byte position image (replaces the OpenMP expansion loop
-// of src/fastmap.cpp:549-613: 13-byte entries + inverse suffix array on the host)
-__global__ void __launch_bounds__(256) k_build_keys(const uint8_t* __restrict__ pos5, i64 n, i64 key_words, const u64* __restrict__ pac,
-                                                     u64* __restrict__ keys, uint32_t* __restrict__ special) {
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < key_words; i += (i64)gridDim.x * blockDim.x) {
-    u64 key = ~0ull;
-    if (i < n) {
-        const u64 pos = load_pos5(pos5, i);
-        key = extract32(pac, (i64)pos);   // the pad words make this "T-filled past the text end"
-        if ((i64)pos > n - SPECIAL_SPAN) {
-            const uint32_t line = (uint32_t)(i >> 4);
-            uint32_t h = (line * 2654435761u) >> 20;
-            for (;;) {
-                const uint32_t old = atomicCAS(&special[h], 0u, line + 1u);
-                if (old == 0u || old == line + 1u) break;
-                h = (h + 1u) & (uint32_t)(SPECIAL_SLOTS - 1);
-            }
-        }
-    }
-    keys[i] = key;
+// probe-ready entries {64-bit key, text position} from the 5-byte position image (or a u64 suffix array): replaces the
+// OpenMP expansion loop of src/fastmap.cpp:549-613 (13-byte entries + inverse suffix array on the host)
+__global__ void __launch_bounds__(256) k_build_entries(const uint8_t* __restrict__ pos_packed, const u64* __restrict__ sa_u64,
+                                                        i64 n, const u64* __restrict__ pac, SaEnt* __restrict__ ent) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const u64 pos = sa_u64 ? sa_u64[i] : load_pos5(pos_packed, i);
+    SaEnt e;
+    e.key = extract32(pac, (i64)pos);   // the pad words make this "T-filled past the text end"
+    e.pos = pos;
+    ent[i] = e;
   }
 }
 
-// 8-byte suffix array -> the 5-byte on-disk image (hosts that hold the array as u64, e.g. bench.py's builder)
+// 8-byte suffix array -> the 5-byte on-disk image (hosts that hold the array as u64, e.g. bench.py's builder; the image is
+// what a multi-GPU start-up broadcasts: 5 instead of 8 bytes per suffix)
 __global__ void __launch_bounds__(256) k_pos5_from_sa(const u64* __restrict__ sa, i64 n, uint8_t* __restrict__ pos5) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
     const u64 pos = sa[i];
@@ -207,14 +199,22 @@ extern "C" int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text, int64_
     return MEME_OK;
 }
 
-extern "C" int meme_stage_build_keys(meme_ctx* ctx, const uint8_t* d_pos5, int64_t n, const void* d_pac64, void* d_keys,
-                                     void* d_special) {
-    if (!ctx || !d_pos5 || !d_pac64 || !d_keys || !d_special || n <= 0) return MEME_E_ARG;
+extern "C" int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t n, const void* d_pac64,
+                                        void* d_sa_ent) {
+    if (!ctx || !d_pos_packed || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(d_special, 0, (size_t)SPECIAL_SLOTS * 4, ctx->stream));
-    const i64 kw = meme_index_key_words(n);
-    hipLaunchKernelGGL(k_build_keys, dim3(stage_blocks(kw)), dim3(256), 0, ctx->stream, d_pos5, (i64)n, kw,
-                       (const u64*)d_pac64, (u64*)d_keys, (uint32_t*)d_special);
+    hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream, d_pos_packed,
+                       (const u64*)nullptr, (i64)n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
+extern "C" int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t n, const void* d_pac64,
+                                          void* d_sa_ent) {
+    if (!ctx || !d_sa || !d_pac64 || !d_sa_ent || n <= 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream,
+                       (const uint8_t*)nullptr, (const u64*)d_sa, (i64)n, (const u64*)d_pac64, (SaEnt*)d_sa_ent);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
 }
@@ -282,42 +282,37 @@ extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, in
     drop_index(ctx);
     int rc = set_rmi(ctx, l2_bytes / 24, l1_bytes / 24);
     if (rc) return rc;
-    const i64 words = meme_index_pac64_words(n), kw = meme_index_key_words(n);
+    const i64 words = meme_index_pac64_words(n);
     const i64 n_l2 = l2_bytes / 24, n_l1 = l1_bytes / 24;
-    void *d_keys = nullptr, *d_pos5 = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_spec = nullptr, *d_tmp = nullptr;
-    if ((rc = own_alloc(ctx, &d_keys, (size_t)kw * 8))) return rc;
-    if ((rc = own_alloc(ctx, &d_pos5, (size_t)meme_index_pos5_bytes(n)))) return rc;
+    void *d_ent = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_tmp = nullptr;
+    if ((rc = own_alloc(ctx, &d_ent, (size_t)n * sizeof(SaEnt)))) return rc;
     if ((rc = own_alloc(ctx, &d_pac, (size_t)words * 8))) return rc;
     if ((rc = own_alloc(ctx, &d_l2, (size_t)n_l2 * 32))) return rc;
     if ((rc = own_alloc(ctx, &d_l1, (size_t)(n_l1 > 0 ? n_l1 : 1) * 32))) return rc;
-    if ((rc = own_alloc(ctx, &d_spec, (size_t)SPECIAL_SLOTS * 4))) return rc;
-    // staging buffer for the text bytes and the 24-byte parameter records
-    size_t tmp_bytes = (size_t)n + 64;
+    // staging buffer: the 5-byte position image (the largest input), reused for the text bytes and the parameter records
+    size_t tmp_bytes = (size_t)meme_index_pos5_bytes(n);
     if ((size_t)l2_bytes > tmp_bytes) tmp_bytes = (size_t)l2_bytes;
     if ((size_t)l1_bytes > tmp_bytes) tmp_bytes = (size_t)l1_bytes;
     HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
     auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d_tmp); return code; };
     if (hipMemcpyAsync(d_tmp, text, (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     if ((rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac))) return fail(rc);
-    if (hipMemcpyAsync(d_pos5, pos_packed, (size_t)n * 5, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
-    if (hipMemsetAsync((uint8_t*)d_pos5 + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
-    if ((rc = meme_stage_build_keys(ctx, (const uint8_t*)d_pos5, n, d_pac, d_keys, d_spec))) return fail(rc);
+    if (hipMemcpyAsync(d_tmp, pos_packed, (size_t)n * 5, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if (hipMemsetAsync((uint8_t*)d_tmp + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent))) return fail(rc);
     if (hipMemcpyAsync(d_tmp, l2, (size_t)l2_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l2, d_l2))) return fail(rc);
     if (n_l1 > 0) {
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);   // d_tmp is reused
         if (hipMemcpyAsync(d_tmp, l1, (size_t)l1_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
         if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l1, d_l1))) return fail(rc);
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(d_tmp));
     ctx->idx.n = n;
-    ctx->idx.keys = (const u64*)d_keys;
-    ctx->idx.pos5 = (const uint8_t*)d_pos5;
+    ctx->idx.sa = (const SaEnt*)d_ent;
     ctx->idx.pac = (const u64*)d_pac;
     ctx->idx.l2 = (const Rmi32*)d_l2;
     ctx->idx.l1 = (const Rmi32*)d_l1;
-    ctx->idx.special = (const uint32_t*)d_spec;
     return MEME_OK;
 }
 
@@ -346,37 +341,34 @@ extern "C" int meme_index_load_files(meme_ctx* ctx, const char* prefix) {
         meme_set_error("%s: .pos_packed (%zu B) and .0123 (%zu B) disagree on the suffix count", prefix, pos.size(), text.size());
         return MEME_E_IO;
     }
+    pos.resize(pos.size() + 16);          // (the position image is read as aligned dwords around each 5-byte record)
     return meme_index_load_host(ctx, pos.data(), (int64_t)text.size(), text.data(), l1.data(), (int64_t)l1.size(),
                                 l2.data(), (int64_t)l2.size());
 }
 
 extern "C" int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* a) {
-    if (!ctx || !a || !a->d_keys || !a->d_pos5 || !a->d_pac64 || !a->d_l2 || !a->d_special || a->sa_num < 64) return MEME_E_ARG;
+    if (!ctx || !a || !a->d_sa_ent || !a->d_pac64 || !a->d_l2 || a->sa_num < 64) return MEME_E_ARG;
     drop_index(ctx);
     int rc = set_rmi(ctx, a->l2_records, a->l1_records);
     if (rc) return rc;
     ctx->idx.n = a->sa_num;
-    ctx->idx.keys = (const u64*)a->d_keys;
-    ctx->idx.pos5 = (const uint8_t*)a->d_pos5;
+    ctx->idx.sa = (const SaEnt*)a->d_sa_ent;
     ctx->idx.pac = (const u64*)a->d_pac64;
     ctx->idx.l2 = (const Rmi32*)a->d_l2;
     ctx->idx.l1 = (const Rmi32*)a->d_l1;
-    ctx->idx.special = (const uint32_t*)a->d_special;
     return MEME_OK;
 }
 
 extern "C" int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out) {
     if (!ctx || !out) return MEME_E_ARG;
-    if (!ctx->idx.keys) { meme_set_error("no index loaded"); return MEME_E_STATE; }
+    if (!ctx->idx.sa) { meme_set_error("no index loaded"); return MEME_E_STATE; }
     out->sa_num = ctx->idx.n;
-    out->d_keys = (void*)ctx->idx.keys;
-    out->d_pos5 = (void*)ctx->idx.pos5;
+    out->d_sa_ent = (void*)ctx->idx.sa;
     out->d_pac64 = (void*)ctx->idx.pac;
     out->d_l2 = (void*)ctx->idx.l2;
     out->l2_records = ctx->idx.n_l2;
     out->d_l1 = (void*)ctx->idx.l1;
     out->l1_records = ctx->idx.n_l1;
-    out->d_special = (void*)ctx->idx.special;
     return MEME_OK;
 }
 
@@ -385,7 +377,7 @@ extern "C" int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out) {
 // reference's kt_for threads).
 extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
     if (!dst || !src || dst == src) return MEME_E_ARG;
-    if (!src->idx.keys) { meme_set_error("meme_index_replicate: source has no index"); return MEME_E_STATE; }
+    if (!src->idx.sa) { meme_set_error("meme_index_replicate: source has no index"); return MEME_E_STATE; }
     if (dst->device == src->device) return meme_index_share(dst, src);
     if (!src->owns_index) { meme_set_error("meme_index_replicate: the source ctx must own its index (load_host / load_files)"); return MEME_E_STATE; }
     HIP_TRY(hipSetDevice(dst->device));
@@ -399,12 +391,10 @@ extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
         int rc = own_alloc(dst, &d, o.second);
         if (rc) return rc;
         HIP_TRY(hipMemcpyPeerAsync(d, dst->device, o.first, src->device, o.second, dst->stream));
-        if ((const void*)I.keys == o.first) I.keys = (const u64*)d;
-        if ((const void*)I.pos5 == o.first) I.pos5 = (const uint8_t*)d;
+        if ((const void*)I.sa == o.first) I.sa = (const SaEnt*)d;
         if ((const void*)I.pac == o.first) I.pac = (const u64*)d;
         if ((const void*)I.l2 == o.first) I.l2 = (const Rmi32*)d;
         if ((const void*)I.l1 == o.first) I.l1 = (const Rmi32*)d;
-        if ((const void*)I.special == o.first) I.special = (const uint32_t*)d;
     }
     HIP_TRY(hipStreamSynchronize(dst->stream));
     dst->idx = I;
@@ -413,7 +403,7 @@ extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
 
 extern "C" int meme_index_share(meme_ctx* ctx, meme_ctx* owner) {
     if (!ctx || !owner || ctx->device != owner->device) return MEME_E_ARG;
-    if (!owner->idx.keys) { meme_set_error("owner has no index"); return MEME_E_STATE; }
+    if (!owner->idx.sa) { meme_set_error("owner has no index"); return MEME_E_STATE; }
     drop_index(ctx);
     ctx->idx = owner->idx;
     return MEME_OK;

@@ -104,13 +104,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_offsets(const int* __restrict__ 
 }
 
 // ---- compaction + hit gather: one 16-lane group per read --------------------------------------------------
-constexpr int GATHER_BLOCK = 256;
 struct TierTable {
     const SlotRec* base[N_TIERS];
     int cap[N_TIERS];
 };
 
-__global__ void __launch_bounds__(GATHER_BLOCK) k_gather(const uint8_t* __restrict__ pos5, TierTable tiers, const i64* __restrict__ slot_loc,
+__global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, TierTable tiers, const i64* __restrict__ slot_loc,
                                                    const int* __restrict__ cnt, i64 n, int hits_per_smem,
                                                    const i64* __restrict__ smem_off, const i64* __restrict__ hit_off,
                                                    meme_mem_tl* __restrict__ smems, u64* __restrict__ hits) {
@@ -120,8 +119,8 @@ __global__ void __launch_bounds__(GATHER_BLOCK) k_gather(const uint8_t* __restri
     const int lane = threadIdx.x & 63;
     const int t = lane & (GL - 1);
     const int gbase = lane - t;
-    i64 gid = ((i64)blockIdx.x * GATHER_BLOCK + threadIdx.x) / GL;
-    const i64 ngroups = (i64)gridDim.x * GATHER_BLOCK / GL;
+    i64 gid = ((i64)blockIdx.x * BLOCK + threadIdx.x) / GL;
+    const i64 ngroups = (i64)gridDim.x * BLOCK / GL;
     for (i64 r = gid; r < n; r += ngroups) {
         const int c = cnt[r];
         if (c <= 0) continue;
@@ -149,7 +148,7 @@ __global__ void __launch_bounds__(GATHER_BLOCK) k_gather(const uint8_t* __restri
             const i64 hb = hb0 + incl - h;
             u64 first = 0;
             if (act) {
-                first = load_pos5(pos5, s.sa_start);
+                first = sa[s.sa_start].pos;
                 meme_mem_tl m;
                 m.start = s.start;
                 m.end = s.end;
@@ -158,7 +157,7 @@ __global__ void __launch_bounds__(GATHER_BLOCK) k_gather(const uint8_t* __restri
                 m.cache_refpos = first;
                 out[k] = m;
                 if (h > 0) hout[hb] = first;
-                for (i64 i = 1; i < h && i < 4; ++i) hout[hb + i] = load_pos5(pos5, s.sa_start + i);
+                for (i64 i = 1; i < h && i < 4; ++i) hout[hb + i] = sa[s.sa_start + i].pos;
             }
             // long hit lists: all lanes of the group copy them together
             u64 longmask = (__ballot(act && h > 4) >> gbase) & 0xffffull;
@@ -166,67 +165,73 @@ __global__ void __launch_bounds__(GATHER_BLOCK) k_gather(const uint8_t* __restri
                 const int src = __ffsll((long long)longmask) - 1;
                 longmask &= longmask - 1;
                 const i64 lh = __shfl(h, src, GL), lhb = __shfl(hb, src, GL), lsa = __shfl(s.sa_start, src, GL);
-                for (i64 i = 4 + t; i < lh; i += GL) hout[lhb + i] = load_pos5(pos5, lsa + i);
+                for (i64 i = 4 + t; i < lh; i += GL) hout[lhb + i] = sa[lsa + i].pos;
             }
             hb0 += __shfl(incl, GL - 1, GL);
         }
     }
 }
 
+template <int G>
+int launch_k_seed(meme_ctx* ctx, const SeedArgs& A, size_t lds, i64 blocks) {
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_seed<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_seed<G>, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
 int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, i64 max_len, i64 total_bytes,
                 const meme_seed_opt* opt, meme_seed_result* out) {
-    unsigned long long h_counters[16];
+    unsigned long long h_counters[12];
     int rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 12 * sizeof(unsigned long long)))) return rc;
     const int dev_cus = ctx->n_cus;
-    // ---- pack the reads: 2 bits/base, forward strand, N masks (k_pack_reads) ---------------------------------
+    // ---- pack the reads: 2 bits/base, both strands, N masks (k_pack_reads) ---------------------------------
     // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262): fail loudly, never seed part of a batch
     if (max_len > MAX_READ_LEN) {
         meme_set_error("read of %lld bases exceeds the learned-index limit of %d (LEARNED_MAX_READ_LEN)", (long long)max_len, MAX_READ_LEN);
         return MEME_E_ARG;
     }
     if (max_len < 1) max_len = 1;
+    const i64 stage_len = max_len;                                // longest read as staged by the packing kernel
     PackGeom geo;
-    geo.W = (int)((max_len + 31) / 32);
+    geo.W = (int)((max_len + 31) / 32) + 2;
     geo.MW = (int)((max_len + 63) / 64);
-    geo.stride = 1 + geo.W + geo.MW;
+    geo.stride = 2 * geo.W + 2 * geo.MW + 1;
     if ((rc = meme_buf_reserve(ctx, ctx->packed, (size_t)nreads * geo.stride * 8))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[6], ctx->stream));
     {
-        int rb = (int)((48 * 1024) / max_len);                      // reads per workgroup: <= 48 KB of staged bytes
+        int rb = (int)((48 * 1024) / stage_len);                    // reads per workgroup: <= 48 KB of staged bytes
         if (rb > 32) rb = 32;
         if (rb < 1) rb = 1;
         i64 pblocks = (nreads + rb - 1) / rb;
         if (pblocks > (i64)dev_cus * 16) pblocks = (i64)dev_cus * 16;   // grid-stride beyond that
-        size_t plds = ((size_t)rb * (size_t)max_len + 16 + 3) & ~(size_t)3;
+        size_t plds = ((size_t)rb * (size_t)stage_len + 16 + 3) & ~(size_t)3;
         hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)pblocks), dim3(256), plds, ctx->stream, d_reads,
                            d_read_off, nreads, total_bytes, geo, rb, (u64*)ctx->packed.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-    // ---- the search kernel: one wavefront per workgroup, as many resident wavefronts per CU as LDS and registers allow --
-    const size_t lds = seed_lds_bytes(geo.W);
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_seed, BLOCK, lds) != hipSuccess || per_cu < 1) per_cu = 8;
-    if (ctx->seed_waves_per_cu > 0 && ctx->seed_waves_per_cu < per_cu) per_cu = (int)ctx->seed_waves_per_cu;
     float ms_total = 0.f;
-    i64 launches = 0, searches = 0, windows = 0, deep = 0;
+    i64 launches = 0, searches = 0, windows = 0;
     TierTable tiers;
     for (int t = 0; t < N_TIERS; ++t) { tiers.base[t] = nullptr; tiers.cap[t] = 0; }
     i64 n_todo = nreads;
     const i64* pending = nullptr;
     for (int tier = 0;; ++tier) {
+        // overflow tiers hold a 512-entry SMEM ring per read in LDS: run them 32 lanes per read (8 reads per block)
+        int G = tier == 0 ? (int)ctx->group_lanes : 32;
         const int cap = tier == 0 ? (int)ctx->smem_cap : TIER_CAP[tier];
+        const int lcap = cap < TIER_LCAP[tier] ? cap : TIER_LCAP[tier];
         DevBuf& sb = ctx->slots[tier];
         DevBuf& ob = ctx->ovf[tier & 1];
         const size_t need = (size_t)n_todo * cap * sizeof(SlotRec);
         if (tier > 0 && need > sb.cap) {
-            // overflow tiers re-run the reads that emitted more SMEMs than their slots hold, with 8-128x more slots each:
+            // overflow tiers re-run the reads that emitted more SMEMs than their slots hold, with 32 x more slots each:
             // refuse instead of exhausting the HBM the index lives in
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2) {
@@ -238,10 +243,11 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         }
         if ((rc = meme_buf_reserve(ctx, sb, need))) return rc;
         if ((rc = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 12 * sizeof(unsigned long long), ctx->stream));
         SeedArgs A;
         A.I = ctx->idx;
         A.packed = (const u64*)ctx->packed.p;
+        A.read_off = d_read_off;
         A.nreads = n_todo;
         A.geo = geo;
         A.opt = *opt;
@@ -252,17 +258,29 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.pending = pending;
         A.ovf_list = (i64*)ob.p;
         A.cap = cap;
+        A.lcap = lcap;
         A.tier = tier;
         A.counters = (unsigned long long*)ctx->counters.p;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
-        i64 want = (n_todo + BLOCK - 1) / BLOCK;
-        i64 blocks = ctx->seed_blocks > 0 ? ctx->seed_blocks : (i64)dev_cus * per_cu;
+        while (G < 32 && seed_lds_bytes(G, geo, lcap) > (size_t)160 * 1024) G *= 2;   // long reads: fewer reads per workgroup
+        const int groups = BLOCK / G;
+        size_t lds = seed_lds_bytes(G, geo, lcap);
+        i64 want = (n_todo + groups - 1) / groups;
+        i64 blocks = ctx->seed_blocks > 0 ? ctx->seed_blocks : (i64)dev_cus * ctx->seed_blocks_per_cu;
         if (blocks > want) blocks = want;
         if (blocks < 1) blocks = 1;
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL(k_seed, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, A);
-        HIP_TRY(hipGetLastError());
+        switch (G) {
+        case 1: rc = launch_k_seed<1>(ctx, A, lds, blocks); break;
+        case 2: rc = launch_k_seed<2>(ctx, A, lds, blocks); break;
+        case 4: rc = launch_k_seed<4>(ctx, A, lds, blocks); break;
+        case 8: rc = launch_k_seed<8>(ctx, A, lds, blocks); break;
+        case 16: rc = launch_k_seed<16>(ctx, A, lds, blocks); break;
+        case 32: rc = launch_k_seed<32>(ctx, A, lds, blocks); break;
+        default: meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG;
+        }
+        if (rc) return rc;
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -271,17 +289,16 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         ms_total += ms;
         ++launches;
         searches += (i64)h_counters[1];
-        windows += (i64)h_counters[3];
-        deep += (i64)h_counters[4];
 #ifdef SEED_PROF
         {
-            double tot = 0; for (int k = 0; k < 10; ++k) tot += (double)h_counters[5 + k];
-            const char* nm[10] = {"control", "hand-out", "round1 (model|pos|read)", "round2 issue+keys", "text finish", "fresh", "evaluate", "apply", "-", "loop"};
+            double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)h_counters[4 + k];
             fprintf(stderr, "[seed prof] tier %d:", tier);
-            for (int k = 0; k < 10; ++k) if (h_counters[5 + k]) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)h_counters[5 + k] / (tot > 0 ? tot : 1));
+            const char* nm[6] = {"control", "request+rmi", "window+compare", "resolve", "level", "apply"};
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)h_counters[4 + k] / (tot > 0 ? tot : 1));
             fprintf(stderr, "\n");
         }
 #endif
+        windows += (i64)h_counters[3];
         if (h_counters[2] == 0) break;
         // some reads produced more SMEMs than their slots hold (pathological repeats): re-run only those
         if (tier + 1 >= N_TIERS) {
@@ -299,7 +316,6 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     ctx->tm.seed_kernel_ms = ms_total;
     ctx->tm.seed_launches = launches;
     ctx->tm.seed_windows = windows;
-    ctx->tm.seed_text_compares = deep;
     // offsets
     i64 ntiles = (nreads + SCAN_TILE - 1) / SCAN_TILE;
     if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, (size_t)(2 * ntiles + 2) * sizeof(i64)))) return rc;
@@ -323,7 +339,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     i64 gblocks = (nreads + 15) / 16;
     if (gblocks > (i64)dev_cus * 8) gblocks = (i64)dev_cus * 8;
     if (gblocks < 1) gblocks = 1;
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)gblocks), dim3(GATHER_BLOCK), 0, ctx->stream, ctx->idx.pos5, tiers,
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)gblocks), dim3(BLOCK), 0, ctx->stream, ctx->idx.sa, tiers,
                        (const i64*)ctx->slot_loc.p, (const int*)ctx->slot_cnt.p, nreads, opt->hits_per_smem,
                        (const i64*)ctx->smem_off.p, (const i64*)ctx->hit_off.p, (meme_mem_tl*)ctx->smems.p,
                        (u64*)ctx->hits.p);
@@ -390,7 +406,7 @@ extern "C" int meme_seed_batch_device(meme_ctx* ctx, const uint8_t* d_reads, con
     if (!ctx || !d_reads || !d_read_off || !out || nreads < 0) return MEME_E_ARG;
     int rc = check_opt(opt);
     if (rc) return rc;
-    if (!ctx->idx.keys) { meme_set_error("meme_seed_batch: no index loaded"); return MEME_E_STATE; }
+    if (!ctx->idx.sa) { meme_set_error("meme_seed_batch: no index loaded"); return MEME_E_STATE; }
     HIP_TRY(hipSetDevice(ctx->device));
     if (nreads == 0) { memset(out, 0, sizeof(*out)); return MEME_OK; }
     i64 max_len = 0;
@@ -405,7 +421,7 @@ extern "C" int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_
     if (!ctx || !reads || !read_off || !smems || !smem_off || !hits || !hit_off || nreads < 0) return MEME_E_ARG;
     int rc = check_opt(opt);
     if (rc) return rc;
-    if (!ctx->idx.keys) { meme_set_error("meme_seed_batch: no index loaded"); return MEME_E_STATE; }
+    if (!ctx->idx.sa) { meme_set_error("meme_seed_batch: no index loaded"); return MEME_E_STATE; }
     HIP_TRY(hipSetDevice(ctx->device));
     if (nreads == 0) { smem_off[0] = 0; hit_off[0] = 0; if (total_smems) *total_smems = 0; if (total_hits) *total_hits = 0; return MEME_OK; }
     const i64 bases = read_off[nreads] - read_off[0];
@@ -443,7 +459,7 @@ extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const i
     if (!ctx || !reads || !read_off || !out || nreads < 0) return MEME_E_ARG;
     int rc = check_opt(opt);
     if (rc) return rc;
-    if (!ctx->idx.keys) { meme_set_error("meme_seed_batch_host: no index loaded"); return MEME_E_STATE; }
+    if (!ctx->idx.sa) { meme_set_error("meme_seed_batch_host: no index loaded"); return MEME_E_STATE; }
     HIP_TRY(hipSetDevice(ctx->device));
     memset(out, 0, sizeof(*out));
     if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smem_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;

@@ -27,9 +27,8 @@ class BswOpt(C.Structure):
 
 
 class IndexArrays(C.Structure):
-    _fields_ = [("sa_num", C.c_int64), ("d_keys", C.c_void_p), ("d_pos5", C.c_void_p), ("d_pac64", C.c_void_p),
-                ("d_l2", C.c_void_p), ("l2_records", C.c_int64), ("d_l1", C.c_void_p), ("l1_records", C.c_int64),
-                ("d_special", C.c_void_p)]
+    _fields_ = [("sa_num", C.c_int64), ("d_sa_ent", C.c_void_p), ("d_pac64", C.c_void_p), ("d_l2", C.c_void_p),
+                ("l2_records", C.c_int64), ("d_l1", C.c_void_p), ("l1_records", C.c_int64)]
 
 
 class SeedHostResult(C.Structure):
@@ -46,16 +45,16 @@ class SeedResult(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("seed_kernel_ms", C.c_float), ("seed_gather_ms", C.c_float), ("bsw_kernel_ms", C.c_float),
                 ("seed_launches", C.c_int64), ("bsw_launches", C.c_int64), ("seed_pack_ms", C.c_float),
-                ("seed_windows", C.c_int64), ("seed_text_compares", C.c_int64)]
+                ("seed_windows", C.c_int64)]
 
 
 # every symbol include/meme_hip.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_last_error", "meme_ctx_sync",
            "meme_ctx_stream", "meme_index_load_host", "meme_index_load_files", "meme_index_pac64_words",
-           "meme_index_key_words", "meme_index_pos5_bytes", "meme_index_special_bytes",
+           "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
-           "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_keys",
-           "meme_stage_rmi32", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
+           "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -85,10 +84,9 @@ def lib():
         L.meme_last_error.restype = C.c_char_p
         L.meme_ctx_stream.restype = C.c_void_p
         L.meme_ctx_stream.argtypes = [C.c_void_p]
-        for f in ("meme_index_pac64_words", "meme_index_key_words", "meme_index_pos5_bytes"):
+        for f in ("meme_index_pac64_words", "meme_index_pos5_bytes"):
             getattr(L, f).restype = C.c_int64
             getattr(L, f).argtypes = [C.c_int64]
-        L.meme_index_special_bytes.restype = C.c_int64
         L.meme_host_alloc.restype = C.c_void_p
         L.meme_host_alloc.argtypes = [C.c_int64]
         L.meme_host_free.argtypes = [C.c_void_p]
@@ -256,20 +254,18 @@ def stage_index_torch(ctx, n, d_text, d_pos5, d_l2_24, n_l2, d_l1_24, n_l1):
     dev = d_text.device
     torch.cuda.synchronize(dev)     # the images were filled on torch's stream; the staging kernels run on the ctx's own stream
     d_pac = torch.empty(L.meme_index_pac64_words(n), dtype=torch.int64, device=dev)
-    d_keys = torch.empty(L.meme_index_key_words(n), dtype=torch.int64, device=dev)
+    d_ent = torch.empty(2 * n, dtype=torch.int64, device=dev)
     d_l2 = torch.empty(n_l2 * 32, dtype=torch.uint8, device=dev)
     d_l1 = torch.empty(max(n_l1, 1) * 32, dtype=torch.uint8, device=dev)
-    d_spec = torch.empty(L.meme_index_special_bytes(), dtype=torch.uint8, device=dev)
     h = C.c_void_p(ctx.h)
     _check(L.meme_stage_pack_text(h, C.c_void_p(d_text.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr())))
-    _check(L.meme_stage_build_keys(h, C.c_void_p(d_pos5.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr()),
-                                   C.c_void_p(d_keys.data_ptr()), C.c_void_p(d_spec.data_ptr())))
+    _check(L.meme_stage_build_entries(h, C.c_void_p(d_pos5.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr()),
+                                      C.c_void_p(d_ent.data_ptr())))
     _check(L.meme_stage_rmi32(h, C.c_void_p(d_l2_24.data_ptr()), C.c_int64(n_l2), C.c_void_p(d_l2.data_ptr())))
     _check(L.meme_stage_rmi32(h, C.c_void_p(d_l1_24.data_ptr()), C.c_int64(n_l1), C.c_void_p(d_l1.data_ptr())))
     ctx.sync()
-    ctx.attach_index(IndexArrays(n, d_keys.data_ptr(), d_pos5.data_ptr(), d_pac.data_ptr(), d_l2.data_ptr(), n_l2,
-                                 d_l1.data_ptr(), n_l1, d_spec.data_ptr()))
-    return d_pac, d_keys, d_l2, d_l1, d_spec, d_pos5
+    ctx.attach_index(IndexArrays(n, d_ent.data_ptr(), d_pac.data_ptr(), d_l2.data_ptr(), n_l2, d_l1.data_ptr(), n_l1))
+    return d_pac, d_ent, d_l2, d_l1
 
 
 def pos5_from_sa_torch(ctx, d_sa, n):

@@ -81,32 +81,25 @@ void* meme_ctx_stream(meme_ctx* ctx);          /* the hipStream_t every kernel o
 /* ---- index staging ------------------------------------------------------------------------------
  * Inputs are the reference's on-disk images: pos_packed = 5 B per SA slot,
  * text0123 = 1 B per base fwd+rc, L1/L2 = 24-B P-RMI records.  The HBM layout is private:
- *   keys[]      u64 per slot: its suffix's first 32 bases (first base in the top bits, T-filled past the end), 16 per
- *               128-byte line = one search window
- *   pos5[]      the .pos_packed image itself (text positions; read for key ties and by the hit gather)
+ *   sa_ent[n]   16 B {u64 key (32 bases, first base in the top bits, T-filled), u64 text position}
  *   pac64[]     2-bit text, 32 bases per u64, first base in the top bits
- *   l2[], l1[]  P-RMI records padded to 32 bytes
- *   special[]   small hash set of the windows that touch the end of the text
+ *   l2[], l1[]  P-RMI records padded to 32 bytes (a lookup never straddles a 128-byte line)
  * Keys are generated on the device (replaces the OpenMP loop of src/fastmap.cpp:549-613; no inverse suffix array). */
 int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t sa_num,
                          const uint8_t* text0123, const void* l1_params, int64_t l1_bytes,
                          const void* l2_params, int64_t l2_bytes);
 int meme_index_load_files(meme_ctx* ctx, const char* prefix);
-/* Device-resident variant for multi-GPU start-up with one process per GPU: the caller owns the arrays (e.g.
- * received through an RCCL broadcast and staged with the meme_stage_* calls) and they must outlive the ctx. */
+/* Device-resident variant for multi-GPU start-up with one process per GPU: the caller owns the arrays (e.g. the raw
+ * images received through an RCCL broadcast and staged with the meme_stage_* calls) and they must outlive the ctx. */
 typedef struct {
     int64_t sa_num;
-    void* d_keys;              /* meme_index_key_words(sa_num) * 8 B, 128-byte aligned */
-    void* d_pos5;              /* meme_index_pos5_bytes(sa_num) */
+    void* d_sa_ent;            /* sa_num * 16 B */
     void* d_pac64;             /* meme_index_pac64_words(sa_num) * 8 B */
-    void* d_l2; int64_t l2_records;   /* 32-byte records */
+    void* d_l2; int64_t l2_records;   /* 32-byte records (meme_stage_rmi32) */
     void* d_l1; int64_t l1_records;
-    void* d_special;           /* meme_index_special_bytes() */
 } meme_index_arrays;
 int64_t meme_index_pac64_words(int64_t sa_num);
-int64_t meme_index_key_words(int64_t sa_num);
-int64_t meme_index_pos5_bytes(int64_t sa_num);
-int64_t meme_index_special_bytes(void);
+int64_t meme_index_pos5_bytes(int64_t sa_num);                      /* 5 * sa_num + padding */
 int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* arrays);
 int meme_index_describe(meme_ctx* ctx, meme_index_arrays* out);     /* device pointers of a loaded index */
 int meme_index_share(meme_ctx* ctx, meme_ctx* owner);               /* second ctx on the same device */
@@ -120,8 +113,10 @@ void meme_host_free(void* p);
 /* staging kernels usable on caller-owned device buffers (used by the multi-GPU path of bench.py) */
 int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text0123, int64_t sa_num, void* d_pac64);
 int meme_stage_pos5_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t sa_num, void* d_pos5);   /* u64 SA -> 5-byte image */
-int meme_stage_build_keys(meme_ctx* ctx, const uint8_t* d_pos5, int64_t sa_num, const void* d_pac64,
-                          void* d_keys, void* d_special);
+int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t sa_num,
+                             const void* d_pac64, void* d_sa_ent);
+int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t sa_num, const void* d_pac64,
+                               void* d_sa_ent);
 int meme_stage_rmi32(meme_ctx* ctx, const void* d_rmi24, int64_t records, void* d_rmi32);
 
 /* ---- seeding ------------------------------------------------------------------------------------
@@ -180,11 +175,10 @@ typedef struct {
     float bsw_kernel_ms;
     int64_t seed_launches, bsw_launches;
     float seed_pack_ms;        /* read packing kernel */
-    int64_t seed_windows;      /* suffix-array windows (128-byte key lines) loaded by the SA-search kernel */
-    int64_t seed_text_compares;/* key ties resolved in the 2-bit text (one position fetch + text words each) */
+    int64_t seed_windows;      /* suffix-array windows loaded by the SA-search kernel */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "seed_waves_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs" */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs" */
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Kernel-only throughput probe: python scripts/quick_probe.py [Mbp] [Mreads] [bits] [waves_per_cu,...]  (index cached in /dev/shm)"""
+"""Kernel-only throughput probe: python scripts/quick_probe.py [Mbp] [Mreads] [bits] [lanes,...]  (index cached in /dev/shm)"""
 import os, sys, time, tempfile
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "bwa-meme_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -9,7 +9,7 @@ from pymeme import hipapi, synth, workload
 mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 512
 mreads = float(sys.argv[2]) if len(sys.argv) > 2 else 4
 bits = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-lanes_list = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
+lanes_list = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4, 8]
 log = lambda s: print("[probe]", s, flush=True)
 g = synth.make_genome(int(mbp * 1e6), seed=11)
 tmp = "/dev/shm/qprobe_%d_%d" % (int(mbp), bits)
@@ -29,13 +29,11 @@ d_reads = torch.from_numpy(reads.reshape(-1)).cuda()
 d_off = torch.arange(0, (n + 1) * RL, RL, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 for lanes in lanes_list:
-    ctx.set_tuning("seed_waves_per_cu", lanes)
+    ctx.set_tuning("group_lanes", lanes)
     for rounds in [int(x) for x in os.environ.get("PROBE_ROUNDS", "1,3").split(",")]:
         for it in range(2):
             res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * RL, hipapi.default_seed_opt(rounds=rounds))
             tm = ctx.timings()
-        log("%s len=%d sub=%.3f waves/CU=%d rounds=%d: kernel %.1f ms -> %.2f M reads/s (pack %.2f ms, gather %.2f ms); searches/read %.1f "
-            "windows/search %.3f text compares/search %.3f smems %d hits %d" % (
-            os.path.basename(lib), RL, SUB, lanes, rounds, tm.seed_kernel_ms, n / tm.seed_kernel_ms / 1e3, tm.seed_pack_ms,
-            tm.seed_gather_ms, res.searches / n, tm.seed_windows / max(res.searches, 1),
-            tm.seed_text_compares / max(res.searches, 1), res.total_smems, res.total_hits))
+        log("%s len=%d sub=%.3f G=%d rounds=%d: kernel %.1f ms -> %.2f M reads/s; searches/read %.1f windows/search %.3f smems %d hits %d" % (
+            os.path.basename(lib), RL, SUB, lanes, rounds, tm.seed_kernel_ms, n / tm.seed_kernel_ms / 1e3, res.searches / n,
+            tm.seed_windows / max(res.searches, 1), res.total_smems, res.total_hits))

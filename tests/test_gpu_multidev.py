@@ -33,7 +33,7 @@ def test_replicate_on_the_same_device_shares_the_index():
         a.load_index_files(prefix)
         b.replicate_index_from(a)
         assert _dump(b, reads, off) == want
-        assert b.describe_index().d_keys == a.describe_index().d_keys
+        assert b.describe_index().d_sa_ent == a.describe_index().d_sa_ent
     finally:
         b.close()
         a.close()
@@ -47,7 +47,7 @@ def test_replicate_to_a_second_device():
     try:
         a.load_index_files(prefix)
         b.replicate_index_from(a)
-        assert b.describe_index().d_keys != a.describe_index().d_keys
+        assert b.describe_index().d_sa_ent != a.describe_index().d_sa_ent
         for length in (150, 250):
             reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
             want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()

@@ -48,12 +48,14 @@ def test_seeds_equal_oracle_above_2_pow_32_suffixes():
         if l1.shape[0]:
             d_l1[:l1.shape[0] * 24].copy_(torch.from_numpy(np.ascontiguousarray(l1).view(np.uint8).reshape(-1)))
         keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, l2.shape[0], d_l1, l1.shape[0])
-        d_keys = keep[1]
-        # keys: sorted, and the first 32 bases of the suffix each slot points to (sampled around 2^32 and at the ends)
-        tp = np.concatenate([text[-64:], np.full(64, 3, np.uint8)])
+        d_ent = keep[1].view(-1, 2)
+        # entries: keys sorted, positions = the suffix array, and each key the first 32 bases of the suffix its slot points to
+        # (sampled around 2^32 and at the ends)
         for lo in (0, (1 << 32) - 500, n - 1000):
-            k = d_keys[lo:lo + 1000].cpu().numpy().view(np.uint64)
+            e = d_ent[lo:lo + 1000].cpu().numpy()
+            k = e[:, 0].view(np.uint64)
             assert np.all(k[1:] >= k[:-1]), lo
+            assert np.array_equal(e[:, 1].view(np.uint64), sa[lo:lo + 1000]), lo
             for i in (0, 499, 999):
                 p = int(sa[lo + i])
                 s32 = text[p:p + 32] if p + 32 <= n else np.concatenate([text[p:], np.full(32 - (n - p), 3, np.uint8)])

@@ -38,13 +38,12 @@ def test_hip_seeds_equal_reference_golden(ctx, g1, length):
     assert _gpu_dump(ctx, reads, off) == want
 
 
-@pytest.mark.parametrize("waves", [1, 4, 0])
-def test_hip_seeds_equal_golden_at_every_occupancy(g1, waves):
-    """Results must not depend on how many wavefronts share a CU (read hand-out order, ticket chunks)."""
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32])
+def test_hip_seeds_equal_golden_for_every_group_width(g1, lanes):
     c = hipapi.Context(0)
     try:
         c.load_index_files(g1)
-        c.set_tuning("seed_waves_per_cu", waves)
+        c.set_tuning("group_lanes", lanes)
         for length in (150, 250, 60, 25):
             reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_%d.fq" % length))
             want = open(os.path.join(GOLDEN, "g1_seeds_%d.txt" % length)).read()
@@ -55,7 +54,8 @@ def test_hip_seeds_equal_golden_at_every_occupancy(g1, waves):
 
 def test_overflow_tiers_give_the_same_seeds(g1):
     """With 8 SMEM slots per read in the first pass most 150/250-bp reads overflow and are re-run in the bigger tiers
-    (the pending / overflow-list ping-pong, slot locators of several tiers in one gather): same dump."""
+    (the pending / overflow-list ping-pong, slot locators of several tiers in one gather, the 32-lanes-per-read
+    instantiation with its 512-entry LDS ring): same dump."""
     c = hipapi.Context(0)
     try:
         c.load_index_files(g1)
