@@ -22,7 +22,7 @@ Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 3100),
 per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's rule),
 MEME_BENCH_LANES (lanes per read in the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the
 compiled reference, timed in this run), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables the /dev/shm caches),
-MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
+MEME_BENCH_SA (device | host: where the suffix array is built), MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
 2,000,000), MEME_BENCH_BUDGET_S (wall budget in seconds after which optional legs are skipped, default 1500).
 """
 import argparse
@@ -333,10 +333,23 @@ def main():
             l2 = np.fromfile(cache + ".l2", dtype=hostapi.RMI_DTYPE)
             log("genome %.0f Mbp: index loaded from the /dev/shm cache in %.1f s" % (l_pac / 1e6, time.time() - t0))
         else:
-            text, sa = hostapi.build_sa(fwd)
+            if os.environ.get("MEME_BENCH_SA", "device") == "device":
+                # suffix array on the GPU (meme_sa_build_device: radix sort + prefix doubling), model training on the host
+                text = hipapi.fwd_rc_text(fwd)
+                c0 = hipapi.Context(local)
+                d_t, d_s = hipapi.build_sa_device(c0, text)
+                sa = d_s.cpu().numpy().view(np.uint64)
+                del d_t, d_s
+                c0.close()
+                torch.cuda.empty_cache()
+                t_sa = time.time() - t0
+            else:
+                text, sa = hostapi.build_sa(fwd)
+                t_sa = time.time() - t0
             l1, l2 = hostapi.train_prmi(text, sa, bits=bits)
-            log("genome %.0f Mbp: suffix array + P-RMI (2^%d leaves, %d partial) built on host in %.1f s"
-                % (l_pac / 1e6, int(np.log2(l2.shape[0])), l1.shape[0], time.time() - t0))
+            log("genome %.0f Mbp: suffix array in %.1f s (%s), P-RMI (2^%d leaves, %d partial) trained on the host in %.1f s"
+                % (l_pac / 1e6, t_sa, os.environ.get("MEME_BENCH_SA", "device"), int(np.log2(l2.shape[0])), l1.shape[0],
+                   time.time() - t0 - t_sa))
             if cache:
                 try:
                     import glob

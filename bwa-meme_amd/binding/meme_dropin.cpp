@@ -17,13 +17,14 @@
 //                                   -> meme_bsw_batch(); the concurrent calls of the kt_for workers are combined into one
 //                                   backend call per GPU (group commit), staged through pinned buffers
 #include <dlfcn.h>
+#include <sched.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -297,26 +298,36 @@ struct BswReq {
 };
 
 // Group commit with double-buffered pinned staging.  A worker reserves room for its request in the open staging buffer
-// (under the lock), copies its pairs and sequences in by itself (all workers copy in parallel, outside the lock) and
-// waits; the first waiter that finds no call in flight becomes the leader: it closes the buffer, lets new arrivals
-// fill the other one, issues ONE backend call for everything in it and wakes the owners, which copy their own
-// results out.  While a call is in flight the next batch assembles itself.  One combiner per GPU.
+// (a short critical section), copies its pairs and sequences in by itself (all workers copy in parallel) and waits; the
+// first waiter that finds no call in flight becomes the leader: it closes the buffer, lets new arrivals fill the other
+// one, issues ONE backend call for everything in it and publishes the batch's epoch; the owners then copy their own
+// results out.  While a call is in flight the next batch assembles itself.  Waiting is spin + yield on atomics (the
+// workers have nothing else to do, and a condition-variable broadcast to 256 threads costs more than a backend call).
+// One combiner per GPU.
 struct Staging {
     meme_seqpair* pairs = nullptr; uint8_t* ref = nullptr; uint8_t* qer = nullptr;     // pinned, fixed capacity
-    int64_t n = 0, rb = 0, qb = 0;
-    int w = 0; meme_bsw_opt o; bool has_key = false;
-    std::vector<BswReq*> reqs;
-    int copying = 0, reading = 0;
-    bool closed = false;
+    int64_t n = 0, rb = 0, qb = 0;                     // reserved so far          (under Combiner::m)
+    int w = 0; meme_bsw_opt o; bool has_key = false;   // band / penalties of the batch
+    bool closed = false;                               // no more reservations: being executed or drained
+    uint64_t epoch = 1;                                // number of the batch being assembled
+    std::atomic<int> nreq{0}, copying{0}, reading{0};
+    std::atomic<uint64_t> done_epoch{0};
 };
+
+inline void backoff(unsigned& spins) {
+    ++spins;
+    if (spins < 64) { __builtin_ia32_pause(); return; }
+    if ((spins & 15) != 0) { for (int k = 0; k < 16; ++k) __builtin_ia32_pause(); return; }
+    if (spins < 4096) sched_yield();
+    else { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
+}
 
 struct Combiner {
     static constexpr int64_t CAP_PAIRS = 1 << 20, CAP_REF = 384ll << 20, CAP_QER = 192ll << 20;
     std::mutex m, ctx_mu;
-    std::condition_variable cv;
     Staging st[2];
-    int open = 0;
-    bool busy = false;
+    int open = 0;                                       // under m
+    std::atomic<bool> busy{false};
     int device = 0;
 
     void init() {
@@ -332,31 +343,45 @@ struct Combiner {
         return S.n + r->n <= CAP_PAIRS && S.rb + r->rb <= CAP_REF && S.qb + r->qb <= CAP_QER;
     }
 
-    // called with the lock held and busy == false: run everything reserved in S
-    void lead(std::unique_lock<std::mutex>& lk, Staging& S, int expected) {
-        busy = true;
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(100);
-        while ((int)S.reqs.size() < expected && S.n < CAP_PAIRS / 2 && cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
-        S.closed = true;
-        Staging& other = st[&S == &st[0] ? 1 : 0];
-        while (other.closed) cv.wait(lk);                   // its owners are still copying the previous results out
-        open = &S == &st[0] ? 1 : 0;
-        while (S.copying > 0) cv.wait(lk);
-        lk.unlock();
+    // become the leader if nobody is, and run the batch that is being assembled.  `mine` / `my_epoch`: the caller's own
+    // request, if it has one -- a thread whose batch has just been completed must first take its results out (the leader of
+    // the next batch waits for exactly that before it can reuse the buffer), so it does not lead.
+    void try_lead(int expected, const Staging* mine = nullptr, uint64_t my_epoch = 0) {
+        bool f = false;
+        if (!busy.compare_exchange_strong(f, true, std::memory_order_acquire)) return;
+        if (mine && mine->done_epoch.load(std::memory_order_acquire) >= my_epoch) { busy.store(false, std::memory_order_release); return; }
+        Staging* S;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            S = &st[open];
+            if (S->closed || S->nreq.load() == 0) { busy.store(false, std::memory_order_release); return; }
+        }
+        // a moment for the rest of the team to join
         const double t0 = now_s();
+        unsigned sp = 0;
+        while (S->nreq.load(std::memory_order_relaxed) < expected && now_s() - t0 < 60e-6) backoff(sp);
+        { std::lock_guard<std::mutex> lk(m); S->closed = true; }
+        Staging* other = &st[S == &st[0] ? 1 : 0];
+        for (sp = 0;;) {                                 // the other buffer is free once its previous owners have drained it
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (!other->closed) { open = S == &st[0] ? 1 : 0; break; }
+            }
+            backoff(sp);
+        }
+        for (sp = 0; S->copying.load(std::memory_order_acquire) > 0;) backoff(sp);
+        const double t1 = now_s();
         {
             std::lock_guard<std::mutex> cl(ctx_mu);
-            if (meme_bsw_batch(g_dev[(size_t)device].bsw, S.pairs, S.ref, S.rb, S.qer, S.qb, (int)S.n, S.w, &S.o)) die("meme_bsw_batch");
+            if (meme_bsw_batch(g_dev[(size_t)device].bsw, S->pairs, S->ref, S->rb, S->qer, S->qb, (int)S->n, S->w, &S->o)) die("meme_bsw_batch");
             if (verbose()) { meme_timings tm; if (!meme_get_timings(g_dev[(size_t)device].bsw, &tm)) g_t_bsw_kernel = g_t_bsw_kernel + tm.bsw_kernel_ms * 1e-3; }
         }
-        g_t_bsw_call = g_t_bsw_call + (now_s() - t0);
+        g_t_bsw_call = g_t_bsw_call + (now_s() - t1);
         g_n_bsw_calls += 1;
-        g_n_bsw_pairs += S.n;
-        lk.lock();
-        S.reading = (int)S.reqs.size();
-        for (BswReq* b : S.reqs) b->done = true;
-        busy = false;
-        cv.notify_all();
+        g_n_bsw_pairs += S->n;
+        S->reading.store(S->nreq.load(), std::memory_order_relaxed);
+        S->done_epoch.store(S->epoch, std::memory_order_release);
+        busy.store(false, std::memory_order_release);
     }
 
     void submit(BswReq* r, int expected) {
@@ -365,21 +390,25 @@ struct Combiner {
             if (meme_bsw_batch(g_dev[(size_t)device].bsw, (meme_seqpair*)r->pairs, r->ref, r->rb, r->qer, r->qb, r->n, r->w, &r->o)) die("meme_bsw_batch");
             return;
         }
-        std::unique_lock<std::mutex> lk(m);
-        Staging* S;
-        for (;;) {
-            S = &st[open];
-            if (!S->closed && (!S->has_key || same_key(*S, r)) && fits(*S, r)) break;
-            if (!busy && !S->closed && S->n > 0) { lead(lk, *S, 0); continue; }   // flush what blocks the way
-            cv.wait(lk);
+        Staging* S = nullptr;
+        uint64_t my_epoch = 0;
+        for (unsigned sp = 0;;) {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                S = &st[open];
+                if (!S->closed && (!S->has_key || same_key(*S, r)) && fits(*S, r)) {
+                    if (!S->has_key) { S->w = r->w; S->o = r->o; S->has_key = true; }
+                    r->pn = S->n; r->pr = S->rb; r->pq = S->qb;
+                    S->n += r->n; S->rb += r->rb; S->qb += r->qb;
+                    S->copying.fetch_add(1, std::memory_order_relaxed);
+                    S->nreq.fetch_add(1, std::memory_order_relaxed);
+                    my_epoch = S->epoch;
+                    break;
+                }
+            }
+            try_lead(0);                                 // flush what blocks the way (other band / penalties, or full)
+            backoff(sp);
         }
-        if (!S->has_key) { S->w = r->w; S->o = r->o; S->has_key = true; }
-        r->pn = S->n; r->pr = S->rb; r->pq = S->qb;
-        S->n += r->n; S->rb += r->rb; S->qb += r->qb;
-        S->reqs.push_back(r);
-        S->copying++;
-        cv.notify_all();
-        lk.unlock();
         const double t0 = now_s();
         memcpy(S->ref + r->pr, r->ref, (size_t)r->rb);
         memcpy(S->qer + r->pq, r->qer, (size_t)r->qb);
@@ -390,22 +419,19 @@ struct Combiner {
             S->pairs[r->pn + i] = p;
         }
         g_t_bsw_gather = g_t_bsw_gather + (now_s() - t0);
-        lk.lock();
-        if (--S->copying == 0) cv.notify_all();
-        while (!r->done) {
-            if (!busy && !S->closed) lead(lk, *S, expected);
-            else cv.wait(lk);
+        S->copying.fetch_sub(1, std::memory_order_release);
+        for (unsigned sp = 0; S->done_epoch.load(std::memory_order_acquire) < my_epoch;) {
+            if (!busy.load(std::memory_order_relaxed)) try_lead(expected, S, my_epoch);
+            backoff(sp);
         }
-        lk.unlock();
         for (int i = 0; i < r->n; ++i) {
             const meme_seqpair& g = S->pairs[r->pn + i];
             SeqPair& p = r->pairs[i];
             p.score = g.score; p.tle = g.tle; p.gtle = g.gtle; p.qle = g.qle; p.gscore = g.gscore; p.max_off = g.max_off;
         }
-        lk.lock();
-        if (--S->reading == 0) {                              // last owner out: the buffer can be filled again
-            S->n = S->rb = S->qb = 0; S->has_key = false; S->closed = false; S->reqs.clear();
-            cv.notify_all();
+        if (S->reading.fetch_sub(1, std::memory_order_acq_rel) == 1) {      // last owner out: the buffer can be filled again
+            std::lock_guard<std::mutex> lk(m);
+            S->n = S->rb = S->qb = 0; S->has_key = false; S->nreq.store(0); S->epoch += 1; S->closed = false;
         }
     }
 };

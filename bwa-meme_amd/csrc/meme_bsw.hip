@@ -562,7 +562,11 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     if (mq < 1) mq = 1;
     if (use_lane) {
         // ---- lane-per-pair kernel, one launch per LDS size class (pairs are sorted by query length); a class finds its
-        // range in the device-side scan and leaves at once when it is empty
+        // range in the device-side scan and leaves at once when it is empty.  Launches of one stream run one after the
+        // other, so a batch that cannot fill the GPU anyway (a combined call of the aligner's worker threads: 20-300 k
+        // pairs) goes out as ONE launch with the LDS of the longest query's class: its time is the slowest wavefront's,
+        // not the sum over the classes.
+        const bool one_launch = host_maxq >= 0 && (i64)npairs < (i64)dev_cus * 64 * 16;
         int qlo = 0;
         for (int c = 0; c < N_LANE_CLS; ++c) {
             const int qhi = LANE_CLS_Q[c];                       // class = query lengths [qlo, qhi]
@@ -571,7 +575,11 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
             L.w = w; L.o = *opt; L.ticket = tickets + c;
             L.offs = offs; L.key_first = QKEY(qlo); L.key_last = QKEY(qhi + 1);
             qlo = qhi + 1;
-            if (host_maxq >= 0 && L.key_first > QKEY(host_maxq) ) continue;    // no query of the batch is that long
+            if (host_maxq >= 0 && L.key_first > QKEY(host_maxq)) continue;    // no query of the batch is that long
+            if (one_launch) {
+                if (qhi < host_maxq && c + 1 < N_LANE_CLS) continue;           // not the top class of this batch yet
+                L.key_first = 0;
+            }
             const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
             if (lds > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -580,6 +588,7 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
             if (blocks > want) blocks = want;
             hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
             HIP_TRY(hipGetLastError());
+            if (one_launch) break;
         }
     }
     // ---- lanes-per-pair kernel: the pairs the lane kernel cannot take (long queries, scores beyond 14 bits), or the whole

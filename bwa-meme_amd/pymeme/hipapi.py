@@ -54,7 +54,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -76,6 +76,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: build it with `make -C bwa-meme_amd hip` "
                                "(or __graft_entry__.build())" % LIB_PATH)
+        try:
+            # torch ships its own copy of the HIP runtime: when both live in one process, torch's has to be loaded first
+            # (with ours first, torch finds no GPU)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.meme_ctx_create.restype = C.c_void_p
         L.meme_ctx_create.argtypes = [C.c_int]
@@ -278,3 +284,23 @@ def pos5_from_sa_torch(ctx, d_sa, n):
                                      C.c_void_p(d_pos5.data_ptr())))
     ctx.sync()
     return d_pos5
+
+
+def fwd_rc_text(fwd: np.ndarray) -> np.ndarray:
+    """The reference's .0123 image: the forward strand followed by its reverse complement (codes 0..3)."""
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+    return np.concatenate([fwd, (3 - fwd[::-1]).astype(np.uint8)])
+
+
+def build_sa_device(ctx, text: np.ndarray):
+    """Suffix array of the fwd+rc text on the GPU (meme_sa_build_device).  Returns the torch int64 tensor in HBM."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    n = int(text.shape[0])
+    d_text = torch.from_numpy(text).to(dev)
+    d_sa = torch.empty(n, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    _check(lib().meme_sa_build_device(C.c_void_p(ctx.h), C.c_void_p(d_text.data_ptr()), C.c_int64(n),
+                                      C.c_void_p(d_sa.data_ptr())))
+    ctx.sync()
+    return d_text, d_sa

@@ -119,6 +119,13 @@ int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t sa_n
                                void* d_sa_ent);
 int meme_stage_rmi32(meme_ctx* ctx, const void* d_rmi24, int64_t records, void* d_rmi32);
 
+/* ---- suffix-array construction on the device (index building) -----------------------------------------
+ * d_text0123: sa_num bytes, the forward strand followed by its reverse complement (codes 0..3, the reference's .0123 image);
+ * d_sa: sa_num u64 out, the suffix array in the order `bwa-meme index` writes to .pos_packed (a suffix that ends sorts
+ * before its continuations).  Radix sort by the first 32 bases + prefix doubling on the tied groups; workspace
+ * (~10 bytes per suffix) is allocated and released inside the call. */
+int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, int64_t sa_num, uint64_t* d_sa);
+
 /* ---- seeding ------------------------------------------------------------------------------------
  * reads: concatenated base codes 0..3, >=4 = ambiguous (what mem_kernel1_core_Learned leaves in
  * bseq1_t.seq, src/bwamem.cpp:1277-1279); read_off[nreads+1].  A read longer than 500 bases
