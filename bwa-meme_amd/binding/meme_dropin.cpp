@@ -95,6 +95,8 @@ void init_devices(const char* prefix) {
 // ---- memoryAllocLearned (src/fastmap.cpp:351-641) ----------------------------------------------------------------
 // Worker buffers exactly as the reference sizes them (they are indexed by the kt_for thread id all over
 // mem_chain2aln_across_reads_V2 and freed by process(), src/fastmap.cpp:1098-1110); the host-side index expansion is gone.
+void ext_prepare(int64_t chunk_reads, int threads);       // defined with the extension stage below
+
 uint8_t bitrev8(uint8_t b) {
     b = (uint8_t)(((b & 0xF0) >> 4) | ((b & 0x0F) << 4));
     b = (uint8_t)(((b & 0xCC) >> 2) | ((b & 0x33) << 2));
@@ -163,7 +165,9 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     w.useLearned = 1;
     const double t1 = now_s();
     const char* prefix = getenv("MEME_INDEX_PREFIX") ? getenv("MEME_INDEX_PREFIX") : idx_prefix;
+    std::thread prep(ext_prepare, (int64_t)nreads, (int)nthreads);             // pinned staging + helper threads, while the index loads
     init_devices(prefix);
+    prep.join();
     fprintf(stderr, "[meme-dropin] worker buffers + fwd/rc text %.2f s, HBM index %.2f s (no host-side index expansion)\n",
             t1 - t0, now_s() - t1);
 }
@@ -239,6 +243,7 @@ int g_team = 1;                        // kt_for worker threads of the run (opt-
 uint64_t g_chunk_gen = 0;               // counts the chunks seeded
 
 typedef void (*process_fn)(mem_opt_t*, int64_t, int, bseq1_t*, const mem_pestat_t*, worker_t&);
+void ext_report();
 
 }  // namespace
 
@@ -257,6 +262,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
                 "(copy-in thread-seconds %.3f, backend calls %.3f s of which kernels %.3f s)\n",
                 (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs,
                 (double)g_t_bsw_gather, (double)g_t_bsw_call, (double)g_t_bsw_kernel);
+    if (verbose()) ext_report();
 }
 
 int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
@@ -703,7 +709,7 @@ void ext_run_stage(ExtStage& S, int w, const meme_bsw_opt& o) {
     static const int want_parts = getenv("MEME_DROPIN_EXT_SPLIT") ? atoi(getenv("MEME_DROPIN_EXT_SPLIT")) : 0;
     const int nd = (int)g_dev.size();
     int parts = want_parts > 0 ? want_parts : nd;
-    if (S.n < 65536 * (int64_t)parts || S.cuts.size() < (size_t)parts) parts = 1;
+    if ((want_parts <= 0 && S.n < 65536 * (int64_t)parts) || S.cuts.size() < (size_t)parts) parts = 1;
     std::vector<ExtStage::Cut> at((size_t)parts + 1);
     at[0] = {0, 0, 0};
     at[(size_t)parts] = {S.n, S.rb, S.qb};
@@ -847,6 +853,23 @@ void ext_purge_read(const mem_opt_t* opt, const bseq1_t* seqs, mem_chain_v* chai
     }
 }
 
+int64_t ext_slab_reads() {
+    static const int64_t v = getenv("MEME_DROPIN_EXT_SLAB") && atoll(getenv("MEME_DROPIN_EXT_SLAB")) > 0 ? atoll(getenv("MEME_DROPIN_EXT_SLAB")) : 262144;
+    return v;
+}
+bool ext_enabled() {
+    static const bool v = !(getenv("MEME_DROPIN_EXT") && atoi(getenv("MEME_DROPIN_EXT")) == 0);
+    return v;
+}
+// first guess of a slab's staging (3 jobs per read and direction; a job's target is the query side plus the gap allowance);
+// a slab that needs more is rebuilt once with the exact sizes
+void ext_size_for(int64_t reads, int64_t read_len) {
+    Ext& E = *g_ext;
+    static const bool undersize = getenv("MEME_DROPIN_EXT_UNDERSIZE") != nullptr;      // tests: force the rebuild path
+    if (undersize) reads = reads / 16 + 1;
+    for (ExtStage* S : {&E.L, &E.R}) S->fit(reads * 3, reads * 3 * (read_len + 64), reads * 2 * read_len);
+}
+
 void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const bseq1_t* seqs, int64_t n, mem_chain_v* chain_ar,
                uint8_t* ref_string) {
     Ext& E = *g_ext;
@@ -855,7 +878,7 @@ void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, co
     E.av.assign((size_t)n, mem_alnreg_v());
     for (mem_alnreg_v& v : E.av) memset(&v, 0, sizeof(v));
     E.order_off.assign((size_t)n, 0);
-    static const int64_t slab_reads = getenv("MEME_DROPIN_EXT_SLAB") ? atoll(getenv("MEME_DROPIN_EXT_SLAB")) : 262144;
+    const int64_t slab_reads = ext_slab_reads();
     meme_bsw_opt ol, orr;
     memset(&ol, 0, sizeof(ol));
     ol.o_del = opt->o_del; ol.e_del = opt->e_del; ol.o_ins = opt->o_ins; ol.e_ins = opt->e_ins; ol.zdrop = opt->zdrop;
@@ -867,7 +890,7 @@ void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, co
         const int64_t ns = n - slab0 < slab_reads ? n - slab0 : slab_reads;
         const int64_t nblk = (ns + EXT_BLOCK - 1) / EXT_BLOCK;
         if ((int64_t)E.order.size() < nblk) E.order.resize((size_t)nblk);
-        if (!E.L.pairs) { E.L.fit(ns * 2, ns * 200, ns * 120); E.R.fit(ns * 2, ns * 200, ns * 120); }
+        ext_size_for(ns, n > 0 ? (int64_t)seqs[0].l_seq : READ_LEN);
         const std::function<void(int64_t)> build = [&](int64_t b) {
             const int64_t g0 = slab0 + b * EXT_BLOCK;
             ext_build_block(opt, bns, pac, seqs, chain_ar, ref_string, slab0, b, g0, g0 + EXT_BLOCK < slab0 + ns ? g0 + EXT_BLOCK : slab0 + ns);
@@ -915,13 +938,30 @@ void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, co
     E.t_total += now_s() - t_begin;
 }
 
+void ext_report() {
+    if (!g_ext) return;
+    const Ext& E = *g_ext;
+    static double last[5] = {0, 0, 0, 0, 0};
+    fprintf(stderr, "[meme-dropin] extension: this chunk %.3f s (jobs built %.3f, backend calls %.3f, folded %.3f, purged %.3f); totals %.3f s, "
+            "%lld backend calls with %lld pairs, %lld slab rebuilds\n", E.t_total - last[0], E.t_build - last[1], E.t_call - last[2],
+            E.t_fold - last[3], E.t_purge - last[4], E.t_total, (long long)E.n_calls, (long long)E.n_pairs, (long long)E.n_rebuilt);
+    last[0] = E.t_total; last[1] = E.t_build; last[2] = E.t_call; last[3] = E.t_fold; last[4] = E.t_purge;
+}
+
+void ext_prepare(int64_t chunk_reads, int threads) {
+    if (!ext_enabled() || g_ext) return;
+    g_ext = new Ext;
+    g_ext->team.ensure(threads > 1 ? threads - 1 : 0);
+    // pinned memory needs a HIP context; device 0's is created here if init_devices() has not got there yet
+    ext_size_for(chunk_reads < ext_slab_reads() ? chunk_reads : ext_slab_reads(), READ_LEN);
+}
+
 typedef void (*chain2aln_fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, bseq1_t*, int, mem_chain_v*, mem_alnreg_v*, mem_cache*, uint8_t*, int);
 }  // namespace
 
 void mem_chain2aln_across_reads_V2(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
                                    mem_chain_v* chain_ar, mem_alnreg_v* av_v, mem_cache* mmc, uint8_t* ref_string, int tid) {
-    static const bool chunk_wide = !(getenv("MEME_DROPIN_EXT") && atoi(getenv("MEME_DROPIN_EXT")) == 0);
-    if (!chunk_wide || !g_chunk.seqs) {
+    if (!ext_enabled() || !g_chunk.seqs) {
         static chain2aln_fn next = (chain2aln_fn)dlsym(RTLD_NEXT, "_Z29mem_chain2aln_across_reads_V2PK9mem_opt_tPK8bntseq_tPKhP7bseq1_tiP11mem_chain_vP12mem_alnreg_vP9mem_cachePhi");
         if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_chain2aln_across_reads_V2 was not found\n"); exit(1); }
         next(opt, bns, pac, seq_, nseq, chain_ar, av_v, mmc, ref_string, tid);
@@ -929,10 +969,7 @@ void mem_chain2aln_across_reads_V2(const mem_opt_t* opt, const bntseq_t* bns, co
     }
     const int64_t g0 = seq_ - g_chunk.seqs;
     if (g0 < 0 || g0 + nseq > g_chunk.n) { fprintf(stderr, "[meme-dropin] batch outside the chunk\n"); exit(1); }
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_ext) g_ext = new Ext;
-    }
+    if (!g_ext) { fprintf(stderr, "[meme-dropin] extension stage used before memoryAllocLearned\n"); exit(1); }
     {
         std::lock_guard<std::mutex> lk(g_ext->mu);                             // the first batch to arrive extends the whole chunk
         if (g_ext->gen != g_chunk_gen) {

@@ -3,8 +3,14 @@
 // Replaces, on the device, the index part of memoryAllocLearned() (reference src/fastmap.cpp:422-617):
 // the 2-bit fwd+rc text image and the widening of the 5-byte suffix-array file into probe-ready
 // entries with their 64-bit keys are produced by two streaming HIP kernels instead of an OpenMP loop.
+#include <fcntl.h>
 #include <stdarg.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <functional>
+#include <thread>
 
 #include "meme_common.h"
 
@@ -272,10 +278,12 @@ static int own_alloc(meme_ctx* ctx, void** p, size_t bytes) {
     return MEME_OK;
 }
 
-extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t n, const uint8_t* text,
-                                    const void* l1, int64_t l1_bytes, const void* l2, int64_t l2_bytes) {
-    if (!ctx || !pos_packed || !text || !l2 || n < 64 || l2_bytes < 24 || l2_bytes % 24 || l1_bytes % 24) {
-        meme_set_error("meme_index_load_host: bad argument (sa_num must be >= 64, parameter files multiples of 24 B)");
+// One loader for both sources.  `fetch(which, d_dst, bytes)` brings input `which` (0 text bytes, 1 position image,
+// 2 second-layer records, 3 partial-layer records) to the device buffer; the staging kernels then run on ctx->stream.
+typedef std::function<int(int, void*, size_t)> index_fetch_fn;
+static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t l2_bytes, const index_fetch_fn& fetch) {
+    if (n < 64 || l2_bytes < 24 || l2_bytes % 24 || l1_bytes % 24) {
+        meme_set_error("index: bad sizes (sa_num must be >= 64, parameter files multiples of 24 B)");
         return MEME_E_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));
@@ -295,15 +303,18 @@ extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, in
     if ((size_t)l1_bytes > tmp_bytes) tmp_bytes = (size_t)l1_bytes;
     HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
     auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d_tmp); return code; };
-    if (hipMemcpyAsync(d_tmp, text, (size_t)n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = fetch(0, d_tmp, (size_t)n))) return fail(rc);
     if ((rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac))) return fail(rc);
-    if (hipMemcpyAsync(d_tmp, pos_packed, (size_t)n * 5, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = fetch(1, d_tmp, (size_t)n * 5))) return fail(rc);
     if (hipMemsetAsync((uint8_t*)d_tmp + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     if ((rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent))) return fail(rc);
-    if (hipMemcpyAsync(d_tmp, l2, (size_t)l2_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if ((rc = fetch(2, d_tmp, (size_t)l2_bytes))) return fail(rc);
     if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l2, d_l2))) return fail(rc);
     if (n_l1 > 0) {
-        if (hipMemcpyAsync(d_tmp, l1, (size_t)l1_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+        if ((rc = fetch(3, d_tmp, (size_t)l1_bytes))) return fail(rc);
         if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l1, d_l1))) return fail(rc);
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -316,34 +327,86 @@ extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, in
     return MEME_OK;
 }
 
-static bool slurp(const std::string& path, std::vector<uint8_t>& out) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize((size_t)sz);
-    size_t r = sz ? fread(out.data(), 1, (size_t)sz, f) : 0;
-    fclose(f);
-    return r == (size_t)sz;
+extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t n, const uint8_t* text,
+                                    const void* l1, int64_t l1_bytes, const void* l2, int64_t l2_bytes) {
+    if (!ctx || !pos_packed || !text || !l2 || (l1_bytes > 0 && !l1)) { meme_set_error("meme_index_load_host: null argument"); return MEME_E_ARG; }
+    const void* src[4] = {text, pos_packed, l2, l1};
+    return index_build_from(ctx, n, l1_bytes, l2_bytes, [&](int which, void* d_dst, size_t bytes) {
+        if (hipMemcpyAsync(d_dst, src[which], bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return (int)MEME_E_HIP;
+        return hipStreamSynchronize(ctx->stream) == hipSuccess ? (int)MEME_OK : (int)MEME_E_HIP;
+    });
+}
+
+// A file straight to device memory: reader threads, each with two pinned pieces and a stream of its own -- piece k of the
+// file is read by thread k mod T while the thread's previous piece is still on its way over PCIe.  (A 31 GB position image
+// read into a zero-filled std::vector by one thread and copied from pageable memory took 20 s; this takes what the
+// slower of page cache and PCIe allows.)
+static long long file_size(const std::string& path) {
+    struct stat st;
+    return stat(path.c_str(), &st) == 0 ? (long long)st.st_size : -1;
+}
+
+static int file_to_device(meme_ctx* ctx, const std::string& path, void* d_dst, size_t bytes) {
+    if (bytes == 0) return MEME_OK;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { meme_set_error("cannot open %s", path.c_str()); return MEME_E_IO; }
+    const size_t piece = (size_t)32 << 20;
+    const size_t n_pieces = (bytes + piece - 1) / piece;
+    const int T = (int)(n_pieces < 12 ? n_pieces : 12);
+    std::atomic<int> err{MEME_OK};
+    auto reader = [&](int t) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { err = MEME_E_HIP; return; }
+        hipStream_t st = nullptr;
+        uint8_t* buf[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; b < 2 && ok; ++b)
+            ok = hipHostMalloc((void**)&buf[b], piece, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) == hipSuccess;
+        int turn = 0;
+        for (size_t k = (size_t)t; ok && k < n_pieces && err == MEME_OK; k += (size_t)T, turn ^= 1) {
+            const size_t off = k * piece, len = bytes - off < piece ? bytes - off : piece;
+            if (hipEventSynchronize(ev[turn]) != hipSuccess) { ok = false; break; }       // the buffer's previous copy has left
+            size_t got = 0;
+            while (got < len) {
+                const ssize_t r = pread(fd, buf[turn] + got, len - got, (off_t)(off + got));
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            if (got != len) { err = MEME_E_IO; break; }
+            ok = hipMemcpyAsync((uint8_t*)d_dst + off, buf[turn], len, hipMemcpyHostToDevice, st) == hipSuccess &&
+                 hipEventRecord(ev[turn], st) == hipSuccess;
+        }
+        if (st && hipStreamSynchronize(st) != hipSuccess) ok = false;
+        for (int b = 0; b < 2; ++b) { if (ev[b]) (void)hipEventDestroy(ev[b]); if (buf[b]) (void)hipHostFree(buf[b]); }
+        if (st) (void)hipStreamDestroy(st);
+        if (!ok && err == MEME_OK) err = MEME_E_HIP;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(reader, t);
+    reader(0);
+    for (auto& x : th) x.join();
+    close(fd);
+    if (err == MEME_E_IO) meme_set_error("short read from %s", path.c_str());
+    else if (err != MEME_OK) meme_set_error("HIP error while loading %s: %s", path.c_str(), hipGetErrorString(hipGetLastError()));
+    return err;
 }
 
 extern "C" int meme_index_load_files(meme_ctx* ctx, const char* prefix) {
     if (!ctx || !prefix) return MEME_E_ARG;
-    std::string p(prefix);
-    std::vector<uint8_t> pos, text, l1, l2;
+    const std::string p(prefix);
     // same file names memoryAllocLearned() opens (src/fastmap.cpp:425-470, 1496-1525)
-    if (!slurp(p + ".pos_packed", pos)) { meme_set_error("cannot read %s.pos_packed", prefix); return MEME_E_IO; }
-    if (!slurp(p + ".0123", text)) { meme_set_error("cannot read %s.0123", prefix); return MEME_E_IO; }
-    if (!slurp(p + ".suffixarray_uint64_L1_PARAMETERS", l1)) { meme_set_error("cannot read %s.suffixarray_uint64_L1_PARAMETERS", prefix); return MEME_E_IO; }
-    if (!slurp(p + ".suffixarray_uint64_L2_PARAMETERS", l2)) { meme_set_error("cannot read %s.suffixarray_uint64_L2_PARAMETERS", prefix); return MEME_E_IO; }
-    if (pos.size() % 5 || pos.size() / 5 != text.size()) {
-        meme_set_error("%s: .pos_packed (%zu B) and .0123 (%zu B) disagree on the suffix count", prefix, pos.size(), text.size());
+    const std::string name[4] = {p + ".0123", p + ".pos_packed", p + ".suffixarray_uint64_L2_PARAMETERS", p + ".suffixarray_uint64_L1_PARAMETERS"};
+    long long size[4];
+    for (int i = 0; i < 4; ++i)
+        if ((size[i] = file_size(name[i])) < 0) { meme_set_error("cannot read %s", name[i].c_str()); return MEME_E_IO; }
+    if (size[1] % 5 || size[1] / 5 != size[0]) {
+        meme_set_error("%s: .pos_packed (%lld B) and .0123 (%lld B) disagree on the suffix count", prefix, size[1], size[0]);
         return MEME_E_IO;
     }
-    pos.resize(pos.size() + 16);          // (the position image is read as aligned dwords around each 5-byte record)
-    return meme_index_load_host(ctx, pos.data(), (int64_t)text.size(), text.data(), l1.data(), (int64_t)l1.size(),
-                                l2.data(), (int64_t)l2.size());
+    return index_build_from(ctx, size[0], size[3], size[2], [&](int which, void* d_dst, size_t bytes) {
+        if ((long long)bytes != size[which]) { meme_set_error("%s changed size while loading", name[which].c_str()); return (int)MEME_E_IO; }
+        return file_to_device(ctx, name[which], d_dst, bytes);
+    });
 }
 
 extern "C" int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* a) {

@@ -51,13 +51,22 @@ def test_sam_identical_to_reference(tmp_path, paired):
     want = _sam("bwa-meme_mode3", prefix, fqs)
     # chunk-level seeding + combined extension calls: the SAM must not depend on how many worker threads feed the
     # combiner, nor on the -K chunk size (several chunks per run, the last one ragged)
-    for threads, chunk in ((4, 100000000), (16, 400000)):
-        env = dict(os.environ, MEME_INDEX_PREFIX=prefix)
+    # The extension stage has two implementations in the binding: chunk-wide (default; here also with slabs of 1 000 reads
+    # whose staging starts too small and is rebuilt, and with every stage split in three backend calls as on three GPUs)
+    # and the reference's own per-batch function over the combiner (MEME_DROPIN_EXT=0).
+    small = {}
+    for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}),
+                                  (8, 100000000, {"MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
+                                  (16, 400000, {"MEME_DROPIN_EXT": "0"})):
+        env = dict(os.environ, MEME_INDEX_PREFIX=prefix, **extra)
         got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
-        ref = want if chunk == 100000000 else _sam("bwa-meme_mode3", prefix, fqs, threads=threads, chunk=chunk)
+        if chunk == 100000000: ref = want
+        else:
+            if "ref" not in small: small["ref"] = _sam("bwa-meme_mode3", prefix, fqs, threads=threads, chunk=chunk)
+            ref = small["ref"]
         assert len(got) == len(ref) and len(ref) > n
         diff = [(a, b) for a, b in zip(got, ref) if a != b]
-        assert not diff, "threads=%d chunk=%d, first differing SAM line:\n%s\n%s" % ((threads, chunk) + diff[0])
+        assert not diff, "threads=%d chunk=%d %r, first differing SAM line:\n%s\n%s" % ((threads, chunk, extra) + diff[0])
 
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
