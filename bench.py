@@ -319,7 +319,8 @@ def main():
 
     # ---- index: built on rank 0's host, staged on every GPU ----------------------------------------
     meta = torch.zeros(4, dtype=torch.int64, device=dev)
-    fwd = text = sa = l1 = l2 = None
+    fwd = text = sa = l1 = l2 = pre = None
+    ctx = hipapi.Context(local)
     if rank == 0:
         t0 = time.time()
         fwd = synth.make_genome(l_pac, seed=11)
@@ -334,22 +335,32 @@ def main():
             log("genome %.0f Mbp: index loaded from the /dev/shm cache in %.1f s" % (l_pac / 1e6, time.time() - t0))
         else:
             if os.environ.get("MEME_BENCH_SA", "device") == "device":
-                # suffix array on the GPU (meme_sa_build_device: radix sort + prefix doubling), model training on the host
+                # the whole index on the GPU: suffix array (meme_sa_build_device: radix sort + prefix doubling), the 5-byte
+                # image, the probe-ready entries and the P-RMI (meme_prmi_train_device); the host keeps copies for the
+                # reference-format index files of the cpu_baseline / e2e legs
                 text = hipapi.fwd_rc_text(fwd)
-                c0 = hipapi.Context(local)
-                d_t, d_s = hipapi.build_sa_device(c0, text)
-                sa = d_s.cpu().numpy().view(np.uint64)
-                del d_t, d_s
-                c0.close()
-                torch.cuda.empty_cache()
+                d_text0, d_s = hipapi.build_sa_device(ctx, text)
                 t_sa = time.time() - t0
+                d_pos50 = hipapi.pos5_from_sa_torch(ctx, d_s, n)
+                sa = d_s.cpu().numpy().view(np.uint64)
+                del d_s
+                torch.cuda.empty_cache()
+                t1 = time.time()
+                d_pac0, d_ent0 = hipapi.stage_entries_torch(ctx, n, d_text0, d_pos50)
+                use_bits = bits if bits > 0 else (28 if 8.0 * n + 8 > 8.0e9 else 26 if 8.0 * n + 8 > 1.0e9 else 24)   # build_rmis_dna.sh:68-77
+                d_l2_0, n_l2_0, d_l1_0, n_l1_0 = hipapi.train_prmi_device(ctx, d_ent0, n, use_bits)
+                t_train = time.time() - t1
+                l2 = d_l2_0.cpu().numpy().view(hostapi.RMI_DTYPE)
+                l1 = d_l1_0.cpu().numpy().view(hostapi.RMI_DTYPE)[:n_l1_0]
+                pre = (d_text0, d_pos50, d_l2_0, d_l1_0, d_pac0, d_ent0)
+                log("genome %.0f Mbp: suffix array in %.1f s, entries + P-RMI (2^%d leaves, %d partial) in %.1f s, all on the device"
+                    % (l_pac / 1e6, t_sa, use_bits, n_l1_0, t_train))
             else:
                 text, sa = hostapi.build_sa(fwd)
                 t_sa = time.time() - t0
-            l1, l2 = hostapi.train_prmi(text, sa, bits=bits)
-            log("genome %.0f Mbp: suffix array in %.1f s (%s), P-RMI (2^%d leaves, %d partial) trained on the host in %.1f s"
-                % (l_pac / 1e6, t_sa, os.environ.get("MEME_BENCH_SA", "device"), int(np.log2(l2.shape[0])), l1.shape[0],
-                   time.time() - t0 - t_sa))
+                l1, l2 = hostapi.train_prmi(text, sa, bits=bits)
+                log("genome %.0f Mbp: suffix array in %.1f s (host), P-RMI (2^%d leaves, %d partial) trained on the host in %.1f s"
+                    % (l_pac / 1e6, t_sa, int(np.log2(l2.shape[0])), l1.shape[0], time.time() - t0 - t_sa))
             if cache:
                 try:
                     import glob
@@ -371,32 +382,38 @@ def main():
         dist.broadcast(meta, 0)
     n_l2, n_l1 = int(meta[1]), int(meta[2])
     t0 = time.time()
-    ctx = hipapi.Context(local)
     if os.environ.get("MEME_BENCH_LANES"):
         ctx.set_tuning("group_lanes", int(os.environ["MEME_BENCH_LANES"]))
     L = hipapi.lib()
-    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_pos5 = torch.zeros(L.meme_index_pos5_bytes(n), dtype=torch.uint8, device=dev)
-    d_l2 = torch.empty(n_l2 * 24, dtype=torch.uint8, device=dev)
-    d_l1 = torch.empty(max(n_l1, 1) * 24, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        d_text.copy_(torch.from_numpy(text))
-        # the host builder holds the suffix array as u64; the GPU index (and the broadcast) use the reference's 5-byte image
-        d_sa = torch.from_numpy(sa.view(np.int64)).to(dev)
-        d_pos5 = hipapi.pos5_from_sa_torch(ctx, d_sa, n)
-        del d_sa
-        torch.cuda.empty_cache()
-        d_l2.copy_(torch.from_numpy(l2.view(np.uint8).reshape(-1)))
-        if n_l1:
-            d_l1[:n_l1 * 24].copy_(torch.from_numpy(l1.view(np.uint8).reshape(-1)))
+    if pre is not None:
+        d_text, d_pos5, d_l2, d_l1 = pre[:4]
+    else:
+        d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_pos5 = torch.zeros(L.meme_index_pos5_bytes(n), dtype=torch.uint8, device=dev)
+        d_l2 = torch.empty(n_l2 * 24, dtype=torch.uint8, device=dev)
+        d_l1 = torch.empty(max(n_l1, 1) * 24, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            d_text.copy_(torch.from_numpy(text))
+            # the host builder holds the suffix array as u64; the GPU index (and the broadcast) use the reference's 5-byte image
+            d_sa = torch.from_numpy(sa.view(np.int64)).to(dev)
+            d_pos5 = hipapi.pos5_from_sa_torch(ctx, d_sa, n)
+            del d_sa
+            torch.cuda.empty_cache()
+            d_l2.copy_(torch.from_numpy(l2.view(np.uint8).reshape(-1)))
+            if n_l1:
+                d_l1[:n_l1 * 24].copy_(torch.from_numpy(l1.view(np.uint8).reshape(-1)))
     if world > 1:
         # one-off RCCL broadcast of the raw index images over xGMI (5 B per suffix + 1 B per base + the model tables);
         # no collective in steady state
         for t in (d_text, d_pos5, d_l2, d_l1):
             dist.broadcast(t, 0)
     torch.cuda.synchronize()
-    keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, n_l2, d_l1, n_l1)
+    if pre is not None:
+        keep = (pre[4], pre[5]) + hipapi.attach_index_torch(ctx, n, pre[4], pre[5], d_l2, n_l2, d_l1, n_l1)
+    else:
+        keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, n_l2, d_l1, n_l1)
     del d_text, d_l2, d_l1, d_pos5
+    pre = None
     torch.cuda.empty_cache()
     log("index staged in HBM in %.1f s (%.2f GB entries)" % (time.time() - t0, 16 * n / 1e9))
 

@@ -730,6 +730,7 @@ void ext_run_stage(ExtStage& S, int w, const meme_bsw_opt& o) {
             std::lock_guard<std::mutex> lk(dev_mu[p % nd]);
             if (meme_bsw_batch(g_dev[(size_t)(p % nd)].bsw, (meme_seqpair*)P, S.ref + a.rb, b.rb - a.rb, S.qer + a.qb, b.qb - a.qb, (int32_t)n, w, &o))
                 die("meme_bsw_batch");
+            if (verbose()) { meme_timings tm; if (!meme_get_timings(g_dev[(size_t)(p % nd)].bsw, &tm)) g_t_bsw_kernel = g_t_bsw_kernel + tm.bsw_kernel_ms * 1e-3; }
         }
         if (a.rb || a.qb) for (int64_t i = 0; i < n; ++i) { P[i].idr += (int32_t)a.rb; P[i].idq += (int32_t)a.qb; }
     };
@@ -741,6 +742,7 @@ void ext_run_stage(ExtStage& S, int w, const meme_bsw_opt& o) {
         for (auto& t : th) t.join();
     }
     E.t_call += now_s() - t0;
+    g_t_bsw_call = g_t_bsw_call + (now_s() - t0);
     E.n_calls += parts;
     E.n_pairs += S.n;
     g_n_bsw_calls += parts;

@@ -54,7 +54,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -251,26 +251,67 @@ def smems_to_slots(smems, smem_off, hits, hit_off, smem_cap=None):
     return out, counts.astype(np.int32), hl
 
 
-def stage_index_torch(ctx, n, d_text, d_pos5, d_l2_24, n_l2, d_l1_24, n_l1):
-    """Multi-GPU / bench start-up: the raw images (text0123 bytes, 5-byte position image, 24-byte P-RMI records) are
-    already in HBM as torch uint8 tensors (uploaded, or received through an RCCL broadcast); run the staging kernels
-    into torch-owned buffers and attach them.  Returns the tensors that must outlive the ctx."""
+def stage_entries_torch(ctx, n, d_text, d_pos5):
+    """text0123 bytes + 5-byte position image (torch uint8 tensors in HBM) -> 2-bit text words and probe-ready entries."""
     import torch
     L = lib()
     dev = d_text.device
     torch.cuda.synchronize(dev)     # the images were filled on torch's stream; the staging kernels run on the ctx's own stream
     d_pac = torch.empty(L.meme_index_pac64_words(n), dtype=torch.int64, device=dev)
     d_ent = torch.empty(2 * n, dtype=torch.int64, device=dev)
-    d_l2 = torch.empty(n_l2 * 32, dtype=torch.uint8, device=dev)
-    d_l1 = torch.empty(max(n_l1, 1) * 32, dtype=torch.uint8, device=dev)
     h = C.c_void_p(ctx.h)
     _check(L.meme_stage_pack_text(h, C.c_void_p(d_text.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr())))
     _check(L.meme_stage_build_entries(h, C.c_void_p(d_pos5.data_ptr()), C.c_int64(n), C.c_void_p(d_pac.data_ptr()),
                                       C.c_void_p(d_ent.data_ptr())))
+    ctx.sync()
+    return d_pac, d_ent
+
+
+def train_prmi_device(ctx, d_ent, n, bits, partial_threshold=1000):
+    """P-RMI trained on the GPU from the staged entries (meme_prmi_train_device).  Returns (d_l2_24, n_l2, d_l1_24, n_l1):
+    torch uint8 tensors holding the records in the 24-byte file layout."""
+    import torch
+    L = lib()
+    dev = d_ent.device
+    n_l2 = 1 << bits
+    d_l2 = torch.empty(n_l2 * 24, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    cnt = C.c_int64(0)
+    args = (C.c_void_p(ctx.h), C.c_void_p(d_ent.data_ptr()), C.c_int64(n), C.c_int(bits), C.c_int(partial_threshold), C.c_void_p(d_l2.data_ptr()))
+    rc = L.meme_prmi_train_device(*args, C.c_void_p(0), C.c_int64(0), C.byref(cnt))
+    n_l1 = int(cnt.value)
+    d_l1 = torch.empty(max(n_l1, 1) * 24, dtype=torch.uint8, device=dev)
+    if rc != 0:
+        if n_l1 == 0:
+            _check(rc)
+        torch.cuda.synchronize(dev)
+        _check(L.meme_prmi_train_device(*args, C.c_void_p(d_l1.data_ptr()), C.c_int64(n_l1), C.byref(cnt)))
+    ctx.sync()
+    return d_l2, n_l2, d_l1, n_l1
+
+
+def attach_index_torch(ctx, n, d_pac, d_ent, d_l2_24, n_l2, d_l1_24, n_l1):
+    """24-byte model records -> 32-byte records, and the whole index attached to the ctx.  Returns the record tensors."""
+    import torch
+    L = lib()
+    dev = d_ent.device
+    torch.cuda.synchronize(dev)
+    d_l2 = torch.empty(n_l2 * 32, dtype=torch.uint8, device=dev)
+    d_l1 = torch.empty(max(n_l1, 1) * 32, dtype=torch.uint8, device=dev)
+    h = C.c_void_p(ctx.h)
     _check(L.meme_stage_rmi32(h, C.c_void_p(d_l2_24.data_ptr()), C.c_int64(n_l2), C.c_void_p(d_l2.data_ptr())))
     _check(L.meme_stage_rmi32(h, C.c_void_p(d_l1_24.data_ptr()), C.c_int64(n_l1), C.c_void_p(d_l1.data_ptr())))
     ctx.sync()
     ctx.attach_index(IndexArrays(n, d_ent.data_ptr(), d_pac.data_ptr(), d_l2.data_ptr(), n_l2, d_l1.data_ptr(), n_l1))
+    return d_l2, d_l1
+
+
+def stage_index_torch(ctx, n, d_text, d_pos5, d_l2_24, n_l2, d_l1_24, n_l1):
+    """Multi-GPU / bench start-up: the raw images (text0123 bytes, 5-byte position image, 24-byte P-RMI records) are
+    already in HBM as torch uint8 tensors (uploaded, or received through an RCCL broadcast); run the staging kernels
+    into torch-owned buffers and attach them.  Returns the tensors that must outlive the ctx."""
+    d_pac, d_ent = stage_entries_torch(ctx, n, d_text, d_pos5)
+    d_l2, d_l1 = attach_index_torch(ctx, n, d_pac, d_ent, d_l2_24, n_l2, d_l1_24, n_l1)
     return d_pac, d_ent, d_l2, d_l1
 
 

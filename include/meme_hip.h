@@ -126,6 +126,16 @@ int meme_stage_rmi32(meme_ctx* ctx, const void* d_rmi24, int64_t records, void* 
  * (~10 bytes per suffix) is allocated and released inside the call. */
 int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, int64_t sa_num, uint64_t* d_sa);
 
+/* ---- P-RMI training on the device (index building) --------------------------------------------------------------------
+ * Trains the model the aligner loads from <prefix>.suffixarray_uint64_L2_PARAMETERS / _L1_PARAMETERS (reference
+ * src/LearnedIndex_seeding.cpp:74-122; trained offline by RMI/rmi_lib/src/train/two_layer.rs) from the staged entry array
+ * (sorted 32-base keys): 2^bits second-layer records into d_l2_24 and the partial third layer (leaves with more than
+ * partial_threshold keys, default 1000) into d_l1_24, both in the 24-byte file layout.  *l1_records receives the number
+ * of third-layer records; when it exceeds l1_capacity nothing is written and MEME_E_CAPACITY is returned -- call once
+ * with l1_capacity 0 to learn the size.  Same records, bit for bit, as the host trainer (bwa-meme_amd/host/meme_prmi.cpp). */
+int meme_prmi_train_device(meme_ctx* ctx, const void* d_sa_ent, int64_t sa_num, int bits, int partial_threshold,
+                           void* d_l2_24, void* d_l1_24, int64_t l1_capacity, int64_t* l1_records);
+
 /* ---- seeding ------------------------------------------------------------------------------------
  * reads: concatenated base codes 0..3, >=4 = ambiguous (what mem_kernel1_core_Learned leaves in
  * bseq1_t.seq, src/bwamem.cpp:1277-1279); read_off[nreads+1].  A read longer than 500 bases

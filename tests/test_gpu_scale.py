@@ -1,13 +1,14 @@
 """Parity at the size the headline number is quoted on: an index of more than 2^32 suffixes (64-bit slot arithmetic in
 the search kernel, grid-stride staging kernels, the 5-byte position image above 4 G entries), full seed dump against
-the pinned oracle.  Takes a few minutes: the suffix array of 4.3 G suffixes is built on the host first."""
+the pinned oracle.  The index is built the way bench.py builds it -- suffix array, entries and P-RMI on the GPU -- and the
+suffix array is verified here on the host (a permutation whose sampled neighbours are in suffix order) before the oracle uses it."""
 import os
 
 import numpy as np
 import pytest
 
 import oracle_py as O
-from pymeme import hipapi, hostapi, synth, workload
+from pymeme import hipapi, synth, workload
 
 pytestmark = pytest.mark.gpu
 
@@ -28,13 +29,40 @@ def test_seeds_equal_oracle_above_2_pow_32_suffixes():
     n = 2 * l_pac
     assert n > 1 << 32
     g = synth.make_genome(l_pac, seed=11)
-    text, sa = hostapi.build_sa(g)
-    l1, l2 = hostapi.train_prmi(text, sa, bits=24)
+    text = hipapi.fwd_rc_text(g)
     dev = torch.device("cuda", 0)
     ctx = hipapi.Context(0)
     try:
-        d_text = torch.from_numpy(text).to(dev)
-        d_sa = torch.from_numpy(sa.view(np.int64)).to(dev)
+        d_text, d_sa = hipapi.build_sa_device(ctx, text)
+        # a permutation of 0..n-1 ...
+        seen = torch.zeros(n, dtype=torch.bool, device=dev)
+        seen[d_sa] = True
+        assert bool(seen.all())
+        del seen
+        sa = d_sa.cpu().numpy().view(np.uint64)
+        # ... whose neighbours are in suffix order (a suffix that ends sorts as if followed by T's), sampled at the ends, around
+        # slot 2^32 and at random
+        rng = np.random.default_rng(5)
+        slots = np.concatenate([np.arange(0, 400), np.arange((1 << 32) - 200, (1 << 32) + 200), np.arange(n - 401, n - 1),
+                                rng.integers(0, n - 1, size=3000)])
+
+        def suffix(p, m):
+            s_ = text[p:p + m]
+            return s_ if s_.shape[0] == m else np.concatenate([s_, np.full(m - s_.shape[0], 3, np.uint8)])
+
+        for i in slots:
+            a, b = int(sa[i]), int(sa[i + 1])
+            m = 64
+            while True:
+                x, y = suffix(a, m), suffix(b, m)
+                if not np.array_equal(x, y) or m > 1 << 16:
+                    break
+                m *= 4
+            d = np.nonzero(x != y)[0]
+            if d.size == 0:
+                assert a > b, (int(i), a, b)          # both run into the end of the text: the shorter suffix first
+            else:
+                assert x[d[0]] < y[d[0]], (int(i), a, b)
         d_pos5 = hipapi.pos5_from_sa_torch(ctx, d_sa, n)
         # the 5-byte image equals the reference's on-disk encoding, also above 2^32 entries
         for lo in (0, (1 << 32) - 500, n - 1000):
@@ -43,11 +71,9 @@ def test_seeds_equal_oracle_above_2_pow_32_suffixes():
             assert np.array_equal(pos, sa[lo:lo + 1000]), lo
         del d_sa
         torch.cuda.empty_cache()
-        d_l2 = torch.from_numpy(l2.view(np.uint8).reshape(-1)).to(dev)
-        d_l1 = torch.zeros(max(l1.shape[0], 1) * 24, dtype=torch.uint8, device=dev)
-        if l1.shape[0]:
-            d_l1[:l1.shape[0] * 24].copy_(torch.from_numpy(np.ascontiguousarray(l1).view(np.uint8).reshape(-1)))
-        keep = hipapi.stage_index_torch(ctx, n, d_text, d_pos5, d_l2, l2.shape[0], d_l1, l1.shape[0])
+        d_pac, d_ent0 = hipapi.stage_entries_torch(ctx, n, d_text, d_pos5)
+        d_l2, n_l2, d_l1, n_l1 = hipapi.train_prmi_device(ctx, d_ent0, n, 24)
+        keep = (d_pac, d_ent0) + hipapi.attach_index_torch(ctx, n, d_pac, d_ent0, d_l2, n_l2, d_l1, n_l1)
         d_ent = keep[1].view(-1, 2)
         # entries: keys sorted, positions = the suffix array, and each key the first 32 bases of the suffix its slot points to
         # (sampled around 2^32 and at the ends)
