@@ -258,6 +258,8 @@ def e2e_leg(prefix, genome, npairs, threads):
                                  r"([0-9.]+), backend calls ([0-9.]+) s of which kernels ([0-9.]+) s\)", err):
                 info["backend"] = {"seeding_s": float(m.group(1)), "bsw_calls": int(m.group(3)), "bsw_pairs": int(m.group(4)),
                                    "bsw_backend_s": float(m.group(6)), "bsw_kernel_s": float(m.group(7))}
+            for m in re.finditer(r"extension: this chunk .*?totals ([0-9.]+) s, (\d+) backend calls", err):
+                info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # jobs built + calls + fold + purge
             out[exe] = info
             log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
         ref, drop = out["bwa-meme_mode3"], out["bwa-meme_dropin"]
