@@ -101,40 +101,53 @@ def make_bsw_pairs(n_pairs: int, seed: int, read_len: int = 150, base: int = 819
     return out, np.concatenate(refs), np.concatenate(qers), base
 
 
-def make_bsw_pairs_distinct(n_pairs: int, seed: int, read_len: int = 150, sub=0.01, indel_frac=0.2, amb=0.001):
-    """Like make_bsw_pairs, but every pair is its own job (vectorised generator): query = 1 .. read_len-19 random bases,
-    target = the same stretch with substitutions, one 1-3 base indel in `indel_frac` of the pairs, plus the gap allowance
-    (10-59 random bases, cal_max_gap, reference src/bwamem.cpp:85-95); h0 the seed's score.  Sequences are packed
-    back to back.  Returns (pairs[SEQPAIR], ref bytes, query bytes)."""
-    from .hipapi import SEQPAIR
-    rng = np.random.default_rng(seed)
-    ql = rng.integers(1, read_len - 19 + 1, size=n_pairs).astype(np.int64)
-    gap = rng.integers(10, 60, size=n_pairs).astype(np.int64)
-    ind = np.where(rng.random(n_pairs) < indel_frac, rng.integers(-3, 4, size=n_pairs), 0).astype(np.int64)
-    ind = np.where(ql + ind < 1, 0, ind)
+def _bsw_pairs_distinct_block(n_pairs: int, rng, read_len, sub, indel_frac, amb):
+    ql = rng.integers(1, read_len - 19 + 1, size=n_pairs).astype(np.int32)
+    gap = rng.integers(10, 60, size=n_pairs).astype(np.int32)
+    ind = np.where(rng.random(n_pairs) < indel_frac, rng.integers(-3, 4, size=n_pairs), 0).astype(np.int32)
+    ind = np.where(ql + ind < 1, 0, ind).astype(np.int32)
     tl = ql + ind + gap
     qo = np.zeros(n_pairs + 1, np.int64); qo[1:] = np.cumsum(ql)
     to = np.zeros(n_pairs + 1, np.int64); to[1:] = np.cumsum(tl)
     qer = rng.integers(0, 4, size=int(qo[-1]), dtype=np.uint8)
     ref = rng.integers(0, 4, size=int(to[-1]), dtype=np.uint8)
     # copy the query into the head of its target, shifted past the indel point
-    pid_q = np.repeat(np.arange(n_pairs), ql)
-    j = np.arange(int(qo[-1]), dtype=np.int64) - qo[pid_q]                    # position inside the query
-    cut = (ql // 2)[pid_q]
-    shift = np.where(j >= cut, ind[pid_q], 0)
-    tj = j + shift
+    pid_q = np.repeat(np.arange(n_pairs, dtype=np.int32), ql)
+    j = (np.arange(int(qo[-1]), dtype=np.int64) - qo[pid_q]).astype(np.int32)     # position inside the query
+    tj = j + np.where(j >= (ql >> 1)[pid_q], ind[pid_q], 0).astype(np.int32)
     ok = (tj >= 0) & (tj < (ql + ind)[pid_q])
     ref[(to[pid_q] + tj)[ok]] = qer[ok]
-    sm = rng.random(ref.shape[0]) < sub
-    ref[sm] = (ref[sm] + rng.integers(1, 4, size=int(sm.sum()), dtype=np.uint8)) & 3
-    ref[rng.random(ref.shape[0]) < amb] = 4
+    # substitutions and ambiguous bases at their expected number of random positions (cheaper than a draw per base)
+    nb = ref.shape[0]
+    sm = rng.integers(0, nb, size=rng.binomial(nb, sub))
+    ref[sm] = (ref[sm] + rng.integers(1, 4, size=sm.shape[0], dtype=np.uint8)) & 3
+    ref[rng.integers(0, nb, size=rng.binomial(nb, amb))] = 4
+    h0 = np.where(rng.random(n_pairs) < 0.7, read_len - ql, rng.integers(19, read_len, size=n_pairs))
+    return ql, tl, qo, to, qer, ref, h0
+
+
+def make_bsw_pairs_distinct(n_pairs: int, seed: int, read_len: int = 150, sub=0.01, indel_frac=0.2, amb=0.001):
+    """Like make_bsw_pairs, but every pair is its own job (vectorised generator, built in cache-sized blocks): query =
+    1 .. read_len-19 random bases, target = the same stretch with substitutions, one 1-3 base indel in `indel_frac` of the
+    pairs, plus the gap allowance (10-59 random bases, cal_max_gap, reference src/bwamem.cpp:85-95); h0 the seed's score.
+    Sequences are packed back to back.  Returns (pairs[SEQPAIR], ref bytes, query bytes)."""
+    from .hipapi import SEQPAIR
+    rng = np.random.default_rng(seed)
     pairs = np.zeros(n_pairs, dtype=SEQPAIR)
-    pairs["idr"] = to[:-1]; pairs["idq"] = qo[:-1]
-    pairs["len1"] = tl; pairs["len2"] = ql
-    pairs["h0"] = np.where(rng.random(n_pairs) < 0.7, read_len - ql, rng.integers(19, read_len, size=n_pairs))
+    refs, qers = [], []
+    rbase = qbase = 0
+    block = 1 << 16
+    for p0 in range(0, n_pairs, block):
+        m = min(block, n_pairs - p0)
+        ql, tl, qo, to, qer, ref, h0 = _bsw_pairs_distinct_block(m, rng, read_len, sub, indel_frac, amb)
+        v = pairs[p0:p0 + m]
+        v["idr"] = to[:-1] + rbase; v["idq"] = qo[:-1] + qbase
+        v["len1"] = tl; v["len2"] = ql; v["h0"] = h0
+        refs.append(ref); qers.append(qer)
+        rbase += ref.shape[0]; qbase += qer.shape[0]
     pairs["id"] = np.arange(n_pairs, dtype=np.int32)
     pairs["seqid"] = pairs["id"]
-    return pairs, ref, qer
+    return pairs, np.concatenate(refs), np.concatenate(qers)
 
 
 def write_fastq_fast(path: str, reads: np.ndarray, prefix: str = "r") -> None:
