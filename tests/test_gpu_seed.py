@@ -199,3 +199,37 @@ def test_hip_seeds_equal_oracle_midsize_default_model(tmp_path):
             assert _gpu_dump(c, reads, off) == O.format_seed_dump(sm, ns, hits), L
     finally:
         c.close()
+
+
+def test_index_files_loader_errors_and_equals_host_loader(g1, tmp_path):
+    """meme_index_load_files streams the four files to the device through pinned pieces; the same failure modes as the
+    reference's loader (message + error code instead of its exit, src/fastmap.cpp:430-433, 472-475), and the same index
+    as meme_index_load_host on the same bytes."""
+    import shutil
+    c = hipapi.Context(0)
+    try:
+        with pytest.raises(hipapi.MemeError, match="cannot read"):
+            c.load_index_files(str(tmp_path / "nothing_here"))
+        broken = str(tmp_path / "broken")
+        for ext in (".0123", ".pos_packed", ".suffixarray_uint64_L1_PARAMETERS", ".suffixarray_uint64_L2_PARAMETERS"):
+            shutil.copy(g1 + ext, broken + ext)
+        with open(broken + ".pos_packed", "ab") as fh:
+            fh.write(b"\0" * 5)                                  # one suffix more than the text has bases
+        with pytest.raises(hipapi.MemeError, match="disagree"):
+            c.load_index_files(broken)
+        with open(broken + ".pos_packed", "r+b") as fh:
+            fh.truncate(os.path.getsize(g1 + ".pos_packed"))
+        with open(broken + ".suffixarray_uint64_L2_PARAMETERS", "ab") as fh:
+            fh.write(b"\0" * 24)                                 # no longer a power of two of records
+        with pytest.raises(hipapi.MemeError, match="power-of-two"):
+            c.load_index_files(broken)
+        reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_150.fq"))
+        want = open(os.path.join(GOLDEN, "g1_seeds_150.txt")).read()
+        c.load_index_host(np.fromfile(g1 + ".pos_packed", np.uint8), np.fromfile(g1 + ".0123", np.uint8),
+                          np.fromfile(g1 + ".suffixarray_uint64_L1_PARAMETERS", np.uint8),
+                          np.fromfile(g1 + ".suffixarray_uint64_L2_PARAMETERS", np.uint8))
+        assert _gpu_dump(c, reads, off) == want
+        c.load_index_files(g1)                                   # a ctx can be re-loaded
+        assert _gpu_dump(c, reads, off) == want
+    finally:
+        c.close()
