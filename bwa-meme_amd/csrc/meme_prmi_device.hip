@@ -20,6 +20,10 @@
 
 #include "meme_common.h"
 
+// The records have to equal the host trainer's bit for bit: no implicit fused multiply-adds (the host build pins the same,
+// -ffp-contract=off); the one FMA of the model is the explicit fma() of the prediction, as in the aligner.
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ inline double lin(double icpt, double slope, double x) { return fma(slope, x, icpt); }
