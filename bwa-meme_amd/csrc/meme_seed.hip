@@ -210,7 +210,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         if (rb < 1) rb = 1;
         i64 pblocks = (nreads + rb - 1) / rb;
         if (pblocks > (i64)dev_cus * 16) pblocks = (i64)dev_cus * 16;   // grid-stride beyond that
-        size_t plds = ((size_t)rb * (size_t)stage_len + 16 + 3) & ~(size_t)3;
+        size_t plds = ((size_t)rb * (size_t)stage_len + 16 + 48 + 3) & ~(size_t)3;   // + the packer's 9-dword reads past a read's last word
         hipLaunchKernelGGL(k_pack_reads, dim3((unsigned)pblocks), dim3(256), plds, ctx->stream, d_reads,
                            d_read_off, nreads, total_bytes, geo, rb, (u64*)ctx->packed.p);
         HIP_TRY(hipGetLastError());

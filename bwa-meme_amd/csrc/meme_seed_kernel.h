@@ -133,19 +133,50 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
             int len = (int)(read_off[r + 1] - ro);
             u64 v = 0;
             if (len > MAX_READ_LEN) len = 0;
-            const uint8_t* p = sb + shift + (int)(ro - b0);
+            const int po = shift + (int)(ro - b0);              // the read's first byte in the staged area
+            const uint8_t* p = sb + po;
             if (k < 2 * g.W) {
                 const bool rc = k >= g.W;
                 const int w = rc ? k - g.W : k;
-#pragma unroll 16
-                for (int j = 0; j < 32; ++j) {
-                    const int i = 32 * w + j;
-                    u64 c = 0;
-                    if (i < len) {
-                        const uint8_t bb = rc ? p[len - 1 - i] : p[i];
-                        c = bb < 4 ? (rc ? 3 - bb : bb) : 0;   // N packed as A (src/bwamem.cpp:1293-1294)
+                const int nvalid = len - 32 * w;                // bases of this word
+                if (nvalid <= 0) v = 0;
+                else if (!has_n[rr]) {
+                    // Every byte of the read is 0..3: 32 bases = 8 staged dwords (re-aligned with v_alignbyte), four bases
+                    // of a dword gathered into one byte by a multiplication, no per-base loop.  Forward: bases 32w..32w+31;
+                    // reverse complement: the same for the 32 bases that END at len-1-32w, bytes and dwords in reverse
+                    // order, complemented.  Bytes beyond the read (the neighbours' bases) are shifted / masked away.
+                    const int s0 = rc ? (nvalid >= 32 ? nvalid - 32 : 0) : 32 * w;
+                    const int o = po + s0, dwi = o >> 2;
+                    const unsigned sh = (unsigned)(o & 3);
+                    uint32_t a[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) a[q] = stage[dwi + q];
+                    if (!rc) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const uint32_t x = __builtin_amdgcn_alignbyte(a[q + 1], a[q], sh) & 0x03030303u;
+                            v = (v << 8) | ((x * 0x40100401u) >> 24);          // first base of the dword in the top two bits
+                        }
+                        if (nvalid < 32) v &= ~0ull << (2 * (32 - nvalid));
+                    } else {
+#pragma unroll
+                        for (int q = 7; q >= 0; --q) {
+                            const uint32_t x = (__builtin_amdgcn_alignbyte(a[q + 1], a[q], sh) & 0x03030303u) ^ 0x03030303u;
+                            v = (v << 8) | ((x * 0x01041040u) >> 24);          // last base of the dword in the top two bits
+                        }
+                        if (nvalid < 32) v <<= 2 * (32 - nvalid);
                     }
-                    v = (v << 2) | c;
+                } else {
+#pragma unroll 16
+                    for (int j = 0; j < 32; ++j) {
+                        const int i = 32 * w + j;
+                        u64 c = 0;
+                        if (i < len) {
+                            const uint8_t bb = rc ? p[len - 1 - i] : p[i];
+                            c = bb < 4 ? (rc ? 3 - bb : bb) : 0;   // N packed as A (src/bwamem.cpp:1293-1294)
+                        }
+                        v = (v << 2) | c;
+                    }
                 }
             } else if (has_n[rr]) {
                 int m = k - 2 * g.W;
