@@ -77,33 +77,49 @@ __global__ void __launch_bounds__(256) k_sa_hist(const u64* __restrict__ pac, i6
     if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
 }
 
-// (key, position) of every suffix whose first four bases fall into buckets [b0, b1); order does not matter (sorted next)
+// (key, position) of every suffix whose first four bases fall into buckets [b0, b1); order does not matter (sorted next).
+// A workgroup takes tiles of 4 096 consecutive suffixes: every lane notes which of its 16 suffixes qualify, one scan over
+// the workgroup and ONE global atomic per tile reserve the output range (a reservation per wavefront round -- 16 M atomics on
+// one address per pass over a 1 G-suffix text -- made this kernel 85 % of the whole construction).
+constexpr int GATHER_ITEMS = 16;
 __global__ void __launch_bounds__(256) k_sa_gather(const u64* __restrict__ pac, i64 n, unsigned b0, unsigned b1,
                                                     unsigned long long* __restrict__ counter, u64* __restrict__ keys,
                                                     u64* __restrict__ vals) {
-    const int lane = threadIdx.x & 63;
-    const i64 stride = (i64)gridDim.x * blockDim.x;
-    const i64 n_up = (n + stride - 1) / stride * stride;       // every lane runs the same number of rounds (ballots below)
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += stride) {
-        u64 k = 0;
-        bool take = false;
-        if (i < n) {
-            k = sa_key(pac, n, i);
-            const unsigned b = (unsigned)(k >> 56);
-            take = b >= b0 && b < b1;
-        }
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            unsigned long long basep = 0;
-            const int first = __ffsll((long long)m) - 1;
-            if (lane == first) basep = atomicAdd(counter, (unsigned long long)__popcll(m));
-            basep = ((unsigned long long)(unsigned)__shfl((int)(basep >> 32), first) << 32) | (unsigned)__shfl((int)(basep & 0xffffffffull), first);
-            if (take) {
-                const unsigned long long p = basep + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-                keys[p] = k;
-                vals[p] = (u64)i;
+    __shared__ unsigned int wsum[4];
+    __shared__ unsigned long long tile_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 tile = (i64)256 * GATHER_ITEMS;
+    const i64 ntiles = (n + tile - 1) / tile;
+    for (i64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const i64 i0 = tl * tile + threadIdx.x;
+        unsigned mask = 0;
+#pragma unroll
+        for (int r = 0; r < GATHER_ITEMS; ++r) {
+            const i64 i = i0 + (i64)256 * r;
+            if (i < n) {
+                const unsigned b = (unsigned)(sa_key(pac, n, i) >> 56);
+                if (b >= b0 && b < b1) mask |= 1u << r;
             }
         }
+        const unsigned cnt = (unsigned)__popc(mask);
+        unsigned incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned v = (unsigned)__shfl_up((int)incl, d); if (lane >= d) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+        if (threadIdx.x == 0) tile_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        unsigned long long p = tile_base + woff + (incl - cnt);
+        for (unsigned m = mask; m; m &= m - 1) {
+            const i64 i = i0 + (i64)256 * (__ffs((int)m) - 1);
+            keys[p] = sa_key(pac, n, i);
+            vals[p] = (u64)i;
+            ++p;
+        }
+        __syncthreads();                                       // wsum / tile_base are reused by the next tile
     }
 }
 
@@ -259,7 +275,7 @@ extern "C" int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, in
         i64 m = 0;
         for (unsigned b = g.first; b < g.second; ++b) m += (i64)h_hist[b];
         HIP_TRY(hipMemsetAsync(d_nsel, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_sa_gather, dim3(grid_for(N)), dim3(256), 0, st, (const u64*)pac, N, g.first, g.second, d_nsel, ka, va);
+        hipLaunchKernelGGL(k_sa_gather, dim3(grid_for((N + GATHER_ITEMS - 1) / GATHER_ITEMS)), dim3(256), 0, st, (const u64*)pac, N, g.first, g.second, d_nsel, ka, va);
         hipcub::DoubleBuffer<u64> dk(ka, kb), dv(va, vb);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, dk, dv, m, 0, 64, st));
         hipLaunchKernelGGL(k_sa_heads, dim3(grid_for(m)), dim3(256), 0, st, (const u64*)dk.Current(), (const u64*)nullptr, m, head, vv);
