@@ -560,6 +560,12 @@ struct Ext {
     std::vector<mem_alnreg_v> av;               // per read of the chunk; arrays pass to the reference batch by batch
     std::vector<std::vector<uint32_t>> order;   // per block: seed indices in extension order, chain after chain (srtgg)
     std::vector<int64_t> order_off;             // per read: where its seeds start in its block's `order`
+    // alignment records of the chunk in ONE buffer kept across chunks (reg_off[g] = first record of read g).  A batch copies
+    // its reads' records into calloc'ed arrays of its own when it takes them: the reference frees them one by one, and small
+    // allocations made by the helper threads would grow 255 fresh malloc arenas page by page (2.7 s for a first chunk of 2 M reads).
+    mem_alnreg_t* regs = nullptr;
+    int64_t regs_cap = 0;
+    std::vector<int64_t> reg_off;
     ExtStage L, R, X[2];
     std::vector<SeqPair> retry;                 // jobs of the stage just folded that need the next band width
     std::mutex retry_mu;
@@ -600,11 +606,10 @@ void ext_build_block(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* p
         const int l_query = seqs[g].l_seq;
         mem_chain_v* chn = &chain_ar[g];
         mem_alnreg_v* av = &E.av[(size_t)g];
-        free(av->a);                                              // only set when the slab is being rebuilt
-        av->m = 0;
-        for (size_t j = 0; j < chn->n; ++j) av->m += (size_t)chn->a[j].n;
+        av->m = (size_t)(E.reg_off[(size_t)g + 1] - E.reg_off[(size_t)g]);      // one record per chained seed
         av->n = 0;
-        av->a = (mem_alnreg_t*)calloc(av->m, sizeof(mem_alnreg_t));
+        av->a = E.regs + E.reg_off[(size_t)g];
+        if (av->m) memset(av->a, 0, av->m * sizeof(mem_alnreg_t));
         E.order_off[(size_t)g] = (int64_t)order.size();
         for (size_t j = 0; j < chn->n; ++j) {
             mem_chain_t* c = &chn->a[j];
@@ -880,6 +885,26 @@ void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, co
     E.av.assign((size_t)n, mem_alnreg_v());
     for (mem_alnreg_v& v : E.av) memset(&v, 0, sizeof(v));
     E.order_off.assign((size_t)n, 0);
+    E.reg_off.assign((size_t)n + 1, 0);
+    {
+        const int64_t step = 4096;
+        const std::function<void(int64_t)> count = [&](int64_t item) {
+            const int64_t g1 = (item + 1) * step < n ? (item + 1) * step : n;
+            for (int64_t g = item * step; g < g1; ++g) {
+                int64_t m = 0;
+                for (size_t j = 0; j < chain_ar[g].n; ++j) m += chain_ar[g].a[j].n;
+                E.reg_off[(size_t)g + 1] = m;
+            }
+        };
+        E.team.run((n + step - 1) / step, count);
+        for (int64_t g = 0; g < n; ++g) E.reg_off[(size_t)g + 1] += E.reg_off[(size_t)g];
+        const int64_t total = E.reg_off[(size_t)n];
+        if (total > E.regs_cap) {
+            free(E.regs);
+            E.regs_cap = total + total / 8 + 1024;
+            if (!(E.regs = (mem_alnreg_t*)malloc((size_t)E.regs_cap * sizeof(mem_alnreg_t)))) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+        }
+    }
     const int64_t slab_reads = ext_slab_reads();
     meme_bsw_opt ol, orr;
     memset(&ol, 0, sizeof(ol));
@@ -979,10 +1004,11 @@ void mem_chain2aln_across_reads_V2(const mem_opt_t* opt, const bntseq_t* bns, co
             g_ext->gen = g_chunk_gen;
         }
     }
-    for (int l = 0; l < nseq; ++l) {
-        mem_alnreg_v& src = g_ext->av[(size_t)(g0 + l)];
-        av_v[l].n = src.n; av_v[l].m = src.m; av_v[l].a = src.a;
-        src.a = nullptr;
+    for (int l = 0; l < nseq; ++l) {                       // this batch's alignment arrays, owned by the reference from here on (:2633)
+        const mem_alnreg_v& src = g_ext->av[(size_t)(g0 + l)];
+        mem_alnreg_t* a = (mem_alnreg_t*)calloc(src.m, sizeof(mem_alnreg_t));
+        if (src.n) { if (!a) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); } memcpy(a, src.a, src.n * sizeof(mem_alnreg_t)); }
+        av_v[l].n = src.n; av_v[l].m = src.m; av_v[l].a = a;
     }
 }
 

@@ -41,7 +41,9 @@ for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
     if os.environ.get("E2E_BSW_TRACE"): env["MEME_BSW_TRACE"] = "1"
     t0 = time.time()
     with open(out, "wb") as fh:
-        r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
+        chunk = os.environ.get("E2E_CHUNK", "100000000")       # E2E_CHUNK=default: the aligner's own chunking (10 M bases x threads)
+        kopt = [] if chunk == "default" else ["-K", chunk]
+        r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y"] + kopt + ["-t", str(threads), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
     wall = time.time() - t0
     err = r.stderr.decode()
     if os.environ.get("E2E_STDERR_DIR"):
