@@ -73,11 +73,15 @@ void init_devices(const char* prefix) {
     int n = meme_device_count();
     if (n <= 0) die("no HIP device");
     if (getenv("MEME_DROPIN_DEVICES")) { int want = atoi(getenv("MEME_DROPIN_DEVICES")); if (want >= 1 && want < n) n = want; }
+    // MEME_DROPIN_VIRTUAL=k (tests): k device slots cycling over the real devices, so that the multi-GPU paths -- a chunk's
+    // reads split over the slots, replicas of the index, one extension call per slot -- also run on a one-GPU box
+    const int n_real = n;
+    if (getenv("MEME_DROPIN_VIRTUAL") && atoi(getenv("MEME_DROPIN_VIRTUAL")) > n) n = atoi(getenv("MEME_DROPIN_VIRTUAL"));
     g_dev.resize((size_t)n);
     const double t0 = now_s();
     for (int d = 0; d < n; ++d) {
-        if (!(g_dev[(size_t)d].seed = meme_ctx_create(d))) die("meme_ctx_create");
-        if (!(g_dev[(size_t)d].bsw = meme_ctx_create(d))) die("meme_ctx_create");
+        if (!(g_dev[(size_t)d].seed = meme_ctx_create(d % n_real))) die("meme_ctx_create");
+        if (!(g_dev[(size_t)d].bsw = meme_ctx_create(d % n_real))) die("meme_ctx_create");
         // small combined calls keep the lanes-per-pair kernels; combined calls of the whole thread team are big enough
         // for the lane-per-pair kernel much earlier than a lone caller's
         if (getenv("MEME_DROPIN_BSW_LANE_MIN")) meme_set_tuning(g_dev[(size_t)d].bsw, "bsw_lane_min_pairs", atoll(getenv("MEME_DROPIN_BSW_LANE_MIN")));

@@ -53,11 +53,14 @@ def test_sam_identical_to_reference(tmp_path, paired):
     # combiner, nor on the -K chunk size (several chunks per run, the last one ragged)
     # The extension stage has two implementations in the binding: chunk-wide (default; here also with slabs of 1 000 reads
     # whose staging starts too small and is rebuilt, and with every stage split in three backend calls as on three GPUs)
-    # and the reference's own per-batch function over the combiner (MEME_DROPIN_EXT=0).
+    # and the reference's own per-batch function over the combiner (MEME_DROPIN_EXT=0).  MEME_DROPIN_VIRTUAL=3 runs the
+    # multi-GPU arrangement (three device slots: reads of a chunk split three ways, index replicas, one extension call per slot)
+    # on however many GPUs the box has.
     small = {}
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}),
                                   (8, 100000000, {"MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
-                                  (16, 400000, {"MEME_DROPIN_EXT": "0"})):
+                                  (16, 400000, {"MEME_DROPIN_EXT": "0"}),
+                                  (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"})):
         env = dict(os.environ, MEME_INDEX_PREFIX=prefix, **extra)
         got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
         if chunk == 100000000: ref = want
