@@ -575,7 +575,7 @@ struct Ext {
     std::mutex retry_mu;
     Team team;
     double t_build = 0, t_call = 0, t_fold = 0, t_purge = 0, t_total = 0;
-    int64_t n_calls = 0, n_pairs = 0, n_rebuilt = 0;
+    int64_t n_calls = 0, n_pairs = 0, n_rebuilt = 0, n_retried = 0;
 } *g_ext = nullptr;
 
 inline int ext_max_gap(const mem_opt_t* opt, int qlen) {          // cal_max_gap, src/bwamem.cpp:85-95
@@ -953,6 +953,7 @@ void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, co
                 ext_run_stage(*S, w, dir == 0 ? ol : orr);
                 ext_fold(opt, seqs, slab0, *S, dir == 0, w, attempt);
                 if (E.retry.empty()) break;
+                E.n_retried += (int64_t)E.retry.size();
                 ExtStage* again = &E.X[attempt & 1];
                 ext_stage_retry(*S, *again);
                 S = again;
@@ -974,8 +975,9 @@ void ext_report() {
     const Ext& E = *g_ext;
     static double last[5] = {0, 0, 0, 0, 0};
     fprintf(stderr, "[meme-dropin] extension: this chunk %.3f s (jobs built %.3f, backend calls %.3f, folded %.3f, purged %.3f); totals %.3f s, "
-            "%lld backend calls with %lld pairs, %lld slab rebuilds\n", E.t_total - last[0], E.t_build - last[1], E.t_call - last[2],
-            E.t_fold - last[3], E.t_purge - last[4], E.t_total, (long long)E.n_calls, (long long)E.n_pairs, (long long)E.n_rebuilt);
+            "%lld backend calls with %lld pairs (%lld of them again with the doubled band), %lld slab rebuilds\n", E.t_total - last[0],
+            E.t_build - last[1], E.t_call - last[2], E.t_fold - last[3], E.t_purge - last[4], E.t_total, (long long)E.n_calls,
+            (long long)E.n_pairs, (long long)E.n_retried, (long long)E.n_rebuilt);
     last[0] = E.t_total; last[1] = E.t_build; last[2] = E.t_call; last[3] = E.t_fold; last[4] = E.t_purge;
 }
 

@@ -91,3 +91,51 @@ def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
     assert len(got) == len(want) and len(want) > n
     diff = [(a, b) for a, b in zip(got, want) if a != b]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
+    """Reads that need the second band width (an 80-95-base deletion or insertion next to the seed: max_off >= 3w/4, so the job
+    is run again with w = 200, src/bwamem.cpp:2985-3018), 250-bp reads with 5 % substitutions (BASELINE configs[5]) and reads
+    too short to seed, mixed in one run; the chunk-wide extension stage must report that it took the retry path."""
+    import re
+    g = synth.make_genome(600_000, seed=51, repeat_frac=0.05, n_families=4, n_dups=4, dup_len=1000)
+    fa = str(tmp_path / "gaps.fa")
+    synth.write_fasta(fa, g, contigs=2)
+    prefix = build_index(fa, bits=14)
+    rng = np.random.default_rng(52)
+    rows = []
+    for _ in range(1500):
+        p = int(rng.integers(1000, g.shape[0] - 2000))
+        d = int(rng.integers(80, 96))
+        if rng.random() < 0.5:                                   # deletion in the read: two stretches of the genome, d bases apart
+            r = np.concatenate([g[p:p + 110], g[p + 110 + d:p + 110 + d + 140]])
+        else:                                                    # insertion of d random bases
+            r = np.concatenate([g[p:p + 90], rng.integers(0, 4, size=d).astype(np.uint8), g[p + 90:p + 90 + 160 - d]])
+        r = r[:250].copy()
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        rows.append(r)
+    noisy, _, _ = synth.make_reads(g, 1500, 250, seed=53, sub_rate=0.05, indel_rate=0.0075, n_frac=0.02)
+    short, _, _ = synth.make_reads(g, 300, 250, seed=54)
+    fq = str(tmp_path / "gaps.fq")
+    with open(fq, "w") as fh:
+        k = 0
+        for r in rows + list(noisy):
+            fh.write("@g%d\n%s\n+\n%s\n" % (k, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+            k += 1
+        for r in short:                                          # 12 - 30 bases: below or just above min_seed_len
+            L = 12 + k % 19
+            fh.write("@g%d\n%s\n+\n%s\n" % (k, "".join("ACGTN"[c] for c in r[:L]), "I" * L))
+            k += 1
+    want = _sam("bwa-meme_mode3", prefix, [fq], threads=8)
+    cmd = [os.path.join(REF, "bwa-meme_dropin"), "mem", "-7", "-Y", "-K", "100000000", "-t", "8", prefix, fq]
+    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
+    assert len(got) == len(want) and len(want) > 3300
+    diff = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+    m = re.search(r"\((\d+) of them again with the doubled band\)", r.stderr.decode())
+    assert m and int(m.group(1)) > 100, r.stderr.decode()[-1500:]
