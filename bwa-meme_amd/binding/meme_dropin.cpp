@@ -182,6 +182,7 @@ namespace {
 struct ChunkPart {                     // the slice of a chunk one GPU seeded
     int64_t first = 0, count = 0;
     meme_seed_host_result res;
+    meme_chain_host_result chains;                       // valid when g_chain_on_device
     uint8_t* flat = nullptr; int64_t flat_cap = 0;       // pinned staging (grow-only)
     int64_t* off = nullptr; int64_t off_cap = 0;
 };
@@ -190,6 +191,12 @@ struct Chunk {
     int64_t n = 0;
     std::vector<ChunkPart> part;
 } g_chunk;
+
+const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process_seqs)
+std::vector<meme_contig> g_contigs;
+bool chain_on_device() { static const bool v = !(getenv("MEME_DROPIN_CHAIN") && atoi(getenv("MEME_DROPIN_CHAIN")) == 0); return v; }
+bool chain_check() { static const bool v = getenv("MEME_DROPIN_CHAIN_CHECK") != nullptr; return v; }
+std::atomic<int64_t> g_n_chain_fallback{0}, g_n_chain_reads{0};
 
 meme_seed_opt seed_opt_of(const mem_opt_t* opt) {
     meme_seed_opt so;
@@ -217,6 +224,14 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     }
     const meme_seed_opt so = seed_opt_of(opt);
     if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
+    memset(&P.chains, 0, sizeof(P.chains));
+    if (chain_on_device() && P.count > 0) {              // mem_chain_Learned + mem_chain_flt while the seeds are still in HBM
+        meme_chain_opt co;
+        co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;
+        co.min_chain_weight = opt->min_chain_weight; co.max_chain_extend = opt->max_chain_extend;
+        co.mask_level = opt->mask_level; co.drop_ratio = opt->drop_ratio; co.l_pac = g_bns->l_pac;
+        if (meme_chain_last_batch_host(g_dev[(size_t)d].seed, g_contigs.data(), (int32_t)g_contigs.size(), &co, &P.chains)) die("meme_chain_last_batch_host");
+    }
 }
 
 void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n) {
@@ -258,6 +273,10 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_process_seqs was not found: %s\n", dlerror()); exit(1); }
     }
     g_team = opt->n_threads > 0 ? opt->n_threads : 1;
+    if (w.useLearned && !g_bns) {
+        g_bns = w.fmi->idx->bns;
+        for (int i = 0; i < g_bns->n_seqs; ++i) g_contigs.push_back({g_bns->anns[i].offset, g_bns->anns[i].len, g_bns->anns[i].is_alt});
+    }
     if (w.useLearned) { seed_chunk(opt, seqs, n); ++g_chunk_gen; }
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
@@ -266,8 +285,93 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
                 "(copy-in thread-seconds %.3f, backend calls %.3f s of which kernels %.3f s)\n",
                 (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs,
                 (double)g_t_bsw_gather, (double)g_t_bsw_call, (double)g_t_bsw_kernel);
+    if (verbose() && chain_on_device())
+        fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead (scratch capacity / equal positions)\n",
+                (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
     if (verbose()) ext_report();
 }
+
+namespace {
+
+// one read's chains on the host, with the reference's own functions (src/bwamem.cpp:1396-1407)
+void host_chain_read(const mem_opt_t* opt, const bntseq_t* bns, const bseq1_t& rd, const ChunkPart& P, int64_t r, int seqid, mem_tlv* smems,
+                     u64v* hits, mem_chain_v* chain, mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid) {
+    const int64_t s0 = P.res.smem_off[r], ns = P.res.smem_off[r + 1] - s0;
+    const int64_t h0 = P.res.hit_off[r], nh = P.res.hit_off[r + 1] - h0;
+    smems->n = 0;
+    hits->n = 0;
+    if ((int64_t)smems->m < ns) kv_resize(mem_tl, *smems, (size_t)ns);
+    if ((int64_t)hits->m < nh) kv_resize(uint64_t, *hits, (size_t)nh);
+    if (ns) memcpy(smems->a, P.res.smems + s0, (size_t)ns * sizeof(mem_tl));
+    if (nh) memcpy(hits->a, P.res.hits + h0, (size_t)nh * sizeof(uint64_t));
+    smems->n = (size_t)ns;
+    hits->n = (size_t)nh;
+    ks_introsort(meme_dropin_smem, smems->n, smems->a);            // src/bwamem.cpp:1397
+    kv_init(*chain);
+    mem_chain_Learned(opt, bns, rd.l_seq, smems, chain, seqid, hits, seedBuf, seedBufSize, seedBufCount, tid);
+    chain->n = mem_chain_flt(opt, chain->n, chain->a, tid);
+}
+
+// the device's chains of one read as the reference's structures: chain array sized like kv_resize(kb_size(tree)) leaves it,
+// single-seed chains in the batch's seed slab, longer ones in arrays of their own (the reference frees those, :1667-1676)
+void device_chain_read(const mem_opt_t* opt, const bseq1_t& rd, const ChunkPart& P, int64_t r, int seqid, mem_chain_v* chain, mem_seed_t* seedBuf,
+                       int64_t seedBufSize, int64_t& seedBufCount) {
+    kv_init(*chain);
+    if (rd.l_seq < opt->min_seed_len) return;                      // (:1138)
+    const meme_chain_host_result& C = P.chains;
+    chain->m = (size_t)C.tree_size[r];
+    chain->a = (mem_chain_t*)malloc(sizeof(mem_chain_t) * (chain->m ? chain->m : 1));
+    const int64_t c0 = C.chain_off[r], nc = C.chain_off[r + 1] - c0;
+    const meme_chain_seed* sd = C.seeds + C.seed_off[r];
+    for (int64_t k = 0; k < nc; ++k) {
+        const meme_chain& m = C.chains[c0 + k];
+        mem_chain_t c;
+        memset(&c, 0, sizeof(c));
+        c.seqid = seqid; c.n = m.n_seeds; c.first = m.first; c.rid = m.rid; c.w = (uint32_t)m.w; c.kept = (uint32_t)m.kept;
+        c.is_alt = (uint32_t)m.is_alt; c.frac_rep = C.frac_rep[r]; c.pos = m.pos;
+        c.m = SEEDS_PER_CHAIN;
+        while (c.m < c.n) c.m <<= 1;                               // how test_and_merge grows a chain (:474-489)
+        if (c.m == SEEDS_PER_CHAIN && seedBufCount + c.m <= seedBufSize) { c.seeds = seedBuf + seedBufCount; seedBufCount += c.m; memset((void*)c.seeds, 0, c.m * sizeof(mem_seed_t)); }
+        else { if (c.m == SEEDS_PER_CHAIN) c.m += 1; c.seeds = (mem_seed_t*)calloc((size_t)c.m, sizeof(mem_seed_t)); }
+        for (int j = 0; j < c.n; ++j) {
+            const meme_chain_seed& s = sd[m.seed_beg + j];
+            c.seeds[j].rbeg = s.rbeg; c.seeds[j].qbeg = s.qbeg; c.seeds[j].len = s.len; c.seeds[j].score = s.len;
+        }
+        chain->a[chain->n++] = c;
+    }
+}
+
+void free_chains(mem_chain_v* chain) {
+    for (size_t i = 0; i < chain->n; ++i) if (chain->a[i].m > SEEDS_PER_CHAIN) free(chain->a[i].seeds);
+    free(chain->a);
+}
+
+// MEME_DROPIN_CHAIN_CHECK: every read chained both ways, any difference is fatal
+void compare_chains(const bseq1_t& rd, const mem_chain_v* dev, const mem_chain_v* host) {
+    bool same = dev->n == host->n;
+    for (size_t i = 0; same && i < dev->n; ++i) {
+        const mem_chain_t &a = dev->a[i], &b = host->a[i];
+        same = a.n == b.n && a.first == b.first && a.rid == b.rid && a.w == b.w && a.kept == b.kept && a.is_alt == b.is_alt && a.pos == b.pos &&
+               a.seqid == b.seqid && !memcmp(&a.frac_rep, &b.frac_rep, sizeof(float));
+        for (int j = 0; same && j < a.n; ++j)
+            same = a.seeds[j].rbeg == b.seeds[j].rbeg && a.seeds[j].qbeg == b.seeds[j].qbeg && a.seeds[j].len == b.seeds[j].len && a.seeds[j].score == b.seeds[j].score;
+    }
+    if (same) return;
+    fprintf(stderr, "[meme-dropin] chains of read %s differ between the device and the host (%zu vs %zu chains)\n", rd.name, dev->n, host->n);
+    for (int side = 0; side < 2; ++side) {
+        const mem_chain_v* v = side ? host : dev;
+        for (size_t i = 0; i < v->n; ++i) {
+            const mem_chain_t& c = v->a[i];
+            fprintf(stderr, "  %s chain %zu: pos %lld rid %d n %d w %d kept %d first %d frac_rep %.6f seeds", side ? "host  " : "device", i, (long long)c.pos, c.rid, c.n, (int)c.w,
+                    (int)c.kept, c.first, c.frac_rep);
+            for (int j = 0; j < c.n; ++j) fprintf(stderr, " (%lld,%d,%d)", (long long)c.seeds[j].rbeg, c.seeds[j].qbeg, c.seeds[j].len);
+            fprintf(stderr, "\n");
+        }
+    }
+    exit(1);
+}
+
+}  // namespace
 
 int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
                              mem_chain_v* chain_ar, mem_seed_t* seedBuf, int64_t seedBufSize, uint8_t* sa_pos,
@@ -276,29 +380,33 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
     static_assert(sizeof(meme_mem_tl) == sizeof(mem_tl), "mem_tl layout");
     const int64_t g0 = seq_ - g_chunk.seqs;                   // this batch's position in the chunk seeded above
     if (!g_chunk.seqs || g0 < 0 || g0 + nseq > g_chunk.n) { fprintf(stderr, "[meme-dropin] batch outside the seeded chunk\n"); exit(1); }
-    int64_t seedBufCount = 0;
+    int64_t seedBufCount = 0, n_fb = 0;
+    static thread_local mem_seed_t* check_buf = nullptr;
     for (int l = 0; l < nseq; ++l) {
         const int64_t g = g0 + l;
         const ChunkPart* P = nullptr;
         for (const ChunkPart& c : g_chunk.part) if (g >= c.first && g < c.first + c.count) { P = &c; break; }
         const int64_t r = g - P->first;
-        const int64_t s0 = P->res.smem_off[r], ns = P->res.smem_off[r + 1] - s0;
-        const int64_t h0 = P->res.hit_off[r], nh = P->res.hit_off[r + 1] - h0;
-        smems->n = 0;
-        hits->n = 0;
-        if ((int64_t)smems->m < ns) kv_resize(mem_tl, *smems, (size_t)ns);
-        if ((int64_t)hits->m < nh) kv_resize(uint64_t, *hits, (size_t)nh);
-        if (ns) memcpy(smems->a, P->res.smems + s0, (size_t)ns * sizeof(mem_tl));
-        if (nh) memcpy(hits->a, P->res.hits + h0, (size_t)nh * sizeof(uint64_t));
-        smems->n = (size_t)ns;
-        hits->n = (size_t)nh;
-        ks_introsort(meme_dropin_smem, smems->n, smems->a);            // src/bwamem.cpp:1397
-        kv_init(chain_ar[l]);
-        mem_chain_Learned(opt, bns, seq_[l].l_seq, smems, &chain_ar[l], l, hits, seedBuf, seedBufSize, seedBufCount, tid);
         mem_chain_v* chn = &chain_ar[l];
-        chn->n = mem_chain_flt(opt, chn->n, chn->a, tid);
+        if (P->chains.nreads == P->count && !P->chains.fallback[r]) {
+            device_chain_read(opt, seq_[l], *P, r, l, chn, seedBuf, seedBufSize, seedBufCount);
+            if (chain_check()) {
+                const int64_t check_slots = 4096;
+                if (!check_buf) check_buf = (mem_seed_t*)calloc((size_t)check_slots + 8, sizeof(mem_seed_t));
+                mem_chain_v ref;
+                int64_t cnt = 0;
+                host_chain_read(opt, bns, seq_[l], *P, r, l, smems, hits, &ref, check_buf, check_slots, cnt, tid);
+                compare_chains(seq_[l], chn, &ref);
+                free_chains(&ref);
+            }
+        } else {
+            host_chain_read(opt, bns, seq_[l], *P, r, l, smems, hits, chn, seedBuf, seedBufSize, seedBufCount, tid);
+            ++n_fb;
+        }
         mem_flt_chained_seeds(opt, bns, pac, seq_, chn->n, chn->a);
     }
+    g_n_chain_fallback += n_fb;
+    g_n_chain_reads += nseq;
     return 1;
 }
 

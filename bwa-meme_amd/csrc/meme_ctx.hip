@@ -92,6 +92,8 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
                       &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws};
     for (DevBuf* b : bufs) free_buf(*b);
+    for (DevBuf& b : ctx->chain) free_buf(b);
+    for (meme_ctx::HostBuf& h : ctx->h_chain) if (h.p) (void)hipHostFree(h.p);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     for (meme_ctx::HostBuf* h : {&ctx->h_smems, &ctx->h_hits, &ctx->h_smem_off, &ctx->h_hit_off, &ctx->h_misc})
         if (h->p) (void)hipHostFree(h->p);

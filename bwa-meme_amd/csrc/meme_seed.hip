@@ -466,6 +466,7 @@ extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const i
     if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hit_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
     out->smem_off = (const int64_t*)ctx->h_smem_off.p;
     out->hit_off = (const int64_t*)ctx->h_hit_off.p;
+    ctx->last_seed_reads = 0;
     if (nreads == 0) { ((i64*)ctx->h_smem_off.p)[0] = 0; ((i64*)ctx->h_hit_off.p)[0] = 0; return MEME_OK; }
     if (read_off[0] != 0) { meme_set_error("read_off[0] must be 0"); return MEME_E_ARG; }
     const i64 bases = read_off[nreads];
@@ -489,5 +490,6 @@ extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const i
     out->hits = (const uint64_t*)ctx->h_hits.p;
     out->total_smems = res.total_smems;
     out->total_hits = res.total_hits;
+    ctx->last_seed_reads = nreads;
     return MEME_OK;
 }

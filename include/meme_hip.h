@@ -160,6 +160,37 @@ typedef struct {
 int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
                          const meme_seed_opt* opt, meme_seed_host_result* out);
 
+/* ---- chaining of the batch just seeded -------------------------------------------------------------------------------------
+ * mem_chain_Learned() + mem_chain_flt() (reference src/bwamem.cpp:1122-1204, 599-717) for every read of the batch the last
+ * meme_seed_batch_host() call on this ctx has seeded -- the SMEMs and hits are still in HBM.  Per read: the chains that survive
+ * the filter, in the filter's output order, each with its seeds in chain order (seed score = seed length, as mem_chain_Learned
+ * sets it).  tree_size[r] = number of chains before the filter (what the reference sizes chain_ar[r] with); frac_rep[r] as
+ * mem_chain_Learned computes it.  fallback[r] != 0: the read does not fit the device scratch (more than 16 chains, a chain of
+ * more than 8 seeds, more than 256 SMEMs) or would insert two chains at one position (B-tree order of equal keys): it has no
+ * chains here and the caller chains it with the reference's host functions.  Results live in pinned buffers of the ctx until
+ * the next call.  meme_contig = the fields of bntann1_t the stage needs (src/bntseq.h). */
+typedef struct { int64_t offset; int32_t len; int32_t is_alt; } meme_contig;
+typedef struct {
+    int32_t w, max_chain_gap, max_occ, min_seed_len, min_chain_weight, max_chain_extend;   /* mem_opt_t fields of the same names */
+    float mask_level, drop_ratio;
+    int64_t l_pac;
+} meme_chain_opt;
+typedef struct { int64_t pos; int32_t rid, n_seeds, w, first; int16_t kept, is_alt; int32_t seed_beg /* in the read's seeds */; int32_t pad; } meme_chain;
+typedef struct { int64_t rbeg; int32_t qbeg, len; } meme_chain_seed;
+typedef struct {
+    int64_t nreads;
+    const int64_t* chain_off;        /* nreads+1 */
+    const meme_chain* chains;
+    const int64_t* seed_off;         /* nreads+1 */
+    const meme_chain_seed* seeds;
+    const int32_t* tree_size;
+    const float* frac_rep;
+    const uint8_t* fallback;
+    int64_t total_chains, total_seeds, n_fallback;
+} meme_chain_host_result;
+int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt,
+                               meme_chain_host_result* out);
+
 /* Same with inputs and outputs resident in HBM (pointers valid until the next call on this ctx).
  * d_reads must be 4-byte aligned (any hipMalloc'ed pointer is); total_bases = read_off[nreads] = bytes in d_reads. */
 typedef struct {

@@ -55,13 +55,16 @@ def test_sam_identical_to_reference(tmp_path, paired):
     # whose staging starts too small and is rebuilt, and with every stage split in three backend calls as on three GPUs)
     # and the reference's own per-batch function over the combiner (MEME_DROPIN_EXT=0).  MEME_DROPIN_VIRTUAL=3 runs the
     # multi-GPU arrangement (three device slots: reads of a chunk split three ways, index replicas, one extension call per slot)
-    # on however many GPUs the box has.
+    # on however many GPUs the box has.  Chaining runs on the device (mem_chain_Learned + mem_chain_flt) with
+    # MEME_DROPIN_CHAIN_CHECK set: every read is also chained by the reference's host functions and any difference in any
+    # chain or seed is fatal; MEME_DROPIN_CHAIN=0 keeps chaining on the host.
     small = {}
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}),
                                   (8, 100000000, {"MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
-                                  (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"})):
-        env = dict(os.environ, MEME_INDEX_PREFIX=prefix, **extra)
+                                  (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
+                                  (4, 100000000, {"MEME_DROPIN_CHAIN": "0"})):
+        env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", **extra)
         got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
         if chunk == 100000000: ref = want
         else:
@@ -87,7 +90,7 @@ def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
     synth.write_fastq(fq, r1, prefix="e")
     threads = min(32, os.cpu_count() or 4)
     want = _sam("bwa-meme_mode3", prefix, [fq], threads=threads)
-    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix), threads=threads)
+    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1"), threads=threads)
     assert len(got) == len(want) and len(want) > n
     diff = [(a, b) for a, b in zip(got, want) if a != b]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
@@ -131,7 +134,7 @@ def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
             k += 1
     want = _sam("bwa-meme_mode3", prefix, [fq], threads=8)
     cmd = [os.path.join(REF, "bwa-meme_dropin"), "mem", "-7", "-Y", "-K", "100000000", "-t", "8", prefix, fq]
-    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1"), timeout=900)
+    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_CHAIN_CHECK="1"), timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
     assert len(got) == len(want) and len(want) > 3300
