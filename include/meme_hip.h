@@ -11,6 +11,7 @@
  *                                      + Learned_bwtSeedStrategyAllPosOneThread[_mem_tradeoff]() :241,:247
  *                                      (outputs: mem_tl records + hit positions, the inputs of the unchanged
  *                                       host consumer mem_chain_Learned(), src/bwamem.cpp:1122-1204)
+ *   meme_chain_last_batch_host      <- mem_chain_Learned() + mem_chain_flt()          src/bwamem.cpp:1122-1204, 599-717
  *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
  *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
  *
