@@ -241,6 +241,9 @@ def e2e_leg(prefix, genome, npairs, threads):
                                     prefix] + fqs, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=3000)
             wall = time.time() - t0
             err = r.stderr.decode(errors="replace")
+            if os.environ.get("MEME_BENCH_E2E_STDERR"):            # keep the aligner's own profile / the binding's per-chunk report
+                os.makedirs(os.environ["MEME_BENCH_E2E_STDERR"], exist_ok=True)
+                open(os.path.join(os.environ["MEME_BENCH_E2E_STDERR"], exe + ".stderr"), "w").write(err)
             if r.returncode != 0:
                 raise RuntimeError("%s failed: %s" % (exe, err[-800:]))
             proc = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
