@@ -67,7 +67,7 @@ std::mutex g_mu;
 std::atomic<double> g_t_seed{0}, g_t_bsw_gather{0}, g_t_bsw_call{0}, g_t_bsw_kernel{0};
 std::atomic<int64_t> g_n_bsw_calls{0}, g_n_bsw_pairs{0}, g_n_seed_reads{0};
 
-void init_devices(const char* prefix) {
+void init_devices(const char* prefix, int64_t chunk_reads) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_dev.empty()) return;
     int n = meme_device_count();
@@ -86,7 +86,14 @@ void init_devices(const char* prefix) {
         // for the lane-per-pair kernel much earlier than a lone caller's
         if (getenv("MEME_DROPIN_BSW_LANE_MIN")) meme_set_tuning(g_dev[(size_t)d].bsw, "bsw_lane_min_pairs", atoll(getenv("MEME_DROPIN_BSW_LANE_MIN")));
     }
+    // while the index streams in: the seeding / chaining buffers of a chunk on every device slot (pinned memory is slow to allocate)
+    std::thread reserve([n, chunk_reads] {
+        int64_t per = chunk_reads / n + BATCH_SIZE;
+        if (per > (1 << 20)) per = 1 << 20;                  // beyond a million reads per device the buffers grow on first use
+        for (int d = 0; d < n; ++d) if (meme_seed_reserve(g_dev[(size_t)d].seed, per, per * READ_LEN)) die("meme_seed_reserve");
+    });
     if (meme_index_load_files(g_dev[0].seed, prefix)) die("meme_index_load_files");
+    reserve.join();
     const double t1 = now_s();
     std::vector<std::thread> th;
     for (int d = 1; d < n; ++d)                                 // device-to-device over xGMI, all replicas at once
@@ -170,7 +177,7 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     const double t1 = now_s();
     const char* prefix = getenv("MEME_INDEX_PREFIX") ? getenv("MEME_INDEX_PREFIX") : idx_prefix;
     std::thread prep(ext_prepare, (int64_t)nreads, (int)nthreads);             // pinned staging + helper threads, while the index loads
-    init_devices(prefix);
+    init_devices(prefix, (int64_t)nreads);
     prep.join();
     fprintf(stderr, "[meme-dropin] worker buffers + fwd/rc text %.2f s, HBM index %.2f s (no host-side index expansion)\n",
             t1 - t0, now_s() - t1);

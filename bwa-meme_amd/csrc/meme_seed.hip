@@ -454,6 +454,32 @@ extern "C" int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_
 // Host-pointer variant whose results land in pinned buffers owned by the ctx (valid until the next seeding call on it):
 // no capacity negotiation, and the device-to-host copies are plain DMA transfers.  `reads` / `read_off` may be pageable or
 // pinned (meme_host_alloc).  This is the call a chunk-level binding issues once per -K chunk.
+// Workspaces and pinned result buffers of a meme_seed_batch_host() + meme_chain_last_batch_host() call of this size, ahead of
+// time: pinned host memory takes ~0.4 s per GB to allocate, which a caller can hide behind its index load.  Sizes are estimates
+// (12 SMEMs, 24 hits, 3 chains, 6 chained seeds per read); whatever turns out larger grows on first use as before.
+extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_bases) {
+    if (!ctx || nreads < 0 || total_bases < 0) return MEME_E_ARG;
+    if (nreads == 0) return MEME_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n = (size_t)nreads;
+    const i64 len = total_bases / nreads + 32;
+    const size_t stride = (size_t)(2 * ((len + 31) / 32 + 2) + 2 * ((len + 63) / 64) + 1);
+    int rc;
+    struct { DevBuf* b; size_t bytes; } dev[] = {
+        {&ctx->reads, (size_t)total_bases + 16}, {&ctx->read_off, (n + 1) * 8}, {&ctx->slot_cnt, n * 4}, {&ctx->slot_hits, n * 8},
+        {&ctx->slot_loc, n * 8}, {&ctx->counters, 12 * 8}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
+        {&ctx->smem_off, (n + 1) * 8}, {&ctx->hit_off, (n + 1) * 8}, {&ctx->smems, n * 12 * sizeof(meme_mem_tl)}, {&ctx->hits, n * 24 * 8},
+        {&ctx->chain[0], n * 16 * 32}, {&ctx->chain[1], n * 16 * 8 * 16}, {&ctx->chain[2], n * 16}, {&ctx->chain[3], n * 4},
+        {&ctx->chain[5], (n + 1) * 32 + n * 5 + 64}, {&ctx->chain[6], n * 3 * sizeof(meme_chain)}, {&ctx->chain[7], n * 6 * sizeof(meme_chain_seed)}};
+    for (auto& d : dev) if ((rc = meme_buf_reserve(ctx, *d.b, d.bytes))) return rc;
+    struct { meme_ctx::HostBuf* b; size_t bytes; } host[] = {
+        {&ctx->h_smem_off, (n + 1) * 8}, {&ctx->h_hit_off, (n + 1) * 8}, {&ctx->h_smems, n * 12 * sizeof(meme_mem_tl)}, {&ctx->h_hits, n * 24 * 8},
+        {&ctx->h_chain[0], (n + 1) * 8}, {&ctx->h_chain[1], n * 3 * sizeof(meme_chain)}, {&ctx->h_chain[2], (n + 1) * 8},
+        {&ctx->h_chain[3], n * 6 * sizeof(meme_chain_seed)}, {&ctx->h_chain[4], n * 4}, {&ctx->h_chain[5], n * 4}, {&ctx->h_chain[6], n}};
+    for (auto& h : host) if ((rc = meme_hostbuf_reserve(ctx, *h.b, h.bytes))) return rc;
+    return MEME_OK;
+}
+
 extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
                                     const meme_seed_opt* opt, meme_seed_host_result* out) {
     if (!ctx || !reads || !read_off || !out || nreads < 0) return MEME_E_ARG;

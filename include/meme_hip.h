@@ -161,6 +161,10 @@ typedef struct {
 int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
                          const meme_seed_opt* opt, meme_seed_host_result* out);
 
+/* Optional: allocate the workspaces and pinned result buffers of a meme_seed_batch_host() (+ meme_chain_last_batch_host()) call of
+ * this size ahead of time, e.g. on a helper thread while the index loads (pinned memory is slow to allocate). */
+int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_bases);
+
 /* ---- chaining of the batch just seeded -------------------------------------------------------------------------------------
  * mem_chain_Learned() + mem_chain_flt() (reference src/bwamem.cpp:1122-1204, 599-717) for every read of the batch the last
  * meme_seed_batch_host() call on this ctx has seeded -- the SMEMs and hits are still in HBM.  Per read: the chains that survive
