@@ -28,6 +28,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -608,32 +609,37 @@ void bsw_forward(const int8_t* mat, int o_del, int e_del, int o_ins, int e_ins, 
 namespace {
 
 struct Team {                                   // persistent helper threads (the kt_for workers are parked on g_ext.mu meanwhile)
+    struct Job {                                // one run(): a late waker that still holds an old Job finds it exhausted
+        std::function<void(int64_t)> fn;
+        int64_t n = 0;
+        std::atomic<int64_t> next{0}, done{0};
+    };
     std::vector<std::thread> th;
     std::mutex m;
-    std::condition_variable cv_go, cv_done;
-    const std::function<void(int64_t)>* fn = nullptr;
-    std::atomic<int64_t> next{0};
-    int64_t n = 0;
+    std::condition_variable cv_go;
+    std::shared_ptr<Job> job;
     uint64_t gen = 0;
-    int running = 0;
-    void work(const std::function<void(int64_t)>* f) { for (int64_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) (*f)(i); }
+    static void work(Job& j) {
+        for (int64_t i; (i = j.next.fetch_add(1, std::memory_order_relaxed)) < j.n;) { j.fn(i); j.done.fetch_add(1, std::memory_order_release); }
+    }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void(int64_t)>* f;
-            { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return gen != seen; }); seen = gen; f = fn; }
-            work(f);
-            { std::lock_guard<std::mutex> lk(m); if (--running == 0) cv_done.notify_one(); }
+            std::shared_ptr<Job> j;
+            { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return gen != seen; }); seen = gen; j = job; }
+            work(*j);
         }
     }
     void ensure(int nt) { while ((int)th.size() < nt) { th.emplace_back([this] { loop(); }); th.back().detach(); } }
+    // returns when every item is done -- not when every helper has woken up: one descheduled thread must not hold up a stage
     void run(int64_t items, const std::function<void(int64_t)>& f) {
         if (items <= 0) return;
-        { std::lock_guard<std::mutex> lk(m); fn = &f; n = items; next.store(0); running = (int)th.size(); ++gen; }
+        auto j = std::make_shared<Job>();
+        j->fn = f; j->n = items;
+        { std::lock_guard<std::mutex> lk(m); job = j; ++gen; }
         cv_go.notify_all();
-        work(&f);
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return running == 0; });
+        work(*j);
+        for (unsigned sp = 0; j->done.load(std::memory_order_acquire) < items;) backoff(sp);
     }
 };
 
@@ -979,6 +985,13 @@ void ext_purge_read(const mem_opt_t* opt, const bseq1_t* seqs, mem_chain_v* chai
     }
 }
 
+// helper threads of the extension stage: the aligner's thread count minus the caller (MEME_DROPIN_TEAM overrides)
+int team_helpers(int threads) {
+    static const int forced = getenv("MEME_DROPIN_TEAM") ? atoi(getenv("MEME_DROPIN_TEAM")) : -1;
+    if (forced >= 0) return forced;
+    return threads > 1 ? threads - 1 : 0;
+}
+
 int64_t ext_slab_reads() {
     static const int64_t v = getenv("MEME_DROPIN_EXT_SLAB") && atoll(getenv("MEME_DROPIN_EXT_SLAB")) > 0 ? atoll(getenv("MEME_DROPIN_EXT_SLAB")) : 262144;
     return v;
@@ -1000,7 +1013,7 @@ void ext_chunk(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, co
                uint8_t* ref_string) {
     Ext& E = *g_ext;
     const double t_begin = now_s();
-    E.team.ensure(g_team > 1 ? g_team - 1 : 0);
+    E.team.ensure(team_helpers(g_team));
     E.av.assign((size_t)n, mem_alnreg_v());
     for (mem_alnreg_v& v : E.av) memset(&v, 0, sizeof(v));
     E.order_off.assign((size_t)n, 0);
@@ -1099,7 +1112,7 @@ void ext_report() {
 void ext_prepare(int64_t chunk_reads, int threads) {
     if (!ext_enabled() || g_ext) return;
     g_ext = new Ext;
-    g_ext->team.ensure(threads > 1 ? threads - 1 : 0);
+    g_ext->team.ensure(team_helpers(threads));
     // pinned memory needs a HIP context; device 0's is created here if init_devices() has not got there yet
     ext_size_for(chunk_reads < ext_slab_reads() ? chunk_reads : ext_slab_reads(), READ_LEN);
 }
