@@ -204,6 +204,10 @@ const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process
 std::vector<meme_contig> g_contigs;
 bool chain_on_device() { static const bool v = !(getenv("MEME_DROPIN_CHAIN") && atoi(getenv("MEME_DROPIN_CHAIN")) == 0); return v; }
 bool chain_check() { static const bool v = getenv("MEME_DROPIN_CHAIN_CHECK") != nullptr; return v; }
+// MEME_DROPIN_CHAIN_DUMP=<file> (fixture generation, tests/golden/make_chain_golden.py): every read's seeds and the chains the
+// REFERENCE's host functions make of them, as text
+FILE* chain_dump() { static FILE* f = getenv("MEME_DROPIN_CHAIN_DUMP") ? fopen(getenv("MEME_DROPIN_CHAIN_DUMP"), "w") : nullptr; return f; }
+std::mutex g_dump_mu;
 std::atomic<int64_t> g_n_chain_fallback{0}, g_n_chain_reads{0};
 
 meme_seed_opt seed_opt_of(const mem_opt_t* opt) {
@@ -354,6 +358,26 @@ void free_chains(mem_chain_v* chain) {
     free(chain->a);
 }
 
+void dump_chains(int64_t g, const bseq1_t& rd, const ChunkPart& P, int64_t r, const mem_chain_v* host) {
+    const int64_t s0 = P.res.smem_off[r], ns = P.res.smem_off[r + 1] - s0;
+    const int64_t h0 = P.res.hit_off[r], nh = P.res.hit_off[r + 1] - h0;
+    std::lock_guard<std::mutex> lk(g_dump_mu);
+    FILE* f = chain_dump();
+    uint32_t fr = 0;
+    if (host->n) memcpy(&fr, &host->a[0].frac_rep, 4);
+    fprintf(f, "R %lld %d %lld %lld %zu %zu %u\n", (long long)g, rd.l_seq, (long long)ns, (long long)nh, host->m, host->n, fr);
+    for (int64_t i = 0; i < ns; ++i) { const meme_mem_tl& m = P.res.smems[s0 + i]; fprintf(f, "S %d %d %d %d\n", m.start, m.end, m.hitbeg, m.hitcount); }
+    fprintf(f, "H");
+    for (int64_t i = 0; i < nh; ++i) fprintf(f, " %llu", (unsigned long long)P.res.hits[h0 + i]);
+    fprintf(f, "\n");
+    for (size_t i = 0; i < host->n; ++i) {
+        const mem_chain_t& c = host->a[i];
+        fprintf(f, "C %lld %d %d %d %d %d %d :", (long long)c.pos, c.rid, c.n, (int)c.w, (int)c.kept, c.first, (int)c.is_alt);
+        for (int j = 0; j < c.n; ++j) fprintf(f, " %lld %d %d", (long long)c.seeds[j].rbeg, c.seeds[j].qbeg, c.seeds[j].len);
+        fprintf(f, "\n");
+    }
+}
+
 // MEME_DROPIN_CHAIN_CHECK: every read chained both ways, any difference is fatal
 void compare_chains(const bseq1_t& rd, const mem_chain_v* dev, const mem_chain_v* host) {
     bool same = dev->n == host->n;
@@ -398,18 +422,20 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
         mem_chain_v* chn = &chain_ar[l];
         if (P->chains.nreads == P->count && !P->chains.fallback[r]) {
             device_chain_read(opt, seq_[l], *P, r, l, chn, seedBuf, seedBufSize, seedBufCount);
-            if (chain_check()) {
+            if (chain_check() || chain_dump()) {
                 const int64_t check_slots = 4096;
                 if (!check_buf) check_buf = (mem_seed_t*)calloc((size_t)check_slots + 8, sizeof(mem_seed_t));
                 mem_chain_v ref;
                 int64_t cnt = 0;
                 host_chain_read(opt, bns, seq_[l], *P, r, l, smems, hits, &ref, check_buf, check_slots, cnt, tid);
-                compare_chains(seq_[l], chn, &ref);
+                if (chain_check()) compare_chains(seq_[l], chn, &ref);
+                if (chain_dump()) dump_chains(g, seq_[l], *P, r, &ref);
                 free_chains(&ref);
             }
         } else {
             host_chain_read(opt, bns, seq_[l], *P, r, l, smems, hits, chn, seedBuf, seedBufSize, seedBufCount, tid);
             ++n_fb;
+            if (chain_dump()) dump_chains(g, seq_[l], *P, r, chn);
         }
         mem_flt_chained_seeds(opt, bns, pac, seq_, chn->n, chn->a);
     }

@@ -3,21 +3,23 @@
 //
 // One lane per read (the work per read is small and strictly sequential: every hit is tested against the chain with the
 // closest position below it and either merged into it or becomes a new chain).  What the reference keeps in a B-tree keyed
-// by position is a position-sorted array of at most CHAIN_CAP chains here; what it sorts with klib's introsort is sorted by
-// the same sequence of comparisons and swaps (below 17 elements: one median-of-three partition pass, then insertion sort),
-// because chains of equal weight keep whatever order that algorithm leaves them in and the filter that follows depends on it.
+// by position is a position-sorted array of chains in a per-read scratch here; what it sorts with klib's introsort is sorted by
+// the same sequence of comparisons and swaps, because chains of equal weight keep whatever order that algorithm leaves them in
+// and the filter that follows depends on it.
 //
-// Reads the fixed-capacity scratch cannot hold (more than CHAIN_CAP chains, a chain of more than SEED_CAP seeds, more than
-// SMEM_CAP SMEMs) and reads that would insert two chains at the same position (the B-tree's order of equal keys is an
-// implementation detail) are flagged: the caller chains those on the host with the reference's own functions.
+// Reads that fit neither scratch size (more than 128 chains, a chain of more than 32 seeds, more than SMEM_CAP SMEMs) and reads
+// that would insert two chains at the same position (the B-tree's order of equal keys is an implementation detail) are flagged:
+// the caller chains those on the host with the reference's own functions.
 #include <hipcub/hipcub.hpp>
 
 #include "meme_common.h"
 
 namespace {
 
-constexpr int CHAIN_CAP = 16;      // chains per read in the scratch
-constexpr int SEED_CAP = 8;        // seeds per chain
+// Two passes with different scratch sizes: every read with room for 16 chains of 8 seeds (2.5 KB per read); the few per cent
+// that need more (repeats) again, alone, with room for 128 chains of 32 seeds (68 KB per read).
+constexpr int CHAIN_CAP = 16, SEED_CAP = 8;
+constexpr int CHAIN_CAP2 = 128, SEED_CAP2 = 32;
 constexpr int SMEM_CAP = 256;      // SMEMs per read (the sorted walk is quadratic in it)
 
 struct DChain {                    // 32 bytes
@@ -27,7 +29,7 @@ struct DChain {                    // 32 bytes
     int row;                       // which seed row of the read's scratch holds its seeds
 };
 struct DSeed { i64 rbeg; int qbeg, len; };
-struct ReadHdr { int tree_size, n_kept, n_seeds, fallback; };
+struct ReadHdr { int tree_size, n_kept, n_seeds, fallback; i64 slot; };   // fallback: 0 done, 1 needs the bigger scratch / the host; slot: scratch index, bit 62 = second pass
 
 struct ChainArgs {
     const meme_mem_tl* smems; const i64* smem_off; const u64* hits; const i64* hit_off; const i64* read_off;
@@ -35,6 +37,7 @@ struct ChainArgs {
     const i64* contig_off; const int* contig_len; const unsigned char* contig_alt; int n_contigs;
     meme_chain_opt o;
     DChain* ch; DSeed* sd; ReadHdr* hdr; float* frac_rep;
+    const i64* list; i64 nlist;        // second pass: the reads to redo (nullptr: all reads)
 };
 
 __device__ inline int pos2rid(const ChainArgs& A, i64 pos_f) {            // bns_pos2rid, src/bntseq.cpp:392-406
@@ -82,45 +85,78 @@ __device__ inline int chain_weight(const DChain& c, const DSeed* row) {   // mem
 #define FLT_LT(a_, b_) ((a_).w > (b_).w)                                 // flt_lt, src/bwamem.cpp:80
 __device__ inline void swap_chain(DChain& a, DChain& b) { const DChain t = a; a = b; b = t; }
 
-// ks_introsort for n <= 16 (klib ksort.h): two elements are compared and swapped; otherwise ONE partition pass around the
-// median of first / middle / last -- the sub-ranges are then at most 16 long and are left to the final insertion sort.
+// ks_introsort (klib ksort.h), restated: two elements are compared and swapped; otherwise quicksort around the median of first /
+// middle / last with an explicit stack, sub-ranges of at most 16 elements are left to the final insertion sort, comb sort takes
+// over when the depth budget is spent.  (Up to 16 elements this is ONE partition pass over the whole array + insertion sort.)
+__device__ inline void insert_sort(DChain* s, DChain* t) {
+    for (DChain* i = s + 1; i < t; ++i)
+        for (DChain* j = i; j > s && FLT_LT(*j, *(j - 1)); --j) swap_chain(*j, *(j - 1));
+}
+__device__ void comb_sort(int n, DChain* a) {
+    const double shrink = 1.2473309501039786540366528676643;
+    bool do_swap;
+    int gap = n;
+    do {
+        if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+        do_swap = false;
+        for (DChain* i = a; i < a + n - gap; ++i) { DChain* j = i + gap; if (FLT_LT(*j, *i)) { swap_chain(*i, *j); do_swap = true; } }
+    } while (do_swap || gap > 2);
+    if (gap != 1) insert_sort(a, a + n);
+}
 __device__ void sort_by_weight(DChain* a, int n) {
-    if (n < 2) return;
+    if (n < 1) return;
     if (n == 2) { if (FLT_LT(a[1], a[0])) swap_chain(a[0], a[1]); return; }
-    {
-        int i = 0, j = n - 1, k = i + ((j - i) >> 1) + 1;
-        const int t = n - 1;
-        if (FLT_LT(a[k], a[i])) { if (FLT_LT(a[k], a[j])) k = j; }
-        else k = FLT_LT(a[j], a[i]) ? i : j;
-        const DChain rp = a[k];
-        if (k != t) swap_chain(a[k], a[t]);
-        for (;;) {
-            do ++i; while (FLT_LT(a[i], rp));
-            do --j; while (i <= j && FLT_LT(rp, a[j]));
-            if (j <= i) break;
-            swap_chain(a[i], a[j]);
+    struct { DChain *left, *right; int depth; } stack[40], *top = stack;
+    int d;
+    for (d = 2; (1 << d) < n; ++d) {}
+    DChain *s = a, *t = a + (n - 1);
+    d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) { comb_sort((int)(t - s) + 1, s); t = s; continue; }
+            DChain *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
+            if (FLT_LT(*k, *i)) { if (FLT_LT(*k, *j)) k = j; }
+            else k = FLT_LT(*j, *i) ? i : j;
+            const DChain rp = *k;
+            if (k != t) swap_chain(*k, *t);
+            for (;;) {
+                do ++i; while (FLT_LT(*i, rp));
+                do --j; while (i <= j && FLT_LT(rp, *j));
+                if (j <= i) break;
+                swap_chain(*i, *j);
+            }
+            swap_chain(*i, *t);
+            if (i - s > t - i) {
+                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == stack) { insert_sort(a, a + n); return; }
+            --top; s = top->left; t = top->right; d = top->depth;
         }
-        swap_chain(a[i], a[t]);
     }
-    for (int i = 1; i < n; ++i)
-        for (int j = i; j > 0 && FLT_LT(a[j], a[j - 1]); --j) swap_chain(a[j], a[j - 1]);
 }
 
+template <int CC, int SC>
 __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
-    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= A.nreads) return;
+    const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (A.list ? A.nlist : A.nreads)) return;
+    const i64 r = A.list ? A.list[tid] : tid;
     const meme_chain_opt& o = A.o;
     const meme_mem_tl* sm = A.smems + A.smem_off[r];
     const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
     const u64* ht = A.hits + A.hit_off[r];
     const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
-    DChain* ch = A.ch + r * CHAIN_CAP;
-    DSeed* sd = A.sd + r * (CHAIN_CAP * SEED_CAP);
-    ReadHdr H = {0, 0, 0, 0};
+    DChain* ch = A.ch + tid * CC;
+    DSeed* sd = A.sd + tid * (CC * SC);
+    ReadHdr H = {0, 0, 0, 0, tid | (A.list ? (i64)1 << 62 : 0)};
     float frac = 0.f;
     int nc = 0;
     if (len >= o.min_seed_len && ns > 0) {                                // (:1138)
-        if (ns > SMEM_CAP) H.fallback = 1;
+        if (ns > SMEM_CAP) H.fallback = 2;                                // the bigger scratch does not help: host
         int b = 0, e = 0, l_rep = 0;                                      // frac_rep (:1140-1147)
         // walk the SMEMs in (start, end) order; records with equal (start, end) describe the same substring, hence the same
         // hits, and the second one only meets seeds that are already contained: their relative order cannot matter
@@ -154,7 +190,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
                 bool merged = false;
                 if (lower >= 0) {                                         // test_and_merge, src/bwamem.cpp:450-492
                     DChain& c = ch[lower];
-                    DSeed* row = sd + c.row * SEED_CAP;
+                    DSeed* row = sd + c.row * SC;
                     const DSeed last = row[c.n - 1], first = row[0];
                     const i64 qend = last.qbeg + last.len, rend = last.rbeg + last.len;
                     if (rid == c.rid) {
@@ -163,7 +199,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
                         else {
                             const i64 x = s.qbeg - last.qbeg, y = s.rbeg - last.rbeg;
                             if (y >= 0 && x - y <= o.w && y - x <= o.w && x - last.len < o.max_chain_gap && y - last.len < o.max_chain_gap) {
-                                if (c.n == SEED_CAP) { H.fallback = 1; break; }
+                                if (c.n == SC) { H.fallback = 1; break; }
                                 row[c.n++] = s;
                                 merged = true;
                             }
@@ -171,14 +207,15 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
                     }
                 }
                 if (!merged) {                                            // a new chain (:1172-1191)
-                    if (nc == CHAIN_CAP || (lower >= 0 && ch[lower].pos == s.rbeg)) { H.fallback = 1; break; }
+                    if (lower >= 0 && ch[lower].pos == s.rbeg) { H.fallback = 2; break; }   // equal B-tree keys: the host decides
+                    if (nc == CC) { H.fallback = 1; break; }
                     for (int i = nc; i > lower + 1; --i) ch[i] = ch[i - 1];
                     DChain c;
                     c.pos = s.rbeg; c.rid = rid; c.n = 1; c.w = 0; c.first = -1; c.kept = 0;
                     c.is_alt = A.contig_alt[rid] ? 1 : 0;
                     c.row = nc;
                     ch[lower + 1] = c;
-                    sd[nc * SEED_CAP] = s;
+                    sd[nc * SC] = s;
                     ++nc;
                 }
             }
@@ -192,23 +229,23 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
         for (int i = 0; i < nc; ++i) {
             DChain c = ch[i];
             c.first = -1; c.kept = 0;
-            c.w = chain_weight(c, sd + c.row * SEED_CAP);
+            c.w = chain_weight(c, sd + c.row * SC);
             if (c.w >= o.min_chain_weight) ch[n++] = c;
         }
         if (n > 0) {
             sort_by_weight(ch, n);
-            int kept_idx[CHAIN_CAP];
+            int kept_idx[CC];
             int nk = 0;
             ch[0].kept = 3;
             kept_idx[nk++] = 0;
             for (int i = 1; i < n; ++i) {
                 bool large_ovlp = false;
                 int k = 0;
-                const DSeed* ri = sd + ch[i].row * SEED_CAP;
+                const DSeed* ri = sd + ch[i].row * SC;
                 const int beg_i = ri[0].qbeg, end_i = ri[ch[i].n - 1].qbeg + ri[ch[i].n - 1].len;
                 for (; k < nk; ++k) {
                     const int j = kept_idx[k];
-                    const DSeed* rj = sd + ch[j].row * SEED_CAP;
+                    const DSeed* rj = sd + ch[j].row * SC;
                     const int beg_j = rj[0].qbeg, end_j = rj[ch[j].n - 1].qbeg + rj[ch[j].n - 1].len;
                     const int b_max = beg_j > beg_i ? beg_j : beg_i;
                     const int e_min = end_j < end_i ? end_j : end_i;
@@ -242,25 +279,38 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     A.frac_rep[r] = frac;
 }
 
-// the kept chains and their seeds, densely packed in read order
-__global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch, const DSeed* __restrict__ sd, const ReadHdr* __restrict__ hdr,
+// the kept chains and their seeds, densely packed in read order (the scratch of the pass that finished the read)
+__global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch1, const DSeed* __restrict__ sd1, const DChain* __restrict__ ch2,
+                                                     const DSeed* __restrict__ sd2, const ReadHdr* __restrict__ hdr,
                                                      const i64* __restrict__ chain_off, const i64* __restrict__ seed_off, i64 nreads,
                                                      meme_chain* __restrict__ out_ch, meme_chain_seed* __restrict__ out_sd) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x) {
         const ReadHdr H = hdr[r];
+        if (H.fallback || H.n_kept == 0) continue;
+        const bool second = (H.slot >> 62) & 1;
+        const i64 slot = H.slot & (((i64)1 << 62) - 1);
+        const int cc = second ? CHAIN_CAP2 : CHAIN_CAP, sc = second ? SEED_CAP2 : SEED_CAP;
+        const DChain* ch = (second ? ch2 : ch1) + slot * cc;
+        const DSeed* sd = (second ? sd2 : sd1) + slot * (i64)cc * sc;
         i64 so = seed_off[r];
         const i64 s0 = so;
         for (int k = 0; k < H.n_kept; ++k) {
-            const DChain c = ch[r * CHAIN_CAP + k];
+            const DChain c = ch[k];
             meme_chain m;
             m.pos = c.pos; m.rid = c.rid; m.n_seeds = c.n; m.w = c.w; m.first = c.first; m.kept = c.kept; m.is_alt = c.is_alt;
             m.seed_beg = (int32_t)(so - s0);
             m.pad = 0;
             out_ch[chain_off[r] + k] = m;
-            const DSeed* row = sd + r * (CHAIN_CAP * SEED_CAP) + c.row * SEED_CAP;
+            const DSeed* row = sd + c.row * sc;
             for (int j = 0; j < c.n; ++j) { meme_chain_seed s; s.rbeg = row[j].rbeg; s.qbeg = row[j].qbeg; s.len = row[j].len; out_sd[so++] = s; }
         }
     }
+}
+
+// reads the first pass could not hold (fallback == 1): their indices, for the second pass
+__global__ void __launch_bounds__(256) k_chain_redo(const ReadHdr* __restrict__ hdr, i64 nreads, unsigned long long* __restrict__ count, i64* __restrict__ list) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x)
+        if (hdr[r].fallback == 1) list[atomicAdd(count, 1ull)] = r;
 }
 
 __global__ void __launch_bounds__(256) k_chain_counts(const ReadHdr* __restrict__ hdr, i64 nreads, i64* __restrict__ nch, i64* __restrict__ nsd,
@@ -268,7 +318,7 @@ __global__ void __launch_bounds__(256) k_chain_counts(const ReadHdr* __restrict_
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r <= nreads; r += (i64)gridDim.x * blockDim.x) {
         if (r == nreads) { nch[r] = 0; nsd[r] = 0; continue; }
         const ReadHdr H = hdr[r];
-        nch[r] = H.n_kept; nsd[r] = H.n_seeds; tree[r] = H.tree_size; fb[r] = (unsigned char)H.fallback;
+        nch[r] = H.fallback ? 0 : H.n_kept; nsd[r] = H.fallback ? 0 : H.n_seeds; tree[r] = H.tree_size; fb[r] = H.fallback ? 1 : 0;
     }
 }
 
@@ -285,7 +335,8 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     const i64 n = ctx->last_seed_reads;
     if (n <= 0 || !ctx->smem_off.p || !ctx->read_off.p) { meme_set_error("meme_chain_last_batch_host: no seeded batch on this ctx"); return MEME_E_STATE; }
     int rc;
-    DevBuf* B = ctx->chain;     // 0 chains scratch, 1 seeds scratch, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds
+    DevBuf* B = ctx->chain;     // 0 chains scratch, 1 seeds scratch, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
+                                // 8 redo list, 9 / 10 scratch of the second pass
     if ((rc = meme_buf_reserve(ctx, B[0], (size_t)n * CHAIN_CAP * sizeof(DChain)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[1], (size_t)n * CHAIN_CAP * SEED_CAP * sizeof(DSeed)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[2], (size_t)n * sizeof(ReadHdr)))) return rc;
@@ -293,7 +344,7 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     const size_t ctab = (size_t)n_contigs * (8 + 4 + 1) + 64;
     if ((rc = meme_buf_reserve(ctx, B[4], ctab))) return rc;
     // counts, their scans, tree sizes, fallback flags
-    const size_t cnt_bytes = (size_t)(n + 1) * 8 * 4 + (size_t)n * 4 + (size_t)n + 64;
+    const size_t cnt_bytes = ((size_t)(n + 1) * 8 * 4 + (size_t)n * 4 + (size_t)n + 64 + 15) / 16 * 16 + 16;   // (+ the redo counter at the end)
     if ((rc = meme_buf_reserve(ctx, B[5], cnt_bytes))) return rc;
     // contig table: offsets | lengths | alt flags
     std::vector<unsigned char> tab(ctab, 0);
@@ -311,7 +362,27 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     A.contig_alt = (const unsigned char*)B[4].p + (size_t)n_contigs * 12; A.n_contigs = n_contigs;
     A.o = *opt;
     A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
-    hipLaunchKernelGGL(k_chain, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
+    A.list = nullptr; A.nlist = 0;
+    hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
+    // second pass: the reads that did not fit, with the big scratch
+    unsigned long long* d_redo_n = (unsigned long long*)((unsigned char*)B[5].p + cnt_bytes - 16);
+    HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
+    if ((rc = meme_buf_reserve(ctx, B[8], (size_t)n * 8))) return rc;
+    hipLaunchKernelGGL(k_chain_redo, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, d_redo_n, (i64*)B[8].p);
+    unsigned long long n_redo = 0;
+    HIP_TRY(hipMemcpyAsync(&n_redo, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_redo > 0) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)n_redo * CHAIN_CAP2 * (sizeof(DChain) + SEED_CAP2 * sizeof(DSeed));
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2) {          // else: those reads stay flagged for the host
+            if ((rc = meme_buf_reserve(ctx, B[9], (size_t)n_redo * CHAIN_CAP2 * sizeof(DChain)))) return rc;
+            if ((rc = meme_buf_reserve(ctx, B[10], (size_t)n_redo * CHAIN_CAP2 * SEED_CAP2 * sizeof(DSeed)))) return rc;
+            ChainArgs A2 = A;
+            A2.ch = (DChain*)B[9].p; A2.sd = (DSeed*)B[10].p; A2.list = (const i64*)B[8].p; A2.nlist = (i64)n_redo;
+            hipLaunchKernelGGL((k_chain<CHAIN_CAP2, SEED_CAP2>), dim3((unsigned)((n_redo + 63) / 64)), dim3(64), 0, ctx->stream, A2);
+        }
+    }
     i64* d_nch = (i64*)B[5].p;
     i64* d_nsd = d_nch + (n + 1);
     i64* d_choff = d_nsd + (n + 1);
@@ -331,7 +402,8 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     if ((rc = meme_buf_reserve(ctx, B[6], (size_t)(tot[0] + 1) * sizeof(meme_chain)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[7], (size_t)(tot[1] + 1) * sizeof(meme_chain_seed)))) return rc;
     hipLaunchKernelGGL(k_chain_pack, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const DChain*)B[0].p, (const DSeed*)B[1].p,
-                       (const ReadHdr*)B[2].p, (const i64*)d_choff, (const i64*)d_sdoff, n, (meme_chain*)B[6].p, (meme_chain_seed*)B[7].p);
+                       (const DChain*)B[9].p, (const DSeed*)B[10].p, (const ReadHdr*)B[2].p, (const i64*)d_choff, (const i64*)d_sdoff, n,
+                       (meme_chain*)B[6].p, (meme_chain_seed*)B[7].p);
     HIP_TRY(hipGetLastError());
     meme_ctx::HostBuf* Hb = ctx->h_chain;   // 0 chain_off, 1 chains, 2 seed_off, 3 seeds, 4 tree sizes, 5 frac_rep, 6 fallback flags
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(tot[0] + 1) * sizeof(meme_chain))) ||

@@ -58,7 +58,7 @@ struct meme_ctx {
     std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[8];
+           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[11];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7];
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)

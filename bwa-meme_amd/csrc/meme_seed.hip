@@ -469,7 +469,7 @@ extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_ba
         {&ctx->reads, (size_t)total_bases + 16}, {&ctx->read_off, (n + 1) * 8}, {&ctx->slot_cnt, n * 4}, {&ctx->slot_hits, n * 8},
         {&ctx->slot_loc, n * 8}, {&ctx->counters, 12 * 8}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
         {&ctx->smem_off, (n + 1) * 8}, {&ctx->hit_off, (n + 1) * 8}, {&ctx->smems, n * 12 * sizeof(meme_mem_tl)}, {&ctx->hits, n * 24 * 8},
-        {&ctx->chain[0], n * 16 * 32}, {&ctx->chain[1], n * 16 * 8 * 16}, {&ctx->chain[2], n * 16}, {&ctx->chain[3], n * 4},
+        {&ctx->chain[0], n * 16 * 32}, {&ctx->chain[1], n * 16 * 8 * 16}, {&ctx->chain[2], n * 24}, {&ctx->chain[3], n * 4}, {&ctx->chain[8], n * 8},
         {&ctx->chain[5], (n + 1) * 32 + n * 5 + 64}, {&ctx->chain[6], n * 3 * sizeof(meme_chain)}, {&ctx->chain[7], n * 6 * sizeof(meme_chain_seed)}};
     for (auto& d : dev) if ((rc = meme_buf_reserve(ctx, *d.b, d.bytes))) return rc;
     struct { meme_ctx::HostBuf* b; size_t bytes; } host[] = {

@@ -36,6 +36,33 @@ class SeedHostResult(C.Structure):
                 ("total_smems", C.c_int64), ("total_hits", C.c_int64)]
 
 
+class ChainOpt(C.Structure):
+    _fields_ = [("w", C.c_int32), ("max_chain_gap", C.c_int32), ("max_occ", C.c_int32), ("min_seed_len", C.c_int32),
+                ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32), ("mask_level", C.c_float), ("drop_ratio", C.c_float),
+                ("l_pac", C.c_int64)]
+
+
+class Contig(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("len", C.c_int32), ("is_alt", C.c_int32)]
+
+
+class ChainHostResult(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("chain_off", C.c_void_p), ("chains", C.c_void_p), ("seed_off", C.c_void_p), ("seeds", C.c_void_p),
+                ("tree_size", C.c_void_p), ("frac_rep", C.c_void_p), ("fallback", C.c_void_p), ("total_chains", C.c_int64),
+                ("total_seeds", C.c_int64), ("n_fallback", C.c_int64)]
+
+
+CHAIN = np.dtype({"names": ["pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"],
+                  "formats": ["<i8", "<i4", "<i4", "<i4", "<i4", "<i2", "<i2", "<i4"], "offsets": [0, 8, 12, 16, 20, 24, 26, 28], "itemsize": 40})
+CHAIN_SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+
+
+def default_chain_opt(l_pac):
+    # mem_opt_init (reference src/bwamem.cpp:126-162): w 100, max_chain_gap 10000, max_occ 500, min_seed_len 19,
+    # min_chain_weight 0, max_chain_extend 1<<30, mask_level 0.5, drop_ratio 0.5
+    return ChainOpt(100, 10000, 500, 19, 0, 1 << 30, 0.5, 0.5, l_pac)
+
+
 class SeedResult(C.Structure):
     _fields_ = [("d_smems", C.c_void_p), ("d_smem_off", C.c_void_p), ("d_hits", C.c_void_p),
                 ("d_hit_off", C.c_void_p), ("total_smems", C.c_int64), ("total_hits", C.c_int64),
@@ -213,6 +240,24 @@ class Context:
             return np.frombuffer(buf, dtype=dtype, count=count).copy()
         return (view(res.smems, res.total_smems, MEM_TL), view(res.smem_off, n + 1, np.int64),
                 view(res.hits, res.total_hits, np.uint64), view(res.hit_off, n + 1, np.int64))
+
+    def chain_last_batch_host(self, contigs, opt):
+        """meme_chain_last_batch_host on the batch the last seed_batch_host call seeded.  contigs: (offset, len, is_alt) tuples.
+        Returns a dict of numpy arrays (copies of the ctx's pinned buffers)."""
+        arr = (Contig * len(contigs))(*[Contig(int(o), int(l), int(a)) for o, l, a in contigs])
+        res = ChainHostResult()
+        _check(lib().meme_chain_last_batch_host(C.c_void_p(self.h), arr, C.c_int32(len(contigs)), C.byref(opt), C.byref(res)))
+        n = res.nreads
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return {"chain_off": view(res.chain_off, n + 1, np.int64), "chains": view(res.chains, res.total_chains, CHAIN),
+                "seed_off": view(res.seed_off, n + 1, np.int64), "seeds": view(res.seeds, res.total_seeds, CHAIN_SEED),
+                "tree_size": view(res.tree_size, n, np.int32), "frac_rep": view(res.frac_rep, n, np.float32),
+                "fallback": view(res.fallback, n, np.uint8), "n_fallback": int(res.n_fallback)}
 
     def seed_batch_device(self, d_reads_ptr, d_read_off_ptr, nreads, total_bases, opt=None) -> SeedResult:
         opt = opt or default_seed_opt()

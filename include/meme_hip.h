@@ -170,8 +170,8 @@ int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_bases);
  * meme_seed_batch_host() call on this ctx has seeded -- the SMEMs and hits are still in HBM.  Per read: the chains that survive
  * the filter, in the filter's output order, each with its seeds in chain order (seed score = seed length, as mem_chain_Learned
  * sets it).  tree_size[r] = number of chains before the filter (what the reference sizes chain_ar[r] with); frac_rep[r] as
- * mem_chain_Learned computes it.  fallback[r] != 0: the read does not fit the device scratch (more than 16 chains, a chain of
- * more than 8 seeds, more than 256 SMEMs) or would insert two chains at one position (B-tree order of equal keys): it has no
+ * mem_chain_Learned computes it.  fallback[r] != 0: the read does not fit the device scratch (more than 128 chains, a chain of
+ * more than 32 seeds, more than 256 SMEMs) or would insert two chains at one position (B-tree order of equal keys): it has no
  * chains here and the caller chains it with the reference's host functions.  Results live in pinned buffers of the ctx until
  * the next call.  meme_contig = the fields of bntann1_t the stage needs (src/bntseq.h). */
 typedef struct { int64_t offset; int32_t len; int32_t is_alt; } meme_contig;

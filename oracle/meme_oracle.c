@@ -517,3 +517,233 @@ void orc_bsw_batch(orc_seqpair* pairs, const uint8_t* ref, const uint8_t* qer, i
     }
     if (cells) *cells = total;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) chaining: mem_chain_Learned (reference src/bwamem.cpp:1122-1204) + test_and_merge (:450-492)
+ *     + mem_chain_weight (:522-541) + mem_chain_flt (:599-717), one read at a time.
+ *
+ * The reference keeps the chains of a read in a B-tree keyed by position (klib kbtree) and sorts them by
+ * weight with klib's introsort (ksort.h) -- both third-party code vendored in the reference tree.  What is
+ * output-visible of them is restated here: the chain with the largest position <= the seed's is the merge
+ * candidate, traversal is by ascending position, and the sort performs klib's sequence of comparisons and
+ * swaps (median-of-three quicksort with an explicit stack, partitions of <= 16 elements left to a final
+ * insertion sort, comb sort when the depth budget runs out) because chains of EQUAL weight stay in the order
+ * that algorithm leaves them in and the overlap filter depends on it.  A read that inserts a second chain at
+ * a position that already has one makes the reference depend on the B-tree's order of equal keys: the oracle
+ * reports such reads as undefined (-1) instead of guessing.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct { int64_t pos; int32_t rid, n, m, w, first, kept, is_alt; orc_cseed* seeds; } ochain;
+
+static int o_pos2rid(const int64_t* off, int n_contigs, int64_t l_pac, int64_t pos_f) {   /* bns_pos2rid, src/bntseq.cpp:392-406 */
+    int left = 0, mid = 0, right = n_contigs;
+    if (pos_f >= l_pac) return -1;
+    while (left < right) {
+        mid = (left + right) >> 1;
+        if (pos_f >= off[mid]) {
+            if (mid == n_contigs - 1) break;
+            if (pos_f < off[mid + 1]) break;
+            left = mid + 1;
+        } else right = mid;
+    }
+    return mid;
+}
+static int o_intv2rid(const int64_t* off, int n_contigs, int64_t l_pac, int64_t rb, int64_t re) {   /* bns_intv2rid, :408-416 */
+    int rid_b, rid_e;
+    if (rb < l_pac && re > l_pac) return -2;
+    rid_b = o_pos2rid(off, n_contigs, l_pac, rb >= l_pac ? (l_pac << 1) - 1 - rb : rb);
+    rid_e = rb < re ? o_pos2rid(off, n_contigs, l_pac, re - 1 >= l_pac ? (l_pac << 1) - 1 - (re - 1) : re - 1) : rid_b;
+    return rid_b == rid_e ? rid_b : -1;
+}
+static int o_weight(const ochain* c) {
+    int64_t end = 0;
+    int j, w = 0, tmp;
+    for (j = 0; j < c->n; ++j) {
+        const orc_cseed* s = &c->seeds[j];
+        if (s->qbeg >= end) w += s->len;
+        else if (s->qbeg + s->len > end) w += (int)(s->qbeg + s->len - end);
+        end = end > s->qbeg + s->len ? end : s->qbeg + s->len;
+    }
+    tmp = w; w = 0;
+    for (j = 0, end = 0; j < c->n; ++j) {
+        const orc_cseed* s = &c->seeds[j];
+        if (s->rbeg >= end) w += s->len;
+        else if (s->rbeg + s->len > end) w += (int)(s->rbeg + s->len - end);
+        end = end > s->rbeg + s->len ? end : s->rbeg + s->len;
+    }
+    w = w < tmp ? w : tmp;
+    return w < 1 << 30 ? w : (1 << 30) - 1;
+}
+#define O_LT(a, b) ((a).w > (b).w)            /* flt_lt, src/bwamem.cpp:80 */
+#define O_SWAP(a, b) do { ochain t_ = (a); (a) = (b); (b) = t_; } while (0)
+static void o_insertsort(ochain* s, ochain* t) {
+    ochain *i, *j;
+    for (i = s + 1; i < t; ++i) for (j = i; j > s && O_LT(*j, *(j - 1)); --j) O_SWAP(*j, *(j - 1));
+}
+static void o_combsort(size_t n, ochain* a) {
+    const double shrink = 1.2473309501039786540366528676643;
+    int do_swap;
+    size_t gap = n;
+    ochain *i, *j;
+    do {
+        if (gap > 2) { gap = (size_t)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+        do_swap = 0;
+        for (i = a; i < a + n - gap; ++i) { j = i + gap; if (O_LT(*j, *i)) { O_SWAP(*i, *j); do_swap = 1; } }
+    } while (do_swap || gap > 2);
+    if (gap != 1) o_insertsort(a, a + n);
+}
+static void o_introsort(size_t n, ochain* a) {
+    struct { ochain *left, *right; int depth; } stack[160], *top = stack;
+    ochain rp, *s, *t, *i, *j, *k;
+    int d;
+    if (n < 1) return;
+    if (n == 2) { if (O_LT(a[1], a[0])) O_SWAP(a[0], a[1]); return; }
+    for (d = 2; 1ul << d < n; ++d);
+    s = a; t = a + (n - 1); d <<= 1;
+    for (;;) {
+        if (s < t) {
+            if (--d == 0) { o_combsort((size_t)(t - s) + 1, s); t = s; continue; }
+            i = s; j = t; k = i + ((j - i) >> 1) + 1;
+            if (O_LT(*k, *i)) { if (O_LT(*k, *j)) k = j; }
+            else k = O_LT(*j, *i) ? i : j;
+            rp = *k;
+            if (k != t) O_SWAP(*k, *t);
+            for (;;) {
+                do ++i; while (O_LT(*i, rp));
+                do --j; while (i <= j && O_LT(rp, *j));
+                if (j <= i) break;
+                O_SWAP(*i, *j);
+            }
+            O_SWAP(*i, *t);
+            if (i - s > t - i) {
+                if (i - s > 16) { top->left = s; top->right = i - 1; top->depth = d; ++top; }
+                s = t - i > 16 ? i + 1 : t;
+            } else {
+                if (t - i > 16) { top->left = i + 1; top->right = t; top->depth = d; ++top; }
+                t = i - s > 16 ? i - 1 : s;
+            }
+        } else {
+            if (top == stack) { o_insertsort(a, a + n); return; }
+            --top; s = top->left; t = top->right; d = top->depth;
+        }
+    }
+}
+static int smem_cmp(const void* a_, const void* b_) {      /* (start, end) ascending; ties cannot matter (same substring, same hits) */
+    const orc_mem_tl* a = (const orc_mem_tl*)a_; const orc_mem_tl* b = (const orc_mem_tl*)b_;
+    if (a->start != b->start) return a->start < b->start ? -1 : 1;
+    if (a->end != b->end) return a->end < b->end ? -1 : 1;
+    return a->hitbeg < b->hitbeg ? -1 : (a->hitbeg > b->hitbeg);
+}
+
+int orc_chain_read(const orc_mem_tl* smems_in, int n_smems, const uint64_t* hits, int len, const int64_t* contig_off,
+                   const uint8_t* contig_alt, int n_contigs, const orc_chain_opt* o, orc_chain* out, int chain_cap,
+                   orc_cseed* seeds_out, int seed_cap, int* tree_size, float* frac_rep) {
+    ochain* ch = NULL;
+    orc_mem_tl* sm = NULL;
+    int nc = 0, cap = 0, i, k, n, rc = 0, b = 0, e = 0, l_rep = 0;
+    *tree_size = 0; *frac_rep = 0.f;
+    if (len < o->min_seed_len) return 0;
+    sm = (orc_mem_tl*)malloc(sizeof(orc_mem_tl) * (size_t)(n_smems > 0 ? n_smems : 1));
+    memcpy(sm, smems_in, sizeof(orc_mem_tl) * (size_t)n_smems);
+    qsort(sm, (size_t)n_smems, sizeof(orc_mem_tl), smem_cmp);
+    for (i = 0; i < n_smems; ++i) {                           /* frac_rep, :1140-1147 */
+        if (sm[i].hitcount <= o->max_occ) continue;
+        if (sm[i].start > e) { l_rep += e - b; b = sm[i].start; e = sm[i].end; }
+        else e = e > sm[i].end ? e : sm[i].end;
+    }
+    l_rep += e - b;
+    for (i = 0; i < n_smems && rc == 0; ++i) {                /* :1149-1193 */
+        const orc_mem_tl* p = &sm[i];
+        const int step = p->hitcount > o->max_occ ? p->hitcount / o->max_occ : 1;
+        int64_t kk; int count;
+        for (kk = 0, count = 0; kk < p->hitcount && count < o->max_occ; kk += step, ++count) {
+            orc_cseed s; int rid, lower = -1, merged = 0, j;
+            s.rbeg = (int64_t)hits[p->hitbeg + kk]; s.qbeg = p->start; s.len = p->end - p->start;
+            rid = o_intv2rid(contig_off, n_contigs, o->l_pac, s.rbeg, s.rbeg + s.len);
+            if (rid < 0) continue;
+            for (j = 0; j < nc; ++j) { if (ch[j].pos <= s.rbeg) lower = j; else break; }
+            if (lower >= 0) {                                 /* test_and_merge */
+                ochain* c = &ch[lower];
+                const orc_cseed* last = &c->seeds[c->n - 1];
+                const int64_t qend = last->qbeg + last->len, rend = last->rbeg + last->len;
+                if (rid == c->rid) {
+                    if (s.qbeg >= c->seeds[0].qbeg && s.qbeg + s.len <= qend && s.rbeg >= c->seeds[0].rbeg && s.rbeg + s.len <= rend) merged = 1;
+                    else if ((last->rbeg < o->l_pac || c->seeds[0].rbeg < o->l_pac) && s.rbeg >= o->l_pac) merged = 0;
+                    else {
+                        const int64_t x = s.qbeg - last->qbeg, y = s.rbeg - last->rbeg;
+                        if (y >= 0 && x - y <= o->w && y - x <= o->w && x - last->len < o->max_chain_gap && y - last->len < o->max_chain_gap) {
+                            if (c->n == c->m) { c->m <<= 1; c->seeds = (orc_cseed*)realloc(c->seeds, sizeof(orc_cseed) * (size_t)c->m); }
+                            c->seeds[c->n++] = s;
+                            merged = 1;
+                        }
+                    }
+                }
+            }
+            if (!merged) {
+                ochain c;
+                if (lower >= 0 && ch[lower].pos == s.rbeg) { rc = -1; break; }     /* equal B-tree keys: undefined here */
+                if (nc == cap) { cap = cap ? cap * 2 : 8; ch = (ochain*)realloc(ch, sizeof(ochain) * (size_t)cap); }
+                memmove(&ch[lower + 2], &ch[lower + 1], sizeof(ochain) * (size_t)(nc - lower - 1));
+                c.pos = s.rbeg; c.rid = rid; c.n = 1; c.m = 4; c.w = 0; c.first = -1; c.kept = 0; c.is_alt = contig_alt[rid] ? 1 : 0;
+                c.seeds = (orc_cseed*)malloc(sizeof(orc_cseed) * 4);
+                c.seeds[0] = s;
+                ch[lower + 1] = c;
+                ++nc;
+            }
+        }
+    }
+    *tree_size = nc;
+    *frac_rep = (float)l_rep / len;
+    n = 0;
+    if (rc == 0 && nc > 0) {                                  /* mem_chain_flt */
+        int* kept_idx = (int*)malloc(sizeof(int) * (size_t)nc);
+        int nk = 0, ns_out = 0;
+        for (i = 0; i < nc; ++i) {
+            ch[i].first = -1; ch[i].kept = 0; ch[i].w = o_weight(&ch[i]);
+            if (ch[i].w < o->min_chain_weight) free(ch[i].seeds); else ch[n++] = ch[i];
+        }
+        nc = n;                                               /* (dropped chains are gone) */
+        if (n > 0) {
+            o_introsort((size_t)n, ch);
+            ch[0].kept = 3; kept_idx[nk++] = 0;
+            for (i = 1; i < n; ++i) {
+                int large_ovlp = 0;
+                const int beg_i = ch[i].seeds[0].qbeg, end_i = ch[i].seeds[ch[i].n - 1].qbeg + ch[i].seeds[ch[i].n - 1].len;
+                for (k = 0; k < nk; ++k) {
+                    const int j = kept_idx[k];
+                    const int beg_j = ch[j].seeds[0].qbeg, end_j = ch[j].seeds[ch[j].n - 1].qbeg + ch[j].seeds[ch[j].n - 1].len;
+                    const int b_max = beg_j > beg_i ? beg_j : beg_i, e_min = end_j < end_i ? end_j : end_i;
+                    if (e_min > b_max && (!ch[j].is_alt || ch[i].is_alt)) {
+                        const int li = end_i - beg_i, lj = end_j - beg_j, min_l = li < lj ? li : lj;
+                        if (e_min - b_max >= min_l * o->mask_level && min_l < o->max_chain_gap) {
+                            large_ovlp = 1;
+                            if (ch[j].first < 0) ch[j].first = i;
+                            if (ch[i].w < ch[j].w * o->drop_ratio && ch[j].w - ch[i].w >= o->min_seed_len << 1) break;
+                        }
+                    }
+                }
+                if (k == nk) { kept_idx[nk++] = i; ch[i].kept = large_ovlp ? 2 : 3; }
+            }
+            for (i = 0; i < nk; ++i) if (ch[kept_idx[i]].first >= 0) ch[ch[kept_idx[i]].first].kept = 1;
+            for (i = k = 0; i < n; ++i) {
+                if (ch[i].kept == 0 || ch[i].kept == 3) continue;
+                if (++k >= o->max_chain_extend) break;
+            }
+            for (; i < n; ++i) if (ch[i].kept < 3) ch[i].kept = 0;
+            for (i = k = 0; i < n; ++i) {
+                int j;
+                if (ch[i].kept == 0) continue;
+                if (k >= chain_cap || ns_out + ch[i].n > seed_cap) { rc = -2; break; }
+                out[k].pos = ch[i].pos; out[k].rid = ch[i].rid; out[k].n_seeds = ch[i].n; out[k].w = ch[i].w; out[k].first = ch[i].first;
+                out[k].kept = ch[i].kept; out[k].is_alt = ch[i].is_alt; out[k].seed_beg = ns_out;
+                for (j = 0; j < ch[i].n; ++j) seeds_out[ns_out++] = ch[i].seeds[j];
+                ++k;
+            }
+            n = k;
+        }
+        free(kept_idx);
+    }
+    for (i = 0; i < nc; ++i) free(ch[i].seeds);
+    free(ch);
+    free(sm);
+    return rc ? rc : n;
+}

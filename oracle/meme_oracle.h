@@ -87,6 +87,22 @@ int orc_bsw_extend(int qlen, const uint8_t* query, int tlen, const uint8_t* targ
 void orc_bsw_batch(orc_seqpair* pairs, const uint8_t* ref, const uint8_t* qer, int32_t n, int32_t w,
                    const orc_bsw_params* p, int threads, int64_t* cells);
 
+/* ---- chaining (mem_chain_Learned + mem_chain_flt, reference src/bwamem.cpp:1122-1204, 599-717) ---------------------------- */
+typedef struct {
+    int32_t w, max_chain_gap, max_occ, min_seed_len, min_chain_weight, max_chain_extend;
+    float mask_level, drop_ratio;
+    int64_t l_pac;
+} orc_chain_opt;
+typedef struct { int64_t pos; int32_t rid, n_seeds, w, first, kept, is_alt; int32_t seed_beg; } orc_chain;
+typedef struct { int64_t rbeg; int32_t qbeg, len; } orc_cseed;
+/* Chains of one read from its SMEMs (any order) and hits: the chains that survive the filter, in the filter's output order, into
+ * out[chain_cap] / seeds_out[seed_cap].  Returns their number; -1 when the read inserts two chains at one position (the reference
+ * then depends on its B-tree's order of equal keys: undefined here); -2 when a capacity is too small.  *tree_size = chains before
+ * the filter, *frac_rep as mem_chain_Learned computes it. */
+int orc_chain_read(const orc_mem_tl* smems, int n_smems, const uint64_t* hits, int len, const int64_t* contig_off,
+                   const uint8_t* contig_alt, int n_contigs, const orc_chain_opt* o, orc_chain* out, int chain_cap,
+                   orc_cseed* seeds_out, int seed_cap, int* tree_size, float* frac_rep);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,3 +41,20 @@ def build_index(fasta, bits=12, threads=4):
                     str(threads)], check=True, capture_output=True)
     _CACHE[key] = dst
     return dst
+
+
+def chain_golden_workload():
+    """The genome and reads tests/golden/chain_golden.npz was generated from (same seeds as tests/golden/make_chain_golden.py):
+    returns (genome, list of reads as uint8 code arrays of their own lengths)."""
+    from pymeme import synth
+    g = synth.make_genome(300_000, seed=201, repeat_frac=0.15, repeat_len=250, n_families=5, divergence=0.02, n_dups=8, dup_len=1200, poly_runs=4)
+    r1, _, _ = synth.make_reads(g, 2000, 150, seed=202, n_frac=0.03, exact_frac=0.2)
+    r2, _, _ = synth.make_reads(g, 500, 250, seed=203, sub_rate=0.05, indel_rate=0.0075, n_frac=0.02)
+    r3, _, _ = synth.make_reads(g, 300, 60, seed=204, sub_rate=0.02)
+    reads, k = [], 0
+    for rs in (r1, r2, r3):
+        for r in rs:
+            L = len(r) if rs is not r3 else 15 + k % 46
+            reads.append(np.ascontiguousarray(r[:L], dtype=np.uint8))
+            k += 1
+    return g, reads

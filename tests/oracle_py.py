@@ -179,3 +179,42 @@ def load_index_files(prefix: str) -> Index:
     raw = np.fromfile(prefix + ".pos_packed", dtype=np.uint8).reshape(-1, 5)
     sa = (raw[:, :4].copy().view("<u4").reshape(-1).astype(np.uint64) << np.uint64(8)) | raw[:, 4].astype(np.uint64)
     return Index(text, sa)
+
+
+# ---- chaining (mem_chain_Learned + mem_chain_flt) --------------------------------------------------------------------------
+class OrcChainOpt(C.Structure):
+    _fields_ = [("w", C.c_int32), ("max_chain_gap", C.c_int32), ("max_occ", C.c_int32), ("min_seed_len", C.c_int32),
+                ("min_chain_weight", C.c_int32), ("max_chain_extend", C.c_int32), ("mask_level", C.c_float), ("drop_ratio", C.c_float),
+                ("l_pac", C.c_int64)]
+
+
+ORC_CHAIN_DTYPE = np.dtype([("pos", "<i8"), ("rid", "<i4"), ("n_seeds", "<i4"), ("w", "<i4"), ("first", "<i4"), ("kept", "<i4"),
+                            ("is_alt", "<i4"), ("seed_beg", "<i4"), ("_pad", "<i4")])
+ORC_CSEED_DTYPE = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+assert ORC_CHAIN_DTYPE.itemsize == 40 and ORC_CSEED_DTYPE.itemsize == 16
+
+
+def default_chain_opt(l_pac, w=100, max_chain_gap=10000, max_occ=500, min_seed_len=19, min_chain_weight=0, max_chain_extend=1 << 30,
+                      mask_level=0.5, drop_ratio=0.5):
+    # mem_opt_init, reference src/bwamem.cpp:126-162
+    return OrcChainOpt(w, max_chain_gap, max_occ, min_seed_len, min_chain_weight, max_chain_extend, mask_level, drop_ratio, l_pac)
+
+
+def chain_read(smems, hits, read_len, contig_off, contig_alt, opt, chain_cap=4096, seed_cap=1 << 16):
+    """orc_chain_read for one read.  smems: MEM_TL_DTYPE array (hitbeg relative to `hits`); returns (rc, chains, seeds, tree_size,
+    frac_rep) with rc = number of chains, -1 = undefined (equal B-tree keys), -2 = capacity."""
+    L = lib()
+    L.orc_chain_read.restype = C.c_int
+    smems = np.ascontiguousarray(smems, dtype=MEM_TL_DTYPE)
+    hits = np.ascontiguousarray(hits, dtype=np.uint64)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_alt = np.ascontiguousarray(contig_alt, dtype=np.uint8)
+    out = np.zeros(chain_cap, ORC_CHAIN_DTYPE)
+    sd = np.zeros(seed_cap, ORC_CSEED_DTYPE)
+    tree, frac = C.c_int(0), C.c_float(0)
+    rc = L.orc_chain_read(C.c_void_p(smems.ctypes.data), C.c_int(smems.shape[0]), C.c_void_p(hits.ctypes.data), C.c_int(int(read_len)),
+                          C.c_void_p(contig_off.ctypes.data), C.c_void_p(contig_alt.ctypes.data), C.c_int(contig_off.shape[0]), C.byref(opt),
+                          C.c_void_p(out.ctypes.data), C.c_int(chain_cap), C.c_void_p(sd.ctypes.data), C.c_int(seed_cap), C.byref(tree), C.byref(frac))
+    n = max(rc, 0)
+    ns = int(out["n_seeds"][:n].sum())
+    return rc, out[:n], sd[:ns], tree.value, frac.value

@@ -65,3 +65,36 @@ def test_refpath_restatement_agrees_with_semantic_oracle(g1_index, length):
         for f in ("start", "end", "hitcount"):
             assert np.array_equal(sm[r, :k][f], rsm[r, :k][f]), (r, f)
     assert ctr["compares"] > ctr["lookups"] > 0 and ctr["smems"] == int(ns.sum())
+
+
+def test_chain_oracle_equals_reference_golden():
+    """orc_chain_read (restatement of mem_chain_Learned + test_and_merge + mem_chain_weight + mem_chain_flt, klib sort order
+    included) against the chains the compiled reference made of the same seeds (tests/golden/chain_golden.npz, 2 800 reads of a
+    repeat-rich genome, 689 of them with several chains; generator: tests/golden/make_chain_golden.py)."""
+    import numpy as np
+    G = np.load(os.path.join(GOLDEN, "chain_golden.npz"))
+    opt = O.default_chain_opt(int(G["l_pac"]))
+    contig_alt = np.zeros(G["contig_off"].shape[0], np.uint8)
+    undefined = 0
+    for r in range(G["read_len"].shape[0]):
+        s0, s1 = int(G["smem_off"][r]), int(G["smem_off"][r + 1])
+        sm = np.zeros(s1 - s0, O.MEM_TL_DTYPE)
+        sm["start"], sm["end"], sm["hitbeg"], sm["hitcount"] = G["smems"][s0:s1].T
+        hits = G["hits"][int(G["hit_off"][r]):int(G["hit_off"][r + 1])]
+        rc, ch, sd, tree, frac = O.chain_read(sm, hits, int(G["read_len"][r]), G["contig_off"], contig_alt, opt)
+        if rc == -1:
+            undefined += 1
+            continue
+        c0, c1 = int(G["chain_off"][r]), int(G["chain_off"][r + 1])
+        want = G["chains"][c0:c1]
+        assert rc == c1 - c0 and tree == int(G["tree_size"][r]), (r, rc, c1 - c0, tree, int(G["tree_size"][r]))
+        if rc:
+            assert np.float32(frac).view(np.uint32) == G["frac_rep_bits"][r], r
+        for k in range(rc):
+            got = [int(ch[k][f]) for f in ("pos", "rid", "n_seeds", "w", "kept", "first", "is_alt")]
+            assert got == [int(x) for x in want[k][:7]], (r, k, got, want[k])
+            b = int(want[k][7])
+            ws = G["seeds"][b:b + int(want[k][2])]
+            gs = sd[int(ch[k]["seed_beg"]):int(ch[k]["seed_beg"]) + int(ch[k]["n_seeds"])]
+            assert np.array_equal(np.stack([gs["rbeg"], gs["qbeg"], gs["len"]], 1), ws), (r, k)
+    assert undefined < 30, undefined
