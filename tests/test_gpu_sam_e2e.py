@@ -142,3 +142,32 @@ def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
     m = re.search(r"\((\d+) of them again with the doubled band\)", r.stderr.decode())
     assert m and int(m.group(1)) > 100, r.stderr.decode()[-1500:]
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_with_alt_contigs(tmp_path):
+    """A reference with ALT contigs (<prefix>.alt, src/bntseq.cpp:208-239): the third contig is a diverged copy of a stretch of the
+    first, so reads from that stretch chain equally well on both and the chain filter's ALT rule decides (src/bwamem.cpp:666);
+    chained on the device and, with MEME_DROPIN_CHAIN_CHECK, on the host."""
+    g = synth.make_genome(300_000, seed=61, repeat_frac=0.02)
+    third = 100_000
+    alt = g[20_000:20_000 + third].copy()
+    rng = np.random.default_rng(62)
+    flip = rng.random(third) < 0.004
+    alt[flip] = (alt[flip] + 1) & 3
+    g = np.concatenate([g[:2 * third], alt])
+    fa = str(tmp_path / "alt.fa")
+    synth.write_fasta(fa, g, contigs=3)
+    prefix = build_index(fa, bits=14)
+    with open(prefix + ".alt", "w") as fh:
+        fh.write("chrS3\n")
+    r1, _, _ = synth.make_reads(g[:2 * third], 4000, 150, seed=63, n_frac=0.01)
+    fq = str(tmp_path / "alt.fq")
+    synth.write_fastq(fq, r1, prefix="a")
+    want = _sam("bwa-meme_mode3", prefix, [fq], threads=8)
+    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1"), threads=8)
+    assert len(got) == len(want) and len(want) > 4000
+    diff = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+    assert sum(1 for l in want if "\tchrS3\t" in l or "chrS3," in l) > 100           # the ALT contig does take part
