@@ -2,20 +2,23 @@
 // headers* and linked into the reference aligner (oracle/Makefile.ref target bwa-meme_dropin).  The reference objects
 // are built position-independent into libbwa_pic.so; the definitions below live in the executable and therefore win
 // symbol resolution (ELF interposition) -- no reference source is modified or copied, the calls below go to functions
-// the reference exports.  A maintainer integrating the backend would put the same code behind an #ifdef at the four
+// the reference exports.  A maintainer integrating the backend would put the same code behind an #ifdef at the five
 // places named here:
 //
-//   memoryAllocLearned()            src/fastmap.cpp:351-641   worker buffers as before, but the index goes to HBM
+//   memoryAllocLearned()            src/fastmap.cpp:351-641   worker buffers as before, but the index files stream to HBM
 //                                   (meme_index_load_files + meme_index_replicate per extra GPU) instead of being
-//                                   expanded on the host (13-byte suffix-array entries + ISA, ~100 s / ~120 GB at GRCh38)
+//                                   expanded on the host (13-byte suffix-array entries + ISA, ~200 s / ~120 GB at GRCh38)
 //   mem_process_seqs()              src/bwamem.cpp:1920-1972  ONE meme_seed_batch_host() per -K chunk (split over the
-//                                   visible GPUs) before kt_for(worker_bwt); the reference's own body then runs unchanged
-//   mem_kernel1_core_Learned()      src/bwamem.cpp:1230-1413  per 512-read batch: takes the chunk's precomputed SMEMs and
-//                                   hits, then the reference's ks_introsort / mem_chain_Learned / mem_chain_flt /
-//                                   mem_flt_chained_seeds
+//                                   visible GPUs) followed by meme_chain_last_batch_host() (mem_chain_Learned +
+//                                   mem_chain_flt on the device) before kt_for(worker_bwt); then the reference's own body
+//   mem_kernel1_core_Learned()      src/bwamem.cpp:1230-1413  per 512-read batch: takes the chunk's chains; the reference's
+//                                   ks_introsort / mem_chain_Learned / mem_chain_flt only for reads the device flagged;
+//                                   mem_flt_chained_seeds as before
+//   mem_chain2aln_across_reads_V2() src/bwamem.cpp:2573-3497  the extension jobs of the WHOLE chunk, stage by stage: one
+//                                   meme_bsw_batch() per direction and band width (the first batch to arrive does it)
 //   BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper   src/bandedSWA.cpp:242-260,1970-,2664-
-//                                   -> meme_bsw_batch(); the concurrent calls of the kt_for workers are combined into one
-//                                   backend call per GPU (group commit), staged through pinned buffers
+//                                   -> meme_bsw_batch(); concurrent calls of the kt_for workers combined into one backend
+//                                   call per GPU (group commit) -- the path when the chunk-wide stage is switched off
 #include <dlfcn.h>
 #include <sched.h>
 #include <time.h>
