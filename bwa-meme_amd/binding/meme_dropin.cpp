@@ -278,6 +278,9 @@ uint64_t g_chunk_gen = 0;               // counts the chunks seeded
 
 typedef void (*process_fn)(mem_opt_t*, int64_t, int, bseq1_t*, const mem_pestat_t*, worker_t&);
 void ext_report();
+}
+void meme_dropin_report_matesw();
+namespace {
 
 }  // namespace
 
@@ -304,6 +307,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead (scratch capacity / equal positions)\n",
                 (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
     if (verbose()) ext_report();
+    if (verbose()) meme_dropin_report_matesw();
 }
 
 namespace {
@@ -1186,4 +1190,22 @@ void BandedPairWiseSW::getScores16(SeqPair* p, uint8_t* r, uint8_t* q, int32_t n
 void BandedPairWiseSW::getScores8(SeqPair* p, uint8_t* r, uint8_t* q, int32_t n, uint16_t nthreads, int32_t w) {
     (void)nthreads;
     bsw_forward(mat, o_del, e_del, o_ins, e_ins, zdrop, end_bonus, p, r, q, n, w);
+}
+
+// ---- measurement only (MEME_DROPIN_VERBOSE): time the worker threads spend in the mate-rescue Smith-Waterman batch ----------
+#include "kswv.h"
+namespace { std::atomic<double> g_t_matesw{0}; std::atomic<int64_t> g_n_matesw{0}; }
+typedef int (*sam_pe_batch_fn)(const mem_opt_t*, mem_cache*, int64_t&, int64_t&, kswr_t*, int32_t, int32_t, int);
+int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_t& pcnt8, kswr_t* aln, int32_t maxRefLen, int32_t maxQerLen, int tid) {
+    static sam_pe_batch_fn next = (sam_pe_batch_fn)dlsym(RTLD_NEXT, "_Z16mem_sam_pe_batchPK9mem_opt_tP9mem_cacheRlS4_P6kswr_tiii");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_sam_pe_batch was not found\n"); exit(1); }
+    const double t0 = now_s();
+    const int64_t n = pcnt;
+    const int rc = next(opt, mmc, pcnt, pcnt8, aln, maxRefLen, maxQerLen, tid);
+    g_t_matesw = g_t_matesw + (now_s() - t0);
+    g_n_matesw += n;
+    return rc;
+}
+void meme_dropin_report_matesw() {
+    fprintf(stderr, "[meme-dropin] mate-rescue SW (reference kswv, host): %lld pairs, %.3f thread-seconds so far\n", (long long)g_n_matesw, (double)g_t_matesw);
 }

@@ -16,13 +16,14 @@ g = synth.make_genome(int(mbp * 1e6) & ~1, seed=11)
 t0 = time.time(); text, sa = hostapi.build_sa(g); l1, l2 = hostapi.train_prmi(text, sa)
 prefix = os.path.join(d, "ref.fa"); hostapi.write_index(prefix, g, text, sa, l1, l2, n_contigs=8); log("index %.1f s" % (time.time() - t0))
 rng = np.random.default_rng(5)
-pos = rng.integers(0, g.shape[0] - 700, size=npairs); ins = rng.integers(300, 500, size=npairs)
-ar = np.arange(150)
+RL = int(os.environ.get("E2E_READ_LEN", "150")); SUB = float(os.environ.get("E2E_SUB", "0.01"))   # BASELINE configs[4] read class: 250 / 0.05
+pos = rng.integers(0, g.shape[0] - 700 - RL, size=npairs); ins = rng.integers(300, 500, size=npairs) + (RL - 150)
+ar = np.arange(RL)
 def mut(x):
-    sub = rng.random(x.shape) < 0.01
+    sub = rng.random(x.shape) < SUB
     return np.where(sub, (x + rng.integers(1, 4, size=x.shape, dtype=np.uint8)) & 3, x).astype(np.uint8)
 r1 = mut(g[pos[:, None] + ar[None, :]])
-r2 = mut(3 - g[(pos + ins - 150)[:, None] + ar[None, :]][:, ::-1])
+r2 = mut(3 - g[(pos + ins - RL)[:, None] + ar[None, :]][:, ::-1])
 def fastq(reads, path):
     n, L = reads.shape
     names = np.char.add("@p", np.arange(n).astype(str)).astype("S")
