@@ -390,6 +390,8 @@ def main():
     t0 = time.time()
     if os.environ.get("MEME_BENCH_LANES"):
         ctx.set_tuning("group_lanes", int(os.environ["MEME_BENCH_LANES"]))
+    if os.environ.get("MEME_BENCH_SMEM_CAP"):
+        ctx.set_tuning("smem_cap", int(os.environ["MEME_BENCH_SMEM_CAP"]))
     L = hipapi.lib()
     if pre is not None:
         d_text, d_pos5, d_l2, d_l1 = pre[:4]

@@ -64,7 +64,8 @@ struct meme_ctx {
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
-    i64 smem_cap = 64;                 // per-read SMEM slots in the search kernel's scratch (tier 0)
+    i64 smem_cap = 128;                // per-read SMEM slots in the search kernel's scratch (tier 0; 3 KB per read.  With 64 a handful of
+                                       // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
     i64 bsw_blocks = 0;

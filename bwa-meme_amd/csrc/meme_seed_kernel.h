@@ -47,7 +47,7 @@ struct SlotRec {          // search-kernel output, one per SMEM
 };
 
 constexpr int N_TIERS = 3;
-constexpr int TIER_CAP[N_TIERS] = {64, 2048, 65536};   // global SMEM slots per read; tier 0 is tunable
+constexpr int TIER_CAP[N_TIERS] = {64, 2048, 65536};   // global SMEM slots per read; tier 0 is tunable (meme_ctx::smem_cap, default 128)
 #ifndef LCAP0
 #define LCAP0 16
 #endif
