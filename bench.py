@@ -313,7 +313,7 @@ def main():
         except ImportError:
             pass
         gpu_free = torch.cuda.mem_get_info(local)[0]
-        while mbp > 64 and 2 * mbp * 1e6 * 33 + nreads * 2200 > 0.9 * gpu_free:
+        while mbp > 64 and 2 * mbp * 1e6 * 33 + nreads * 3800 > 0.9 * gpu_free:     # (3 KB of SMEM slots + packed read + outputs per read)
             mbp /= 2
             log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
     l_pac_t = torch.tensor([int(mbp * 1e6) & ~1], dtype=torch.int64, device=dev)

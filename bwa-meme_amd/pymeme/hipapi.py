@@ -241,6 +241,9 @@ class Context:
         return (view(res.smems, res.total_smems, MEM_TL), view(res.smem_off, n + 1, np.int64),
                 view(res.hits, res.total_hits, np.uint64), view(res.hit_off, n + 1, np.int64))
 
+    def seed_reserve(self, nreads, total_bases):
+        _check(lib().meme_seed_reserve(C.c_void_p(self.h), C.c_int64(nreads), C.c_int64(total_bases)))
+
     def chain_last_batch_host(self, contigs, opt):
         """meme_chain_last_batch_host on the batch the last seed_batch_host call seeded.  contigs: (offset, len, is_alt) tuples.
         Returns a dict of numpy arrays (copies of the ctx's pinned buffers)."""

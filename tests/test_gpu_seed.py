@@ -233,3 +233,18 @@ def test_index_files_loader_errors_and_equals_host_loader(g1, tmp_path):
         assert _gpu_dump(c, reads, off) == want
     finally:
         c.close()
+
+
+def test_reserved_buffers_change_nothing(g1):
+    """meme_seed_reserve only allocates ahead of time (too little, enough, or far too much): same seeds through the pinned-result call."""
+    for nres in (10, 140, 100_000):
+        c = hipapi.Context(0)
+        try:
+            c.load_index_files(g1)
+            c.seed_reserve(nres, nres * 150)
+            reads, off = read_fastq_codes(os.path.join(GOLDEN, "g1_reads_150.fq"))
+            smems, smem_off, hits, hit_off = c.seed_batch_host(reads, off)
+            slots, counts, hl = hipapi.smems_to_slots(smems, smem_off, hits, hit_off)
+            assert O.format_seed_dump(slots, counts, hl) == open(os.path.join(GOLDEN, "g1_seeds_150.txt")).read()
+        finally:
+            c.close()
