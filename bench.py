@@ -45,7 +45,7 @@ import torch.distributed as dist  # noqa: E402
 from pymeme import hipapi, hostapi, synth, workload  # noqa: E402
 
 READ_LEN = 150
-BSW_VALU_PER_CELL = 35.0     # updated from profiles/r02_bsw.md (SQ_INSTS_VALU x 64 / DP cells of the bench's 2 M distinct pairs)
+BSW_VALU_PER_CELL = 33.6     # measured: profiles/r02_bsw.md (SQ_INSTS_VALU x 64 lanes / DP cells of 2 M distinct pairs, a committed PMC pass)
 T_START = time.time()
 
 

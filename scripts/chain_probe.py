@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Chaining-on-the-device probe: python scripts/chain_probe.py [Mbp] [Mreads]
+Seeds a batch through the pinned-result call, chains it with meme_chain_last_batch_host and prints wall times of both calls
+(kernel times: run under `rocprofv3 --kernel-trace --stats`)."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "bwa-meme_amd"))
+import numpy as np, torch
+from pymeme import hipapi, synth, workload
+mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 256
+nreads = int(float(sys.argv[2]) * 1e6) if len(sys.argv) > 2 else 2000000
+l_pac = int(mbp * 1e6) & ~1
+n = 2 * l_pac
+g = synth.make_genome(l_pac, seed=11)
+ctx = hipapi.Context(0)
+text = hipapi.fwd_rc_text(g)
+d_text, d_sa = hipapi.build_sa_device(ctx, text)
+d_pos5 = hipapi.pos5_from_sa_torch(ctx, d_sa, n)
+del d_sa
+d_pac, d_ent = hipapi.stage_entries_torch(ctx, n, d_text, d_pos5)
+bits = 28 if 8.0 * n + 8 > 8.0e9 else 26 if 8.0 * n + 8 > 1.0e9 else 24
+d_l2, n_l2, d_l1, n_l1 = hipapi.train_prmi_device(ctx, d_ent, n, bits)
+keep = (d_pac, d_ent) + hipapi.attach_index_torch(ctx, n, d_pac, d_ent, d_l2, n_l2, d_l1, n_l1)
+reads = workload.make_reads_fast(g, nreads, 150, seed=1000)
+off = np.arange(0, (nreads + 1) * 150, 150, dtype=np.int64)
+contigs = [(l_pac * k // 8, l_pac * (k + 1) // 8 - l_pac * k // 8, 0) for k in range(8)]
+opt = hipapi.default_chain_opt(l_pac)
+for it in range(3):
+    t0 = time.time(); smems, so, hits, ho = ctx.seed_batch_host(reads.reshape(-1), off); t1 = time.time()
+    res = ctx.chain_last_batch_host(contigs, opt); t2 = time.time()
+    print("[chain probe] %d reads: seeding call %.1f ms (%.1f M reads/s incl. transfers), chaining call %.1f ms (%.1f M reads/s incl. transfers + numpy copies); "
+          "%d chains, %d chained seeds, %d reads left to the host" % (nreads, (t1 - t0) * 1e3, nreads / (t1 - t0) / 1e6, (t2 - t1) * 1e3, nreads / (t2 - t1) / 1e6,
+                                                                      res["chains"].shape[0], res["seeds"].shape[0], res["n_fallback"]), flush=True)
