@@ -186,7 +186,12 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
                 const int rid = intv2rid(A, s.rbeg, s.rbeg + s.len);
                 if (rid < 0) continue;                                    // bridging two sequences or the strands (:1166)
                 int lower = -1;                                           // the chain with the largest position <= the seed's
-                for (int i = 0; i < nc; ++i) { if (ch[i].pos <= s.rbeg) lower = i; else break; }
+                if (nc <= 8) { for (int i = 0; i < nc; ++i) { if (ch[i].pos <= s.rbeg) lower = i; else break; } }
+                else {                                                    // (repeats: up to 128 chains and 500 hits per SMEM)
+                    int lo_i = 0, hi_i = nc;                              // first chain with pos > rbeg
+                    while (lo_i < hi_i) { const int mid = (lo_i + hi_i) >> 1; if (ch[mid].pos <= s.rbeg) lo_i = mid + 1; else hi_i = mid; }
+                    lower = lo_i - 1;
+                }
                 bool merged = false;
                 if (lower >= 0) {                                         // test_and_merge, src/bwamem.cpp:450-492
                     DChain& c = ch[lower];
