@@ -185,6 +185,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
                 const meme_seed_opt* opt, meme_seed_result* out) {
     unsigned long long h_counters[12];
     int rc;
+    ctx->last_seed_reads = 0;          // whatever batch meme_chain_last_batch_host could have chained is being overwritten
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;

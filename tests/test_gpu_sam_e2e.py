@@ -122,6 +122,11 @@ def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
         rows.append(r)
     noisy, _, _ = synth.make_reads(g, 1500, 250, seed=53, sub_rate=0.05, indel_rate=0.0075, n_frac=0.02)
     short, _, _ = synth.make_reads(g, 300, 250, seed=54)
+    # pathological reads: homopolymers and a dinucleotide run (thousands of SMEMs and hits where the genome has such runs: overflow
+    # tiers of the search kernel, more SMEMs than the chain kernel takes), all N, N every 20 bases, one base
+    weird = [np.zeros(150, np.uint8), np.full(150, 3, np.uint8), np.tile(np.array([0, 1], np.uint8), 75), np.full(150, 4, np.uint8),
+             np.where(np.arange(150) % 20 == 7, 4, g[5000:5150]).astype(np.uint8), g[7000:7001].copy()]
+    rows += weird
     fq = str(tmp_path / "gaps.fq")
     with open(fq, "w") as fh:
         k = 0
@@ -137,7 +142,7 @@ def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
     r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_CHAIN_CHECK="1"), timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
-    assert len(got) == len(want) and len(want) > 3300
+    assert len(got) == len(want) and len(want) > 3306
     diff = [(a, b) for a, b in zip(got, want) if a != b]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
     m = re.search(r"\((\d+) of them again with the doubled band\)", r.stderr.decode())
