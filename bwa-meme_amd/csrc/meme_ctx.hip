@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <thread>
 
@@ -339,7 +340,7 @@ extern "C" int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, in
     });
 }
 
-// A file straight to device memory: reader threads, each with two pinned pieces and a stream of its own -- piece k of the
+// A file straight to device memory: reader threads, each with two pinned pieces (LoadBuffers) and a stream of its own -- piece k of the
 // file is read by thread k mod T while the thread's previous piece is still on its way over PCIe.  (A 31 GB position image
 // read into a zero-filled std::vector by one thread and copied from pageable memory took 20 s; this takes what the
 // slower of page cache and PCIe allows.)
@@ -348,22 +349,36 @@ static long long file_size(const std::string& path) {
     return stat(path.c_str(), &st) == 0 ? (long long)st.st_size : -1;
 }
 
-static int file_to_device(meme_ctx* ctx, const std::string& path, void* d_dst, size_t bytes) {
+// pinned pieces of the reader threads, allocated once per index load (pinning memory costs ~0.4 s per GB: a fresh set per file
+// was a third of the load time)
+struct LoadBuffers {
+    static constexpr size_t PIECE = (size_t)16 << 20;
+    int T = 0;
+    std::vector<uint8_t*> buf;            // 2 per reader
+    int init(int readers) {
+        T = readers;
+        buf.assign((size_t)2 * T, nullptr);
+        for (auto& b : buf) if (hipHostMalloc((void**)&b, PIECE, hipHostMallocDefault) != hipSuccess) return MEME_E_HIP;
+        return MEME_OK;
+    }
+    ~LoadBuffers() { for (auto b : buf) if (b) (void)hipHostFree(b); }
+};
+
+static int file_to_device(meme_ctx* ctx, LoadBuffers& LB, const std::string& path, void* d_dst, size_t bytes) {
     if (bytes == 0) return MEME_OK;
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) { meme_set_error("cannot open %s", path.c_str()); return MEME_E_IO; }
-    const size_t piece = (size_t)32 << 20;
+    const size_t piece = LoadBuffers::PIECE;
     const size_t n_pieces = (bytes + piece - 1) / piece;
-    const int T = (int)(n_pieces < 12 ? n_pieces : 12);
+    const int T = (int)(n_pieces < (size_t)LB.T ? n_pieces : (size_t)LB.T);
     std::atomic<int> err{MEME_OK};
     auto reader = [&](int t) {
         if (hipSetDevice(ctx->device) != hipSuccess) { err = MEME_E_HIP; return; }
         hipStream_t st = nullptr;
-        uint8_t* buf[2] = {nullptr, nullptr};
+        uint8_t* buf[2] = {LB.buf[(size_t)2 * t], LB.buf[(size_t)2 * t + 1]};
         hipEvent_t ev[2] = {nullptr, nullptr};
         bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
-        for (int b = 0; b < 2 && ok; ++b)
-            ok = hipHostMalloc((void**)&buf[b], piece, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) == hipSuccess;
+        for (int b = 0; b < 2 && ok; ++b) ok = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) == hipSuccess;
         int turn = 0;
         for (size_t k = (size_t)t; ok && k < n_pieces && err == MEME_OK; k += (size_t)T, turn ^= 1) {
             const size_t off = k * piece, len = bytes - off < piece ? bytes - off : piece;
@@ -379,7 +394,7 @@ static int file_to_device(meme_ctx* ctx, const std::string& path, void* d_dst, s
                  hipEventRecord(ev[turn], st) == hipSuccess;
         }
         if (st && hipStreamSynchronize(st) != hipSuccess) ok = false;
-        for (int b = 0; b < 2; ++b) { if (ev[b]) (void)hipEventDestroy(ev[b]); if (buf[b]) (void)hipHostFree(buf[b]); }
+        for (int b = 0; b < 2; ++b) if (ev[b]) (void)hipEventDestroy(ev[b]);
         if (st) (void)hipStreamDestroy(st);
         if (!ok && err == MEME_OK) err = MEME_E_HIP;
     };
@@ -405,9 +420,19 @@ extern "C" int meme_index_load_files(meme_ctx* ctx, const char* prefix) {
         meme_set_error("%s: .pos_packed (%lld B) and .0123 (%lld B) disagree on the suffix count", prefix, size[1], size[0]);
         return MEME_E_IO;
     }
+    const bool trace = getenv("MEME_LOAD_TRACE") != nullptr;
+    LoadBuffers LB;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (LB.init(getenv("MEME_LOAD_THREADS") && atoi(getenv("MEME_LOAD_THREADS")) > 0 ? atoi(getenv("MEME_LOAD_THREADS")) : 8)) { meme_set_error("pinned staging for the index load could not be allocated"); return MEME_E_HIP; }
     return index_build_from(ctx, size[0], size[3], size[2], [&](int which, void* d_dst, size_t bytes) {
         if ((long long)bytes != size[which]) { meme_set_error("%s changed size while loading", name[which].c_str()); return (int)MEME_E_IO; }
-        return file_to_device(ctx, name[which], d_dst, bytes);
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = file_to_device(ctx, LB, name[which], d_dst, bytes);
+        if (trace) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "[meme] %s: %.2f GB to the device in %.2f s (%.1f GB/s)\n", name[which].c_str(), bytes / 1e9, dt, bytes / 1e9 / dt);
+        }
+        return rc;
     });
 }
 
