@@ -57,14 +57,14 @@ def test_sam_identical_to_reference(tmp_path, paired):
     # multi-GPU arrangement (three device slots: reads of a chunk split three ways, index replicas, one extension call per slot)
     # on however many GPUs the box has.  Chaining runs on the device (mem_chain_Learned + mem_chain_flt) with
     # MEME_DROPIN_CHAIN_CHECK set: every read is also chained by the reference's host functions and any difference in any
-    # chain or seed is fatal; MEME_DROPIN_CHAIN=0 keeps chaining on the host, MEME_DROPIN_IO=0 the reference's own FASTQ parser
-    # (by default the binding parses the two files on two threads).
+    # chain or seed is fatal; MEME_DROPIN_CHAIN=0 keeps chaining on the host, MEME_DROPIN_IO=1 lets the binding parse the two
+    # FASTQ files on two threads.
     small = {}
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}),
                                   (8, 100000000, {"MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
                                   (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
-                                  (4, 100000000, {"MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "0"})):
+                                  (4, 100000000, {"MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
         env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", **extra)
         got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
         if chunk == 100000000: ref = want
@@ -196,7 +196,7 @@ def test_sam_identical_when_one_mate_file_is_shorter(tmp_path, short_file):
     synth.write_fastq(f1, r1[:n - 37] if short_file == 1 else r1, prefix="u")
     synth.write_fastq(f2, r2[:n - 37] if short_file == 2 else r2, prefix="u")
     want = _sam("bwa-meme_mode3", prefix, [f1, f2], threads=4, chunk=100000)
-    got = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix), threads=4, chunk=100000)
+    got = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_IO="1"), threads=4, chunk=100000)
     assert len(got) == len(want) and len(want) > 2 * (n - 40)
     diff = [(a, b) for a, b in zip(got, want) if a != b]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
