@@ -293,6 +293,15 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
     drop_index(ctx);
     int rc = set_rmi(ctx, l2_bytes / 24, l1_bytes / 24);
     if (rc) return rc;
+    const bool trace = getenv("MEME_LOAD_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[meme] index build: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     const i64 words = meme_index_pac64_words(n);
     const i64 n_l2 = l2_bytes / 24, n_l1 = l1_bytes / 24;
     void *d_ent = nullptr, *d_pac = nullptr, *d_l2 = nullptr, *d_l1 = nullptr, *d_tmp = nullptr;
@@ -305,14 +314,17 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
     if ((size_t)l2_bytes > tmp_bytes) tmp_bytes = (size_t)l2_bytes;
     if ((size_t)l1_bytes > tmp_bytes) tmp_bytes = (size_t)l1_bytes;
     HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
+    lap("device allocations");
     auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d_tmp); return code; };
     if ((rc = fetch(0, d_tmp, (size_t)n))) return fail(rc);
     if ((rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac))) return fail(rc);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    lap("text + pack kernel");
     if ((rc = fetch(1, d_tmp, (size_t)n * 5))) return fail(rc);
     if (hipMemsetAsync((uint8_t*)d_tmp + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     if ((rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent))) return fail(rc);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    lap("position image + entry kernel");
     if ((rc = fetch(2, d_tmp, (size_t)l2_bytes))) return fail(rc);
     if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l2, d_l2))) return fail(rc);
     if (n_l1 > 0) {
@@ -321,7 +333,9 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
         if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l1, d_l1))) return fail(rc);
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    lap("model records");
     HIP_TRY(hipFree(d_tmp));
+    lap("free of the staging buffer");
     ctx->idx.n = n;
     ctx->idx.sa = (const SaEnt*)d_ent;
     ctx->idx.pac = (const u64*)d_pac;

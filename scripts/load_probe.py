@@ -30,6 +30,6 @@ prefix = "/dev/shm/loadprobe/ref.fa"
 hostapi.write_index(prefix, g, text, sa, l1, l2, n_contigs=4)
 total = sum(os.path.getsize(prefix + e) for e in (".0123", ".pos_packed", ".suffixarray_uint64_L1_PARAMETERS", ".suffixarray_uint64_L2_PARAMETERS"))
 print("[load probe] %.1f GB of index files" % (total / 1e9), flush=True)
-for thr in ("8", "8", "4", "16", "8"):
+for thr in ("8", "8"):
     subprocess.run([sys.executable, __file__, "--load", prefix], env=dict(os.environ, MEME_LOAD_THREADS=thr, MEME_LOAD_TRACE="1"))
 import shutil; shutil.rmtree("/dev/shm/loadprobe")
