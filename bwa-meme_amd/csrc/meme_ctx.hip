@@ -284,7 +284,12 @@ static int own_alloc(meme_ctx* ctx, void** p, size_t bytes) {
 // One loader for both sources.  `fetch(which, d_dst, bytes)` brings input `which` (0 text bytes, 1 position image,
 // 2 second-layer records, 3 partial-layer records) to the device buffer; the staging kernels then run on ctx->stream.
 typedef std::function<int(int, void*, size_t)> index_fetch_fn;
-static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t l2_bytes, const index_fetch_fn& fetch) {
+// Optional second source interface: input `which` arrives in pieces of whole `unit`-byte records; `consume(d_piece, first, count, st)`
+// is called per piece on the stream that carried it (the piece's device buffer may be reused once that stream has passed it).
+typedef std::function<void(const void*, i64, i64, hipStream_t)> index_piece_fn;
+typedef std::function<int(int, int, const index_piece_fn&)> index_stream_fn;
+static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t l2_bytes, const index_fetch_fn& fetch,
+                            const index_stream_fn& stream = index_stream_fn()) {
     if (n < 64 || l2_bytes < 24 || l2_bytes % 24 || l1_bytes % 24) {
         meme_set_error("index: bad sizes (sa_num must be >= 64, parameter files multiples of 24 B)");
         return MEME_E_ARG;
@@ -310,9 +315,10 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
     if ((rc = own_alloc(ctx, &d_l2, (size_t)n_l2 * 32))) return rc;
     if ((rc = own_alloc(ctx, &d_l1, (size_t)(n_l1 > 0 ? n_l1 : 1) * 32))) return rc;
     // staging buffer: the 5-byte position image (the largest input), reused for the text bytes and the parameter records
-    size_t tmp_bytes = (size_t)meme_index_pos5_bytes(n);
-    if ((size_t)l2_bytes > tmp_bytes) tmp_bytes = (size_t)l2_bytes;
-    if ((size_t)l1_bytes > tmp_bytes) tmp_bytes = (size_t)l1_bytes;
+    // (a streaming source needs it for the text bytes only: the 31 GB position image and the 24-byte records pass through small rings)
+    size_t tmp_bytes = stream ? (size_t)n + 64 : (size_t)meme_index_pos5_bytes(n);
+    if (!stream && (size_t)l2_bytes > tmp_bytes) tmp_bytes = (size_t)l2_bytes;
+    if (!stream && (size_t)l1_bytes > tmp_bytes) tmp_bytes = (size_t)l1_bytes;
     HIP_TRY(hipMalloc(&d_tmp, tmp_bytes));
     lap("device allocations");
     auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(d_tmp); return code; };
@@ -320,17 +326,33 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
     if ((rc = meme_stage_pack_text(ctx, (const uint8_t*)d_tmp, n, d_pac))) return fail(rc);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     lap("text + pack kernel");
-    if ((rc = fetch(1, d_tmp, (size_t)n * 5))) return fail(rc);
-    if (hipMemsetAsync((uint8_t*)d_tmp + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
-    if ((rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent))) return fail(rc);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
-    lap("position image + entry kernel");
-    if ((rc = fetch(2, d_tmp, (size_t)l2_bytes))) return fail(rc);
-    if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l2, d_l2))) return fail(rc);
-    if (n_l1 > 0) {
+    if (stream) {
+        // every piece of the position image becomes entries as soon as it is on the device; the same for the model records
+        if ((rc = stream(1, 5, [&](const void* d_piece, i64 first, i64 count, hipStream_t st) {
+                hipLaunchKernelGGL(k_build_entries, dim3(stage_blocks(count)), dim3(256), 0, st, (const uint8_t*)d_piece, (const u64*)nullptr, count,
+                                   (const u64*)d_pac, (SaEnt*)d_ent + first);
+            }))) return fail(rc);
+        lap("position image -> entries (streamed)");
+        if ((rc = stream(2, 24, [&](const void* d_piece, i64 first, i64 count, hipStream_t st) {
+                hipLaunchKernelGGL(k_rmi32, dim3(stage_blocks(count)), dim3(256), 0, st, (const RmiRec*)d_piece, count, (Rmi32*)d_l2 + first);
+            }))) return fail(rc);
+        if (n_l1 > 0 && (rc = stream(3, 24, [&](const void* d_piece, i64 first, i64 count, hipStream_t st) {
+                hipLaunchKernelGGL(k_rmi32, dim3(stage_blocks(count)), dim3(256), 0, st, (const RmiRec*)d_piece, count, (Rmi32*)d_l1 + first);
+            }))) return fail(rc);
+        if (hipGetLastError() != hipSuccess) return fail(MEME_E_HIP);
+    } else {
+        if ((rc = fetch(1, d_tmp, (size_t)n * 5))) return fail(rc);
+        if (hipMemsetAsync((uint8_t*)d_tmp + (size_t)n * 5, 0, 16, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+        if ((rc = meme_stage_build_entries(ctx, (const uint8_t*)d_tmp, n, d_pac, d_ent))) return fail(rc);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
-        if ((rc = fetch(3, d_tmp, (size_t)l1_bytes))) return fail(rc);
-        if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l1, d_l1))) return fail(rc);
+        lap("position image + entry kernel");
+        if ((rc = fetch(2, d_tmp, (size_t)l2_bytes))) return fail(rc);
+        if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l2, d_l2))) return fail(rc);
+        if (n_l1 > 0) {
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+            if ((rc = fetch(3, d_tmp, (size_t)l1_bytes))) return fail(rc);
+            if ((rc = meme_stage_rmi32(ctx, d_tmp, n_l1, d_l1))) return fail(rc);
+        }
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     lap("model records");
@@ -368,21 +390,27 @@ static long long file_size(const std::string& path) {
 struct LoadBuffers {
     static constexpr size_t PIECE = (size_t)16 << 20;
     int T = 0;
-    std::vector<uint8_t*> buf;            // 2 per reader
+    std::vector<uint8_t*> buf;            // 2 per reader (pinned host)
+    std::vector<uint8_t*> dbuf;           // 2 per reader (device): pieces that a kernel consumes where they land
     int init(int readers) {
         T = readers;
         buf.assign((size_t)2 * T, nullptr);
+        dbuf.assign((size_t)2 * T, nullptr);
         for (auto& b : buf) if (hipHostMalloc((void**)&b, PIECE, hipHostMallocDefault) != hipSuccess) return MEME_E_HIP;
+        for (auto& b : dbuf) if (hipMalloc((void**)&b, PIECE + 64) != hipSuccess) return MEME_E_HIP;
         return MEME_OK;
     }
-    ~LoadBuffers() { for (auto b : buf) if (b) (void)hipHostFree(b); }
+    ~LoadBuffers() { for (auto b : buf) if (b) (void)hipHostFree(b); for (auto b : dbuf) if (b) (void)hipFree(b); }
 };
 
-static int file_to_device(meme_ctx* ctx, LoadBuffers& LB, const std::string& path, void* d_dst, size_t bytes) {
+// d_dst != nullptr: the file's bytes to d_dst.  consume != nullptr: pieces of whole `unit`-byte records to the reader's device ring
+// slot, each handed to consume(d_piece, first_record, records, stream) on the reader's stream.
+static int file_to_device(meme_ctx* ctx, LoadBuffers& LB, const std::string& path, void* d_dst, size_t bytes, int unit = 1,
+                          const index_piece_fn* consume = nullptr) {
     if (bytes == 0) return MEME_OK;
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) { meme_set_error("cannot open %s", path.c_str()); return MEME_E_IO; }
-    const size_t piece = LoadBuffers::PIECE;
+    const size_t piece = LoadBuffers::PIECE / (size_t)unit * (size_t)unit;
     const size_t n_pieces = (bytes + piece - 1) / piece;
     const int T = (int)(n_pieces < (size_t)LB.T ? n_pieces : (size_t)LB.T);
     std::atomic<int> err{MEME_OK};
@@ -404,8 +432,14 @@ static int file_to_device(meme_ctx* ctx, LoadBuffers& LB, const std::string& pat
                 got += (size_t)r;
             }
             if (got != len) { err = MEME_E_IO; break; }
-            ok = hipMemcpyAsync((uint8_t*)d_dst + off, buf[turn], len, hipMemcpyHostToDevice, st) == hipSuccess &&
-                 hipEventRecord(ev[turn], st) == hipSuccess;
+            if (consume) {
+                uint8_t* slot = LB.dbuf[(size_t)2 * t + turn];
+                ok = hipMemcpyAsync(slot, buf[turn], len, hipMemcpyHostToDevice, st) == hipSuccess;
+                if (ok) (*consume)(slot, (i64)(off / (size_t)unit), (i64)(len / (size_t)unit), st);
+                ok = ok && hipEventRecord(ev[turn], st) == hipSuccess;      // (after the kernel: it covers the device slot too)
+            } else
+                ok = hipMemcpyAsync((uint8_t*)d_dst + off, buf[turn], len, hipMemcpyHostToDevice, st) == hipSuccess &&
+                     hipEventRecord(ev[turn], st) == hipSuccess;
         }
         if (st && hipStreamSynchronize(st) != hipSuccess) ok = false;
         for (int b = 0; b < 2; ++b) if (ev[b]) (void)hipEventDestroy(ev[b]);
@@ -445,6 +479,15 @@ extern "C" int meme_index_load_files(meme_ctx* ctx, const char* prefix) {
         if (trace) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             fprintf(stderr, "[meme] %s: %.2f GB to the device in %.2f s (%.1f GB/s)\n", name[which].c_str(), bytes / 1e9, dt, bytes / 1e9 / dt);
+        }
+        return rc;
+    }, [&](int which, int unit, const index_piece_fn& consume) {
+        if (size[which] % unit) { meme_set_error("%s is not a whole number of %d-byte records", name[which].c_str(), unit); return (int)MEME_E_IO; }
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = file_to_device(ctx, LB, name[which], nullptr, (size_t)size[which], unit, &consume);
+        if (trace) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "[meme] %s: %.2f GB through the device rings in %.2f s (%.1f GB/s)\n", name[which].c_str(), size[which] / 1e9, dt, size[which] / 1e9 / dt);
         }
         return rc;
     });
