@@ -285,6 +285,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MEME_BENCH_DEVICE"):        # testing the multi-rank path on a box with fewer GPUs than ranks (with MEME_BENCH_BACKEND=gloo)
+        local = int(os.environ["MEME_BENCH_DEVICE"])
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch multi-GPU runs through torch.distributed.run (one rank per GPU)")
@@ -296,7 +298,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # rank 0 builds the index on its host for several minutes while the others wait at the first broadcast
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=90))
+        backend = os.environ.get("MEME_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=90))
+        else:
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=90))
 
     mbp = float(os.environ.get("MEME_BENCH_MBP", "3100"))
     nreads = int(os.environ.get("MEME_BENCH_READS", "10000000"))
