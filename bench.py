@@ -145,6 +145,44 @@ def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
     return O.algorithmic_bytes(ctr, n * READ_LEN) / n, {k: v / n for k, v in ctr.items()}
 
 
+def chain_leg(ctx, reads, l_pac, nsub=2000000, ncheck=3000):
+    """Chaining on the device (mem_chain_Learned + mem_chain_flt): the first `nsub` reads of the benchmark batch
+    are seeded through the pinned-result call and chained where their seeds lie; kernel time by HIP events, parity of `ncheck` reads
+    against the oracle's restatement (pinned on the compiled reference's chains, tests/golden/chain_golden.npz)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py
+    n = min(nsub, reads.shape[0])
+    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    smems, smem_off, hits, hit_off = ctx.seed_batch_host(reads[:n].reshape(-1), off)
+    contigs = [(0, l_pac, 0)]
+    res = ctx.chain_last_batch_host(contigs, hipapi.default_chain_opt(l_pac))
+    res = ctx.chain_last_batch_host(contigs, hipapi.default_chain_opt(l_pac))          # (second call: buffers exist)
+    tm = ctx.timings()
+    copt = oracle_py.default_chain_opt(l_pac)
+    same, checked = True, 0
+    for r in range(min(ncheck, n)):
+        if res["fallback"][r]:
+            continue
+        rc, och, osd, tree, frac = oracle_py.chain_read(smems[smem_off[r]:smem_off[r + 1]], hits[hit_off[r]:hit_off[r + 1]], READ_LEN,
+                                                        np.zeros(1, np.int64), np.zeros(1, np.uint8), copt)
+        if rc == -1:
+            continue
+        d = res["chains"][res["chain_off"][r]:res["chain_off"][r + 1]]
+        sd = res["seeds"][res["seed_off"][r]:res["seed_off"][r + 1]]
+        ok = rc == d.shape[0] and tree == res["tree_size"][r]
+        for k in range(rc if ok else 0):
+            ok = ok and all(int(d[k][f]) == int(och[k][f]) for f in ("pos", "rid", "n_seeds", "w", "kept", "first"))
+            a = sd[int(d[k]["seed_beg"]):int(d[k]["seed_beg"]) + int(d[k]["n_seeds"])]
+            b = osd[int(och[k]["seed_beg"]):int(och[k]["seed_beg"]) + int(och[k]["n_seeds"])]
+            ok = ok and np.array_equal(a["rbeg"], b["rbeg"]) and np.array_equal(a["qbeg"], b["qbeg"]) and np.array_equal(a["len"], b["len"])
+        same = same and ok
+        checked += 1
+    return {"metric": "chain_reads_per_sec", "value": n / (tm.chain_kernel_ms * 1e-3) if same and tm.chain_kernel_ms > 0 else None, "unit": "reads/s",
+            "reads": n, "kernel_ms": tm.chain_kernel_ms, "second_pass_ms": tm.chain_pass2_ms, "chains": int(res["chains"].shape[0]),
+            "chained_seeds": int(res["seeds"].shape[0]), "reads_left_to_host": int(res["n_fallback"]), "matches_oracle": bool(same),
+            "checked_reads": checked}
+
+
 def bsw_leg(ctx, dev, world):
     """Second kernel of the path: banded seed extension on rank 0's GPU, pairs resident in HBM.
     Every pair is distinct (no tiling): lengths, targets and errors differ from pair to pair as in a real batch, so the
@@ -570,6 +608,12 @@ def main():
             except Exception as e:  # a secondary measurement: never lose the headline line over it
                 log("bsw leg failed: %r" % (e,))
                 out["bsw"] = None
+        if single and os.environ.get("MEME_BENCH_CHAIN", "1") != "0":
+            try:
+                out["chain"] = chain_leg(ctx, reads, l_pac)
+            except Exception as e:
+                log("chain leg failed: %r" % (e,))
+                out["chain"] = None
         # ---- e2e: BASELINE.json's second metric, the drop-in next to the unmodified reference (last: it needs the HBM) --------
         if single and os.environ.get("MEME_BENCH_E2E", "1") != "0":
             if not ref_prefix:

@@ -21,6 +21,7 @@ namespace {
 constexpr int CHAIN_CAP = 16, SEED_CAP = 8;
 constexpr int CHAIN_CAP2 = 128, SEED_CAP2 = 32;
 constexpr int SMEM_CAP = 256;      // SMEMs per read (the sorted walk is quadratic in it)
+constexpr int HIT_CAP = 8192;      // hits per read that one lane is asked to walk
 
 struct DChain {                    // 32 bytes
     i64 pos;
@@ -157,6 +158,11 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     int nc = 0;
     if (len >= o.min_seed_len && ns > 0) {                                // (:1138)
         if (ns > SMEM_CAP) H.fallback = 2;                                // the bigger scratch does not help: host
+        // One lane walks a read's hits one after the other: a read with tens of thousands of them (hundreds of repeat SMEMs of 500 hits)
+        // would hold its wavefront -- and with it the kernel -- for milliseconds, where a host core needs a fraction of one.
+        i64 work = 0;
+        for (int i = 0; i < ns && i < SMEM_CAP; ++i) work += sm[i].hitcount < o.max_occ ? sm[i].hitcount : o.max_occ;
+        if (work > HIT_CAP) H.fallback = 2;
         int b = 0, e = 0, l_rep = 0;                                      // frac_rep (:1140-1147)
         // walk the SMEMs in (start, end) order; records with equal (start, end) describe the same substring, hence the same
         // hits, and the second one only meets seeds that are already contained: their relative order cannot matter
@@ -368,6 +374,10 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     A.o = *opt;
     A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
     A.list = nullptr; A.nlist = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 4; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
     // second pass: the reads that did not fit, with the big scratch
     unsigned long long* d_redo_n = (unsigned long long*)((unsigned char*)B[5].p + cnt_bytes - 16);
@@ -385,7 +395,9 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
             if ((rc = meme_buf_reserve(ctx, B[10], (size_t)n_redo * CHAIN_CAP2 * SEED_CAP2 * sizeof(DSeed)))) return rc;
             ChainArgs A2 = A;
             A2.ch = (DChain*)B[9].p; A2.sd = (DSeed*)B[10].p; A2.list = (const i64*)B[8].p; A2.nlist = (i64)n_redo;
+            HIP_TRY(hipEventRecord(ev[1], ctx->stream));
             hipLaunchKernelGGL((k_chain<CHAIN_CAP2, SEED_CAP2>), dim3((unsigned)((n_redo + 63) / 64)), dim3(64), 0, ctx->stream, A2);
+            HIP_TRY(hipEventRecord(ev[2], ctx->stream));
         }
     }
     i64* d_nch = (i64*)B[5].p;
@@ -410,6 +422,7 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
                        (const DChain*)B[9].p, (const DSeed*)B[10].p, (const ReadHdr*)B[2].p, (const i64*)d_choff, (const i64*)d_sdoff, n,
                        (meme_chain*)B[6].p, (meme_chain_seed*)B[7].p);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[3], ctx->stream));
     meme_ctx::HostBuf* Hb = ctx->h_chain;   // 0 chain_off, 1 chains, 2 seed_off, 3 seeds, 4 tree sizes, 5 frac_rep, 6 fallback flags
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(tot[0] + 1) * sizeof(meme_chain))) ||
         (rc = meme_hostbuf_reserve(ctx, Hb[2], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[3], (size_t)(tot[1] + 1) * sizeof(meme_chain_seed))) ||
@@ -423,6 +436,13 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     HIP_TRY(hipMemcpyAsync(Hb[5].p, B[3].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(Hb[6].p, d_fb, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f, ms2 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
+        if (n_redo > 0 && hipEventQuery(ev[2]) == hipSuccess && hipEventElapsedTime(&ms2, ev[1], ev[2]) != hipSuccess) ms2 = 0.f;
+        ctx->tm.chain_kernel_ms = ms;          // (includes the two small host round trips between the passes)
+        ctx->tm.chain_pass2_ms = ms2;
+    }
     out->nreads = n;
     out->chain_off = (const int64_t*)Hb[0].p; out->chains = (const meme_chain*)Hb[1].p;
     out->seed_off = (const int64_t*)Hb[2].p; out->seeds = (const meme_chain_seed*)Hb[3].p;

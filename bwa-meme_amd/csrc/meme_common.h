@@ -73,7 +73,7 @@ struct meme_ctx {
                                        // lanes-per-pair kernel (latency: a lone pair takes ~6 ms on one lane, ~0.3 ms on 64)
     // timings
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    meme_timings tm = {0, 0, 0, 0, 0, 0, 0};
+    meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 void meme_set_error(const char* fmt, ...);

@@ -171,7 +171,7 @@ int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_bases);
  * the filter, in the filter's output order, each with its seeds in chain order (seed score = seed length, as mem_chain_Learned
  * sets it).  tree_size[r] = number of chains before the filter (what the reference sizes chain_ar[r] with); frac_rep[r] as
  * mem_chain_Learned computes it.  fallback[r] != 0: the read does not fit the device scratch (more than 128 chains, a chain of
- * more than 32 seeds, more than 256 SMEMs) or would insert two chains at one position (B-tree order of equal keys): it has no
+ * more than 32 seeds, more than 256 SMEMs or 8 192 hits to walk) or would insert two chains at one position (B-tree order of equal keys): it has no
  * chains here and the caller chains it with the reference's host functions.  Results live in pinned buffers of the ctx until
  * the next call.  meme_contig = the fields of bntann1_t the stage needs (src/bntseq.h). */
 typedef struct { int64_t offset; int32_t len; int32_t is_alt; } meme_contig;
@@ -229,6 +229,8 @@ typedef struct {
     int64_t seed_launches, bsw_launches;
     float seed_pack_ms;        /* read packing kernel */
     int64_t seed_windows;      /* suffix-array windows loaded by the SA-search kernel */
+    float chain_kernel_ms;     /* chaining kernels of the last meme_chain_last_batch_host call (both passes + packing) */
+    float chain_pass2_ms;      /* of which the second pass (reads that needed the bigger scratch) */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
 int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs" */
