@@ -1236,8 +1236,32 @@ int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_
     g_n_matesw += n;
     return rc;
 }
+namespace { std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0}, g_n_sam{0}; }
+// (measurement only, verbose runs) the two other candidates of the SAM phase: CIGAR generation and SAM formatting
+typedef uint32_t* (*gen_cigar2_fn)(const int8_t*, int, int, int, int, int, int64_t, const uint8_t*, int, uint8_t*, int64_t, int64_t, int*, int*, int*);
+extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t* pac, int l_query,
+                                    uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
+    static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
+    if (!verbose()) return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+    const double t0 = now_s();
+    uint32_t* r = next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+    g_t_cigar = g_t_cigar + (now_s() - t0);
+    g_n_cigar += 1;
+    return r;
+}
+typedef void (*aln2sam_fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
+void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
+    static aln2sam_fn next = (aln2sam_fn)dlsym(RTLD_NEXT, "_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
+    if (!verbose()) { next(opt, bns, str, s, n, list, which, m); return; }
+    const double t0 = now_s();
+    next(opt, bns, str, s, n, list, which, m);
+    g_t_sam = g_t_sam + (now_s() - t0);
+    g_n_sam += 1;
+}
 void meme_dropin_report_matesw() {
-    fprintf(stderr, "[meme-dropin] mate-rescue SW (reference kswv, host): %lld pairs, %.3f thread-seconds so far\n", (long long)g_n_matesw, (double)g_t_matesw);
+    fprintf(stderr, "[meme-dropin] SAM phase on the host, thread-seconds so far: mate-rescue SW (kswv) %.3f for %lld pairs; CIGAR generation (bwa_gen_cigar2) %.3f "
+            "for %lld alignments; SAM formatting (mem_aln2sam) %.3f for %lld records\n", (double)g_t_matesw, (long long)g_n_matesw, (double)g_t_cigar,
+            (long long)g_n_cigar, (double)g_t_sam, (long long)g_n_sam);
 }
 
 // ---- FASTQ input (first step): the two mate files parsed by two threads, ahead of the pipeline ---------------------
