@@ -12,9 +12,10 @@ batch); the index is built once by rank 0 and broadcast over RCCL.  One JSON lin
 
 Default workload = BASELINE.json configs[1]: a GRCh38-sized (3.1 Gbp) synthetic genome -- 6.2 G suffixes, 99 GB of
 suffix-array entries in HBM -- and 10 M synthetic 150-bp single-end reads per GPU per step, seeding only.  The index
-is built on the host (about 4-6 minutes on the 256-thread box) and cached in /dev/shm for the next invocation.
+-- suffix array, entries, P-RMI -- is built on the GPU in a few seconds (MEME_BENCH_SA=host: our host builders, minutes,
+cached in /dev/shm for the next invocation).
 
-Besides the headline line's `roofline` and `cpu_baseline` objects, rank 0 at N=1 adds `bsw` (the banded-SW kernel on 2 M
+Besides the headline line's `roofline` and `cpu_baseline` objects, rank 0 at N=1 adds `chain` (chaining of 2 M of the batch's reads on the device), `bsw` (the banded-SW kernel on 2 M
 distinct extension jobs) and `e2e` (BASELINE.json's second metric: paired-end `mem -7` through the reference aligner
 with the HIP backend bound in, next to the unmodified reference on the same host cores, SAM md5 compared).
 
@@ -22,7 +23,7 @@ Workload knobs (environment): MEME_BENCH_MBP (genome size in Mbp, default 3100),
 per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: the reference's rule),
 MEME_BENCH_LANES (lanes per read in the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the
 compiled reference, timed in this run), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables the /dev/shm caches),
-MEME_BENCH_SA (device | host: where the suffix array is built), MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
+MEME_BENCH_SA (device | host: where the suffix array is built), MEME_BENCH_CHAIN / MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
 2,000,000), MEME_BENCH_BUDGET_S (wall budget in seconds after which optional legs are skipped, default 1500).
 """
 import argparse
@@ -374,7 +375,8 @@ def main():
         t0 = time.time()
         fwd = synth.make_genome(l_pac, seed=11)
         cache = None
-        if os.environ.get("MEME_BENCH_CACHE", "1") != "0" and os.path.isdir("/dev/shm"):
+        # (only the host build is worth caching: the device build is faster than reading 62 GB back from /dev/shm)
+        if os.environ.get("MEME_BENCH_CACHE", "1") != "0" and os.path.isdir("/dev/shm") and os.environ.get("MEME_BENCH_SA", "device") != "device":
             cache = "/dev/shm/meme_bench_idx_%d_b%d" % (l_pac, bits)
         if cache and os.path.exists(cache + ".ok"):
             text = np.fromfile(cache + ".text", dtype=np.uint8)
