@@ -436,6 +436,8 @@ def main():
     t0 = time.time()
     if os.environ.get("MEME_BENCH_LANES"):
         ctx.set_tuning("group_lanes", int(os.environ["MEME_BENCH_LANES"]))
+    if os.environ.get("MEME_BENCH_BPC"):
+        ctx.set_tuning("seed_blocks_per_cu", int(os.environ["MEME_BENCH_BPC"]))
     if os.environ.get("MEME_BENCH_SMEM_CAP"):
         ctx.set_tuning("smem_cap", int(os.environ["MEME_BENCH_SMEM_CAP"]))
     L = hipapi.lib()
