@@ -337,7 +337,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead (scratch capacity / equal positions)\n",
                 (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
     if (verbose()) ext_report();
-    if (verbose()) meme_dropin_report_matesw();
+    if (verbose() && getenv("MEME_DROPIN_PROFILE_SAM")) meme_dropin_report_matesw();
 }
 
 namespace {
@@ -1236,13 +1236,17 @@ int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_
     g_n_matesw += n;
     return rc;
 }
-namespace { std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0}, g_n_sam{0}; }
-// (measurement only, verbose runs) the two other candidates of the SAM phase: CIGAR generation and SAM formatting
+namespace {
+std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0}, g_n_sam{0};
+// per-record timing with shared counters costs a 256-thread run a third of its compute time: only on request
+bool profile_sam() { static const bool v = getenv("MEME_DROPIN_PROFILE_SAM") != nullptr; return v; }
+}
+// (measurement only, MEME_DROPIN_PROFILE_SAM=1) the two other candidates of the SAM phase: CIGAR generation and SAM formatting
 typedef uint32_t* (*gen_cigar2_fn)(const int8_t*, int, int, int, int, int, int64_t, const uint8_t*, int, uint8_t*, int64_t, int64_t, int*, int*, int*);
 extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t* pac, int l_query,
                                     uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
     static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
-    if (!verbose()) return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+    if (!profile_sam()) return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
     const double t0 = now_s();
     uint32_t* r = next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
     g_t_cigar = g_t_cigar + (now_s() - t0);
@@ -1252,7 +1256,7 @@ extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, 
 typedef void (*aln2sam_fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
 void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
     static aln2sam_fn next = (aln2sam_fn)dlsym(RTLD_NEXT, "_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
-    if (!verbose()) { next(opt, bns, str, s, n, list, which, m); return; }
+    if (!profile_sam()) { next(opt, bns, str, s, n, list, which, m); return; }
     const double t0 = now_s();
     next(opt, bns, str, s, n, list, which, m);
     g_t_sam = g_t_sam + (now_s() - t0);
