@@ -98,3 +98,40 @@ def test_chain_oracle_equals_reference_golden():
             gs = sd[int(ch[k]["seed_beg"]):int(ch[k]["seed_beg"]) + int(ch[k]["n_seeds"])]
             assert np.array_equal(np.stack([gs["rbeg"], gs["qbeg"], gs["len"]], 1), ws), (r, k)
     assert undefined < 30, undefined
+
+
+def test_chain_oracle_edge_cases():
+    """orc_chain_read on hand-made inputs: no seeds, a read shorter than min_seed_len, two chains forced onto one position
+    (undefined: -1), a seed that bridges two contigs (dropped), merging of collinear seeds, too small an output (-2)."""
+    import numpy as np
+    opt = O.default_chain_opt(10_000)
+    off = np.array([0, 5_000], np.int64)
+    alt = np.zeros(2, np.uint8)
+
+    def smem(start, end, hitbeg, hitcount):
+        a = np.zeros(1, O.MEM_TL_DTYPE)
+        a["start"], a["end"], a["hitbeg"], a["hitcount"] = start, end, hitbeg, hitcount
+        return a
+    none = np.zeros(0, O.MEM_TL_DTYPE)
+    rc, ch, sd, tree, frac = O.chain_read(none, np.zeros(0, np.uint64), 100, off, alt, opt)
+    assert (rc, tree) == (0, 0)
+    rc, ch, sd, tree, frac = O.chain_read(smem(0, 15, 0, 1), np.array([100], np.uint64), 15, off, alt, opt)     # len < min_seed_len
+    assert (rc, tree) == (0, 0)
+    # one seed: one chain of weight = seed length
+    rc, ch, sd, tree, frac = O.chain_read(smem(10, 40, 0, 1), np.array([1000], np.uint64), 100, off, alt, opt)
+    assert rc == 1 and tree == 1 and int(ch[0]["w"]) == 30 and int(ch[0]["pos"]) == 1000 and int(ch[0]["rid"]) == 0 and int(ch[0]["kept"]) == 3
+    # two collinear seeds merge into one chain; a third on the other contig makes a second chain
+    sm = np.concatenate([smem(0, 30, 0, 1), smem(40, 70, 1, 1), smem(72, 100, 2, 1)])
+    rc, ch, sd, tree, frac = O.chain_read(sm, np.array([1000, 1040, 6000], np.uint64), 100, off, alt, opt)
+    assert rc == 2 and tree == 2 and sorted(int(x) for x in ch["n_seeds"]) == [1, 2] and int(ch[0]["w"]) == 60     # heavier chain first
+    # a seed across the contig boundary at 5 000 is dropped (bns_intv2rid < 0)
+    rc, ch, sd, tree, frac = O.chain_read(smem(0, 30, 0, 1), np.array([4990], np.uint64), 100, off, alt, opt)
+    assert (rc, tree) == (0, 0)
+    # the same position twice with query offsets too far apart to merge: the reference's answer depends on its B-tree -> undefined
+    sm = np.concatenate([smem(0, 20, 0, 1), smem(150, 170, 1, 1)])
+    rc, ch, sd, tree, frac = O.chain_read(sm, np.array([2000, 2000], np.uint64), 200, off, alt, opt)
+    assert rc == -1
+    # capacity
+    sm = np.concatenate([smem(0, 30, 0, 1), smem(60, 90, 1, 1)])
+    rc, ch, sd, tree, frac = O.chain_read(sm, np.array([1000, 3000], np.uint64), 100, off, alt, opt, chain_cap=1)
+    assert rc == -2
