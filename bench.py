@@ -239,7 +239,40 @@ def sam_md5(path):
     return h.hexdigest(), nlines
 
 
-def e2e_leg(prefix, genome, npairs, threads):
+class RefCache:
+    """Results of the compiled reference's legs (minutes each: it expands its index on the host every time), kept in /dev/shm so that the
+    N=2,4,8 runs of a scaling sweep on the same box reuse what the N=1 run measured instead of timing the same CPU job again."""
+    def __init__(self, l_pac, bits):
+        root = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        self.path = os.path.join(root, "meme_bench_refcache_%d_b%d.json" % (l_pac, bits))
+
+    def _load(self):
+        try:
+            return json.load(open(self.path))
+        except (OSError, ValueError):
+            return {}
+
+    def get(self, key):
+        return self._load().get(key)
+
+    def put(self, key, val):
+        d = self._load()
+        d[key] = val
+        try:
+            json.dump(d, open(self.path, "w"))
+        except OSError:
+            pass
+
+
+def wait_for_free_gpus(n, timeout=120.0):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if all(torch.cuda.mem_get_info(d)[0] > 0.9 * torch.cuda.mem_get_info(d)[1] for d in range(1, min(n, torch.cuda.device_count()))):
+            return
+        time.sleep(1.0)
+
+
+def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
     """BASELINE.json's end-to-end metric: `mem -7` on paired-end 150-bp reads through the reference aligner with the HIP
     backend bound in (oracle/_ref/bwa-meme_dropin = reference main + reference objects + bwa-meme_amd/binding) and
     through the unmodified reference (oracle/_ref/bwa-meme_mode3, AVX-512) on the same host cores, same index files,
@@ -271,9 +304,16 @@ def e2e_leg(prefix, genome, npairs, threads):
             fqs.append(f)
             del r
         out = {}
+        ckey = "e2e_reference_%d_t%d" % (npairs, threads)
+        cached = refcache.get(ckey) if (refcache is not None and devices > 1) else None
         for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+            if exe == "bwa-meme_mode3" and cached:
+                out[exe] = dict(cached, cached="timed by the N=1 run on this box")
+                continue
             sam = os.path.join(d, exe + ".sam")
-            env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1")
+            env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_DEVICES=str(devices))
+            if torch.cuda.device_count() < devices:      # fewer GPUs than asked for (the 1-GPU test box): device slots share the GPUs
+                env["MEME_DROPIN_VIRTUAL"] = str(devices)
             t0 = time.time()
             with open(sam, "wb") as fh:
                 r = subprocess.run([os.path.join(ref_dir, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads),
@@ -303,16 +343,36 @@ def e2e_leg(prefix, genome, npairs, threads):
             for m in re.finditer(r"extension: this chunk .*?totals ([0-9.]+) s, (\d+) backend calls", err):
                 info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # jobs built + calls + fold + purge
             out[exe] = info
+            if exe == "bwa-meme_mode3" and refcache is not None:
+                refcache.put(ckey, info)
             log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
         ref, drop = out["bwa-meme_mode3"], out["bwa-meme_dropin"]
         return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
                 "workload": "mem -7 -t %d, %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the benchmark "
                             "genome (%d bp), wall time incl. index loading" % (threads, npairs, READ_LEN, genome.shape[0]),
-                "threads": threads, "pairs": npairs, "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]),
+                "threads": threads, "pairs": npairs, "gpus_driven_by_the_one_aligner_process": devices, "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]),
                 "dropin": drop, "reference": ref, "speedup_wall": ref["wall_s"] / drop["wall_s"],
                 "speedup_process": (ref["process_s"] / drop["process_s"]) if drop["process_s"] > 0 else None}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: re-executes itself under torch.distributed.run, one rank per GPU over RCCL.
+    On a box with fewer GPUs than ranks (the 1-GPU test box) the ranks share the devices and talk over gloo -- RCCL refuses two
+    ranks on one device; the line then says so (`collective.backend`, `collective.ranks_per_device`)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < a.gpus:
+        env.setdefault("MEME_BENCH_BACKEND", "gloo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup)]
+    log("spawning %d ranks: %s" % (a.gpus, " ".join(cmd[1:])))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -326,11 +386,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("MEME_BENCH_DEVICE"):        # testing the multi-rank path on a box with fewer GPUs than ranks (with MEME_BENCH_BACKEND=gloo)
         local = int(os.environ["MEME_BENCH_DEVICE"])
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))                   # `python bench.py --gpus N` spawns its own ranks (one per GPU)
+    if a.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (a.gpus, world))
+    n_dev = torch.cuda.device_count()
+    ranks_per_device = 1
+    if local >= n_dev:                             # more ranks than GPUs (tests on a 1-GPU box): ranks share devices, gloo instead of RCCL
+        ranks_per_device = (world + n_dev - 1) // n_dev
+        local = local % n_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -357,7 +423,7 @@ def main():
                 log("host RAM too small for the configured genome: falling back to %.0f Mbp" % mbp)
         except ImportError:
             pass
-        gpu_free = torch.cuda.mem_get_info(local)[0]
+        gpu_free = torch.cuda.mem_get_info(local)[0] // ranks_per_device
         while mbp > 64 and 2 * mbp * 1e6 * 33 + nreads * 3800 > 0.9 * gpu_free:     # (3 KB of SMEM slots + packed read + outputs per read)
             mbp /= 2
             log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
@@ -441,6 +507,7 @@ def main():
     if os.environ.get("MEME_BENCH_SMEM_CAP"):
         ctx.set_tuning("smem_cap", int(os.environ["MEME_BENCH_SMEM_CAP"]))
     L = hipapi.lib()
+    bcast_bytes = 0
     if pre is not None:
         d_text, d_pos5, d_l2, d_l1 = pre[:4]
     else:
@@ -463,6 +530,7 @@ def main():
         # no collective in steady state
         for t in (d_text, d_pos5, d_l2, d_l1):
             dist.broadcast(t, 0)
+            bcast_bytes += t.numel() * t.element_size()
     torch.cuda.synchronize()
     if pre is not None:
         keep = (pre[4], pre[5]) + hipapi.attach_index_torch(ctx, n, pre[4], pre[5], d_l2, n_l2, d_l1, n_l1)
@@ -516,6 +584,22 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0])
+    # what every rank processed (whole-job value = all ranks' reads over the slowest rank's time), and what the collective layer saw
+    per_rank = [nreads * a.steps]
+    collective = {"backend": None, "ranks_seen": 1, "ranks_per_device": 1, "index_broadcast_bytes": 0}
+    if world > 1:
+        cnt = torch.tensor([nreads * a.steps], dtype=torch.int64, device=dev)
+        got = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(got, cnt)
+        per_rank = [int(g[0]) for g in got]
+        collective = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                      "ranks_per_device": ranks_per_device, "index_broadcast_bytes": int(bcast_bytes)}
+        dist.barrier()
+        dist.destroy_process_group()                 # no collective in steady state, none after the timed region either
+        if rank != 0:                                # rank 0 goes on alone with the reported extras (baseline, legs)
+            del keep, d_reads, d_off
+            ctx.close()
+            sys.exit(0)
 
     if rank == 0:
         k_ms = float(np.mean([k for k, _ in kernel_ms]))
@@ -538,7 +622,7 @@ def main():
             log("PARITY MISMATCH on the %d-read sample: the GPU seed dump differs from the oracle's" % ns)
         achieved = bpr * nreads / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "seeding_reads_per_sec", "value": (world * nreads * a.steps / dt) if sample_parity else None,
+            "metric": "seeding_reads_per_sec", "value": (sum(per_rank) / dt) if sample_parity else None,
             "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
@@ -548,6 +632,7 @@ def main():
                                    % (READ_LEN, l_pac / 1e6, n),
                        "genome_bp": l_pac, "sa_entries": n, "reads_per_gpu_per_step": nreads, "read_len": READ_LEN,
                        "rmi_leaves_log2": int(np.log2(n_l2)), "sharding": "reads/%d ranks, index replicated by RCCL broadcast" % world,
+                       "reads_per_rank": per_rank, "collective": collective,
                        "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
                        "searches_per_read": res.searches / nreads,
                        "windows_per_search": windows / max(res.searches, 1),
@@ -578,8 +663,9 @@ def main():
             except Exception as e:  # never lose the headline line over an annotation
                 log("pmc annotation skipped: %r" % (e,))
         budget = float(os.environ.get("MEME_BENCH_BUDGET_S", "1500"))
-        single = world == 1
+        single = True        # (rank 0 is alone from here on at every N: the other ranks have left after the timed region)
         cores = min(256, os.cpu_count() or 1)
+        refcache = RefCache(l_pac, bits)
         # ---- the reference's own file formats on disk, for the two legs that run compiled reference binaries ----------
         ref_prefix = None
         want_ref = single and (os.environ.get("MEME_BENCH_CPU", "reference") == "reference" or
@@ -595,9 +681,13 @@ def main():
         cpu_mode = os.environ.get("MEME_BENCH_CPU", "reference")
         if single and cpu_mode != "0":
             nsamp = min(nreads, int(os.environ.get("MEME_BENCH_CPU_READS", "2000000")))
-            if cpu_mode == "reference" and ref_prefix and time.time() - T_START < budget - 400:
+            cpu = refcache.get("cpu_baseline_%d" % nsamp) if world > 1 else None      # N>1 lines reuse the N=1 run's figure of this box
+            if cpu is not None:
+                cpu["sample"] += " (timed by the N=1 run on this box, cached in /dev/shm)"
+            elif cpu_mode == "reference" and ref_prefix and time.time() - T_START < budget - 400:
                 try:
                     cpu = cpu_baseline_reference(ref_prefix, reads[:nsamp], os.cpu_count() or 1)
+                    refcache.put("cpu_baseline_%d" % nsamp, cpu)
                 except Exception as e:  # the baseline is a reported extra, never the measured value
                     log("cpu_baseline (reference) failed: %r -- falling back to the port" % (e,))
             port = cpu_baseline_port(text, sa, l1, l2, reads[:min(nsamp, 400000)], os.cpu_count() or 1)
@@ -631,16 +721,16 @@ def main():
                     ctx = None
                     del keep, d_reads, d_off
                     torch.cuda.empty_cache()
-                    out["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_E2E_PAIRS", "2000000")), cores)
+                    if world > 1:                    # the other ranks' processes release their GPUs when they exit
+                        wait_for_free_gpus(world)
+                    out["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_E2E_PAIRS", "2000000")), cores, devices=world,
+                                         refcache=refcache)
                 except Exception as e:
                     log("e2e leg failed: %r" % (e,))
                     out["e2e"] = {"failed": repr(e)[:300]}
         print(json.dumps(out), flush=True)
         if not sample_parity:
             rc_exit = 1
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     if ctx is not None:
         ctx.close()
     sys.exit(rc_exit)
