@@ -634,11 +634,106 @@ static int smem_cmp(const void* a_, const void* b_) {      /* (start, end) ascen
     return a->hitbeg < b->hitbeg ? -1 : (a->hitbeg > b->hitbeg);
 }
 
+/* ---- the reference's position-keyed B-tree (klib kbtree.h, instantiated src/bwamem.cpp:43-44 with key = mem_chain_t, compare = position only;
+ * kb_init(chn, KB_DEFAULT_SIZE + 8): t = ((520 - 4 - 8) / (8 + sizeof(mem_chain_t) = 48) + 1) >> 1 = 5, at most 9 keys per node).
+ * Restated on chain ids so that chains with EQUAL positions come out of the traversal -- and are found by the interval query --
+ * exactly where the reference's tree puts them (equal keys go after the first equal key of the leaf the descent reaches;
+ * splits move the median up).  Nodes live in one growing array; child / key slots hold indices. */
+#define OBT_T 5
+#define OBT_MAXK (2 * OBT_T - 1)
+typedef struct { int n, internal; int key[OBT_MAXK]; int ptr[OBT_MAXK + 1]; } obt_node;
+typedef struct { obt_node* nd; int n_nodes, cap, root, n_keys; const ochain* ch; } obt_tree;
+static int obt_new(obt_tree* T) {
+    if (T->n_nodes == T->cap) { T->cap = T->cap ? T->cap * 2 : 16; T->nd = (obt_node*)realloc(T->nd, sizeof(obt_node) * (size_t)T->cap); }
+    memset(&T->nd[T->n_nodes], 0, sizeof(obt_node));
+    return T->n_nodes++;
+}
+/* __kb_getp_aux: first key >= pos; if that key is greater than pos, the one before it; *r = sign of (pos - key found) as the macro leaves it */
+static int obt_getp_aux(const obt_tree* T, const obt_node* x, int64_t pos, int* r) {
+    int begin = 0, end = x->n, tr;
+    if (!r) r = &tr;
+    if (x->n == 0) return -1;
+    while (begin < end) {
+        const int mid = (begin + end) >> 1;
+        if (T->ch[x->key[mid]].pos < pos) begin = mid + 1; else end = mid;
+    }
+    if (begin == x->n) { *r = 1; return x->n - 1; }
+    *r = (T->ch[x->key[begin]].pos < pos) - (pos < T->ch[x->key[begin]].pos);
+    if (*r < 0) --begin;
+    return begin;
+}
+/* kb_intervalp, lower bound only: the chain id test_and_merge is tried on, or -1 */
+static int obt_lower(const obt_tree* T, int64_t pos) {
+    int x = T->root, lower = -1;
+    while (x >= 0) {
+        const obt_node* nd = &T->nd[x];
+        int r = 0;
+        const int i = obt_getp_aux(T, nd, pos, &r);
+        if (i >= 0 && r == 0) return nd->key[i];
+        if (i >= 0) lower = nd->key[i];
+        if (!nd->internal) return lower;
+        x = nd->ptr[i + 1];
+    }
+    return lower;
+}
+static void obt_split(obt_tree* T, int xi, int i, int yi) {                  /* __kb_split: child yi of xi (at slot i) is full */
+    const int zi = obt_new(T);
+    obt_node *x = &T->nd[xi], *y = &T->nd[yi], *z = &T->nd[zi];
+    z->internal = y->internal;
+    z->n = OBT_T - 1;
+    memcpy(z->key, y->key + OBT_T, sizeof(int) * (OBT_T - 1));
+    if (y->internal) memcpy(z->ptr, y->ptr + OBT_T, sizeof(int) * OBT_T);
+    y->n = OBT_T - 1;
+    memmove(x->ptr + i + 2, x->ptr + i + 1, sizeof(int) * (size_t)(x->n - i));
+    x->ptr[i + 1] = zi;
+    memmove(x->key + i + 1, x->key + i, sizeof(int) * (size_t)(x->n - i));
+    x->key[i] = y->key[OBT_T - 1];
+    ++x->n;
+}
+static void obt_put(obt_tree* T, int id) {                                    /* kb_putp */
+    const int64_t pos = T->ch[id].pos;
+    int x;
+    ++T->n_keys;
+    if (T->nd[T->root].n == OBT_MAXK) {
+        const int s = obt_new(T), r = T->root;
+        T->nd[s].internal = 1; T->nd[s].n = 0; T->nd[s].ptr[0] = r;
+        T->root = s;
+        obt_split(T, s, 0, r);
+    }
+    x = T->root;
+    for (;;) {                                                                /* __kb_putp_aux, iteratively */
+        obt_node* nd = &T->nd[x];
+        int i = obt_getp_aux(T, nd, pos, NULL);
+        if (!nd->internal) {
+            if (i != nd->n - 1) memmove(nd->key + i + 2, nd->key + i + 1, sizeof(int) * (size_t)(nd->n - i - 1));
+            nd->key[i + 1] = id;
+            ++nd->n;
+            return;
+        }
+        ++i;
+        if (T->nd[nd->ptr[i]].n == OBT_MAXK) {
+            obt_split(T, x, i, nd->ptr[i]);
+            nd = &T->nd[x];                                                   /* (the node array may have moved) */
+            if (pos > T->ch[nd->key[i]].pos) ++i;
+        }
+        x = nd->ptr[i];
+    }
+}
+static void obt_traverse(const obt_tree* T, int x, int* out, int* n) {       /* __kb_traverse: in order */
+    const obt_node* nd = &T->nd[x];
+    int i;
+    for (i = 0; i <= nd->n; ++i) {
+        if (nd->internal) obt_traverse(T, nd->ptr[i], out, n);
+        if (i < nd->n) out[(*n)++] = nd->key[i];
+    }
+}
+
 int orc_chain_read(const orc_mem_tl* smems_in, int n_smems, const uint64_t* hits, int len, const int64_t* contig_off,
                    const uint8_t* contig_alt, int n_contigs, const orc_chain_opt* o, orc_chain* out, int chain_cap,
                    orc_cseed* seeds_out, int seed_cap, int* tree_size, float* frac_rep) {
     ochain* ch = NULL;
     orc_mem_tl* sm = NULL;
+    obt_tree T;
     int nc = 0, cap = 0, i, k, n, rc = 0, b = 0, e = 0, l_rep = 0;
     *tree_size = 0; *frac_rep = 0.f;
     if (len < o->min_seed_len) return 0;
@@ -651,16 +746,19 @@ int orc_chain_read(const orc_mem_tl* smems_in, int n_smems, const uint64_t* hits
         else e = e > sm[i].end ? e : sm[i].end;
     }
     l_rep += e - b;
+    memset(&T, 0, sizeof(T));
+    T.root = obt_new(&T);                                     /* kb_init: an empty leaf */
     for (i = 0; i < n_smems && rc == 0; ++i) {                /* :1149-1193 */
         const orc_mem_tl* p = &sm[i];
         const int step = p->hitcount > o->max_occ ? p->hitcount / o->max_occ : 1;
         int64_t kk; int count;
         for (kk = 0, count = 0; kk < p->hitcount && count < o->max_occ; kk += step, ++count) {
-            orc_cseed s; int rid, lower = -1, merged = 0, j;
+            orc_cseed s; int rid, lower = -1, merged = 0;
             s.rbeg = (int64_t)hits[p->hitbeg + kk]; s.qbeg = p->start; s.len = p->end - p->start;
             rid = o_intv2rid(contig_off, n_contigs, o->l_pac, s.rbeg, s.rbeg + s.len);
             if (rid < 0) continue;
-            for (j = 0; j < nc; ++j) { if (ch[j].pos <= s.rbeg) lower = j; else break; }
+            T.ch = ch;
+            if (T.n_keys) lower = obt_lower(&T, s.rbeg);      /* kb_intervalp (:1167-1169) */
             if (lower >= 0) {                                 /* test_and_merge */
                 ochain* c = &ch[lower];
                 const orc_cseed* last = &c->seeds[c->n - 1];
@@ -680,19 +778,30 @@ int orc_chain_read(const orc_mem_tl* smems_in, int n_smems, const uint64_t* hits
             }
             if (!merged) {
                 ochain c;
-                if (lower >= 0 && ch[lower].pos == s.rbeg) { rc = -1; break; }     /* equal B-tree keys: undefined here */
                 if (nc == cap) { cap = cap ? cap * 2 : 8; ch = (ochain*)realloc(ch, sizeof(ochain) * (size_t)cap); }
-                memmove(&ch[lower + 2], &ch[lower + 1], sizeof(ochain) * (size_t)(nc - lower - 1));
                 c.pos = s.rbeg; c.rid = rid; c.n = 1; c.m = 4; c.w = 0; c.first = -1; c.kept = 0; c.is_alt = contig_alt[rid] ? 1 : 0;
                 c.seeds = (orc_cseed*)malloc(sizeof(orc_cseed) * 4);
                 c.seeds[0] = s;
-                ch[lower + 1] = c;
+                ch[nc] = c;                                   /* chains are stored in creation order; the tree orders their ids */
+                T.ch = ch;
+                obt_put(&T, nc);                              /* kb_putp (:1190) */
                 ++nc;
             }
         }
     }
     *tree_size = nc;
     *frac_rep = (float)l_rep / len;
+    if (nc > 0) {                                             /* __kb_traverse into chain->a (:1194-1198) */
+        int* ord = (int*)malloc(sizeof(int) * (size_t)nc);
+        ochain* sorted = (ochain*)malloc(sizeof(ochain) * (size_t)nc);
+        int m = 0;
+        T.ch = ch;
+        obt_traverse(&T, T.root, ord, &m);
+        for (i = 0; i < nc; ++i) sorted[i] = ch[ord[i]];
+        free(ch); free(ord);
+        ch = sorted;
+    }
+    free(T.nd);
     n = 0;
     if (rc == 0 && nc > 0) {                                  /* mem_chain_flt */
         int* kept_idx = (int*)malloc(sizeof(int) * (size_t)nc);

@@ -96,8 +96,8 @@ typedef struct {
 typedef struct { int64_t pos; int32_t rid, n_seeds, w, first, kept, is_alt; int32_t seed_beg; } orc_chain;
 typedef struct { int64_t rbeg; int32_t qbeg, len; } orc_cseed;
 /* Chains of one read from its SMEMs (any order) and hits: the chains that survive the filter, in the filter's output order, into
- * out[chain_cap] / seeds_out[seed_cap].  Returns their number; -1 when the read inserts two chains at one position (the reference
- * then depends on its B-tree's order of equal keys: undefined here); -2 when a capacity is too small.  *tree_size = chains before
+ * out[chain_cap] / seeds_out[seed_cap].  Returns their number (chains at equal positions are ordered as the reference's
+ * B-tree, src/kbtree.h, orders them: the tree is restated); -2 when a capacity is too small.  *tree_size = chains before
  * the filter, *frac_rep as mem_chain_Learned computes it. */
 int orc_chain_read(const orc_mem_tl* smems, int n_smems, const uint64_t* hits, int len, const int64_t* contig_off,
                    const uint8_t* contig_alt, int n_contigs, const orc_chain_opt* o, orc_chain* out, int chain_cap,

@@ -1,0 +1,104 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): a C shim of OURS over the *reference's* own functions of the stages between the two
+// kernels, so that the test-suite and the fixture generators can call them through ctypes on arbitrary inputs:
+//
+//   ref_chain_read      mem_chain_Learned() + mem_chain_flt()              reference src/bwamem.cpp:1122-1204, 599-717
+//                       (klib B-tree src/kbtree.h, ks_introsort src/ksort.h included -- whatever they do with equal keys)
+//   ref_extend_reads    mem_chain2aln_across_reads_V2()                    reference src/bwamem.cpp:2573-3497
+//                       with the reference's own BandedPairWiseSW kernels
+//   ref_gen_cigar       bwa_gen_cigar2()                                   reference src/bwa.cpp:274-362 (ksw_global2, src/ksw.cpp:560-670)
+//
+// Linked against oracle/_ref/libbwa_pic.so (the reference's objects, built where the sources lie by oracle/Makefile.ref) into
+// oracle/_ref/libstage_ref.so.  Contains no reference code: structures are filled through the reference's headers.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bwamem.h"      // reference headers, found via -I$(REF)/src at build time
+#include "bwa.h"
+#include "LearnedIndex_seeding.h"
+#include "ksort.h"
+
+// globals the reference objects expect from the rest of the binary (src/main.cpp)
+uint64_t proc_freq = 1, tprof[LIM_R][LIM_C];
+
+void mem_chain_Learned(const mem_opt_t* opt, const bntseq_t* bns, int len, mem_tlv* smems, mem_chain_v* chain, int seqid, u64v* hits,
+                       mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid);
+int mem_chain_flt(const mem_opt_t* opt, int n_chn_, mem_chain_t* a_, int tid);
+
+#define shim_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
+KSORT_INIT(shim_smem, mem_tl, shim_smem_lt)
+
+namespace {
+
+struct Bns {
+    bntseq_t b;
+    bntann1_t* anns;
+    Bns(const int64_t* off, const int32_t* len, const uint8_t* alt, int n, int64_t l_pac) {
+        memset(&b, 0, sizeof(b));
+        anns = (bntann1_t*)calloc((size_t)n, sizeof(bntann1_t));
+        for (int i = 0; i < n; ++i) { anns[i].offset = off[i]; anns[i].len = len[i]; anns[i].is_alt = alt ? alt[i] : 0; anns[i].name = (char*)"c"; anns[i].anno = (char*)""; }
+        b.l_pac = l_pac; b.n_seqs = n; b.anns = anns;
+    }
+    ~Bns() { free(anns); }
+};
+
+}  // namespace
+
+extern "C" {
+
+struct shim_chain_opt {   // = orc_chain_opt / meme_chain_opt
+    int32_t w, max_chain_gap, max_occ, min_seed_len, min_chain_weight, max_chain_extend;
+    float mask_level, drop_ratio;
+    int64_t l_pac;
+};
+struct shim_chain { int64_t pos; int32_t rid, n_seeds, w, first, kept, is_alt; int32_t seed_beg; };
+struct shim_cseed { int64_t rbeg; int32_t qbeg, len; };
+
+static void fill_opt(mem_opt_t* opt, const shim_chain_opt* o) {
+    opt->w = o->w; opt->max_chain_gap = o->max_chain_gap; opt->max_occ = o->max_occ; opt->min_seed_len = o->min_seed_len;
+    opt->min_chain_weight = o->min_chain_weight; opt->max_chain_extend = o->max_chain_extend; opt->mask_level = o->mask_level;
+    opt->drop_ratio = o->drop_ratio;
+}
+
+// One read: SMEMs in any order (sorted here the way mem_kernel1_core_Learned sorts them, src/bwamem.cpp:1397) + hits -> the chains that
+// survive the filter.  Returns their number or -2 when a capacity is too small; *tree_size = chains before the filter.
+int ref_chain_read(const mem_tl* smems_in, int n_smems, const uint64_t* hits_in, int64_t n_hits, int len, const int64_t* contig_off,
+                   const int32_t* contig_len, const uint8_t* contig_alt, int n_contigs, const shim_chain_opt* o, shim_chain* out, int chain_cap,
+                   shim_cseed* seeds_out, int seed_cap, int* tree_size, uint32_t* frac_rep_bits) {
+    mem_opt_t* opt = mem_opt_init();
+    fill_opt(opt, o);
+    Bns bns(contig_off, contig_len, contig_alt, n_contigs, o->l_pac);
+    mem_tlv smems; u64v hits;
+    kv_init(smems); kv_init(hits);
+    kv_resize(mem_tl, smems, (size_t)(n_smems + 1));
+    kv_resize(uint64_t, hits, (size_t)(n_hits + 1));
+    memcpy(smems.a, smems_in, sizeof(mem_tl) * (size_t)n_smems); smems.n = (size_t)n_smems;
+    memcpy(hits.a, hits_in, sizeof(uint64_t) * (size_t)n_hits); hits.n = (size_t)n_hits;
+    ks_introsort(shim_smem, smems.n, smems.a);
+    mem_chain_v chn;
+    kv_init(chn);
+    const int64_t slab = 1 << 16;
+    mem_seed_t* seedBuf = (mem_seed_t*)calloc((size_t)slab, sizeof(mem_seed_t));
+    int64_t seedBufCount = 0;
+    mem_chain_Learned(opt, &bns.b, len, &smems, &chn, 0, &hits, seedBuf, slab, seedBufCount, 0);
+    *tree_size = (int)chn.m;
+    *frac_rep_bits = 0;
+    if (chn.n) memcpy(frac_rep_bits, &chn.a[0].frac_rep, 4);
+    const size_t n_before = chn.n;
+    int n = chn.n ? mem_chain_flt(opt, (int)chn.n, chn.a, 0) : 0;      // (frees the seeds of the chains it drops)
+    int rc = n, ns = 0;
+    for (int k = 0; k < n && rc >= 0; ++k) {
+        const mem_chain_t& c = chn.a[k];
+        if (k >= chain_cap || ns + c.n > seed_cap) { rc = -2; break; }
+        out[k].pos = c.pos; out[k].rid = c.rid; out[k].n_seeds = c.n; out[k].w = (int32_t)c.w; out[k].first = c.first; out[k].kept = (int32_t)c.kept;
+        out[k].is_alt = (int32_t)c.is_alt; out[k].seed_beg = ns;
+        for (int j = 0; j < c.n; ++j) { seeds_out[ns].rbeg = c.seeds[j].rbeg; seeds_out[ns].qbeg = c.seeds[j].qbeg; seeds_out[ns].len = c.seeds[j].len; ++ns; }
+    }
+    (void)n_before;
+    for (int k = 0; k < n; ++k) if (chn.a[k].m > SEEDS_PER_CHAIN) free(chn.a[k].seeds);
+    free(chn.a); free(seedBuf); free(smems.a); free(hits.a); free(opt);
+    return rc;
+}
+
+}  // extern "C"

@@ -64,3 +64,36 @@ def run_seed_dump(prefix: str, fastq: str, mode: int = 3, steps: int = 4, thread
     out = subprocess.run([exe, prefix, fastq, "1000", str(threads), str(steps)], capture_output=True,
                          timeout=timeout, check=True)
     return out.stdout.decode()
+
+
+# ---- the stages between the two kernels: the reference's own functions behind oracle/ref_stage_shim.cpp -----------------------
+_STAGE = None
+
+
+def stage_lib():
+    global _STAGE
+    if _STAGE is None:
+        _STAGE = C.CDLL(os.path.join(REF_DIR, "libstage_ref.so"))
+    return _STAGE
+
+
+def chain_read(smems, hits, read_len, contig_off, contig_len, contig_alt, opt, chain_cap=8192, seed_cap=1 << 17):
+    """mem_chain_Learned + mem_chain_flt of the compiled reference for one read; same return shape as oracle_py.chain_read."""
+    from oracle_py import MEM_TL_DTYPE, ORC_CHAIN_DTYPE, ORC_CSEED_DTYPE
+    L = stage_lib()
+    L.ref_chain_read.restype = C.c_int
+    smems = np.ascontiguousarray(smems, dtype=MEM_TL_DTYPE)
+    hits = np.ascontiguousarray(hits, dtype=np.uint64)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+    contig_alt = np.ascontiguousarray(contig_alt, dtype=np.uint8)
+    out = np.zeros(chain_cap, ORC_CHAIN_DTYPE)
+    sd = np.zeros(seed_cap, ORC_CSEED_DTYPE)
+    tree, frac = C.c_int(0), C.c_uint32(0)
+    rc = L.ref_chain_read(C.c_void_p(smems.ctypes.data), C.c_int(smems.shape[0]), C.c_void_p(hits.ctypes.data), C.c_int64(hits.shape[0]),
+                          C.c_int(int(read_len)), C.c_void_p(contig_off.ctypes.data), C.c_void_p(contig_len.ctypes.data),
+                          C.c_void_p(contig_alt.ctypes.data), C.c_int(contig_off.shape[0]), C.byref(opt), C.c_void_p(out.ctypes.data),
+                          C.c_int(chain_cap), C.c_void_p(sd.ctypes.data), C.c_int(seed_cap), C.byref(tree), C.byref(frac))
+    n = max(rc, 0)
+    ns = int(out["n_seeds"][:n].sum())
+    return rc, out[:n], sd[:ns], tree.value, np.uint32(frac.value).view(np.float32)
