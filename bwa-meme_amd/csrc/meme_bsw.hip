@@ -625,6 +625,11 @@ int finish_bsw(meme_ctx* ctx) {
 
 }  // namespace
 
+int meme_bsw_launch(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w, const meme_bsw_opt* opt,
+                    int host_maxq) {
+    return launch_bsw(ctx, d_pairs, d_ref, d_qer, npairs, w, opt, host_maxq);
+}
+
 extern "C" int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer,
                                      int32_t npairs, int32_t w, const meme_bsw_opt* opt) {
     if (!ctx || !d_pairs || !d_ref || !d_qer || !opt || npairs < 0) return MEME_E_ARG;

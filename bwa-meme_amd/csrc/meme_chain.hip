@@ -7,21 +7,23 @@
 // the same sequence of comparisons and swaps, because chains of equal weight keep whatever order that algorithm leaves them in
 // and the filter that follows depends on it.
 //
-// Reads that fit neither scratch size (more than 128 chains, a chain of more than 32 seeds, more than SMEM_CAP SMEMs) and reads
-// that would insert two chains at the same position (the B-tree's order of equal keys is an implementation detail) are flagged:
-// the caller chains those on the host with the reference's own functions.
-#include <hipcub/hipcub.hpp>
+// Two tiers, no host fallback.  Tier 1: one lane per read with a small fixed scratch (16 chains of 8 seeds) -- 97 % of the reads.
+// Tier 2 (k_chain_wave): one WAVEFRONT per read for everything else -- reads with many chains / long chains / hundreds of hits to walk
+// (repeats), and reads that put two chains on one position.  Its state is sized by the read's own work (hits to walk), the chains
+// live in a faithful restatement of the reference's B-tree (klib kbtree.h, t = 5) so that chains with EQUAL positions are found and
+// ordered exactly as the reference finds and orders them, and the 64 lanes test 64 hits of an SMEM against the tree at once; the
+// results are then committed in hit order, a hit whose neighbourhood an earlier hit of the same batch has changed being re-tested.
+#include <string.h>
+#include <algorithm>
 
 #include "meme_common.h"
 
 namespace {
 
-// Two passes with different scratch sizes: every read with room for 16 chains of 8 seeds (2.5 KB per read); the few per cent
-// that need more (repeats) again, alone, with room for 128 chains of 32 seeds (68 KB per read).
+// Tier 1: every read with room for 16 chains of 8 seeds (2.5 KB per read), as long as one lane can walk it quickly.
 constexpr int CHAIN_CAP = 16, SEED_CAP = 8;
-constexpr int CHAIN_CAP2 = 128, SEED_CAP2 = 32;
-constexpr int SMEM_CAP = 256;      // SMEMs per read (the sorted walk is quadratic in it)
-constexpr int HIT_CAP = 8192;      // hits per read that one lane is asked to walk
+constexpr int SMEM_CAP1 = 48;      // SMEMs per read in tier 1 (its sorted walk is quadratic in it)
+constexpr int HIT_CAP1 = 256;      // hits per read that one lane is asked to walk (dependent loads: ~1 us each)
 
 struct DChain {                    // 32 bytes
     i64 pos;
@@ -30,7 +32,7 @@ struct DChain {                    // 32 bytes
     int row;                       // which seed row of the read's scratch holds its seeds
 };
 struct DSeed { i64 rbeg; int qbeg, len; };
-struct ReadHdr { int tree_size, n_kept, n_seeds, fallback; i64 slot; };   // fallback: 0 done, 1 needs the bigger scratch / the host; slot: scratch index, bit 62 = second pass
+struct ReadHdr { int tree_size, n_kept, n_seeds, fallback; i64 slot; i64 work; };   // fallback: 0 done, 1 = for tier 2; slot: scratch index, bit 62 = tier 2; work: hits to walk
 
 struct ChainArgs {
     const meme_mem_tl* smems; const i64* smem_off; const u64* hits; const i64* hit_off; const i64* read_off;
@@ -38,7 +40,6 @@ struct ChainArgs {
     const i64* contig_off; const int* contig_len; const unsigned char* contig_alt; int n_contigs;
     meme_chain_opt o;
     DChain* ch; DSeed* sd; ReadHdr* hdr; float* frac_rep;
-    const i64* list; i64 nlist;        // second pass: the reads to redo (nullptr: all reads)
 };
 
 __device__ inline int pos2rid(const ChainArgs& A, i64 pos_f) {            // bns_pos2rid, src/bntseq.cpp:392-406
@@ -144,8 +145,8 @@ __device__ void sort_by_weight(DChain* a, int n) {
 template <int CC, int SC>
 __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (A.list ? A.nlist : A.nreads)) return;
-    const i64 r = A.list ? A.list[tid] : tid;
+    if (tid >= A.nreads) return;
+    const i64 r = tid;
     const meme_chain_opt& o = A.o;
     const meme_mem_tl* sm = A.smems + A.smem_off[r];
     const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
@@ -153,16 +154,16 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
     DChain* ch = A.ch + tid * CC;
     DSeed* sd = A.sd + tid * (CC * SC);
-    ReadHdr H = {0, 0, 0, 0, tid | (A.list ? (i64)1 << 62 : 0)};
+    ReadHdr H = {0, 0, 0, 0, tid, 0};
     float frac = 0.f;
     int nc = 0;
     if (len >= o.min_seed_len && ns > 0) {                                // (:1138)
-        if (ns > SMEM_CAP) H.fallback = 2;                                // the bigger scratch does not help: host
-        // One lane walks a read's hits one after the other: a read with tens of thousands of them (hundreds of repeat SMEMs of 500 hits)
-        // would hold its wavefront -- and with it the kernel -- for milliseconds, where a host core needs a fraction of one.
+        // One lane walks a read's hits one after the other through dependent loads: a read with hundreds of them (repeats) would hold
+        // its wavefront -- and with it the kernel -- for milliseconds.  Those go to the wavefront-per-read tier at once.
         i64 work = 0;
-        for (int i = 0; i < ns && i < SMEM_CAP; ++i) work += sm[i].hitcount < o.max_occ ? sm[i].hitcount : o.max_occ;
-        if (work > HIT_CAP) H.fallback = 2;
+        for (int i = 0; i < ns; ++i) work += sm[i].hitcount < o.max_occ ? sm[i].hitcount : o.max_occ;
+        H.work = work;
+        if (ns > SMEM_CAP1 || work > HIT_CAP1) H.fallback = 1;
         int b = 0, e = 0, l_rep = 0;                                      // frac_rep (:1140-1147)
         // walk the SMEMs in (start, end) order; records with equal (start, end) describe the same substring, hence the same
         // hits, and the second one only meets seeds that are already contained: their relative order cannot matter
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
                     }
                 }
                 if (!merged) {                                            // a new chain (:1172-1191)
-                    if (lower >= 0 && ch[lower].pos == s.rbeg) { H.fallback = 2; break; }   // equal B-tree keys: the host decides
+                    if (lower >= 0 && ch[lower].pos == s.rbeg) { H.fallback = 1; break; }   // equal B-tree keys: the tier with the B-tree decides
                     if (nc == CC) { H.fallback = 1; break; }
                     for (int i = nc; i > lower + 1; --i) ch[i] = ch[i - 1];
                     DChain c;
@@ -290,44 +291,479 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     A.frac_rep[r] = frac;
 }
 
-// the kept chains and their seeds, densely packed in read order (the scratch of the pass that finished the read)
-__global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch1, const DSeed* __restrict__ sd1, const DChain* __restrict__ ch2,
-                                                     const DSeed* __restrict__ sd2, const ReadHdr* __restrict__ hdr,
-                                                     const i64* __restrict__ chain_off, const i64* __restrict__ seed_off, i64 nreads,
-                                                     meme_chain* __restrict__ out_ch, meme_chain_seed* __restrict__ out_sd) {
+// ---- tier 2: one wavefront per read ---------------------------------------------------------------------------------------------
+// klib's B-tree as the reference instantiates it (src/bwamem.cpp:43-44, kb_init(chn, KB_DEFAULT_SIZE + 8), src/kbtree.h:60-77):
+// t = ((520 - 4 - 8) / (8 + sizeof(mem_chain_t) = 48) + 1) >> 1 = 5, at most 9 keys per node.  Keys are chain positions; a node
+// also carries the chain ids.  The first NODE_LDS nodes of a read live in LDS, the rest in its HBM scratch.
+constexpr int T_ORD = 5, T_MAXK = 2 * T_ORD - 1;
+struct TNode { int n, internal; i64 key[T_MAXK]; int cid[T_MAXK]; int ptr[T_MAXK + 1]; int pad; };
+static_assert(sizeof(TNode) == 160, "TNode layout");
+// Two builds of the kernel: reads with up to WAVE_LIGHT hits to walk (most of the tier) keep 64 nodes (>= 256 chains) and 512 sort
+// slots in LDS (15 KB per wavefront, 10 wavefronts per CU); the few heavy ones get 288 nodes (>= 1 150 chains) and 2 048 sort slots
+// (63 KB) -- a node or sort slot that spills to HBM turns every step of the sequential parts from ~30 ns into ~1 us.
+constexpr int WAVE_LIGHT = 256;
+constexpr int CONTIG_LDS = 256;    // contig offsets kept in LDS for bns_intv2rid (all of them when the reference has that few)
+
+struct C2 {                        // chain record (64 bytes), indexed by creation order
+    i64 pos; int rid, n;
+    i64 f_rbeg; int f_qbeg, f_len; // first seed: what test_and_merge reads besides the last one
+    i64 l_rbeg; int l_qbeg, l_len; // last seed
+    int head, tail;                // the chain's seeds: a list through S2::next
+    int w; short is_alt, pad;
+};
+static_assert(sizeof(C2) == 64, "C2 layout");
+struct S2 { i64 rbeg; int qbeg, len; int next, pad; };
+struct FRec { int beg, end, w, first; int kept, is_alt, id, pad; };   // the filter's view of a chain (query span, weight, marks)
+
+struct WaveArgs {
+    const i64* list; const i64* woff; i64 nlist;     // reads of this tier, exclusive prefix of their work
+    C2* C; S2* S; FRec* F; u64* srt; int* ia; int* ib; TNode* nodes;
+};
+
+struct WTree {
+    TNode* lds; TNode* glb;
+    int root, n_nodes, n_lds;
+    __device__ __forceinline__ TNode* nd(int id) const { return id < n_lds ? lds + id : glb + (id - n_lds); }
+    __device__ int fresh() { const int id = n_nodes++; TNode* x = nd(id); x->n = 0; x->internal = 0; return id; }
+};
+
+// kb_intervalp, lower side (src/kbtree.h:153-176 with __kb_getp_aux :125-140): the chain test_and_merge is tried on
+__device__ int tree_lower(const WTree& T, i64 pos, i64* lpos) {
+    int x = T.root, lower = -1;
+    i64 lp = 0;
+    for (;;) {
+        const TNode* nd = T.nd(x);
+        const int n = nd->n;
+        if (n == 0) break;
+        int b = 0, e = n;
+        while (b < e) { const int m = (b + e) >> 1; if (nd->key[m] < pos) b = m + 1; else e = m; }
+        int i;
+        bool eq = false;
+        if (b == n) i = n - 1;
+        else { eq = nd->key[b] == pos; i = eq ? b : b - 1; }
+        if (i >= 0 && eq) { *lpos = pos; return nd->cid[i]; }
+        if (i >= 0) { lower = nd->cid[i]; lp = nd->key[i]; }
+        if (!nd->internal) break;
+        x = nd->ptr[i + 1];
+    }
+    *lpos = lp;
+    return lower;
+}
+// __kb_getp_aux as kb_putp uses it (result only)
+__device__ __forceinline__ int tree_slot(const TNode* nd, i64 pos) {
+    const int n = nd->n;
+    if (n == 0) return -1;
+    int b = 0, e = n;
+    while (b < e) { const int m = (b + e) >> 1; if (nd->key[m] < pos) b = m + 1; else e = m; }
+    if (b == n) return n - 1;
+    return nd->key[b] == pos ? b : b - 1;
+}
+__device__ void tree_split(WTree& T, int xi, int i, int yi) {                // __kb_split (src/kbtree.h:181-197)
+    const int zi = T.fresh();
+    TNode *x = T.nd(xi), *y = T.nd(yi), *z = T.nd(zi);
+    z->internal = y->internal;
+    z->n = T_ORD - 1;
+    for (int k = 0; k < T_ORD - 1; ++k) { z->key[k] = y->key[T_ORD + k]; z->cid[k] = y->cid[T_ORD + k]; }
+    if (y->internal) for (int k = 0; k < T_ORD; ++k) z->ptr[k] = y->ptr[T_ORD + k];
+    y->n = T_ORD - 1;
+    for (int k = x->n; k > i; --k) x->ptr[k + 1] = x->ptr[k];
+    x->ptr[i + 1] = zi;
+    for (int k = x->n - 1; k >= i; --k) { x->key[k + 1] = x->key[k]; x->cid[k + 1] = x->cid[k]; }
+    x->key[i] = y->key[T_ORD - 1];
+    x->cid[i] = y->cid[T_ORD - 1];
+    ++x->n;
+}
+__device__ void tree_put(WTree& T, int id, i64 pos) {                        // kb_putp + __kb_putp_aux (src/kbtree.h:198-233)
+    if (T.nd(T.root)->n == T_MAXK) {
+        const int r = T.root, s = T.fresh();
+        TNode* sn = T.nd(s);
+        sn->internal = 1; sn->n = 0; sn->ptr[0] = r;
+        T.root = s;
+        tree_split(T, s, 0, r);
+    }
+    int x = T.root;
+    for (;;) {
+        TNode* nd = T.nd(x);
+        int i = tree_slot(nd, pos);
+        if (!nd->internal) {
+            for (int k = nd->n - 1; k > i; --k) { nd->key[k + 1] = nd->key[k]; nd->cid[k + 1] = nd->cid[k]; }
+            nd->key[i + 1] = pos;
+            nd->cid[i + 1] = id;
+            ++nd->n;
+            return;
+        }
+        ++i;
+        if (T.nd(nd->ptr[i])->n == T_MAXK) {
+            tree_split(T, x, i, nd->ptr[i]);
+            if (pos > nd->key[i]) ++i;
+        }
+        x = nd->ptr[i];
+    }
+}
+
+// what a hit does to the chain below it (test_and_merge, src/bwamem.cpp:450-492): 0 nothing (contained), 1 appended, 2 a new chain
+__device__ __forceinline__ int hit_outcome(const C2& c, i64 rbeg, int qbeg, int len, int rid, const meme_chain_opt& o) {
+    if (rid != c.rid) return 2;
+    const i64 qend = c.l_qbeg + c.l_len, rend = c.l_rbeg + c.l_len;
+    if (qbeg >= c.f_qbeg && qbeg + len <= qend && rbeg >= c.f_rbeg && rbeg + len <= rend) return 0;
+    if ((c.l_rbeg < o.l_pac || c.f_rbeg < o.l_pac) && rbeg >= o.l_pac) return 2;
+    const i64 x = qbeg - c.l_qbeg, y = rbeg - c.l_rbeg;
+    if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c.l_len < o.max_chain_gap && y - c.l_len < o.max_chain_gap) return 1;
+    return 2;
+}
+
+// every lane stores through its own view of shared state below ("uniform" code: all 64 lanes execute the same stores with the same
+// values), so a later load by any lane is an ordinary read-after-write of that lane; where ONE lane produces what others read, the
+// wavefront passes this fence
+__device__ __forceinline__ void wave_fence() { __threadfence(); __syncthreads(); }
+
+template <int NODE_LDS, int SRT_LDS>
+__global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 t_first) {
+    __shared__ TNode lds_nodes[NODE_LDS];
+    __shared__ u64 lds_srt[SRT_LDS];
+    __shared__ int stk_x[40], stk_i[20];
+    __shared__ i64 lds_contig[CONTIG_LDS];
+    const i64 t = t_first + blockIdx.x;
+    if (t >= W.nlist) return;
+    const int lane = threadIdx.x;
+    if (A.n_contigs <= CONTIG_LDS) {                 // bns_intv2rid searches the contig offsets twice per hit
+        for (int i = lane; i < A.n_contigs; i += 64) lds_contig[i] = A.contig_off[i];
+        __syncthreads();
+        A.contig_off = lds_contig;
+    }
+    const i64 r = W.list[t];
+    const i64 base = W.woff[t];
+    const meme_chain_opt& o = A.o;
+    const meme_mem_tl* sm = A.smems + A.smem_off[r];
+    const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
+    const u64* ht = A.hits + A.hit_off[r];
+    const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
+    C2* C = W.C + base;
+    S2* S = W.S + base;
+    FRec* F = W.F + base;
+    int* ia = W.ia + base;
+    int* ib = W.ib + base;
+    WTree T;
+    T.lds = lds_nodes;
+    T.glb = W.nodes + (base / 3 + 4 * t);
+    T.n_nodes = 0;
+    T.n_lds = NODE_LDS;
+    T.root = T.fresh();
+    // ---- the SMEMs in (start, end) order (ks_introsort at src/bwamem.cpp:1397; equal keys describe the same substring, hence the
+    //      same hits: their order cannot matter): rank of every SMEM by counting
+    for (int i = lane; i < ns; i += 64) {
+        const int s = sm[i].start, e = sm[i].end;
+        int rank = 0;
+        for (int j = 0; j < ns; ++j) {
+            const int sj = sm[j].start, ej = sm[j].end;
+            rank += (sj < s || (sj == s && (ej < e || (ej == e && j < i)))) ? 1 : 0;
+        }
+        ia[rank] = i;
+    }
+    wave_fence();
+    // ---- mem_chain_Learned (src/bwamem.cpp:1149-1193)
+    int nchain = 0, nseed = 0;
+    bool has_dups = false;
+    int fb = 0, fe = 0, l_rep = 0;
+    for (int si = 0; si < ns; ++si) {
+        const meme_mem_tl p = sm[ia[si]];
+        if (p.hitcount > o.max_occ) {                                     // frac_rep (:1140-1147)
+            if (p.start > fe) { l_rep += fe - fb; fb = p.start; fe = p.end; }
+            else fe = fe > p.end ? fe : p.end;
+        }
+        const int slen = p.end - p.start;
+        const int step = p.hitcount > o.max_occ ? p.hitcount / o.max_occ : 1;
+        int cnt = (p.hitcount + step - 1) / step;
+        if (cnt > o.max_occ) cnt = o.max_occ;
+        for (int cb = 0; cb < cnt; cb += 64) {
+            const int c = cb + lane;
+            bool valid = c < cnt;
+            const i64 rbeg = valid ? (i64)ht[p.hitbeg + (i64)c * step] : 0;
+            const int rid = valid ? intv2rid(A, rbeg, rbeg + slen) : -1;
+            valid = rid >= 0;                                             // bridging two sequences or the strands (:1166)
+            int low = -1, out = 0;
+            i64 lowpos = 0;
+            if (valid) {
+                low = tree_lower(T, rbeg, &lowpos);
+                out = low >= 0 ? hit_outcome(C[low], rbeg, p.start, slen, rid, o) : 2;
+            }
+            // commit in hit order
+            u64 todo = __ballot(valid), stale = 0;
+            for (;;) {
+                const u64 act = __ballot(valid && out != 0);
+                const u64 cand = todo & (act | stale);
+                if (!cand) break;
+                const int j = __builtin_ctzll(cand);
+                todo &= ~(((u64)2 << j) - 1);                             // (j == 63: the shift wraps to 0, the mask is all ones)
+                if ((stale >> j) & 1) {                                   // an earlier hit of this batch touched what j (and others) looked at
+                    if ((stale >> lane) & 1) {
+                        low = tree_lower(T, rbeg, &lowpos);
+                        out = low >= 0 ? hit_outcome(C[low], rbeg, p.start, slen, rid, o) : 2;
+                    }
+                    stale = 0;
+                }
+                const int out_j = __shfl(out, j);
+                if (out_j == 0) continue;
+                const int low_j = __shfl(low, j), rid_j = __shfl(rid, j);
+                const i64 rbeg_j = __shfl(rbeg, j), lowpos_j = __shfl(lowpos, j);
+                const int sid = nseed++;
+                S2 sn;
+                sn.rbeg = rbeg_j; sn.qbeg = p.start; sn.len = slen; sn.next = -1; sn.pad = 0;
+                S[sid] = sn;
+                if (out_j == 1) {                                         // grow the chain (:461-489)
+                    C2* c = &C[low_j];
+                    S[c->tail].next = sid;
+                    c->n += 1; c->l_rbeg = rbeg_j; c->l_qbeg = p.start; c->l_len = slen; c->tail = sid;
+                    stale |= todo & __ballot(valid && low == low_j);
+                } else {                                                  // a new chain (:1172-1191)
+                    const int id = nchain++;
+                    C2 c;
+                    c.pos = rbeg_j; c.rid = rid_j; c.n = 1;
+                    c.f_rbeg = c.l_rbeg = rbeg_j; c.f_qbeg = c.l_qbeg = p.start; c.f_len = c.l_len = slen;
+                    c.head = c.tail = sid; c.w = 0; c.is_alt = A.contig_alt[rid_j] ? 1 : 0; c.pad = 0;
+                    C[id] = c;
+                    if (low_j >= 0 && lowpos_j == rbeg_j) has_dups = true;
+                    tree_put(T, id, rbeg_j);
+                    // whose view is now out of date: hits between the new chain and the chain they found below them; once equal keys
+                    // exist, WHICH of them a descent meets first also depends on the tree's shape, so everybody looks again
+                    if (has_dups) stale |= todo & __ballot(valid);
+                    else stale |= todo & __ballot(valid && rbeg >= rbeg_j && (low < 0 || lowpos <= rbeg_j));
+                }
+            }
+        }
+    }
+    l_rep += fe - fb;
+    // ---- the chains in tree order (__kb_traverse, :1194-1198) into ib[]
+    int m = 0;
+    {
+        int sp = 0;
+        stk_x[0] = T.root; stk_i[0] = 0;
+        while (sp >= 0) {
+            const TNode* nd = T.nd(stk_x[sp]);
+            if (!nd->internal) { for (int i = 0; i < nd->n; ++i) ib[m++] = nd->cid[i]; --sp; continue; }
+            const int i = stk_i[sp] >> 1, ph = stk_i[sp] & 1;
+            if (i > nd->n) { --sp; continue; }
+            if (ph == 0) { stk_i[sp] |= 1; ++sp; stk_x[sp] = nd->ptr[i]; stk_i[sp] = 0; continue; }
+            if (i < nd->n) ib[m++] = nd->cid[i];
+            stk_i[sp] = (i + 1) << 1;
+        }
+    }
+    // ---- mem_chain_flt (src/bwamem.cpp:599-717): weights, one chain per lane
+    for (int c = lane; c < nchain; c += 64) {
+        const int id = ib[c];
+        i64 end = 0;
+        int w = 0;
+        for (int k = C[id].head; k >= 0; k = S[k].next) {
+            const S2 s = S[k];
+            if (s.qbeg >= end) w += s.len;
+            else if (s.qbeg + s.len > end) w += (int)(s.qbeg + s.len - end);
+            end = end > s.qbeg + s.len ? end : s.qbeg + s.len;
+        }
+        const int tmp = w;
+        w = 0; end = 0;
+        for (int k = C[id].head; k >= 0; k = S[k].next) {
+            const S2 s = S[k];
+            if (s.rbeg >= end) w += s.len;
+            else if (s.rbeg + s.len > end) w += (int)(s.rbeg + s.len - end);
+            end = end > s.rbeg + s.len ? end : s.rbeg + s.len;
+        }
+        w = w < tmp ? w : tmp;
+        C[id].w = w < 1 << 30 ? w : (1 << 30) - 1;
+    }
+    wave_fence();
+    // chains of at least min_chain_weight, in tree order, as (weight, id) pairs
+    u64* srt = nchain <= SRT_LDS ? lds_srt : W.srt + base;
+    int n = 0;
+    for (int cb = 0; cb < nchain; cb += 64) {
+        const int c = cb + lane;
+        const int id = c < nchain ? ib[c] : 0;
+        const int w = c < nchain ? C[id].w : 0;
+        const bool keep = c < nchain && w >= o.min_chain_weight;
+        const u64 mk = __ballot(keep);
+        if (keep) srt[n + __popcll(mk & (((u64)1 << lane) - 1))] = (u64)(unsigned)w << 32 | (unsigned)id;
+        n += __popcll(mk);
+    }
+    wave_fence();
+    int n_kept = 0, n_seeds = 0;
+    if (n > 0) {
+        // ks_introsort(mem_flt) by weight, descending: the same comparisons and swaps, so that chains of equal weight end up where klib leaves them
+#define W_LT(a_, b_) (((a_) >> 32) > ((b_) >> 32))
+#define W_SWAP(a_, b_) do { const u64 t_ = (a_); (a_) = (b_); (b_) = t_; } while (0)
+#define W_INSERT(s_, t_) do { for (u64* i_ = (s_) + 1; i_ < (t_); ++i_) for (u64* j_ = i_; j_ > (s_) && W_LT(*j_, *(j_ - 1)); --j_) W_SWAP(*j_, *(j_ - 1)); } while (0)
+        if (n == 2) { if (W_LT(srt[1], srt[0])) W_SWAP(srt[0], srt[1]); }
+        else if (n > 2) {
+            int d;
+            for (d = 2; (1 << d) < n; ++d) {}
+            d <<= 1;
+            u64 *s = srt, *tt = srt + (n - 1);
+            // explicit stack of (left, right, depth) in the int stack arrays: ranges as offsets into srt
+            int top = 0;
+            for (;;) {
+                if (s < tt) {
+                    if (--d == 0) {                                       // comb sort (ks_combsort)
+                        const int cn = (int)(tt - s) + 1;
+                        const double shrink = 1.2473309501039786540366528676643;
+                        bool do_swap;
+                        int gap = cn;
+                        do {
+                            if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+                            do_swap = false;
+                            for (u64* i = s; i < s + cn - gap; ++i) { u64* j = i + gap; if (W_LT(*j, *i)) { W_SWAP(*i, *j); do_swap = true; } }
+                        } while (do_swap || gap > 2);
+                        if (gap != 1) W_INSERT(s, s + cn);
+                        tt = s;
+                        continue;
+                    }
+                    u64 *i = s, *j = tt, *k = i + ((j - i) >> 1) + 1;
+                    if (W_LT(*k, *i)) { if (W_LT(*k, *j)) k = j; }
+                    else k = W_LT(*j, *i) ? i : j;
+                    const u64 rp = *k;
+                    if (k != tt) W_SWAP(*k, *tt);
+                    for (;;) {
+                        do ++i; while (W_LT(*i, rp));
+                        do --j; while (i <= j && W_LT(rp, *j));
+                        if (j <= i) break;
+                        W_SWAP(*i, *j);
+                    }
+                    W_SWAP(*i, *tt);
+                    if (i - s > tt - i) {
+                        if (i - s > 16) { stk_x[top] = (int)(s - srt); stk_i[top] = (int)(i - 1 - srt); stk_x[top + 20] = d; ++top; }
+                        s = tt - i > 16 ? i + 1 : tt;
+                    } else {
+                        if (tt - i > 16) { stk_x[top] = (int)(i + 1 - srt); stk_i[top] = (int)(tt - srt); stk_x[top + 20] = d; ++top; }
+                        tt = i - s > 16 ? i - 1 : s;
+                    }
+                } else {
+                    if (top == 0) { W_INSERT(srt, srt + n); break; }
+                    --top; s = srt + stk_x[top]; tt = srt + stk_i[top]; d = stk_x[top + 20];
+                }
+            }
+        }
+#undef W_LT
+#undef W_SWAP
+#undef W_INSERT
+        // the filter's view of the sorted chains
+        for (int i = lane; i < n; i += 64) {
+            const int id = (int)(unsigned)srt[i];
+            const C2 c = C[id];
+            FRec f;
+            f.beg = c.f_qbeg; f.end = c.l_qbeg + c.l_len; f.w = c.w; f.first = -1; f.kept = 0; f.is_alt = c.is_alt; f.id = id; f.pad = 0;
+            F[i] = f;
+        }
+        wave_fence();
+        // kept list in ia[] (the SMEM order is no longer needed); lane L always handles kept entries L, L + 64, ...
+        int nk = 1;
+        F[0].kept = 3;
+        ia[0] = 0;
+        for (int i = 1; i < n; ++i) {
+            const FRec fi = F[i];
+            bool large = false, broke = false;
+            for (int kb = 0; kb < nk && !broke; kb += 64) {
+                const int k = kb + lane;
+                const bool in = k < nk;
+                const int j = in ? ia[k] : 0;
+                bool lo = false, br = false;
+                int first_j = 0;
+                if (in) {
+                    const FRec fj = F[j];
+                    first_j = fj.first;
+                    const int b_max = fj.beg > fi.beg ? fj.beg : fi.beg;
+                    const int e_min = fj.end < fi.end ? fj.end : fi.end;
+                    if (e_min > b_max && (!fj.is_alt || fi.is_alt)) {
+                        const int li = fi.end - fi.beg, lj = fj.end - fj.beg;
+                        const int min_l = li < lj ? li : lj;
+                        if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
+                            lo = true;
+                            br = (float)fi.w < (float)fj.w * o.drop_ratio && fj.w - fi.w >= o.min_seed_len << 1;
+                        }
+                    }
+                }
+                const u64 lom = __ballot(lo), brm = __ballot(br);
+                u64 upto = ~(u64)0;
+                if (brm) { const int kx = __builtin_ctzll(brm); upto = ((u64)2 << kx) - 1; broke = true; }
+                if (lo && ((upto >> lane) & 1) && first_j < 0) F[j].first = i;
+                if (lom & upto) large = true;
+            }
+            if (!broke) { ia[nk++] = i; F[i].kept = large ? 2 : 3; }
+        }
+        for (int k = lane; k < nk; k += 64) { const int f = F[ia[k]].first; if (f >= 0) F[f].kept = 1; }
+        wave_fence();
+        int i = 0, k = 0;
+        for (; i < n; ++i) {                                              // at most max_chain_extend chains of kind 1 / 2
+            const int kp = F[i].kept;
+            if (kp == 0 || kp == 3) continue;
+            if (++k >= o.max_chain_extend) break;
+        }
+        for (; i < n; ++i) if (F[i].kept < 3) F[i].kept = 0;
+        for (i = 0; i < n; ++i) {
+            const FRec f = F[i];
+            if (f.kept == 0) continue;
+            F[n_kept++] = f;
+            n_seeds += C[f.id].n;
+        }
+    }
+    if (lane == 0) {
+        ReadHdr H;
+        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base;
+        A.hdr[r] = H;
+        A.frac_rep[r] = (float)l_rep / len;
+    }
+}
+
+// the kept chains and their seeds, densely packed in read order (from the scratch of the tier that finished the read)
+__global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch1, const DSeed* __restrict__ sd1, WaveArgs W,
+                                                     const ReadHdr* __restrict__ hdr, const i64* __restrict__ chain_off,
+                                                     const i64* __restrict__ seed_off, i64 nreads, meme_chain* __restrict__ out_ch,
+                                                     meme_chain_seed* __restrict__ out_sd) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x) {
         const ReadHdr H = hdr[r];
-        if (H.fallback || H.n_kept == 0) continue;
+        if (H.n_kept == 0) continue;
         const bool second = (H.slot >> 62) & 1;
         const i64 slot = H.slot & (((i64)1 << 62) - 1);
-        const int cc = second ? CHAIN_CAP2 : CHAIN_CAP, sc = second ? SEED_CAP2 : SEED_CAP;
-        const DChain* ch = (second ? ch2 : ch1) + slot * cc;
-        const DSeed* sd = (second ? sd2 : sd1) + slot * (i64)cc * sc;
         i64 so = seed_off[r];
         const i64 s0 = so;
-        for (int k = 0; k < H.n_kept; ++k) {
-            const DChain c = ch[k];
-            meme_chain m;
-            m.pos = c.pos; m.rid = c.rid; m.n_seeds = c.n; m.w = c.w; m.first = c.first; m.kept = c.kept; m.is_alt = c.is_alt;
-            m.seed_beg = (int32_t)(so - s0);
-            m.pad = 0;
-            out_ch[chain_off[r] + k] = m;
-            const DSeed* row = sd + c.row * sc;
-            for (int j = 0; j < c.n; ++j) { meme_chain_seed s; s.rbeg = row[j].rbeg; s.qbeg = row[j].qbeg; s.len = row[j].len; out_sd[so++] = s; }
+        if (!second) {
+            const DChain* ch = ch1 + slot * CHAIN_CAP;
+            const DSeed* sd = sd1 + slot * (i64)CHAIN_CAP * SEED_CAP;
+            for (int k = 0; k < H.n_kept; ++k) {
+                const DChain c = ch[k];
+                meme_chain m;
+                m.pos = c.pos; m.rid = c.rid; m.n_seeds = c.n; m.w = c.w; m.first = c.first; m.kept = c.kept; m.is_alt = c.is_alt;
+                m.seed_beg = (int32_t)(so - s0);
+                m.pad = 0;
+                out_ch[chain_off[r] + k] = m;
+                const DSeed* row = sd + c.row * SEED_CAP;
+                for (int j = 0; j < c.n; ++j) { meme_chain_seed s; s.rbeg = row[j].rbeg; s.qbeg = row[j].qbeg; s.len = row[j].len; out_sd[so++] = s; }
+            }
+        } else {
+            const i64 base = W.woff[slot];
+            const C2* C = W.C + base;
+            const S2* S = W.S + base;
+            const FRec* F = W.F + base;
+            for (int k = 0; k < H.n_kept; ++k) {
+                const FRec f = F[k];
+                const C2 c = C[f.id];
+                meme_chain m;
+                m.pos = c.pos; m.rid = c.rid; m.n_seeds = c.n; m.w = f.w; m.first = f.first; m.kept = (int16_t)f.kept; m.is_alt = c.is_alt;
+                m.seed_beg = (int32_t)(so - s0);
+                m.pad = 0;
+                out_ch[chain_off[r] + k] = m;
+                for (int j = c.head; j >= 0; j = S[j].next) { meme_chain_seed s; s.rbeg = S[j].rbeg; s.qbeg = S[j].qbeg; s.len = S[j].len; out_sd[so++] = s; }
+            }
         }
     }
 }
 
-// reads the first pass could not hold (fallback == 1): their indices, for the second pass
-__global__ void __launch_bounds__(256) k_chain_redo(const ReadHdr* __restrict__ hdr, i64 nreads, unsigned long long* __restrict__ count, i64* __restrict__ list) {
+// reads the first tier left (fallback == 1): their indices and work, for the second tier
+__global__ void __launch_bounds__(256) k_chain_redo(const ReadHdr* __restrict__ hdr, i64 nreads, unsigned long long* __restrict__ count, i64* __restrict__ list,
+                                                     i64* __restrict__ lwork) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x)
-        if (hdr[r].fallback == 1) list[atomicAdd(count, 1ull)] = r;
+        if (hdr[r].fallback == 1) { const unsigned long long k = atomicAdd(count, 1ull); list[k] = r; lwork[k] = hdr[r].work > 0 ? hdr[r].work : 1; }
 }
 
 __global__ void __launch_bounds__(256) k_chain_counts(const ReadHdr* __restrict__ hdr, i64 nreads, i64* __restrict__ nch, i64* __restrict__ nsd,
                                                        int* __restrict__ tree, unsigned char* __restrict__ fb) {
-    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r <= nreads; r += (i64)gridDim.x * blockDim.x) {
-        if (r == nreads) { nch[r] = 0; nsd[r] = 0; continue; }
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x) {
         const ReadHdr H = hdr[r];
         nch[r] = H.fallback ? 0 : H.n_kept; nsd[r] = H.fallback ? 0 : H.n_seeds; tree[r] = H.tree_size; fb[r] = H.fallback ? 1 : 0;
     }
@@ -336,6 +772,141 @@ __global__ void __launch_bounds__(256) k_chain_counts(const ReadHdr* __restrict_
 unsigned blocks_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
 
 }  // namespace
+
+// Chains of the batch the ctx has just seeded, left in HBM: ctx->chain[5] = {chain_off[n+1], seed_off[n+1], nch[n+1], nsd[n+1], tree[n], fb[n]},
+// [6] = packed meme_chain, [7] = packed meme_chain_seed, [3] = frac_rep.  totals[0..1] = chains, seeds.
+int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt, i64* totals) {
+    const i64 n = ctx->last_seed_reads;
+    int rc;
+    DevBuf* B = ctx->chain;     // 0 chains scratch, 1 seeds scratch, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
+                                // 8 tier-2 list + work + offsets, 9 tier-2 scratch
+    if ((rc = meme_buf_reserve(ctx, B[0], (size_t)n * CHAIN_CAP * sizeof(DChain)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, B[1], (size_t)n * CHAIN_CAP * SEED_CAP * sizeof(DSeed)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, B[2], (size_t)n * sizeof(ReadHdr)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, B[3], (size_t)n * sizeof(float)))) return rc;
+    const size_t ctab = (size_t)n_contigs * (8 + 4 + 1) + 64;
+    if ((rc = meme_buf_reserve(ctx, B[4], ctab))) return rc;
+    // counts, their scans, tree sizes, fallback flags (+ the tier-2 counter at the end)
+    const size_t cnt_bytes = ((size_t)(n + 1) * 8 * 4 + (size_t)n * 4 + (size_t)n + 64 + 15) / 16 * 16 + 16;
+    if ((rc = meme_buf_reserve(ctx, B[5], cnt_bytes))) return rc;
+    // contig table: offsets | lengths | alt flags
+    std::vector<unsigned char> tab(ctab, 0);
+    i64* t_off = (i64*)tab.data();
+    int* t_len = (int*)(tab.data() + (size_t)n_contigs * 8);
+    unsigned char* t_alt = tab.data() + (size_t)n_contigs * 12;
+    for (int i = 0; i < n_contigs; ++i) { t_off[i] = contigs[i].offset; t_len[i] = contigs[i].len; t_alt[i] = contigs[i].is_alt ? 1 : 0; }
+    HIP_TRY(hipMemcpyAsync(B[4].p, tab.data(), ctab, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                           // (`tab` is a local)
+    ChainArgs A;
+    A.smems = (const meme_mem_tl*)ctx->smems.p; A.smem_off = (const i64*)ctx->smem_off.p;
+    A.hits = (const u64*)ctx->hits.p; A.hit_off = (const i64*)ctx->hit_off.p; A.read_off = (const i64*)ctx->read_off.p;
+    A.nreads = n;
+    A.contig_off = (const i64*)B[4].p; A.contig_len = (const int*)((unsigned char*)B[4].p + (size_t)n_contigs * 8);
+    A.contig_alt = (const unsigned char*)B[4].p + (size_t)n_contigs * 12; A.n_contigs = n_contigs;
+    A.o = *opt;
+    A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
+    hipEvent_t* ev = ctx->ev_chain;
+    for (int i = 0; i < 4; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
+    // tier 2: the reads the first tier left
+    unsigned long long* d_redo_n = (unsigned long long*)((unsigned char*)B[5].p + cnt_bytes - 16);
+    HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
+    if ((rc = meme_buf_reserve(ctx, B[8], (size_t)(n + 1) * 8 * 3))) return rc;
+    i64* d_list = (i64*)B[8].p;
+    i64* d_lwork = d_list + (n + 1);
+    i64* d_woff = d_lwork + (n + 1);
+    hipLaunchKernelGGL(k_chain_redo, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, d_redo_n, d_list, d_lwork);
+    unsigned long long n_redo = 0;
+    HIP_TRY(hipMemcpyAsync(&n_redo, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    WaveArgs W;
+    memset(&W, 0, sizeof(W));
+    bool tier2 = false;
+    if (n_redo > 0) {
+        // the heavy reads first (longest first) and with the big-LDS build of the kernel, on a stream of their own, so that the few
+        // reads that take milliseconds start at once and run beside the many light ones
+        std::vector<i64> h_list((size_t)n_redo), h_work((size_t)n_redo), h_off((size_t)n_redo + 1);
+        HIP_TRY(hipMemcpyAsync(h_list.data(), d_list, (size_t)n_redo * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_work.data(), d_lwork, (size_t)n_redo * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        std::vector<std::pair<i64, i64>> heavy, light;                       // (work, read)
+        for (size_t k = 0; k < (size_t)n_redo; ++k) (h_work[k] > WAVE_LIGHT ? heavy : light).push_back({h_work[k], h_list[k]});
+        std::sort(heavy.begin(), heavy.end(), [](const std::pair<i64, i64>& x, const std::pair<i64, i64>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+        const i64 n_heavy = (i64)heavy.size();
+        i64 total_work = 0;
+        for (size_t k = 0; k < (size_t)n_redo; ++k) {
+            const std::pair<i64, i64>& e = k < heavy.size() ? heavy[k] : light[k - heavy.size()];
+            h_list[k] = e.second; h_off[k] = total_work; total_work += e.first;
+        }
+        h_off[(size_t)n_redo] = total_work;
+        HIP_TRY(hipMemcpyAsync(d_list, h_list.data(), (size_t)n_redo * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_woff, h_off.data(), (size_t)(n_redo + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        const size_t units = (size_t)total_work + 8, nodes = (size_t)total_work / 3 + 4 * (size_t)n_redo + 8;
+        const size_t sz[7] = {units * sizeof(C2), units * sizeof(S2), units * sizeof(FRec), units * 8, units * 4, units * 4, nodes * sizeof(TNode)};
+        size_t need = 0, at[7];
+        for (int k = 0; k < 7; ++k) { at[k] = need; need += (sz[k] + 255) / 256 * 256; }
+        if (need > B[9].cap) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2 + B[9].cap) {
+                meme_set_error("chaining %llu repeat-rich reads of this batch (%lld hits to walk) needs %.1f GB of scratch, more than half of the free HBM "
+                               "(%.1f GB): chain this batch in smaller pieces", n_redo, (long long)total_work, need / 1e9, free_b / 1e9);
+                return MEME_E_CAPACITY;
+            }
+        }
+        if ((rc = meme_buf_reserve(ctx, B[9], need))) return rc;
+        unsigned char* p9 = (unsigned char*)B[9].p;
+        W.list = d_list; W.woff = d_woff; W.nlist = (i64)n_redo;
+        W.C = (C2*)(p9 + at[0]); W.S = (S2*)(p9 + at[1]); W.F = (FRec*)(p9 + at[2]); W.srt = (u64*)(p9 + at[3]); W.ia = (int*)(p9 + at[4]);
+        W.ib = (int*)(p9 + at[5]); W.nodes = (TNode*)(p9 + at[6]);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));                       // (the host vectors above are locals; and stream2 starts from here)
+        HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+        if (n_heavy > 0) {
+            if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            if (!ctx->ev_aux) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+            WaveArgs Wh = W;
+            Wh.nlist = n_heavy;
+            hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)n_heavy), dim3(64), 0, ctx->stream2, A, Wh, (i64)0);
+            HIP_TRY(hipEventRecord(ctx->ev_aux, ctx->stream2));
+        }
+        if ((i64)n_redo > n_heavy)
+            hipLaunchKernelGGL((k_chain_wave<64, 512>), dim3((unsigned)((i64)n_redo - n_heavy)), dim3(64), 0, ctx->stream, A, W, n_heavy);
+        if (n_heavy > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
+        HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+        tier2 = true;
+    }
+    i64* d_choff = (i64*)B[5].p;
+    i64* d_sdoff = d_choff + (n + 1);
+    i64* d_nch = d_sdoff + (n + 1);
+    i64* d_nsd = d_nch + (n + 1);
+    int* d_tree = (int*)(d_nsd + (n + 1));
+    unsigned char* d_fb = (unsigned char*)(d_tree + n);
+    hipLaunchKernelGGL(k_chain_counts, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, d_nch, d_nsd, d_tree, d_fb);
+    if ((rc = meme_scan_exclusive(ctx, d_nch, d_choff, n))) return rc;
+    i64 tot[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&tot[0], d_choff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = meme_scan_exclusive(ctx, d_nsd, d_sdoff, n))) return rc;
+    HIP_TRY(hipMemcpyAsync(&tot[1], d_sdoff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = meme_buf_reserve(ctx, B[6], (size_t)(tot[0] + 1) * sizeof(meme_chain)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, B[7], (size_t)(tot[1] + 1) * sizeof(meme_chain_seed)))) return rc;
+    hipLaunchKernelGGL(k_chain_pack, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const DChain*)B[0].p, (const DSeed*)B[1].p, W,
+                       (const ReadHdr*)B[2].p, (const i64*)d_choff, (const i64*)d_sdoff, n, (meme_chain*)B[6].p, (meme_chain_seed*)B[7].p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[3], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f, ms2 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
+        if (tier2) HIP_TRY(hipEventElapsedTime(&ms2, ev[1], ev[2]));
+        ctx->tm.chain_kernel_ms = ms;          // (includes the small host round trips between the tiers)
+        ctx->tm.chain_pass2_ms = ms2;
+    }
+    ctx->chain_reads = n;
+    ctx->chain_tier2_reads = (i64)n_redo;
+    totals[0] = tot[0]; totals[1] = tot[1];
+    return MEME_OK;
+}
 
 extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt,
                                           meme_chain_host_result* out) {
@@ -346,85 +917,13 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     const i64 n = ctx->last_seed_reads;
     if (n <= 0 || !ctx->smem_off.p || !ctx->read_off.p) { meme_set_error("meme_chain_last_batch_host: no seeded batch on this ctx"); return MEME_E_STATE; }
     int rc;
-    DevBuf* B = ctx->chain;     // 0 chains scratch, 1 seeds scratch, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
-                                // 8 redo list, 9 / 10 scratch of the second pass
-    if ((rc = meme_buf_reserve(ctx, B[0], (size_t)n * CHAIN_CAP * sizeof(DChain)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, B[1], (size_t)n * CHAIN_CAP * SEED_CAP * sizeof(DSeed)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, B[2], (size_t)n * sizeof(ReadHdr)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, B[3], (size_t)n * sizeof(float)))) return rc;
-    const size_t ctab = (size_t)n_contigs * (8 + 4 + 1) + 64;
-    if ((rc = meme_buf_reserve(ctx, B[4], ctab))) return rc;
-    // counts, their scans, tree sizes, fallback flags
-    const size_t cnt_bytes = ((size_t)(n + 1) * 8 * 4 + (size_t)n * 4 + (size_t)n + 64 + 15) / 16 * 16 + 16;   // (+ the redo counter at the end)
-    if ((rc = meme_buf_reserve(ctx, B[5], cnt_bytes))) return rc;
-    // contig table: offsets | lengths | alt flags
-    std::vector<unsigned char> tab(ctab, 0);
-    i64* t_off = (i64*)tab.data();
-    int* t_len = (int*)(tab.data() + (size_t)n_contigs * 8);
-    unsigned char* t_alt = tab.data() + (size_t)n_contigs * 12;
-    for (int i = 0; i < n_contigs; ++i) { t_off[i] = contigs[i].offset; t_len[i] = contigs[i].len; t_alt[i] = contigs[i].is_alt ? 1 : 0; }
-    HIP_TRY(hipMemcpyAsync(B[4].p, tab.data(), ctab, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));                           // `tab` goes out of scope with the function only, but keep it simple
-    ChainArgs A;
-    A.smems = (const meme_mem_tl*)ctx->smems.p; A.smem_off = (const i64*)ctx->smem_off.p;
-    A.hits = (const u64*)ctx->hits.p; A.hit_off = (const i64*)ctx->hit_off.p; A.read_off = (const i64*)ctx->read_off.p;
-    A.nreads = n;
-    A.contig_off = (const i64*)B[4].p; A.contig_len = (const int*)((unsigned char*)B[4].p + (size_t)n_contigs * 8);
-    A.contig_alt = (const unsigned char*)B[4].p + (size_t)n_contigs * 12; A.n_contigs = n_contigs;
-    A.o = *opt;
-    A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
-    A.list = nullptr; A.nlist = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 4; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
-    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
-    // second pass: the reads that did not fit, with the big scratch
-    unsigned long long* d_redo_n = (unsigned long long*)((unsigned char*)B[5].p + cnt_bytes - 16);
-    HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
-    if ((rc = meme_buf_reserve(ctx, B[8], (size_t)n * 8))) return rc;
-    hipLaunchKernelGGL(k_chain_redo, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, d_redo_n, (i64*)B[8].p);
-    unsigned long long n_redo = 0;
-    HIP_TRY(hipMemcpyAsync(&n_redo, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (n_redo > 0) {
-        size_t free_b = 0, total_b = 0;
-        const size_t need = (size_t)n_redo * CHAIN_CAP2 * (sizeof(DChain) + SEED_CAP2 * sizeof(DSeed));
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 2) {          // else: those reads stay flagged for the host
-            if ((rc = meme_buf_reserve(ctx, B[9], (size_t)n_redo * CHAIN_CAP2 * sizeof(DChain)))) return rc;
-            if ((rc = meme_buf_reserve(ctx, B[10], (size_t)n_redo * CHAIN_CAP2 * SEED_CAP2 * sizeof(DSeed)))) return rc;
-            ChainArgs A2 = A;
-            A2.ch = (DChain*)B[9].p; A2.sd = (DSeed*)B[10].p; A2.list = (const i64*)B[8].p; A2.nlist = (i64)n_redo;
-            HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-            // (4 lanes per wavefront: these reads are few and each is a long chain of dependent loads -- more, shorter-lived wavefronts hide
-            //  more latency and wait less for their slowest read than fewer full ones: 18.3 -> 12.7 ms per 2 M reads)
-            hipLaunchKernelGGL((k_chain<CHAIN_CAP2, SEED_CAP2>), dim3((unsigned)((n_redo + 3) / 4)), dim3(4), 0, ctx->stream, A2);
-            HIP_TRY(hipEventRecord(ev[2], ctx->stream));
-        }
-    }
-    i64* d_nch = (i64*)B[5].p;
-    i64* d_nsd = d_nch + (n + 1);
-    i64* d_choff = d_nsd + (n + 1);
-    i64* d_sdoff = d_choff + (n + 1);
-    int* d_tree = (int*)(d_sdoff + (n + 1));
-    unsigned char* d_fb = (unsigned char*)(d_tree + n);
-    hipLaunchKernelGGL(k_chain_counts, dim3(blocks_of(n + 1, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, d_nch, d_nsd, d_tree, d_fb);
-    size_t tb = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_nch, d_choff, (i64)(n + 1), ctx->stream));
-    if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, tb + 64))) return rc;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->scan_tmp.p, tb, d_nch, d_choff, (i64)(n + 1), ctx->stream));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(ctx->scan_tmp.p, tb, d_nsd, d_sdoff, (i64)(n + 1), ctx->stream));
-    i64 tot[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(&tot[0], d_choff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&tot[1], d_sdoff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if ((rc = meme_buf_reserve(ctx, B[6], (size_t)(tot[0] + 1) * sizeof(meme_chain)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, B[7], (size_t)(tot[1] + 1) * sizeof(meme_chain_seed)))) return rc;
-    hipLaunchKernelGGL(k_chain_pack, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const DChain*)B[0].p, (const DSeed*)B[1].p,
-                       (const DChain*)B[9].p, (const DSeed*)B[10].p, (const ReadHdr*)B[2].p, (const i64*)d_choff, (const i64*)d_sdoff, n,
-                       (meme_chain*)B[6].p, (meme_chain_seed*)B[7].p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev[3], ctx->stream));
+    i64 tot[2];
+    if ((rc = meme_chain_run(ctx, contigs, n_contigs, opt, tot))) return rc;
+    DevBuf* B = ctx->chain;
+    const i64* d_choff = (const i64*)B[5].p;
+    const i64* d_sdoff = d_choff + (n + 1);
+    const int* d_tree = (const int*)(d_sdoff + 3 * (n + 1));
+    const unsigned char* d_fb = (const unsigned char*)(d_tree + n);
     meme_ctx::HostBuf* Hb = ctx->h_chain;   // 0 chain_off, 1 chains, 2 seed_off, 3 seeds, 4 tree sizes, 5 frac_rep, 6 fallback flags
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(tot[0] + 1) * sizeof(meme_chain))) ||
         (rc = meme_hostbuf_reserve(ctx, Hb[2], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[3], (size_t)(tot[1] + 1) * sizeof(meme_chain_seed))) ||
@@ -438,13 +937,6 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     HIP_TRY(hipMemcpyAsync(Hb[5].p, B[3].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(Hb[6].p, d_fb, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    {
-        float ms = 0.f, ms2 = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
-        if (n_redo > 0 && hipEventQuery(ev[2]) == hipSuccess && hipEventElapsedTime(&ms2, ev[1], ev[2]) != hipSuccess) ms2 = 0.f;
-        ctx->tm.chain_kernel_ms = ms;          // (includes the two small host round trips between the passes)
-        ctx->tm.chain_pass2_ms = ms2;
-    }
     out->nreads = n;
     out->chain_off = (const int64_t*)Hb[0].p; out->chains = (const meme_chain*)Hb[1].p;
     out->seed_off = (const int64_t*)Hb[2].p; out->seeds = (const meme_chain_seed*)Hb[3].p;
@@ -452,6 +944,34 @@ extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* cont
     out->total_chains = tot[0]; out->total_seeds = tot[1];
     i64 nfb = 0;
     for (i64 i = 0; i < n; ++i) nfb += out->fallback[i] ? 1 : 0;
-    out->n_fallback = nfb;
+    out->n_fallback = nfb;                 // always 0: both tiers run on the device
+    out->n_tier2 = ctx->chain_tier2_reads;
     return MEME_OK;
+}
+
+// The same for seeds the caller brings (host arrays in the layout meme_seed_batch_host returns them in): any seeder's SMEMs and
+// hits can be chained, and the parity tests feed made-up seed sets (chains at equal positions, thousands of chains) through here.
+extern "C" int meme_chain_batch_host(meme_ctx* ctx, const meme_mem_tl* smems, const int64_t* smem_off, const uint64_t* hits, const int64_t* hit_off,
+                                     const int32_t* read_len, int64_t nreads, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt,
+                                     meme_chain_host_result* out) {
+    if (!ctx || !smem_off || !hit_off || !read_len || nreads < 1 || !out) { meme_set_error("meme_chain_batch_host: bad argument"); return MEME_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const i64 ns = smem_off[nreads], nh = hit_off[nreads];
+    if (smem_off[0] != 0 || hit_off[0] != 0 || ns < 0 || nh < 0 || (ns > 0 && !smems) || (nh > 0 && !hits)) { meme_set_error("meme_chain_batch_host: bad offsets"); return MEME_E_ARG; }
+    int rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->smems, (size_t)(ns + 1) * sizeof(meme_mem_tl))) || (rc = meme_buf_reserve(ctx, ctx->hits, (size_t)(nh + 1) * 8)) ||
+        (rc = meme_buf_reserve(ctx, ctx->smem_off, (size_t)(nreads + 1) * 8)) || (rc = meme_buf_reserve(ctx, ctx->hit_off, (size_t)(nreads + 1) * 8)) ||
+        (rc = meme_buf_reserve(ctx, ctx->read_off, (size_t)(nreads + 1) * 8))) return rc;
+    std::vector<i64> roff((size_t)nreads + 1, 0);
+    for (i64 i = 0; i < nreads; ++i) roff[(size_t)i + 1] = roff[(size_t)i] + read_len[i];
+    if (ns) HIP_TRY(hipMemcpyAsync(ctx->smems.p, smems, (size_t)ns * sizeof(meme_mem_tl), hipMemcpyHostToDevice, ctx->stream));
+    if (nh) HIP_TRY(hipMemcpyAsync(ctx->hits.p, hits, (size_t)nh * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->smem_off.p, smem_off, (size_t)(nreads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->hit_off.p, hit_off, (size_t)(nreads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->read_off.p, roff.data(), (size_t)(nreads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->last_seed_reads = nreads;
+    ctx->last_seed_max_len = 0;
+    for (i64 i = 0; i < nreads; ++i) ctx->last_seed_max_len = read_len[i] > ctx->last_seed_max_len ? read_len[i] : ctx->last_seed_max_len;
+    return meme_chain_last_batch_host(ctx, contigs, n_contigs, opt, out);
 }

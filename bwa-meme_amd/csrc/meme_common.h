@@ -58,9 +58,10 @@ struct meme_ctx {
     std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[11];
+           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[11], ext[9];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
-    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7];
+    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2];
+    i64 last_seed_max_len = 0;         // longest read of that batch
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
@@ -73,12 +74,24 @@ struct meme_ctx {
                                        // lanes-per-pair kernel (latency: a lone pair takes ~6 ms on one lane, ~0.3 ms on 64)
     // timings
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_ext[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr;     // side stream: the heavy reads of the chaining tier run beside the light ones
+    hipEvent_t ev_aux = nullptr;
+    i64 chain_reads = 0, chain_tier2_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
     meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 void meme_set_error(const char* fmt, ...);
 int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes);
 int meme_hostbuf_reserve(meme_ctx* ctx, meme_ctx::HostBuf& b, size_t bytes);
+// exclusive prefix sum of n 64-bit counts into out[0..n] (out[n] = total), asynchronous on ctx->stream (meme_scan.hip)
+int meme_scan_exclusive(meme_ctx* ctx, const i64* d_in, i64* d_out, i64 n);
+// the banded-SW kernels on device-resident pairs, no host synchronisation (meme_bsw.hip); host_maxq = an upper bound of the query lengths or -1
+int meme_bsw_launch(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w, const meme_bsw_opt* opt,
+                    int host_maxq);
+// chains of the batch just seeded, left in HBM (meme_chain.hip); totals[0..1] = chains, chained seeds
+int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt, i64* totals);
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \

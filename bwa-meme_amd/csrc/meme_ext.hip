@@ -1,0 +1,433 @@
+// Seed extension of a whole batch on the device: mem_chain2aln_across_reads_V2 (reference src/bwamem.cpp:2573-3497) behind the chaining
+// kernels -- seeds, chains, extension jobs and their sequences never leave HBM; the host receives mem_alnreg_t records.
+//
+//   k_ext_jobs<false>  per read: the reference span of every chain (:2648-2690 + bns_fetch_seq_v2, src/bntseq.cpp:479-512), the
+//                      number of left / right extension jobs and of sequence bytes                                  -> scans
+//   k_ext_jobs<true>   per read: one alignment record per chained seed in extension order (best seed of a chain first, :2692-2702),
+//                      the left (:2722-2781) and right (:2783-2850) jobs as SeqPair records, their sequences copied from the 2-bit
+//                      text and the read (left jobs reversed), the per-chain seed order the purge step walks
+//   meme_bsw           k_bsw_lane / k_bsw<LP> on the jobs of one direction and band width (meme_bsw.hip)
+//   k_ext_fold<left>   results into the records (:2985-3018 and siblings); jobs whose band was too narrow to a retry list (MAX_BAND_TRY 2)
+//   k_ext_h0           start score of the right extension = score after the left one (:3371-3376)
+//   k_ext_purge        alignments of seeds an earlier alignment of the read already covers are dropped (:3389-3485)
+//
+// One wavefront per read in the kernels that walk a read's chains (a read has 1 to a few hundred chained seeds: lanes take seeds, the
+// wavefront reduces / scans across them, and a repeat-rich read cannot hold 63 others back); one lane per job in the others.
+#include <string.h>
+
+#include "meme_common.h"
+
+namespace {
+
+constexpr int H0 = -99;                    // H0_, src/macro.h:44
+constexpr int EXT_BAND_TRIES = 2;          // MAX_BAND_TRY, src/bwamem.cpp:62
+
+struct ExtArgs {
+    const uint8_t* reads; const i64* read_off; i64 g0, ns;            // reads [g0, g0 + ns) of the batch
+    const i64* chain_off; const meme_chain* chains; const i64* seed_off; const meme_chain_seed* seeds; const float* frac_rep;
+    const u64* pac; i64 l_pac;
+    const i64* contig_off; const int* contig_len;
+    meme_ext_opt o;
+    i64* rmax;                        // [2 * chain]: reference span of a chain
+    meme_alnreg* regs; int* order;    // per chained seed of the batch
+    i64 *cntL, *cntR, *cntB;          // per read (from g0): left jobs, right jobs, sequence bytes (k_ext_jobs<false>)
+    const i64 *offL, *offR, *offB;    // their exclusive scans over the batch (pointing at read g0)
+    i64 job0L, job0R, byte0;          // offsets of this slab's first job / byte (subtracted: SeqPair offsets are 32-bit)
+    meme_seqpair* L; meme_seqpair* R; uint8_t* seq;
+};
+
+__device__ __forceinline__ int cal_max_gap(const meme_ext_opt& o, int qlen) {       // src/bwamem.cpp:85-95
+    const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
+    const int l_ins = (int)((double)(qlen * o.a - o.o_ins) / o.e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < o.w << 1 ? l : o.w << 1;
+}
+__device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(pac[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3; }
+__device__ __forceinline__ i64 wave_min(i64 v) { for (int d = 32; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y < v ? y : v; } return v; }
+__device__ __forceinline__ i64 wave_max(i64 v) { for (int d = 32; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y > v ? y : v; } return v; }
+__device__ __forceinline__ int pad4(int x) { return (x + 3) & ~3; }
+
+// seeds of the chain fully inside the alignment (src/bwamem.cpp:2907-2917 and after every fold)
+__device__ inline void seedcov(meme_alnreg* a, const meme_chain_seed* sd, int n) {
+    if (a->rb == H0 || a->qb == H0 || a->qe == H0 || a->re == H0) return;
+    int cov = 0;
+    for (int i = 0; i < n; ++i) {
+        const meme_chain_seed t = sd[i];
+        if (t.qbeg >= a->qb && t.qbeg + t.len <= a->qe && t.rbeg >= a->rb && t.rbeg + t.len <= a->re) cov += t.len;
+    }
+    a->seedcov = cov;
+}
+
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
+    const i64 rl = blockIdx.x;                       // read of the slab
+    if (rl >= A.ns) return;
+    const i64 r = A.g0 + rl;
+    const int lane = threadIdx.x;
+    const i64 c0 = A.chain_off[r];
+    const int nc = (int)(A.chain_off[r + 1] - c0);
+    const i64 s0 = A.seed_off[r];
+    const int S = (int)(A.seed_off[r + 1] - s0);
+    const int l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
+    const meme_ext_opt& o = A.o;
+    if (!WRITE) {
+        // ---- reference span of every chain: the widest any of its seeds may reach (:2648-2690)
+        for (int c = 0; c < nc; ++c) {
+            const meme_chain ch = A.chains[c0 + c];
+            const meme_chain_seed* sd = A.seeds + s0 + ch.seed_beg;
+            i64 b_min = A.l_pac << 1, e_max = 0;
+            for (int i = lane; i < ch.n_seeds; i += 64) {
+                const meme_chain_seed t = sd[i];
+                const i64 b = t.rbeg - (t.qbeg + cal_max_gap(o, t.qbeg));
+                const int tail = l_query - t.qbeg - t.len;
+                const i64 e = t.rbeg + t.len + (tail + cal_max_gap(o, tail));
+                b_min = b < b_min ? b : b_min;
+                e_max = e > e_max ? e : e_max;
+            }
+            i64 rmax0 = wave_min(b_min), rmax1 = wave_max(e_max);
+            if (rmax0 < 0) rmax0 = 0;
+            if (rmax1 > A.l_pac << 1) rmax1 = A.l_pac << 1;
+            const i64 mid = sd[0].rbeg;
+            if (rmax0 < A.l_pac && A.l_pac < rmax1) { if (mid < A.l_pac) rmax1 = A.l_pac; else rmax0 = A.l_pac; }
+            // bns_fetch_seq_v2: the span stays inside the chain's reference sequence (on the strand of its first seed)
+            i64 far_beg = A.contig_off[ch.rid], far_end = far_beg + A.contig_len[ch.rid];
+            if (mid >= A.l_pac) { const i64 t = far_beg; far_beg = (A.l_pac << 1) - far_end; far_end = (A.l_pac << 1) - t; }
+            rmax0 = rmax0 > far_beg ? rmax0 : far_beg;
+            rmax1 = rmax1 < far_end ? rmax1 : far_end;
+            A.rmax[2 * (c0 + c)] = rmax0;
+            A.rmax[2 * (c0 + c) + 1] = rmax1;
+        }
+    }
+    // ---- one lane per chained seed: its place in the extension order, its two jobs
+    i64 nL = 0, nR = 0, nB = 0;                       // running totals of the read (uniform)
+    const i64 jobL0 = WRITE ? A.offL[rl] - A.job0L : 0, jobR0 = WRITE ? A.offR[rl] - A.job0R : 0;
+    const i64 byte0 = WRITE ? A.offB[rl] - A.byte0 : 0;
+    for (int jb = 0; jb < S; jb += 64) {
+        const int j = jb + lane;
+        const bool valid = j < S;
+        int c = 0;
+        if (valid) {                                  // the chain of seed j: chains are packed in order, seed_beg ascending
+            int lo = 0, hi = nc - 1;
+            while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (A.chains[c0 + m].seed_beg <= j) lo = m; else hi = m - 1; }
+            c = lo;
+        }
+        const meme_chain ch = A.chains[c0 + (valid ? c : 0)];
+        const meme_chain_seed* sd = A.seeds + s0 + ch.seed_beg;
+        const int il = valid ? j - ch.seed_beg : 0;
+        const meme_chain_seed t = sd[il];
+        const i64 rmax0 = A.rmax[2 * (c0 + c)], rmax1 = A.rmax[2 * (c0 + c) + 1];
+        const bool hasL = valid && t.qbeg > 0, hasR = valid && t.qbeg + t.len != l_query;
+        const int qe = t.qbeg + t.len;
+        const int l2L = t.qbeg, l1L = (int)(t.rbeg - rmax0);
+        const int l2R = l_query - qe, l1R = (int)(rmax1 - (t.rbeg + t.len));
+        const int bytesL = hasL ? pad4(l1L) + pad4(l2L) : 0, bytesR = hasR ? pad4(l1R) + pad4(l2R) : 0;
+        const u64 mL = __ballot(hasL), mR = __ballot(hasR), below = ((u64)1 << lane) - 1;
+        // exclusive scan of the bytes over the lanes
+        int bsum = bytesL + bytesR, bex;
+        {
+            int x = bsum;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            bex = x - bsum;
+            bsum = __shfl(x, 63);
+        }
+        if (WRITE && valid) {
+            // rank among the chain's seeds by (score = length, index): ks_introsort_64 on score << 32 | index, keys unique (:2692-2699)
+            int rank = 0;
+            for (int k = 0; k < ch.n_seeds; ++k) { const int lk = sd[k].len; rank += (lk < t.len || (lk == t.len && k < il)) ? 1 : 0; }
+            A.order[s0 + ch.seed_beg + rank] = il;
+            const i64 reg = s0 + ch.seed_beg + (ch.n_seeds - 1 - rank);        // best seed first
+            meme_alnreg a;
+            memset(&a, 0, sizeof(a));
+            a.w = o.w; a.score = a.truesc = -1; a.rid = ch.rid; a.frac_rep = A.frac_rep[r]; a.seedlen0 = t.len; a.c = (u64)(c0 + c);
+            a.rb = a.re = H0; a.qb = a.qe = H0;
+            if (hasL) {
+                meme_seqpair sp;
+                memset(&sp, 0, sizeof(sp));
+                sp.h0 = t.len * o.a; sp.seqid = (int32_t)r; sp.regid = (int32_t)reg; sp.len1 = l1L; sp.len2 = l2L;
+                sp.idr = (int32_t)(byte0 + nB + bex); sp.idq = sp.idr + pad4(l1L);
+                A.L[jobL0 + nL + __popcll(mL & below)] = sp;
+                a.qb = t.qbeg; a.rb = t.rbeg;
+            } else { a.score = a.truesc = t.len * o.a; a.qb = 0; a.rb = t.rbeg; }
+            if (hasR) {
+                meme_seqpair sp;
+                memset(&sp, 0, sizeof(sp));
+                sp.h0 = H0; sp.seqid = (int32_t)r; sp.regid = (int32_t)reg; sp.len1 = l1R; sp.len2 = l2R;
+                sp.idr = (int32_t)(byte0 + nB + bex + bytesL); sp.idq = sp.idr + pad4(l1R);
+                A.R[jobR0 + nR + __popcll(mR & below)] = sp;
+                a.qe = qe; a.re = t.rbeg + t.len;
+            } else { a.qe = l_query; a.re = t.rbeg + t.len; seedcov(&a, sd, ch.n_seeds); }
+            A.regs[reg] = a;
+        }
+        if (WRITE) {
+            // the sequences, job after job, 64 lanes x 4 bases per step: left jobs reversed (both sequences run away from the seed)
+            const uint8_t* rd = A.reads + A.read_off[r];
+            for (int side = 0; side < 2; ++side) {
+                u64 m = side ? mR : mL;
+                while (m) {
+                    const int jl = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const i64 rbeg = __shfl(t.rbeg, jl);
+                    const int qb = __shfl(t.qbeg, jl), ln = __shfl(t.len, jl);
+                    const int l1 = __shfl(side ? l1R : l1L, jl), l2 = __shfl(side ? l2R : l2L, jl);
+                    const i64 dst = byte0 + nB + __shfl(bex, jl) + (side ? __shfl(bytesL, jl) : 0);
+                    uint8_t* dr = A.seq + dst;
+                    uint8_t* dq = dr + pad4(l1);
+                    for (int i = lane * 4; i < l1; i += 256) {
+                        unsigned v = 0;
+                        for (int b = 0; b < 4; ++b) {
+                            const int k = i + b;
+                            const int code = k < l1 ? text_base(A.pac, side ? rbeg + ln + k : rbeg - 1 - k) : 0;
+                            v |= (unsigned)code << (8 * b);
+                        }
+                        *reinterpret_cast<unsigned*>(dr + i) = v;
+                    }
+                    for (int i = lane * 4; i < l2; i += 256) {
+                        unsigned v = 0;
+                        for (int b = 0; b < 4; ++b) {
+                            const int k = i + b;
+                            const int code = k < l2 ? rd[side ? qb + ln + k : qb - 1 - k] : 0;
+                            v |= (unsigned)code << (8 * b);
+                        }
+                        *reinterpret_cast<unsigned*>(dq + i) = v;
+                    }
+                }
+            }
+        }
+        nL += __popcll(mL); nR += __popcll(mR); nB += bsum;
+    }
+    if (!WRITE && lane == 0) { A.cntL[rl] = nL; A.cntR[rl] = nR; A.cntB[rl] = nB; }
+}
+
+struct FoldArgs {
+    meme_seqpair* pairs; i64 n;
+    meme_alnreg* regs; const meme_chain* chains; const i64* seed_off; const meme_chain_seed* seeds; const i64* read_off;
+    meme_ext_opt o; int w, last;
+    meme_seqpair* retry; unsigned long long* n_retry;
+};
+
+// results of one stage into the alignment records (src/bwamem.cpp:2985-3018 left, :3253-3290 right, and their siblings)
+template <bool LEFT>
+__global__ void __launch_bounds__(256) k_ext_fold(FoldArgs F) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < F.n; i += (i64)gridDim.x * blockDim.x) {
+        const meme_seqpair sp = F.pairs[i];
+        meme_alnreg* a = &F.regs[sp.regid];
+        const int prev = a->score;
+        a->score = sp.score;
+        if (a->score == prev || sp.max_off < (F.w >> 1) + (F.w >> 2) || F.last) {
+            if (LEFT) {
+                if (sp.gscore <= 0 || sp.gscore <= a->score - F.o.pen_clip5) { a->qb -= sp.qle; a->rb -= sp.tle; a->truesc = a->score; }
+                else { a->qb = 0; a->rb -= sp.gtle; a->truesc = sp.gscore; }
+            } else {
+                if (sp.gscore <= 0 || sp.gscore <= a->score - F.o.pen_clip3) { a->qe += sp.qle; a->re += sp.tle; a->truesc += a->score - sp.h0; }
+                else { a->qe = (int)(F.read_off[sp.seqid + 1] - F.read_off[sp.seqid]); a->re += sp.gtle; a->truesc += sp.gscore - sp.h0; }
+            }
+            a->w = a->w > F.w ? a->w : F.w;
+            const meme_chain ch = F.chains[a->c];
+            seedcov(a, F.seeds + F.seed_off[sp.seqid] + ch.seed_beg, ch.n_seeds);
+        } else F.retry[atomicAdd(F.n_retry, 1ull)] = sp;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ext_h0(meme_seqpair* __restrict__ pairs, i64 n, const meme_alnreg* __restrict__ regs) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) pairs[i].h0 = regs[pairs[i].regid].score;
+}
+
+struct PurgeArgs {
+    const i64* read_off; i64 nreads;
+    const i64* chain_off; const meme_chain* chains; const i64* seed_off; const meme_chain_seed* seeds;
+    meme_alnreg* regs; int* order;
+    meme_ext_opt o;
+};
+
+// (:3389-3485) in the order the one-read-at-a-time aligner would have met the seeds: chain after chain, best seed first
+__global__ void __launch_bounds__(64) k_ext_purge(PurgeArgs P) {
+    const i64 r = blockIdx.x;
+    if (r >= P.nreads) return;
+    const int lane = threadIdx.x;
+    const i64 c0 = P.chain_off[r];
+    const int nc = (int)(P.chain_off[r + 1] - c0);
+    const i64 s0 = P.seed_off[r];
+    const int S = (int)(P.seed_off[r + 1] - s0);
+    if (S < 2) return;                                 // a lone alignment has nothing before it
+    const int l_query = (int)(P.read_off[r + 1] - P.read_off[r]);
+    meme_alnreg* av = P.regs + s0;
+    int cur = 0;                                       // record of the seed at hand = number of seeds met so far
+    for (int c = 0; c < nc; ++c) {
+        const meme_chain ch = P.chains[c0 + c];
+        const meme_chain_seed* sd = P.seeds + s0 + ch.seed_beg;
+        int* ord = P.order + s0 + ch.seed_beg;
+        for (int k = ch.n_seeds - 1; k >= 0; --k, ++cur) {
+            const meme_chain_seed s = sd[ord[k]];
+            // an earlier, surviving alignment that contains the seed and has it within its band on either side?
+            bool found = false;
+            for (int ib = 0; ib < cur && !found; ib += 64) {
+                const int i = ib + lane;
+                bool hit = false;
+                if (i < cur) {
+                    const meme_alnreg* p = &av[i];
+                    const i64 prb = p->rb, pre = p->re;
+                    const int pqb = p->qb, pqe = p->qe;
+                    if (!(pqb == -1 && pqe == -1) && !(s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) &&
+                        !(s.len - p->seedlen0 > .1 * l_query)) {
+                        const int pw = p->w;
+                        int qd = s.qbeg - pqb;
+                        i64 rd = s.rbeg - prb;
+                        int max_gap = cal_max_gap(P.o, qd < rd ? qd : (int)rd);
+                        int band = max_gap < pw ? max_gap : pw;
+                        if (qd - rd < band && rd - qd < band) hit = true;
+                        else {
+                            qd = pqe - (s.qbeg + s.len);
+                            rd = pre - (s.rbeg + s.len);
+                            max_gap = cal_max_gap(P.o, qd < rd ? qd : (int)rd);
+                            band = max_gap < pw ? max_gap : pw;
+                            if (qd - rd < band && rd - qd < band) hit = true;
+                        }
+                    }
+                }
+                found = __ballot(hit) != 0;
+            }
+            if (!found) continue;
+            // (almost) contained -- unless a long, overlapping, better seed of the chain on another diagonal says otherwise
+            bool other = false;
+            for (int ub = k + 1; ub < ch.n_seeds && !other; ub += 64) {
+                const int u = ub + lane;
+                bool hit = false;
+                if (u < ch.n_seeds && ord[u] >= 0) {
+                    const meme_chain_seed t = sd[ord[u]];
+                    if (!(t.len < s.len * .95)) {
+                        if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) hit = true;
+                        else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
+                    }
+                }
+                other = __ballot(hit) != 0;
+            }
+            if (!other) { av[cur].qb = -1; av[cur].qe = -1; ord[k] = -1; }
+        }
+    }
+}
+
+unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
+
+}  // namespace
+
+extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* copt,
+                                           const meme_ext_opt* eopt, meme_ext_host_result* out) {
+    if (!ctx || !contigs || n_contigs < 1 || !copt || !eopt || !out) { meme_set_error("meme_extend_last_batch_host: null argument"); return MEME_E_ARG; }
+    if (copt->max_occ < 1 || copt->l_pac < 1 || eopt->e_del < 1 || eopt->e_ins < 1 || eopt->w < 1) { meme_set_error("meme_extend_last_batch_host: bad options"); return MEME_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    const i64 n = ctx->last_seed_reads;
+    if (n <= 0 || !ctx->smem_off.p || !ctx->read_off.p || !ctx->reads.p) { meme_set_error("meme_extend_last_batch_host: no seeded batch on this ctx"); return MEME_E_STATE; }
+    if (copt->l_pac * 2 != ctx->idx.n) { meme_set_error("meme_extend_last_batch_host: l_pac does not match the loaded index"); return MEME_E_ARG; }
+    int rc;
+    i64 tot[2];
+    if ((rc = meme_chain_run(ctx, contigs, n_contigs, copt, tot))) return rc;
+    hipEvent_t* ev = ctx->ev_ext;
+    for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    DevBuf* B = ctx->chain;
+    DevBuf* E = ctx->ext;       // 0 rmax, 1 regs, 2 order, 3 counts + scans, 4 L pairs, 5 R pairs, 6 retry pairs (two halves), 7 sequences, 8 counter
+    const i64* d_choff = (const i64*)B[5].p;
+    const i64* d_sdoff = d_choff + (n + 1);
+    const i64 n_chains = tot[0], n_seeds = tot[1];
+    if ((rc = meme_buf_reserve(ctx, E[0], (size_t)(n_chains + 1) * 16)) || (rc = meme_buf_reserve(ctx, E[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg))) ||
+        (rc = meme_buf_reserve(ctx, E[2], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[3], (size_t)(n + 1) * 8 * 6)) ||
+        (rc = meme_buf_reserve(ctx, E[8], 64))) return rc;
+    ExtArgs A;
+    memset(&A, 0, sizeof(A));
+    A.reads = (const uint8_t*)ctx->reads.p; A.read_off = (const i64*)ctx->read_off.p; A.g0 = 0; A.ns = n;
+    A.chain_off = d_choff; A.chains = (const meme_chain*)B[6].p; A.seed_off = d_sdoff; A.seeds = (const meme_chain_seed*)B[7].p; A.frac_rep = (const float*)B[3].p;
+    A.pac = ctx->idx.pac; A.l_pac = copt->l_pac;
+    A.contig_off = (const i64*)B[4].p; A.contig_len = (const int*)((unsigned char*)B[4].p + (size_t)n_contigs * 8);
+    A.o = *eopt;
+    A.rmax = (i64*)E[0].p; A.regs = (meme_alnreg*)E[1].p; A.order = (int*)E[2].p;
+    i64* d_cnt = (i64*)E[3].p;
+    i64* d_off = d_cnt + 3 * (n + 1);
+    A.cntL = d_cnt; A.cntR = d_cnt + (n + 1); A.cntB = d_cnt + 2 * (n + 1);
+    // ---- plan: spans, job and byte counts of every read, their scans
+    hipLaunchKernelGGL((k_ext_jobs<false>), dim3((unsigned)n), dim3(64), 0, ctx->stream, A);
+    for (int k = 0; k < 3; ++k) if ((rc = meme_scan_exclusive(ctx, d_cnt + k * (n + 1), d_off + k * (n + 1), n))) return rc;
+    std::vector<i64> h_off((size_t)(3 * (n + 1)));
+    HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, h_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const i64* oL = h_off.data();
+    const i64* oR = oL + (n + 1);
+    const i64* oB = oR + (n + 1);
+    meme_bsw_opt bl, br;
+    memset(&bl, 0, sizeof(bl));
+    bl.o_del = eopt->o_del; bl.e_del = eopt->e_del; bl.o_ins = eopt->o_ins; bl.e_ins = eopt->e_ins; bl.zdrop = eopt->zdrop; bl.a = eopt->a; bl.b = eopt->b;
+    br = bl;
+    bl.end_bonus = eopt->pen_clip5;                   // bswLeft / bswRight, src/bwamem.cpp:2953-2959
+    br.end_bonus = eopt->pen_clip3;
+    unsigned long long* d_nretry = (unsigned long long*)E[8].p;
+    i64 n_pairs = 0, n_retried = 0, n_calls = 0;
+    float bsw_ms = 0.f;
+    // ---- slabs of reads whose jobs' sequences fit 32-bit offsets (SeqPair::idr / idq)
+    const i64 SLAB_BYTES = (i64)3 << 29, SLAB_JOBS = 8 << 20;
+    for (i64 g0 = 0; g0 < n;) {
+        i64 g1 = g0 + 1;
+        while (g1 < n && oB[g1 + 1] - oB[g0] <= SLAB_BYTES && oL[g1 + 1] - oL[g0] <= SLAB_JOBS && oR[g1 + 1] - oR[g0] <= SLAB_JOBS) {
+            i64 step = 1;                               // gallop to the slab's end
+            while (g1 + 2 * step < n && oB[g1 + 2 * step + 1] - oB[g0] <= SLAB_BYTES && oL[g1 + 2 * step + 1] - oL[g0] <= SLAB_JOBS &&
+                   oR[g1 + 2 * step + 1] - oR[g0] <= SLAB_JOBS) step *= 2;
+            g1 += step;
+        }
+        if (oB[g1] - oB[g0] >= ((i64)1 << 31)) { meme_set_error("a read's extension jobs need more than 2 GiB of sequence"); return MEME_E_CAPACITY; }
+        const i64 nL = oL[g1] - oL[g0], nR = oR[g1] - oR[g0], nB = oB[g1] - oB[g0];
+        const i64 nmax = nL > nR ? nL : nR;
+        if ((rc = meme_buf_reserve(ctx, E[4], (size_t)(nL + 1) * sizeof(meme_seqpair))) || (rc = meme_buf_reserve(ctx, E[5], (size_t)(nR + 1) * sizeof(meme_seqpair))) ||
+            (rc = meme_buf_reserve(ctx, E[6], (size_t)(2 * nmax + 2) * sizeof(meme_seqpair))) || (rc = meme_buf_reserve(ctx, E[7], (size_t)nB + 256))) return rc;
+        ExtArgs S = A;
+        S.g0 = g0; S.ns = g1 - g0;
+        // (the scans cover the whole batch: a slab's first read has its own offsets to subtract)
+        S.offL = d_off + g0; S.offR = d_off + (n + 1) + g0; S.offB = d_off + 2 * (n + 1) + g0;
+        S.job0L = oL[g0]; S.job0R = oR[g0]; S.byte0 = oB[g0];
+        S.L = (meme_seqpair*)E[4].p; S.R = (meme_seqpair*)E[5].p; S.seq = (uint8_t*)E[7].p;
+        hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)(g1 - g0)), dim3(64), 0, ctx->stream, S);
+        HIP_TRY(hipGetLastError());
+        for (int dir = 0; dir < 2; ++dir) {
+            meme_seqpair* P = dir == 0 ? S.L : S.R;
+            i64 np = dir == 0 ? nL : nR;
+            if (dir == 1 && np > 0) hipLaunchKernelGGL(k_ext_h0, dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, P, np, (const meme_alnreg*)A.regs);
+            for (int attempt = 0; attempt < EXT_BAND_TRIES && np > 0; ++attempt) {
+                const int w = eopt->w << attempt;
+                if ((rc = meme_bsw_launch(ctx, P, S.seq, S.seq, (int)np, w, dir == 0 ? &bl : &br, (int)ctx->last_seed_max_len))) return rc;
+                HIP_TRY(hipMemsetAsync(d_nretry, 0, 8, ctx->stream));
+                FoldArgs F;
+                F.pairs = P; F.n = np; F.regs = A.regs; F.chains = A.chains; F.seed_off = A.seed_off; F.seeds = A.seeds; F.read_off = A.read_off;
+                F.o = *eopt; F.w = w; F.last = attempt + 1 == EXT_BAND_TRIES;
+                F.retry = (meme_seqpair*)E[6].p + (size_t)(attempt & 1) * (size_t)(nmax + 1); F.n_retry = d_nretry;
+                if (dir == 0) hipLaunchKernelGGL((k_ext_fold<true>), dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, F);
+                else hipLaunchKernelGGL((k_ext_fold<false>), dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, F);
+                unsigned long long h_retry = 0;
+                HIP_TRY(hipMemcpyAsync(&h_retry, d_nretry, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) bsw_ms += ms; }
+                n_pairs += np; ++n_calls;
+                if (attempt > 0) n_retried += np;
+                P = F.retry;
+                np = (i64)h_retry;
+            }
+        }
+        g0 = g1;
+    }
+    // ---- purge, then the records to the host
+    PurgeArgs P;
+    P.read_off = A.read_off; P.nreads = n; P.chain_off = A.chain_off; P.chains = A.chains; P.seed_off = A.seed_off; P.seeds = A.seeds;
+    P.regs = A.regs; P.order = A.order; P.o = *eopt;
+    hipLaunchKernelGGL(k_ext_purge, dim3((unsigned)n), dim3(64), 0, ctx->stream, P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+    meme_ctx::HostBuf* Hb = ctx->h_ext;
+    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg)))) return rc;
+    HIP_TRY(hipMemcpyAsync(Hb[0].p, d_sdoff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_seeds) HIP_TRY(hipMemcpyAsync(Hb[1].p, A.regs, (size_t)n_seeds * sizeof(meme_alnreg), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out->nreads = n; out->reg_off = (const int64_t*)Hb[0].p; out->regs = (const meme_alnreg*)Hb[1].p; out->total_regs = n_seeds;
+    out->total_chains = n_chains; out->n_pairs = n_pairs; out->n_retried = n_retried; out->n_bsw_calls = n_calls;
+    out->n_tier2 = ctx->chain_tier2_reads; out->chain_ms = ctx->tm.chain_kernel_ms; out->ext_ms = ms; out->bsw_ms = bsw_ms;
+    return MEME_OK;
+}

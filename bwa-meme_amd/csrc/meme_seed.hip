@@ -518,5 +518,6 @@ extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const i
     out->total_smems = res.total_smems;
     out->total_hits = res.total_hits;
     ctx->last_seed_reads = nreads;
+    ctx->last_seed_max_len = max_len;
     return MEME_OK;
 }

@@ -49,7 +49,7 @@ class Contig(C.Structure):
 class ChainHostResult(C.Structure):
     _fields_ = [("nreads", C.c_int64), ("chain_off", C.c_void_p), ("chains", C.c_void_p), ("seed_off", C.c_void_p), ("seeds", C.c_void_p),
                 ("tree_size", C.c_void_p), ("frac_rep", C.c_void_p), ("fallback", C.c_void_p), ("total_chains", C.c_int64),
-                ("total_seeds", C.c_int64), ("n_fallback", C.c_int64)]
+                ("total_seeds", C.c_int64), ("n_fallback", C.c_int64), ("n_tier2", C.c_int64)]
 
 
 CHAIN = np.dtype({"names": ["pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"],
@@ -81,7 +81,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -250,6 +250,23 @@ class Context:
         arr = (Contig * len(contigs))(*[Contig(int(o), int(l), int(a)) for o, l, a in contigs])
         res = ChainHostResult()
         _check(lib().meme_chain_last_batch_host(C.c_void_p(self.h), arr, C.c_int32(len(contigs)), C.byref(opt), C.byref(res)))
+        return self._chain_result(res)
+
+    def chain_batch_host(self, smems, smem_off, hits, hit_off, read_len, contigs, opt):
+        """meme_chain_batch_host: chains of seeds the caller brings (numpy arrays laid out as seed_batch_host returns them)."""
+        arr = (Contig * len(contigs))(*[Contig(int(o), int(l), int(a)) for o, l, a in contigs])
+        smems = np.ascontiguousarray(smems, dtype=MEM_TL)
+        smem_off = np.ascontiguousarray(smem_off, dtype=np.int64)
+        hits = np.ascontiguousarray(hits, dtype=np.uint64)
+        hit_off = np.ascontiguousarray(hit_off, dtype=np.int64)
+        read_len = np.ascontiguousarray(read_len, dtype=np.int32)
+        res = ChainHostResult()
+        _check(lib().meme_chain_batch_host(C.c_void_p(self.h), _p(smems), _p(smem_off), _p(hits), _p(hit_off), _p(read_len), C.c_int64(read_len.shape[0]),
+                                           arr, C.c_int32(len(contigs)), C.byref(opt), C.byref(res)))
+        return self._chain_result(res)
+
+    @staticmethod
+    def _chain_result(res):
         n = res.nreads
 
         def view(ptr, count, dtype):
@@ -260,7 +277,7 @@ class Context:
         return {"chain_off": view(res.chain_off, n + 1, np.int64), "chains": view(res.chains, res.total_chains, CHAIN),
                 "seed_off": view(res.seed_off, n + 1, np.int64), "seeds": view(res.seeds, res.total_seeds, CHAIN_SEED),
                 "tree_size": view(res.tree_size, n, np.int32), "frac_rep": view(res.frac_rep, n, np.float32),
-                "fallback": view(res.fallback, n, np.uint8), "n_fallback": int(res.n_fallback)}
+                "fallback": view(res.fallback, n, np.uint8), "n_fallback": int(res.n_fallback), "n_tier2": int(res.n_tier2)}
 
     def seed_batch_device(self, d_reads_ptr, d_read_off_ptr, nreads, total_bases, opt=None) -> SeedResult:
         opt = opt or default_seed_opt()

@@ -12,6 +12,7 @@
  *                                      (outputs: mem_tl records + hit positions, the inputs of the unchanged
  *                                       host consumer mem_chain_Learned(), src/bwamem.cpp:1122-1204)
  *   meme_chain_last_batch_host      <- mem_chain_Learned() + mem_chain_flt()          src/bwamem.cpp:1122-1204, 599-717
+ *   meme_extend_last_batch_host     <- mem_chain2aln_across_reads_V2()              src/bwamem.cpp:2573-3497 (behind the chaining stage)
  *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
  *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
  *
@@ -170,9 +171,9 @@ int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_bases);
  * meme_seed_batch_host() call on this ctx has seeded -- the SMEMs and hits are still in HBM.  Per read: the chains that survive
  * the filter, in the filter's output order, each with its seeds in chain order (seed score = seed length, as mem_chain_Learned
  * sets it).  tree_size[r] = number of chains before the filter (what the reference sizes chain_ar[r] with); frac_rep[r] as
- * mem_chain_Learned computes it.  fallback[r] != 0: the read does not fit the device scratch (more than 128 chains, a chain of
- * more than 32 seeds, more than 256 SMEMs or 8 192 hits to walk) or would insert two chains at one position (B-tree order of equal keys): it has no
- * chains here and the caller chains it with the reference's host functions.  Results live in pinned buffers of the ctx until
+ * mem_chain_Learned computes it.  Every read is chained on the device (reads with many chains, long chains, hundreds of hits to walk
+ * or chains at equal positions by a wavefront-per-read tier that keeps the reference's B-tree, src/kbtree.h): fallback[r] is always 0
+ * and n_fallback == 0 (the fields remain for ABI stability).  Results live in pinned buffers of the ctx until
  * the next call.  meme_contig = the fields of bntann1_t the stage needs (src/bntseq.h). */
 typedef struct { int64_t offset; int32_t len; int32_t is_alt; } meme_contig;
 typedef struct {
@@ -192,9 +193,42 @@ typedef struct {
     const float* frac_rep;
     const uint8_t* fallback;
     int64_t total_chains, total_seeds, n_fallback;
+    int64_t n_tier2;                 /* reads chained by the wavefront-per-read tier (repeats, equal positions) */
 } meme_chain_host_result;
 int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt,
                                meme_chain_host_result* out);
+/* The same for seeds the caller brings (host arrays laid out as meme_seed_batch_host returns them; read_len[r] = length of read r). */
+int meme_chain_batch_host(meme_ctx* ctx, const meme_mem_tl* smems, const int64_t* smem_off, const uint64_t* hits, const int64_t* hit_off,
+                          const int32_t* read_len, int64_t nreads, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt,
+                          meme_chain_host_result* out);
+
+/* ---- seed extension of the batch just seeded ----------------------------------------------------------------------------------
+ * mem_chain2aln_across_reads_V2() (reference src/bwamem.cpp:2573-3497) for every read of the batch the last meme_seed_batch_host() call
+ * on this ctx has seeded, behind the chaining stage above and without leaving HBM in between: per chained seed one alignment record in
+ * the reference's extension order (chain after chain, best seed of a chain first), left and right banded extensions with the band
+ * doubled once where the reference doubles it (MAX_BAND_TRY 2), records of seeds an earlier alignment already covers marked qb = qe = -1
+ * (:3389-3485).  regs[reg_off[r] .. reg_off[r+1]) = what the reference leaves in av_v[r] (n = m = the number of chained seeds).
+ * meme_alnreg = mem_alnreg_t (src/bwamem.h:143-165, 112 bytes); its `c` (a chain pointer in the reference, dead after the stage)
+ * holds the chain's index in the batch.  Reads are at most 500 bases here, so mem_flt_chained_seeds (src/bwamem.cpp:565-598) between
+ * the two stages is the no-op it is in the reference; callers that set min_chain_weight must run that filter themselves. */
+typedef struct {
+    int64_t rb, re; int32_t qb, qe; int32_t rid; int32_t pad0; uint64_t c;
+    int32_t score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0;
+    int32_t n_comp_is_alt;        /* n_comp:30, is_alt:2 */
+    float frac_rep; int32_t pad1; uint64_t hash; int32_t flg; int32_t pad2;
+} meme_alnreg;
+typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop; } meme_ext_opt;   /* mem_opt_t fields of the same names */
+typedef struct {
+    int64_t nreads;
+    const int64_t* reg_off;          /* nreads+1 */
+    const meme_alnreg* regs;
+    int64_t total_regs, total_chains;
+    int64_t n_pairs, n_retried, n_bsw_calls;   /* extension jobs run, of which with the doubled band; backend launches */
+    int64_t n_tier2;                 /* reads chained by the wavefront-per-read tier */
+    float chain_ms, ext_ms, bsw_ms;  /* HIP-event times: chaining kernels; the extension stage (incl. its host round trips); of which banded SW */
+} meme_ext_host_result;
+int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* chain_opt,
+                                const meme_ext_opt* ext_opt, meme_ext_host_result* out);
 
 /* Same with inputs and outputs resident in HBM (pointers valid until the next call on this ctx).
  * d_reads must be 4-byte aligned (any hipMalloc'ed pointer is); total_bases = read_off[nreads] = bytes in d_reads. */

@@ -856,3 +856,50 @@ int orc_chain_read(const orc_mem_tl* smems_in, int n_smems, const uint64_t* hits
     free(sm);
     return rc ? rc : n;
 }
+
+/* Batched checker: the chains of every read of a batch (flat arrays as meme_chain_last_batch_host returns them; dev_* = what the
+ * device computed) against orc_chain_read, on `threads` OpenMP threads.  Returns the number of reads that differ in any field of any
+ * chain or seed, in tree size or in frac_rep; *first_bad = the first such read (-1 if none). */
+typedef struct { int64_t pos; int32_t rid, n_seeds, w, first; int16_t kept, is_alt; int32_t seed_beg, pad; } orc_dev_chain;   /* = meme_chain */
+int64_t orc_chain_compare_batch(const orc_mem_tl* smems, const int64_t* smem_off, const uint64_t* hits, const int64_t* hit_off, const int32_t* read_len,
+                                int64_t nreads, const int64_t* contig_off, const uint8_t* contig_alt, int n_contigs, const orc_chain_opt* o,
+                                const int64_t* dev_chain_off, const orc_dev_chain* dev_chains, const int64_t* dev_seed_off, const orc_cseed* dev_seeds,
+                                const int32_t* dev_tree, const float* dev_frac, int threads, int64_t* first_bad) {
+    int64_t n_bad = 0, first = -1, r;
+    if (threads < 1) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads) reduction(+ : n_bad)
+    for (r = 0; r < nreads; ++r) {
+        const int ns = (int)(smem_off[r + 1] - smem_off[r]);
+        int64_t work = 0;
+        int i, cap, rc, tree = 0, bad = 0;
+        float frac = 0.f;
+        orc_chain* ch; orc_cseed* sd;
+        for (i = 0; i < ns; ++i) work += smems[smem_off[r] + i].hitcount < o->max_occ ? smems[smem_off[r] + i].hitcount : o->max_occ;
+        cap = (int)(work + 8);
+        ch = (orc_chain*)malloc(sizeof(orc_chain) * (size_t)cap);
+        sd = (orc_cseed*)malloc(sizeof(orc_cseed) * (size_t)cap);
+        rc = orc_chain_read(smems + smem_off[r], ns, hits + hit_off[r], read_len[r], contig_off, contig_alt, n_contigs, o, ch, cap, sd, cap, &tree, &frac);
+        if (rc < 0 || rc != dev_chain_off[r + 1] - dev_chain_off[r] || tree != dev_tree[r]) bad = 1;
+        else {
+            const orc_dev_chain* d = dev_chains + dev_chain_off[r];
+            const orc_cseed* ds = dev_seeds + dev_seed_off[r];
+            int k, j, nsd = 0;
+            if (rc > 0 && memcmp(&frac, &dev_frac[r], 4) != 0) bad = 1;
+            for (k = 0; k < rc && !bad; ++k) {
+                if (d[k].pos != ch[k].pos || d[k].rid != ch[k].rid || d[k].n_seeds != ch[k].n_seeds || d[k].w != ch[k].w || d[k].first != ch[k].first ||
+                    d[k].kept != ch[k].kept || d[k].is_alt != ch[k].is_alt || d[k].seed_beg != ch[k].seed_beg) bad = 1;
+                for (j = 0; j < ch[k].n_seeds && !bad; ++j, ++nsd)
+                    if (ds[nsd].rbeg != sd[nsd].rbeg || ds[nsd].qbeg != sd[nsd].qbeg || ds[nsd].len != sd[nsd].len) bad = 1;
+            }
+            if (!bad && nsd != dev_seed_off[r + 1] - dev_seed_off[r]) bad = 1;
+        }
+        free(ch); free(sd);
+        if (bad) {
+            n_bad += 1;
+#pragma omp critical
+            { if (first < 0 || r < first) first = r; }
+        }
+    }
+    *first_bad = first;
+    return n_bad;
+}

@@ -31,3 +31,20 @@ for it in range(3):
     print("[chain probe] %d reads: seeding call %.1f ms (%.1f M reads/s incl. transfers), chaining call %.1f ms (%.1f M reads/s incl. transfers + numpy copies); "
           "%d chains, %d chained seeds, %d reads left to the host" % (nreads, (t1 - t0) * 1e3, nreads / (t1 - t0) / 1e6, (t2 - t1) * 1e3, nreads / (t2 - t1) / 1e6,
                                                                       res["chains"].shape[0], res["seeds"].shape[0], res["n_fallback"]), flush=True)
+# ---- distribution of the per-read work (what the second pass has to cope with) ----
+hc = np.minimum(smems["hitcount"].astype(np.int64), 500)
+cs = np.concatenate([[0], np.cumsum(hc)])
+work = cs[so[1:]] - cs[so[:-1]]
+ns = np.diff(so)
+tree = res["tree_size"]
+def pct(a):
+    return " ".join("%s=%d" % (p, np.percentile(a, p)) for p in (50, 90, 99, 99.9, 99.99, 100))
+print("[chain probe] work per read (sampled hits walked): " + pct(work))
+print("[chain probe] SMEMs per read: " + pct(ns))
+print("[chain probe] chains before the filter: " + pct(tree))
+for lim in (16, 32, 64, 128, 256, 1024):
+    print("[chain probe] reads with more than %d chains: %d; with work > %d: %d" % (lim, int((tree > lim).sum()), lim * 8, int((work > lim * 8).sum())))
+tm = ctx.timings()
+print("[chain probe] chain kernels %.2f ms, of which second pass %.2f ms" % (tm.chain_kernel_ms, tm.chain_pass2_ms))
+big = np.argsort(work)[-10:]
+print("[chain probe] ten heaviest reads: work", work[big].tolist(), "smems", ns[big].tolist(), "chains", tree[big].tolist())

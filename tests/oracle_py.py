@@ -218,3 +218,26 @@ def chain_read(smems, hits, read_len, contig_off, contig_alt, opt, chain_cap=409
     n = max(rc, 0)
     ns = int(out["n_seeds"][:n].sum())
     return rc, out[:n], sd[:ns], tree.value, frac.value
+
+
+def chain_compare_batch(smems, smem_off, hits, hit_off, read_len, contig_off, contig_alt, opt, res, threads=0):
+    """orc_chain_compare_batch: every read of a device chaining result (the dict hipapi's chain calls return) against orc_chain_read.
+    Returns (number of differing reads, first differing read or -1)."""
+    L = lib()
+    L.orc_chain_compare_batch.restype = C.c_int64
+    smems = np.ascontiguousarray(smems, dtype=MEM_TL_DTYPE)
+    smem_off = np.ascontiguousarray(smem_off, dtype=np.int64)
+    hits = np.ascontiguousarray(hits, dtype=np.uint64)
+    hit_off = np.ascontiguousarray(hit_off, dtype=np.int64)
+    read_len = np.ascontiguousarray(read_len, dtype=np.int32)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_alt = np.ascontiguousarray(contig_alt, dtype=np.uint8)
+    ch = np.ascontiguousarray(res["chains"]); sd = np.ascontiguousarray(res["seeds"])
+    assert ch.dtype.itemsize == 40 and sd.dtype.itemsize == 16
+    co = np.ascontiguousarray(res["chain_off"], dtype=np.int64); so = np.ascontiguousarray(res["seed_off"], dtype=np.int64)
+    tree = np.ascontiguousarray(res["tree_size"], dtype=np.int32); frac = np.ascontiguousarray(res["frac_rep"], dtype=np.float32)
+    first = C.c_int64(-1)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    nbad = L.orc_chain_compare_batch(p(smems), p(smem_off), p(hits), p(hit_off), p(read_len), C.c_int64(read_len.shape[0]), p(contig_off), p(contig_alt),
+                                     C.c_int(contig_off.shape[0]), C.byref(opt), p(co), p(ch), p(so), p(sd), p(tree), p(frac), C.c_int(threads), C.byref(first))
+    return int(nbad), int(first.value)

@@ -155,3 +155,51 @@ def test_chain_oracle_edge_cases():
     sm = np.concatenate([smem(0, 30, 0, 1), smem(60, 90, 1, 1)])
     rc, ch, sd, tree, frac = O.chain_read(sm, np.array([1000, 3000], np.uint64), 100, off, alt, opt, chain_cap=1)
     assert rc == -2
+
+
+def _fixture_as_device_result(G):
+    """The reference's chains of a fixture in the layout the device returns (meme_chain / meme_chain_seed records)."""
+    import numpy as np
+    from pymeme import hipapi
+    n = G["read_len"].shape[0]
+    ch = np.zeros(G["chains"].shape[0], hipapi.CHAIN)
+    for k, f in enumerate(("pos", "rid", "n_seeds", "w", "kept", "first", "is_alt")):
+        ch[f] = G["chains"][:, k]
+    seed_off = G["seed_off"] if "seed_off" in G else None
+    if seed_off is None:                                     # chain_golden.npz stores a global seed_beg per chain
+        seed_off = np.zeros(n + 1, np.int64)
+        per_chain = G["chains"][:, 2]
+        cs = np.concatenate([[0], np.cumsum(per_chain)])
+        seed_off[1:] = cs[G["chain_off"][1:]]
+        ch["seed_beg"] = G["chains"][:, 7] - np.repeat(seed_off[:-1], np.diff(G["chain_off"]))
+    else:
+        ch["seed_beg"] = G["chains"][:, 7]
+    sd = np.zeros(G["seeds"].shape[0], hipapi.CHAIN_SEED)
+    sd["rbeg"], sd["qbeg"], sd["len"] = G["seeds"].T
+    return {"chains": ch, "seeds": sd, "chain_off": G["chain_off"], "seed_off": seed_off, "tree_size": G["tree_size"],
+            "frac_rep": G["frac_rep_bits"].view(np.float32)}
+
+
+def test_batched_chain_checker_accepts_the_reference_and_sees_a_flipped_field():
+    """orc_chain_compare_batch (what bench.py and the -m gpu tests check whole batches with) on both fixtures: the reference's chains
+    pass; one changed field, one changed seed and one changed tree size are each reported."""
+    import numpy as np
+    for name in ("chain_golden.npz", "chain_dup_golden.npz"):
+        G = np.load(os.path.join(GOLDEN, name))
+        res = _fixture_as_device_result(G)
+        sm = np.zeros(G["smems"].shape[0], O.MEM_TL_DTYPE)
+        sm["start"], sm["end"], sm["hitbeg"], sm["hitcount"] = G["smems"].T
+        alt = G["contig_alt"] if "contig_alt" in G else np.zeros(G["contig_off"].shape[0], np.uint8)
+        opt = O.default_chain_opt(int(G["l_pac"]))
+        args = (sm, G["smem_off"], G["hits"], G["hit_off"], G["read_len"], G["contig_off"], alt, opt)
+        assert O.chain_compare_batch(*args, res) == (0, -1), name
+        r = int(np.nonzero(np.diff(G["chain_off"]) > 1)[0][3])
+        bad = dict(res, chains=res["chains"].copy())
+        bad["chains"]["w"][int(G["chain_off"][r]) + 1] += 1
+        assert O.chain_compare_batch(*args, bad) == (1, r)
+        bad = dict(res, seeds=res["seeds"].copy())
+        bad["seeds"]["qbeg"][int(res["seed_off"][r])] += 1
+        assert O.chain_compare_batch(*args, bad) == (1, r)
+        bad = dict(res, tree_size=res["tree_size"].copy())
+        bad["tree_size"][r] += 1
+        assert O.chain_compare_batch(*args, bad) == (1, r)
