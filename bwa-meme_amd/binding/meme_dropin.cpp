@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 #include <sched.h>
 #include <time.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -139,6 +140,7 @@ __attribute__((constructor)) void meme_dropin_early_start() {
 // Worker buffers exactly as the reference sizes them (they are indexed by the kt_for thread id all over
 // mem_chain2aln_across_reads_V2 and freed by process(), src/fastmap.cpp:1098-1110); the host-side index expansion is gone.
 void ext_prepare(int64_t chunk_reads, int threads);       // defined with the extension stage below
+int ext_mode();
 
 uint8_t bitrev8(uint8_t b) {
     b = (uint8_t)(((b & 0xF0) >> 4) | ((b & 0x0F) << 4));
@@ -208,11 +210,22 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     w.useLearned = 1;
     const double t1 = now_s();
     const char* prefix = getenv("MEME_INDEX_PREFIX") ? getenv("MEME_INDEX_PREFIX") : idx_prefix;
-    std::thread prep(ext_prepare, (int64_t)nreads, (int)nthreads);             // pinned staging + helper threads, while the index loads
+    if (strcmp(prefix, idx_prefix) != 0)
+        fprintf(stderr, "[meme-dropin] note: the HBM index comes from MEME_INDEX_PREFIX=%s, bns / pac / .0123 from %s (checked below: same number of suffixes)\n", prefix, idx_prefix);
+    std::thread prep([nreads, nthreads] { if (ext_mode() == 1) ext_prepare((int64_t)nreads, (int)nthreads); });   // host stage: pinned staging + helper threads, while the index loads
     if (g_early_prefix && strcmp(g_early_prefix, prefix) != 0) { fprintf(stderr, "[meme-dropin] MEME_INDEX_PREFIX changed after start-up\n"); exit(1); }
     init_devices(prefix, (int64_t)nreads);                                       // (returns at once when the early load below has done it)
     if (g_early) { g_early->join(); delete g_early; g_early = nullptr; }
     prep.join();
+    {   // the suffix array in HBM must describe the genome whose bns / pac the aligner loaded
+        meme_index_arrays ia;
+        if (meme_index_describe(g_dev[0].seed, &ia)) die("meme_index_describe");
+        if (ia.sa_num != 2 * l_pac) {
+            fprintf(stderr, "[meme-dropin] the index staged from %s has %lld suffixes, the reference sequence of %s needs %lld: wrong MEME_INDEX_PREFIX?\n", prefix,
+                    (long long)ia.sa_num, idx_prefix, (long long)(2 * l_pac));
+            exit(1);
+        }
+    }
     fprintf(stderr, "[meme-dropin] worker buffers + fwd/rc text %.2f s, HBM index %.2f s (no host-side index expansion)\n",
             t1 - t0, now_s() - t1);
 }
@@ -223,7 +236,9 @@ namespace {
 struct ChunkPart {                     // the slice of a chunk one GPU seeded
     int64_t first = 0, count = 0;
     meme_seed_host_result res;
-    meme_chain_host_result chains;                       // valid when g_chain_on_device
+    meme_chain_host_result chains;                       // valid when g_chain_on_device (host extension stage)
+    meme_ext_host_result ext;                            // valid in device-extension mode: alignment records of the part's reads
+    bool has_ext = false;
     uint8_t* flat = nullptr; int64_t flat_cap = 0;       // pinned staging (grow-only)
     int64_t* off = nullptr; int64_t off_cap = 0;
 };
@@ -235,6 +250,21 @@ struct Chunk {
 
 const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process_seqs)
 std::vector<meme_contig> g_contigs;
+// MEME_DROPIN_EXT: "device" (default) = chaining AND seed extension on the GPU, the host receives alignment records;
+// "host" = chains from the device, extension jobs built / folded / purged by the binding's thread team (round 2's arrangement, and
+// what runs when -W min_chain_weight makes mem_flt_chained_seeds more than a no-op); "0" = the reference's own per-batch function.
+int ext_mode() {
+    static const int v = [] {
+        const char* e = getenv("MEME_DROPIN_EXT");
+        if (!e || !strcmp(e, "device") || !strcmp(e, "2")) return 2;
+        if (!strcmp(e, "0")) return 0;
+        return 1;
+    }();
+    return v;
+}
+bool g_ext_on_device = false;           // decided per run in mem_process_seqs (needs opt)
+std::atomic<double> g_t_ext_dev{0}, g_t_ext_chain_ms{0}, g_t_ext_ms{0}, g_t_ext_bsw_ms{0};
+std::atomic<int64_t> g_n_ext_pairs{0}, g_n_ext_retried{0}, g_n_ext_regs{0}, g_n_ext_tier2{0};
 bool chain_on_device() { static const bool v = !(getenv("MEME_DROPIN_CHAIN") && atoi(getenv("MEME_DROPIN_CHAIN")) == 0); return v; }
 bool chain_check() { static const bool v = getenv("MEME_DROPIN_CHAIN_CHECK") != nullptr; return v; }
 // MEME_DROPIN_CHAIN_DUMP=<file> (fixture generation, tests/golden/make_chain_golden.py): every read's seeds and the chains the
@@ -270,6 +300,23 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     const meme_seed_opt so = seed_opt_of(opt);
     if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
     memset(&P.chains, 0, sizeof(P.chains));
+    P.has_ext = false;
+    if (g_ext_on_device && P.count > 0) {                // chains + extension where the seeds lie: only alignment records come back
+        meme_chain_opt co;
+        co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;
+        co.min_chain_weight = opt->min_chain_weight; co.max_chain_extend = opt->max_chain_extend;
+        co.mask_level = opt->mask_level; co.drop_ratio = opt->drop_ratio; co.l_pac = g_bns->l_pac;
+        meme_ext_opt eo;
+        eo.a = opt->a; eo.b = opt->b; eo.o_del = opt->o_del; eo.e_del = opt->e_del; eo.o_ins = opt->o_ins; eo.e_ins = opt->e_ins;
+        eo.pen_clip5 = opt->pen_clip5; eo.pen_clip3 = opt->pen_clip3; eo.w = opt->w; eo.zdrop = opt->zdrop;
+        const double t0 = now_s();
+        if (meme_extend_last_batch_host(g_dev[(size_t)d].seed, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, &P.ext)) die("meme_extend_last_batch_host");
+        g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
+        g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
+        g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
+        P.has_ext = true;
+        return;
+    }
     if (chain_on_device() && P.count > 0) {              // mem_chain_Learned + mem_chain_flt while the seeds are still in HBM
         meme_chain_opt co;
         co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;
@@ -304,6 +351,7 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n) {
 }
 
 int g_team = 1;                        // kt_for worker threads of the run (opt->n_threads)
+mem_chain_v* g_chunk_chain_ar = nullptr;   // w.chain_ar of the chunk being processed: every batch's chain_ar is a slice of it
 uint64_t g_chunk_gen = 0;               // counts the chunks seeded
 
 typedef void (*process_fn)(mem_opt_t*, int64_t, int, bseq1_t*, const mem_pestat_t*, worker_t&);
@@ -325,7 +373,14 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         g_bns = w.fmi->idx->bns;
         for (int i = 0; i < g_bns->n_seqs; ++i) g_contigs.push_back({g_bns->anns[i].offset, g_bns->anns[i].len, g_bns->anns[i].is_alt});
     }
-    if (w.useLearned) { seed_chunk(opt, seqs, n); ++g_chunk_gen; }
+    if (w.useLearned) {
+        // mem_flt_chained_seeds (src/bwamem.cpp:565-598) sits between chaining and extension; it is a no-op unless
+        // 1.1 * min_chain_weight <= 0.05 * read length (never with the default min_chain_weight 0 and reads of at most 500 bases)
+        g_ext_on_device = ext_mode() == 2 && opt->min_chain_weight == 0;
+        g_chunk_chain_ar = w.chain_ar;
+        seed_chunk(opt, seqs, n);
+        ++g_chunk_gen;
+    }
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
     if (verbose())
@@ -333,10 +388,15 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
                 "(copy-in thread-seconds %.3f, backend calls %.3f s of which kernels %.3f s)\n",
                 (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs,
                 (double)g_t_bsw_gather, (double)g_t_bsw_call, (double)g_t_bsw_kernel);
-    if (verbose() && chain_on_device())
-        fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead (scratch capacity / equal positions)\n",
+    if (verbose() && g_ext_on_device)
+        fprintf(stderr, "[meme-dropin] chaining + extension on the device: %.3f s in the backend calls so far (HIP events: chaining %.3f s, extension stage %.3f s of "
+                "which banded SW %.3f s); %lld alignment records, %lld extension jobs (%lld of them again with the doubled band), %lld reads chained by the "
+                "wavefront-per-read tier, 0 reads chained on the host\n", (double)g_t_ext_dev, (double)g_t_ext_chain_ms * 1e-3, (double)g_t_ext_ms * 1e-3,
+                (double)g_t_ext_bsw_ms * 1e-3, (long long)g_n_ext_regs, (long long)g_n_ext_pairs, (long long)g_n_ext_retried, (long long)g_n_ext_tier2);
+    if (verbose() && !g_ext_on_device && chain_on_device())
+        fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead\n",
                 (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
-    if (verbose()) ext_report();
+    if (verbose() && !g_ext_on_device) ext_report();
     if (verbose() && getenv("MEME_DROPIN_PROFILE_SAM")) meme_dropin_report_matesw();
 }
 
@@ -449,6 +509,10 @@ int mem_kernel1_core_Learned(const mem_opt_t* opt, const bntseq_t* bns, const ui
     static_assert(sizeof(meme_mem_tl) == sizeof(mem_tl), "mem_tl layout");
     const int64_t g0 = seq_ - g_chunk.seqs;                   // this batch's position in the chunk seeded above
     if (!g_chunk.seqs || g0 < 0 || g0 + nseq > g_chunk.n) { fprintf(stderr, "[meme-dropin] batch outside the seeded chunk\n"); exit(1); }
+    if (g_ext_on_device) {                                       // the chains stay in HBM: worker_aln takes the alignment records
+        for (int l = 0; l < nseq; ++l) kv_init(chain_ar[l]);
+        return 1;
+    }
     int64_t seedBufCount = 0, n_fb = 0;
     static thread_local mem_seed_t* check_buf = nullptr;
     for (int l = 0; l < nseq; ++l) {
@@ -1059,10 +1123,7 @@ int64_t ext_slab_reads() {
     static const int64_t v = getenv("MEME_DROPIN_EXT_SLAB") && atoll(getenv("MEME_DROPIN_EXT_SLAB")) > 0 ? atoll(getenv("MEME_DROPIN_EXT_SLAB")) : 262144;
     return v;
 }
-bool ext_enabled() {
-    static const bool v = !(getenv("MEME_DROPIN_EXT") && atoi(getenv("MEME_DROPIN_EXT")) == 0);
-    return v;
-}
+bool ext_enabled() { return ext_mode() != 0; }
 // first guess of a slab's staging (3 jobs per read and direction; a job's target is the query side plus the gap allowance);
 // a slab that needs more is rebuilt once with the exact sizes
 void ext_size_for(int64_t reads, int64_t read_len) {
@@ -1173,7 +1234,7 @@ void ext_report() {
 }
 
 void ext_prepare(int64_t chunk_reads, int threads) {
-    if (!ext_enabled() || g_ext) return;
+    if (ext_mode() == 0 || g_ext) return;
     g_ext = new Ext;
     g_ext->team.ensure(team_helpers(threads));
     // pinned memory needs a HIP context; device 0's is created here if init_devices() has not got there yet
@@ -1185,7 +1246,7 @@ typedef void (*chain2aln_fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, 
 
 void mem_chain2aln_across_reads_V2(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
                                    mem_chain_v* chain_ar, mem_alnreg_v* av_v, mem_cache* mmc, uint8_t* ref_string, int tid) {
-    if (!ext_enabled() || !g_chunk.seqs) {
+    if (ext_mode() == 0 || !g_chunk.seqs) {
         static chain2aln_fn next = (chain2aln_fn)dlsym(RTLD_NEXT, "_Z29mem_chain2aln_across_reads_V2PK9mem_opt_tPK8bntseq_tPKhP7bseq1_tiP11mem_chain_vP12mem_alnreg_vP9mem_cachePhi");
         if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_chain2aln_across_reads_V2 was not found\n"); exit(1); }
         next(opt, bns, pac, seq_, nseq, chain_ar, av_v, mmc, ref_string, tid);
@@ -1193,7 +1254,33 @@ void mem_chain2aln_across_reads_V2(const mem_opt_t* opt, const bntseq_t* bns, co
     }
     const int64_t g0 = seq_ - g_chunk.seqs;
     if (g0 < 0 || g0 + nseq > g_chunk.n) { fprintf(stderr, "[meme-dropin] batch outside the chunk\n"); exit(1); }
-    if (!g_ext) { fprintf(stderr, "[meme-dropin] extension stage used before memoryAllocLearned\n"); exit(1); }
+    if (g_ext_on_device) {                                 // the records the device made of this batch's reads (:2633: the reference owns them from here on)
+        static_assert(sizeof(meme_alnreg) == sizeof(mem_alnreg_t), "mem_alnreg_t layout");
+        static_assert(offsetof(meme_alnreg, c) == offsetof(mem_alnreg_t, c) && offsetof(meme_alnreg, score) == offsetof(mem_alnreg_t, score) &&
+                      offsetof(meme_alnreg, seedlen0) == offsetof(mem_alnreg_t, seedlen0) && offsetof(meme_alnreg, frac_rep) == offsetof(mem_alnreg_t, frac_rep) &&
+                      offsetof(meme_alnreg, hash) == offsetof(mem_alnreg_t, hash) && offsetof(meme_alnreg, flg) == offsetof(mem_alnreg_t, flg), "mem_alnreg_t layout");
+        for (int l = 0; l < nseq; ++l) {
+            const int64_t g = g0 + l;
+            const ChunkPart* P = nullptr;
+            for (const ChunkPart& c : g_chunk.part) if (g >= c.first && g < c.first + c.count) { P = &c; break; }
+            if (!P || !P->has_ext) { fprintf(stderr, "[meme-dropin] no alignment records for a read of the chunk\n"); exit(1); }
+            const int64_t r = g - P->first, b = P->ext.reg_off[r], m = P->ext.reg_off[r + 1] - b;
+            mem_alnreg_t* a = (mem_alnreg_t*)calloc((size_t)m, sizeof(mem_alnreg_t));
+            if (m) {
+                if (!a) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+                memcpy(a, P->ext.regs + b, (size_t)m * sizeof(mem_alnreg_t));
+                for (int64_t i = 0; i < m; ++i) a[i].c = nullptr;                  // (held the chain's index; dead after the stage)
+            }
+            av_v[l].n = (size_t)m; av_v[l].m = (size_t)m; av_v[l].a = a;
+        }
+        return;
+    }
+    if (chain_ar - g0 != g_chunk_chain_ar) { fprintf(stderr, "[meme-dropin] the batch's chains are not a slice of the chunk's chain array\n"); exit(1); }
+    {
+        static std::mutex prep_mu;                              // (device mode skips the host stage's set-up; -W brings the run back here)
+        std::lock_guard<std::mutex> lk(prep_mu);
+        if (!g_ext) ext_prepare(g_chunk.n, g_team);
+    }
     {
         std::lock_guard<std::mutex> lk(g_ext->mu);                             // the first batch to arrive extends the whole chunk
         if (g_ext->gen != g_chunk_gen) {

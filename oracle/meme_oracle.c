@@ -903,3 +903,177 @@ int64_t orc_chain_compare_batch(const orc_mem_tl* smems, const int64_t* smem_off
     *first_bad = first;
     return n_bad;
 }
+
+/* ---- seed extension: mem_chain2aln_across_reads_V2 (reference src/bwamem.cpp:2573-3497), one read at a time ----------------------
+ * The reference works through a 512-read batch stage by stage (all left extensions of the batch in its 8-bit / 16-bit / scalar
+ * SIMD classes, then the band retries, then the right extensions ...); per read that is: one record per chained seed in extension
+ * order, left extension (band w, once more with 2w when the result touches the band edge and changed the score), right extension
+ * likewise from the left result's score, then the purge of records an earlier record of the read explains.  The classes compute the
+ * same function (pinned: tests/test_oracle_golden.py), so their batching does not show in the result. */
+#define O_H0 (-99)                                            /* H0_, src/macro.h:44 */
+static int o_max_gap(const orc_ext_opt* o, int qlen) {        /* cal_max_gap, :85-95 */
+    const int l_del = (int)((double)(qlen * o->a - o->o_del) / o->e_del + 1.);
+    const int l_ins = (int)((double)(qlen * o->a - o->o_ins) / o->e_ins + 1.);
+    int l = l_del > l_ins ? l_del : l_ins;
+    l = l > 1 ? l : 1;
+    return l < o->w << 1 ? l : o->w << 1;
+}
+static void o_seedcov(orc_alnreg* a, const orc_cseed* sd, int n) {   /* :2907-2917 */
+    int i, cov = 0;
+    if (a->rb == O_H0 || a->qb == O_H0 || a->qe == O_H0 || a->re == O_H0) return;
+    for (i = 0; i < n; ++i)
+        if (sd[i].qbeg >= a->qb && sd[i].qbeg + sd[i].len <= a->qe && sd[i].rbeg >= a->rb && sd[i].rbeg + sd[i].len <= a->re) cov += sd[i].len;
+    a->seedcov = cov;
+}
+static int o_u64_cmp(const void* a, const void* b) { const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : x > y; }
+
+int orc_extend_read(const uint8_t* read, int l_query, const orc_chain* chains, int n_chains, const orc_cseed* seeds, float frac_rep,
+                    const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o,
+                    orc_alnreg* out, int64_t* n_jobs, int64_t* n_retried) {
+    int c, i, k, n_reg = 0, total = 0, max_n = 1, kept = 0, cur = 0;
+    orc_bsw_params bl, br;
+    uint64_t* srt;
+    int* ord;                                                 /* per chain: seed indices in ascending (score, index) order; -1 = purged */
+    uint8_t *qs, *rs;
+    for (c = 0; c < n_chains; ++c) { total += chains[c].n_seeds; if (chains[c].n_seeds > max_n) max_n = chains[c].n_seeds; }
+    memset(&bl, 0, sizeof(bl));
+    bl.o_del = o->o_del; bl.e_del = o->e_del; bl.o_ins = o->o_ins; bl.e_ins = o->e_ins; bl.zdrop = o->zdrop; bl.a = o->a; bl.b = o->b;
+    br = bl;
+    bl.end_bonus = o->pen_clip5; br.end_bonus = o->pen_clip3;  /* bswLeft / bswRight, :2953-2959 */
+    srt = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)max_n);
+    ord = (int*)malloc(sizeof(int) * (size_t)(total + 1));
+    qs = (uint8_t*)malloc((size_t)l_query + 8);
+    rs = NULL;
+    for (c = 0; c < n_chains; ++c) {
+        const orc_chain* ch = &chains[c];
+        const orc_cseed* sd = seeds + ch->seed_beg;
+        int64_t rmax0 = l_pac << 1, rmax1 = 0, far_beg, far_end;
+        int* co = ord + ch->seed_beg;
+        if (ch->n_seeds == 0) continue;
+        for (i = 0; i < ch->n_seeds; ++i) {                   /* the widest span any seed may reach (:2648-2666) */
+            const int64_t b = sd[i].rbeg - (sd[i].qbeg + o_max_gap(o, sd[i].qbeg));
+            const int tail = l_query - sd[i].qbeg - sd[i].len;
+            const int64_t e = sd[i].rbeg + sd[i].len + (tail + o_max_gap(o, tail));
+            if (b < rmax0) rmax0 = b;
+            if (e > rmax1) rmax1 = e;
+        }
+        if (rmax0 < 0) rmax0 = 0;
+        if (rmax1 > l_pac << 1) rmax1 = l_pac << 1;
+        if (rmax0 < l_pac && l_pac < rmax1) { if (sd[0].rbeg < l_pac) rmax1 = l_pac; else rmax0 = l_pac; }
+        far_beg = contig_off[ch->rid]; far_end = far_beg + contig_len[ch->rid];      /* bns_fetch_seq_v2, src/bntseq.cpp:492-501 */
+        if (sd[0].rbeg >= l_pac) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+        if (rmax0 < far_beg) rmax0 = far_beg;
+        if (rmax1 > far_end) rmax1 = far_end;
+        rs = (uint8_t*)realloc(rs, (size_t)(rmax1 - rmax0) + 8);
+        for (i = 0; i < ch->n_seeds; ++i) srt[i] = (uint64_t)sd[i].len << 32 | (uint32_t)i;      /* score = length; keys unique */
+        qsort(srt, (size_t)ch->n_seeds, 8, o_u64_cmp);
+        for (i = 0; i < ch->n_seeds; ++i) co[i] = (int)(uint32_t)srt[i];
+        for (k = ch->n_seeds - 1; k >= 0; --k) {              /* best seed first (:2702-2850) */
+            const orc_cseed* s = &sd[co[k]];
+            orc_alnreg* a = &out[n_reg++];
+            int side;
+            memset(a, 0, sizeof(*a));
+            a->w = o->w; a->score = a->truesc = -1; a->rid = ch->rid; a->frac_rep = frac_rep; a->seedlen0 = s->len;
+            a->rb = a->re = O_H0; a->qb = a->qe = O_H0;
+            if (s->qbeg) { a->qb = s->qbeg; a->rb = s->rbeg; }
+            else { a->score = a->truesc = s->len * o->a; a->qb = 0; a->rb = s->rbeg; }
+            if (s->qbeg + s->len != l_query) { a->qe = s->qbeg + s->len; a->re = s->rbeg + s->len; }
+            else { a->qe = l_query; a->re = s->rbeg + s->len; o_seedcov(a, sd, ch->n_seeds); }
+            for (side = 0; side < 2; ++side) {                /* left, then right from the left result's score (:3371-3376) */
+                int len1, len2, h0, attempt, j;
+                if (side == 0 && !s->qbeg) continue;
+                if (side == 1 && s->qbeg + s->len == l_query) continue;
+                if (side == 0) {                              /* both sequences run away from the seed */
+                    len2 = s->qbeg; len1 = (int)(s->rbeg - rmax0); h0 = s->len * o->a;
+                    for (j = 0; j < len2; ++j) qs[j] = read[s->qbeg - 1 - j];
+                    for (j = 0; j < len1; ++j) rs[j] = text[s->rbeg - 1 - j];
+                } else {
+                    const int qe = s->qbeg + s->len;
+                    len2 = l_query - qe; len1 = (int)(rmax1 - (s->rbeg + s->len)); h0 = a->score;
+                    memcpy(qs, read + qe, (size_t)len2);
+                    memcpy(rs, text + s->rbeg + s->len, (size_t)len1);
+                }
+                for (attempt = 0; attempt < 2; ++attempt) {   /* MAX_BAND_TRY (:62); fold: :2985-3018 and siblings */
+                    const int w = o->w << attempt, prev = a->score;
+                    int qle, tle, gtle, gscore, max_off;
+                    if (n_jobs) ++*n_jobs;
+                    if (attempt && n_retried) ++*n_retried;
+                    a->score = orc_bsw_extend(len2, qs, len1, rs, w, h0, side ? &br : &bl, &qle, &tle, &gtle, &gscore, &max_off, NULL);
+                    if (a->score == prev || max_off < (w >> 1) + (w >> 2) || attempt == 1) {
+                        if (side == 0) {
+                            if (gscore <= 0 || gscore <= a->score - o->pen_clip5) { a->qb -= qle; a->rb -= tle; a->truesc = a->score; }
+                            else { a->qb = 0; a->rb -= gtle; a->truesc = gscore; }
+                        } else {
+                            if (gscore <= 0 || gscore <= a->score - o->pen_clip3) { a->qe += qle; a->re += tle; a->truesc += a->score - h0; }
+                            else { a->qe = l_query; a->re += gtle; a->truesc += gscore - h0; }
+                        }
+                        a->w = a->w > w ? a->w : w;
+                        o_seedcov(a, sd, ch->n_seeds);
+                        break;
+                    }
+                }
+            }
+        }
+    }
+    /* purge (:3389-3485), in the same order */
+    for (c = 0; c < n_chains; ++c) {
+        const orc_chain* ch = &chains[c];
+        const orc_cseed* sd = seeds + ch->seed_beg;
+        int* co = ord + ch->seed_beg;
+        for (k = ch->n_seeds - 1; k >= 0; --k, ++cur) {
+            const orc_cseed* s = &sd[co[k]];
+            int v = 0;
+            for (i = 0; i < n_reg && v < kept; ++i) {
+                const orc_alnreg* p = &out[i];
+                int qd, max_gap, band;
+                int64_t rd;
+                if (p->qb == -1 && p->qe == -1) continue;
+                if (s->rbeg < p->rb || s->rbeg + s->len > p->re || s->qbeg < p->qb || s->qbeg + s->len > p->qe) { ++v; continue; }
+                if (s->len - p->seedlen0 > .1 * l_query) { ++v; continue; }
+                qd = s->qbeg - p->qb; rd = s->rbeg - p->rb;
+                max_gap = o_max_gap(o, qd < rd ? qd : (int)rd);
+                band = max_gap < p->w ? max_gap : p->w;
+                if (qd - rd < band && rd - qd < band) break;
+                qd = p->qe - (s->qbeg + s->len); rd = p->re - (s->rbeg + s->len);
+                max_gap = o_max_gap(o, qd < rd ? qd : (int)rd);
+                band = max_gap < p->w ? max_gap : p->w;
+                if (qd - rd < band && rd - qd < band) break;
+                ++v;
+            }
+            if (v < kept) {
+                int u;
+                for (u = k + 1; u < ch->n_seeds; ++u) {
+                    const orc_cseed* t;
+                    if (co[u] < 0) continue;
+                    t = &sd[co[u]];
+                    if (t->len < s->len * .95) continue;
+                    if (s->qbeg <= t->qbeg && s->qbeg + s->len - t->qbeg >= s->len >> 2 && t->qbeg - s->qbeg != t->rbeg - s->rbeg) break;
+                    if (t->qbeg <= s->qbeg && t->qbeg + t->len - s->qbeg >= s->len >> 2 && s->qbeg - t->qbeg != s->rbeg - t->rbeg) break;
+                }
+                if (u == ch->n_seeds) { out[cur].qb = out[cur].qe = -1; co[k] = -1; continue; }
+            }
+            ++kept;
+        }
+    }
+    free(srt); free(ord); free(qs); free(rs);
+    return n_reg;
+}
+
+/* batch form: reads flat, chains / seeds flat with per-read offsets (seed_beg relative to the read's first seed); out[seed_off[r] + i] */
+int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const orc_chain* chains,
+                     const int64_t* seed_off, const orc_cseed* seeds, const float* frac_rep, const uint8_t* text, int64_t l_pac,
+                     const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats) {
+    int64_t r, jobs = 0, retried = 0;
+    int bad = 0;
+    if (threads < 1) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : jobs, retried) reduction(| : bad)
+    for (r = 0; r < nreads; ++r) {
+        int64_t j = 0, t = 0;
+        const int n = orc_extend_read(reads + read_off[r], (int)(read_off[r + 1] - read_off[r]), chains + chain_off[r], (int)(chain_off[r + 1] - chain_off[r]),
+                                      seeds + seed_off[r], frac_rep[r], text, l_pac, contig_off, contig_len, o, out + seed_off[r], &j, &t);
+        if (n != seed_off[r + 1] - seed_off[r]) bad = 1;
+        jobs += j; retried += t;
+    }
+    if (stats) { stats[0] = jobs; stats[1] = retried; }
+    return bad ? -1 : 0;
+}

@@ -103,6 +103,22 @@ int orc_chain_read(const orc_mem_tl* smems, int n_smems, const uint64_t* hits, i
                    const uint8_t* contig_alt, int n_contigs, const orc_chain_opt* o, orc_chain* out, int chain_cap,
                    orc_cseed* seeds_out, int seed_cap, int* tree_size, float* frac_rep);
 
+/* ---- seed extension (mem_chain2aln_across_reads_V2, reference src/bwamem.cpp:2573-3497) ------------------------------------------- */
+typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop; } orc_ext_opt;
+typedef struct {                 /* the fields of mem_alnreg_t the stage sets (src/bwamem.h:143-165) */
+    int64_t rb, re; int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
+    float frac_rep; int32_t pad;
+} orc_alnreg;
+/* One read: its chains (as orc_chain_read returns them; seed_beg indexes `seeds`) -> one record per chained seed in extension order
+ * (chain after chain, best seed of a chain first), purged records marked qb = qe = -1.  text = fwd+rc codes, 1 byte per base.
+ * Returns the number of records; *n_jobs / *n_retried count the banded-SW calls and those with the doubled band. */
+int orc_extend_read(const uint8_t* read, int l_query, const orc_chain* chains, int n_chains, const orc_cseed* seeds, float frac_rep,
+                    const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o,
+                    orc_alnreg* out, int64_t* n_jobs, int64_t* n_retried);
+int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const orc_chain* chains,
+                     const int64_t* seed_off, const orc_cseed* seeds, const float* frac_rep, const uint8_t* text, int64_t l_pac,
+                     const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats);
+
 #ifdef __cplusplus
 }
 #endif

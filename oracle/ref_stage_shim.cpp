@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "bwamem.h"      // reference headers, found via -I$(REF)/src at build time
 #include "bwa.h"
@@ -99,6 +100,91 @@ int ref_chain_read(const mem_tl* smems_in, int n_smems, const uint64_t* hits_in,
     for (int k = 0; k < n; ++k) if (chn.a[k].m > SEEDS_PER_CHAIN) free(chn.a[k].seeds);
     free(chn.a); free(seedBuf); free(smems.a); free(hits.a); free(opt);
     return rc;
+}
+
+
+// ---- mem_chain2aln_across_reads_V2 on chains the caller brings --------------------------------------------------------------------
+// reads: concatenated codes 0..4 with read_off[nreads+1]; chains / seeds flat with chain_off / seed_off per read (seed_beg relative to the
+// read's first seed, as ref_chain_read and the device return them); text0123: the fwd+rc text, 1 byte per base (= the reference's
+// ref_string).  Output: per read the records the reference leaves in av_v (reg_off[r] = seed_off[r]: one record per chained seed).
+struct shim_ext_opt { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_clip5, pen_clip3, w, zdrop; };
+struct shim_alnreg {        // the fields of mem_alnreg_t the stage sets
+    int64_t rb, re; int32_t qb, qe, rid, score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0, n_comp, is_alt;
+    float frac_rep; int32_t pad;
+};
+
+int ref_extend_reads(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const shim_chain* chains,
+                     const int64_t* seed_off, const shim_cseed* seeds, const uint32_t* frac_rep_bits, uint8_t* text0123,
+                     const int64_t* contig_off, const int32_t* contig_len, const uint8_t* contig_alt, int n_contigs, int64_t l_pac,
+                     const shim_ext_opt* eo, shim_alnreg* out) {
+    mem_opt_t* opt = mem_opt_init();
+    opt->a = eo->a; opt->b = eo->b; opt->o_del = eo->o_del; opt->e_del = eo->e_del; opt->o_ins = eo->o_ins; opt->e_ins = eo->e_ins;
+    opt->pen_clip5 = eo->pen_clip5; opt->pen_clip3 = eo->pen_clip3; opt->w = eo->w; opt->zdrop = eo->zdrop;
+    bwa_fill_scmat(opt->a, opt->b, opt->mat);
+    Bns bns(contig_off, contig_len, contig_alt, n_contigs, l_pac);
+    // worker buffers as memoryAllocLearned sizes them for one thread (src/fastmap.cpp:351-420)
+    static mem_cache mmc;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const int64_t wsize = BATCH_SIZE * SEEDS_PER_READ;
+        mmc.seqBufLeftRef[0] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64);
+        mmc.seqBufLeftQer[0] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_QER + MAX_LINE_LEN, 64);
+        mmc.seqBufRightRef[0] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_REF + MAX_LINE_LEN, 64);
+        mmc.seqBufRightQer[0] = (uint8_t*)_mm_malloc((size_t)wsize * MAX_SEQ_LEN_QER + MAX_LINE_LEN, 64);
+        mmc.wsize_buf_ref[0] = wsize * MAX_SEQ_LEN_REF;
+        mmc.wsize_buf_qer[0] = wsize * MAX_SEQ_LEN_QER;
+        mmc.seqPairArrayAux[0] = (SeqPair*)malloc((size_t)(wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+        mmc.seqPairArrayLeft128[0] = (SeqPair*)malloc((size_t)(wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+        mmc.seqPairArrayRight128[0] = (SeqPair*)malloc((size_t)(wsize + MAX_LINE_LEN) * sizeof(SeqPair));
+        mmc.wsize[0] = wsize;
+        mmc.lim[0] = (int32_t*)_mm_malloc((BATCH_SIZE + 32) * sizeof(int32_t), 64);
+    }
+    for (int64_t g0 = 0; g0 < nreads; g0 += BATCH_SIZE) {
+        const int nseq = (int)(nreads - g0 < BATCH_SIZE ? nreads - g0 : BATCH_SIZE);
+        std::vector<bseq1_t> seq((size_t)nseq);
+        std::vector<mem_chain_v> chn((size_t)nseq);
+        std::vector<mem_alnreg_v> av((size_t)nseq);
+        for (int l = 0; l < nseq; ++l) {
+            const int64_t r = g0 + l;
+            memset(&seq[l], 0, sizeof(bseq1_t));
+            seq[l].l_seq = (int)(read_off[r + 1] - read_off[r]);
+            seq[l].seq = (char*)(reads + read_off[r]);
+            kv_init(chn[l]);
+            memset(&av[l], 0, sizeof(mem_alnreg_v));
+            const int64_t c0 = chain_off[r], nc = chain_off[r + 1] - c0;
+            chn[l].n = chn[l].m = (size_t)nc;
+            chn[l].a = (mem_chain_t*)calloc((size_t)(nc ? nc : 1), sizeof(mem_chain_t));
+            for (int64_t k = 0; k < nc; ++k) {
+                const shim_chain& sc = chains[c0 + k];
+                mem_chain_t& c = chn[l].a[k];
+                c.seqid = l; c.n = c.m = sc.n_seeds; c.first = sc.first; c.rid = sc.rid; c.w = (uint32_t)sc.w; c.kept = (uint32_t)sc.kept;
+                c.is_alt = (uint32_t)sc.is_alt; memcpy(&c.frac_rep, &frac_rep_bits[r], 4); c.pos = sc.pos;
+                c.seeds = (mem_seed_t*)calloc((size_t)sc.n_seeds, sizeof(mem_seed_t));
+                for (int j = 0; j < sc.n_seeds; ++j) {
+                    const shim_cseed& sd = seeds[seed_off[r] + sc.seed_beg + j];
+                    c.seeds[j].rbeg = sd.rbeg; c.seeds[j].qbeg = sd.qbeg; c.seeds[j].len = sd.len; c.seeds[j].score = sd.len;
+                }
+            }
+        }
+        mem_chain2aln_across_reads_V2(opt, &bns.b, text0123 /* pac: unused when ref_string is given */, seq.data(), nseq, chn.data(), av.data(), &mmc, text0123, 0);
+        for (int l = 0; l < nseq; ++l) {
+            const int64_t r = g0 + l;
+            if ((int64_t)av[l].n != seed_off[r + 1] - seed_off[r]) return -1;
+            for (size_t i = 0; i < av[l].n; ++i) {
+                const mem_alnreg_t& a = av[l].a[i];
+                shim_alnreg& o = out[seed_off[r] + (int64_t)i];
+                o.rb = a.rb; o.re = a.re; o.qb = a.qb; o.qe = a.qe; o.rid = a.rid; o.score = a.score; o.truesc = a.truesc; o.sub = a.sub; o.alt_sc = a.alt_sc;
+                o.csub = a.csub; o.sub_n = a.sub_n; o.w = a.w; o.seedcov = a.seedcov; o.secondary = a.secondary; o.secondary_all = a.secondary_all;
+                o.seedlen0 = a.seedlen0; o.n_comp = a.n_comp; o.is_alt = a.is_alt; o.frac_rep = a.frac_rep; o.pad = 0;
+            }
+            free(av[l].a);
+            for (size_t k = 0; k < chn[l].n; ++k) free(chn[l].a[k].seeds);
+            free(chn[l].a);
+        }
+    }
+    free(opt);
+    return 0;
 }
 
 }  // extern "C"

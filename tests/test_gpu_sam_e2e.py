@@ -60,11 +60,13 @@ def test_sam_identical_to_reference(tmp_path, paired):
     # chain or seed is fatal; MEME_DROPIN_CHAIN=0 keeps chaining on the host, MEME_DROPIN_IO=1 lets the binding parse the two
     # FASTQ files on two threads.
     small = {}
-    for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}),
-                                  (8, 100000000, {"MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
+    # Round 3: the DEFAULT is chaining + extension on the device (meme_extend_last_batch_host: the host only receives alignment records);
+    # MEME_DROPIN_EXT=host is the arrangement described above, kept for -W runs and as a cross-check.
+    for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}), (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
+                                  (8, 100000000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
-                                  (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
-                                  (4, 100000000, {"MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
+                                  (8, 400000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_VIRTUAL": "3"}),
+                                  (4, 100000000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
         env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", **extra)
         got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
         if chunk == 100000000: ref = want
