@@ -330,7 +330,15 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                 info["backend"] = {"seeding_s": float(m.group(1)), "bsw_calls": int(m.group(3)), "bsw_pairs": int(m.group(4)),
                                    "bsw_backend_s": float(m.group(6)), "bsw_kernel_s": float(m.group(7))}
             for m in re.finditer(r"extension: this chunk .*?totals ([0-9.]+) s, (\d+) backend calls", err):
-                info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # jobs built + calls + fold + purge
+                info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # host stage (MEME_DROPIN_EXT=host): jobs built + calls + fold + purge
+            for m in re.finditer(r"chaining \+ extension on the device: ([0-9.]+) s in the backend calls so far \(HIP events: chaining ([0-9.]+) s, extension stage "
+                                 r"([0-9.]+) s of which banded SW ([0-9.]+) s\); (\d+) alignment records, (\d+) extension jobs \((\d+) of them again with the doubled "
+                                 r"band\), (\d+) reads chained by the wavefront-per-read tier, (\d+) reads chained on the host", err):
+                info.setdefault("backend", {}).update({
+                    "extension_stage_s": float(m.group(1)),     # wall of the chaining + extension calls (kernels, their host round trips, D2H of the records)
+                    "chain_kernels_s": float(m.group(2)), "ext_kernels_s": float(m.group(3)), "bsw_kernel_s": float(m.group(4)),
+                    "alignment_records": int(m.group(5)), "bsw_pairs": int(m.group(6)), "bsw_pairs_doubled_band": int(m.group(7)),
+                    "reads_chained_on_host": int(m.group(9))})
             out[exe] = info
             if exe == "bwa-meme_mode3" and refcache is not None:
                 refcache.put(ckey, info)

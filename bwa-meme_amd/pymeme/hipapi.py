@@ -52,6 +52,27 @@ class ChainHostResult(C.Structure):
                 ("total_seeds", C.c_int64), ("n_fallback", C.c_int64), ("n_tier2", C.c_int64)]
 
 
+class ExtOpt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "zdrop")]
+
+
+class ExtHostResult(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("reg_off", C.c_void_p), ("regs", C.c_void_p), ("total_regs", C.c_int64), ("total_chains", C.c_int64),
+                ("n_pairs", C.c_int64), ("n_retried", C.c_int64), ("n_bsw_calls", C.c_int64), ("n_tier2", C.c_int64), ("chain_ms", C.c_float),
+                ("ext_ms", C.c_float), ("bsw_ms", C.c_float)]
+
+
+def default_ext_opt(w=100):
+    # mem_opt_init (reference src/bwamem.cpp:126-162): a 1, b 4, o_del = o_ins 6, e_del = e_ins 1, pen_clip5 = pen_clip3 5, w 100, zdrop 100
+    return ExtOpt(1, 4, 6, 1, 6, 1, 5, 5, w, 100)
+
+
+# = meme_alnreg = mem_alnreg_t (112 bytes)
+ALNREG = np.dtype({"names": ["rb", "re", "qb", "qe", "rid", "c", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary",
+                             "secondary_all", "seedlen0", "n_comp_is_alt", "frac_rep", "hash", "flg"],
+                   "formats": ["<i8", "<i8", "<i4", "<i4", "<i4", "<u8"] + ["<i4"] * 12 + ["<f4", "<u8", "<i4"],
+                   "offsets": [0, 8, 16, 20, 24, 32] + [40 + 4 * k for k in range(12)] + [88, 96, 104], "itemsize": 112})
+
 CHAIN = np.dtype({"names": ["pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"],
                   "formats": ["<i8", "<i4", "<i4", "<i4", "<i4", "<i2", "<i2", "<i4"], "offsets": [0, 8, 12, 16, 20, 24, 26, 28], "itemsize": 40})
 CHAIN_SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
@@ -81,7 +102,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -251,6 +272,24 @@ class Context:
         res = ChainHostResult()
         _check(lib().meme_chain_last_batch_host(C.c_void_p(self.h), arr, C.c_int32(len(contigs)), C.byref(opt), C.byref(res)))
         return self._chain_result(res)
+
+    def extend_last_batch_host(self, contigs, chain_opt, ext_opt=None):
+        """meme_extend_last_batch_host on the batch the last seed_batch_host call seeded: chaining + seed extension on the device.
+        Returns {"reg_off", "regs" (ALNREG records, copies), stats...}."""
+        ext_opt = ext_opt or default_ext_opt()
+        arr = (Contig * len(contigs))(*[Contig(int(o), int(l), int(a)) for o, l, a in contigs])
+        res = ExtHostResult()
+        _check(lib().meme_extend_last_batch_host(C.c_void_p(self.h), arr, C.c_int32(len(contigs)), C.byref(chain_opt), C.byref(ext_opt), C.byref(res)))
+        n = res.nreads
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return {"reg_off": view(res.reg_off, n + 1, np.int64), "regs": view(res.regs, res.total_regs, ALNREG), "total_chains": int(res.total_chains),
+                "n_pairs": int(res.n_pairs), "n_retried": int(res.n_retried), "n_bsw_calls": int(res.n_bsw_calls), "n_tier2": int(res.n_tier2),
+                "chain_ms": float(res.chain_ms), "ext_ms": float(res.ext_ms), "bsw_ms": float(res.bsw_ms)}
 
     def chain_batch_host(self, smems, smem_off, hits, hit_off, read_len, contigs, opt):
         """meme_chain_batch_host: chains of seeds the caller brings (numpy arrays laid out as seed_batch_host returns them)."""

@@ -58,3 +58,71 @@ def chain_golden_workload():
             reads.append(np.ascontiguousarray(r[:L], dtype=np.uint8))
             k += 1
     return g, reads
+
+
+def gap_reads(g, n, seed):
+    """Reads with an 80-95-base deletion or insertion next to a long exact stretch: the extension touches the band edge and is run
+    again with the doubled band (src/bwamem.cpp:2985-3018)."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        p = int(rng.integers(1000, g.shape[0] - 2000))
+        d = int(rng.integers(80, 96))
+        if rng.random() < 0.5:
+            r = np.concatenate([g[p:p + 110], g[p + 110 + d:p + 110 + d + 140]])
+        else:
+            r = np.concatenate([g[p:p + 90], rng.integers(0, 4, size=d).astype(np.uint8), g[p + 90:p + 90 + 160 - d]])
+        r = r[:250].copy()
+        if rng.random() < 0.5:
+            r = (3 - r[::-1]).astype(np.uint8)
+        rows.append(np.ascontiguousarray(r, dtype=np.uint8))
+    return rows
+
+
+def ext_golden_inputs():
+    """Inputs of tests/golden/ext_golden.npz: the reads of the chain fixture + 300 gap reads, and their chains -- for the first 2 800
+    reads the chains of tests/golden/chain_golden.npz (made by the compiled reference), for the gap reads the oracle's chains of the
+    oracle's seeds (both pinned on the reference elsewhere).  Everything in the flat layout the batch calls use."""
+    import oracle_py as O
+    from pymeme import hipapi
+    g, reads = chain_golden_workload()
+    G = np.load(os.path.join(GOLDEN, "chain_golden.npz"))
+    text = hipapi.fwd_rc_text(g)
+    l_pac = int(G["l_pac"])
+    n0 = len(reads)
+    chains0 = np.zeros(G["chains"].shape[0], O.ORC_CHAIN_DTYPE)
+    for k, f in enumerate(("pos", "rid", "n_seeds", "w", "kept", "first", "is_alt")):
+        chains0[f] = G["chains"][:, k]
+    per_chain = G["chains"][:, 2]
+    cs = np.concatenate([[0], np.cumsum(per_chain)])
+    seed_off0 = cs[G["chain_off"]]
+    chains0["seed_beg"] = G["chains"][:, 7] - np.repeat(seed_off0[:-1], np.diff(G["chain_off"]))
+    seeds0 = np.zeros(G["seeds"].shape[0], O.ORC_CSEED_DTYPE)
+    seeds0["rbeg"], seeds0["qbeg"], seeds0["len"] = G["seeds"].T
+    frac0 = G["frac_rep_bits"].view(np.float32)
+    # gap reads: seeds and chains from the oracle (index = plain suffix array of the fixture's text)
+    extra = gap_reads(g, 300, seed=205)
+    from pymeme import hostapi
+    _, sa = hostapi.build_sa(g)
+    idx = O.Index(text, sa)
+    eoff = np.zeros(len(extra) + 1, np.int64)
+    eoff[1:] = np.cumsum([len(r) for r in extra])
+    sm, nsm, hits, nh, _ = O.seed_batch(idx, np.concatenate(extra), eoff, smem_cap=512, hit_cap=1 << 14)
+    copt = O.default_chain_opt(l_pac)
+    alt = np.zeros(G["contig_off"].shape[0], np.uint8)
+    ch_list, sd_list, frac1, coff1, soff1 = [], [], [], [0], [0]
+    for r in range(len(extra)):
+        rc, ch, sd, tree, frac = O.chain_read(sm[r, :nsm[r]], hits[r, :nh[r]], len(extra[r]), G["contig_off"], alt, copt)
+        assert rc >= 0
+        ch_list.append(ch); sd_list.append(sd); frac1.append(frac)
+        coff1.append(coff1[-1] + rc); soff1.append(soff1[-1] + sd.shape[0])
+    allreads = reads + extra
+    read_off = np.zeros(len(allreads) + 1, np.int64)
+    read_off[1:] = np.cumsum([len(r) for r in allreads])
+    chains = np.concatenate([chains0] + ch_list)
+    seeds = np.concatenate([seeds0] + sd_list)
+    chain_off = np.concatenate([G["chain_off"], G["chain_off"][-1] + np.array(coff1[1:], np.int64)])
+    seed_off = np.concatenate([seed_off0, seed_off0[-1] + np.array(soff1[1:], np.int64)])
+    return {"genome": g, "reads_list": allreads, "reads": np.concatenate(allreads), "read_off": read_off, "chain_off": chain_off, "chains": chains,
+            "seed_off": seed_off, "seeds": seeds, "frac_rep": np.concatenate([frac0, np.array(frac1, np.float32)]), "text": text, "l_pac": l_pac,
+            "contig_off": G["contig_off"], "contig_len": G["contig_len"], "n_fixture_reads": n0}

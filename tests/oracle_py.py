@@ -241,3 +241,51 @@ def chain_compare_batch(smems, smem_off, hits, hit_off, read_len, contig_off, co
     nbad = L.orc_chain_compare_batch(p(smems), p(smem_off), p(hits), p(hit_off), p(read_len), C.c_int64(read_len.shape[0]), p(contig_off), p(contig_alt),
                                      C.c_int(contig_off.shape[0]), C.byref(opt), p(co), p(ch), p(so), p(sd), p(tree), p(frac), C.c_int(threads), C.byref(first))
     return int(nbad), int(first.value)
+
+
+# ---- seed extension stage ---------------------------------------------------------------------------------------------------------
+class OrcExtOpt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_clip5", "pen_clip3", "w", "zdrop")]
+
+
+ORC_ALNREG_DTYPE = np.dtype([("rb", "<i8"), ("re", "<i8")] + [(n, "<i4") for n in ("qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w",
+                                                                                   "seedcov", "secondary", "secondary_all", "seedlen0", "n_comp", "is_alt")] +
+                            [("frac_rep", "<f4"), ("pad", "<i4")])
+assert ORC_ALNREG_DTYPE.itemsize == 88
+ALNREG_FIELDS = ("rb", "re", "qb", "qe", "rid", "score", "truesc", "sub", "alt_sc", "csub", "sub_n", "w", "seedcov", "secondary", "secondary_all", "seedlen0")
+
+
+def default_ext_opt(w=100):
+    return OrcExtOpt(1, 4, 6, 1, 6, 1, 5, 5, w, 100)
+
+
+def chains_as_orc(chains):
+    """meme_chain / fixture rows -> ORC_CHAIN_DTYPE records"""
+    out = np.zeros(chains.shape[0], ORC_CHAIN_DTYPE)
+    for f in ("pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"):
+        out[f] = chains[f]
+    return out
+
+
+def extend_batch(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, text, l_pac, contig_off, contig_len, opt=None, threads=0):
+    """orc_extend_batch: records of every read's chained seeds (ORC_ALNREG_DTYPE, indexed by seed_off) + (jobs, retried)."""
+    L = lib()
+    L.orc_extend_batch.restype = C.c_int
+    opt = opt or default_ext_opt()
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    chain_off = np.ascontiguousarray(chain_off, dtype=np.int64)
+    chains = np.ascontiguousarray(chains, dtype=ORC_CHAIN_DTYPE)
+    seed_off = np.ascontiguousarray(seed_off, dtype=np.int64)
+    seeds = np.ascontiguousarray(seeds, dtype=ORC_CSEED_DTYPE)
+    frac_rep = np.ascontiguousarray(frac_rep, dtype=np.float32)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+    out = np.zeros(int(seed_off[-1]), ORC_ALNREG_DTYPE)
+    stats = np.zeros(2, np.int64)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = L.orc_extend_batch(p(reads), p(read_off), C.c_int64(read_off.shape[0] - 1), p(chain_off), p(chains), p(seed_off), p(seeds), p(frac_rep), p(text),
+                            C.c_int64(int(l_pac)), p(contig_off), p(contig_len), C.byref(opt), p(out), C.c_int(threads), p(stats))
+    assert rc == 0
+    return out, (int(stats[0]), int(stats[1]))

@@ -1,0 +1,85 @@
+"""Seed extension on the device (meme_extend_last_batch_host = mem_chain2aln_across_reads_V2 behind the chaining kernels), through the
+C ABI, against the records the compiled reference made (tests/golden/ext_golden.npz) and against the oracle with other options."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+from common import GOLDEN, build_index, ext_golden_inputs
+from pymeme import hipapi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_records(tmp_path, I, ext_opt=None):
+    fa = str(tmp_path / "c.fa")
+    synth.write_fasta(fa, I["genome"], name="cg", contigs=3)
+    prefix = build_index(fa, bits=14)
+    ctx = hipapi.Context(0)
+    try:
+        ctx.load_index_files(prefix)
+        ctx.seed_batch_host(I["reads"], I["read_off"])
+        contigs = [(int(o), int(l), 0) for o, l in zip(I["contig_off"], I["contig_len"])]
+        return ctx.extend_last_batch_host(contigs, hipapi.default_chain_opt(I["l_pac"]), ext_opt)
+    finally:
+        ctx.close()
+
+
+def _assert_same(regs, want_cols_or_regs, frac_bits):
+    for k, f in enumerate(O.ALNREG_FIELDS):
+        want = want_cols_or_regs[:, k] if isinstance(want_cols_or_regs, np.ndarray) and want_cols_or_regs.dtype == np.int64 else want_cols_or_regs[f].astype(np.int64)
+        bad = np.nonzero(regs[f].astype(np.int64) != want)[0]
+        assert bad.size == 0, (f, int(bad[0]), int(regs[f][bad[0]]), int(want[bad[0]]))
+    assert np.array_equal(regs["frac_rep"].view(np.uint32), frac_bits)
+    assert not regs["n_comp_is_alt"].any() and not regs["hash"].any() and not regs["flg"].any()
+
+
+def test_device_records_equal_reference_golden(tmp_path):
+    I = ext_golden_inputs()
+    G = np.load(os.path.join(GOLDEN, "ext_golden.npz"))
+    R = _device_records(tmp_path, I)
+    assert np.array_equal(R["reg_off"], G["reg_off"])           # same chains, hence one record per chained seed in the same places
+    _assert_same(R["regs"], G["regs"], G["frac_rep_bits"])
+    assert R["n_retried"] > 300 and R["n_pairs"] > R["regs"].shape[0]
+    purged = (R["regs"]["qb"] == -1) & (R["regs"]["qe"] == -1)
+    assert int(purged.sum()) == int(((G["regs"][:, 2] == -1) & (G["regs"][:, 3] == -1)).sum()) > 5000
+
+
+@pytest.mark.parametrize("w,clip,zdrop", [(20, 5, 100), (100, 0, 30)])
+def test_device_records_equal_oracle_with_other_options(tmp_path, w, clip, zdrop):
+    I = ext_golden_inputs()
+    eo = hipapi.default_ext_opt(w)
+    eo.pen_clip5 = eo.pen_clip3 = clip
+    eo.zdrop = zdrop
+    oo = O.default_ext_opt(w)
+    oo.pen_clip5 = oo.pen_clip3 = clip
+    oo.zdrop = zdrop
+    R = _device_records(tmp_path, I, eo)
+    want, _ = O.extend_batch(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["frac_rep"], I["text"], I["l_pac"],
+                             I["contig_off"], I["contig_len"], oo)
+    assert np.array_equal(R["reg_off"], I["seed_off"])
+    _assert_same(R["regs"], want, want["frac_rep"].view(np.uint32))
+
+
+def test_extend_call_needs_a_seeded_batch_and_the_right_genome(tmp_path):
+    g = synth.make_genome(60_000, seed=9)
+    fa = str(tmp_path / "e.fa")
+    synth.write_fasta(fa, g, contigs=1)
+    prefix = build_index(fa, bits=12)
+    ctx = hipapi.Context(0)
+    try:
+        ctx.load_index_files(prefix)
+        with pytest.raises(hipapi.MemeError, match="no seeded batch"):
+            ctx.extend_last_batch_host([(0, 60_000, 0)], hipapi.default_chain_opt(60_000))
+        r, _, _ = synth.make_reads(g, 50, 100, seed=10)
+        ctx.seed_batch_host(r.reshape(-1), np.arange(0, 51 * 100, 100, dtype=np.int64))
+        with pytest.raises(hipapi.MemeError, match="l_pac does not match"):
+            ctx.extend_last_batch_host([(0, 50_000, 0)], hipapi.default_chain_opt(50_000))
+        res = ctx.extend_last_batch_host([(0, 60_000, 0)], hipapi.default_chain_opt(60_000))
+        assert res["reg_off"].shape[0] == 51 and res["reg_off"][-1] == res["regs"].shape[0] >= 40
+        a = res["regs"]
+        live = ~((a["qb"] == -1) & (a["qe"] == -1))
+        assert np.all(a["qe"][live] > a["qb"][live]) and np.all(a["re"][live] > a["rb"][live]) and np.all(a["score"][live] >= 19)
+    finally:
+        ctx.close()

@@ -203,3 +203,21 @@ def test_batched_chain_checker_accepts_the_reference_and_sees_a_flipped_field():
         bad = dict(res, tree_size=res["tree_size"].copy())
         bad["tree_size"][r] += 1
         assert O.chain_compare_batch(*args, bad) == (1, r)
+
+
+def test_ext_oracle_equals_reference_golden():
+    """orc_extend_batch (restatement of mem_chain2aln_across_reads_V2: job construction, banded SW, fold, band retry, purge) against the
+    records the compiled reference made of the same reads and chains (tests/golden/ext_golden.npz; generator make_ext_golden.py):
+    3 100 reads, 16 802 records, 10 208 of them purged, 443 extended with the doubled band."""
+    import numpy as np
+    from common import ext_golden_inputs
+    I = ext_golden_inputs()
+    G = np.load(os.path.join(GOLDEN, "ext_golden.npz"))
+    assert np.array_equal(G["reg_off"], I["seed_off"])
+    regs, (jobs, retried) = O.extend_batch(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["frac_rep"], I["text"],
+                                           I["l_pac"], I["contig_off"], I["contig_len"])
+    for k, f in enumerate(O.ALNREG_FIELDS):
+        bad = np.nonzero(regs[f].astype(np.int64) != G["regs"][:, k])[0]
+        assert bad.size == 0, (f, int(bad[0]), int(regs[f][bad[0]]), int(G["regs"][bad[0], k]))
+    assert np.array_equal(regs["frac_rep"].view(np.uint32), G["frac_rep_bits"])
+    assert retried > 300 and jobs > regs.shape[0]

@@ -44,3 +44,24 @@ def test_chain_oracle_equals_reference_on_adversarial_reads():
         n_deep += want[3] > 9
         n_dup += len(np.unique(want[1]["pos"])) < want[0]
     assert n_dup > 300 and n_deep > 300, (n_dup, n_deep)
+
+
+@needs_stage
+@pytest.mark.parametrize("w,clip,zdrop", [(100, 5, 100), (20, 5, 100), (100, 0, 30), (7, 11, 100)])
+def test_ext_oracle_equals_reference_on_other_options(w, clip, zdrop):
+    """orc_extend_batch == the compiled reference's mem_chain2aln_across_reads_V2 on the extension fixture's reads and chains with
+    other band widths (narrow bands: most jobs retried), clipping penalties and z-drop than the committed fixture was made with."""
+    from common import ext_golden_inputs
+    I = ext_golden_inputs()
+    opt = O.default_ext_opt(w)
+    opt.pen_clip5 = opt.pen_clip3 = clip
+    opt.zdrop = zdrop
+    sel = slice(0, None)
+    want = ref_py.extend_reads(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["frac_rep"], I["text"], I["l_pac"],
+                               I["contig_off"], I["contig_len"], np.zeros(I["contig_off"].shape[0], np.uint8), opt)
+    got, (jobs, retried) = O.extend_batch(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["frac_rep"], I["text"],
+                                          I["l_pac"], I["contig_off"], I["contig_len"], opt)
+    for f in O.ALNREG_FIELDS:
+        bad = np.nonzero(got[f][sel] != want[f][sel])[0]
+        assert bad.size == 0, (f, int(bad[0]), int(got[f][bad[0]]), int(want[f][bad[0]]))
+    assert np.array_equal(got["frac_rep"].view(np.uint32), want["frac_rep"].view(np.uint32))
