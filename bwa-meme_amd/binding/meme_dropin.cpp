@@ -351,6 +351,9 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n) {
 }
 
 int g_team = 1;                        // kt_for worker threads of the run (opt->n_threads)
+worker_t* g_worker = nullptr;             // of the chunk being processed (alignment records, ref_string: the CIGAR stage reads them)
+const mem_opt_t* g_opt = nullptr;
+std::atomic<int>& ktfor_calls();
 mem_chain_v* g_chunk_chain_ar = nullptr;   // w.chain_ar of the chunk being processed: every batch's chain_ar is a slice of it
 uint64_t g_chunk_gen = 0;               // counts the chunks seeded
 
@@ -358,6 +361,7 @@ typedef void (*process_fn)(mem_opt_t*, int64_t, int, bseq1_t*, const mem_pestat_
 void ext_report();
 }
 void meme_dropin_report_matesw();
+void meme_dropin_report_cigar();
 namespace {
 
 }  // namespace
@@ -378,6 +382,9 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         // 1.1 * min_chain_weight <= 0.05 * read length (never with the default min_chain_weight 0 and reads of at most 500 bases)
         g_ext_on_device = ext_mode() == 2 && opt->min_chain_weight == 0;
         g_chunk_chain_ar = w.chain_ar;
+        g_worker = &w;
+        g_opt = opt;
+        ktfor_calls() = 0;
         seed_chunk(opt, seqs, n);
         ++g_chunk_gen;
     }
@@ -398,6 +405,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
                 (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
     if (verbose() && !g_ext_on_device) ext_report();
     if (verbose() && getenv("MEME_DROPIN_PROFILE_SAM")) meme_dropin_report_matesw();
+    if (verbose()) meme_dropin_report_cigar();
 }
 
 namespace {
@@ -1353,6 +1361,218 @@ void meme_dropin_report_matesw() {
     fprintf(stderr, "[meme-dropin] SAM phase on the host, thread-seconds so far: mate-rescue SW (kswv) %.3f for %lld pairs; CIGAR generation (bwa_gen_cigar2) %.3f "
             "for %lld alignments; SAM formatting (mem_aln2sam) %.3f for %lld records\n", (double)g_t_matesw, (long long)g_n_matesw, (double)g_t_cigar,
             (long long)g_n_cigar, (double)g_t_sam, (long long)g_n_sam);
+}
+
+// ---- CIGAR generation of the SAM phase on the device ---------------------------------------------------------------------
+// mem_reg2aln (src/bwamem.cpp:2314-2380) calls bwa_gen_cigar2 (src/bwa.cpp:274-362) up to three times per alignment written out, and
+// that runs ksw_global2 (src/ksw.cpp:560-670): banded global alignment with traceback, 42 % of the SAM phase's thread time on 250-bp
+// reads with 5 % errors.  Between the two kt_for phases -- worker_aln has joined, worker_sam has not started: the third kt_for call of
+// mem_process_seqs (src/bwamem.cpp:1941-1965) is interposed -- the binding poses the same alignments for EVERY alignment record of the
+// chunk (the records are complete and nobody touches them; same band arithmetic as mem_reg2aln / bwa_gen_cigar2), runs them
+// on the GPU(s) as one batch per band attempt (meme_global_batch_host) and keeps score + CIGAR; ksw_global2 calls are then answered
+// from that table after an exact comparison of both sequences.  Calls the table does not hold (alignments made later by mate rescue,
+// calls without traceback from mem_patch_reg) go to the reference's function.  MEME_DROPIN_CIGAR=0 switches the stage off.
+#include <unordered_map>
+namespace {
+
+struct CigEntry { int64_t g; int64_t rb; int32_t qb, qlen, tlen, w, rev, score, n_cigar; int64_t ops; };
+struct CigTable {
+    std::mutex mu;
+    uint64_t gen = 0;
+    std::vector<CigEntry> e;
+    std::vector<uint32_t> ops;
+    std::unordered_multimap<uint64_t, uint32_t> idx;
+    double t_prepass = 0, t_kernel_ms = 0;
+    int64_t n_jobs = 0;
+} g_cig;
+std::atomic<int64_t> g_cig_hits{0}, g_cig_miss{0};
+bool cigar_on_device() { static const bool v = !(getenv("MEME_DROPIN_CIGAR") && atoi(getenv("MEME_DROPIN_CIGAR")) == 0); return v; }
+
+inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
+inline uint64_t hash_bytes(const uint8_t* p, int n, bool rev) {
+    uint64_t h = 1469598103934665603ull;
+    if (!rev) for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    else for (int i = n - 1; i >= 0; --i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+inline uint64_t cig_key(int qlen, int tlen, int w, uint64_t hq, uint64_t ht) {
+    return mix64(mix64(mix64(mix64((uint64_t)qlen, (uint64_t)tlen), (uint64_t)w), hq), ht);
+}
+inline int infer_bw_(int l1, int l2, int score, int a, int q, int r) {        // infer_bw, src/bwamem.cpp:2151-2158
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+    int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    if (w < abs(l1 - l2)) w = abs(l1 - l2);
+    return w;
+}
+// the band bwa_gen_cigar2 hands to ksw_global2 for a call with w_ (src/bwa.cpp:306-316); false: no DP (rejected, or the gap-free shortcut)
+inline bool gen_cigar_band(const mem_opt_t* opt, int64_t l_pac, int l_query, int64_t rb, int64_t re, int w_, int* w_out) {
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
+    const int64_t rlen = re - rb;
+    if (l_query == rlen && w_ == 0) return false;
+    int max_ins = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+    int max_del = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+    int max_gap = max_ins > max_del ? max_ins : max_del;
+    max_gap = max_gap > 1 ? max_gap : 1;
+    int w = (max_gap + abs((int)rlen - l_query) + 1) >> 1;
+    w = w < w_ ? w : w_;
+    const int min_w = abs((int)rlen - l_query) + 3;
+    w = w > min_w ? w : min_w;
+    *w_out = w;
+    return true;
+}
+
+void cig_prepass() {
+    const double t0 = now_s();
+    CigTable& T = g_cig;
+    T.e.clear(); T.ops.clear(); T.idx.clear();
+    const mem_opt_t* opt = g_opt;
+    const int64_t n = g_chunk.n, l_pac = g_bns->l_pac;
+    // per alignment record: where mem_reg2aln's loop stands (band of the next call, score of the last one)
+    struct Cand { int64_t g; int32_t reg, w2, last_sc, tries; };
+    std::vector<Cand> cand;
+    for (int64_t g = 0; g < n; ++g) {
+        const mem_alnreg_v& av = g_worker->regs[g];
+        for (size_t i = 0; i < av.n; ++i) {
+            const mem_alnreg_t& p = av.a[i];
+            if (p.rb < 0 || p.re < 0 || p.score < opt->T) continue;
+            if (p.secondary >= 0 && p.secondary < (int)av.n && p.score < av.a[p.secondary].score * opt->XA_drop_ratio) continue;
+            const int tmp = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_del, opt->e_del);
+            int w2 = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_ins, opt->e_ins);
+            w2 = w2 > tmp ? w2 : tmp;
+            if (w2 > opt->w) w2 = w2 < p.w ? w2 : p.w;
+            cand.push_back({g, (int32_t)i, w2, -(1 << 30), 0});
+        }
+    }
+    const int nd = (int)g_dev.size();
+    meme_bsw_opt bo;
+    memset(&bo, 0, sizeof(bo));
+    bo.o_del = opt->o_del; bo.e_del = opt->e_del; bo.o_ins = opt->o_ins; bo.e_ins = opt->e_ins; bo.a = opt->a; bo.b = opt->b;
+    for (int round = 0; round < 3 && !cand.empty(); ++round) {
+        // this round's calls, per device part
+        std::vector<std::vector<meme_gjob>> jobs((size_t)nd);
+        std::vector<std::vector<uint32_t>> who((size_t)nd);
+        for (size_t c = 0; c < cand.size(); ++c) {
+            Cand& C = cand[c];
+            const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
+            C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;
+            int w = 0;
+            if (!gen_cigar_band(opt, l_pac, p.qe - p.qb, p.rb, p.re, C.w2, &w)) { C.tries = 99; continue; }
+            int d = 0;
+            while (d + 1 < nd && C.g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
+            meme_gjob J;
+            J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w = w;
+            J.rev = p.rb >= l_pac ? 1 : 0;
+            jobs[(size_t)d].push_back(J);
+            who[(size_t)d].push_back((uint32_t)c);
+        }
+        std::vector<meme_gres_host> res((size_t)nd);
+        std::vector<std::thread> th;
+        auto run = [&](int d) {
+            memset(&res[(size_t)d], 0, sizeof(meme_gres_host));
+            if (jobs[(size_t)d].empty()) return;
+            if (meme_global_batch_host(g_dev[(size_t)d].seed, jobs[(size_t)d].data(), (int64_t)jobs[(size_t)d].size(), &bo, &res[(size_t)d])) die("meme_global_batch_host");
+        };
+        for (int d = 1; d < nd; ++d) th.emplace_back(run, d);
+        run(0);
+        for (auto& t : th) t.join();
+        std::vector<Cand> next;
+        for (int d = 0; d < nd; ++d) {
+            const meme_gres_host& R = res[(size_t)d];
+            T.t_kernel_ms += R.kernel_ms;
+            T.n_jobs += R.njobs;
+            for (int64_t k = 0; k < R.njobs; ++k) {
+                const meme_gjob& J = jobs[(size_t)d][(size_t)k];
+                Cand& C = cand[who[(size_t)d][(size_t)k]];
+                CigEntry E;
+                E.g = C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev; E.score = R.res[k].score; E.n_cigar = R.res[k].n_cigar;
+                E.ops = (int64_t)T.ops.size();
+                T.ops.insert(T.ops.end(), R.cigars + R.res[k].cigar_off, R.cigars + R.res[k].cigar_off + E.n_cigar);
+                T.e.push_back(E);
+                // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
+                const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
+                const int score = E.score;
+                if (score == C.last_sc || C.w2 == opt->w << 2) continue;
+                C.last_sc = score;
+                C.w2 <<= 1;
+                if (++C.tries < 3 && score < p.truesc - opt->a) next.push_back(C);
+            }
+        }
+        cand.swap(next);
+    }
+    // index: sequences hashed the way the hook will see them (both reversed on the reverse strand)
+    const uint8_t* ref = g_worker->ref_string;
+    std::vector<uint64_t> keys(T.e.size());
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < (int64_t)T.e.size(); ++k) {
+        const CigEntry& E = T.e[(size_t)k];
+        const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
+        keys[(size_t)k] = cig_key(E.qlen, E.tlen, E.w, hash_bytes(q, E.qlen, E.rev), hash_bytes(ref + E.rb, E.tlen, E.rev));
+    }
+    T.idx.reserve(T.e.size() * 2);
+    for (size_t k = 0; k < T.e.size(); ++k) T.idx.emplace(keys[k], (uint32_t)k);
+    T.t_prepass += now_s() - t0;
+}
+
+typedef int (*ksw_global2_fn)(int, const uint8_t*, int, const uint8_t*, int, const int8_t*, int, int, int, int, int, int*, uint32_t**);
+}  // namespace
+
+extern "C" int ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int m, const int8_t* mat, int o_del, int e_del, int o_ins,
+                           int e_ins, int w, int* n_cigar_, uint32_t** cigar_) {
+    static ksw_global2_fn next = (ksw_global2_fn)dlsym(RTLD_NEXT, "ksw_global2");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's ksw_global2 was not found\n"); exit(1); }
+    const mem_opt_t* opt = g_opt;
+    if (!cigar_on_device() || !n_cigar_ || !cigar_ || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || m != 5 || mat != opt->mat || o_del != opt->o_del ||
+        e_del != opt->e_del || o_ins != opt->o_ins || e_ins != opt->e_ins)
+        return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
+    CigTable& T = g_cig;
+    if (T.gen != g_chunk_gen) return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);   // (no table for this chunk)
+    const uint64_t key = cig_key(qlen, tlen, w, hash_bytes(query, qlen, false), hash_bytes(target, tlen, false));
+    auto range = T.idx.equal_range(key);
+    const uint8_t* ref = g_worker->ref_string;
+    for (auto it = range.first; it != range.second; ++it) {
+        const CigEntry& E = T.e[it->second];
+        if (E.qlen != qlen || E.tlen != tlen || E.w != w) continue;
+        const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
+        const uint8_t* t = ref + E.rb;
+        bool same = true;
+        if (!E.rev) same = !memcmp(q, query, (size_t)qlen) && !memcmp(t, target, (size_t)tlen);
+        else {
+            for (int i = 0; same && i < qlen; ++i) same = q[qlen - 1 - i] == query[i];
+            for (int i = 0; same && i < tlen; ++i) same = t[tlen - 1 - i] == target[i];
+        }
+        if (!same) continue;
+        uint32_t* cg = (uint32_t*)malloc((size_t)(E.n_cigar > 0 ? E.n_cigar : 1) * 4);   // the caller owns (and grows) it, as with the reference's
+        if (!cg) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+        memcpy(cg, T.ops.data() + E.ops, (size_t)E.n_cigar * 4);
+        *cigar_ = cg;
+        *n_cigar_ = E.n_cigar;
+        g_cig_hits.fetch_add(1, std::memory_order_relaxed);
+        return E.score;
+    }
+    g_cig_miss.fetch_add(1, std::memory_order_relaxed);
+    return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
+}
+
+void meme_dropin_report_cigar() {
+    if (!cigar_on_device()) return;
+    fprintf(stderr, "[meme-dropin] CIGAR stage on the device: %lld global alignments with traceback posed so far (kernels %.3f s, whole pre-pass %.3f s); "
+            "ksw_global2 calls answered from the table %lld, computed by the reference's function %lld (alignments made by mate rescue, calls without traceback)\n",
+            (long long)g_cig.n_jobs, g_cig.t_kernel_ms * 1e-3, g_cig.t_prepass, (long long)g_cig_hits.load(), (long long)g_cig_miss.load());
+}
+
+// kt_for (src/kthread.cpp:79-114) is called three times per chunk by mem_process_seqs: worker_bwt, worker_aln, worker_sam.  Before the
+// third call every alignment record of the chunk exists and no worker thread is running: the CIGAR stage's quiescent point.
+namespace { std::atomic<int> g_ktfor_calls{0}; std::atomic<int>& ktfor_calls() { return g_ktfor_calls; } }
+typedef void (*kt_for_fn)(void (*)(void*, long, long, int), void*, int);
+void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
+    static kt_for_fn next = (kt_for_fn)dlsym(RTLD_NEXT, "_Z6kt_forPFvPvlliES_i");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_for was not found\n"); exit(1); }
+    if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2 && cigar_on_device()) {
+        std::lock_guard<std::mutex> lk(g_cig.mu);
+        cig_prepass();
+        g_cig.gen = g_chunk_gen;
+    }
+    next(func, data, n);
 }
 
 // ---- FASTQ input (first step): the two mate files parsed by two threads, ahead of the pipeline ---------------------

@@ -58,9 +58,9 @@ struct meme_ctx {
     std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[11], ext[9];
+           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[11], ext[9], gcig[6];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
-    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2];
+    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2];
     i64 last_seed_max_len = 0;         // longest read of that batch
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
     // tuning
@@ -76,6 +76,7 @@ struct meme_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_ext[2] = {nullptr, nullptr};
+    hipEvent_t ev_gcig[2] = {nullptr, nullptr};
     hipStream_t stream2 = nullptr;     // side stream: the heavy reads of the chaining tier run beside the light ones
     hipEvent_t ev_aux = nullptr;
     i64 chain_reads = 0, chain_tier2_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier

@@ -95,6 +95,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (DevBuf* b : bufs) free_buf(*b);
     for (DevBuf& b : ctx->chain) free_buf(b);
     for (DevBuf& b : ctx->ext) free_buf(b);
+    for (DevBuf& b : ctx->gcig) free_buf(b);
     for (meme_ctx::HostBuf& h : ctx->h_chain) if (h.p) (void)hipHostFree(h.p);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     for (meme_ctx::HostBuf* h : {&ctx->h_smems, &ctx->h_hits, &ctx->h_smem_off, &ctx->h_hit_off, &ctx->h_misc})
@@ -102,6 +103,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_chain) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_ext) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_gcig) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -1,0 +1,240 @@
+// Banded global alignment with traceback -- the CIGAR kernel of the SAM phase: ksw_global2 (reference src/ksw.cpp:560-670)
+// as bwa_gen_cigar2 (src/bwa.cpp:274-362) calls it from mem_reg2aln (src/bwamem.cpp:2314-2380) for every alignment that is written out.
+//
+// One wavefront per alignment; the lanes take the query columns of the band (64 at a time), the target rows run in sequence:
+//   M(i,j)   = H(i-1,j-1) + S(i,j)                         lane-parallel (H of the row above, shifted by one column, in LDS)
+//   E(i+1,j) = max{M(i,j) - gapo_del, E(i,j)} - gape_del    lane-parallel (E stays with its column)
+//   F(i,j+1) = max{M(i,j) - gapo_ins, F(i,j)} - gape_ins    along the row: a max-plus prefix scan over the lanes, carried across chunks
+//   H(i,j)   = max{M, E, F}; the direction byte of the cell (h from M/E/F, e opened or extended, f opened or extended) goes to the
+//   backtrack matrix exactly as the reference stores it, and the backtrack walks it the reference's way -- so that ties (M over E over F)
+//   and with them the placement of gaps in the CIGAR come out the same.
+// Sequences are not shipped: a job names a read of the batch resident on the ctx, its query span, and a span of the fwd+rc text (2-bit
+// pac64 in HBM); alignments on the reverse strand have both sequences reversed, as bwa_gen_cigar2 does to keep gaps left-aligned.
+#include <string.h>
+
+#include "meme_common.h"
+
+namespace {
+
+constexpr int MINUS_INF = -0x40000000;       // src/ksw.cpp:545
+
+struct GcigArgs {
+    const meme_gjob* jobs; i64 njobs;
+    const uint8_t* reads; const i64* read_off; const u64* pac;
+    meme_bsw_opt o;                          // o_del, e_del, o_ins, e_ins, a, b (zdrop / end_bonus unused)
+    const i64* zoff; uint8_t* z;             // backtrack matrices: n_col * tlen bytes per job
+    const i64* coff; uint32_t* cig;          // CIGAR scratch: qlen + tlen + 2 operations per job, filled from the back
+    meme_gres* res;                          // score, n_cigar, (cigar_off = first operation inside the job's scratch, for the pack kernel)
+};
+
+__device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(pac[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3; }
+
+__global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
+    extern __shared__ int lds[];             // hA[qlen + 2] | hB[qlen + 2] | e[qlen + 2] | query bytes (as ints, 4 per word)
+    const i64 jb = blockIdx.x;
+    if (jb >= A.njobs) return;
+    const int lane = threadIdx.x;
+    const meme_gjob J = A.jobs[jb];
+    const int qlen = J.qlen, tlen = J.tlen, w = J.w;
+    int* hA = lds;
+    int* hB = hA + (qlen + 2);
+    int* eE = hB + (qlen + 2);
+    uint8_t* qs = reinterpret_cast<uint8_t*>(eE + (qlen + 2));
+    const uint8_t* rd = A.reads + A.read_off[J.read] + J.qb;
+    for (int j = lane; j < qlen; j += 64) qs[j] = J.rev ? rd[qlen - 1 - j] : rd[j];
+    const int oe_del = A.o.o_del + A.o.e_del, oe_ins = A.o.o_ins + A.o.e_ins, e_del = A.o.e_del, e_ins = A.o.e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    uint8_t* z = A.z + A.zoff[jb];
+    // first row (src/ksw.cpp:591-595)
+    for (int j = lane; j <= qlen; j += 64) {
+        hA[j] = j == 0 ? 0 : (j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF);
+        eE[j] = MINUS_INF;
+    }
+    __syncthreads();
+    int* hp = hA;                            // H(i-1, j-1) at [j]
+    int* hn = hB;
+    for (int i = 0; i < tlen; ++i) {
+        const int tb = text_base(A.pac, J.rev ? J.rb + tlen - 1 - i : J.rb + i);
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        int f_in = MINUS_INF;                                         // F(i, first column of the chunk)
+        int h_in = beg == 0 ? -(A.o.o_del + e_del * (i + 1)) : MINUS_INF;   // H(i, beg - 1): what the reference's h1 starts from
+        if (lane == 0) hn[beg] = h_in;
+        uint8_t* zi = z + (i64)i * n_col;
+        for (int cb = beg; cb < end; cb += 64) {
+            const int j = cb + lane;
+            const bool in = j < end;
+            int m = MINUS_INF, e = MINUS_INF;
+            if (in) {
+                const int qb = qs[j];
+                const int sc = (tb > 3 || qb > 3) ? -1 : (tb == qb ? A.o.a : -A.o.b);      // bwa_fill_scmat (src/bwa.cpp:262-270)
+                m = hp[j] + sc;
+                e = eE[j];
+            }
+            // F along the row: F(i,j) = max( f_in - (j-cb)*e_ins , max_{cb <= k < j} (M(i,k) - oe_ins - (j-1-k)*e_ins) )
+            // as an inclusive max-scan of G_k = M(i,k) - oe_ins + k*e_ins over the lanes, shifted by one lane
+            const int g = in ? m - oe_ins + (j - cb) * e_ins : -2000000000;
+            int sg = g;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sg, d); if (lane >= d) sg = sg > y ? sg : y; }
+            int ex = __shfl_up(sg, 1);                                   // max over lanes below
+            // f at this column: from the carry (decayed) or from a column of this chunk
+            const int from_carry = f_in - lane * e_ins;
+            int f = lane == 0 ? f_in : (ex - (lane - 1) * e_ins > from_carry ? ex - (lane - 1) * e_ins : from_carry);
+            // the reference's cell, on this lane's values
+            unsigned d = m >= e ? 0u : 1u;
+            int h = m >= e ? m : e;
+            d = h >= f ? d : 2u;
+            h = h >= f ? h : f;
+            int t = m - oe_del;
+            int e2 = e - e_del;
+            d |= e2 > t ? 1u << 2 : 0u;
+            e2 = e2 > t ? e2 : t;
+            t = m - oe_ins;
+            int f2 = f - e_ins;
+            d |= f2 > t ? 2u << 4 : 0u;
+            f2 = f2 > t ? f2 : t;
+            if (in) { eE[j] = e2; hn[j + 1] = h; zi[j - beg] = (uint8_t)d; }
+            // carry to the next chunk: F(i, cb + 64) = f2 of lane 63
+            f_in = __shfl(f2, 63);
+        }
+        if (lane == 0) eE[end] = MINUS_INF;                              // eh[end].e (:647); eh[end].h was stored by the row's last column
+        __syncthreads();
+        int* tsw = hp; hp = hn; hn = tsw;
+    }
+    const int score = hp[qlen];
+    // backtrack (src/ksw.cpp:650-664), every lane the same walk; the operations are written from the back of the job's scratch
+    uint32_t* cg = A.cig + A.coff[jb];
+    const int cap = qlen + tlen + 2;
+    int n = 0;                               // operations so far; cg[cap - 1 - k] = k-th pushed
+    {
+        __threadfence();
+        __syncthreads();
+        int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+        const i64 zsize = (i64)n_col * tlen;
+        int last_op = -1;
+        unsigned cur = 0;
+        auto push = [&](int op, int len) {
+            if (last_op == op) cur += (unsigned)len << 4;
+            else { if (last_op >= 0) { cg[cap - 1 - n] = cur; ++n; } cur = (unsigned)len << 4 | (unsigned)op; last_op = op; }
+        };
+        while (i >= 0 && k >= 0) {
+            i64 zi = (i64)i * n_col + (k - (i > w ? i - w : 0));
+            if (zi < 0) zi = 0;
+            if (zi >= zsize) zi = zsize - 1;
+            which = z[zi] >> (which << 1) & 3;
+            if (which == 0) { push(0, 1); --i; --k; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --k; }
+        }
+        if (i >= 0) push(2, i + 1);
+        if (k >= 0) push(1, k + 1);
+        if (last_op >= 0) { cg[cap - 1 - n] = cur; ++n; }
+    }
+    if (lane == 0) { meme_gres R; R.score = score; R.n_cigar = n; R.cigar_off = cap - n; A.res[jb] = R; }
+}
+
+// the operations of every job, densely packed in job order (they were pushed back to front: already in CIGAR order)
+__global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__ res, const i64* __restrict__ coff, const uint32_t* __restrict__ cig,
+                                                    const i64* __restrict__ ooff, i64 njobs, uint32_t* __restrict__ out) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
+        const meme_gres R = res[jb];
+        const uint32_t* src = cig + coff[jb] + R.cigar_off;
+        uint32_t* dst = out + ooff[jb];
+        for (int k = 0; k < R.n_cigar; ++k) dst[k] = src[k];
+    }
+}
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, i64* __restrict__ zsz, i64* __restrict__ csz) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
+        const meme_gjob J = jobs[jb];
+        const i64 n_col = J.qlen < 2 * J.w + 1 ? J.qlen : 2 * J.w + 1;
+        zsz[jb] = (n_col * J.tlen + 15) & ~(i64)15;
+        csz[jb] = J.qlen + J.tlen + 2;
+    }
+}
+__global__ void __launch_bounds__(256) k_gcig_ncig(const meme_gres* __restrict__ res, i64 njobs, i64* __restrict__ ncig) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) ncig[jb] = res[jb].n_cigar;
+}
+__global__ void __launch_bounds__(256) k_gcig_fix(meme_gres* __restrict__ res, const i64* __restrict__ ooff, i64 njobs) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) res[jb].cigar_off = ooff[jb];
+}
+
+unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
+
+}  // namespace
+
+extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int64_t njobs, const meme_bsw_opt* opt, meme_gres_host* out) {
+    if (!ctx || !jobs || njobs < 0 || !opt || !out) { meme_set_error("meme_global_batch_host: null argument"); return MEME_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    if (njobs == 0) return MEME_OK;
+    const i64 nreads = ctx->last_seed_reads;
+    if (nreads <= 0 || !ctx->reads.p || !ctx->read_off.p || !ctx->idx.pac) { meme_set_error("meme_global_batch_host: no seeded batch on this ctx (the jobs name its reads)"); return MEME_E_STATE; }
+    if (opt->e_del < 1 || opt->e_ins < 1) { meme_set_error("meme_global_batch_host: gap extension penalties must be positive"); return MEME_E_ARG; }
+    int qmax = 0;
+    for (i64 k = 0; k < njobs; ++k) {
+        const meme_gjob& J = jobs[k];
+        if (J.read < 0 || J.read >= nreads || J.qb < 0 || J.qlen < 1 || J.tlen < 1 || J.w < 0 || J.rb < 0 || J.rb + J.tlen > ctx->idx.n || J.qlen > 65535 || J.tlen > 65535) {
+            meme_set_error("meme_global_batch_host: job %lld is malformed (read %d, query %d+%d, target %lld+%d, band %d)", (long long)k, J.read, J.qb, J.qlen,
+                           (long long)J.rb, J.tlen, J.w);
+            return MEME_E_ARG;
+        }
+        qmax = J.qlen > qmax ? J.qlen : qmax;
+    }
+    int rc;
+    DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (4 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars
+    if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob))) || (rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 6)) ||
+        (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
+    hipEvent_t* ev = ctx->ev_gcig;
+    for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipMemcpyAsync(G[0].p, jobs, (size_t)njobs * sizeof(meme_gjob), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    i64* d_zsz = (i64*)G[1].p;
+    i64* d_csz = d_zsz + (njobs + 1);
+    i64* d_zoff = d_csz + (njobs + 1);
+    i64* d_coff = d_zoff + (njobs + 1);
+    i64* d_ncig = d_coff + (njobs + 1);
+    i64* d_ooff = d_ncig + (njobs + 1);
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, d_zsz, d_csz);
+    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs))) return rc;
+    i64 tz = 0, tc = 0;
+    HIP_TRY(hipMemcpyAsync(&tz, d_zoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&tc, d_coff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)tz + (size_t)tc * 4;
+        if (need > G[2].cap + G[3].cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2 + G[2].cap + G[3].cap) {
+            meme_set_error("meme_global_batch_host: %lld alignments need %.1f GB of backtrack matrices, more than half of the free HBM: submit fewer at a time",
+                           (long long)njobs, need / 1e9);
+            return MEME_E_CAPACITY;
+        }
+    }
+    if ((rc = meme_buf_reserve(ctx, G[2], (size_t)tz + 64)) || (rc = meme_buf_reserve(ctx, G[3], (size_t)(tc + 1) * 4))) return rc;
+    GcigArgs A;
+    A.jobs = (const meme_gjob*)G[0].p; A.njobs = njobs; A.reads = (const uint8_t*)ctx->reads.p; A.read_off = (const i64*)ctx->read_off.p; A.pac = ctx->idx.pac;
+    A.o = *opt; A.zoff = d_zoff; A.z = (uint8_t*)G[2].p; A.coff = d_coff; A.cig = (uint32_t*)G[3].p; A.res = (meme_gres*)G[4].p;
+    const size_t lds = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_gcig, dim3((unsigned)njobs), dim3(64), lds, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_gcig_ncig, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (i64)njobs, d_ncig);
+    if ((rc = meme_scan_exclusive(ctx, d_ncig, d_ooff, njobs))) return rc;
+    i64 tops = 0;
+    HIP_TRY(hipMemcpyAsync(&tops, d_ooff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = meme_buf_reserve(ctx, G[5], (size_t)(tops + 1) * 4))) return rc;
+    hipLaunchKernelGGL(k_gcig_pack, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (const i64*)d_coff, (const uint32_t*)G[3].p,
+                       (const i64*)d_ooff, (i64)njobs, (uint32_t*)G[5].p);
+    hipLaunchKernelGGL(k_gcig_fix, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (meme_gres*)G[4].p, (const i64*)d_ooff, (i64)njobs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+    meme_ctx::HostBuf* Hb = ctx->h_gcig;
+    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)njobs * sizeof(meme_gres))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(tops + 1) * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(Hb[0].p, G[4].p, (size_t)njobs * sizeof(meme_gres), hipMemcpyDeviceToHost, ctx->stream));
+    if (tops) HIP_TRY(hipMemcpyAsync(Hb[1].p, G[5].p, (size_t)tops * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out->njobs = njobs; out->res = (const meme_gres*)Hb[0].p; out->cigars = (const uint32_t*)Hb[1].p; out->total_ops = tops; out->kernel_ms = ms;
+    return MEME_OK;
+}

@@ -73,6 +73,15 @@ ALNREG = np.dtype({"names": ["rb", "re", "qb", "qe", "rid", "c", "score", "trues
                    "formats": ["<i8", "<i8", "<i4", "<i4", "<i4", "<u8"] + ["<i4"] * 12 + ["<f4", "<u8", "<i4"],
                    "offsets": [0, 8, 16, 20, 24, 32] + [40 + 4 * k for k in range(12)] + [88, 96, 104], "itemsize": 112})
 
+GJOB = np.dtype([("rb", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("rev", "<i4")])
+GRES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar_off", "<i8")])
+assert GJOB.itemsize == 32 and GRES.itemsize == 16
+
+
+class GresHost(C.Structure):
+    _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("cigars", C.c_void_p), ("total_ops", C.c_int64), ("kernel_ms", C.c_float)]
+
+
 CHAIN = np.dtype({"names": ["pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"],
                   "formats": ["<i8", "<i4", "<i4", "<i4", "<i4", "<i2", "<i2", "<i4"], "offsets": [0, 8, 12, 16, 20, 24, 26, 28], "itemsize": 40})
 CHAIN_SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
@@ -102,7 +111,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -290,6 +299,21 @@ class Context:
         return {"reg_off": view(res.reg_off, n + 1, np.int64), "regs": view(res.regs, res.total_regs, ALNREG), "total_chains": int(res.total_chains),
                 "n_pairs": int(res.n_pairs), "n_retried": int(res.n_retried), "n_bsw_calls": int(res.n_bsw_calls), "n_tier2": int(res.n_tier2),
                 "chain_ms": float(res.chain_ms), "ext_ms": float(res.ext_ms), "bsw_ms": float(res.bsw_ms)}
+
+    def global_batch_host(self, jobs, opt=None):
+        """meme_global_batch_host: banded global alignments with traceback (ksw_global2) of query spans of the batch's reads against
+        spans of the text.  jobs: GJOB records.  Returns (GRES records with cigar_off into `cigars`, cigars uint32, kernel_ms)."""
+        opt = opt or default_bsw_opt()
+        jobs = np.ascontiguousarray(jobs, dtype=GJOB)
+        res = GresHost()
+        _check(lib().meme_global_batch_host(C.c_void_p(self.h), _p(jobs), C.c_int64(jobs.shape[0]), C.byref(opt), C.byref(res)))
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return view(res.res, res.njobs, GRES), view(res.cigars, res.total_ops, np.uint32), float(res.kernel_ms)
 
     def chain_batch_host(self, smems, smem_off, hits, hit_off, read_len, contigs, opt):
         """meme_chain_batch_host: chains of seeds the caller brings (numpy arrays laid out as seed_batch_host returns them)."""

@@ -13,6 +13,7 @@
  *                                       host consumer mem_chain_Learned(), src/bwamem.cpp:1122-1204)
  *   meme_chain_last_batch_host      <- mem_chain_Learned() + mem_chain_flt()          src/bwamem.cpp:1122-1204, 599-717
  *   meme_extend_last_batch_host     <- mem_chain2aln_across_reads_V2()              src/bwamem.cpp:2573-3497 (behind the chaining stage)
+ *   meme_global_batch_host          <- ksw_global2() under bwa_gen_cigar2()         src/ksw.cpp:560-670, src/bwa.cpp:274-362
  *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
  *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
  *
@@ -253,6 +254,19 @@ int meme_bsw_batch(meme_ctx* ctx, meme_seqpair* pairs, const uint8_t* ref_buf, i
                    const meme_bsw_opt* opt);
 int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer,
                           int32_t npairs, int32_t w, const meme_bsw_opt* opt);
+
+/* ---- banded global alignment with traceback: the CIGAR kernel of the SAM phase -----------------------------------------------------
+ * ksw_global2() (reference src/ksw.cpp:560-670) as bwa_gen_cigar2() (src/bwa.cpp:274-362) calls it from mem_reg2aln()
+ * (src/bwamem.cpp:2314-2380): score and CIGAR of the global alignment of a read's query span [qb, qb+qlen) against the text span
+ * [rb, rb+tlen) of the fwd+rc reference within band w.  Sequences are not shipped: `read` indexes the batch the last
+ * meme_seed_batch_host() call staged on this ctx, the text is the 2-bit image in HBM; rev != 0 (alignments on the reverse strand,
+ * rb >= l_pac) reverses both sequences as bwa_gen_cigar2 does.  CIGAR operations in the BAM encoding (len << 4 | op, op 0 M, 1 I, 2 D),
+ * ties broken as the reference breaks them (M over E over F), so gaps sit where the reference puts them. */
+typedef struct { int64_t rb; int32_t read, qb, qlen, tlen, w, rev; } meme_gjob;
+typedef struct { int32_t score, n_cigar; int64_t cigar_off; /* first operation in meme_gres_host::cigars */ } meme_gres;
+typedef struct { int64_t njobs; const meme_gres* res; const uint32_t* cigars; int64_t total_ops; float kernel_ms; } meme_gres_host;
+int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int64_t njobs, const meme_bsw_opt* opt /* o_del e_del o_ins e_ins a b */,
+                           meme_gres_host* out);
 
 /* ---- measurement ---------------------------------------------------------------------------------
  * HIP-event timings of the kernels of the last *_device call, measured on the ctx's stream.          */

@@ -1077,3 +1077,70 @@ int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nrea
     if (stats) { stats[0] = jobs; stats[1] = retried; }
     return bad ? -1 : 0;
 }
+
+/* ---- banded global alignment with traceback: ksw_global2 (reference src/ksw.cpp:560-670) --------------------------------------------
+ * Restated cell by cell: M separated from H, ties M >= E >= F, direction byte f<<4 | e<<2 | h per cell, backtrack from the last cell of
+ * the last row's band.  mat = bwa_fill_scmat(a, b): match a, mismatch -b, anything with an ambiguous base -1.  cigar[] (capacity
+ * qlen + tlen + 2) receives the operations in CIGAR order, BAM encoding.  Returns the score. */
+#define O_MINUS_INF (-0x40000000)
+int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w,
+                    int* n_cigar_, uint32_t* cigar) {
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    int i, j, score, n = 0;
+    int* eh_h = (int*)calloc((size_t)qlen + 2, sizeof(int));
+    int* eh_e = (int*)calloc((size_t)qlen + 2, sizeof(int));
+    uint8_t* z = (uint8_t*)malloc((size_t)n_col * (size_t)tlen + 1);
+    eh_h[0] = 0; eh_e[0] = O_MINUS_INF;
+    for (j = 1; j <= qlen && j <= w; ++j) { eh_h[j] = -(o_ins + e_ins * j); eh_e[j] = O_MINUS_INF; }
+    for (; j <= qlen; ++j) eh_h[j] = eh_e[j] = O_MINUS_INF;
+    for (i = 0; i < tlen; ++i) {
+        int f = O_MINUS_INF, h1, beg, end, t;
+        uint8_t* zi = &z[(size_t)i * n_col];
+        beg = i > w ? i - w : 0;
+        end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        h1 = beg == 0 ? -(o_del + e_del * (i + 1)) : O_MINUS_INF;
+        for (j = beg; j < end; ++j) {
+            int h, m = eh_h[j], e = eh_e[j];
+            uint8_t d;
+            eh_h[j] = h1;
+            m += (target[i] > 3 || query[j] > 3) ? -1 : (target[i] == query[j] ? a : -b);
+            d = m >= e ? 0 : 1;
+            h = m >= e ? m : e;
+            d = h >= f ? d : 2;
+            h = h >= f ? h : f;
+            h1 = h;
+            t = m - oe_del;
+            e -= e_del;
+            d |= e > t ? 1 << 2 : 0;
+            e = e > t ? e : t;
+            eh_e[j] = e;
+            t = m - oe_ins;
+            f -= e_ins;
+            d |= f > t ? 2 << 4 : 0;
+            f = f > t ? f : t;
+            zi[j - beg] = d;
+        }
+        eh_h[end] = h1; eh_e[end] = O_MINUS_INF;
+    }
+    score = eh_h[qlen];
+    if (n_cigar_ && cigar) {
+        int k, which = 0, last = -1;
+        uint32_t tmp;
+        i = tlen - 1; k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1;
+#define O_PUSH(op_, len_) do { if (last == (op_)) cigar[n - 1] += (uint32_t)(len_) << 4; else { cigar[n++] = (uint32_t)(len_) << 4 | (uint32_t)(op_); last = (op_); } } while (0)
+        while (i >= 0 && k >= 0) {
+            which = z[(size_t)i * n_col + (k - (i > w ? i - w : 0))] >> (which << 1) & 3;
+            if (which == 0) { O_PUSH(0, 1); --i; --k; }
+            else if (which == 1) { O_PUSH(2, 1); --i; }
+            else { O_PUSH(1, 1); --k; }
+        }
+        if (i >= 0) O_PUSH(2, i + 1);
+        if (k >= 0) O_PUSH(1, k + 1);
+#undef O_PUSH
+        for (i = 0; i < n >> 1; ++i) { tmp = cigar[i]; cigar[i] = cigar[n - 1 - i]; cigar[n - 1 - i] = tmp; }
+        *n_cigar_ = n;
+    }
+    free(eh_h); free(eh_e); free(z);
+    return score;
+}

@@ -119,6 +119,10 @@ int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nrea
                      const int64_t* seed_off, const orc_cseed* seeds, const float* frac_rep, const uint8_t* text, int64_t l_pac,
                      const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats);
 
+/* ---- banded global alignment with traceback (ksw_global2, reference src/ksw.cpp:560-670) ------------------------------------------ */
+int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w,
+                    int* n_cigar, uint32_t* cigar /* capacity qlen + tlen + 2 */);
+
 #ifdef __cplusplus
 }
 #endif

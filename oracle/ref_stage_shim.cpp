@@ -19,6 +19,7 @@
 #include "bwa.h"
 #include "LearnedIndex_seeding.h"
 #include "ksort.h"
+#include "ksw.h"
 
 // globals the reference objects expect from the rest of the binary (src/main.cpp)
 uint64_t proc_freq = 1, tprof[LIM_R][LIM_C];
@@ -185,6 +186,23 @@ int ref_extend_reads(const uint8_t* reads, const int64_t* read_off, int64_t nrea
     }
     free(opt);
     return 0;
+}
+
+
+// ---- ksw_global2 (src/ksw.cpp:560-670) and bwa_gen_cigar2 (src/bwa.cpp:274-362) ------------------------------------------------------
+// cigar receives at most cap operations; returns the score, *n_cigar the number of operations (or -1 when cap is too small)
+int ref_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w,
+                    int* n_cigar, uint32_t* cigar, int cap) {
+    int8_t mat[25];
+    bwa_fill_scmat(a, b, mat);
+    uint32_t* cg = nullptr;
+    int n = 0;
+    const int score = ksw_global2(qlen, query, tlen, target, 5, mat, o_del, e_del, o_ins, e_ins, w, &n, &cg);
+    if (n > cap) n = -1;
+    for (int i = 0; i < n; ++i) cigar[i] = cg[i];
+    free(cg);
+    *n_cigar = n;
+    return score;
 }
 
 }  // extern "C"

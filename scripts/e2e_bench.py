@@ -36,9 +36,12 @@ def fastq(reads, path):
 f1, f2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
 t0 = time.time(); fastq(r1, f1); fastq(r2, f2); log("fastq %.1f s" % (time.time() - t0))
 res = {}
-for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+runs = [("bwa-meme_mode3", None)] + [("bwa-meme_dropin", m) for m in os.environ.get("E2E_EXT_MODES", "device").split(",")]
+if os.environ.get("E2E_SKIP_REF"): runs = runs[1:]
+for exe, mode in runs:
     out = os.path.join(d, exe + ".sam")
     env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1")
+    if mode: env["MEME_DROPIN_EXT"] = mode
     if os.environ.get("E2E_BSW_TRACE"): env["MEME_BSW_TRACE"] = "1"
     t0 = time.time()
     with open(out, "wb") as fh:
@@ -56,9 +59,9 @@ for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
         for line in fh:
             if not line.startswith(b"@PG"):
                 h.update(line); nlines += 1
-    res[exe] = (wall, h.hexdigest(), nlines)
-    log(exe, "rc", r.returncode, "wall %.1f s" % wall, "->", "%.0f reads/s (wall, incl. index load)" % (2 * npairs / wall), "sam lines", nlines)
+    res[exe + (":" + mode if mode else "")] = (wall, h.hexdigest(), nlines)
+    log(exe, mode or "", "rc", r.returncode, "wall %.1f s" % wall, "->", "%.0f reads/s (wall, incl. index load)" % (2 * npairs / wall), "sam lines", nlines)
     for k in err.split("\n")[-45:]:
         if k.strip(): log("   ", k.strip())
-log("SAM identical:", res["bwa-meme_mode3"][1] == res["bwa-meme_dropin"][1])
+log("SAM md5:", {k: v[1] for k, v in res.items()}, "all identical:", len({v[1] for v in res.values()}) == 1)
 import shutil; shutil.rmtree(d, ignore_errors=True)

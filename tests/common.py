@@ -126,3 +126,52 @@ def ext_golden_inputs():
     return {"genome": g, "reads_list": allreads, "reads": np.concatenate(allreads), "read_off": read_off, "chain_off": chain_off, "chains": chains,
             "seed_off": seed_off, "seeds": seeds, "frac_rep": np.concatenate([frac0, np.array(frac1, np.float32)]), "text": text, "l_pac": l_pac,
             "contig_off": G["contig_off"], "contig_len": G["contig_len"], "n_fixture_reads": n0}
+
+
+def gcig_workload(n=3000, seed=77):
+    """Inputs of the CIGAR-kernel tests (tests/golden/gcig_golden.npz): a 300 kbp genome, reads of 40-250 bases sampled with
+    substitutions, indels (up to 30 bases) and an occasional N, from both strands; per read one or two global-alignment jobs the way
+    mem_reg2aln (src/bwamem.cpp:2314-2380) would pose them -- a query span of the read against the text span it came from (fwd+rc
+    coordinates; rev = both sequences reversed when on the reverse strand), band from 1 to 400.
+    Returns (genome, reads list, jobs as hipapi.GJOB records, explicit (query, target) code arrays per job)."""
+    from pymeme import hipapi, synth
+    rng = np.random.default_rng(seed)
+    g = synth.make_genome(300_000, seed=seed + 1, repeat_frac=0.05)
+    text = hipapi.fwd_rc_text(g)
+    l_pac = g.shape[0]
+    reads, jobs, seqs = [], [], []
+    for r in range(n):
+        L = int(rng.integers(40, 251))
+        strand = int(rng.integers(0, 2))
+        p = int(rng.integers(0, 2 * l_pac - 2 * L - 64)) if False else int(rng.integers(0, l_pac - L - 64)) + strand * l_pac
+        src = text[p:p + L + 40]
+        out, i, tl = [], 0, 0
+        rate_sub, rate_indel = rng.choice([0.0, 0.01, 0.05]), rng.choice([0.0, 0.003, 0.02])
+        while len(out) < L:
+            u = rng.random()
+            if u < rate_indel / 2:                                  # insertion in the read
+                out += list(rng.integers(0, 4, size=int(rng.integers(1, 31))))
+            elif u < rate_indel:                                    # deletion from the read
+                i += int(rng.integers(1, 31))
+            else:
+                c = int(src[min(i, src.shape[0] - 1)])
+                if rng.random() < rate_sub:
+                    c = (c + int(rng.integers(1, 4))) & 3
+                if rng.random() < 0.002:
+                    c = 4
+                out.append(c); i += 1
+        read = np.array(out[:L], np.uint8)
+        tlen = int(min(max(i, 1), src.shape[0]))
+        reads.append(read)
+        for _ in range(1 + (r % 3 == 0)):
+            qb = int(rng.integers(0, 8)) if rng.random() < 0.5 else 0
+            qe = L - (int(rng.integers(0, 8)) if rng.random() < 0.5 else 0)
+            rb = p + qb
+            tl = max(1, min(tlen - qb + int(rng.integers(-3, 4)), 2 * l_pac - rb - 1, (l_pac - rb) if rb < l_pac else 10 ** 9))
+            w = int(rng.choice([1, 3, 10, 30, 100, 200, 400]))
+            w = max(w, abs(tl - (qe - qb)) + 3)                    # min_w of bwa_gen_cigar2 (src/bwa.cpp:314-315): the last cell is inside the band
+            rev = 1 if rb >= l_pac else 0
+            jobs.append((rb, r, qb, qe - qb, tl, w, rev))
+            q, t = read[qb:qe], text[rb:rb + tl]
+            seqs.append((q[::-1].copy(), t[::-1].copy()) if rev else (q.copy(), t.copy()))
+    return g, reads, np.array(jobs, dtype=hipapi.GJOB), seqs

@@ -289,3 +289,16 @@ def extend_batch(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, 
                             C.c_int64(int(l_pac)), p(contig_off), p(contig_len), C.byref(opt), p(out), C.c_int(threads), p(stats))
     assert rc == 0
     return out, (int(stats[0]), int(stats[1]))
+
+
+def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
+    """orc_ksw_global2: (score, cigar as uint32 array) of the banded global alignment of two code arrays."""
+    L = lib()
+    L.orc_ksw_global2.restype = C.c_int
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    cig = np.zeros(query.shape[0] + target.shape[0] + 2, np.uint32)
+    n = C.c_int(0)
+    sc = L.orc_ksw_global2(C.c_int(query.shape[0]), C.c_void_p(query.ctypes.data), C.c_int(target.shape[0]), C.c_void_p(target.ctypes.data), C.c_int(a),
+                           C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_int(int(w)), C.byref(n), C.c_void_p(cig.ctypes.data))
+    return sc, cig[:n.value].copy()

@@ -122,3 +122,19 @@ def extend_reads(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, 
                             p(contig_off), p(contig_len), p(contig_alt), C.c_int(contig_off.shape[0]), C.c_int64(int(l_pac)), C.byref(opt), p(out))
     assert rc == 0, rc
     return out
+
+
+def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
+    """ksw_global2 of the compiled reference: (score, cigar)."""
+    L = stage_lib()
+    L.ref_ksw_global2.restype = C.c_int
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    target = np.ascontiguousarray(target, dtype=np.uint8)
+    cap = query.shape[0] + target.shape[0] + 2
+    cig = np.zeros(cap, np.uint32)
+    n = C.c_int(0)
+    sc = L.ref_ksw_global2(C.c_int(query.shape[0]), C.c_void_p(query.ctypes.data), C.c_int(target.shape[0]), C.c_void_p(target.ctypes.data), C.c_int(a),
+                           C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_int(int(w)), C.byref(n), C.c_void_p(cig.ctypes.data),
+                           C.c_int(cap))
+    assert n.value >= 0
+    return sc, cig[:n.value].copy()

@@ -221,3 +221,16 @@ def test_ext_oracle_equals_reference_golden():
         assert bad.size == 0, (f, int(bad[0]), int(regs[f][bad[0]]), int(G["regs"][bad[0], k]))
     assert np.array_equal(regs["frac_rep"].view(np.uint32), G["frac_rep_bits"])
     assert retried > 300 and jobs > regs.shape[0]
+
+
+def test_ksw_global2_oracle_equals_reference_golden():
+    """orc_ksw_global2 against score and CIGAR of the compiled reference's ksw_global2 (tests/golden/gcig_golden.npz, 4 000 alignments:
+    both strands, substitutions, indels up to 30 bases, N, bands 1..400, target shorter / longer than the query)."""
+    import numpy as np
+    from common import gcig_workload
+    _, _, jobs, seqs = gcig_workload()
+    G = np.load(os.path.join(GOLDEN, "gcig_golden.npz"))
+    off = np.concatenate([[0], np.cumsum(G["n_cigar"])])
+    for k, (J, (q, t)) in enumerate(zip(jobs, seqs)):
+        sc, cg = O.ksw_global2(q, t, int(J["w"]))
+        assert sc == int(G["score"][k]) and np.array_equal(cg, G["cigars"][off[k]:off[k + 1]]), (k, sc, int(G["score"][k]))

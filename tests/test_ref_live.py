@@ -65,3 +65,16 @@ def test_ext_oracle_equals_reference_on_other_options(w, clip, zdrop):
         bad = np.nonzero(got[f][sel] != want[f][sel])[0]
         assert bad.size == 0, (f, int(bad[0]), int(got[f][bad[0]]), int(want[f][bad[0]]))
     assert np.array_equal(got["frac_rep"].view(np.uint32), want["frac_rep"].view(np.uint32))
+
+
+@needs_stage
+def test_ksw_global2_oracle_equals_reference_on_other_penalties():
+    """orc_ksw_global2 == the compiled reference's ksw_global2 with other scores (asymmetric gap penalties, cheap gaps: the case the
+    reference's comment warns about, insertion next to deletion) on a sample of the fixture's alignments."""
+    from common import gcig_workload
+    _, _, jobs, seqs = gcig_workload(n=600, seed=91)
+    for a, b, od, ed, oi, ei in ((1, 4, 6, 1, 6, 1), (2, 3, 4, 2, 7, 1), (1, 9, 1, 1, 1, 1), (3, 1, 5, 3, 2, 2)):
+        for J, (q, t) in zip(jobs, seqs):
+            want = ref_py.ksw_global2(q, t, int(J["w"]), a, b, od, ed, oi, ei)
+            got = O.ksw_global2(q, t, int(J["w"]), a, b, od, ed, oi, ei)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]), (a, b, od, ed, oi, ei, int(J["w"]), got[0], want[0])
