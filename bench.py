@@ -305,7 +305,10 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                 env["MEME_DROPIN_VIRTUAL"] = str(devices)
             t0 = time.time()
             with open(sam, "wb") as fh:
-                r = subprocess.run([os.path.join(ref_dir, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(threads),
+                # the reference does its seeding and extension on the host threads: all of them; with the backend bound the host threads only
+                # do the SAM phase and 64 of them are faster than 256 (allocator contention in worker_sam, profiles/r03_e2e_threads.md)
+                nthr = threads if exe == "bwa-meme_mode3" else min(threads, int(os.environ.get("MEME_BENCH_E2E_DROPIN_THREADS", "64")))
+                r = subprocess.run([os.path.join(ref_dir, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(nthr),
                                     prefix] + fqs, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=3000)
             wall = time.time() - t0
             err = r.stderr.decode(errors="replace")
@@ -317,7 +320,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
             proc = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
             md5, nlines = sam_md5(sam)
             os.remove(sam)
-            info = {"wall_s": wall, "process_s": proc, "reads_per_s_wall": 2 * npairs / wall,
+            info = {"threads": nthr, "wall_s": wall, "process_s": proc, "reads_per_s_wall": 2 * npairs / wall,
                     "reads_per_s_process": 2 * npairs / proc if proc > 0 else None, "sam_md5": md5, "sam_lines": nlines}
             m = re.search(r"Runtime-build-index took ([0-9.]+) sec", err)
             if m:
@@ -331,6 +334,10 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                                    "bsw_backend_s": float(m.group(6)), "bsw_kernel_s": float(m.group(7))}
             for m in re.finditer(r"extension: this chunk .*?totals ([0-9.]+) s, (\d+) backend calls", err):
                 info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # host stage (MEME_DROPIN_EXT=host): jobs built + calls + fold + purge
+            for m in re.finditer(r"CIGAR stage on the device: (\d+) global alignments with traceback posed so far \(kernels ([0-9.]+) s, whole pre-pass ([0-9.]+) s\); "
+                                 r"ksw_global2 calls answered from the table (\d+), computed by the reference's function (\d+)", err):
+                info.setdefault("backend", {}).update({"cigar_jobs": int(m.group(1)), "cigar_kernels_s": float(m.group(2)), "cigar_prepass_s": float(m.group(3)),
+                                                        "cigar_calls_from_table": int(m.group(4)), "cigar_calls_by_reference": int(m.group(5))})
             for m in re.finditer(r"chaining \+ extension on the device: ([0-9.]+) s in the backend calls so far \(HIP events: chaining ([0-9.]+) s, extension stage "
                                  r"([0-9.]+) s of which banded SW ([0-9.]+) s\); (\d+) alignment records, (\d+) extension jobs \((\d+) of them again with the doubled "
                                  r"band\), (\d+) reads chained by the wavefront-per-read tier, (\d+) reads chained on the host", err):

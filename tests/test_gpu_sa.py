@@ -1,5 +1,5 @@
 """Device-side suffix-array construction (meme_sa_build_device) against the host builder, whose output is verified
-byte-identical to `bwa-meme index -a meme` (tests/test_host_index.py)."""
+byte-identical to `bwa-meme index -a meme` (tests/test_ref_live.py, where the compiled reference is available)."""
 import numpy as np
 import pytest
 

@@ -78,3 +78,97 @@ def test_ksw_global2_oracle_equals_reference_on_other_penalties():
             want = ref_py.ksw_global2(q, t, int(J["w"]), a, b, od, ed, oi, ei)
             got = O.ksw_global2(q, t, int(J["w"]), a, b, od, ed, oi, ei)
             assert got[0] == want[0] and np.array_equal(got[1], want[1]), (a, b, od, ed, oi, ei, int(J["w"]), got[0], want[0])
+
+
+needs_aligner = pytest.mark.skipif(not (ref_py.have("bwa-meme_mode3") and ref_py.cpu_can_run()), reason="compiled reference (bwa-meme_mode3) not available")
+
+
+@needs_aligner
+@pytest.mark.parametrize("case", ["plain", "runs_and_N"])
+def test_index_files_byte_identical_to_bwa_meme_index(tmp_path, case):
+    """`meme-index build` (bwa-meme_amd/host) against `bwa-meme index -a meme` (reference src/Learnedindex.cpp:456-548, src/bwtindex.cpp,
+    src/bntseq.cpp:313-371) on the same FASTA: all six files the learned path reads -- .pac .ann .amb .0123 .pos_packed
+    .suffixarray_uint64 -- byte for byte.  Second case: several contigs, long A / T runs at contig ends (the T-padding rule of the
+    suffix order) and ambiguous bases (replaced by the reference's srand48(11) stream, recorded in .amb)."""
+    import filecmp
+    import shutil
+    import subprocess
+    from pymeme import synth
+    rng = np.random.default_rng(5)
+    if case == "plain":
+        g = synth.make_genome(200_000, seed=31, repeat_frac=0.05)
+        fa = str(tmp_path / "a.fa")
+        synth.write_fasta(fa, g, contigs=2)
+    else:
+        g = synth.make_genome(120_000, seed=32, repeat_frac=0.03)
+        g[:40] = 0; g[-55:] = 3; g[60_000:60_070] = 3; g[30_000:30_033] = 0
+        fa = str(tmp_path / "a.fa")
+        seq = np.frombuffer(b"ACGT", np.uint8)[g].copy()
+        for p in rng.integers(100, g.shape[0] - 100, size=12):
+            seq[p:p + int(rng.integers(1, 30))] = ord("N")
+        cuts = [0, 25_000, 60_035, 90_001, g.shape[0]]
+        with open(fa, "w") as fh:
+            for k in range(4):
+                fh.write(">ctg%d some text\n" % k)
+                s = seq[cuts[k]:cuts[k + 1]].tobytes().decode()
+                for i in range(0, len(s), 70):
+                    fh.write(s[i:i + 70] + "\n")
+    ours = str(tmp_path / "ours.fa")
+    theirs = str(tmp_path / "theirs.fa")
+    shutil.copy(fa, ours)
+    shutil.copy(fa, theirs)
+    subprocess.run([os.path.join(O.REPO, "bwa-meme_amd", "meme-index"), "build", ours, "-b", "12", "-t", "4"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(ref_py.REF_DIR, "bwa-meme_mode3"), "index", "-a", "meme", "-t", "4", theirs], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    for ext in (".pac", ".ann", ".amb", ".0123", ".pos_packed", ".suffixarray_uint64"):
+        assert os.path.exists(theirs + ext), ext
+        if ext == ".ann":      # (the first line carries the FASTA's seed-independent numbers only; compare as text)
+            assert open(ours + ext).read() == open(theirs + ext).read(), ext
+        else:
+            assert filecmp.cmp(ours + ext, theirs + ext, shallow=False), ext
+
+
+@pytest.mark.skipif(not (ref_py.have("learned_seeding_count1") and ref_py.have("learned_seeding_count3") and ref_py.cpu_can_run()),
+                    reason="compiled reference with Count_mem_ref (oracle/Makefile.ref) not available")
+def test_refpath_work_counters_match_the_reference_own_counters(tmp_path):
+    """oracle/meme_refpath.c's work counters (what bench.py's roofline numerator is made of: model lookups and suffix-array compares per
+    read) against the REFERENCE'S OWN counters: the seeding harness rebuilt with Count_mem_ref 1 (src/LearnedIndex_seeding.h:94) prints,
+    per search, how many entries it compared (binary + linear + min_intv phases).  MODE 1 has the probe sequence the restatement
+    follows (no inverse suffix array).  A few of the reference's exits return without printing their line (~4 % of the searches), so it
+    reports slightly fewer searches AND leaves out those searches' compares: searches must agree within 6 %, compares within 3 %, and
+    the surplus of compares must be what the unprinted searches account for (a handful of compares each).  MODE 3 (ISA shortcuts for reads that matched end to end) does less work: reported."""
+    import re
+    import subprocess
+    from common import build_index
+    from pymeme import synth
+    g = synth.make_genome(2_000_000, seed=301, repeat_frac=0.04)
+    fa = str(tmp_path / "c.fa")
+    synth.write_fasta(fa, g, contigs=2)
+    prefix = build_index(fa, bits=16)
+    reads, _, _ = synth.make_reads(g, 3000, 150, seed=302, n_frac=0.02)
+    fq = str(tmp_path / "c.fq")
+    synth.write_fastq(fq, reads, prefix="c")
+    idx = O.load_index_files(prefix)
+    l1, l2 = O.load_prmi_files(prefix)
+    off = np.arange(0, (reads.shape[0] + 1) * 150, 150, dtype=np.int64)
+    _, _, ctr = O.refpath_seed_batch(idx, l1, l2, reads.reshape(-1), off, threads=1)
+    got = {}
+    for mode in (1, 3):
+        r = subprocess.run([os.path.join(ref_py.REF_DIR, "learned_seeding_count%d" % mode), prefix, fq, "1000", "1", "3"], capture_output=True, text=True)
+        assert r.returncode == 0
+        lines = compares = 0
+        for line in r.stdout.splitlines():
+            m = re.search(r"Count Total: (\d+)", line)
+            if m:
+                lines += 1; compares += int(m.group(1))
+                continue
+            m = re.search(r"Count_bs:(\d+) Count_linear:(\d+) Count_minintv:(\d+)", line)
+            if m:
+                lines += 1; compares += sum(int(x) for x in m.groups())
+        got[mode] = (lines, compares)
+    lines1, cmp1 = got[1]
+    assert lines1 <= ctr["lookups"] <= 1.06 * lines1, (ctr, got)
+    assert cmp1 <= ctr["compares"] <= 1.03 * cmp1, (ctr, got)
+    assert ctr["compares"] - cmp1 <= 8 * (ctr["lookups"] - lines1), (ctr, got)
+    assert got[3][1] < cmp1                         # the ISA shortcut saves compares, not searches
+    print("MODE 3 / MODE 1 compares: %.3f; restatement / MODE 1: %.4f" % (got[3][1] / cmp1, ctr["compares"] / cmp1))
