@@ -1372,7 +1372,8 @@ void meme_dropin_report_matesw() {
 // on the GPU(s) as one batch per band attempt (meme_global_batch_host) and keeps score + CIGAR; ksw_global2 calls are then answered
 // from that table after an exact comparison of both sequences.  Calls the table does not hold (alignments made later by mate rescue,
 // calls without traceback from mem_patch_reg) go to the reference's function.  MEME_DROPIN_CIGAR=0 switches the stage off.
-#include <unordered_map>
+#include <omp.h>
+#include <parallel/algorithm>
 namespace {
 
 struct CigEntry { int64_t g; int64_t rb; int32_t qb, qlen, tlen, w, rev, score, n_cigar; int64_t ops; };
@@ -1381,7 +1382,7 @@ struct CigTable {
     uint64_t gen = 0;
     std::vector<CigEntry> e;
     std::vector<uint32_t> ops;
-    std::unordered_multimap<uint64_t, uint32_t> idx;
+    std::vector<std::pair<uint64_t, uint32_t>> idx;      // (key, entry), sorted
     double t_prepass = 0, t_kernel_ms = 0;
     int64_t n_jobs = 0;
 } g_cig;
@@ -1421,6 +1422,9 @@ inline bool gen_cigar_band(const mem_opt_t* opt, int64_t l_pac, int l_query, int
     return true;
 }
 
+// helper threads of the pre-pass's host loops: a few dozen are enough, and an OpenMP team of 256 would still be spinning when worker_sam starts
+int cig_threads() { const int m = omp_get_max_threads(); return m < 32 ? m : 32; }
+
 void cig_prepass() {
     const double t0 = now_s();
     CigTable& T = g_cig;
@@ -1430,25 +1434,38 @@ void cig_prepass() {
     // per alignment record: where mem_reg2aln's loop stands (band of the next call, score of the last one)
     struct Cand { int64_t g; int32_t reg, w2, last_sc, tries; };
     std::vector<Cand> cand;
-    for (int64_t g = 0; g < n; ++g) {
-        const mem_alnreg_v& av = g_worker->regs[g];
-        for (size_t i = 0; i < av.n; ++i) {
-            const mem_alnreg_t& p = av.a[i];
-            if (p.rb < 0 || p.re < 0 || p.score < opt->T) continue;
-            if (p.secondary >= 0 && p.secondary < (int)av.n && p.score < av.a[p.secondary].score * opt->XA_drop_ratio) continue;
-            const int tmp = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_del, opt->e_del);
-            int w2 = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_ins, opt->e_ins);
-            w2 = w2 > tmp ? w2 : tmp;
-            if (w2 > opt->w) w2 = w2 < p.w ? w2 : p.w;
-            cand.push_back({g, (int32_t)i, w2, -(1 << 30), 0});
+    {
+        const int nt = cig_threads();
+        std::vector<std::vector<Cand>> part((size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+            std::vector<Cand>& mine = part[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+            for (int64_t g = 0; g < n; ++g) {
+                const mem_alnreg_v& av = g_worker->regs[g];
+                for (size_t i = 0; i < av.n; ++i) {
+                    const mem_alnreg_t& p = av.a[i];
+                    if (p.rb < 0 || p.re < 0 || p.score < opt->T) continue;
+                    if (p.secondary >= 0 && p.secondary < (int)av.n && p.score < av.a[p.secondary].score * opt->XA_drop_ratio) continue;
+                    const int tmp = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_del, opt->e_del);
+                    int w2 = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_ins, opt->e_ins);
+                    w2 = w2 > tmp ? w2 : tmp;
+                    if (w2 > opt->w) w2 = w2 < p.w ? w2 : p.w;
+                    mine.push_back({g, (int32_t)i, w2, -(1 << 30), 0});
+                }
+            }
         }
+        size_t tot = 0;
+        for (auto& v : part) tot += v.size();
+        cand.reserve(tot);
+        for (auto& v : part) cand.insert(cand.end(), v.begin(), v.end());      // (static schedule: still in read order)
     }
     const int nd = (int)g_dev.size();
     meme_bsw_opt bo;
     memset(&bo, 0, sizeof(bo));
     bo.o_del = opt->o_del; bo.e_del = opt->e_del; bo.o_ins = opt->o_ins; bo.e_ins = opt->e_ins; bo.a = opt->a; bo.b = opt->b;
     for (int round = 0; round < 3 && !cand.empty(); ++round) {
-        // this round's calls, per device part
+        // this round's calls, per device part (candidates are in read order: a part's candidates are contiguous)
         std::vector<std::vector<meme_gjob>> jobs((size_t)nd);
         std::vector<std::vector<uint32_t>> who((size_t)nd);
         for (size_t c = 0; c < cand.size(); ++c) {
@@ -1478,19 +1495,24 @@ void cig_prepass() {
         std::vector<Cand> next;
         for (int d = 0; d < nd; ++d) {
             const meme_gres_host& R = res[(size_t)d];
+            if (R.njobs == 0) continue;
             T.t_kernel_ms += R.kernel_ms;
             T.n_jobs += R.njobs;
+            const size_t e0 = T.e.size(), o0 = T.ops.size();
+            T.ops.insert(T.ops.end(), R.cigars, R.cigars + R.total_ops);      // the device packs the operations in job order
+            T.e.resize(e0 + (size_t)R.njobs);
+#pragma omp parallel for schedule(static) num_threads(cig_threads())
             for (int64_t k = 0; k < R.njobs; ++k) {
                 const meme_gjob& J = jobs[(size_t)d][(size_t)k];
-                Cand& C = cand[who[(size_t)d][(size_t)k]];
-                CigEntry E;
-                E.g = C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev; E.score = R.res[k].score; E.n_cigar = R.res[k].n_cigar;
-                E.ops = (int64_t)T.ops.size();
-                T.ops.insert(T.ops.end(), R.cigars + R.res[k].cigar_off, R.cigars + R.res[k].cigar_off + E.n_cigar);
-                T.e.push_back(E);
+                CigEntry& E = T.e[e0 + (size_t)k];
+                E.g = cand[who[(size_t)d][(size_t)k]].g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev;
+                E.score = R.res[k].score; E.n_cigar = R.res[k].n_cigar; E.ops = (int64_t)o0 + R.res[k].cigar_off;
+            }
+            for (int64_t k = 0; k < R.njobs; ++k) {
                 // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
+                Cand& C = cand[who[(size_t)d][(size_t)k]];
                 const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
-                const int score = E.score;
+                const int score = R.res[k].score;
                 if (score == C.last_sc || C.w2 == opt->w << 2) continue;
                 C.last_sc = score;
                 C.w2 <<= 1;
@@ -1499,17 +1521,16 @@ void cig_prepass() {
         }
         cand.swap(next);
     }
-    // index: sequences hashed the way the hook will see them (both reversed on the reverse strand)
+    // index: sequences hashed the way the hook will see them (both reversed on the reverse strand); sorted by key, looked up by bisection
     const uint8_t* ref = g_worker->ref_string;
-    std::vector<uint64_t> keys(T.e.size());
-#pragma omp parallel for schedule(static)
+    T.idx.resize(T.e.size());
+#pragma omp parallel for schedule(static) num_threads(cig_threads())
     for (int64_t k = 0; k < (int64_t)T.e.size(); ++k) {
         const CigEntry& E = T.e[(size_t)k];
         const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
-        keys[(size_t)k] = cig_key(E.qlen, E.tlen, E.w, hash_bytes(q, E.qlen, E.rev), hash_bytes(ref + E.rb, E.tlen, E.rev));
+        T.idx[(size_t)k] = {cig_key(E.qlen, E.tlen, E.w, hash_bytes(q, E.qlen, E.rev), hash_bytes(ref + E.rb, E.tlen, E.rev)), (uint32_t)k};
     }
-    T.idx.reserve(T.e.size() * 2);
-    for (size_t k = 0; k < T.e.size(); ++k) T.idx.emplace(keys[k], (uint32_t)k);
+    __gnu_parallel::sort(T.idx.begin(), T.idx.end(), __gnu_parallel::default_parallel_tag((unsigned)cig_threads()));
     T.t_prepass += now_s() - t0;
 }
 
@@ -1527,9 +1548,8 @@ extern "C" int ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8
     CigTable& T = g_cig;
     if (T.gen != g_chunk_gen) return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);   // (no table for this chunk)
     const uint64_t key = cig_key(qlen, tlen, w, hash_bytes(query, qlen, false), hash_bytes(target, tlen, false));
-    auto range = T.idx.equal_range(key);
     const uint8_t* ref = g_worker->ref_string;
-    for (auto it = range.first; it != range.second; ++it) {
+    for (auto it = std::lower_bound(T.idx.begin(), T.idx.end(), std::make_pair(key, (uint32_t)0)); it != T.idx.end() && it->first == key; ++it) {
         const CigEntry& E = T.e[it->second];
         if (E.qlen != qlen || E.tlen != tlen || E.w != w) continue;
         const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
@@ -1579,50 +1599,79 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
 // bseq_read_orig() (src/bwa.cpp:184-230) parses both files of a paired run with one thread, read by read; with the backend bound
 // that parser is the longest stage of the aligner's three-stage pipeline (0.9 s per 100 M-base chunk against 0.5-0.7 s of compute).
 // The records come from the same kseq_read() calls on the same streams, in the same order -- only that each stream has a thread
-// of its own that keeps a bounded queue filled, and the pipeline's step 0 takes what is ready.  Opt-in (MEME_DROPIN_IO=1): it
-// halves the time the pipeline spends reading (3.2 -> 1.3 s for 4 M reads), but on the shared test boxes the two parser threads and
-// their allocations slowed the first chunks' compute by as much, so the measured end-to-end time did not improve.
+// of its own that keeps a bounded queue filled (records travel in batches of 4 096), and the pipeline's step 0 takes what is ready.
+// MEME_DROPIN_IO=0 switches it off (the reference's reader).
 #include <deque>
 namespace {
 
 struct ReadQueue {
+    // Records travel in batches: one lock + one wake-up per BATCH records (per-record locking cost more than the parsing it was meant to
+    // hide).  The parser thread keeps a batch's text in ONE arena; the strings the reference frees one by one (free(seqs[i].name) ... in
+    // its output step) are allocated by the caller of bseq_read_orig, as in the reference -- strings allocated by the parser threads
+    // would be freed into those threads' malloc arenas while they allocate from them (measured: the SAM-writing step 3x slower).
+    static constexpr int BATCH = 4096;
+    struct Rec { uint32_t name, name_l, comment, comment_l, seq, seq_l, qual, qual_l; };     // offsets into the arena; comment / qual: *_l == UINT32_MAX when absent
+    struct Batch { std::vector<char> text; std::vector<Rec> recs; int64_t bases = 0; };
     std::mutex m;
     std::condition_variable cv_put, cv_get;
-    std::deque<bseq1_t> q;
-    int64_t bases = 0;
+    std::deque<Batch> q;
+    int64_t bases = 0;                                          // parsed and not yet taken
     bool eof = false;
     kseq_t* ks = nullptr;
     std::thread th;
     int64_t LIMIT = 100000000;                                 // bases parsed ahead per stream (set to the chunk size on the first call)
+    Batch cur;                                                  // the consumer's current batch
+    size_t cur_i = 0;
+    static uint32_t put(std::vector<char>& t, const char* p, size_t l) { const uint32_t o = (uint32_t)t.size(); t.insert(t.end(), p, p + l); t.push_back(0); return o; }
     void run() {
+        Batch b;
+        b.recs.reserve(BATCH);
         for (;;) {
             const bool got = kseq_read(ks) >= 0;
-            bseq1_t b;
-            memset(&b, 0, sizeof(b));
-            if (got) {                                           // trim_readno + kseq2bseq1, src/bwa.cpp:66-89
+            if (got) {                                           // trim_readno, src/bwa.cpp:66-70
                 if (ks->name.l > 2 && ks->name.s[ks->name.l - 2] == '/' && isdigit((unsigned char)ks->name.s[ks->name.l - 1])) { ks->name.l -= 2; ks->name.s[ks->name.l] = 0; }
-                b.name = strdup(ks->name.s);
-                b.comment = ks->comment.l ? strdup(ks->comment.s) : 0;
-                b.seq = strdup(ks->seq.s);
-                b.qual = ks->qual.l ? strdup(ks->qual.s) : 0;
-                b.l_seq = (int)strnlen(b.seq, ERT_MAX_READ_LEN);  // strnlen_s(s->seq, ERT_MAX_READ_LEN)
+                Rec r;
+                r.name_l = (uint32_t)strlen(ks->name.s); r.name = put(b.text, ks->name.s, r.name_l);          // (strdup: up to the first NUL)
+                if (ks->comment.l) { r.comment_l = (uint32_t)strlen(ks->comment.s); r.comment = put(b.text, ks->comment.s, r.comment_l); } else { r.comment = 0; r.comment_l = UINT32_MAX; }
+                r.seq_l = (uint32_t)strlen(ks->seq.s); r.seq = put(b.text, ks->seq.s, r.seq_l);
+                if (ks->qual.l) { r.qual_l = (uint32_t)strlen(ks->qual.s); r.qual = put(b.text, ks->qual.s, r.qual_l); } else { r.qual = 0; r.qual_l = UINT32_MAX; }
+                b.recs.push_back(r);
+                b.bases += r.seq_l < (uint32_t)ERT_MAX_READ_LEN ? r.seq_l : (uint32_t)ERT_MAX_READ_LEN;
             }
-            std::unique_lock<std::mutex> lk(m);
-            if (!got) { eof = true; cv_get.notify_all(); return; }
-            cv_put.wait(lk, [&] { return bases < LIMIT; });
-            q.push_back(b);
-            bases += b.l_seq;
-            cv_get.notify_one();
+            if (!got || (int)b.recs.size() == BATCH) {
+                std::unique_lock<std::mutex> lk(m);
+                if (!b.recs.empty()) {
+                    cv_put.wait(lk, [&] { return bases < LIMIT; });
+                    bases += b.bases;
+                    q.push_back(std::move(b));
+                    b = Batch(); b.recs.reserve(BATCH);
+                }
+                if (!got) eof = true;
+                cv_get.notify_all();
+                if (!got) return;
+            }
         }
     }
-    bool pop(bseq1_t& out) {                                     // false: the stream is exhausted
-        std::unique_lock<std::mutex> lk(m);
-        cv_get.wait(lk, [&] { return !q.empty() || eof; });
-        if (q.empty()) return false;
-        out = q.front();
-        q.pop_front();
-        bases -= out.l_seq;
-        cv_put.notify_one();
+    static char* dup(const char* p, uint32_t l) { char* s = (char*)malloc((size_t)l + 1); if (!s) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); } memcpy(s, p, (size_t)l + 1); return s; }
+    bool pop(bseq1_t& out) {                                     // false: the stream is exhausted.  kseq2bseq1, src/bwa.cpp:82-89
+        if (cur_i == cur.recs.size()) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_get.wait(lk, [&] { return !q.empty() || eof; });
+            if (q.empty()) return false;
+            cur = std::move(q.front());
+            q.pop_front();
+            cur_i = 0;
+            bases -= cur.bases;
+            cv_put.notify_one();
+        }
+        const Rec& r = cur.recs[cur_i++];
+        const char* t = cur.text.data();
+        memset(&out, 0, sizeof(out));
+        out.name = dup(t + r.name, r.name_l);
+        out.comment = r.comment_l == UINT32_MAX ? 0 : dup(t + r.comment, r.comment_l);
+        out.seq = dup(t + r.seq, r.seq_l);
+        out.qual = r.qual_l == UINT32_MAX ? 0 : dup(t + r.qual, r.qual_l);
+        out.l_seq = (int)(r.seq_l < (uint32_t)ERT_MAX_READ_LEN ? r.seq_l : (uint32_t)ERT_MAX_READ_LEN);   // strnlen_s(s->seq, ERT_MAX_READ_LEN)
         return true;
     }
 };
@@ -1633,7 +1682,7 @@ typedef bseq1_t* (*bseq_read_fn)(int64_t, int*, void*, void*, int64_t*);
 }  // namespace
 
 extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void* ks2_, int64_t* s) {
-    static const bool on = getenv("MEME_DROPIN_IO") && atoi(getenv("MEME_DROPIN_IO")) != 0;      // opt-in: see the note above
+    static const bool on = !(getenv("MEME_DROPIN_IO") && atoi(getenv("MEME_DROPIN_IO")) == 0);
     static bseq_read_fn next = (bseq_read_fn)dlsym(RTLD_NEXT, "bseq_read_orig");
     // only the run's read files (the first streams seen); any other caller gets the reference's function
     if (on && !g_rq[0] && ks1_) {

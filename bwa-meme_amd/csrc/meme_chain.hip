@@ -317,6 +317,7 @@ struct FRec { int beg, end, w, first; int kept, is_alt, id, pad; };   // the fil
 
 struct WaveArgs {
     const i64* list; const i64* woff; i64 nlist;     // reads of this tier, exclusive prefix of their work
+    const i64* sub; i64 nsub;                        // B-tree tier: the entries of `list` it takes (those the register tier left)
     C2* C; S2* S; FRec* F; u64* srt; int* ia; int* ib; TNode* nodes;
 };
 
@@ -423,7 +424,8 @@ __global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 
     __shared__ u64 lds_srt[SRT_LDS];
     __shared__ int stk_x[40], stk_i[20];
     __shared__ i64 lds_contig[CONTIG_LDS];
-    const i64 t = t_first + blockIdx.x;
+    if (W.sub && (i64)blockIdx.x >= W.nsub) return;
+    const i64 t = W.sub ? W.sub[blockIdx.x] : t_first + blockIdx.x;
     if (t >= W.nlist) return;
     const int lane = threadIdx.x;
     if (A.n_contigs <= CONTIG_LDS) {                 // bns_intv2rid searches the contig offsets twice per hit
@@ -710,6 +712,367 @@ __global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 
     }
 }
 
+// ---- tier 2: one wavefront per read, the chains in registers ----------------------------------------------------------------------
+// Repeat-rich reads make tens to hundreds of chains from hundreds of hits.  Here a read's chains live in the wavefront's registers:
+// chain slot s = k * 64 + lane (k < REG_K, up to 256 chains), each slot its position, its last seed, and the running coverage sums that
+// mem_chain_weight (src/bwamem.cpp:522-541) would compute -- so a hit costs a wave-wide max (the chain with the closest position at
+// or below it: what the reference asks its B-tree), a few lane reads of that chain's fields and a predicated update; no memory round
+// trip except the stores of the seed records.  As long as all chain positions differ, the B-tree's in-order traversal is simply the
+// order of the positions; a read that would put two chains on ONE position (then the tree's shape matters) or needs more than 256
+// chains leaves with fallback = 3 and is done by the B-tree tier below.  The filter's sort replays klib's introsort on (weight, chain)
+// pairs held one per lane slot, read and written through v_readlane / predicated moves (tens of cycles per access instead of a memory
+// round trip), and the overlap loop of mem_chain_flt runs lane-parallel over the kept chains.
+constexpr int REG_K = 4;
+constexpr int REG_CHAINS = REG_K * 64;
+
+__device__ __forceinline__ int rdl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ i64 rdl64(i64 v, int l) {
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((i64)hi << 32) | (i64)(unsigned)lo;
+}
+// element i of a per-lane array of REG_K registers (element = k * 64 + lane); i is wave-uniform
+#define REG_SEL(a_, k_) ((k_) == 0 ? (a_)[0] : (k_) == 1 ? (a_)[1] : (k_) == 2 ? (a_)[2] : (a_)[3])
+__device__ __forceinline__ int reg_get(const int (&a)[REG_K], int i) { const int k = i >> 6; const int v = REG_SEL(a, k); return rdl(v, i & 63); }
+__device__ __forceinline__ i64 reg_get64(const i64 (&a)[REG_K], int i) { const int k = i >> 6; const i64 v = REG_SEL(a, k); return rdl64(v, i & 63); }
+__device__ __forceinline__ void reg_set(int (&a)[REG_K], int i, int v, int lane) {
+    const int k = i >> 6;
+    const bool me = lane == (i & 63);
+#pragma unroll
+    for (int q = 0; q < REG_K; ++q) if (q == k && me) a[q] = v;
+}
+__device__ __forceinline__ void reg_set64(i64 (&a)[REG_K], int i, i64 v, int lane) {
+    const int k = i >> 6;
+    const bool me = lane == (i & 63);
+#pragma unroll
+    for (int q = 0; q < REG_K; ++q) if (q == k && me) a[q] = v;
+}
+__device__ __forceinline__ i64 wave_max64(i64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y > v ? y : v; }
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_chain_reg(ChainArgs A, WaveArgs W) {
+    __shared__ int s_w[REG_CHAINS], s_id[REG_CHAINS], s_beg[REG_CHAINS], s_end[REG_CHAINS], s_n[REG_CHAINS], s_alt[REG_CHAINS];
+    __shared__ i64 lds_contig[CONTIG_LDS];
+    __shared__ int stk[60];
+    const i64 t = blockIdx.x;
+    if (t >= W.nlist) return;
+    const int lane = threadIdx.x;
+    if (A.n_contigs <= CONTIG_LDS) {
+        for (int i = lane; i < A.n_contigs; i += 64) lds_contig[i] = A.contig_off[i];
+        __syncthreads();
+        A.contig_off = lds_contig;
+    }
+    const i64 r = W.list[t];
+    const i64 base = W.woff[t];
+    const meme_chain_opt& o = A.o;
+    const meme_mem_tl* sm = A.smems + A.smem_off[r];
+    const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
+    const u64* ht = A.hits + A.hit_off[r];
+    const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
+    C2* C = W.C + base;
+    S2* S = W.S + base;
+    FRec* F = W.F + base;
+    int* ia = W.ia + base;
+    // SMEMs in (start, end) order (src/bwamem.cpp:1397): rank by counting
+    for (int i = lane; i < ns; i += 64) {
+        const int s = sm[i].start, e = sm[i].end;
+        int rank = 0;
+        for (int j = 0; j < ns; ++j) {
+            const int sj = sm[j].start, ej = sm[j].end;
+            rank += (sj < s || (sj == s && (ej < e || (ej == e && j < i)))) ? 1 : 0;
+        }
+        ia[rank] = i;
+    }
+    wave_fence();
+    // ---- the chains: slot s = k * 64 + lane
+    i64 pos[REG_K];
+    int rid[REG_K], cn[REG_K], fqb[REG_K], lrb[REG_K], lqb[REG_K], lln[REG_K], tail[REG_K], wq[REG_K], eq[REG_K], wr[REG_K], er[REG_K];
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) { pos[k] = -1; rid[k] = cn[k] = fqb[k] = lrb[k] = lqb[k] = lln[k] = tail[k] = wq[k] = eq[k] = wr[k] = er[k] = 0; }
+    int nchain = 0, nseed = 0, bail = 0;
+    int fb = 0, fe = 0, l_rep = 0;
+    for (int si = 0; si < ns && !bail; ++si) {
+        const meme_mem_tl p = sm[ia[si]];
+        if (p.hitcount > o.max_occ) {                                     // frac_rep (:1140-1147)
+            if (p.start > fe) { l_rep += fe - fb; fb = p.start; fe = p.end; }
+            else fe = fe > p.end ? fe : p.end;
+        }
+        const int slen = p.end - p.start, qb = p.start;
+        const int step = p.hitcount > o.max_occ ? p.hitcount / o.max_occ : 1;
+        int cnt = (p.hitcount + step - 1) / step;
+        if (cnt > o.max_occ) cnt = o.max_occ;
+        for (int cb = 0; cb < cnt && !bail; cb += 64) {
+            const int c = cb + lane;
+            const bool have = c < cnt;
+            const i64 h_rbeg = have ? (i64)ht[p.hitbeg + (i64)c * step] : 0;
+            const int h_rid = have ? intv2rid(A, h_rbeg, h_rbeg + slen) : -1;
+            u64 todo = __ballot(h_rid >= 0);                              // (:1166: seeds bridging two sequences or the strands are dropped)
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const i64 rb = rdl64(h_rbeg, j);
+                const int hr = rdl(h_rid, j);
+                // the chain with the largest position <= rb (kb_intervalp's lower; all positions differ)
+                i64 best = -1;
+#pragma unroll
+                for (int k = 0; k < REG_K; ++k) if (pos[k] >= 0 && pos[k] <= rb && pos[k] > best) best = pos[k];
+                const i64 M = wave_max64(best);
+                int out = 2, ow = 0;                                      // 0 contained, 1 append, 2 new chain; ow = the chain's slot
+                if (M >= 0) {
+                    int ok = -1, ol = 0;
+#pragma unroll
+                    for (int k = 0; k < REG_K; ++k) { const u64 bm = __ballot(pos[k] == M); if (ok < 0 && bm) { ok = k; ol = __builtin_ctzll(bm); } }
+                    ow = ok * 64 + ol;
+                    const int c_rid = reg_get(rid, ow), c_fqb = reg_get(fqb, ow), c_lrb = reg_get(lrb, ow), c_lqb = reg_get(lqb, ow), c_lln = reg_get(lln, ow);
+                    const i64 l_rbeg = M + c_lrb;
+                    if (hr == c_rid) {                                    // test_and_merge (:450-492)
+                        const i64 qend = c_lqb + c_lln, rend = l_rbeg + c_lln;
+                        if (qb >= c_fqb && qb + slen <= qend && rb >= M && rb + slen <= rend) out = 0;
+                        else if ((l_rbeg < o.l_pac || M < o.l_pac) && rb >= o.l_pac) out = 2;
+                        else {
+                            const i64 x = qb - c_lqb, y = rb - l_rbeg;
+                            if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c_lln < o.max_chain_gap && y - c_lln < o.max_chain_gap) out = 1;
+                        }
+                    }
+                }
+                if (out == 0) continue;
+                const int sid = nseed++;
+                if (lane == 0) { S2 sn; sn.rbeg = rb; sn.qbeg = qb; sn.len = slen; sn.next = -1; sn.pad = 0; S[sid] = sn; }
+                if (out == 1) {
+                    const int c_tail = reg_get(tail, ow);
+                    if (lane == 0) S[c_tail].next = sid;
+                    const int rel = (int)(rb - M);
+                    const int k = ow >> 6;
+                    const bool me = lane == (ow & 63);
+#pragma unroll
+                    for (int q = 0; q < REG_K; ++q) if (q == k && me) {
+                        cn[q] += 1; lrb[q] = rel; lqb[q] = qb; lln[q] = slen; tail[q] = sid;
+                        if (qb >= eq[q]) wq[q] += slen; else if (qb + slen > eq[q]) wq[q] += qb + slen - eq[q];
+                        eq[q] = eq[q] > qb + slen ? eq[q] : qb + slen;
+                        if (rel >= er[q]) wr[q] += slen; else if (rel + slen > er[q]) wr[q] += rel + slen - er[q];
+                        er[q] = er[q] > rel + slen ? er[q] : rel + slen;
+                    }
+                } else {
+                    if (M == rb || nchain == REG_CHAINS) { bail = 1; break; }     // equal positions / too many chains: the B-tree tier
+                    const int id = nchain++;
+                    if (lane == 0) C[id].head = sid;
+                    const int k = id >> 6;
+                    const bool me = lane == (id & 63);
+#pragma unroll
+                    for (int q = 0; q < REG_K; ++q) if (q == k && me) {
+                        pos[q] = rb; rid[q] = hr; cn[q] = 1; fqb[q] = qb; lrb[q] = 0; lqb[q] = qb; lln[q] = slen; tail[q] = sid;
+                        wq[q] = slen; eq[q] = qb + slen; wr[q] = slen; er[q] = slen;
+                    }
+                }
+            }
+        }
+    }
+    l_rep += fe - fb;
+    if (bail) {
+        if (lane == 0) { ReadHdr H; H.tree_size = 0; H.n_kept = 0; H.n_seeds = 0; H.fallback = 3; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base; A.hdr[r] = H; }
+        return;
+    }
+    // ---- chain records for the pack kernel; tree order = order of the positions: rank by counting
+    int rank[REG_K], cw[REG_K];
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+        rank[k] = 0;
+        int w = wq[k] < wr[k] ? wq[k] : wr[k];
+        cw[k] = w < 1 << 30 ? w : (1 << 30) - 1;
+        const int id = k * 64 + lane;
+        if (id < nchain) {
+            C2* c = &C[id];
+            c->pos = pos[k]; c->rid = rid[k]; c->n = cn[k]; c->w = cw[k]; c->is_alt = A.contig_alt[rid[k]] ? 1 : 0; c->tail = tail[k];
+        }
+    }
+    for (int u = 0; u < nchain; ++u) {
+        const i64 pu = reg_get64(pos, u);
+#pragma unroll
+        for (int k = 0; k < REG_K; ++k) rank[k] += (pu < pos[k]) ? 1 : 0;
+    }
+    // mem_chain_flt (src/bwamem.cpp:599-717): chains of at least min_chain_weight in tree order as (weight, chain) elements e = k * 64 + lane
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < REG_K; ++k) {
+        const int id = k * 64 + lane;
+        if (id < nchain) {
+            s_w[rank[k]] = cw[k]; s_id[rank[k]] = id;
+            s_beg[id] = fqb[k]; s_end[id] = lqb[k] + lln[k]; s_n[id] = cn[k]; s_alt[id] = A.contig_alt[rid[k]] ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    int ew[REG_K], eid[REG_K];
+    int n = 0;
+    {
+        int tw[REG_K], tid2[REG_K];
+        u64 keepm[REG_K];
+#pragma unroll
+        for (int k = 0; k < REG_K; ++k) {
+            const int e = k * 64 + lane;
+            tw[k] = e < nchain ? s_w[e] : 0; tid2[k] = e < nchain ? s_id[e] : 0;
+            keepm[k] = __ballot(e < nchain && tw[k] >= o.min_chain_weight);
+        }
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < REG_K; ++k) {
+            if ((keepm[k] >> lane) & 1) { const int d = before + __popcll(keepm[k] & (((u64)1 << lane) - 1)); s_w[d] = tw[k]; s_id[d] = tid2[k]; }
+            before += __popcll(keepm[k]);
+        }
+        n = before;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < REG_K; ++k) { const int e = k * 64 + lane; ew[k] = e < n ? s_w[e] : 0; eid[k] = e < n ? s_id[e] : 0; }
+    }
+    int n_kept = 0, n_seeds = 0;
+    if (n > 0) {
+        // ks_introsort(mem_flt) by weight, descending (klib ksort.h), on element indices: the same comparisons and swaps
+#define E_LT(i_, j_) (reg_get(ew, (i_)) > reg_get(ew, (j_)))
+#define E_SWAP(i_, j_) do { const int i__ = (i_), j__ = (j_); const int wi = reg_get(ew, i__), di = reg_get(eid, i__), wj = reg_get(ew, j__), dj = reg_get(eid, j__); \
+                            reg_set(ew, i__, wj, lane); reg_set(eid, i__, dj, lane); reg_set(ew, j__, wi, lane); reg_set(eid, j__, di, lane); } while (0)
+#define E_INSERT(s_, t_) do { for (int i_ = (s_) + 1; i_ < (t_); ++i_) for (int j_ = i_; j_ > (s_) && E_LT(j_, j_ - 1); --j_) E_SWAP(j_, j_ - 1); } while (0)
+        if (n == 2) { if (E_LT(1, 0)) E_SWAP(0, 1); }
+        else if (n > 2) {
+            int d;
+            for (d = 2; (1 << d) < n; ++d) {}
+            d <<= 1;
+            int s = 0, tt = n - 1, top = 0;
+            for (;;) {
+                if (s < tt) {
+                    if (--d == 0) {                                       // ks_combsort
+                        const int cnn = tt - s + 1;
+                        const double shrink = 1.2473309501039786540366528676643;
+                        bool do_swap;
+                        int gap = cnn;
+                        do {
+                            if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+                            do_swap = false;
+                            for (int i = s; i < s + cnn - gap; ++i) { const int j = i + gap; if (E_LT(j, i)) { E_SWAP(i, j); do_swap = true; } }
+                        } while (do_swap || gap > 2);
+                        if (gap != 1) E_INSERT(s, s + cnn);
+                        tt = s;
+                        continue;
+                    }
+                    int i = s, j = tt, k = i + ((j - i) >> 1) + 1;
+                    if (E_LT(k, i)) { if (E_LT(k, j)) k = j; }
+                    else k = E_LT(j, i) ? i : j;
+                    const int rpw = reg_get(ew, k);                       // the pivot's weight (the pivot element itself goes to tt)
+                    if (k != tt) E_SWAP(k, tt);
+                    for (;;) {
+                        do ++i; while (reg_get(ew, i) > rpw);
+                        do --j; while (i <= j && rpw > reg_get(ew, j));
+                        if (j <= i) break;
+                        E_SWAP(i, j);
+                    }
+                    E_SWAP(i, tt);
+                    if (i - s > tt - i) {
+                        if (i - s > 16) { stk[top] = s; stk[top + 20] = i - 1; stk[top + 40] = d; ++top; }
+                        s = tt - i > 16 ? i + 1 : tt;
+                    } else {
+                        if (tt - i > 16) { stk[top] = i + 1; stk[top + 20] = tt; stk[top + 40] = d; ++top; }
+                        tt = i - s > 16 ? i - 1 : s;
+                    }
+                } else {
+                    if (top == 0) { E_INSERT(0, n); break; }
+                    --top; s = stk[top]; tt = stk[top + 20]; d = stk[top + 40];
+                }
+            }
+        }
+#undef E_LT
+#undef E_SWAP
+#undef E_INSERT
+        // the filter's view of the sorted chains, element e on lane e & 63
+        int ebeg[REG_K], eend[REG_K], ealt[REG_K], efirst[REG_K], ekept[REG_K];
+#pragma unroll
+        for (int k = 0; k < REG_K; ++k) {
+            const int e = k * 64 + lane;
+            const int id = e < n ? eid[k] : 0;
+            ebeg[k] = s_beg[id]; eend[k] = s_end[id]; ealt[k] = s_alt[id]; efirst[k] = -1; ekept[k] = 0;
+        }
+        if (lane == 0) ekept[0] = 3;
+        for (int i = 1; i < n; ++i) {
+            const int bi = reg_get(ebeg, i), ei = reg_get(eend, i), wi = reg_get(ew, i), ai = reg_get(ealt, i);
+            // over the kept chains in order (= the sorted elements before i that were kept), up to the first that shadows chain i
+            bool lo[REG_K];
+            int brk = -1;
+#pragma unroll
+            for (int k = 0; k < REG_K; ++k) {
+                const int e = k * 64 + lane;
+                lo[k] = false;
+                bool br = false;
+                if (e < i && ekept[k] != 0) {
+                    const int b_max = ebeg[k] > bi ? ebeg[k] : bi, e_min = eend[k] < ei ? eend[k] : ei;
+                    if (e_min > b_max && (!ealt[k] || ai)) {
+                        const int li = ei - bi, lj = eend[k] - ebeg[k];
+                        const int min_l = li < lj ? li : lj;
+                        if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
+                            lo[k] = true;
+                            br = (float)wi < (float)ew[k] * o.drop_ratio && ew[k] - wi >= o.min_seed_len << 1;
+                        }
+                    }
+                }
+                const u64 brm = __ballot(br);
+                if (brk < 0 && brm) brk = k * 64 + __builtin_ctzll(brm);
+            }
+            bool large = false;
+#pragma unroll
+            for (int k = 0; k < REG_K; ++k) {
+                const int e = k * 64 + lane;
+                const bool upto = brk < 0 || e <= brk;
+                if (lo[k] && upto && efirst[k] < 0) efirst[k] = i;
+                if (__ballot(lo[k] && upto)) large = true;
+            }
+            if (brk < 0) reg_set(ekept, i, large ? 2 : 3, lane);
+        }
+        // the first chain a kept chain shadows becomes kind 1 (:690-691), whatever it was
+        {
+            u64 inlist[REG_K];
+#pragma unroll
+            for (int k = 0; k < REG_K; ++k) inlist[k] = __ballot(k * 64 + lane < n && ekept[k] != 0);
+            for (int e = 0; e < n; ++e) {
+                if (!((REG_SEL(inlist, e >> 6) >> (e & 63)) & 1)) continue;
+                const int f = reg_get(efirst, e);
+                if (f >= 0) reg_set(ekept, f, 1, lane);
+            }
+        }
+        {
+            int i = 0, k = 0;
+            for (; i < n; ++i) {                                          // at most max_chain_extend chains of kind 1 / 2
+                const int kp = reg_get(ekept, i);
+                if (kp == 0 || kp == 3) continue;
+                if (++k >= o.max_chain_extend) break;
+            }
+            for (; i < n; ++i) if (reg_get(ekept, i) < 3) reg_set(ekept, i, 0, lane);
+        }
+        // the kept chains in order -> F[0 .. n_kept)
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < REG_K; ++k) {
+            const int e = k * 64 + lane;
+            const bool kp = e < n && ekept[k] != 0;
+            const u64 km = __ballot(kp);
+            if (kp) {
+                FRec f;
+                f.beg = ebeg[k]; f.end = eend[k]; f.w = ew[k]; f.first = efirst[k]; f.kept = ekept[k]; f.is_alt = ealt[k]; f.id = eid[k]; f.pad = 0;
+                F[before + __popcll(km & (((u64)1 << lane) - 1))] = f;
+            }
+            int ns_k = kp ? s_n[eid[k]] : 0;
+            for (int dd = 32; dd >= 1; dd >>= 1) ns_k += __shfl_xor(ns_k, dd);
+            n_seeds += ns_k;
+            before += __popcll(km);
+        }
+        n_kept = before;
+    }
+    if (lane == 0) {
+        ReadHdr H;
+        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base;
+        A.hdr[r] = H;
+        A.frac_rep[r] = (float)l_rep / len;
+    }
+}
+
 // the kept chains and their seeds, densely packed in read order (from the scratch of the tier that finished the read)
 __global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch1, const DSeed* __restrict__ sd1, WaveArgs W,
                                                      const ReadHdr* __restrict__ hdr, const i64* __restrict__ chain_off,
@@ -759,6 +1122,13 @@ __global__ void __launch_bounds__(256) k_chain_redo(const ReadHdr* __restrict__ 
                                                      i64* __restrict__ lwork) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x)
         if (hdr[r].fallback == 1) { const unsigned long long k = atomicAdd(count, 1ull); list[k] = r; lwork[k] = hdr[r].work > 0 ? hdr[r].work : 1; }
+}
+
+// list entries the register tier left (fallback == 3)
+__global__ void __launch_bounds__(256) k_chain_redo3(const ReadHdr* __restrict__ hdr, const i64* __restrict__ list, i64 nlist, unsigned long long* __restrict__ count,
+                                                      i64* __restrict__ sub) {
+    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nlist; t += (i64)gridDim.x * blockDim.x)
+        if (hdr[list[t]].fallback == 3) sub[atomicAdd(count, 1ull)] = t;
 }
 
 __global__ void __launch_bounds__(256) k_chain_counts(const ReadHdr* __restrict__ hdr, i64 nreads, i64* __restrict__ nch, i64* __restrict__ nsd,
@@ -824,8 +1194,8 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     memset(&W, 0, sizeof(W));
     bool tier2 = false;
     if (n_redo > 0) {
-        // the heavy reads first (longest first) and with the big-LDS build of the kernel, on a stream of their own, so that the few
-        // reads that take milliseconds start at once and run beside the many light ones
+        // register tier for all of them (longest first: a wavefront per read, the long ones should not start last), then the B-tree tier
+        // for what the register tier left: reads with two chains on one position, reads with more than 256 chains
         std::vector<i64> h_list((size_t)n_redo), h_work((size_t)n_redo), h_off((size_t)n_redo + 1);
         HIP_TRY(hipMemcpyAsync(h_list.data(), d_list, (size_t)n_redo * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_work.data(), d_lwork, (size_t)n_redo * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -833,7 +1203,6 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
         std::vector<std::pair<i64, i64>> heavy, light;                       // (work, read)
         for (size_t k = 0; k < (size_t)n_redo; ++k) (h_work[k] > WAVE_LIGHT ? heavy : light).push_back({h_work[k], h_list[k]});
         std::sort(heavy.begin(), heavy.end(), [](const std::pair<i64, i64>& x, const std::pair<i64, i64>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-        const i64 n_heavy = (i64)heavy.size();
         i64 total_work = 0;
         for (size_t k = 0; k < (size_t)n_redo; ++k) {
             const std::pair<i64, i64>& e = k < heavy.size() ? heavy[k] : light[k - heavy.size()];
@@ -855,24 +1224,27 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
             }
         }
         if ((rc = meme_buf_reserve(ctx, B[9], need))) return rc;
+        if ((rc = meme_buf_reserve(ctx, B[10], (size_t)(n_redo + 1) * 8))) return rc;
         unsigned char* p9 = (unsigned char*)B[9].p;
-        W.list = d_list; W.woff = d_woff; W.nlist = (i64)n_redo;
+        W.list = d_list; W.woff = d_woff; W.nlist = (i64)n_redo; W.sub = nullptr; W.nsub = 0;
         W.C = (C2*)(p9 + at[0]); W.S = (S2*)(p9 + at[1]); W.F = (FRec*)(p9 + at[2]); W.srt = (u64*)(p9 + at[3]); W.ia = (int*)(p9 + at[4]);
         W.ib = (int*)(p9 + at[5]); W.nodes = (TNode*)(p9 + at[6]);
-        HIP_TRY(hipStreamSynchronize(ctx->stream));                       // (the host vectors above are locals; and stream2 starts from here)
+        HIP_TRY(hipStreamSynchronize(ctx->stream));                       // (the host vectors above are locals)
         HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-        if (n_heavy > 0) {
-            if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-            if (!ctx->ev_aux) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
-            WaveArgs Wh = W;
-            Wh.nlist = n_heavy;
-            hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)n_heavy), dim3(64), 0, ctx->stream2, A, Wh, (i64)0);
-            HIP_TRY(hipEventRecord(ctx->ev_aux, ctx->stream2));
+        const bool no_reg_tier = ctx->chain_reg_tier == 0;                 // (tests: everything through the B-tree tier)
+        unsigned long long n3 = n_redo;
+        if (!no_reg_tier) {
+            hipLaunchKernelGGL(k_chain_reg, dim3((unsigned)n_redo), dim3(64), 0, ctx->stream, A, W);
+            HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(k_chain_redo3, dim3(blocks_of((i64)n_redo, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, (const i64*)d_list, (i64)n_redo,
+                               d_redo_n, (i64*)B[10].p);
+            HIP_TRY(hipMemcpyAsync(&n3, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            W.sub = (const i64*)B[10].p; W.nsub = (i64)n3;
         }
-        if ((i64)n_redo > n_heavy)
-            hipLaunchKernelGGL((k_chain_wave<64, 512>), dim3((unsigned)((i64)n_redo - n_heavy)), dim3(64), 0, ctx->stream, A, W, n_heavy);
-        if (n_heavy > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_aux, 0));
+        if (n3 > 0) hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W, (i64)0);
         HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+        ctx->chain_tier3_reads = (i64)(no_reg_tier ? n_redo : n3);
         tier2 = true;
     }
     i64* d_choff = (i64*)B[5].p;

@@ -69,6 +69,7 @@ struct meme_ctx {
                                        // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
+    i64 chain_reg_tier = 1;            // 0: the chaining stage skips the register tier (everything beyond tier 1 through the B-tree tier; tests)
     i64 bsw_blocks = 0;
     i64 bsw_lane_min_pairs = 32768;   // batches at least this big use the lane-per-pair kernel (throughput); smaller ones the
                                        // lanes-per-pair kernel (latency: a lone pair takes ~6 ms on one lane, ~0.3 ms on 64)
@@ -79,7 +80,7 @@ struct meme_ctx {
     hipEvent_t ev_gcig[2] = {nullptr, nullptr};
     hipStream_t stream2 = nullptr;     // side stream: the heavy reads of the chaining tier run beside the light ones
     hipEvent_t ev_aux = nullptr;
-    i64 chain_reads = 0, chain_tier2_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
+    i64 chain_reads = 0, chain_tier2_reads = 0, chain_tier3_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
     meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 

@@ -281,7 +281,7 @@ typedef struct {
     float chain_pass2_ms;      /* of which the second pass (reads that needed the bigger scratch) */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs" */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_reg_tier" */
 
 #ifdef __cplusplus
 }

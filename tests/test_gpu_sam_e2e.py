@@ -202,3 +202,94 @@ def test_sam_identical_when_one_mate_file_is_shorter(tmp_path, short_file):
     assert len(got) == len(want) and len(want) > 2 * (n - 40)
     diff = [(a, b) for a, b in zip(got, want) if a != b]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+
+
+def _pe_reads(g, n, length, seed, sub, indel, n_frac=0.01):
+    """n read pairs of one length: mate 1 forward, mate 2 the reverse complement 300-500 bases downstream, both with errors."""
+    rng = np.random.default_rng(seed)
+    pos = rng.integers(0, g.shape[0] - 700 - length, size=n)
+    ins = rng.integers(300, 500, size=n) + (length - 150)
+
+    def noisy(x):
+        out = []
+        for row in x:
+            r = []
+            i = 0
+            while len(r) < length and i < row.shape[0]:
+                u = rng.random()
+                if u < indel / 2: r.append(int(rng.integers(0, 4)))                 # insertion
+                elif u < indel: i += 1                                               # deletion
+                else:
+                    c = int(row[i]); i += 1
+                    if rng.random() < sub: c = (c + int(rng.integers(1, 4))) & 3
+                    if rng.random() < n_frac / length * 3: c = 4
+                    r.append(c)
+            while len(r) < length: r.append(int(rng.integers(0, 4)))
+            out.append(r)
+        return np.array(out, np.uint8)
+    ar = np.arange(length + 40)
+    a = noisy(g[pos[:, None] + ar[None, :]])
+    b = noisy((3 - g[(pos + ins - length - 40)[:, None] + ar[None, :]][:, ::-1]).astype(np.uint8))
+    return a, b
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_mixed_250bp_high_error_paired(tmp_path):
+    """BASELINE configs[4]'s read class as a PAIRED run: half 150-bp pairs with 1 % substitutions, half 250-bp pairs with 5 % substitutions
+    and 0.75 % indels, mixed in one pair of files (several -K chunks): long banded-DP jobs, SMEM divergence, band retries, mate rescue, and
+    the CIGAR stage (most alignments need the global alignment with gaps)."""
+    import re
+    g = synth.make_genome(1_500_000, seed=81, repeat_frac=0.06, n_families=6, n_dups=6, dup_len=1500)
+    fa = str(tmp_path / "mix.fa")
+    synth.write_fasta(fa, g, contigs=4)
+    prefix = build_index(fa, bits=16)
+    a150, b150 = _pe_reads(g, 3000, 150, 82, 0.01, 0.0015)
+    a250, b250 = _pe_reads(g, 3000, 250, 83, 0.05, 0.0075)
+    order = np.random.default_rng(84).permutation(6000)
+    f1, f2 = str(tmp_path / "m1.fq"), str(tmp_path / "m2.fq")
+    with open(f1, "w") as h1, open(f2, "w") as h2:
+        for k in order:
+            ra, rb = (a150[k], b150[k]) if k < 3000 else (a250[k - 3000], b250[k - 3000])
+            for fh, r in ((h1, ra), (h2, rb)):
+                fh.write("@m%d\n%s\n+\n%s\n" % (k, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    want = _sam("bwa-meme_mode3", prefix, [f1, f2], threads=8, chunk=700000)
+    cmd = [os.path.join(REF, "bwa-meme_dropin"), "mem", "-7", "-Y", "-K", "700000", "-t", "8", prefix, f1, f2]
+    r = subprocess.run(cmd, capture_output=True, env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    got = [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
+    assert len(got) == len(want) and len(want) > 12000
+    diff = [(x, y) for x, y in zip(got, want) if x != y]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+    err = r.stderr.decode()
+    m = list(re.finditer(r"ksw_global2 calls answered from the table (\d+), computed by the reference's function (\d+)", err))
+    assert m and int(m[-1].group(1)) > 5000 and int(m[-1].group(1)) > 20 * int(m[-1].group(2)), err[-1500:]   # the CIGAR table answers (nearly) all calls
+    assert re.search(r"0 reads chained on the host", err)
+    # and with the CIGAR stage off the same SAM comes out (the table only ever replaces identical answers)
+    got2 = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CIGAR="0"), threads=8, chunk=700000)
+    assert got2 == got
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_to_the_fm_index_path(tmp_path):
+    """BASELINE configs[2] asks for the SAM diff against BWA-MEM2's FM-index path, not only against `mem -7`: the reference binary
+    without -7 (FM-index SMEMs, its own index built by `index -a mem2`) on the same reads -- paired, 6 000 pairs."""
+    g = synth.make_genome(400_000, seed=41, repeat_frac=0.08, n_families=6, n_dups=6, dup_len=1500)
+    fa = str(tmp_path / "fm.fa")
+    synth.write_fasta(fa, g, contigs=3)
+    prefix = build_index(fa, bits=14)
+    r = subprocess.run([os.path.join(REF, "bwa-meme_mode3"), "index", "-a", "mem2", prefix], capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    a, b = _pe_reads(g, 6000, 150, 45, 0.01, 0.0015)
+    f1, f2 = str(tmp_path / "f1.fq"), str(tmp_path / "f2.fq")
+    synth.write_fastq(f1, a, prefix="q")
+    synth.write_fastq(f2, b, prefix="q")
+    cmd = [os.path.join(REF, "bwa-meme_mode3"), "mem", "-Y", "-K", "100000000", "-t", "8", prefix, f1, f2]          # no -7: the FM-index engine
+    rr = subprocess.run(cmd, capture_output=True, timeout=900)
+    assert rr.returncode == 0, rr.stderr.decode()[-2000:]
+    want = [l for l in rr.stdout.decode().split("\n") if not l.startswith("@PG")]
+    got = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix), threads=8)
+    assert len(got) == len(want) and len(want) > 12000
+    diff = [(x, y) for x, y in zip(got, want) if x != y]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
