@@ -146,6 +146,12 @@ def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
     return O.algorithmic_bytes(ctr, n * READ_LEN) / n, {k: v / n for k, v in ctr.items()}
 
 
+def leg_contigs(l_pac, k=4):
+    """The benchmark genome as k reference sequences (a bntann1_t length is 32-bit: one 3.1 Gbp contig is not a valid reference)."""
+    cut = [l_pac * i // k for i in range(k + 1)]
+    return [(cut[i], cut[i + 1] - cut[i], 0) for i in range(k)]
+
+
 def chain_leg(ctx, reads, l_pac, nsub=2000000):
     """Chaining on the device (mem_chain_Learned + mem_chain_flt): the first `nsub` reads of the benchmark batch
     are seeded through the pinned-result call and chained where their seeds lie; kernel time by HIP events, parity of `ncheck` reads
@@ -155,22 +161,76 @@ def chain_leg(ctx, reads, l_pac, nsub=2000000):
     n = min(nsub, reads.shape[0])
     off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
     smems, smem_off, hits, hit_off = ctx.seed_batch_host(reads[:n].reshape(-1), off)
-    contigs = [(0, l_pac, 0)]
+    contigs = leg_contigs(l_pac)
     res = ctx.chain_last_batch_host(contigs, hipapi.default_chain_opt(l_pac))
     res = ctx.chain_last_batch_host(contigs, hipapi.default_chain_opt(l_pac))          # (second call: buffers exist)
     tm = ctx.timings()
     # every read of the leg against the oracle's restatement (batched C call, all host cores)
     copt = oracle_py.default_chain_opt(l_pac)
-    n_bad, first_bad = oracle_py.chain_compare_batch(smems, smem_off, hits, hit_off, np.full(n, READ_LEN, np.int32), np.zeros(1, np.int64),
-                                                     np.zeros(1, np.uint8), copt, res)
+    n_bad, first_bad = oracle_py.chain_compare_batch(smems, smem_off, hits, hit_off, np.full(n, READ_LEN, np.int32), np.array([c[0] for c in contigs], np.int64),
+                                                     np.zeros(len(contigs), np.uint8), copt, res)
     same, checked = n_bad == 0 and res["n_fallback"] == 0, n
     if not same:
         log("chain leg: %d reads differ from the oracle (first: %d), %d left to the host" % (n_bad, first_bad, res["n_fallback"]))
     return {"metric": "chain_reads_per_sec", "value": n / (tm.chain_kernel_ms * 1e-3) if same and tm.chain_kernel_ms > 0 else None, "unit": "reads/s",
-            "reads": n, "kernel_ms": tm.chain_kernel_ms, "second_pass_ms": tm.chain_pass2_ms, "chains": int(res["chains"].shape[0]),
+            "reads": n, "kernel_ms": tm.chain_kernel_ms, "wavefront_tiers_ms": tm.chain_pass2_ms, "btree_tier_ms": tm.chain_tier3_ms, "btree_tier_reads": int(tm.chain_tier3_reads), "chains": int(res["chains"].shape[0]),
             "chained_seeds": int(res["seeds"].shape[0]), "reads_left_to_host": int(res["n_fallback"]), "reads_in_wavefront_tier": int(res["n_tier2"]),
             "matches_oracle": bool(same),
             "checked_reads": checked}
+
+
+def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
+    """The stages behind seeding, on the device: chaining + seed extension of `nsub` of the benchmark's reads without leaving
+    HBM (meme_extend_last_batch_host: the host receives alignment records), then the CIGAR kernel (meme_global_batch_host) on the best
+    record of `ncig` reads.  Kernel times by HIP events; EVERY record is compared with the oracle's restatement of
+    mem_chain2aln_across_reads_V2 (orc_extend_batch on the device's chains, themselves checked by the chain leg), and the CIGARs of a
+    sample with orc_ksw_global2."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py
+    n = min(nsub, reads.shape[0])
+    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    ctx.seed_batch_host(reads[:n].reshape(-1), off)
+    contigs = leg_contigs(l_pac)
+    copt = hipapi.default_chain_opt(l_pac)
+    R = ctx.extend_last_batch_host(contigs, copt)
+    R = ctx.extend_last_batch_host(contigs, copt)          # (second call: buffers exist)
+    ch = ctx.chain_last_batch_host(contigs, copt)
+    text = hipapi.fwd_rc_text(genome)
+    want, (jobs, retried) = oracle_py.extend_batch(reads[:n].reshape(-1), off, ch["chain_off"], oracle_py.chains_as_orc(ch["chains"]), ch["seed_off"],
+                                                  ch["seeds"], ch["frac_rep"], text, l_pac, np.array([c[0] for c in contigs], np.int64),
+                                                  np.array([c[1] for c in contigs], np.int32))
+    same = np.array_equal(R["reg_off"], ch["seed_off"]) and all(np.array_equal(R["regs"][f].astype(np.int64), want[f].astype(np.int64)) for f in oracle_py.ALNREG_FIELDS)
+    out = {"metric": "extend_reads_per_sec", "value": n / ((R["chain_ms"] + R["ext_ms"]) * 1e-3) if same else None, "unit": "reads/s", "reads": n,
+           "chain_ms": R["chain_ms"], "ext_ms": R["ext_ms"], "bsw_ms": R["bsw_ms"], "alignment_records": int(R["regs"].shape[0]), "extension_jobs": R["n_pairs"],
+           "jobs_with_doubled_band": R["n_retried"], "reads_in_wavefront_tiers": R["n_tier2"], "matches_oracle": bool(same), "checked_records": int(want.shape[0])}
+    # CIGAR kernel: the global alignment mem_reg2aln would pose for every read's best live record (band as bwa_gen_cigar2 sets it for w_ = 100)
+    regs, ro = R["regs"], R["reg_off"]
+    rid = np.repeat(np.arange(n), np.diff(ro))
+    live = np.nonzero((regs["qe"] > regs["qb"]) & (regs["rb"] >= 0) & (rid < ncig) & ((regs["rb"] < l_pac) == (regs["re"] <= l_pac)))[0]
+    live = live[np.lexsort((-regs["score"][live].astype(np.int64), rid[live]))]
+    best = live[np.concatenate([[True], rid[live][1:] != rid[live][:-1]])] if live.shape[0] else live
+    ql = (regs["qe"][best] - regs["qb"][best]).astype(np.int64)
+    tl = (regs["re"][best] - regs["rb"][best]).astype(np.int64)
+    max_gap = np.maximum(1, (((ql + 1) >> 1) * 1 - 6) // 1 + 1)                     # src/bwa.cpp:308-311 with a 1, o 6, e 1
+    w = np.maximum(np.minimum((max_gap + np.abs(tl - ql) + 1) >> 1, 100), np.abs(tl - ql) + 3)
+    J = np.zeros(best.shape[0], dtype=hipapi.GJOB)
+    J["rb"], J["read"], J["qb"], J["qlen"], J["tlen"], J["w"] = regs["rb"][best], rid[best], regs["qb"][best], ql, tl, w
+    J["rev"] = regs["rb"][best] >= l_pac
+    res, cig, ms = ctx.global_batch_host(J)
+    res, cig, ms = ctx.global_batch_host(J)
+    ok = True
+    for k in range(0, J.shape[0], max(1, J.shape[0] // 20000)):
+        j = J[k]
+        q = reads[int(j["read"])][int(j["qb"]):int(j["qb"]) + int(j["qlen"])]
+        t = text[int(j["rb"]):int(j["rb"]) + int(j["tlen"])]
+        if j["rev"]:
+            q, t = q[::-1], t[::-1]
+        sc, cg = oracle_py.ksw_global2(q, t, int(j["w"]))
+        o0 = int(res["cigar_off"][k])
+        ok = ok and sc == int(res["score"][k]) and np.array_equal(cg, cig[o0:o0 + int(res["n_cigar"][k])])
+    out["cigar"] = {"metric": "cigar_alignments_per_sec", "value": J.shape[0] / (ms * 1e-3) if ok and ms > 0 else None, "unit": "alignments/s", "alignments": int(J.shape[0]),
+                    "kernel_ms": ms, "operations": int(cig.shape[0]), "matches_oracle": bool(ok), "checked": int(len(range(0, J.shape[0], max(1, J.shape[0] // 20000))))}
+    return out
 
 
 def bsw_leg(ctx, dev, world):
@@ -712,6 +772,12 @@ def main():
             except Exception as e:
                 log("chain leg failed: %r" % (e,))
                 out["chain"] = None
+        if single and os.environ.get("MEME_BENCH_EXT", "1") != "0":
+            try:
+                out["ext"] = ext_leg(ctx, reads, fwd, l_pac)
+            except Exception as e:
+                log("ext leg failed: %r" % (e,))
+                out["ext"] = None
         # ---- e2e: BASELINE.json's second metric, the drop-in next to the unmodified reference (last: it needs the HBM) --------
         if single and os.environ.get("MEME_BENCH_E2E", "1") != "0":
             if not ref_prefix:

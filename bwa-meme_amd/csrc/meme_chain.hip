@@ -722,8 +722,7 @@ __global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 
 // chains leaves with fallback = 3 and is done by the B-tree tier below.  The filter's sort replays klib's introsort on (weight, chain)
 // pairs held one per lane slot, read and written through v_readlane / predicated moves (tens of cycles per access instead of a memory
 // round trip), and the overlap loop of mem_chain_flt runs lane-parallel over the kept chains.
-constexpr int REG_K = 4;
-constexpr int REG_CHAINS = REG_K * 64;
+// REG_K register slots per lane: the kernel is built for 4 (256 chains: all but 0.05 % of the named configuration's reads) and 8 (512).
 
 __device__ __forceinline__ int rdl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ i64 rdl64(i64 v, int l) {
@@ -731,16 +730,20 @@ __device__ __forceinline__ i64 rdl64(i64 v, int l) {
     return ((i64)hi << 32) | (i64)(unsigned)lo;
 }
 // element i of a per-lane array of REG_K registers (element = k * 64 + lane); i is wave-uniform
-#define REG_SEL(a_, k_) ((k_) == 0 ? (a_)[0] : (k_) == 1 ? (a_)[1] : (k_) == 2 ? (a_)[2] : (a_)[3])
-__device__ __forceinline__ int reg_get(const int (&a)[REG_K], int i) { const int k = i >> 6; const int v = REG_SEL(a, k); return rdl(v, i & 63); }
-__device__ __forceinline__ i64 reg_get64(const i64 (&a)[REG_K], int i) { const int k = i >> 6; const i64 v = REG_SEL(a, k); return rdl64(v, i & 63); }
-__device__ __forceinline__ void reg_set(int (&a)[REG_K], int i, int v, int lane) {
+template <typename T> __device__ __forceinline__ T reg_pick(const T (&a)[4], int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; }
+template <typename T> __device__ __forceinline__ T reg_pick(const T (&a)[8], int k) {
+    return k < 4 ? (k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]) : (k == 4 ? a[4] : k == 5 ? a[5] : k == 6 ? a[6] : a[7]);
+}
+#define REG_SEL(a_, k_) reg_pick(a_, k_)
+template <int REG_K> __device__ __forceinline__ int reg_get(const int (&a)[REG_K], int i) { const int v = reg_pick(a, i >> 6); return rdl(v, i & 63); }
+template <int REG_K> __device__ __forceinline__ i64 reg_get64(const i64 (&a)[REG_K], int i) { const i64 v = reg_pick(a, i >> 6); return rdl64(v, i & 63); }
+template <int REG_K> __device__ __forceinline__ void reg_set(int (&a)[REG_K], int i, int v, int lane) {
     const int k = i >> 6;
     const bool me = lane == (i & 63);
 #pragma unroll
     for (int q = 0; q < REG_K; ++q) if (q == k && me) a[q] = v;
 }
-__device__ __forceinline__ void reg_set64(i64 (&a)[REG_K], int i, i64 v, int lane) {
+template <int REG_K> __device__ __forceinline__ void reg_set64(i64 (&a)[REG_K], int i, i64 v, int lane) {
     const int k = i >> 6;
     const bool me = lane == (i & 63);
 #pragma unroll
@@ -752,11 +755,14 @@ __device__ __forceinline__ i64 wave_max64(i64 v) {
     return v;
 }
 
+template <int REG_K>
 __global__ void __launch_bounds__(64) k_chain_reg(ChainArgs A, WaveArgs W) {
+    constexpr int REG_CHAINS = REG_K * 64;
     __shared__ int s_w[REG_CHAINS], s_id[REG_CHAINS], s_beg[REG_CHAINS], s_end[REG_CHAINS], s_n[REG_CHAINS], s_alt[REG_CHAINS];
     __shared__ i64 lds_contig[CONTIG_LDS];
     __shared__ int stk[60];
-    const i64 t = blockIdx.x;
+    if (W.sub && (i64)blockIdx.x >= W.nsub) return;
+    const i64 t = W.sub ? W.sub[blockIdx.x] : (i64)blockIdx.x;
     if (t >= W.nlist) return;
     const int lane = threadIdx.x;
     if (A.n_contigs <= CONTIG_LDS) {
@@ -1148,6 +1154,12 @@ unsigned blocks_of(i64 items, int per) { i64 b = (items + per - 1) / per; const 
 int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt, i64* totals) {
     const i64 n = ctx->last_seed_reads;
     int rc;
+    for (int i = 0; i < n_contigs; ++i)            // bntann1_t: 64-bit offset, 32-bit length; ascending, inside the forward strand
+        if (contigs[i].len < 1 || contigs[i].offset < 0 || contigs[i].offset + contigs[i].len > opt->l_pac || (i > 0 && contigs[i].offset < contigs[i - 1].offset + contigs[i - 1].len)) {
+            meme_set_error("contig %d (offset %lld, length %d) is not a valid reference sequence of a %lld-base genome", i, (long long)contigs[i].offset, contigs[i].len,
+                           (long long)opt->l_pac);
+            return MEME_E_ARG;
+        }
     DevBuf* B = ctx->chain;     // 0 chains scratch, 1 seeds scratch, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
                                 // 8 tier-2 list + work + offsets, 9 tier-2 scratch
     if ((rc = meme_buf_reserve(ctx, B[0], (size_t)n * CHAIN_CAP * sizeof(DChain)))) return rc;
@@ -1176,7 +1188,7 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     A.o = *opt;
     A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
     hipEvent_t* ev = ctx->ev_chain;
-    for (int i = 0; i < 4; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    for (int i = 0; i < 5; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
     // tier 2: the reads the first tier left
@@ -1224,7 +1236,7 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
             }
         }
         if ((rc = meme_buf_reserve(ctx, B[9], need))) return rc;
-        if ((rc = meme_buf_reserve(ctx, B[10], (size_t)(n_redo + 1) * 8))) return rc;
+        if ((rc = meme_buf_reserve(ctx, B[10], (size_t)(n_redo + 1) * 8 * 2))) return rc;
         unsigned char* p9 = (unsigned char*)B[9].p;
         W.list = d_list; W.woff = d_woff; W.nlist = (i64)n_redo; W.sub = nullptr; W.nsub = 0;
         W.C = (C2*)(p9 + at[0]); W.S = (S2*)(p9 + at[1]); W.F = (FRec*)(p9 + at[2]); W.srt = (u64*)(p9 + at[3]); W.ia = (int*)(p9 + at[4]);
@@ -1234,14 +1246,20 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
         const bool no_reg_tier = ctx->chain_reg_tier == 0;                 // (tests: everything through the B-tree tier)
         unsigned long long n3 = n_redo;
         if (!no_reg_tier) {
-            hipLaunchKernelGGL(k_chain_reg, dim3((unsigned)n_redo), dim3(64), 0, ctx->stream, A, W);
-            HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(k_chain_redo3, dim3(blocks_of((i64)n_redo, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, (const i64*)d_list, (i64)n_redo,
-                               d_redo_n, (i64*)B[10].p);
-            HIP_TRY(hipMemcpyAsync(&n3, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            W.sub = (const i64*)B[10].p; W.nsub = (i64)n3;
+            // 256 chains per read in registers; what that leaves again with 512; what that leaves (equal positions, > 512 chains) to the B-tree tier
+            for (int pass = 0; pass < 2 && n3 > 0; ++pass) {
+                if (pass == 0) hipLaunchKernelGGL((k_chain_reg<4>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
+                else hipLaunchKernelGGL((k_chain_reg<8>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
+                i64* d_sub = (i64*)B[10].p + (size_t)pass * (size_t)(n_redo + 1);
+                HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
+                hipLaunchKernelGGL(k_chain_redo3, dim3(blocks_of((i64)n_redo, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, (const i64*)d_list, (i64)n_redo,
+                                   d_redo_n, d_sub);
+                HIP_TRY(hipMemcpyAsync(&n3, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                W.sub = (const i64*)d_sub; W.nsub = (i64)n3;
+            }
         }
+        HIP_TRY(hipEventRecord(ev[4], ctx->stream));
         if (n3 > 0) hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W, (i64)0);
         HIP_TRY(hipEventRecord(ev[2], ctx->stream));
         ctx->chain_tier3_reads = (i64)(no_reg_tier ? n_redo : n3);
@@ -1268,11 +1286,14 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     HIP_TRY(hipEventRecord(ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     {
-        float ms = 0.f, ms2 = 0.f;
+        float ms = 0.f, ms2 = 0.f, ms3 = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
-        if (tier2) HIP_TRY(hipEventElapsedTime(&ms2, ev[1], ev[2]));
+        if (tier2) { HIP_TRY(hipEventElapsedTime(&ms2, ev[1], ev[2])); HIP_TRY(hipEventElapsedTime(&ms3, ev[4], ev[2])); }
         ctx->tm.chain_kernel_ms = ms;          // (includes the small host round trips between the tiers)
         ctx->tm.chain_pass2_ms = ms2;
+        ctx->tm.chain_tier3_ms = ms3;
+        ctx->tm.chain_tier2_reads = (i64)n_redo;
+        ctx->tm.chain_tier3_reads = tier2 ? ctx->chain_tier3_reads : 0;
     }
     ctx->chain_reads = n;
     ctx->chain_tier2_reads = (i64)n_redo;

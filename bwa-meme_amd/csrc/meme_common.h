@@ -75,13 +75,13 @@ struct meme_ctx {
                                        // lanes-per-pair kernel (latency: a lone pair takes ~6 ms on one lane, ~0.3 ms on 64)
     // timings
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_chain[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_ext[2] = {nullptr, nullptr};
     hipEvent_t ev_gcig[2] = {nullptr, nullptr};
     hipStream_t stream2 = nullptr;     // side stream: the heavy reads of the chaining tier run beside the light ones
     hipEvent_t ev_aux = nullptr;
     i64 chain_reads = 0, chain_tier2_reads = 0, chain_tier3_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
-    meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 void meme_set_error(const char* fmt, ...);

@@ -125,8 +125,9 @@ int meme_stage_rmi32(meme_ctx* ctx, const void* d_rmi24, int64_t records, void* 
 /* ---- suffix-array construction on the device (index building) -----------------------------------------
  * d_text0123: sa_num bytes, the forward strand followed by its reverse complement (codes 0..3, the reference's .0123 image);
  * d_sa: sa_num u64 out, the suffix array in the order `bwa-meme index` writes to .pos_packed (a suffix that ends sorts
- * before its continuations).  Radix sort by the first 32 bases + prefix doubling on the tied groups; workspace
- * (~10 bytes per suffix) is allocated and released inside the call. */
+ * before its continuations).  Radix sort by the first 32 bases + prefix doubling on the tied groups.  Workspace, allocated and
+ * released inside the call: rank + suffix arrays of the padded text (16 bytes per suffix), ~13 GB for the sort of one 2^28-suffix
+ * group, and ~90 bytes per suffix that still ties after 32 bases -- over 110 GB beside d_sa and the text at GRCh38 size. */
 int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, int64_t sa_num, uint64_t* d_sa);
 
 /* ---- P-RMI training on the device (index building) --------------------------------------------------------------------
@@ -278,7 +279,9 @@ typedef struct {
     float seed_pack_ms;        /* read packing kernel */
     int64_t seed_windows;      /* suffix-array windows loaded by the SA-search kernel */
     float chain_kernel_ms;     /* chaining kernels of the last meme_chain_last_batch_host call (both passes + packing) */
-    float chain_pass2_ms;      /* of which the second pass (reads that needed the bigger scratch) */
+    float chain_pass2_ms;      /* of which the wavefront-per-read tiers (register tier + B-tree tier, incl. the host round trip between them) */
+    float chain_tier3_ms;      /* of which the B-tree tier (reads with chains at equal positions or more than 256 chains) */
+    int64_t chain_tier2_reads, chain_tier3_reads;   /* reads beyond the lane-per-read tier; of which through the B-tree tier */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
 int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_reg_tier" */

@@ -45,6 +45,7 @@ print("[chain probe] chains before the filter: " + pct(tree))
 for lim in (16, 32, 64, 128, 256, 1024):
     print("[chain probe] reads with more than %d chains: %d; with work > %d: %d" % (lim, int((tree > lim).sum()), lim * 8, int((work > lim * 8).sum())))
 tm = ctx.timings()
-print("[chain probe] chain kernels %.2f ms, of which second pass %.2f ms" % (tm.chain_kernel_ms, tm.chain_pass2_ms))
+print("[chain probe] chain kernels %.2f ms, of which the wavefront tiers %.2f ms (%d reads), of which the B-tree tier %.2f ms (%d reads)"
+      % (tm.chain_kernel_ms, tm.chain_pass2_ms, tm.chain_tier2_reads, tm.chain_tier3_ms, tm.chain_tier3_reads))
 big = np.argsort(work)[-10:]
 print("[chain probe] ten heaviest reads: work", work[big].tolist(), "smems", ns[big].tolist(), "chains", tree[big].tolist())

@@ -133,6 +133,8 @@ def test_chain_call_needs_a_seeded_batch_and_sane_options(tmp_path):
         bad.max_occ = 0
         with pytest.raises(hipapi.MemeError, match="bad options"):
             ctx.chain_last_batch_host([(0, 60_000, 0)], bad)
+        with pytest.raises(hipapi.MemeError, match="not a valid reference sequence"):          # a bntann1_t length is positive and inside the genome
+            ctx.chain_last_batch_host([(0, 70_000, 0)], hipapi.default_chain_opt(60_000))
         res = ctx.chain_last_batch_host([(0, 60_000, 0)], hipapi.default_chain_opt(60_000))
         assert res["chain_off"].shape[0] == 51 and res["chain_off"][-1] == res["chains"].shape[0] >= 40
         w = res["chains"]["w"]

@@ -1,0 +1,62 @@
+"""BASELINE configs[2] at a size where positions need more than 30 bits: a 512 Mbp genome (1.02 G suffixes, 8 reference sequences),
+200 k read pairs through the reference aligner with the HIP backend bound in (seeding, chaining, extension and the CIGAR table on the
+device) against the unmodified reference's `mem -7` on the same index files: SAM identical.  (The GRCh38-sized comparison is
+bench.py's e2e leg; the FM-index engine is compared at 400 kbp in test_gpu_sam_e2e.py -- its index build takes minutes at this size.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ref_py as R
+from pymeme import hostapi, synth, workload
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_512mbp_paired(tmp_path):
+    import psutil
+    if psutil.virtual_memory().available < 80e9:
+        pytest.skip("needs ~60 GB of host RAM for the index build and the reference's index expansion")
+    root = "/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path)
+    d = os.path.join(root, "meme_sam_scale_%d" % os.getpid())
+    os.makedirs(d, exist_ok=True)
+    try:
+        l_pac = 512_000_000
+        g = synth.make_genome(l_pac, seed=11)
+        text, sa = hostapi.build_sa(g)
+        l1, l2 = hostapi.train_prmi(text, sa)
+        prefix = os.path.join(d, "ref.fa")
+        hostapi.write_index(prefix, g, text, sa, l1, l2, n_contigs=8)
+        del text, sa
+        n = 200_000
+        rng = np.random.default_rng(5)
+        pos = rng.integers(0, l_pac - 700, size=n)
+        ins = rng.integers(300, 500, size=n)
+        ar = np.arange(150)
+
+        def mut(x):
+            sub = rng.random(x.shape) < 0.01
+            return np.where(sub, (x + rng.integers(1, 4, size=x.shape, dtype=np.uint8)) & 3, x).astype(np.uint8)
+        f1, f2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
+        workload.write_fastq_fast(f1, mut(g[pos[:, None] + ar[None, :]]), prefix="p")
+        workload.write_fastq_fast(f2, mut(3 - g[(pos + ins - 150)[:, None] + ar[None, :]][:, ::-1]), prefix="p")
+        out = {}
+        for exe, thr in (("bwa-meme_mode3", str(min(128, os.cpu_count() or 8))), ("bwa-meme_dropin", "32")):
+            sam = os.path.join(d, exe + ".sam")
+            with open(sam, "wb") as fh:
+                r = subprocess.run([os.path.join(R.REF_DIR, exe), "mem", "-7", "-Y", "-K", "20000000", "-t", thr, prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE,
+                                   env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1"), timeout=1500)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            out[exe] = [l for l in open(sam, "rb") if not l.startswith(b"@PG")]
+            if exe == "bwa-meme_dropin":
+                assert b"0 reads chained on the host" in r.stderr
+        a, b = out["bwa-meme_dropin"], out["bwa-meme_mode3"]
+        assert len(a) == len(b) and len(b) > 2 * n
+        diff = [(x, y) for x, y in zip(a, b) if x != y]
+        assert not diff, "first differing SAM line:\n%s\n%s" % (diff[0][0].decode(), diff[0][1].decode())
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
