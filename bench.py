@@ -412,8 +412,8 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
             log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
         ref, drop = out["bwa-meme_mode3"], out["bwa-meme_dropin"]
         return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
-                "workload": "mem -7 -t %d, %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the benchmark "
-                            "genome (%d bp), wall time incl. index loading" % (threads, npairs, READ_LEN, genome.shape[0]),
+                "workload": "mem -7 (reference: -t %d; with the backend bound: -t %d), %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the "
+                            "benchmark genome (%d bp), wall time incl. index loading" % (ref["threads"], drop["threads"], npairs, READ_LEN, genome.shape[0]),
                 "threads": threads, "pairs": npairs, "gpus_driven_by_the_one_aligner_process": devices, "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]),
                 "dropin": drop, "reference": ref, "speedup_wall": ref["wall_s"] / drop["wall_s"],
                 "speedup_process": (ref["process_s"] / drop["process_s"]) if drop["process_s"] > 0 else None}

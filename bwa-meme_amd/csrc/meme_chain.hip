@@ -1,18 +1,15 @@
 // Chaining on the device: mem_chain_Learned + mem_chain_flt (reference src/bwamem.cpp:1122-1204, 599-717) for every read
 // of the batch the ctx has just seeded -- the seeds never leave HBM between the two stages.
 //
-// One lane per read (the work per read is small and strictly sequential: every hit is tested against the chain with the
-// closest position below it and either merged into it or becomes a new chain).  What the reference keeps in a B-tree keyed
-// by position is a position-sorted array of chains in a per-read scratch here; what it sorts with klib's introsort is sorted by
-// the same sequence of comparisons and swaps, because chains of equal weight keep whatever order that algorithm leaves them in
-// and the filter that follows depends on it.
-//
-// Two tiers, no host fallback.  Tier 1: one lane per read with a small fixed scratch (16 chains of 8 seeds) -- 97 % of the reads.
-// Tier 2 (k_chain_wave): one WAVEFRONT per read for everything else -- reads with many chains / long chains / hundreds of hits to walk
-// (repeats), and reads that put two chains on one position.  Its state is sized by the read's own work (hits to walk), the chains
-// live in a faithful restatement of the reference's B-tree (klib kbtree.h, t = 5) so that chains with EQUAL positions are found and
-// ordered exactly as the reference finds and orders them, and the 64 lanes test 64 hits of an SMEM against the tree at once; the
-// results are then committed in hit order, a hit whose neighbourhood an earlier hit of the same batch has changed being re-tested.
+// The work per read is strictly sequential (every hit is tested against the chain with the closest position at or below it and either
+// merged into it or becomes a new chain) and spans four orders of magnitude, so the reads are tiered by their own work; no host fallback:
+//   k_chain       one lane per read, position-sorted array of <= 16 chains of <= 8 seeds            97.9 % of the reads
+//   k_chain_reg   one wavefront per read, <= 256 chains in registers (slot = k * 64 + lane)           repeats
+//   k_chain_lds   one wavefront per read, <= 1 024 chains in LDS, parallel introsort / filter         heavy repeats
+//   k_chain_wave  one wavefront per read, the reference's B-tree (klib kbtree.h, t = 5) node for node: reads that put two chains on ONE
+//                 position (then the tree's shape decides their order and which one a query finds) and reads beyond 1 024 chains
+// What the reference sorts with klib's introsort is sorted by the same sequence of comparisons and swaps in every tier, because chains
+// of equal weight keep whatever order that algorithm leaves them in and the filter that follows depends on it.
 #include <string.h>
 #include <algorithm>
 
@@ -23,7 +20,7 @@ namespace {
 // Tier 1: every read with room for 16 chains of 8 seeds (2.5 KB per read), as long as one lane can walk it quickly.
 constexpr int CHAIN_CAP = 16, SEED_CAP = 8;
 constexpr int SMEM_CAP1 = 48;      // SMEMs per read in tier 1 (its sorted walk is quadratic in it)
-constexpr int HIT_CAP1 = 256;      // hits per read that one lane is asked to walk (dependent loads: ~1 us each)
+// (hits per read that one lane is asked to walk -- dependent loads, ~1 us each: meme_ctx::chain_lane_hits, default 256)
 
 struct DChain {                    // 32 bytes
     i64 pos;
@@ -39,6 +36,7 @@ struct ChainArgs {
     i64 nreads;
     const i64* contig_off; const int* contig_len; const unsigned char* contig_alt; int n_contigs;
     meme_chain_opt o;
+    int hit_cap1;                      // hits a lane of tier 1 is asked to walk
     DChain* ch; DSeed* sd; ReadHdr* hdr; float* frac_rep;
 };
 
@@ -144,6 +142,12 @@ __device__ void sort_by_weight(DChain* a, int n) {
 
 template <int CC, int SC>
 __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
+    __shared__ i64 lds_contig1[256];                 // bns_intv2rid searches the contig offsets twice per hit: keep them out of the dependent-load chain
+    if (A.n_contigs <= 256) {
+        for (int i = threadIdx.x; i < A.n_contigs; i += 64) lds_contig1[i] = A.contig_off[i];
+        __syncthreads();
+        A.contig_off = lds_contig1;
+    }
     const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= A.nreads) return;
     const i64 r = tid;
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
         i64 work = 0;
         for (int i = 0; i < ns; ++i) work += sm[i].hitcount < o.max_occ ? sm[i].hitcount : o.max_occ;
         H.work = work;
-        if (ns > SMEM_CAP1 || work > HIT_CAP1) H.fallback = 1;
+        if (ns > SMEM_CAP1 || work > A.hit_cap1) H.fallback = 1;
         int b = 0, e = 0, l_rep = 0;                                      // frac_rep (:1140-1147)
         // walk the SMEMs in (start, end) order; records with equal (start, end) describe the same substring, hence the same
         // hits, and the second one only meets seeds that are already contained: their relative order cannot matter
@@ -712,6 +716,96 @@ __global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 
     }
 }
 
+// klib's ks_introsort (src/ksort.h) by descending weight on (EW, EID)[0 .. n) in LDS, executed by one wavefront: every Hoare partition
+// step from the two lists of scan stops (ballots), the swaps in parallel, the closing insertion sort as a stable rank by counting
+// (tests/test_introsort_model.py checks this formulation against the sequential algorithm).  LIDX / RIDX: scratch of n ints each;
+// stk: 60 ints.  All lanes call it together.
+__device__ void wave_introsort_lds(int* EW, int* EID, int n, int* LIDX, int* RIDX, int* stk, int lane) {
+    const u64 below = ((u64)1 << lane) - 1;
+#define L_SWAP(i_, j_) do { const int i__ = (i_), j__ = (j_); const int wi_ = EW[i__], di_ = EID[i__], wj_ = EW[j__], dj_ = EID[j__]; \
+                            EW[i__] = wj_; EID[i__] = dj_; EW[j__] = wi_; EID[j__] = di_; } while (0)
+    if (n == 2) { if (EW[1] > EW[0]) L_SWAP(0, 1); }
+    else if (n > 2) {
+        int d;
+        for (d = 2; (1 << d) < n; ++d) {}
+        d <<= 1;
+        int s = 0, tt = n - 1, top = 0;
+        for (;;) {
+            if (s < tt) {
+                if (--d == 0) {                               // ks_combsort, as written (rare: the depth budget is 2 log2 n)
+                    const int cnn = tt - s + 1;
+                    const double shrink = 1.2473309501039786540366528676643;
+                    bool do_swap;
+                    int gap = cnn;
+                    do {
+                        if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
+                        do_swap = false;
+                        for (int i = s; i < s + cnn - gap; ++i) { const int j = i + gap; if (EW[j] > EW[i]) { L_SWAP(i, j); do_swap = true; } }
+                    } while (do_swap || gap > 2);
+                    if (gap != 1) for (int i = s + 1; i < s + cnn; ++i) for (int j = i; j > s && EW[j] > EW[j - 1]; --j) L_SWAP(j, j - 1);
+                    tt = s;
+                    continue;
+                }
+                int k = s + ((tt - s) >> 1) + 1;
+                { const int wi = EW[s], wj = EW[tt], wk = EW[k]; if (wk > wi) { if (wk > wj) k = tt; } else k = wj > wi ? s : tt; }
+                const int rpw = EW[k];
+                if (k != tt) L_SWAP(k, tt);
+                // the stops of the up-scan (weight <= pivot; positions s+1 .. tt, ascending) and of the down-scan (weight >= pivot; tt-1 .. s+1, descending)
+                int nL = 0, nR = 0;
+                for (int cb = s + 1; cb <= tt; cb += 64) {
+                    const int p = cb + lane;
+                    const bool is = p <= tt && EW[p] <= rpw;
+                    const u64 m = __ballot(is);
+                    if (is) LIDX[nL + __popcll(m & below)] = p;
+                    nL += __popcll(m);
+                }
+                for (int cb = tt - 1; cb > s; cb -= 64) {
+                    const int p = cb - lane;
+                    const bool is = p > s && EW[p] >= rpw;
+                    const u64 m = __ballot(is);
+                    if (is) RIDX[nR + __popcll(m & below)] = p;
+                    nR += __popcll(m);
+                }
+                __syncthreads();
+                const int nmin = nL < nR ? nL : nR;
+                int mm = 0;
+                for (int kb = 0; kb < nmin; kb += 64) {
+                    const int kk = kb + lane;
+                    const u64 m = __ballot(kk < nmin && LIDX[kk] < RIDX[kk]);
+                    mm += __popcll(m);
+                    if (m != ~(u64)0) break;                // (the condition holds for a prefix of the pairs)
+                }
+                for (int kk = lane; kk < mm; kk += 64) L_SWAP(LIDX[kk], RIDX[kk]);
+                __syncthreads();
+                int i = LIDX[mm];
+                if (mm >= 1 && RIDX[mm - 1] < i) i = RIDX[mm - 1];
+                L_SWAP(i, tt);
+                if (i - s > tt - i) {
+                    if (i - s > 16) { stk[top] = s; stk[top + 20] = i - 1; stk[top + 40] = d; ++top; }
+                    s = tt - i > 16 ? i + 1 : tt;
+                } else {
+                    if (tt - i > 16) { stk[top] = i + 1; stk[top + 20] = tt; stk[top + 40] = d; ++top; }
+                    tt = i - s > 16 ? i - 1 : s;
+                }
+            } else {
+                if (top == 0) break;
+                --top; s = stk[top]; tt = stk[top + 20]; d = stk[top + 40];
+            }
+        }
+        // __ks_insertsort over the whole array: a stable sort by descending weight
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) {
+            const int w = EW[e];
+            int rank = 0;
+            for (int f = 0; f < n; ++f) { const int wf = EW[f]; rank += (wf > w || (wf == w && f < e)) ? 1 : 0; }
+            LIDX[rank] = w; RIDX[rank] = EID[e];
+        }
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) { EW[e] = LIDX[e]; EID[e] = RIDX[e]; }
+    }
+#undef L_SWAP
+}
+
 // ---- tier 2: one wavefront per read, the chains in registers ----------------------------------------------------------------------
 // Repeat-rich reads make tens to hundreds of chains from hundreds of hits.  Here a read's chains live in the wavefront's registers:
 // chain slot s = k * 64 + lane (k < REG_K, up to 256 chains), each slot its position, its last seed, and the running coverage sums that
@@ -758,7 +852,7 @@ __device__ __forceinline__ i64 wave_max64(i64 v) {
 template <int REG_K>
 __global__ void __launch_bounds__(64) k_chain_reg(ChainArgs A, WaveArgs W) {
     constexpr int REG_CHAINS = REG_K * 64;
-    __shared__ int s_w[REG_CHAINS], s_id[REG_CHAINS], s_beg[REG_CHAINS], s_end[REG_CHAINS], s_n[REG_CHAINS], s_alt[REG_CHAINS];
+    __shared__ int s_w[REG_CHAINS], s_id[REG_CHAINS], s_beg[REG_CHAINS], s_end[REG_CHAINS], s_n[REG_CHAINS], s_alt[REG_CHAINS], s_x[2 * REG_CHAINS];
     __shared__ i64 lds_contig[CONTIG_LDS];
     __shared__ int stk[60];
     if (W.sub && (i64)blockIdx.x >= W.nsub) return;
@@ -929,66 +1023,14 @@ __global__ void __launch_bounds__(64) k_chain_reg(ChainArgs A, WaveArgs W) {
         }
         n = before;
         __syncthreads();
+        // ks_introsort(mem_flt) by weight, descending: the same result as klib's comparisons and swaps (chains of equal weight included)
+        wave_introsort_lds(s_w, s_id, n, s_x, s_x + REG_CHAINS, stk, lane);
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < REG_K; ++k) { const int e = k * 64 + lane; ew[k] = e < n ? s_w[e] : 0; eid[k] = e < n ? s_id[e] : 0; }
     }
     int n_kept = 0, n_seeds = 0;
     if (n > 0) {
-        // ks_introsort(mem_flt) by weight, descending (klib ksort.h), on element indices: the same comparisons and swaps
-#define E_LT(i_, j_) (reg_get(ew, (i_)) > reg_get(ew, (j_)))
-#define E_SWAP(i_, j_) do { const int i__ = (i_), j__ = (j_); const int wi = reg_get(ew, i__), di = reg_get(eid, i__), wj = reg_get(ew, j__), dj = reg_get(eid, j__); \
-                            reg_set(ew, i__, wj, lane); reg_set(eid, i__, dj, lane); reg_set(ew, j__, wi, lane); reg_set(eid, j__, di, lane); } while (0)
-#define E_INSERT(s_, t_) do { for (int i_ = (s_) + 1; i_ < (t_); ++i_) for (int j_ = i_; j_ > (s_) && E_LT(j_, j_ - 1); --j_) E_SWAP(j_, j_ - 1); } while (0)
-        if (n == 2) { if (E_LT(1, 0)) E_SWAP(0, 1); }
-        else if (n > 2) {
-            int d;
-            for (d = 2; (1 << d) < n; ++d) {}
-            d <<= 1;
-            int s = 0, tt = n - 1, top = 0;
-            for (;;) {
-                if (s < tt) {
-                    if (--d == 0) {                                       // ks_combsort
-                        const int cnn = tt - s + 1;
-                        const double shrink = 1.2473309501039786540366528676643;
-                        bool do_swap;
-                        int gap = cnn;
-                        do {
-                            if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
-                            do_swap = false;
-                            for (int i = s; i < s + cnn - gap; ++i) { const int j = i + gap; if (E_LT(j, i)) { E_SWAP(i, j); do_swap = true; } }
-                        } while (do_swap || gap > 2);
-                        if (gap != 1) E_INSERT(s, s + cnn);
-                        tt = s;
-                        continue;
-                    }
-                    int i = s, j = tt, k = i + ((j - i) >> 1) + 1;
-                    if (E_LT(k, i)) { if (E_LT(k, j)) k = j; }
-                    else k = E_LT(j, i) ? i : j;
-                    const int rpw = reg_get(ew, k);                       // the pivot's weight (the pivot element itself goes to tt)
-                    if (k != tt) E_SWAP(k, tt);
-                    for (;;) {
-                        do ++i; while (reg_get(ew, i) > rpw);
-                        do --j; while (i <= j && rpw > reg_get(ew, j));
-                        if (j <= i) break;
-                        E_SWAP(i, j);
-                    }
-                    E_SWAP(i, tt);
-                    if (i - s > tt - i) {
-                        if (i - s > 16) { stk[top] = s; stk[top + 20] = i - 1; stk[top + 40] = d; ++top; }
-                        s = tt - i > 16 ? i + 1 : tt;
-                    } else {
-                        if (tt - i > 16) { stk[top] = i + 1; stk[top + 20] = tt; stk[top + 40] = d; ++top; }
-                        tt = i - s > 16 ? i - 1 : s;
-                    }
-                } else {
-                    if (top == 0) { E_INSERT(0, n); break; }
-                    --top; s = stk[top]; tt = stk[top + 20]; d = stk[top + 40];
-                }
-            }
-        }
-#undef E_LT
-#undef E_SWAP
-#undef E_INSERT
         // the filter's view of the sorted chains, element e on lane e & 63
         int ebeg[REG_K], eend[REG_K], ealt[REG_K], efirst[REG_K], ekept[REG_K];
 #pragma unroll
@@ -1067,6 +1109,231 @@ __global__ void __launch_bounds__(64) k_chain_reg(ChainArgs A, WaveArgs W) {
             int ns_k = kp ? s_n[eid[k]] : 0;
             for (int dd = 32; dd >= 1; dd >>= 1) ns_k += __shfl_xor(ns_k, dd);
             n_seeds += ns_k;
+            before += __popcll(km);
+        }
+        n_kept = before;
+    }
+    if (lane == 0) {
+        ReadHdr H;
+        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base;
+        A.hdr[r] = H;
+        A.frac_rep[r] = (float)l_rep / len;
+    }
+}
+
+// ---- tier 2b: one wavefront per read, the chains in LDS -------------------------------------------------------------------------------
+// The same algorithm as the register tier for reads with 257 to 1 024 chains (0.05 % of the named configuration's reads, but each of them
+// milliseconds in the B-tree tier): chain fields as arrays in LDS, the lookup a strided scan of the positions by all lanes plus one
+// wave-wide max of (position << 11 | slot).  What is sequential per chain in the smaller tiers is done wave-parallel here, exactly:
+//  * klib's introsort (src/ksort.h): each Hoare partition step in O(range / 64) -- the k-th swap of the sequential loop pairs the k-th
+//    element from the left that stops the up-scan (weight <= pivot) with the k-th from the right that stops the down-scan (weight >=
+//    pivot), as long as the left one lies before the right one; the lists come from ballots, the swaps run in parallel, and the scan
+//    position the loop ends on follows from the two lists (checked against the sequential loop on 200 000 random arrays full of ties);
+//    the closing insertion sort over the whole array is a stable sort, i.e. a rank by counting;
+//  * mem_chain_flt's overlap loop: 64 kept chains per step, the first shadowing one by ballot.
+constexpr int LDS_CHAINS = 1024;
+
+__global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
+    constexpr int N = LDS_CHAINS;
+    __shared__ i64 s_pos[N];
+    __shared__ int s_a[12][N];
+    __shared__ i64 lds_contig[CONTIG_LDS];
+    __shared__ int stk[60];
+    int* const RID = s_a[0]; int* const CN = s_a[1]; int* const FQB = s_a[2]; int* const LRB = s_a[3]; int* const LQB = s_a[4]; int* const LLN = s_a[5];
+    int* const TAIL = s_a[6]; int* const WQ = s_a[7]; int* const EQ = s_a[8]; int* const WR = s_a[9]; int* const ER = s_a[10];
+    // after the walk: per chain ALT = s_a[0], CN, FQB (= query begin), END = s_a[4], CW = s_a[7]; per sorted element:
+    int* const EW = s_a[3]; int* const EID = s_a[5]; int* const EBEG = s_a[6]; int* const EEND = s_a[8]; int* const EALT = s_a[9]; int* const EFIRST = s_a[10];
+    int* const EKEPT = s_a[11];
+    int* const LIDX = reinterpret_cast<int*>(s_pos);            // scratch of the sort / the filter, once the positions are ranked
+    int* const RIDX = LIDX + N;
+    if (W.sub && (i64)blockIdx.x >= W.nsub) return;
+    const i64 t = W.sub ? W.sub[blockIdx.x] : (i64)blockIdx.x;
+    if (t >= W.nlist) return;
+    const int lane = threadIdx.x;
+    const u64 below = ((u64)1 << lane) - 1;
+    if (A.n_contigs <= CONTIG_LDS) {
+        for (int i = lane; i < A.n_contigs; i += 64) lds_contig[i] = A.contig_off[i];
+        __syncthreads();
+        A.contig_off = lds_contig;
+    }
+    const i64 r = W.list[t];
+    const i64 base = W.woff[t];
+    const meme_chain_opt& o = A.o;
+    const meme_mem_tl* sm = A.smems + A.smem_off[r];
+    const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
+    const u64* ht = A.hits + A.hit_off[r];
+    const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
+    C2* C = W.C + base;
+    S2* S = W.S + base;
+    FRec* F = W.F + base;
+    int* ia = W.ia + base;
+    for (int i = lane; i < ns; i += 64) {                       // SMEMs in (start, end) order (src/bwamem.cpp:1397)
+        const int s = sm[i].start, e = sm[i].end;
+        int rank = 0;
+        for (int j = 0; j < ns; ++j) {
+            const int sj = sm[j].start, ej = sm[j].end;
+            rank += (sj < s || (sj == s && (ej < e || (ej == e && j < i)))) ? 1 : 0;
+        }
+        ia[rank] = i;
+    }
+    wave_fence();
+    int nchain = 0, nseed = 0, bail = 0;
+    int fb = 0, fe = 0, l_rep = 0;
+    for (int si = 0; si < ns && !bail; ++si) {
+        const meme_mem_tl p = sm[ia[si]];
+        if (p.hitcount > o.max_occ) {
+            if (p.start > fe) { l_rep += fe - fb; fb = p.start; fe = p.end; }
+            else fe = fe > p.end ? fe : p.end;
+        }
+        const int slen = p.end - p.start, qb = p.start;
+        const int step = p.hitcount > o.max_occ ? p.hitcount / o.max_occ : 1;
+        int cnt = (p.hitcount + step - 1) / step;
+        if (cnt > o.max_occ) cnt = o.max_occ;
+        for (int cb = 0; cb < cnt && !bail; cb += 64) {
+            const int c = cb + lane;
+            const bool have = c < cnt;
+            const i64 h_rbeg = have ? (i64)ht[p.hitbeg + (i64)c * step] : 0;
+            const int h_rid = have ? intv2rid(A, h_rbeg, h_rbeg + slen) : -1;
+            u64 todo = __ballot(h_rid >= 0);
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const i64 rb = rdl64(h_rbeg, j);
+                const int hr = rdl(h_rid, j);
+                i64 best = -1;                                  // (position << 11 | slot) of the chain with the largest position <= rb
+                for (int s = lane; s < nchain; s += 64) { const i64 ps = s_pos[s]; if (ps <= rb) { const i64 key = (ps << 11) | s; best = key > best ? key : best; } }
+                const i64 M = wave_max64(best);
+                int out = 2, ow = 0;
+                i64 mp = -1;
+                if (M >= 0) {
+                    ow = (int)(M & 2047);
+                    mp = M >> 11;
+                    const int c_rid = RID[ow], c_fqb = FQB[ow], c_lrb = LRB[ow], c_lqb = LQB[ow], c_lln = LLN[ow];
+                    const i64 l_rbeg = mp + c_lrb;
+                    if (hr == c_rid) {                          // test_and_merge (:450-492)
+                        const i64 qend = c_lqb + c_lln, rend = l_rbeg + c_lln;
+                        if (qb >= c_fqb && qb + slen <= qend && rb >= mp && rb + slen <= rend) out = 0;
+                        else if ((l_rbeg < o.l_pac || mp < o.l_pac) && rb >= o.l_pac) out = 2;
+                        else {
+                            const i64 x = qb - c_lqb, y = rb - l_rbeg;
+                            if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c_lln < o.max_chain_gap && y - c_lln < o.max_chain_gap) out = 1;
+                        }
+                    }
+                }
+                if (out == 0) continue;
+                const int sid = nseed++;
+                if (lane == 0) { S2 sn; sn.rbeg = rb; sn.qbeg = qb; sn.len = slen; sn.next = -1; sn.pad = 0; S[sid] = sn; }
+                if (out == 1) {                                 // (every lane stores the same values: later reads are the reader's own writes)
+                    if (lane == 0) S[TAIL[ow]].next = sid;
+                    const int rel = (int)(rb - mp);
+                    CN[ow] += 1; LRB[ow] = rel; LQB[ow] = qb; LLN[ow] = slen; TAIL[ow] = sid;
+                    const int q_e = EQ[ow], r_e = ER[ow];
+                    if (qb >= q_e) WQ[ow] += slen; else if (qb + slen > q_e) WQ[ow] += qb + slen - q_e;
+                    EQ[ow] = q_e > qb + slen ? q_e : qb + slen;
+                    if (rel >= r_e) WR[ow] += slen; else if (rel + slen > r_e) WR[ow] += rel + slen - r_e;
+                    ER[ow] = r_e > rel + slen ? r_e : rel + slen;
+                } else {
+                    if (mp == rb || nchain == N) { bail = 1; break; }
+                    const int id = nchain++;
+                    if (lane == 0) C[id].head = sid;
+                    s_pos[id] = rb; RID[id] = hr; CN[id] = 1; FQB[id] = qb; LRB[id] = 0; LQB[id] = qb; LLN[id] = slen; TAIL[id] = sid;
+                    WQ[id] = slen; EQ[id] = qb + slen; WR[id] = slen; ER[id] = slen;
+                }
+            }
+        }
+    }
+    l_rep += fe - fb;
+    if (bail) {
+        if (lane == 0) { ReadHdr H; H.tree_size = 0; H.n_kept = 0; H.n_seeds = 0; H.fallback = 3; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base; A.hdr[r] = H; }
+        return;
+    }
+    // ---- chain records for the pack kernel; weight, query end and ALT flag per chain
+    __syncthreads();
+    for (int s = lane; s < nchain; s += 64) {
+        int w = WQ[s] < WR[s] ? WQ[s] : WR[s];
+        w = w < 1 << 30 ? w : (1 << 30) - 1;
+        const int alt = A.contig_alt[RID[s]] ? 1 : 0;
+        C2* c = &C[s];
+        c->pos = s_pos[s]; c->rid = RID[s]; c->n = CN[s]; c->w = w; c->is_alt = (short)alt; c->tail = TAIL[s];
+        WQ[s] = w; RID[s] = alt; LQB[s] = LQB[s] + LLN[s];
+    }
+    __syncthreads();
+    int* const ALT = RID; int* const END = LQB; int* const CW = WQ;
+    // tree order = order of the positions: rank by counting, elements (weight, chain) scattered to their rank
+    for (int s = lane; s < nchain; s += 64) {
+        const i64 ps = s_pos[s];
+        int rank = 0;
+        for (int u = 0; u < nchain; ++u) rank += s_pos[u] < ps ? 1 : 0;
+        EW[rank] = CW[s]; EID[rank] = s;
+    }
+    __syncthreads();
+    int n = nchain;
+    if (o.min_chain_weight > 0) {                               // (default 0: nothing is dropped)
+        n = 0;
+        for (int e = 0; e < nchain; ++e) { const int w = EW[e], id = EID[e]; if (w >= o.min_chain_weight) { EW[n] = w; EID[n] = id; ++n; } }
+    }
+    int n_kept = 0, n_seeds = 0;
+    if (n > 0) {
+        wave_introsort_lds(EW, EID, n, LIDX, RIDX, stk, lane);
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) { const int id = EID[e]; EBEG[e] = FQB[id]; EEND[e] = END[id]; EALT[e] = ALT[id]; EFIRST[e] = -1; EKEPT[e] = 0; }
+        __syncthreads();
+        EKEPT[0] = 3;
+        for (int i = 1; i < n; ++i) {
+            const int bi = EBEG[i], ei = EEND[i], wi = EW[i], ai = EALT[i];
+            bool large = false;
+            int brk = -1;
+            for (int cb = 0; cb < i && brk < 0; cb += 64) {
+                const int e = cb + lane;
+                bool lo = false, br = false;
+                if (e < i && EKEPT[e] != 0) {
+                    const int be = EBEG[e], ee = EEND[e], we = EW[e];
+                    const int b_max = be > bi ? be : bi, e_min = ee < ei ? ee : ei;
+                    if (e_min > b_max && (!EALT[e] || ai)) {
+                        const int li = ei - bi, lj = ee - be;
+                        const int min_l = li < lj ? li : lj;
+                        if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
+                            lo = true;
+                            br = (float)wi < (float)we * o.drop_ratio && we - wi >= o.min_seed_len << 1;
+                        }
+                    }
+                }
+                const u64 lom = __ballot(lo), brm = __ballot(br);
+                u64 upto = ~(u64)0;
+                if (brm) { const int kx = __builtin_ctzll(brm); brk = cb + kx; upto = ((u64)2 << kx) - 1; }
+                if (lo && ((upto >> lane) & 1) && EFIRST[e] < 0) EFIRST[e] = i;
+                if (lom & upto) large = true;
+            }
+            if (brk < 0) EKEPT[i] = large ? 2 : 3;
+        }
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) LIDX[e] = EKEPT[e];      // the kept list before the marks below
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) { if (LIDX[e] != 0) { const int f = EFIRST[e]; if (f >= 0) EKEPT[f] = 1; } }
+        __syncthreads();
+        {
+            int i = 0, k = 0;
+            for (; i < n; ++i) {
+                const int kp = EKEPT[i];
+                if (kp == 0 || kp == 3) continue;
+                if (++k >= o.max_chain_extend) break;
+            }
+            for (; i < n; ++i) if (EKEPT[i] < 3) EKEPT[i] = 0;
+        }
+        int before = 0;
+        for (int cb = 0; cb < n; cb += 64) {
+            const int e = cb + lane;
+            const bool kp = e < n && EKEPT[e] != 0;
+            const u64 km = __ballot(kp);
+            int nsd = 0;
+            if (kp) {
+                FRec f;
+                f.beg = EBEG[e]; f.end = EEND[e]; f.w = EW[e]; f.first = EFIRST[e]; f.kept = EKEPT[e]; f.is_alt = EALT[e]; f.id = EID[e]; f.pad = 0;
+                F[before + __popcll(km & below)] = f;
+                nsd = CN[f.id];
+            }
+            for (int dd = 32; dd >= 1; dd >>= 1) nsd += __shfl_xor(nsd, dd);
+            n_seeds += nsd;
             before += __popcll(km);
         }
         n_kept = before;
@@ -1186,6 +1453,7 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     A.contig_off = (const i64*)B[4].p; A.contig_len = (const int*)((unsigned char*)B[4].p + (size_t)n_contigs * 8);
     A.contig_alt = (const unsigned char*)B[4].p + (size_t)n_contigs * 12; A.n_contigs = n_contigs;
     A.o = *opt;
+    A.hit_cap1 = (int)ctx->chain_lane_hits;
     A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
     hipEvent_t* ev = ctx->ev_chain;
     for (int i = 0; i < 5; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
@@ -1246,10 +1514,10 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
         const bool no_reg_tier = ctx->chain_reg_tier == 0;                 // (tests: everything through the B-tree tier)
         unsigned long long n3 = n_redo;
         if (!no_reg_tier) {
-            // 256 chains per read in registers; what that leaves again with 512; what that leaves (equal positions, > 512 chains) to the B-tree tier
+            // 256 chains per read in registers; what that leaves with up to 1 024 chains in LDS; what that leaves (equal positions, more chains) to the B-tree tier
             for (int pass = 0; pass < 2 && n3 > 0; ++pass) {
                 if (pass == 0) hipLaunchKernelGGL((k_chain_reg<4>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
-                else hipLaunchKernelGGL((k_chain_reg<8>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
+                else hipLaunchKernelGGL(k_chain_lds, dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
                 i64* d_sub = (i64*)B[10].p + (size_t)pass * (size_t)(n_redo + 1);
                 HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
                 hipLaunchKernelGGL(k_chain_redo3, dim3(blocks_of((i64)n_redo, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, (const i64*)d_list, (i64)n_redo,

@@ -69,6 +69,7 @@ struct meme_ctx {
                                        // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
+    i64 chain_lane_hits = 256;         // hits per read the lane-per-read chaining tier walks; reads with more go to the wavefront tiers at once
     i64 chain_reg_tier = 1;            // 0: the chaining stage skips the register tier (everything beyond tier 1 through the B-tree tier; tests)
     i64 bsw_blocks = 0;
     i64 bsw_lane_min_pairs = 32768;   // batches at least this big use the lane-per-pair kernel (throughput); smaller ones the

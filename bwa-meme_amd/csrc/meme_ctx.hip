@@ -131,6 +131,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
     else if (!strcmp(key, "chain_reg_tier")) ctx->chain_reg_tier = value;
+    else if (!strcmp(key, "chain_lane_hits")) ctx->chain_lane_hits = value;
     else if (!strcmp(key, "group_lanes")) {
         if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) { meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG; }
         ctx->group_lanes = value;

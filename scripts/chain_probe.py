@@ -25,7 +25,7 @@ reads = workload.make_reads_fast(g, nreads, 150, seed=1000)
 off = np.arange(0, (nreads + 1) * 150, 150, dtype=np.int64)
 contigs = [(l_pac * k // 8, l_pac * (k + 1) // 8 - l_pac * k // 8, 0) for k in range(8)]
 opt = hipapi.default_chain_opt(l_pac)
-for it in range(3):
+for it in range(3 if not os.environ.get("CHAIN_LANE_HITS") else 1):
     t0 = time.time(); smems, so, hits, ho = ctx.seed_batch_host(reads.reshape(-1), off); t1 = time.time()
     res = ctx.chain_last_batch_host(contigs, opt); t2 = time.time()
     print("[chain probe] %d reads: seeding call %.1f ms (%.1f M reads/s incl. transfers), chaining call %.1f ms (%.1f M reads/s incl. transfers + numpy copies); "
@@ -49,3 +49,11 @@ print("[chain probe] chain kernels %.2f ms, of which the wavefront tiers %.2f ms
       % (tm.chain_kernel_ms, tm.chain_pass2_ms, tm.chain_tier2_reads, tm.chain_tier3_ms, tm.chain_tier3_reads))
 big = np.argsort(work)[-10:]
 print("[chain probe] ten heaviest reads: work", work[big].tolist(), "smems", ns[big].tolist(), "chains", tree[big].tolist())
+
+for cap in [int(x) for x in os.environ.get("CHAIN_LANE_HITS", "").split(",") if x]:
+    ctx.set_tuning("chain_lane_hits", cap)
+    for _ in range(2):
+        res = ctx.chain_last_batch_host(contigs, opt)
+    tm = ctx.timings()
+    print("[chain probe] lane tier walks <= %d hits: chain kernels %.2f ms, wavefront tiers %.2f ms (%d reads), B-tree tier %.2f ms (%d reads)"
+          % (cap, tm.chain_kernel_ms, tm.chain_pass2_ms, tm.chain_tier2_reads, tm.chain_tier3_ms, tm.chain_tier3_reads))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_named_r2/ (written by scripts/profile_named_r2.sh) -> profiles/r02_named_config.md + profiles/pmc_named.json.
+"""gpurun_out/prof_named_r<N>/ (written by scripts/profile_named_r<N>.sh) -> profiles/r0<N>_named_config.md + profiles/pmc_named.json.
+python scripts/make_named_profile_md.py [N]   (default 3; bench.json of round 3 = the plain default run, profiles/r03_bench_default_a.json)
 Per-launch figures: the PMC passes run --steps 2 --warmup 1 = 3 launches of 10 M reads + the 20 k-read parity sample."""
 import json
 import os
@@ -7,7 +8,8 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-D = os.path.join(REPO, "gpurun_out", "prof_named_r2") + "/"
+RND = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+D = os.path.join(REPO, "gpurun_out", "prof_named_r%d" % RND) + "/"
 
 
 def rows(f, pat):
@@ -23,13 +25,14 @@ def total(f, counter, kernel="k_seed<4>"):
 
 
 def trace_row(kernel="k_seed<4>"):
-    for l in rows("trace.md", re.escape(kernel)):
+    for l in rows("trace_seed.md" if os.path.exists(D + "trace_seed.md") else "trace.md", re.escape(kernel)):
         c = [x.strip() for x in l.strip("|").split("|")]
         return int(c[1]), float(c[2]), float(c[3]), float(c[4]), float(c[5])      # calls avg min max total_ms
     raise SystemExit("kernel not in trace")
 
 
-bench = json.loads(open(D + "bench.json").read().strip().splitlines()[-1])
+bench_path = D + "bench.json" if os.path.exists(D + "bench.json") else os.path.join(REPO, "profiles", "r%02d_bench_default_a.json" % RND)
+bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 traced = json.loads(open(D + "bench_traced.json").read().strip().splitlines()[-1])
 fetch = total("pmc_fetch.md", "FETCH_SIZE") / 3
 write = total("pmc_write.md", "WRITE_SIZE") / 3
@@ -42,7 +45,7 @@ k_avg = (tot - mn / 1000.0) / (calls - 1)
 searches = bench["roofline"]["work_per_read"]["searches"] * 1e7
 pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_named.json")))
 pmc.update({"fetch_size_kb_per_launch": fetch, "write_size_kb_per_launch": write, "tcc_miss_lines_per_launch": miss, "valu_insts_per_launch": valu,
-            "source": "profiles/r02_named_config.md (scripts/profile_named_r2.sh: separate rocprofv3 --pmc passes of the same bench command, round 2)",
+            "source": "profiles/r%02d_named_config.md (scripts/profile_named_r%d.sh: separate rocprofv3 --pmc passes of the same bench command, round %d)" % (RND, RND, RND),
             "note": "per-launch = column sum / 3 timed launches of 10 M reads (the passes run --steps 2 --warmup 1; the fourth dispatch is the 20 k-read parity sample). "
                     "FETCH_SIZE tallies 128-byte line fills at 64 B on gfx950 (MI355X_MICROARCH.md); cross-check: TCC_MISS_sum x 128 B = %.0f GB vs 2 x FETCH_SIZE = %.0f GB"
                     % (miss * 128 / 1e9, 2 * fetch * 1024 / 1e9)})
@@ -50,16 +53,19 @@ pmc["reference_cpu"] = {k: v for k, v in bench["cpu_baseline"].items() if k != "
 json.dump(pmc, open(os.path.join(REPO, "profiles", "pmc_named.json"), "w"), indent=1)
 alg = bench["roofline"]["algorithmic_bytes_per_read"] * 1e7
 md = []
-md.append("# Round 2 -- named configuration (BASELINE.json configs[1]) on one MI355X: bench line, kernel trace, PMC passes\n")
-md.append("Produced by `scripts/profile_named_r2.sh` in ONE gpurun call (ROCm 7.2, rocprofv3): a plain `python bench.py --steps 5 --warmup 1`, the same command under "
+md.append("# Round %d -- named configuration" % RND + " (BASELINE.json configs[1]) on one MI355X: bench line, kernel trace, PMC passes\n")
+md.append("Produced by `scripts/profile_named_r%d.sh`" % RND + " in ONE gpurun call (ROCm 7.2, rocprofv3): a plain `python bench.py --steps 5 --warmup 1`, the same command under "
           "`rocprofv3 --kernel-trace --stats` (without the two CPU legs), then four separate `--pmc` passes (`--steps 2 --warmup 1`, seeding only).  Tables: "
           "`scripts/rocpd_summary.py` over the rocpd databases; this file: `scripts/make_named_profile_md.py`.\n")
 md.append("## 1. The plain run (`bench.json`)\n```\n" + json.dumps(bench) + "\n```\n")
-md.append("stderr of that run:\n```\n" + "\n".join(l for l in open(D + "bench.err").read().splitlines() if "amdgpu.ids" not in l) + "\n```\n")
+if os.path.exists(D + "bench.err"):
+    md.append("stderr of that run:\n```\n" + "\n".join(l for l in open(D + "bench.err").read().splitlines() if "amdgpu.ids" not in l) + "\n```\n")
 md.append("## 2. Kernel trace of the same command (`rocprofv3 --kernel-trace --stats`; bench line of the traced run: %.1f M reads/s, k_seed %.2f ms by HIP events)\n"
           % (traced["value"] / 1e6, traced["roofline"]["kernel_ms"]))
 md.append("\n".join(open(D + "trace.md").read().splitlines()[1:40]) + "\n")
-md.append("`k_seed<4>`: %d dispatches = %d launches of 10 M reads (1 warm-up + 5 timed) + the 20 000-read parity sample (%.2f ms): **%.2f ms per 10 M-read launch**, max %.2f ms; "
+md.append(("In the seeding-only trace of the same command (`trace_seed`: the chain / ext legs of the full trace seed 2 M-read batches of their own, which would mix into the average): "
+           if os.path.exists(D + "trace_seed.md") else "") +
+          "`k_seed<4>`: %d dispatches = %d launches of 10 M reads (1 warm-up + 5 timed) + the 20 000-read parity sample (%.2f ms): **%.2f ms per 10 M-read launch**, max %.2f ms; "
           "`bench.py`'s HIP-event figure for the timed region: %.2f ms (it includes any overflow-tier launch).\n" % (calls, calls - 1, mn / 1000, k_avg, mx / 1000, traced["roofline"]["kernel_ms"]))
 md.append("## 3. PMC passes (each its own run; 3 launches of 10 M reads + the parity sample per pass)\n")
 for f, t in (("pmc_fetch.md", "FETCH_SIZE"), ("pmc_write.md", "WRITE_SIZE / TCC"), ("pmc_sq.md", "SQ, pass 1"), ("pmc_sq2.md", "SQ, pass 2")):
@@ -78,7 +84,14 @@ md.append("| VALU | SQ_INSTS_VALU %.3g per launch; x 4 cycles / 1 024 SIMDs / (%
           % (valu, k_avg, valu * 4 / 1024 / (k_avg * 1e-3 * 2.4e9) * 100, valu / searches))
 md.append("| SALU | SQ_INSTS_SALU %.3g per launch (%.0f %% of the VALU count) |" % (salu, salu / valu * 100))
 md.append("| L2 hits | TCC_HIT %.3g per launch: the kernel's working set does not live in L2 (model 8.6 GB, entries 99 GB) |" % hit)
-md.append("\nSame kernel as round 1 except the 32-byte model records, the bounded partial-layer index and 128 first-pass SMEM slots per read; the one-lane-per-read kernel that was "
-          "built to halve the lines is documented in `r02_seed_v2_experiment.md`.\n")
-open(os.path.join(REPO, "profiles", "r02_named_config.md"), "w").write("\n".join(md))
+if RND == 2:
+    md.append("\nSame kernel as round 1 except the 32-byte model records, the bounded partial-layer index and 128 first-pass SMEM slots per read; the one-lane-per-read kernel that was "
+              "built to halve the lines is documented in `r02_seed_v2_experiment.md`.\n")
+else:
+    md.append("\n`k_seed` is the round-2 kernel (why the reference's ISA shortcut was not added: DESIGN.md section 8).  New in this trace: the chaining tiers (`k_chain`, `k_chain_reg`, "
+              "`k_chain_lds`, `k_chain_wave`), the extension stage (`k_ext_*` around `k_bsw_lane`) and the CIGAR kernel (`k_gcig`) of bench.py's `chain` / `ext` legs.\n")
+    md.append("## 5. The kernels of the stages behind seeding in the same trace (2 M reads per leg)\n")
+    md.append("| kernel | calls | avg_us | min_us | max_us | total_ms | pct |\n|---|---|---|---|---|---|---|")
+    md.append("\n".join(r for r in open(D + "trace.md").read().splitlines() if re.search(r"k_chain|k_ext|k_gcig|k_bsw|k_scan|k_gather|k_pack_reads|k_offsets", r)) + "\n")
+open(os.path.join(REPO, "profiles", "r%02d_named_config.md" % RND), "w").write("\n".join(md))
 print("k_seed %.2f ms/launch, traffic %.0f GB, miss lines/search %.2f, VALU %.0f %%" % (k_avg, (2 * fetch + write) * 1024 / 1e9, miss / searches, valu * 4 / 1024 / (k_avg * 1e-3 * 2.4e9) * 100))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 rocpd sqlite outputs: per-kernel stats and per-kernel PMC counter averages.
 usage: rocpd_summary.py <results.db> [...]  -> markdown-ish text on stdout"""
+import os
 import sqlite3, sys
 for path in sys.argv[1:]:
     db = sqlite3.connect(path); cur = db.cursor()
@@ -12,7 +13,7 @@ for path in sys.argv[1:]:
         tot = sum(r[5] for r in rows) or 1
         print("| kernel | calls | avg_us | min_us | max_us | total_ms | pct |")
         print("|---|---|---|---|---|---|---|")
-        for r in rows[:12]:
+        for r in rows[:int(os.environ.get("ROCPD_ROWS", "12"))]:
             print("| %s | %d | %.1f | %.1f | %.1f | %.2f | %.1f |" % (r[0][:70], r[1], r[2]/1e3, r[3]/1e3, r[4]/1e3, r[5]/1e6, 100*r[5]/tot))
     except Exception as e:
         print("kernels view failed:", e, cols)
