@@ -4,8 +4,7 @@
 // The work per read is strictly sequential (every hit is tested against the chain with the closest position at or below it and either
 // merged into it or becomes a new chain) and spans four orders of magnitude, so the reads are tiered by their own work; no host fallback:
 //   k_chain       one lane per read, position-sorted array of <= 16 chains of <= 8 seeds            97.9 % of the reads
-//   k_chain_reg   one wavefront per read, <= 256 chains in registers (slot = k * 64 + lane)           repeats
-//   k_chain_lds   one wavefront per read, <= 1 024 chains in LDS, parallel introsort / filter         heavy repeats
+//   k_chain_lds   one wavefront per read, <= 256 / 512 / 1 024 chains in LDS, wave-parallel introsort / filter   repeats (2.1 %)
 //   k_chain_wave  one wavefront per read, the reference's B-tree (klib kbtree.h, t = 5) node for node: reads that put two chains on ONE
 //                 position (then the tree's shape decides their order and which one a query finds) and reads beyond 1 024 chains
 // What the reference sorts with klib's introsort is sorted by the same sequence of comparisons and swaps in every tier, because chains
@@ -37,6 +36,7 @@ struct ChainArgs {
     const i64* contig_off; const int* contig_len; const unsigned char* contig_alt; int n_contigs;
     meme_chain_opt o;
     int hit_cap1;                      // hits a lane of tier 1 is asked to walk
+    const unsigned char* cls;          // per read: 0 = tier 1 takes it; 1 / 2 = routed to a wavefront tier by its work before tier 1 runs
     DChain* ch; DSeed* sd; ReadHdr* hdr; float* frac_rep;
 };
 
@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= A.nreads) return;
     const i64 r = tid;
+    if (A.cls && A.cls[r]) return;                    // a wavefront tier has this read (k_chain_route)
     const meme_chain_opt& o = A.o;
     const meme_mem_tl* sm = A.smems + A.smem_off[r];
     const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
@@ -302,10 +303,8 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
 constexpr int T_ORD = 5, T_MAXK = 2 * T_ORD - 1;
 struct TNode { int n, internal; i64 key[T_MAXK]; int cid[T_MAXK]; int ptr[T_MAXK + 1]; int pad; };
 static_assert(sizeof(TNode) == 160, "TNode layout");
-// Two builds of the kernel: reads with up to WAVE_LIGHT hits to walk (most of the tier) keep 64 nodes (>= 256 chains) and 512 sort
-// slots in LDS (15 KB per wavefront, 10 wavefronts per CU); the few heavy ones get 288 nodes (>= 1 150 chains) and 2 048 sort slots
-// (63 KB) -- a node or sort slot that spills to HBM turns every step of the sequential parts from ~30 ns into ~1 us.
-constexpr int WAVE_LIGHT = 256;
+// The kernel is built with 288 nodes (>= 1 150 chains) and 2 048 sort slots in LDS (63 KB per wavefront): a node or sort slot that spills to HBM
+// turns every step of the sequential parts from ~30 ns into ~1 us.
 constexpr int CONTIG_LDS = 256;    // contig offsets kept in LDS for bns_intv2rid (all of them when the reference has that few)
 
 struct C2 {                        // chain record (64 bytes), indexed by creation order
@@ -321,7 +320,8 @@ struct FRec { int beg, end, w, first; int kept, is_alt, id, pad; };   // the fil
 
 struct WaveArgs {
     const i64* list; const i64* woff; i64 nlist;     // reads of this tier, exclusive prefix of their work
-    const i64* sub; i64 nsub;                        // B-tree tier: the entries of `list` it takes (those the register tier left)
+    const i64* sub; i64 nsub;                        // optional: the entries of `list` this launch takes
+    int set;                                         // which scratch set this launch works in (1..4; recorded in ReadHdr.slot for the pack kernel)
     C2* C; S2* S; FRec* F; u64* srt; int* ia; int* ib; TNode* nodes;
 };
 
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 
     }
     if (lane == 0) {
         ReadHdr H;
-        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base;
+        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)W.set << 60); H.work = W.woff[t + 1] - base;
         A.hdr[r] = H;
         A.frac_rep[r] = (float)l_rep / len;
     }
@@ -806,42 +806,11 @@ __device__ void wave_introsort_lds(int* EW, int* EID, int n, int* LIDX, int* RID
 #undef L_SWAP
 }
 
-// ---- tier 2: one wavefront per read, the chains in registers ----------------------------------------------------------------------
-// Repeat-rich reads make tens to hundreds of chains from hundreds of hits.  Here a read's chains live in the wavefront's registers:
-// chain slot s = k * 64 + lane (k < REG_K, up to 256 chains), each slot its position, its last seed, and the running coverage sums that
-// mem_chain_weight (src/bwamem.cpp:522-541) would compute -- so a hit costs a wave-wide max (the chain with the closest position at
-// or below it: what the reference asks its B-tree), a few lane reads of that chain's fields and a predicated update; no memory round
-// trip except the stores of the seed records.  As long as all chain positions differ, the B-tree's in-order traversal is simply the
-// order of the positions; a read that would put two chains on ONE position (then the tree's shape matters) or needs more than 256
-// chains leaves with fallback = 3 and is done by the B-tree tier below.  The filter's sort replays klib's introsort on (weight, chain)
-// pairs held one per lane slot, read and written through v_readlane / predicated moves (tens of cycles per access instead of a memory
-// round trip), and the overlap loop of mem_chain_flt runs lane-parallel over the kept chains.
-// REG_K register slots per lane: the kernel is built for 4 (256 chains: all but 0.05 % of the named configuration's reads) and 8 (512).
-
+// ---- wavefront helpers ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int rdl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ i64 rdl64(i64 v, int l) {
     const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
     return ((i64)hi << 32) | (i64)(unsigned)lo;
-}
-// element i of a per-lane array of REG_K registers (element = k * 64 + lane); i is wave-uniform
-template <typename T> __device__ __forceinline__ T reg_pick(const T (&a)[4], int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; }
-template <typename T> __device__ __forceinline__ T reg_pick(const T (&a)[8], int k) {
-    return k < 4 ? (k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]) : (k == 4 ? a[4] : k == 5 ? a[5] : k == 6 ? a[6] : a[7]);
-}
-#define REG_SEL(a_, k_) reg_pick(a_, k_)
-template <int REG_K> __device__ __forceinline__ int reg_get(const int (&a)[REG_K], int i) { const int v = reg_pick(a, i >> 6); return rdl(v, i & 63); }
-template <int REG_K> __device__ __forceinline__ i64 reg_get64(const i64 (&a)[REG_K], int i) { const i64 v = reg_pick(a, i >> 6); return rdl64(v, i & 63); }
-template <int REG_K> __device__ __forceinline__ void reg_set(int (&a)[REG_K], int i, int v, int lane) {
-    const int k = i >> 6;
-    const bool me = lane == (i & 63);
-#pragma unroll
-    for (int q = 0; q < REG_K; ++q) if (q == k && me) a[q] = v;
-}
-template <int REG_K> __device__ __forceinline__ void reg_set64(i64 (&a)[REG_K], int i, i64 v, int lane) {
-    const int k = i >> 6;
-    const bool me = lane == (i & 63);
-#pragma unroll
-    for (int q = 0; q < REG_K; ++q) if (q == k && me) a[q] = v;
 }
 __device__ __forceinline__ i64 wave_max64(i64 v) {
 #pragma unroll
@@ -849,292 +818,55 @@ __device__ __forceinline__ i64 wave_max64(i64 v) {
     return v;
 }
 
-template <int REG_K>
-__global__ void __launch_bounds__(64) k_chain_reg(ChainArgs A, WaveArgs W) {
-    constexpr int REG_CHAINS = REG_K * 64;
-    __shared__ int s_w[REG_CHAINS], s_id[REG_CHAINS], s_beg[REG_CHAINS], s_end[REG_CHAINS], s_n[REG_CHAINS], s_alt[REG_CHAINS], s_x[2 * REG_CHAINS];
-    __shared__ i64 lds_contig[CONTIG_LDS];
-    __shared__ int stk[60];
-    if (W.sub && (i64)blockIdx.x >= W.nsub) return;
-    const i64 t = W.sub ? W.sub[blockIdx.x] : (i64)blockIdx.x;
-    if (t >= W.nlist) return;
-    const int lane = threadIdx.x;
-    if (A.n_contigs <= CONTIG_LDS) {
-        for (int i = lane; i < A.n_contigs; i += 64) lds_contig[i] = A.contig_off[i];
-        __syncthreads();
-        A.contig_off = lds_contig;
-    }
-    const i64 r = W.list[t];
-    const i64 base = W.woff[t];
-    const meme_chain_opt& o = A.o;
-    const meme_mem_tl* sm = A.smems + A.smem_off[r];
-    const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
-    const u64* ht = A.hits + A.hit_off[r];
-    const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
-    C2* C = W.C + base;
-    S2* S = W.S + base;
-    FRec* F = W.F + base;
-    int* ia = W.ia + base;
-    // SMEMs in (start, end) order (src/bwamem.cpp:1397): rank by counting
-    for (int i = lane; i < ns; i += 64) {
-        const int s = sm[i].start, e = sm[i].end;
-        int rank = 0;
-        for (int j = 0; j < ns; ++j) {
-            const int sj = sm[j].start, ej = sm[j].end;
-            rank += (sj < s || (sj == s && (ej < e || (ej == e && j < i)))) ? 1 : 0;
-        }
-        ia[rank] = i;
-    }
-    wave_fence();
-    // ---- the chains: slot s = k * 64 + lane
-    i64 pos[REG_K];
-    int rid[REG_K], cn[REG_K], fqb[REG_K], lrb[REG_K], lqb[REG_K], lln[REG_K], tail[REG_K], wq[REG_K], eq[REG_K], wr[REG_K], er[REG_K];
-#pragma unroll
-    for (int k = 0; k < REG_K; ++k) { pos[k] = -1; rid[k] = cn[k] = fqb[k] = lrb[k] = lqb[k] = lln[k] = tail[k] = wq[k] = eq[k] = wr[k] = er[k] = 0; }
-    int nchain = 0, nseed = 0, bail = 0;
-    int fb = 0, fe = 0, l_rep = 0;
-    for (int si = 0; si < ns && !bail; ++si) {
-        const meme_mem_tl p = sm[ia[si]];
-        if (p.hitcount > o.max_occ) {                                     // frac_rep (:1140-1147)
-            if (p.start > fe) { l_rep += fe - fb; fb = p.start; fe = p.end; }
-            else fe = fe > p.end ? fe : p.end;
-        }
-        const int slen = p.end - p.start, qb = p.start;
-        const int step = p.hitcount > o.max_occ ? p.hitcount / o.max_occ : 1;
-        int cnt = (p.hitcount + step - 1) / step;
-        if (cnt > o.max_occ) cnt = o.max_occ;
-        for (int cb = 0; cb < cnt && !bail; cb += 64) {
-            const int c = cb + lane;
-            const bool have = c < cnt;
-            const i64 h_rbeg = have ? (i64)ht[p.hitbeg + (i64)c * step] : 0;
-            const int h_rid = have ? intv2rid(A, h_rbeg, h_rbeg + slen) : -1;
-            u64 todo = __ballot(h_rid >= 0);                              // (:1166: seeds bridging two sequences or the strands are dropped)
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const i64 rb = rdl64(h_rbeg, j);
-                const int hr = rdl(h_rid, j);
-                // the chain with the largest position <= rb (kb_intervalp's lower; all positions differ)
-                i64 best = -1;
-#pragma unroll
-                for (int k = 0; k < REG_K; ++k) if (pos[k] >= 0 && pos[k] <= rb && pos[k] > best) best = pos[k];
-                const i64 M = wave_max64(best);
-                int out = 2, ow = 0;                                      // 0 contained, 1 append, 2 new chain; ow = the chain's slot
-                if (M >= 0) {
-                    int ok = -1, ol = 0;
-#pragma unroll
-                    for (int k = 0; k < REG_K; ++k) { const u64 bm = __ballot(pos[k] == M); if (ok < 0 && bm) { ok = k; ol = __builtin_ctzll(bm); } }
-                    ow = ok * 64 + ol;
-                    const int c_rid = reg_get(rid, ow), c_fqb = reg_get(fqb, ow), c_lrb = reg_get(lrb, ow), c_lqb = reg_get(lqb, ow), c_lln = reg_get(lln, ow);
-                    const i64 l_rbeg = M + c_lrb;
-                    if (hr == c_rid) {                                    // test_and_merge (:450-492)
-                        const i64 qend = c_lqb + c_lln, rend = l_rbeg + c_lln;
-                        if (qb >= c_fqb && qb + slen <= qend && rb >= M && rb + slen <= rend) out = 0;
-                        else if ((l_rbeg < o.l_pac || M < o.l_pac) && rb >= o.l_pac) out = 2;
-                        else {
-                            const i64 x = qb - c_lqb, y = rb - l_rbeg;
-                            if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c_lln < o.max_chain_gap && y - c_lln < o.max_chain_gap) out = 1;
-                        }
-                    }
-                }
-                if (out == 0) continue;
-                const int sid = nseed++;
-                if (lane == 0) { S2 sn; sn.rbeg = rb; sn.qbeg = qb; sn.len = slen; sn.next = -1; sn.pad = 0; S[sid] = sn; }
-                if (out == 1) {
-                    const int c_tail = reg_get(tail, ow);
-                    if (lane == 0) S[c_tail].next = sid;
-                    const int rel = (int)(rb - M);
-                    const int k = ow >> 6;
-                    const bool me = lane == (ow & 63);
-#pragma unroll
-                    for (int q = 0; q < REG_K; ++q) if (q == k && me) {
-                        cn[q] += 1; lrb[q] = rel; lqb[q] = qb; lln[q] = slen; tail[q] = sid;
-                        if (qb >= eq[q]) wq[q] += slen; else if (qb + slen > eq[q]) wq[q] += qb + slen - eq[q];
-                        eq[q] = eq[q] > qb + slen ? eq[q] : qb + slen;
-                        if (rel >= er[q]) wr[q] += slen; else if (rel + slen > er[q]) wr[q] += rel + slen - er[q];
-                        er[q] = er[q] > rel + slen ? er[q] : rel + slen;
-                    }
-                } else {
-                    if (M == rb || nchain == REG_CHAINS) { bail = 1; break; }     // equal positions / too many chains: the B-tree tier
-                    const int id = nchain++;
-                    if (lane == 0) C[id].head = sid;
-                    const int k = id >> 6;
-                    const bool me = lane == (id & 63);
-#pragma unroll
-                    for (int q = 0; q < REG_K; ++q) if (q == k && me) {
-                        pos[q] = rb; rid[q] = hr; cn[q] = 1; fqb[q] = qb; lrb[q] = 0; lqb[q] = qb; lln[q] = slen; tail[q] = sid;
-                        wq[q] = slen; eq[q] = qb + slen; wr[q] = slen; er[q] = slen;
-                    }
-                }
-            }
-        }
-    }
-    l_rep += fe - fb;
-    if (bail) {
-        if (lane == 0) { ReadHdr H; H.tree_size = 0; H.n_kept = 0; H.n_seeds = 0; H.fallback = 3; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base; A.hdr[r] = H; }
-        return;
-    }
-    // ---- chain records for the pack kernel; tree order = order of the positions: rank by counting
-    int rank[REG_K], cw[REG_K];
-#pragma unroll
-    for (int k = 0; k < REG_K; ++k) {
-        rank[k] = 0;
-        int w = wq[k] < wr[k] ? wq[k] : wr[k];
-        cw[k] = w < 1 << 30 ? w : (1 << 30) - 1;
-        const int id = k * 64 + lane;
-        if (id < nchain) {
-            C2* c = &C[id];
-            c->pos = pos[k]; c->rid = rid[k]; c->n = cn[k]; c->w = cw[k]; c->is_alt = A.contig_alt[rid[k]] ? 1 : 0; c->tail = tail[k];
-        }
-    }
-    for (int u = 0; u < nchain; ++u) {
-        const i64 pu = reg_get64(pos, u);
-#pragma unroll
-        for (int k = 0; k < REG_K; ++k) rank[k] += (pu < pos[k]) ? 1 : 0;
-    }
-    // mem_chain_flt (src/bwamem.cpp:599-717): chains of at least min_chain_weight in tree order as (weight, chain) elements e = k * 64 + lane
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < REG_K; ++k) {
-        const int id = k * 64 + lane;
-        if (id < nchain) {
-            s_w[rank[k]] = cw[k]; s_id[rank[k]] = id;
-            s_beg[id] = fqb[k]; s_end[id] = lqb[k] + lln[k]; s_n[id] = cn[k]; s_alt[id] = A.contig_alt[rid[k]] ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    int ew[REG_K], eid[REG_K];
-    int n = 0;
-    {
-        int tw[REG_K], tid2[REG_K];
-        u64 keepm[REG_K];
-#pragma unroll
-        for (int k = 0; k < REG_K; ++k) {
-            const int e = k * 64 + lane;
-            tw[k] = e < nchain ? s_w[e] : 0; tid2[k] = e < nchain ? s_id[e] : 0;
-            keepm[k] = __ballot(e < nchain && tw[k] >= o.min_chain_weight);
-        }
-        __syncthreads();
-        int before = 0;
-#pragma unroll
-        for (int k = 0; k < REG_K; ++k) {
-            if ((keepm[k] >> lane) & 1) { const int d = before + __popcll(keepm[k] & (((u64)1 << lane) - 1)); s_w[d] = tw[k]; s_id[d] = tid2[k]; }
-            before += __popcll(keepm[k]);
-        }
-        n = before;
-        __syncthreads();
-        // ks_introsort(mem_flt) by weight, descending: the same result as klib's comparisons and swaps (chains of equal weight included)
-        wave_introsort_lds(s_w, s_id, n, s_x, s_x + REG_CHAINS, stk, lane);
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < REG_K; ++k) { const int e = k * 64 + lane; ew[k] = e < n ? s_w[e] : 0; eid[k] = e < n ? s_id[e] : 0; }
-    }
-    int n_kept = 0, n_seeds = 0;
-    if (n > 0) {
-        // the filter's view of the sorted chains, element e on lane e & 63
-        int ebeg[REG_K], eend[REG_K], ealt[REG_K], efirst[REG_K], ekept[REG_K];
-#pragma unroll
-        for (int k = 0; k < REG_K; ++k) {
-            const int e = k * 64 + lane;
-            const int id = e < n ? eid[k] : 0;
-            ebeg[k] = s_beg[id]; eend[k] = s_end[id]; ealt[k] = s_alt[id]; efirst[k] = -1; ekept[k] = 0;
-        }
-        if (lane == 0) ekept[0] = 3;
-        for (int i = 1; i < n; ++i) {
-            const int bi = reg_get(ebeg, i), ei = reg_get(eend, i), wi = reg_get(ew, i), ai = reg_get(ealt, i);
-            // over the kept chains in order (= the sorted elements before i that were kept), up to the first that shadows chain i
-            bool lo[REG_K];
-            int brk = -1;
-#pragma unroll
-            for (int k = 0; k < REG_K; ++k) {
-                const int e = k * 64 + lane;
-                lo[k] = false;
-                bool br = false;
-                if (e < i && ekept[k] != 0) {
-                    const int b_max = ebeg[k] > bi ? ebeg[k] : bi, e_min = eend[k] < ei ? eend[k] : ei;
-                    if (e_min > b_max && (!ealt[k] || ai)) {
-                        const int li = ei - bi, lj = eend[k] - ebeg[k];
-                        const int min_l = li < lj ? li : lj;
-                        if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
-                            lo[k] = true;
-                            br = (float)wi < (float)ew[k] * o.drop_ratio && ew[k] - wi >= o.min_seed_len << 1;
-                        }
-                    }
-                }
-                const u64 brm = __ballot(br);
-                if (brk < 0 && brm) brk = k * 64 + __builtin_ctzll(brm);
-            }
-            bool large = false;
-#pragma unroll
-            for (int k = 0; k < REG_K; ++k) {
-                const int e = k * 64 + lane;
-                const bool upto = brk < 0 || e <= brk;
-                if (lo[k] && upto && efirst[k] < 0) efirst[k] = i;
-                if (__ballot(lo[k] && upto)) large = true;
-            }
-            if (brk < 0) reg_set(ekept, i, large ? 2 : 3, lane);
-        }
-        // the first chain a kept chain shadows becomes kind 1 (:690-691), whatever it was
-        {
-            u64 inlist[REG_K];
-#pragma unroll
-            for (int k = 0; k < REG_K; ++k) inlist[k] = __ballot(k * 64 + lane < n && ekept[k] != 0);
-            for (int e = 0; e < n; ++e) {
-                if (!((REG_SEL(inlist, e >> 6) >> (e & 63)) & 1)) continue;
-                const int f = reg_get(efirst, e);
-                if (f >= 0) reg_set(ekept, f, 1, lane);
-            }
-        }
-        {
-            int i = 0, k = 0;
-            for (; i < n; ++i) {                                          // at most max_chain_extend chains of kind 1 / 2
-                const int kp = reg_get(ekept, i);
-                if (kp == 0 || kp == 3) continue;
-                if (++k >= o.max_chain_extend) break;
-            }
-            for (; i < n; ++i) if (reg_get(ekept, i) < 3) reg_set(ekept, i, 0, lane);
-        }
-        // the kept chains in order -> F[0 .. n_kept)
-        int before = 0;
-#pragma unroll
-        for (int k = 0; k < REG_K; ++k) {
-            const int e = k * 64 + lane;
-            const bool kp = e < n && ekept[k] != 0;
-            const u64 km = __ballot(kp);
-            if (kp) {
-                FRec f;
-                f.beg = ebeg[k]; f.end = eend[k]; f.w = ew[k]; f.first = efirst[k]; f.kept = ekept[k]; f.is_alt = ealt[k]; f.id = eid[k]; f.pad = 0;
-                F[before + __popcll(km & (((u64)1 << lane) - 1))] = f;
-            }
-            int ns_k = kp ? s_n[eid[k]] : 0;
-            for (int dd = 32; dd >= 1; dd >>= 1) ns_k += __shfl_xor(ns_k, dd);
-            n_seeds += ns_k;
-            before += __popcll(km);
-        }
-        n_kept = before;
-    }
-    if (lane == 0) {
-        ReadHdr H;
-        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base;
-        A.hdr[r] = H;
-        A.frac_rep[r] = (float)l_rep / len;
-    }
+#ifdef MEME_CHAIN_PROF
+__device__ unsigned long long g_prof[32];
+#define PROF_T0 unsigned long long prof_t = __builtin_readcyclecounter()
+#define PROF(slot_) do { const unsigned long long n__ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_prof[slot_], n__ - prof_t); prof_t = n__; } while (0)
+#else
+#define PROF_T0 do {} while (0)
+#define PROF(slot_) do {} while (0)
+#endif
+// minimum of an unsigned over the wavefront, through DPP: xor 1, xor 2, half-row mirror, row mirror leave every row of 16 lanes with its
+// minimum; the four rows meet on the scalar side.  (Six dependent ds_bpermute round trips per hit was what the lookup used to cost.)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    unsigned y;
+    y = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false); v = y < v ? y : v;      // quad_perm [1,0,3,2]
+    y = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false); v = y < v ? y : v;      // quad_perm [2,3,0,1]
+    y = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false); v = y < v ? y : v;     // row_half_mirror
+    y = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false); v = y < v ? y : v;     // row_mirror
+    const unsigned a = (unsigned)rdl((int)v, 0), b = (unsigned)rdl((int)v, 16), c = (unsigned)rdl((int)v, 32), d = (unsigned)rdl((int)v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// distance of a chain position below (or at) rb, saturated: 0xffffffff = no such chain, 0xfffffffe = one that is at least that far away
+constexpr unsigned DIST_NONE = 0xffffffffu, DIST_FAR = 0xfffffffeu;
+__device__ __forceinline__ unsigned dist_below(i64 pos, i64 rb) {
+    const i64 d = rb - pos;
+    return (pos < 0 || d < 0) ? DIST_NONE : (d >= (i64)DIST_FAR ? DIST_FAR : (unsigned)d);
 }
 
-// ---- tier 2b: one wavefront per read, the chains in LDS -------------------------------------------------------------------------------
-// The same algorithm as the register tier for reads with 257 to 1 024 chains (0.05 % of the named configuration's reads, but each of them
-// milliseconds in the B-tree tier): chain fields as arrays in LDS, the lookup a strided scan of the positions by all lanes plus one
-// wave-wide max of (position << 11 | slot).  What is sequential per chain in the smaller tiers is done wave-parallel here, exactly:
+// ---- tier 2: one wavefront per read, the chains in LDS --------------------------------------------------------------------------------
+// Repeat-rich reads make tens to hundreds of chains from hundreds of hits.  As long as all chain positions differ, the B-tree's in-order
+// traversal is simply the order of the positions and what the reference asks its tree (the chain with the largest position at or below the
+// hit) is a minimum over distances: chain fields as arrays in LDS, the lookup a strided scan of the positions by all lanes plus one
+// wave-wide minimum (DPP) of the 32-bit distance; a read that would put two chains on ONE position (then the tree's shape matters) or
+// needs more than N chains leaves with fallback = 3 and is done by the B-tree tier.  mem_chain_weight's two coverage sums are kept
+// online per chain.  What is sequential per chain in the lane tier is done wave-parallel here, exactly:
 //  * klib's introsort (src/ksort.h): each Hoare partition step in O(range / 64) -- the k-th swap of the sequential loop pairs the k-th
 //    element from the left that stops the up-scan (weight <= pivot) with the k-th from the right that stops the down-scan (weight >=
 //    pivot), as long as the left one lies before the right one; the lists come from ballots, the swaps run in parallel, and the scan
 //    position the loop ends on follows from the two lists (checked against the sequential loop on 200 000 random arrays full of ties);
 //    the closing insertion sort over the whole array is a stable sort, i.e. a rank by counting;
 //  * mem_chain_flt's overlap loop: 64 kept chains per step, the first shadowing one by ballot.
-constexpr int LDS_CHAINS = 1024;
+// Built for N = 256 (16 KB of LDS: nine reads per CU), 512 (30 KB: five) and 1 024 (59 KB: two); a read goes to the smallest one whose N
+// covers its hits (a read cannot make more chains than it has hits).  The wavefronts raise their issue priority: they run beside the
+// lane-per-read tier, which fills every SIMD, and are the long pole.  (Round 3 also had this tier with the chains in registers, slot =
+// k * 64 + lane, fields read through v_readlane: same speed as N = 256 here, three hundred lines more; removed.)
 
+template <int N>
 __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
-    constexpr int N = LDS_CHAINS;
+    static_assert(N <= 2048, "the lookup key keeps the slot in 11 bits");
+    __builtin_amdgcn_s_setprio(3);
     __shared__ i64 s_pos[N];
     __shared__ int s_a[12][N];
     __shared__ i64 lds_contig[CONTIG_LDS];
@@ -1156,6 +888,7 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
         __syncthreads();
         A.contig_off = lds_contig;
     }
+    PROF_T0;
     const i64 r = W.list[t];
     const i64 base = W.woff[t];
     const meme_chain_opt& o = A.o;
@@ -1177,6 +910,7 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
         ia[rank] = i;
     }
     wave_fence();
+    PROF(8);
     int nchain = 0, nseed = 0, bail = 0;
     int fb = 0, fe = 0, l_rep = 0;
     for (int si = 0; si < ns && !bail; ++si) {
@@ -1200,14 +934,23 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
                 todo &= todo - 1;
                 const i64 rb = rdl64(h_rbeg, j);
                 const int hr = rdl(h_rid, j);
-                i64 best = -1;                                  // (position << 11 | slot) of the chain with the largest position <= rb
-                for (int s = lane; s < nchain; s += 64) { const i64 ps = s_pos[s]; if (ps <= rb) { const i64 key = (ps << 11) | s; best = key > best ? key : best; } }
-                const i64 M = wave_max64(best);
+                // the chain with the largest position <= rb: per lane the closest of its slots (distance in 32 bits), the wave's minimum through
+                // DPP; a far-away answer is looked up again as (position << 11 | slot) in 64 bits
+                unsigned dbest = DIST_NONE;
+                int sbest = 0;
+                for (int s = lane; s < nchain; s += 64) { const unsigned d = dist_below(s_pos[s], rb); if (d < dbest) { dbest = d; sbest = s; } }
+                const unsigned dm = wave_min_u32(dbest);
                 int out = 2, ow = 0;
                 i64 mp = -1;
-                if (M >= 0) {
+                if (dm < DIST_FAR) { ow = rdl(sbest, __builtin_ctzll(__ballot(dbest == dm))); mp = rb - (i64)dm; }
+                else if (dm == DIST_FAR) {
+                    i64 best = -1;
+                    for (int s = lane; s < nchain; s += 64) { const i64 ps = s_pos[s]; if (ps <= rb) { const i64 key = (ps << 11) | s; best = key > best ? key : best; } }
+                    const i64 M = wave_max64(best);
                     ow = (int)(M & 2047);
                     mp = M >> 11;
+                }
+                if (mp >= 0) {
                     const int c_rid = RID[ow], c_fqb = FQB[ow], c_lrb = LRB[ow], c_lqb = LQB[ow], c_lln = LLN[ow];
                     const i64 l_rbeg = mp + c_lrb;
                     if (hr == c_rid) {                          // test_and_merge (:450-492)
@@ -1242,9 +985,10 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
             }
         }
     }
+    PROF(9);
     l_rep += fe - fb;
     if (bail) {
-        if (lane == 0) { ReadHdr H; H.tree_size = 0; H.n_kept = 0; H.n_seeds = 0; H.fallback = 3; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base; A.hdr[r] = H; }
+        if (lane == 0) { ReadHdr H; H.tree_size = 0; H.n_kept = 0; H.n_seeds = 0; H.fallback = 3; H.slot = t | ((i64)W.set << 60); H.work = W.woff[t + 1] - base; A.hdr[r] = H; }
         return;
     }
     // ---- chain records for the pack kernel; weight, query end and ALT flag per chain
@@ -1267,6 +1011,7 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
         EW[rank] = CW[s]; EID[rank] = s;
     }
     __syncthreads();
+    PROF(10);
     int n = nchain;
     if (o.min_chain_weight > 0) {                               // (default 0: nothing is dropped)
         n = 0;
@@ -1274,7 +1019,9 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
     }
     int n_kept = 0, n_seeds = 0;
     if (n > 0) {
+        PROF(11);
         wave_introsort_lds(EW, EID, n, LIDX, RIDX, stk, lane);
+        PROF(12);
         __syncthreads();
         for (int e = lane; e < n; e += 64) { const int id = EID[e]; EBEG[e] = FQB[id]; EEND[e] = END[id]; EALT[e] = ALT[id]; EFIRST[e] = -1; EKEPT[e] = 0; }
         __syncthreads();
@@ -1306,6 +1053,7 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
             }
             if (brk < 0) EKEPT[i] = large ? 2 : 3;
         }
+        PROF(13);
         __syncthreads();
         for (int e = lane; e < n; e += 64) LIDX[e] = EKEPT[e];      // the kept list before the marks below
         __syncthreads();
@@ -1338,27 +1086,30 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
         }
         n_kept = before;
     }
+    PROF(14);
     if (lane == 0) {
         ReadHdr H;
-        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)1 << 62); H.work = W.woff[t + 1] - base;
+        H.tree_size = nchain; H.n_kept = n_kept; H.n_seeds = n_seeds; H.fallback = 0; H.slot = t | ((i64)W.set << 60); H.work = W.woff[t + 1] - base;
         A.hdr[r] = H;
         A.frac_rep[r] = (float)l_rep / len;
     }
 }
 
 // the kept chains and their seeds, densely packed in read order (from the scratch of the tier that finished the read)
-__global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch1, const DSeed* __restrict__ sd1, WaveArgs W,
+struct PackSets { const i64* woff[6]; const C2* C[6]; const S2* S[6]; const FRec* F[6]; };      // [1..5]: the scratch sets of the wavefront tiers
+
+__global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ ch1, const DSeed* __restrict__ sd1, PackSets P,
                                                      const ReadHdr* __restrict__ hdr, const i64* __restrict__ chain_off,
                                                      const i64* __restrict__ seed_off, i64 nreads, meme_chain* __restrict__ out_ch,
                                                      meme_chain_seed* __restrict__ out_sd) {
     for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x) {
         const ReadHdr H = hdr[r];
         if (H.n_kept == 0) continue;
-        const bool second = (H.slot >> 62) & 1;
-        const i64 slot = H.slot & (((i64)1 << 62) - 1);
+        const int set = (int)((H.slot >> 60) & 7);
+        const i64 slot = H.slot & (((i64)1 << 60) - 1);
         i64 so = seed_off[r];
         const i64 s0 = so;
-        if (!second) {
+        if (set == 0) {
             const DChain* ch = ch1 + slot * CHAIN_CAP;
             const DSeed* sd = sd1 + slot * (i64)CHAIN_CAP * SEED_CAP;
             for (int k = 0; k < H.n_kept; ++k) {
@@ -1372,10 +1123,10 @@ __global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ c
                 for (int j = 0; j < c.n; ++j) { meme_chain_seed s; s.rbeg = row[j].rbeg; s.qbeg = row[j].qbeg; s.len = row[j].len; out_sd[so++] = s; }
             }
         } else {
-            const i64 base = W.woff[slot];
-            const C2* C = W.C + base;
-            const S2* S = W.S + base;
-            const FRec* F = W.F + base;
+            const i64 base = P.woff[set][slot];
+            const C2* C = P.C[set] + base;
+            const S2* S = P.S[set] + base;
+            const FRec* F = P.F[set] + base;
             for (int k = 0; k < H.n_kept; ++k) {
                 const FRec f = F[k];
                 const C2 c = C[f.id];
@@ -1390,18 +1141,43 @@ __global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ c
     }
 }
 
-// reads the first tier left (fallback == 1): their indices and work, for the second tier
-__global__ void __launch_bounds__(256) k_chain_redo(const ReadHdr* __restrict__ hdr, i64 nreads, unsigned long long* __restrict__ count, i64* __restrict__ list,
-                                                     i64* __restrict__ lwork) {
-    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x)
-        if (hdr[r].fallback == 1) { const unsigned long long k = atomicAdd(count, 1ull); list[k] = r; lwork[k] = hdr[r].work > 0 ? hdr[r].work : 1; }
+// Before tier 1 runs: the hits every read has to walk (sum over its SMEMs of min(hitcount, max_occ)); reads beyond `light` hits go to the
+// LDS tier of 256 chains, beyond `heavy` (256) to the one of 512, beyond `huge` (512) to the one of 1 024, at once and concurrently with
+// tier 1 (a read cannot make more chains than it has hits).  One atomic per wavefront and list.
+__global__ void __launch_bounds__(256) k_chain_route(const meme_mem_tl* __restrict__ smems, const i64* __restrict__ smem_off, const i64* __restrict__ read_off, i64 nreads,
+                                                      int max_occ, int min_seed_len, i64 light, i64 heavy, i64 huge, unsigned char* __restrict__ cls,
+                                                      unsigned long long* __restrict__ counts, i64* __restrict__ listA, i64* __restrict__ workA,
+                                                      i64* __restrict__ listL, i64* __restrict__ workL, i64* __restrict__ listH, i64* __restrict__ workH) {
+    const int lane = threadIdx.x & 63;
+    for (i64 r0 = ((i64)blockIdx.x * blockDim.x + threadIdx.x) - lane; r0 < nreads; r0 += (i64)gridDim.x * blockDim.x) {
+        const i64 r = r0 + lane;
+        i64 work = 0;
+        int c = 0;
+        if (r < nreads && read_off[r + 1] - read_off[r] >= min_seed_len) {
+            for (i64 k = smem_off[r]; k < smem_off[r + 1]; ++k) { const int h = smems[k].hitcount; work += h < max_occ ? h : max_occ; }
+            c = work > huge ? 3 : work > heavy ? 2 : (work > light ? 1 : 0);
+        }
+        if (r < nreads) cls[r] = (unsigned char)c;
+        for (int which = 1; which <= 3; ++which) {
+            const u64 m = __ballot(c == which);
+            if (!m) continue;
+            unsigned long long b = 0;
+            if (lane == __builtin_ctzll(m)) b = atomicAdd(&counts[which - 1], (unsigned long long)__popcll(m));
+            b = __shfl(b, __builtin_ctzll(m));
+            if (c == which) {
+                const unsigned long long k = b + (unsigned long long)__popcll(m & (((u64)1 << lane) - 1));
+                (which == 1 ? listA : which == 2 ? listL : listH)[k] = r;
+                (which == 1 ? workA : which == 2 ? workL : workH)[k] = work;
+            }
+        }
+    }
 }
 
-// list entries the register tier left (fallback == 3)
-__global__ void __launch_bounds__(256) k_chain_redo3(const ReadHdr* __restrict__ hdr, const i64* __restrict__ list, i64 nlist, unsigned long long* __restrict__ count,
-                                                      i64* __restrict__ sub) {
-    for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < nlist; t += (i64)gridDim.x * blockDim.x)
-        if (hdr[list[t]].fallback == 3) sub[atomicAdd(count, 1ull)] = t;
+// reads the first tier left (fallback == 1): their indices and work, for the second tier
+__global__ void __launch_bounds__(256) k_chain_redo(const ReadHdr* __restrict__ hdr, i64 nreads, int want, const unsigned char* __restrict__ skip,
+                                                     unsigned long long* __restrict__ count, i64* __restrict__ list, i64* __restrict__ lwork) {
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < nreads; r += (i64)gridDim.x * blockDim.x)
+        if (!(skip && skip[r]) && hdr[r].fallback == want) { const unsigned long long k = atomicAdd(count, 1ull); list[k] = r; lwork[k] = hdr[r].work > 0 ? hdr[r].work : 1; }
 }
 
 __global__ void __launch_bounds__(256) k_chain_counts(const ReadHdr* __restrict__ hdr, i64 nreads, i64* __restrict__ nch, i64* __restrict__ nsd,
@@ -1418,6 +1194,40 @@ unsigned blocks_of(i64 items, int per) { i64 b = (items + per - 1) / per; const 
 
 // Chains of the batch the ctx has just seeded, left in HBM: ctx->chain[5] = {chain_off[n+1], seed_off[n+1], nch[n+1], nsd[n+1], tree[n], fb[n]},
 // [6] = packed meme_chain, [7] = packed meme_chain_seed, [3] = frac_rep.  totals[0..1] = chains, seeds.
+//
+// Order of events: k_chain_route sends reads to the wavefront tiers by the number of hits they have to walk; then the lane-per-read tier
+// (everything else, main stream) and the three sizes of the LDS tier (> chain_light_hits, > 256, > 512 hits), each on a side stream of its
+// own, run CONCURRENTLY; the reads the lane tier could not hold go through the LDS tier of 256 chains afterwards; whatever is left with
+// fallback = 3 (two chains on one position; more than 1 024 chains) goes to the B-tree tier.  Each of the five wavefront launches has a
+// scratch set of its own.
+namespace {
+struct ScratchSet { DevBuf* buf; WaveArgs W; };
+int make_set(meme_ctx* ctx, DevBuf& buf, const i64* d_list, const i64* d_woff, i64 nlist, i64 total_work, int set, bool with_tree, WaveArgs* out) {
+    const size_t units = (size_t)total_work + 8, nodes = with_tree ? (size_t)total_work / 3 + 4 * (size_t)nlist + 8 : 1;
+    const size_t sz[7] = {units * sizeof(C2), units * sizeof(S2), units * sizeof(FRec), with_tree ? units * 8 : 8, units * 4, with_tree ? units * 4 : 8, nodes * sizeof(TNode)};
+    size_t need = 0, at[7];
+    for (int k = 0; k < 7; ++k) { at[k] = need; need += (sz[k] + 255) / 256 * 256; }
+    if (need > buf.cap) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2 + buf.cap) {
+            meme_set_error("chaining %lld repeat-rich reads of this batch (%lld hits to walk) needs %.1f GB of scratch, more than half of the free HBM "
+                           "(%.1f GB): chain this batch in smaller pieces", (long long)nlist, (long long)total_work, need / 1e9, free_b / 1e9);
+            return MEME_E_CAPACITY;
+        }
+    }
+    int rc = meme_buf_reserve(ctx, buf, need);
+    if (rc) return rc;
+    unsigned char* p = (unsigned char*)buf.p;
+    WaveArgs W;
+    memset(&W, 0, sizeof(W));
+    W.list = d_list; W.woff = d_woff; W.nlist = nlist; W.sub = nullptr; W.nsub = 0; W.set = set;
+    W.C = (C2*)(p + at[0]); W.S = (S2*)(p + at[1]); W.F = (FRec*)(p + at[2]); W.srt = (u64*)(p + at[3]); W.ia = (int*)(p + at[4]);
+    W.ib = (int*)(p + at[5]); W.nodes = (TNode*)(p + at[6]);
+    *out = W;
+    return MEME_OK;
+}
+}  // namespace
+
 int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt, i64* totals) {
     const i64 n = ctx->last_seed_reads;
     int rc;
@@ -1427,25 +1237,25 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
                            (long long)opt->l_pac);
             return MEME_E_ARG;
         }
-    DevBuf* B = ctx->chain;     // 0 chains scratch, 1 seeds scratch, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
-                                // 8 tier-2 list + work + offsets, 9 tier-2 scratch
+    DevBuf* B = ctx->chain;     // 0 tier-1 chains, 1 tier-1 seeds, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
+                                // 8 lists + work + offsets of the five wavefront launches + read classes, 9 .. 13 their scratch sets
     if ((rc = meme_buf_reserve(ctx, B[0], (size_t)n * CHAIN_CAP * sizeof(DChain)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[1], (size_t)n * CHAIN_CAP * SEED_CAP * sizeof(DSeed)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[2], (size_t)n * sizeof(ReadHdr)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[3], (size_t)n * sizeof(float)))) return rc;
     const size_t ctab = (size_t)n_contigs * (8 + 4 + 1) + 64;
     if ((rc = meme_buf_reserve(ctx, B[4], ctab))) return rc;
-    // counts, their scans, tree sizes, fallback flags (+ the tier-2 counter at the end)
-    const size_t cnt_bytes = ((size_t)(n + 1) * 8 * 4 + (size_t)n * 4 + (size_t)n + 64 + 15) / 16 * 16 + 16;
+    const size_t cnt_bytes = ((size_t)(n + 1) * 8 * 4 + (size_t)n * 4 + (size_t)n + 64 + 15) / 16 * 16 + 64;   // (+ five counters at the end)
     if ((rc = meme_buf_reserve(ctx, B[5], cnt_bytes))) return rc;
-    // contig table: offsets | lengths | alt flags
+    if ((rc = meme_buf_reserve(ctx, B[8], (size_t)(n + 1) * 8 * 15 + (size_t)n + 64))) return rc;
     std::vector<unsigned char> tab(ctab, 0);
     i64* t_off = (i64*)tab.data();
     int* t_len = (int*)(tab.data() + (size_t)n_contigs * 8);
     unsigned char* t_alt = tab.data() + (size_t)n_contigs * 12;
     for (int i = 0; i < n_contigs; ++i) { t_off[i] = contigs[i].offset; t_len[i] = contigs[i].len; t_alt[i] = contigs[i].is_alt ? 1 : 0; }
     HIP_TRY(hipMemcpyAsync(B[4].p, tab.data(), ctab, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));                           // (`tab` is a local)
+    unsigned long long* d_cnt4 = (unsigned long long*)((unsigned char*)B[5].p + cnt_bytes - 64);
+    HIP_TRY(hipMemsetAsync(d_cnt4, 0, 64, ctx->stream));
     ChainArgs A;
     A.smems = (const meme_mem_tl*)ctx->smems.p; A.smem_off = (const i64*)ctx->smem_off.p;
     A.hits = (const u64*)ctx->hits.p; A.hit_off = (const i64*)ctx->hit_off.p; A.read_off = (const i64*)ctx->read_off.p;
@@ -1455,84 +1265,79 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     A.o = *opt;
     A.hit_cap1 = (int)ctx->chain_lane_hits;
     A.ch = (DChain*)B[0].p; A.sd = (DSeed*)B[1].p; A.hdr = (ReadHdr*)B[2].p; A.frac_rep = (float*)B[3].p;
+    // lists: [k] list, work, offsets for k = 0 / 1 / 2 LDS tier of 256 / 512 / 1 024 chains (routed), 3 LDS tier of 256 chains (left by the
+    // lane tier), 4 B-tree tier; scratch set k + 1 in B[9 + k]
+    i64* L8 = (i64*)B[8].p;
+    i64 *d_list[5], *d_work[5], *d_woff[5];
+    for (int k = 0; k < 5; ++k) { d_list[k] = L8 + (size_t)(3 * k) * (size_t)(n + 1); d_work[k] = d_list[k] + (n + 1); d_woff[k] = d_work[k] + (n + 1); }
+    unsigned char* d_cls = (unsigned char*)(L8 + (size_t)15 * (size_t)(n + 1));
+    const bool wave_tiers = ctx->chain_wave_tiers != 0;     // (0: tests drive everything the lane tier leaves through the B-tree tier)
+    A.cls = d_cls;
     hipEvent_t* ev = ctx->ev_chain;
     for (int i = 0; i < 5; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
-    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
-    // tier 2: the reads the first tier left
-    unsigned long long* d_redo_n = (unsigned long long*)((unsigned char*)B[5].p + cnt_bytes - 16);
-    HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
-    if ((rc = meme_buf_reserve(ctx, B[8], (size_t)(n + 1) * 8 * 3))) return rc;
-    i64* d_list = (i64*)B[8].p;
-    i64* d_lwork = d_list + (n + 1);
-    i64* d_woff = d_lwork + (n + 1);
-    hipLaunchKernelGGL(k_chain_redo, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, d_redo_n, d_list, d_lwork);
-    unsigned long long n_redo = 0;
-    HIP_TRY(hipMemcpyAsync(&n_redo, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    WaveArgs W;
-    memset(&W, 0, sizeof(W));
-    bool tier2 = false;
-    if (n_redo > 0) {
-        // register tier for all of them (longest first: a wavefront per read, the long ones should not start last), then the B-tree tier
-        // for what the register tier left: reads with two chains on one position, reads with more than 256 chains
-        std::vector<i64> h_list((size_t)n_redo), h_work((size_t)n_redo), h_off((size_t)n_redo + 1);
-        HIP_TRY(hipMemcpyAsync(h_list.data(), d_list, (size_t)n_redo * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(h_work.data(), d_lwork, (size_t)n_redo * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        std::vector<std::pair<i64, i64>> heavy, light;                       // (work, read)
-        for (size_t k = 0; k < (size_t)n_redo; ++k) (h_work[k] > WAVE_LIGHT ? heavy : light).push_back({h_work[k], h_list[k]});
-        std::sort(heavy.begin(), heavy.end(), [](const std::pair<i64, i64>& x, const std::pair<i64, i64>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-        i64 total_work = 0;
-        for (size_t k = 0; k < (size_t)n_redo; ++k) {
-            const std::pair<i64, i64>& e = k < heavy.size() ? heavy[k] : light[k - heavy.size()];
-            h_list[k] = e.second; h_off[k] = total_work; total_work += e.first;
-        }
-        h_off[(size_t)n_redo] = total_work;
-        HIP_TRY(hipMemcpyAsync(d_list, h_list.data(), (size_t)n_redo * 8, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_woff, h_off.data(), (size_t)(n_redo + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        const size_t units = (size_t)total_work + 8, nodes = (size_t)total_work / 3 + 4 * (size_t)n_redo + 8;
-        const size_t sz[7] = {units * sizeof(C2), units * sizeof(S2), units * sizeof(FRec), units * 8, units * 4, units * 4, nodes * sizeof(TNode)};
-        size_t need = 0, at[7];
-        for (int k = 0; k < 7; ++k) { at[k] = need; need += (sz[k] + 255) / 256 * 256; }
-        if (need > B[9].cap) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2 + B[9].cap) {
-                meme_set_error("chaining %llu repeat-rich reads of this batch (%lld hits to walk) needs %.1f GB of scratch, more than half of the free HBM "
-                               "(%.1f GB): chain this batch in smaller pieces", n_redo, (long long)total_work, need / 1e9, free_b / 1e9);
-                return MEME_E_CAPACITY;
-            }
-        }
-        if ((rc = meme_buf_reserve(ctx, B[9], need))) return rc;
-        if ((rc = meme_buf_reserve(ctx, B[10], (size_t)(n_redo + 1) * 8 * 2))) return rc;
-        unsigned char* p9 = (unsigned char*)B[9].p;
-        W.list = d_list; W.woff = d_woff; W.nlist = (i64)n_redo; W.sub = nullptr; W.nsub = 0;
-        W.C = (C2*)(p9 + at[0]); W.S = (S2*)(p9 + at[1]); W.F = (FRec*)(p9 + at[2]); W.srt = (u64*)(p9 + at[3]); W.ia = (int*)(p9 + at[4]);
-        W.ib = (int*)(p9 + at[5]); W.nodes = (TNode*)(p9 + at[6]);
-        HIP_TRY(hipStreamSynchronize(ctx->stream));                       // (the host vectors above are locals)
-        HIP_TRY(hipEventRecord(ev[1], ctx->stream));
-        const bool no_reg_tier = ctx->chain_reg_tier == 0;                 // (tests: everything through the B-tree tier)
-        unsigned long long n3 = n_redo;
-        if (!no_reg_tier) {
-            // 256 chains per read in registers; what that leaves with up to 1 024 chains in LDS; what that leaves (equal positions, more chains) to the B-tree tier
-            for (int pass = 0; pass < 2 && n3 > 0; ++pass) {
-                if (pass == 0) hipLaunchKernelGGL((k_chain_reg<4>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
-                else hipLaunchKernelGGL(k_chain_lds, dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W);
-                i64* d_sub = (i64*)B[10].p + (size_t)pass * (size_t)(n_redo + 1);
-                HIP_TRY(hipMemsetAsync(d_redo_n, 0, 8, ctx->stream));
-                hipLaunchKernelGGL(k_chain_redo3, dim3(blocks_of((i64)n_redo, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, (const i64*)d_list, (i64)n_redo,
-                                   d_redo_n, d_sub);
-                HIP_TRY(hipMemcpyAsync(&n3, d_redo_n, 8, hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                W.sub = (const i64*)d_sub; W.nsub = (i64)n3;
-            }
-        }
-        HIP_TRY(hipEventRecord(ev[4], ctx->stream));
-        if (n3 > 0) hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)n3), dim3(64), 0, ctx->stream, A, W, (i64)0);
-        HIP_TRY(hipEventRecord(ev[2], ctx->stream));
-        ctx->chain_tier3_reads = (i64)(no_reg_tier ? n_redo : n3);
-        tier2 = true;
+    for (int i = 0; i < 3; ++i) {
+        if (!ctx->stream_side[i]) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_side[i], hipStreamNonBlocking));
+        if (!ctx->ev_side[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming));
     }
+    if (!ctx->ev_aux) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    // ---- route by work
+    const i64 never = (i64)1 << 60;
+    const i64 light = wave_tiers ? ctx->chain_light_hits : never, heavy = wave_tiers ? 256 : never, huge = wave_tiers ? 512 : never;
+    hipLaunchKernelGGL(k_chain_route, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, A.smems, A.smem_off, A.read_off, n, opt->max_occ, opt->min_seed_len, light, heavy, huge,
+                       d_cls, d_cnt4, d_list[0], d_work[0], d_list[1], d_work[1], d_list[2], d_work[2]);
+    unsigned long long h_cnt[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt4, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                           // (also: `tab` is a local)
+    i64 nl[5] = {(i64)h_cnt[0], (i64)h_cnt[1], (i64)h_cnt[2], 0, 0}, tw[5] = {0, 0, 0, 0, 0};
+    WaveArgs W[5];
+    memset(W, 0, sizeof(W));
+    bool used[5] = {false, false, false, false, false};
+    for (int k = 0; k < 3; ++k) if (nl[k] > 0) { if ((rc = meme_scan_exclusive(ctx, d_work[k], d_woff[k], nl[k]))) return rc; HIP_TRY(hipMemcpyAsync(&tw[k], d_woff[k] + nl[k], 8, hipMemcpyDeviceToHost, ctx->stream)); }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 3; ++k) if (nl[k] > 0) { if ((rc = make_set(ctx, B[9 + k], d_list[k], d_woff[k], nl[k], tw[k], 1 + k, false, &W[k]))) return rc; used[k] = true; }
+    HIP_TRY(hipEventRecord(ctx->ev_aux, ctx->stream));
+    // ---- four launches at once (the longest-running first)
+    for (int k = 2; k >= 0; --k) {
+        if (nl[k] <= 0) continue;
+        HIP_TRY(hipStreamWaitEvent(ctx->stream_side[k], ctx->ev_aux, 0));
+        if (k == 2) hipLaunchKernelGGL((k_chain_lds<1024>), dim3((unsigned)nl[k]), dim3(64), 0, ctx->stream_side[k], A, W[k]);
+        else if (k == 1) hipLaunchKernelGGL((k_chain_lds<512>), dim3((unsigned)nl[k]), dim3(64), 0, ctx->stream_side[k], A, W[k]);
+        else hipLaunchKernelGGL((k_chain_lds<256>), dim3((unsigned)nl[k]), dim3(64), 0, ctx->stream_side[k], A, W[k]);
+        HIP_TRY(hipEventRecord(ctx->ev_side[k], ctx->stream_side[k]));
+    }
+    hipLaunchKernelGGL((k_chain<CHAIN_CAP, SEED_CAP>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, A);
+    HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+    // ---- what the lane tier left: LDS tier of 256 chains (or, with that switched off, the B-tree tier)
+    hipLaunchKernelGGL(k_chain_redo, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, 1, (const unsigned char*)d_cls, d_cnt4 + 3, d_list[3], d_work[3]);   // (routed reads: their tiers may still be writing)
+    HIP_TRY(hipMemcpyAsync(&h_cnt[3], d_cnt4 + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    nl[3] = (i64)h_cnt[3];
+    if (nl[3] > 0) {
+        if ((rc = meme_scan_exclusive(ctx, d_work[3], d_woff[3], nl[3]))) return rc;
+        HIP_TRY(hipMemcpyAsync(&tw[3], d_woff[3] + nl[3], 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if ((rc = make_set(ctx, B[12], d_list[3], d_woff[3], nl[3], tw[3], 4, !wave_tiers, &W[3]))) return rc;
+        used[3] = true;
+        if (wave_tiers) hipLaunchKernelGGL((k_chain_lds<256>), dim3((unsigned)nl[3]), dim3(64), 0, ctx->stream, A, W[3]);
+        else hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)nl[3]), dim3(64), 0, ctx->stream, A, W[3], (i64)0);
+    }
+    for (int k = 0; k < 3; ++k) if (nl[k] > 0) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_side[k], 0));
+    HIP_TRY(hipEventRecord(ev[4], ctx->stream));
+    // ---- the B-tree tier for what is left (fallback == 3)
+    hipLaunchKernelGGL(k_chain_redo, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const ReadHdr*)B[2].p, n, 3, (const unsigned char*)nullptr, d_cnt4 + 4, d_list[4], d_work[4]);
+    HIP_TRY(hipMemcpyAsync(&h_cnt[4], d_cnt4 + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    nl[4] = (i64)h_cnt[4];
+    if (nl[4] > 0) {
+        if ((rc = meme_scan_exclusive(ctx, d_work[4], d_woff[4], nl[4]))) return rc;
+        HIP_TRY(hipMemcpyAsync(&tw[4], d_woff[4] + nl[4], 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if ((rc = make_set(ctx, B[13], d_list[4], d_woff[4], nl[4], tw[4], 5, true, &W[4]))) return rc;
+        used[4] = true;
+        hipLaunchKernelGGL((k_chain_wave<288, 2048>), dim3((unsigned)nl[4]), dim3(64), 0, ctx->stream, A, W[4], (i64)0);
+    }
+    HIP_TRY(hipEventRecord(ev[2], ctx->stream));
     i64* d_choff = (i64*)B[5].p;
     i64* d_sdoff = d_choff + (n + 1);
     i64* d_nch = d_sdoff + (n + 1);
@@ -1548,26 +1353,39 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((rc = meme_buf_reserve(ctx, B[6], (size_t)(tot[0] + 1) * sizeof(meme_chain)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[7], (size_t)(tot[1] + 1) * sizeof(meme_chain_seed)))) return rc;
-    hipLaunchKernelGGL(k_chain_pack, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const DChain*)B[0].p, (const DSeed*)B[1].p, W,
+    PackSets PS;
+    memset(&PS, 0, sizeof(PS));
+    for (int k = 0; k < 5; ++k) if (used[k]) { PS.woff[k + 1] = W[k].woff; PS.C[k + 1] = W[k].C; PS.S[k + 1] = W[k].S; PS.F[k + 1] = W[k].F; }
+    hipLaunchKernelGGL(k_chain_pack, dim3(blocks_of(n, 256)), dim3(256), 0, ctx->stream, (const DChain*)B[0].p, (const DSeed*)B[1].p, PS,
                        (const ReadHdr*)B[2].p, (const i64*)d_choff, (const i64*)d_sdoff, n, (meme_chain*)B[6].p, (meme_chain_seed*)B[7].p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev[3], ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     {
-        float ms = 0.f, ms2 = 0.f, ms3 = 0.f;
+        float ms = 0.f, ms1 = 0.f, ms3 = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3]));
-        if (tier2) { HIP_TRY(hipEventElapsedTime(&ms2, ev[1], ev[2])); HIP_TRY(hipEventElapsedTime(&ms3, ev[4], ev[2])); }
+        HIP_TRY(hipEventElapsedTime(&ms1, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms3, ev[4], ev[2]));
         ctx->tm.chain_kernel_ms = ms;          // (includes the small host round trips between the tiers)
-        ctx->tm.chain_pass2_ms = ms2;
+        ctx->tm.chain_pass2_ms = ms - ms1;     // everything after the lane-per-read tier has finished (the routed tiers run beside it)
         ctx->tm.chain_tier3_ms = ms3;
-        ctx->tm.chain_tier2_reads = (i64)n_redo;
-        ctx->tm.chain_tier3_reads = tier2 ? ctx->chain_tier3_reads : 0;
+        ctx->tm.chain_tier2_reads = nl[0] + nl[1] + nl[2] + nl[3];
+        ctx->tm.chain_tier3_reads = nl[4];
     }
     ctx->chain_reads = n;
-    ctx->chain_tier2_reads = (i64)n_redo;
+    ctx->chain_tier2_reads = nl[0] + nl[1] + nl[2] + nl[3];
+    ctx->chain_tier3_reads = nl[4];
     totals[0] = tot[0]; totals[1] = tot[1];
     return MEME_OK;
 }
+
+#ifdef MEME_CHAIN_PROF
+extern "C" int meme_debug_chain_prof(unsigned long long* out, int reset) {        // (investigation builds only: cycles per phase, summed over wavefronts)
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 extern "C" int meme_chain_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt,
                                           meme_chain_host_result* out) {

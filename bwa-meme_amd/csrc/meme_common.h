@@ -58,7 +58,7 @@ struct meme_ctx {
     std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[11], ext[9], gcig[6];
+           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[9], gcig[6];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2];
     i64 last_seed_max_len = 0;         // longest read of that batch
@@ -69,8 +69,9 @@ struct meme_ctx {
                                        // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
+    i64 chain_light_hits = 64;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it
     i64 chain_lane_hits = 256;         // hits per read the lane-per-read chaining tier walks; reads with more go to the wavefront tiers at once
-    i64 chain_reg_tier = 1;            // 0: the chaining stage skips the register tier (everything beyond tier 1 through the B-tree tier; tests)
+    i64 chain_wave_tiers = 1;          // 0: the chaining stage skips the LDS tier (everything beyond the lane tier through the B-tree tier; tests)
     i64 bsw_blocks = 0;
     i64 bsw_lane_min_pairs = 32768;   // batches at least this big use the lane-per-pair kernel (throughput); smaller ones the
                                        // lanes-per-pair kernel (latency: a lone pair takes ~6 ms on one lane, ~0.3 ms on 64)
@@ -79,7 +80,8 @@ struct meme_ctx {
     hipEvent_t ev_chain[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_ext[2] = {nullptr, nullptr};
     hipEvent_t ev_gcig[2] = {nullptr, nullptr};
-    hipStream_t stream2 = nullptr;     // side stream: the heavy reads of the chaining tier run beside the light ones
+    hipStream_t stream_side[3] = {nullptr, nullptr, nullptr};   // the routed chaining tiers run beside the lane-per-read tier
+    hipEvent_t ev_side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_aux = nullptr;
     i64 chain_reads = 0, chain_tier2_reads = 0, chain_tier3_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
     meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

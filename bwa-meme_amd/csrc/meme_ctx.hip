@@ -105,7 +105,8 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (auto& e : ctx->ev_ext) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_gcig) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (auto& e : ctx->ev_side) if (e) (void)hipEventDestroy(e);
+    for (auto& st : ctx->stream_side) if (st) (void)hipStreamDestroy(st);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -130,8 +131,9 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
-    else if (!strcmp(key, "chain_reg_tier")) ctx->chain_reg_tier = value;
+    else if (!strcmp(key, "chain_wave_tiers")) ctx->chain_wave_tiers = value;
     else if (!strcmp(key, "chain_lane_hits")) ctx->chain_lane_hits = value;
+    else if (!strcmp(key, "chain_light_hits")) ctx->chain_light_hits = value;
     else if (!strcmp(key, "group_lanes")) {
         if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) { meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG; }
         ctx->group_lanes = value;

@@ -284,7 +284,7 @@ typedef struct {
     int64_t chain_tier2_reads, chain_tier3_reads;   /* reads beyond the lane-per-read tier; of which through the B-tree tier */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_reg_tier" */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits" */
 
 #ifdef __cplusplus
 }

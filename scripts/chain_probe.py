@@ -25,6 +25,7 @@ reads = workload.make_reads_fast(g, nreads, 150, seed=1000)
 off = np.arange(0, (nreads + 1) * 150, 150, dtype=np.int64)
 contigs = [(l_pac * k // 8, l_pac * (k + 1) // 8 - l_pac * k // 8, 0) for k in range(8)]
 opt = hipapi.default_chain_opt(l_pac)
+if os.environ.get("CHAIN_WAVE_TIERS"): ctx.set_tuning("chain_wave_tiers", int(os.environ["CHAIN_WAVE_TIERS"]))
 for it in range(3 if not os.environ.get("CHAIN_LANE_HITS") else 1):
     t0 = time.time(); smems, so, hits, ho = ctx.seed_batch_host(reads.reshape(-1), off); t1 = time.time()
     res = ctx.chain_last_batch_host(contigs, opt); t2 = time.time()
@@ -44,6 +45,17 @@ print("[chain probe] SMEMs per read: " + pct(ns))
 print("[chain probe] chains before the filter: " + pct(tree))
 for lim in (16, 32, 64, 128, 256, 1024):
     print("[chain probe] reads with more than %d chains: %d; with work > %d: %d" % (lim, int((tree > lim).sum()), lim * 8, int((work > lim * 8).sum())))
+try:                                    # investigation builds (-DMEME_CHAIN_PROF): cycles per phase of the wavefront tiers, all launches so far
+    import ctypes
+    f = hipapi.lib().meme_debug_chain_prof
+    buf = (ctypes.c_ulonglong * 32)()
+    if f(buf, 0) == 0:
+        names = ["", "", "", "", "", "", "", "",
+                 "lds: smem order", "lds: walk", "lds: records + rank", "lds: -", "lds: sort", "lds: filter", "lds: marks + output"]
+        for k, nm in enumerate(names):
+            if nm: print("[chain probe] phase %-22s %8.1f Mcycles" % (nm, buf[k] / 1e6))
+except AttributeError:
+    pass
 tm = ctx.timings()
 print("[chain probe] chain kernels %.2f ms, of which the wavefront tiers %.2f ms (%d reads), of which the B-tree tier %.2f ms (%d reads)"
       % (tm.chain_kernel_ms, tm.chain_pass2_ms, tm.chain_tier2_reads, tm.chain_tier3_ms, tm.chain_tier3_reads))

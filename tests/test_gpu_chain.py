@@ -13,8 +13,8 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(ctx, prefix, reads, reg_tier=1):
-    ctx.set_tuning("chain_reg_tier", reg_tier)
+def _run(ctx, prefix, reads, wave_tiers=1):
+    ctx.set_tuning("chain_wave_tiers", wave_tiers)
     off = np.zeros(len(reads) + 1, np.int64)
     off[1:] = np.cumsum([len(r) for r in reads])
     flat = np.concatenate(reads)
@@ -27,9 +27,9 @@ def _run(ctx, prefix, reads, reg_tier=1):
     return (smems, smem_off, hits, hit_off), res, l_pac, contigs
 
 
-@pytest.mark.parametrize("reg_tier", [1, 0])
-def test_device_chains_equal_reference_golden_and_oracle(tmp_path, reg_tier):
-    """reg_tier 1: repeat-rich reads go through the register tier (chains in the wavefront's registers), the B-tree tier takes what that
+@pytest.mark.parametrize("wave_tiers", [1, 0])
+def test_device_chains_equal_reference_golden_and_oracle(tmp_path, wave_tiers):
+    """wave_tiers 1: repeat-rich reads go through the LDS tier (one wavefront per read, chains in LDS), the B-tree tier takes what that
     leaves; 0: everything beyond the lane-per-read tier goes through the B-tree tier."""
     g, reads = chain_golden_workload()
     fa = str(tmp_path / "c.fa")
@@ -38,7 +38,7 @@ def test_device_chains_equal_reference_golden_and_oracle(tmp_path, reg_tier):
     G = np.load(os.path.join(GOLDEN, "chain_golden.npz"))
     ctx = hipapi.Context(0)
     try:
-        (smems, smem_off, hits, hit_off), R, l_pac, contigs = _run(ctx, prefix, reads, reg_tier)
+        (smems, smem_off, hits, hit_off), R, l_pac, contigs = _run(ctx, prefix, reads, wave_tiers)
     finally:
         ctx.close()
     n = len(reads)
