@@ -298,9 +298,12 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
     }
     const meme_seed_opt so = seed_opt_of(opt);
-    if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
     memset(&P.chains, 0, sizeof(P.chains));
     P.has_ext = false;
+    if (g_ext_on_device) {                               // seeds stay in HBM (nothing on the host reads them)
+        memset(&P.res, 0, sizeof(P.res));
+        if (meme_seed_batch_resident(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, nullptr, nullptr)) die("meme_seed_batch_resident");
+    } else if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
     if (g_ext_on_device && P.count > 0) {                // chains + extension where the seeds lie: only alignment records come back
         meme_chain_opt co;
         co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;

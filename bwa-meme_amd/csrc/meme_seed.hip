@@ -481,20 +481,24 @@ extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_ba
     return MEME_OK;
 }
 
-extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
-                                    const meme_seed_opt* opt, meme_seed_host_result* out) {
-    if (!ctx || !reads || !read_off || !out || nreads < 0) return MEME_E_ARG;
+// reads from the host into HBM + the seeding kernels; `out` (may be null) receives the results in the ctx's pinned buffers
+static int seed_host_reads(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads, const meme_seed_opt* opt, const char* who,
+                           meme_seed_host_result* out, int64_t* totals) {
+    if (!ctx || !reads || !read_off || nreads < 0) return MEME_E_ARG;
     int rc = check_opt(opt);
     if (rc) return rc;
-    if (!ctx->idx.sa) { meme_set_error("meme_seed_batch_host: no index loaded"); return MEME_E_STATE; }
+    if (!ctx->idx.sa) { meme_set_error("%s: no index loaded", who); return MEME_E_STATE; }
     HIP_TRY(hipSetDevice(ctx->device));
-    memset(out, 0, sizeof(*out));
-    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smem_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
-    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hit_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
-    out->smem_off = (const int64_t*)ctx->h_smem_off.p;
-    out->hit_off = (const int64_t*)ctx->h_hit_off.p;
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smem_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
+        if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hit_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
+        out->smem_off = (const int64_t*)ctx->h_smem_off.p;
+        out->hit_off = (const int64_t*)ctx->h_hit_off.p;
+    }
+    if (totals) totals[0] = totals[1] = 0;
     ctx->last_seed_reads = 0;
-    if (nreads == 0) { ((i64*)ctx->h_smem_off.p)[0] = 0; ((i64*)ctx->h_hit_off.p)[0] = 0; return MEME_OK; }
+    if (nreads == 0) { if (out) { ((i64*)ctx->h_smem_off.p)[0] = 0; ((i64*)ctx->h_hit_off.p)[0] = 0; } return MEME_OK; }
     if (read_off[0] != 0) { meme_set_error("read_off[0] must be 0"); return MEME_E_ARG; }
     const i64 bases = read_off[nreads];
     if ((rc = meme_buf_reserve(ctx, ctx->reads, (size_t)bases + 16))) return rc;
@@ -506,18 +510,36 @@ extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const i
     meme_seed_result res;
     rc = launch_seed(ctx, (const uint8_t*)ctx->reads.p, (const i64*)ctx->read_off.p, nreads, max_len, bases, opt, &res);
     if (rc) return rc;
-    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smems, (size_t)(res.total_smems + 1) * sizeof(meme_mem_tl)))) return rc;
-    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hits, (size_t)(res.total_hits + 1) * sizeof(u64)))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->h_smem_off.p, res.d_smem_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_hit_off.p, res.d_hit_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_smems.p, res.d_smems, (size_t)res.total_smems * sizeof(meme_mem_tl), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_hits.p, res.d_hits, (size_t)res.total_hits * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    out->smems = (const meme_mem_tl*)ctx->h_smems.p;
-    out->hits = (const uint64_t*)ctx->h_hits.p;
-    out->total_smems = res.total_smems;
-    out->total_hits = res.total_hits;
+    if (out) {
+        if ((rc = meme_hostbuf_reserve(ctx, ctx->h_smems, (size_t)(res.total_smems + 1) * sizeof(meme_mem_tl)))) return rc;
+        if ((rc = meme_hostbuf_reserve(ctx, ctx->h_hits, (size_t)(res.total_hits + 1) * sizeof(u64)))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->h_smem_off.p, res.d_smem_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_hit_off.p, res.d_hit_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_smems.p, res.d_smems, (size_t)res.total_smems * sizeof(meme_mem_tl), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_hits.p, res.d_hits, (size_t)res.total_hits * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        out->smems = (const meme_mem_tl*)ctx->h_smems.p;
+        out->hits = (const uint64_t*)ctx->h_hits.p;
+        out->total_smems = res.total_smems;
+        out->total_hits = res.total_hits;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));             // (the caller's read buffer is free again)
+    if (totals) { totals[0] = res.total_smems; totals[1] = res.total_hits; }
     ctx->last_seed_reads = nreads;
     ctx->last_seed_max_len = max_len;
     return MEME_OK;
+}
+
+extern "C" int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                                    const meme_seed_opt* opt, meme_seed_host_result* out) {
+    if (!out) return MEME_E_ARG;
+    return seed_host_reads(ctx, reads, read_off, nreads, opt, "meme_seed_batch_host", out, nullptr);
+}
+
+extern "C" int meme_seed_batch_resident(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                                        const meme_seed_opt* opt, int64_t* total_smems, int64_t* total_hits) {
+    int64_t tot[2] = {0, 0};
+    const int rc = seed_host_reads(ctx, reads, read_off, nreads, opt, "meme_seed_batch_resident", nullptr, tot);
+    if (total_smems) *total_smems = tot[0];
+    if (total_hits) *total_hits = tot[1];
+    return rc;
 }

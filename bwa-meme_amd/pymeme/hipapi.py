@@ -112,7 +112,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -271,6 +271,16 @@ class Context:
             return np.frombuffer(buf, dtype=dtype, count=count).copy()
         return (view(res.smems, res.total_smems, MEM_TL), view(res.smem_off, n + 1, np.int64),
                 view(res.hits, res.total_hits, np.uint64), view(res.hit_off, n + 1, np.int64))
+
+    def seed_batch_resident(self, reads, read_off, opt=None):
+        """meme_seed_batch_resident: SMEMs and hits stay in HBM for chain_last_batch_host / extend_last_batch_host; returns the totals."""
+        opt = opt or default_seed_opt()
+        reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        ts, th = C.c_int64(0), C.c_int64(0)
+        _check(lib().meme_seed_batch_resident(C.c_void_p(self.h), _p(reads), _p(read_off), C.c_int64(read_off.shape[0] - 1), C.byref(opt),
+                                              C.byref(ts), C.byref(th)))
+        return ts.value, th.value
 
     def seed_reserve(self, nreads, total_bases):
         _check(lib().meme_seed_reserve(C.c_void_p(self.h), C.c_int64(nreads), C.c_int64(total_bases)))

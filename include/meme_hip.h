@@ -164,6 +164,11 @@ typedef struct {
 int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
                          const meme_seed_opt* opt, meme_seed_host_result* out);
 
+/* Same, but SMEMs and hits stay in HBM for the calls that work on "the batch just seeded" (meme_chain_last_batch_host,
+ * meme_extend_last_batch_host): what a binding uses that only wants chains or alignment records back.  Only the totals return. */
+int meme_seed_batch_resident(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                             const meme_seed_opt* opt, int64_t* total_smems, int64_t* total_hits);
+
 /* Optional: allocate the workspaces and pinned result buffers of a meme_seed_batch_host() (+ meme_chain_last_batch_host()) call of
  * this size ahead of time, e.g. on a helper thread while the index loads (pinned memory is slow to allocate). */
 int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_bases);

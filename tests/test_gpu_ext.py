@@ -19,7 +19,7 @@ def _device_records(tmp_path, I, ext_opt=None):
     ctx = hipapi.Context(0)
     try:
         ctx.load_index_files(prefix)
-        ctx.seed_batch_host(I["reads"], I["read_off"])
+        ctx.seed_batch_resident(I["reads"], I["read_off"])
         contigs = [(int(o), int(l), 0) for o, l in zip(I["contig_off"], I["contig_len"])]
         return ctx.extend_last_batch_host(contigs, hipapi.default_chain_opt(I["l_pac"]), ext_opt)
     finally:
