@@ -259,11 +259,11 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
 // the lanes of a vector finish together: sortPairsLenExt, src/bwamem.cpp:2430-2527), at wavefront width: each of the 64
 // lanes runs scalarBandedSWA on its own pair.  No cross-lane traffic at all; per DP cell a lane issues one LDS read,
 // one LDS write and ~16 integer ops.  The row state {H(i-1,j-1), E(i,j)} and the query base of column j share one
-// 32-bit LDS word (14 + 14 + 3 bits), laid out [column][lane] so every access is bank-conflict free whatever column
+// 32-bit LDS word (query code in the low byte, then 12 + 12 bits), laid out [column][lane] so every access is bank-conflict free whatever column
 // each lane is at.  Pairs whose scores could exceed 14 bits or whose query exceeds LANE_QMAX go to the
 // lanes-per-pair kernel above.
 constexpr int LANE_QMAX = 600;
-constexpr int LANE_SCORE_LIMIT = 1 << 14;
+constexpr int LANE_SCORE_LIMIT = 1 << 12;
 constexpr int N_LANE_CLS = 8;                                        // LDS = (q + 2) * 256 B per wavefront: 8 KB ... 150 KB
 constexpr int LANE_CLS_Q[N_LANE_CLS] = {30, 62, 94, 126, 158, 222, 318, LANE_QMAX};
 constexpr int TL_BUCKETS = 8;                                        // sub-key: (target length - query length) / 8
@@ -283,7 +283,15 @@ struct LaneArgs {
     int key_first, key_last;
 };
 
-__device__ __forceinline__ unsigned he_pack(int h, int e, unsigned qbits) { return (unsigned)h | ((unsigned)e << 14) | qbits; }
+__device__ __forceinline__ unsigned he_pack(int h, int e, unsigned qbits) { return ((unsigned)h << 8) | ((unsigned)e << 20) | qbits; }
+// the same for the inner loop, two instructions: (e << 12 | h), then its three low bytes above the low byte of the old word
+__device__ __forceinline__ unsigned he_repack(int h, int e, unsigned old) {
+    unsigned x, w;
+    asm("v_lshl_or_b32 %0, %1, 12, %2" : "=v"(x) : "v"(e), "v"(h));
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(w) : "v"(x), "v"(old), "s"(0x06050400u));
+    return w;
+}
+__device__ __forceinline__ int max3_i32(int a, int b, int c) { int d; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned int he_raw[];
@@ -293,7 +301,7 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
     const int o_del = A.o.o_del, e_del = A.o.e_del, o_ins = A.o.o_ins, e_ins = A.o.e_ins;
     const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = A.o.zdrop;
     const int sa = A.o.a, sb = -A.o.b;
-    constexpr unsigned HE_MASK = (1u << 28) - 1u, QMASK = 7u << 28;
+    constexpr unsigned HE_MASK = 0xffffff00u, QMASK = 0xffu;
     if (A.offs) { A.first = A.offs[A.key_first]; A.count = A.offs[A.key_last] - A.first; }
     for (;;) {
         unsigned int tk = 0;
@@ -321,7 +329,7 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
                     if (j == 0) v = h0;
                     else if (j == 1) v = first;
                     else { const int prev = first - (j - 2) * e_ins; v = prev > e_ins ? prev - e_ins : 0; }
-                    he[j * 64] = he_pack(v, 0, (qb[u] > 4u ? 4u : qb[u]) << 28);
+                    he[j * 64] = he_pack(v, 0, qb[u] > 4u ? 4u : qb[u]);
                 }
             }
         }
@@ -348,45 +356,51 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
             if (end > qlen) end = qlen;
             if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
             else h1 = 0;
-            const int s_eq = tb > 3 ? -1 : sa, s_ne = tb > 3 ? -1 : sb;
+            // the row's substitution scores as a byte table indexed by the query code (v_perm_b32 picks byte q of {hi, lo}): codes 0..3 in
+            // tab_lo (the target base's own slot holds the match score), code 4 = N in byte 0 of tab_hi; a row on an N scores -1 throughout
+            const unsigned sb4 = (unsigned)(sb & 0xff) * 0x01010101u;
+            const unsigned tab_lo = tb > 3 ? 0xffffffffu : (sb4 & ~(0xffu << (8 * tb))) | ((unsigned)(sa & 0xff) << (8 * tb));
+            const unsigned tab_hi = 0xffffffffu;
             // Four cells per trip with rotating registers for the column state: the next column's LDS word is
             // requested before the current cell is computed and first touched a whole cell later (a single rotating
-            // register made the compiler wait for the prefetch in the middle of the cell).
-#define BSW_CELL(cur_, nxt_, j_)                                                                              \
+            // register made the compiler wait for the prefetch in the middle of the cell).  The row maximum and its rightmost
+            // column travel as one key (h << 10 | column), one accumulator per unrolled position (mk_ + its position, joined below).
+#define BSW_CELL(cur_, nxt_, j_, mk_, jb_)                                                                    \
             {                                                                                                  \
                 nxt_ = he[((j_) + 1) * 64];                    /* (j+1 <= qlen: inside the row) */              \
-                int M = (int)(cur_ & 0x3fffu), e = (int)((cur_ >> 14) & 0x3fffu);                               \
-                const int qb = (int)(cur_ >> 28);                                                              \
-                const int sc = qb > 3 ? -1 : (qb == tb ? s_eq : s_ne);                                         \
+                int M = (int)((cur_ >> 8) & 0xfffu), e = (int)(cur_ >> 20);                                     \
+                /* (selector byte 0 = the query code; the other result bytes are not looked at) */             \
+                const int sc = (int)(signed char)(__builtin_amdgcn_perm(tab_hi, tab_lo, cur_) & 0xffu);         \
                 M = M ? M + sc : 0;                            /* :184 */                                      \
-                int h = M > e ? M : e;                                                                         \
-                h = h > f ? h : f;                                                                             \
-                mj = m > h ? mj : (j_);                        /* rightmost column among equal maxima */       \
-                m = m > h ? m : h;                                                                             \
-                int t = M - oe_del;                                                                            \
-                t = t > 0 ? t : 0;                                                                             \
-                e -= e_del;                                                                                    \
-                e = e > t ? e : t;                             /* E(i+1,j) (:190-194) */                       \
-                he[(j_) * 64] = he_pack(h1, e, cur_ & QMASK);  /* H(i,j-1) for the next row (:183) */          \
+                const int h = max3_i32(M, e, f);                                                               \
+                const int key = (h << 10) + (jb_);                                                             \
+                mk_ = mk_ > key ? mk_ : key;                   /* rightmost column among equal maxima */       \
+                e = max3_i32(M - oe_del, e - e_del, 0);        /* E(i+1,j) (:190-194) */                       \
+                he[(j_) * 64] = he_repack(h1, e, cur_);        /* H(i,j-1) for the next row (:183) */          \
                 h1 = h;                                                                                        \
-                t = M - oe_ins;                                                                                \
-                t = t > 0 ? t : 0;                                                                             \
-                f -= e_ins;                                                                                    \
-                f = f > t ? f : t;                             /* F(i,j+1) (:195-198) */                       \
+                f = max3_i32(M - oe_ins, f - e_ins, 0);        /* F(i,j+1) (:195-198) */                       \
             }
             unsigned wa = beg < end ? he[beg * 64] : 0u, wb = 0u, wc = 0u, wd = 0u;
+            int mk0 = -8, mk1 = -8, mk2 = -8, mk3 = -8;
             int j = beg;
             for (; j + 3 < end; j += 4) {
-                BSW_CELL(wa, wb, j)
-                BSW_CELL(wb, wc, j + 1)
-                BSW_CELL(wc, wd, j + 2)
-                BSW_CELL(wd, wa, j + 3)
+                BSW_CELL(wa, wb, j, mk0, j)
+                BSW_CELL(wb, wc, j + 1, mk1, j)
+                BSW_CELL(wc, wd, j + 2, mk2, j)
+                BSW_CELL(wd, wa, j + 3, mk3, j)
             }
             for (; j < end; ++j) {
-                BSW_CELL(wa, wb, j)
+                BSW_CELL(wa, wb, j, mk0, j)
                 wa = wb;
             }
 #undef BSW_CELL
+            {
+                mk1 += 1; mk2 += 2; mk3 += 3;
+                const int ka = mk0 > mk1 ? mk0 : mk1, kb = mk2 > mk3 ? mk2 : mk3;
+                const int key = ka > kb ? ka : kb;
+                m = key < 0 ? 0 : key >> 10;
+                mj = key < 0 ? -1 : key & 1023;
+            }
             he[end * 64] = he_pack(h1, 0, he[end * 64] & QMASK);    // :201
             if ((beg < end ? end : beg) == qlen) {             // "if (j == qlen)" after the column loop, :202-205
                 max_ie = gscore > h1 ? max_ie : i;
@@ -542,7 +556,8 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
     HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
     // big batches: one pair per lane (throughput).  Small batches (the reference's 512-read call granularity): 16-64
     // lanes per pair, because a lone pair on one lane takes milliseconds.
-    const bool use_lane = (i64)npairs >= ctx->bsw_lane_min_pairs;
+    // (the lane kernel keeps a row's substitution scores as signed bytes)
+    const bool use_lane = (i64)npairs >= ctx->bsw_lane_min_pairs && opt->a >= 0 && opt->a <= 127 && opt->b >= 0 && opt->b <= 128;
     const int key_a = use_lane ? (opt->a > 0 ? opt->a : 0) : -1;
     {
         i64 sblocks = ((i64)npairs + 255) / 256;
