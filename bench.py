@@ -46,7 +46,7 @@ import torch.distributed as dist  # noqa: E402
 from pymeme import hipapi, hostapi, synth, workload  # noqa: E402
 
 READ_LEN = 150
-BSW_VALU_PER_CELL = 33.6     # measured: profiles/r02_bsw.md (SQ_INSTS_VALU x 64 lanes / DP cells of 2 M distinct pairs, a committed PMC pass)
+BSW_VALU_PER_CELL = 24.5     # measured: profiles/r03_bsw.md (SQ_INSTS_VALU x 64 lanes / DP cells of 2 M distinct pairs, a committed PMC pass)
 T_START = time.time()
 
 
@@ -233,6 +233,44 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
     return out
 
 
+def bsw_reference_baseline(pairs, ref, qer, w, cores):
+    """The reference's own AVX-512 kernels (BandedPairWiseSW::getScores8 / getScores16 behind oracle/_ref/libbsw_ref.so) on all host
+    cores: pairs classed the way mem_chain2aln_across_reads_V2 classes them (src/bwamem.cpp:2452: both lengths < 128 and
+    h0 + min(len) * a < 128 -> int8 lanes, else int16), each class sorted by query length like sortPairsLenExt so the SIMD lanes fill,
+    512-pair calls spread over a thread pool (ctypes releases the GIL).  None when the compiled reference is not there."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_py, ref_py
+    if not (ref_py.have("libbsw_ref.so") and ref_py.cpu_can_run()):
+        return None
+    L = ref_py.bsw_lib()
+    par = oracle_py.default_bsw_params()
+    refp = np.concatenate([np.ascontiguousarray(ref, dtype=np.uint8), np.zeros(1 << 16, np.uint8)])
+    qerp = np.concatenate([np.ascontiguousarray(qer, dtype=np.uint8), np.zeros(1 << 16, np.uint8)])
+    P = pairs.view(oracle_py.SEQPAIR_DTYPE)
+    small = (P["len1"] < 128) & (P["len2"] < 128) & (P["h0"] + np.minimum(P["len1"], P["len2"]) * par.a < 128)
+    jobs = []
+    for kind, idx in ((8, np.nonzero(small)[0]), (16, np.nonzero(~small)[0])):
+        idx = idx[np.argsort(P["len2"][idx], kind="stable")]
+        for b in range(0, idx.shape[0], 512):
+            sub = np.zeros(min(512, idx.shape[0] - b) + 128, dtype=oracle_py.SEQPAIR_DTYPE)    # (the SIMD wrappers pad past numPairs)
+            sub[:-128] = P[idx[b:b + 512]]
+            jobs.append((kind, sub, idx[b:b + 512]))
+    def run(j):
+        kind, sub, _ = j
+        return L.ref_bsw_run(C.c_int(kind), C.c_void_p(sub.ctypes.data), C.c_void_p(refp.ctypes.data), C.c_void_p(qerp.ctypes.data),
+                             C.c_int32(sub.shape[0] - 128), C.c_int32(w), C.byref(par))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        rcs = list(ex.map(run, jobs))
+    dt = time.perf_counter() - t0
+    assert all(r == 0 for r in rcs)
+    out = P.copy()
+    for kind, sub, idx in jobs:
+        out[idx] = sub[:-128]
+    return dt, out, int(small.sum())
+
+
 def bsw_leg(ctx, dev, world):
     """Second kernel of the path: banded seed extension on rank 0's GPU, pairs resident in HBM.
     Every pair is distinct (no tiling): lengths, targets and errors differ from pair to pair as in a real batch, so the
@@ -264,16 +302,25 @@ def bsw_leg(ctx, dev, world):
     same = all(np.array_equal(got[f], chk[f]) for f in ("score", "tle", "gtle", "qle", "gscore", "max_off"))
     cells_per_pair = cells / ns
     gcups = cells_per_pair * npairs / (k_ms * 1e-3) / 1e9
+    cpu = {"value": ns / cpu_dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d pairs, scalar restatement of scalarBandedSWA on %d threads" % (ns, cores)}
+    rb = bsw_reference_baseline(pairs[:ns].copy(), ref, qer, 100, cores)
+    if rb is not None:
+        r_dt, r_out, n8 = rb
+        r_same = all(np.array_equal(got[f], r_out[f]) for f in ("score", "tle", "gtle", "qle", "gscore", "max_off"))
+        cpu = {"value": ns / r_dt, "unit": "pairs/s", "cores": cores, "kind": "reference",
+               "sample": "%d pairs: BandedPairWiseSW::getScores8 (%d pairs) / getScores16 (%d pairs) of the AVX-512 build, classed and length-sorted as in "
+                         "mem_chain2aln_across_reads_V2, 512-pair calls on %d threads" % (ns, n8, ns - n8, cores),
+               "device_matches_reference": bool(r_same), "port": cpu}
     return {"metric": "bsw_pairs_per_sec", "value": npairs / (k_ms * 1e-3), "unit": "pairs/s", "per": "gpu",
             "pairs": npairs, "distinct_pairs": npairs, "band_w": 100, "kernel_ms": k_ms, "cells_per_pair": cells_per_pair,
             "gcups": gcups, "matches_oracle": bool(same), "checked_pairs": ns,
             # integer-VALU roofline of the lane-per-pair kernel: VALU instructions per DP cell from the committed counter pass
-            # (profiles/r02_bsw.md, SQ_INSTS_VALU / cells), against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz int32 lane-ops/s
+            # (profiles/r03_bsw.md, SQ_INSTS_VALU / cells), against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz int32 lane-ops/s
             "roofline": {"bound": "valu-int32", "peak": 39.3, "unit": "Tops/s", "ops_per_cell": BSW_VALU_PER_CELL,
-                         "ops_per_cell_source": "SQ_INSTS_VALU x 64 lanes / DP cells, profiles/r02_bsw.md",
+                         "ops_per_cell_source": "SQ_INSTS_VALU x 64 lanes / DP cells, profiles/r03_bsw.md",
                          "achieved": BSW_VALU_PER_CELL * gcups / 1e3, "frac": BSW_VALU_PER_CELL * gcups / 1e3 / 39.3},
-            "cpu_baseline": {"value": ns / cpu_dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-                             "sample": "%d pairs, scalar restatement of scalarBandedSWA on %d threads" % (ns, cores)}}
+            "cpu_baseline": cpu}
 
 
 def sam_md5(path):
