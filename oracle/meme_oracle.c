@@ -1144,3 +1144,139 @@ int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* tar
     free(eh_h); free(eh_e); free(z);
     return score;
 }
+
+/* ---- mate-rescue Smith-Waterman of the SAM phase (kswv, reference src/kswv.cpp; driver mem_sam_pe_batch, src/bwamem_pair.cpp:719-818) --------
+ * The reference runs 64 (int8) or 32 (int16) pairs per AVX-512 vector, one pair per SIMD lane; what one lane computes does not depend on
+ * its neighbours (padding rows / columns never hold a row maximum; the cross-lane loop bounds maxl / minh / limit only widen ranges that
+ * per-lane masks cut back), so this is the per-lane arithmetic, literally:
+ *  - local alignment, E along the query and F along the target, both opened from H (MAIN_SAM_CODE8_OPT / 16_OPT, :60-107); int8 lanes
+ *    are unsigned bytes biased by `shift` with saturating adds / subs, int16 lanes plain signed arithmetic;
+ *  - the query is padded to the SSE2 stripe of bwa's ksw_u8 / ksw_i16 (16 / 8 columns) with a base that scores 0 against everything
+ *    (:296-310, :872-887) -- those columns can hold a row's maximum (never the global one) and so shape score2;
+ *  - per row i the maximum and its first column; rowMax[i] keeps it only for rows that are local peaks of that sequence, reach the
+ *    KSW_XSUBO threshold and precede the lane's stop (Block I, :505-518 / :1063-1078);
+ *  - the global maximum moves only on a strictly larger row maximum (Block II); KSW_XSTOP and, for int8, saturation stop the lane;
+ *  - score2 / te2: the largest kept row maximum (first row on ties) outside te +- ceil(score / match) (:594-646 / :1141-1183);
+ *  - second pass for KSW_XSTART (bwamem_pair.cpp:768-808): the prefixes query[0..qe], target[0..te] reversed in place, target length
+ *    unchanged, KSW_XSTOP | score; tb / qb are set when that pass reaches the same score. */
+#define KSW_XBYTE_ 0x10000
+#define KSW_XSTOP_ 0x20000
+#define KSW_XSUBO_ 0x40000
+#define KSW_XSTART_ 0x80000
+
+typedef struct { int score, te, qe, score2, te2; } kswv_fwd;
+
+static void kswv_pass(int is8, const uint8_t* t, int tlen, const uint8_t* q, int qlen, int xtra, int want2, int a, int b, int o_del, int e_del, int o_ins,
+                      int e_ins, kswv_fwd* out, int* raw_score, int64_t* cells) {
+    const int w_match = a, w_mismatch = -b, w_ambig = -1;
+    int mn = w_match < w_mismatch ? w_match : w_mismatch;
+    mn = mn < w_ambig ? mn : w_ambig;
+    const int shift = is8 ? (256 - (mn & 0xff)) & 0xff : 0;                 /* :398-405 */
+    int qmax = w_match > w_mismatch ? w_match : w_mismatch;
+    qmax = qmax > w_ambig ? qmax : w_ambig;                                 /* g_qmax, :131-132 */
+    const int none = is8 ? 0 : -1;
+    const int quanta = is8 ? (qlen + 15) / 16 * 16 : (qlen + 7) / 8 * 8;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins;
+    int v = (xtra & KSW_XSUBO_) ? (xtra & 0xffff) : 0x10000;
+    const int has_minsc = v <= (is8 ? 255 : 32767), minsc = v;
+    v = (xtra & KSW_XSTOP_) ? (xtra & 0xffff) : 0x10000;
+    const int has_endsc = v <= (is8 ? 255 : 32767), endsc = v;
+    int* H0 = (int*)calloc((size_t)quanta + 2, sizeof(int));
+    int* H1 = (int*)calloc((size_t)quanta + 2, sizeof(int));
+    int* F = (int*)calloc((size_t)quanta + 2, sizeof(int));
+    int* rowMax = (int*)malloc(((size_t)tlen + 1) * sizeof(int));
+    int gmax = 0, te = -1, qe = 0, pimax = 0, mask = 0, minsc_ok = 0, exited = 0, rows = 0;
+    for (int i = 0; i < tlen; ++i) {
+        int e = 0, imax = 0, iqe = -1;
+        const int tb = t[i];
+        for (int j = 0; j < quanta; ++j) {
+            int sc, m, h;
+            if (j >= qlen) sc = 0;
+            else if (tb > 3 || q[j] > 3) sc = w_ambig;
+            else sc = tb == q[j] ? w_match : w_mismatch;
+            if (is8) {
+                m = H0[j] + sc + shift;
+                m = m > 255 ? 255 : m;
+                m -= shift;
+                m = m < 0 ? 0 : m;
+                h = m > e ? m : e;
+                h = h > F[j + 1] ? h : F[j + 1];
+            } else {
+                m = H0[j] + sc;
+                h = m > e ? m : e;
+                h = h > F[j + 1] ? h : F[j + 1];
+                h = h > 0 ? h : 0;
+            }
+            if (h > imax) { imax = h; iqe = j; }
+            H1[j + 1] = h;
+            int g = h - oe_ins, e2 = e - e_ins, d = h - oe_del, f2 = F[j + 1] - e_del;
+            if (is8) { g = g < 0 ? 0 : g; e2 = e2 < 0 ? 0 : e2; d = d < 0 ? 0 : d; f2 = f2 < 0 ? 0 : f2; }
+            e = g > e2 ? g : e2;
+            F[j + 1] = d > f2 ? d : f2;
+        }
+        ++rows;
+        if (i > 0) {                                                        /* Block I */
+            const int msk = (imax > pimax) || mask;
+            rowMax[i - 1] = (!msk && minsc_ok && !exited) ? pimax : none;
+            mask = !msk;
+        }
+        pimax = imax;
+        minsc_ok = has_minsc && imax >= minsc;
+        if (imax > gmax && !exited) { gmax = imax; te = i; qe = is8 ? (iqe & 0xff) : iqe; }   /* Block II */
+        if ((has_endsc && gmax >= endsc) || (is8 && gmax + shift >= 255)) exited = 1;
+        { int* s = H1; H1 = H0; H0 = s; }
+        H0[0] = 0;
+        if (exited) {                                                       /* the lane is frozen: later rows keep nothing */
+            for (int r = i; r < tlen; ++r) rowMax[r] = none;
+            break;
+        }
+    }
+    if (!exited && tlen > 0) rowMax[tlen - 1] = (!mask && minsc_ok) ? pimax : none;
+    *raw_score = gmax;
+    out->score = is8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+    out->te = te; out->qe = qe; out->score2 = -1; out->te2 = -1;
+    if (want2 && !(is8 && out->score == 255)) {
+        const int val = (gmax + qmax - 1) / qmax, low = te - val, high = te + val;
+        int mx = none, t2 = -1;
+        for (int i = 0; i < low; ++i) if (rowMax[i] > mx) { mx = rowMax[i]; t2 = i; }
+        for (int i = high + 1; i < tlen; ++i) if (i > high && rowMax[i] > mx) { mx = rowMax[i]; t2 = i; }
+        out->score2 = is8 ? (mx == 0 ? -1 : mx) : mx;
+        out->te2 = t2;
+    }
+    if (cells) *cells += (int64_t)rows * quanta;
+    free(H0); free(H1); free(F); free(rowMax);
+}
+
+void orc_kswv_pair(const uint8_t* target, int tlen, const uint8_t* query, int qlen, int xtra, int a, int b, int o_del, int e_del, int o_ins, int e_ins,
+                   orc_kswr* r, int64_t* cells) {
+    const int is8 = (xtra & KSW_XBYTE_) != 0;                               /* sort_classify, src/bwamem.cpp:1798-1825 */
+    kswv_fwd f;
+    int raw = 0;
+    kswv_pass(is8, target, tlen, query, qlen, xtra, 1, a, b, o_del, e_del, o_ins, e_ins, &f, &raw, cells);
+    r->score = f.score; r->te = f.te; r->qe = f.qe; r->score2 = f.score2; r->te2 = f.te2; r->tb = -1; r->qb = -1;
+    if ((xtra & KSW_XSTART_) == 0 || ((xtra & KSW_XSUBO_) && r->score < (xtra & 0xffff))) return;   /* bwamem_pair.cpp:775, :793 */
+    const int ql2 = r->qe + 1, tl_rev = r->te + 1;
+    uint8_t* q2 = (uint8_t*)malloc((size_t)(ql2 > 0 ? ql2 : 1));
+    uint8_t* t2 = (uint8_t*)malloc((size_t)(tlen > 0 ? tlen : 1));
+    for (int k = 0; k < ql2; ++k) q2[k] = query[ql2 - 1 - k];
+    memcpy(t2, target, (size_t)tlen);
+    for (int k = 0; k < tl_rev; ++k) t2[k] = target[tl_rev - 1 - k];
+    kswv_fwd g;
+    kswv_pass(is8, t2, tlen, q2, ql2, KSW_XSTOP_ | r->score, 0, a, b, o_del, e_del, o_ins, e_ins, &g, &raw, cells);
+    if (r->score == raw) { r->tb = r->te - g.te; r->qb = r->qe - g.qe; }
+    free(q2); free(t2);
+}
+
+int orc_kswv_batch(const orc_kswv_job* jobs, int64_t n, const uint8_t* ref, const uint8_t* qer, int a, int b, int o_del, int e_del, int o_ins, int e_ins,
+                   orc_kswr* out, int threads, int64_t* cells) {
+    int64_t total = 0;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+ : total)
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t c = 0;
+        orc_kswv_pair(ref + jobs[i].idr, jobs[i].len1, qer + jobs[i].idq, jobs[i].len2, jobs[i].xtra, a, b, o_del, e_del, o_ins, e_ins, &out[i], &c);
+        total += c;
+    }
+    if (cells) *cells = total;
+    return 0;
+}

@@ -123,6 +123,15 @@ int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nrea
 int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w,
                     int* n_cigar, uint32_t* cigar /* capacity qlen + tlen + 2 */);
 
+/* ---- mate-rescue Smith-Waterman of the SAM phase (kswv::getScores8 / getScores16 as driven by mem_sam_pe_batch; reference
+ * src/kswv.cpp:372-712, 934-1199, src/bwamem_pair.cpp:719-818): forward pass, second-best score, reverse pass for the start ---------- */
+typedef struct { int64_t idr, idq; int32_t len1 /* target */, len2 /* query */, xtra /* SeqPair.h0: KSW_X* flags | threshold */, pad; } orc_kswv_job;
+typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } orc_kswr;          /* kswr_t, src/ksw.h:44-50 */
+void orc_kswv_pair(const uint8_t* target, int tlen, const uint8_t* query, int qlen, int xtra, int a, int b, int o_del, int e_del, int o_ins, int e_ins,
+                   orc_kswr* r, int64_t* cells);
+int orc_kswv_batch(const orc_kswv_job* jobs, int64_t n, const uint8_t* ref, const uint8_t* qer, int a, int b, int o_del, int e_del, int o_ins, int e_ins,
+                   orc_kswr* out, int threads, int64_t* cells);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,8 @@
 //                       (klib B-tree src/kbtree.h, ks_introsort src/ksort.h included -- whatever they do with equal keys)
 //   ref_extend_reads    mem_chain2aln_across_reads_V2()                    reference src/bwamem.cpp:2573-3497
 //                       with the reference's own BandedPairWiseSW kernels
+//   ref_kswv_batch      sort_classify() + mem_sam_pe_batch()                reference src/bwamem.cpp:1798-1825, src/bwamem_pair.cpp:719-818
+//                       (the AVX-512 mate-rescue kernels kswv::getScores8 / getScores16, src/kswv.cpp)
 //   ref_gen_cigar       bwa_gen_cigar2()                                   reference src/bwa.cpp:274-362 (ksw_global2, src/ksw.cpp:560-670)
 //
 // Linked against oracle/_ref/libbwa_pic.so (the reference's objects, built where the sources lie by oracle/Makefile.ref) into
@@ -27,6 +29,7 @@ uint64_t proc_freq = 1, tprof[LIM_R][LIM_C];
 void mem_chain_Learned(const mem_opt_t* opt, const bntseq_t* bns, int len, mem_tlv* smems, mem_chain_v* chain, int seqid, u64v* hits,
                        mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid);
 int mem_chain_flt(const mem_opt_t* opt, int n_chn_, mem_chain_t* a_, int tid);
+int64_t sort_classify(mem_cache* mmc, int64_t pcnt, int tid);
 
 #define shim_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
 KSORT_INIT(shim_smem, mem_tl, shim_smem_lt)
@@ -203,6 +206,54 @@ int ref_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* tar
     free(cg);
     *n_cigar = n;
     return score;
+}
+
+
+// ---- the mate-rescue Smith-Waterman batch exactly as worker_sam runs it (src/bwamem.cpp:1871-1877) --------------------------------------
+// jobs: idr / idq offsets into ref / qer, len1 (target), len2 (query), xtra (SeqPair.h0).  out[i] = kswr_t of job i.
+struct shim_kswv_job { int64_t idr, idq; int32_t len1, len2, xtra, pad; };
+int ref_kswv_batch(const shim_kswv_job* jobs, int64_t n, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer, int64_t qer_bytes, int a, int b, int o_del,
+                   int e_del, int o_ins, int e_ins, int32_t* out /* n x 7 */) {
+#if __AVX512BW__
+    mem_opt_t* opt = mem_opt_init();
+    opt->a = a; opt->b = b; opt->o_del = o_del; opt->e_del = e_del; opt->o_ins = o_ins; opt->e_ins = e_ins;
+    bwa_fill_scmat(a, b, opt->mat);
+    mem_cache* mmc = (mem_cache*)calloc(1, sizeof(mem_cache));
+    const size_t cap = (size_t)n + 2 * MAX_LINE_LEN + 128;
+    mmc->seqPairArrayLeft128[0] = (SeqPair*)calloc(cap, sizeof(SeqPair));
+    mmc->seqPairArrayRight128[0] = (SeqPair*)calloc(cap, sizeof(SeqPair));
+    mmc->seqPairArrayAux[0] = (SeqPair*)calloc(cap, sizeof(SeqPair));
+    uint8_t* r = (uint8_t*)_mm_malloc((size_t)ref_bytes + 4096, 64);
+    uint8_t* q = (uint8_t*)_mm_malloc((size_t)qer_bytes + 4096, 64);
+    memcpy(r, ref, (size_t)ref_bytes); memset(r + ref_bytes, 0, 4096);     // (the batch reverses prefixes in place)
+    memcpy(q, qer, (size_t)qer_bytes); memset(q + qer_bytes, 0, 4096);
+    mmc->seqBufLeftRef[0] = r; mmc->seqBufLeftQer[0] = q;
+    mmc->wsize[0] = (int64_t)cap; mmc->wsize_buf_ref[0] = ref_bytes + 4096; mmc->wsize_buf_qer[0] = qer_bytes + 4096;
+    int32_t maxRef = 0, maxQer = 0;
+    SeqPair* sp = mmc->seqPairArrayLeft128[0];
+    for (int64_t i = 0; i < n; ++i) {
+        SeqPair p;
+        memset(&p, 0xff, sizeof(p));
+        p.idr = (int32_t)jobs[i].idr; p.idq = (int32_t)jobs[i].idq; p.len1 = jobs[i].len1; p.len2 = jobs[i].len2; p.h0 = jobs[i].xtra; p.regid = (int)i;
+        sp[i] = p;
+        maxRef = maxRef > p.len1 ? maxRef : p.len1; maxQer = maxQer > p.len2 ? maxQer : p.len2;
+    }
+    int64_t pcnt = n;
+    int64_t pcnt8 = sort_classify(mmc, pcnt, 0);
+    kswr_t* aln = (kswr_t*)_mm_malloc((size_t)(pcnt + SIMD_WIDTH8) * sizeof(kswr_t), 64);
+    mem_sam_pe_batch(opt, mmc, pcnt, pcnt8, aln, maxRef, maxQer, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t* o = out + 7 * i;
+        o[0] = aln[i].score; o[1] = aln[i].te; o[2] = aln[i].qe; o[3] = aln[i].score2; o[4] = aln[i].te2; o[5] = aln[i].tb; o[6] = aln[i].qb;
+    }
+    _mm_free(aln); _mm_free(r); _mm_free(q);
+    free(mmc->seqPairArrayLeft128[0]); free(mmc->seqPairArrayRight128[0]); free(mmc->seqPairArrayAux[0]);
+    free(mmc); free(opt);
+    return 0;
+#else
+    (void)jobs; (void)n; (void)ref; (void)ref_bytes; (void)qer; (void)qer_bytes; (void)a; (void)b; (void)o_del; (void)e_del; (void)o_ins; (void)e_ins; (void)out;
+    return -1;          // the batched kernels only exist in the AVX-512 build (src/bwamem.cpp:1838: other builds run mem_sam_pe / ksw_align2)
+#endif
 }
 
 }  // extern "C"

@@ -175,3 +175,68 @@ def gcig_workload(n=3000, seed=77):
             q, t = read[qb:qe], text[rb:rb + tl]
             seqs.append((q[::-1].copy(), t[::-1].copy()) if rev else (q.copy(), t.copy()))
     return g, reads, np.array(jobs, dtype=hipapi.GJOB), seqs
+
+
+def kswv_workload(n=2000, seed=91, read_len=(60, 251), a=1, min_seed_len=19):
+    """Mate-rescue jobs the way mem_matesw_batch_pre (src/bwamem_pair.cpp:1060-1223) poses them: a read (or its reverse complement) against a
+    window of the genome of a few hundred bases that mostly contains its origin -- with substitutions, indels, an occasional N, windows
+    that contain the read twice (tandem copies: the second-best score matters), windows that miss it, reads hanging over a window edge.
+    xtra = KSW_XSUBO | KSW_XSTART | (len * a < 250 ? KSW_XBYTE : 0) | min_seed_len * a.  Returns (jobs KSWV_JOB_DTYPE, ref bytes, query bytes)."""
+    from oracle_py import KSWV_JOB_DTYPE, KSW_XBYTE, KSW_XSUBO, KSW_XSTART
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=400_000, dtype=np.uint8)
+    jobs = np.zeros(n, KSWV_JOB_DTYPE)
+    refs, qers = [], []
+    ro = qo = 0
+    for k in range(n):
+        L = int(rng.integers(read_len[0], read_len[1]))
+        W = int(rng.integers(max(L // 2, min_seed_len), 900))
+        p = int(rng.integers(0, g.shape[0] - 2000))
+        win = g[p:p + W].copy()
+        kind = k % 8
+        off = int(rng.integers(0, max(1, W - L))) if W > L else 0
+        if kind == 5:                                              # the read hangs over the window's edge
+            off = max(0, W - L // 2)
+        src = g[p + off:p + off + L + 40]
+        out, i = [], 0
+        rs, ri = (0.0, 0.0) if kind == 0 else (float(rng.choice([0.01, 0.03, 0.08])), float(rng.choice([0.0, 0.004, 0.02])))
+        while len(out) < L:
+            u = rng.random()
+            if u < ri / 2:
+                out += list(rng.integers(0, 4, size=int(rng.integers(1, 12))))
+            elif u < ri:
+                i += int(rng.integers(1, 12))
+            else:
+                c = int(src[min(i, src.shape[0] - 1)])
+                if rng.random() < rs:
+                    c = (c + int(rng.integers(1, 4))) & 3
+                out.append(c); i += 1
+        q = np.array(out[:L], np.uint8)
+        if kind == 3:                                              # unrelated read: low scores, nothing above the threshold
+            q = rng.integers(0, 4, size=L, dtype=np.uint8)
+        if kind == 4 and W > 2 * L + 20:                           # a second, slightly worse copy of the origin further down the window
+            cp = g[p + off:p + off + L].copy()
+            m = rng.random(L) < 0.04
+            cp[m] = (cp[m] + 1) & 3
+            win[W - L - 5:W - 5] = cp
+        if kind == 6:
+            q[rng.integers(0, L, size=2)] = 4
+            win[rng.integers(0, W, size=3)] = 4
+        if kind == 7:                                              # low-complexity: many equal row maxima
+            unit = rng.integers(0, 4, size=int(rng.integers(1, 4)), dtype=np.uint8)
+            win[:] = np.resize(unit, W)
+            q[:] = np.resize(unit, L)
+            q[rng.integers(0, L, size=3)] = (q[0] + 1) & 3
+        xtra = KSW_XSUBO | KSW_XSTART | (KSW_XBYTE if L * a < 250 else 0) | (min_seed_len * a)
+        jobs[k] = (ro, qo, W, L, xtra, 0)
+        refs.append(win); qers.append(q)
+        ro += W; qo += L
+    return jobs, np.concatenate(refs), np.concatenate(qers)
+
+
+# (name, kswv_workload arguments, scoring parameters) of tests/golden/kswv_golden.npz
+KSWV_GOLDEN_SETS = (
+    ("default", dict(n=2500, seed=91), {}),
+    ("long", dict(n=1500, seed=5, read_len=(200, 420)), {}),
+    ("other", dict(n=1500, seed=6, read_len=(30, 300), a=2), dict(a=2, b=3, o_del=4, e_del=2, o_ins=5, e_ins=1)),
+)

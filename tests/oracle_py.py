@@ -302,3 +302,22 @@ def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
     sc = L.orc_ksw_global2(C.c_int(query.shape[0]), C.c_void_p(query.ctypes.data), C.c_int(target.shape[0]), C.c_void_p(target.ctypes.data), C.c_int(a),
                            C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_int(int(w)), C.byref(n), C.c_void_p(cig.ctypes.data))
     return sc, cig[:n.value].copy()
+
+
+KSWV_JOB_DTYPE = np.dtype([("idr", "<i8"), ("idq", "<i8"), ("len1", "<i4"), ("len2", "<i4"), ("xtra", "<i4"), ("pad", "<i4")])
+KSWR_DTYPE = np.dtype([(n, "<i4") for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")])
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000
+
+
+def kswv_batch(jobs, ref, qer, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, threads=0):
+    """orc_kswv_batch: kswr_t records (KSWR_DTYPE) of the mate-rescue Smith-Waterman jobs (KSWV_JOB_DTYPE), and the DP cells evaluated."""
+    L = lib()
+    jobs = np.ascontiguousarray(jobs, dtype=KSWV_JOB_DTYPE)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qer = np.ascontiguousarray(qer, dtype=np.uint8)
+    out = np.zeros(jobs.shape[0], KSWR_DTYPE)
+    cells = C.c_int64(0)
+    L.orc_kswv_batch(C.c_void_p(jobs.ctypes.data), C.c_int64(jobs.shape[0]), C.c_void_p(ref.ctypes.data), C.c_void_p(qer.ctypes.data), C.c_int(a), C.c_int(b),
+                     C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_void_p(out.ctypes.data), C.c_int(threads or (os.cpu_count() or 1)),
+                     C.byref(cells))
+    return out, cells.value

@@ -138,3 +138,18 @@ def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
                            C.c_int(cap))
     assert n.value >= 0
     return sc, cig[:n.value].copy()
+
+
+def kswv_batch(jobs, ref, qer, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
+    """sort_classify + mem_sam_pe_batch of the compiled reference (its AVX-512 kswv kernels) on the jobs: KSWR_DTYPE records."""
+    from oracle_py import KSWV_JOB_DTYPE, KSWR_DTYPE
+    L = stage_lib()
+    L.ref_kswv_batch.restype = C.c_int
+    jobs = np.ascontiguousarray(jobs, dtype=KSWV_JOB_DTYPE)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    qer = np.ascontiguousarray(qer, dtype=np.uint8)
+    out = np.zeros(jobs.shape[0], KSWR_DTYPE)
+    rc = L.ref_kswv_batch(C.c_void_p(jobs.ctypes.data), C.c_int64(jobs.shape[0]), C.c_void_p(ref.ctypes.data), C.c_int64(ref.shape[0]), C.c_void_p(qer.ctypes.data),
+                          C.c_int64(qer.shape[0]), C.c_int(a), C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    return out

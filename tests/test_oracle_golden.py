@@ -234,3 +234,20 @@ def test_ksw_global2_oracle_equals_reference_golden():
     for k, (J, (q, t)) in enumerate(zip(jobs, seqs)):
         sc, cg = O.ksw_global2(q, t, int(J["w"]))
         assert sc == int(G["score"][k]) and np.array_equal(cg, G["cigars"][off[k]:off[k + 1]]), (k, sc, int(G["score"][k]))
+
+
+def test_kswv_oracle_equals_reference_golden():
+    """orc_kswv_batch against the kswr_t records of the compiled reference's mate-rescue batch (sort_classify + mem_sam_pe_batch with the AVX-512
+    kswv kernels; tests/golden/kswv_golden.npz): 5 500 jobs in three sets -- int8 and int16 classes, reads inside / hanging over / missing
+    their window, tandem copies (second-best score), N, low-complexity sequence (equal row maxima), other scoring parameters.  All seven
+    fields: score, te, qe, score2, te2, tb, qb."""
+    import numpy as np
+    from common import KSWV_GOLDEN_SETS, kswv_workload
+    G = np.load(os.path.join(GOLDEN, "kswv_golden.npz"))
+    for name, kw, pen in KSWV_GOLDEN_SETS:
+        jobs, ref, qer = kswv_workload(**kw)
+        got, cells = O.kswv_batch(jobs, ref, qer, threads=4, **pen)
+        got = got.view(np.int32).reshape(-1, 7)
+        bad = np.nonzero((got != G[name]).any(axis=1))[0]
+        assert bad.size == 0, (name, int(bad[0]), got[bad[0]].tolist(), G[name][bad[0]].tolist())
+        assert cells > 0

@@ -80,6 +80,23 @@ def test_ksw_global2_oracle_equals_reference_on_other_penalties():
             assert got[0] == want[0] and np.array_equal(got[1], want[1]), (a, b, od, ed, oi, ei, int(J["w"]), got[0], want[0])
 
 
+@needs_stage
+def test_kswv_oracle_equals_reference_live():
+    """orc_kswv_batch == the compiled reference's mate-rescue batch (ref_kswv_batch: sort_classify + mem_sam_pe_batch, AVX-512 kswv kernels) on
+    fresh job sets: other seeds, short reads, extreme penalties (free gap opens; mismatch 9), windows shorter than the read."""
+    from common import kswv_workload
+    if ref_py.stage_lib().ref_kswv_batch(None, 0, None, 0, None, 0, 1, 4, 6, 1, 6, 1, None) != 0:
+        pytest.skip("the compiled reference is not an AVX-512 build (no batched kswv kernels)")
+    for kw, pen in ((dict(n=1200, seed=17), {}), (dict(n=800, seed=18, read_len=(19, 140)), dict(a=1, b=9, o_del=1, e_del=1, o_ins=1, e_ins=1)),
+                    (dict(n=800, seed=19, read_len=(240, 260)), dict(a=1, b=1, o_del=0, e_del=1, o_ins=0, e_ins=1)),
+                    (dict(n=600, seed=20, read_len=(100, 500), a=3), dict(a=3, b=5, o_del=7, e_del=2, o_ins=3, e_ins=3))):
+        jobs, ref, qer = kswv_workload(**kw)
+        want = ref_py.kswv_batch(jobs, ref, qer, **pen).view(np.int32).reshape(-1, 7)
+        got = O.kswv_batch(jobs, ref, qer, threads=4, **pen)[0].view(np.int32).reshape(-1, 7)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (kw, pen, int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
+
+
 needs_aligner = pytest.mark.skipif(not (ref_py.have("bwa-meme_mode3") and ref_py.cpu_can_run()), reason="compiled reference (bwa-meme_mode3) not available")
 
 
