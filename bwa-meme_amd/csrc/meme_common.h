@@ -58,9 +58,9 @@ struct meme_ctx {
     std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[9], gcig[6];
+           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[9], gcig[6], kswv[7];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
-    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2];
+    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2], h_kswv;
     i64 last_seed_max_len = 0;         // longest read of that batch
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
     // tuning
@@ -80,6 +80,7 @@ struct meme_ctx {
     hipEvent_t ev_chain[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_ext[2] = {nullptr, nullptr};
     hipEvent_t ev_gcig[2] = {nullptr, nullptr};
+    hipEvent_t ev_kswv[2] = {nullptr, nullptr};
     hipStream_t stream_side[3] = {nullptr, nullptr, nullptr};   // the routed chaining tiers run beside the lane-per-read tier
     hipEvent_t ev_side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_aux = nullptr;

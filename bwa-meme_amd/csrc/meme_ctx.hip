@@ -96,7 +96,11 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (DevBuf& b : ctx->chain) free_buf(b);
     for (DevBuf& b : ctx->ext) free_buf(b);
     for (DevBuf& b : ctx->gcig) free_buf(b);
+    for (DevBuf& b : ctx->kswv) free_buf(b);
     for (meme_ctx::HostBuf& h : ctx->h_chain) if (h.p) (void)hipHostFree(h.p);
+    for (meme_ctx::HostBuf& h : ctx->h_ext) if (h.p) (void)hipHostFree(h.p);
+    for (meme_ctx::HostBuf& h : ctx->h_gcig) if (h.p) (void)hipHostFree(h.p);
+    if (ctx->h_kswv.p) (void)hipHostFree(ctx->h_kswv.p);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     for (meme_ctx::HostBuf* h : {&ctx->h_smems, &ctx->h_hits, &ctx->h_smem_off, &ctx->h_hit_off, &ctx->h_misc})
         if (h->p) (void)hipHostFree(h->p);
@@ -104,6 +108,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (auto& e : ctx->ev_chain) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_ext) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_gcig) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_kswv) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
     for (auto& e : ctx->ev_side) if (e) (void)hipEventDestroy(e);
     for (auto& st : ctx->stream_side) if (st) (void)hipStreamDestroy(st);

@@ -1,0 +1,267 @@
+// Mate-rescue Smith-Waterman of the SAM phase on the device: what mem_sam_pe_batch (reference src/bwamem_pair.cpp:719-818)
+// computes with the AVX-512 kswv kernels (src/kswv.cpp:372-712 int8 lanes, :934-1199 int16 lanes) for the jobs mem_matesw_batch_pre
+// (src/bwamem_pair.cpp:1060-1223) has posed -- a mate (or its reverse complement) against the window of the reference its partner's
+// alignment and the insert-size distribution point at: forward pass (score, end positions, second-best score outside the best hit),
+// then, for hits above the threshold, the pass over the reversed prefixes that finds the start.
+//
+// The reference puts one job in each SIMD lane; so does this kernel, at wavefront width: one job per lane, 64 jobs per wavefront, jobs
+// sorted so that a wavefront's jobs have the same padded query length and similar windows.  Per lane the column state {H(i-1,j), F(i,j),
+// query code} is one 32-bit LDS word, laid out [column][lane] (conflict-free whatever column a lane is at); E and the diagonal travel
+// in registers along the row.  What one SIMD lane of the reference computes does not depend on its neighbours (oracle/meme_oracle.c,
+// kswv_pass, spells out why), so every quirk is per-lane arithmetic here too:
+//   * int8 jobs (KSW_XBYTE: read length x match score < 250): unsigned bytes biased by `shift`, i.e. H + S capped at 255 - shift; the
+//     query padded with a base that scores 0 up to a multiple of 16 columns (8 for int16 jobs), the stripe of bwa's SSE2 ksw_u8 / ksw_i16;
+//   * a row's maximum and its first column; the global maximum moves only on a strictly larger one (first row wins ties);
+//   * rowMax: the row maximum is kept only for rows that are local peaks of that sequence in the reference's sense (Block I, a two-state
+//     mask), reach the KSW_XSUBO threshold and precede the lane's stop (KSW_XSTOP reached; int8: score + shift saturates);
+//   * score2 / te2: the largest kept row maximum outside te +- ceil(score / match), first row on ties; int8: 0 means none;
+//   * second pass when KSW_XSTART is set and the score reaches the threshold: query[0..qe] and target[0..te] reversed, the target's
+//     length unchanged, stop at the first pass's score; tb / qb only if it reaches exactly that score.
+// rowMax lives in HBM ([row][lane] per wavefront: one 128-byte line per row), the only global traffic of the row loop besides one
+// target base per lane and row.
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "meme_common.h"
+
+namespace {
+
+constexpr int XBYTE = 0x10000, XSTOP = 0x20000, XSUBO = 0x40000, XSTART = 0x80000;      // src/ksw.h:31-34
+constexpr int KSWV_SCORE_LIMIT = 1 << 14;            // H and F fields of the column word
+constexpr int N_KSWV_CLS = 6;
+constexpr int KSWV_CLS_Q[N_KSWV_CLS] = {64, 128, 160, 256, 384, 528};     // padded query columns per LDS size class: (q + 1) * 256 B per wavefront
+
+struct KswvArgs {
+    const meme_kswv_job* jobs;
+    const int* order;            // job indices, sorted; this launch: [first, first + count)
+    int first, count;
+    const uint8_t* ref;
+    const uint8_t* qer;
+    meme_kswr* out;
+    unsigned short* rowmax;      // scratch: per wavefront [row][lane]
+    const i64* rm_off;           // first row of each wavefront of this launch in the scratch
+    int a, b, o_del, e_del, o_ins, e_ins;
+};
+
+typedef __attribute__((address_space(3))) unsigned int* lds_u32;
+
+struct PassOut { int raw, score, te, qe, score2, te2; };
+
+// one pass of one job per lane.  target(i) = i <= t_rev ? t[t_rev - i] : t[i]; query(j) = q_rev >= 0 ? q[q_rev - j] : q[j].
+__device__ __forceinline__ PassOut kswv_pass(lds_u32 W, bool is8, const uint8_t* t, int tlen, int t_rev, const uint8_t* q, int qlen, int q_rev, int xtra, bool want2,
+                                             const KswvArgs& A, unsigned short* rm) {
+    const int w_match = A.a, w_mismatch = -A.b, w_ambig = -1;
+    int mn = w_match < w_mismatch ? w_match : w_mismatch;
+    mn = mn < w_ambig ? mn : w_ambig;
+    const int shift = is8 ? (256 - (mn & 0xff)) & 0xff : 0;
+    int qmax = w_match > w_mismatch ? w_match : w_mismatch;
+    qmax = qmax > w_ambig ? qmax : w_ambig;
+    const int cap = is8 ? 255 - shift : 0x3fffffff;
+    const int none = is8 ? 0 : -1;
+    const int quanta = is8 ? (qlen + 15) / 16 * 16 : (qlen + 7) / 8 * 8;
+    const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins, e_del = A.e_del, e_ins = A.e_ins;
+    int v = (xtra & XSUBO) ? (xtra & 0xffff) : 0x10000;
+    const bool has_minsc = v <= (is8 ? 255 : 32767);
+    const int minsc = v;
+    v = (xtra & XSTOP) ? (xtra & 0xffff) : 0x10000;
+    const bool has_endsc = v <= (is8 ? 255 : 32767);
+    const int endsc = v;
+    // column words: word j + 1 = {query code of column j (0..3, 4 = N, 5 = padding), H(i-1, j) = 0, F = 0}
+    for (int j = 0; j < quanta; ++j) {
+        unsigned c = 5u;
+        if (j < qlen) { c = q[q_rev >= 0 ? q_rev - j : j]; c = c > 4u ? 4u : c; }
+        W[(j + 1) * 64] = c << 28;
+    }
+    int gmax = 0, te = -1, qe = 0, pimax = 0;
+    bool mask = false, minsc_ok = false, exited = false;
+    int exit_row = -1;
+    int tb_next = tlen > 0 ? (int)t[0 <= t_rev ? t_rev : 0] : 4;
+    int wave_rows = tlen;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(wave_rows, d); wave_rows = wave_rows > y ? wave_rows : y; }
+    for (int i = 0; i < wave_rows; ++i) {
+        const bool live = i < tlen && !exited;
+        if (!__any(live)) break;
+        if (live) {
+            const int tb = tb_next;
+            if (i + 1 < tlen) tb_next = t[i + 1 <= t_rev ? t_rev - (i + 1) : i + 1];
+            const int s_eq = tb > 3 ? w_ambig : w_match, s_ne = tb > 3 ? w_ambig : w_mismatch;
+            int e = 0, diag = 0, imax = 0, iqe = -1;
+            unsigned nxt = W[64];
+            for (int j = 0; j < quanta; ++j) {
+                const unsigned cur = nxt;
+                if (j + 1 < quanta) nxt = W[(j + 2) * 64];
+                const int hold = (int)(cur & 0x3fffu), f = (int)((cur >> 14) & 0x3fffu), qc = (int)(cur >> 28);
+                const int sc = qc > 4 ? 0 : (qc > 3 ? w_ambig : (qc == tb ? s_eq : s_ne));
+                int m = diag + sc;
+                m = m < cap ? m : cap;
+                int h = m > e ? m : e;
+                h = h > f ? h : f;
+                h = h > 0 ? h : 0;
+                iqe = h > imax ? j : iqe;
+                imax = h > imax ? h : imax;
+                int g = h - oe_ins, e2 = e - e_ins;
+                g = g > e2 ? g : e2;
+                e = g > 0 ? g : 0;
+                int dl = h - oe_del, f2 = f - e_del;
+                dl = dl > f2 ? dl : f2;
+                dl = dl > 0 ? dl : 0;
+                W[(j + 1) * 64] = (unsigned)h | ((unsigned)dl << 14) | (cur & (7u << 28));
+                diag = hold;
+            }
+            if (i > 0) {                                                   // Block I (src/kswv.cpp:505-518, :1063-1078)
+                const bool msk = imax > pimax || mask;
+                rm[(i64)(i - 1) * 64] = (unsigned short)((!msk && minsc_ok) ? pimax : none);
+                mask = !msk;
+            }
+            pimax = imax;
+            minsc_ok = has_minsc && imax >= minsc;
+            if (imax > gmax) { gmax = imax; te = i; qe = is8 ? (iqe & 0xff) : iqe; }       // Block II
+            if ((has_endsc && gmax >= endsc) || (is8 && gmax + shift >= 255)) {
+                exited = true;                                             // (this row and all later ones keep nothing)
+                exit_row = i;
+            }
+        }
+    }
+    if (!exited && tlen > 0) rm[(i64)(tlen - 1) * 64] = (unsigned short)((!mask && minsc_ok) ? pimax : none);
+    PassOut R;
+    R.raw = gmax;
+    R.score = is8 ? (gmax + shift < 255 ? gmax : 255) : gmax;
+    R.te = te; R.qe = qe; R.score2 = -1; R.te2 = -1;
+    if (want2) {                                                           // (wave-uniform: first passes only)
+        const bool on = !(is8 && R.score == 255);
+        const int val = (gmax + qmax - 1) / qmax, low = te - val, high = te + val;
+        const int last = !on ? -1 : (exited ? exit_row - 1 : tlen - 1);    // rows at and after a stop keep nothing (and were not written)
+        int wave_last = last;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(wave_last, d); wave_last = wave_last > y ? wave_last : y; }
+        int mx = none, t2 = -1;
+        __threadfence_block();
+        for (int i = 0; i <= wave_last; ++i) {
+            const bool in = i <= last && (i < low || i > high);
+            if (in) {
+                const unsigned short raw = rm[(i64)i * 64];
+                const int rv = is8 ? (int)raw : (int)(short)raw;
+                if (rv > mx) { mx = rv; t2 = i; }
+            }
+        }
+        if (on) { R.score2 = is8 ? (mx == 0 ? -1 : mx) : mx; R.te2 = t2; }
+    }
+    return R;
+}
+
+__global__ void __launch_bounds__(64) k_kswv(KswvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int w_raw[];
+    const int lane = threadIdx.x;
+    const lds_u32 W = (lds_u32)w_raw + lane;
+    const int slot = (int)blockIdx.x * 64 + lane;
+    const bool active = slot < A.count;
+    const int jid = A.order[A.first + (active ? slot : 0)];
+    const meme_kswv_job J = A.jobs[jid];
+    const int tlen = active ? J.len1 : 0, qlen = active ? J.len2 : 0, xtra = J.xtra;
+    const bool is8 = (xtra & XBYTE) != 0;                                   // sort_classify, src/bwamem.cpp:1798-1825
+    const uint8_t* t = A.ref + J.idr;
+    const uint8_t* q = A.qer + J.idq;
+    unsigned short* rm = A.rowmax + A.rm_off[blockIdx.x] * 64 + lane;
+    const PassOut F = kswv_pass(W, is8, t, tlen, -1, q, qlen, -1, xtra, true, A, rm);
+    meme_kswr R;
+    R.score = F.score; R.te = F.te; R.qe = F.qe; R.score2 = F.score2; R.te2 = F.te2; R.tb = -1; R.qb = -1;
+    // second pass (src/bwamem_pair.cpp:768-808): lanes without one run an empty job
+    const bool again = active && (xtra & XSTART) != 0 && !((xtra & XSUBO) && R.score < (xtra & 0xffff));
+    __builtin_amdgcn_wave_barrier();
+    const PassOut B = kswv_pass(W, is8, t, again ? tlen : 0, R.te, q, again ? R.qe + 1 : 0, R.qe, XSTOP | R.score, false, A, rm);
+    if (again && R.score == B.raw) { R.tb = R.te - B.te; R.qb = R.qe - B.qe; }
+    if (active) A.out[jid] = R;
+}
+
+}  // namespace
+
+extern "C" int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer,
+                                    int64_t qer_bytes, const meme_bsw_opt* opt, meme_kswv_host_result* out) {
+    if (!ctx || !opt || !out || njobs < 0 || (njobs > 0 && (!jobs || !ref || !qer))) { meme_set_error("meme_kswv_batch_host: null argument"); return MEME_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    if (njobs == 0) return MEME_OK;
+    if (njobs > 0x7fffffff / 2) { meme_set_error("meme_kswv_batch_host: too many jobs in one call"); return MEME_E_ARG; }
+    if (opt->a < 1 || opt->b < 0 || opt->e_del < 0 || opt->e_ins < 0 || opt->o_del < 0 || opt->o_ins < 0) { meme_set_error("meme_kswv_batch_host: bad scoring parameters"); return MEME_E_ARG; }
+    const int n = (int)njobs;
+    // classes and order: LDS size class, then padded query length, then window length (descending inside a class, so a wavefront's
+    // lanes run about the same number of rows)
+    std::vector<int> quanta((size_t)n), order((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const meme_kswv_job& J = jobs[k];
+        const bool is8 = (J.xtra & XBYTE) != 0;
+        if (J.len1 < 0 || J.len2 < 0 || J.len1 > 32767 || J.idr < 0 || J.idq < 0 || J.idr + J.len1 > ref_bytes || J.idq + J.len2 > qer_bytes ||
+            (int64_t)J.len2 * opt->a >= KSWV_SCORE_LIMIT || J.len2 > KSWV_CLS_Q[N_KSWV_CLS - 1] - 16 || (is8 && J.len2 > 255)) {
+            meme_set_error("meme_kswv_batch_host: job %d is malformed or beyond the kernel's limits (window %d at %lld, query %d at %lld, match score %d: "
+                           "query x match < %d, query <= %d, window <= 32767)", k, J.len1, (long long)J.idr, J.len2, (long long)J.idq, opt->a, KSWV_SCORE_LIMIT,
+                           KSWV_CLS_Q[N_KSWV_CLS - 1] - 16);
+            return MEME_E_ARG;
+        }
+        quanta[(size_t)k] = is8 ? (J.len2 + 15) / 16 * 16 : (J.len2 + 7) / 8 * 8;
+        order[(size_t)k] = k;
+    }
+    auto cls_of = [&](int qn) { int c = 0; while (KSWV_CLS_Q[c] < qn) ++c; return c; };
+    std::sort(order.begin(), order.end(), [&](int x, int y) {
+        const int cx = cls_of(quanta[(size_t)x]), cy = cls_of(quanta[(size_t)y]);
+        if (cx != cy) return cx < cy;
+        if (quanta[(size_t)x] != quanta[(size_t)y]) return quanta[(size_t)x] < quanta[(size_t)y];
+        if (jobs[x].len1 != jobs[y].len1) return jobs[x].len1 > jobs[y].len1;
+        return x < y;
+    });
+    // launches: one per class; wavefront w of a launch keeps its row maxima at rm_off[w]
+    struct Launch { int first, count, qmax; size_t w0; };
+    std::vector<Launch> launches;
+    std::vector<i64> rm_off;
+    i64 rows_total = 0;
+    for (int p = 0; p < n;) {
+        const int c = cls_of(quanta[(size_t)order[(size_t)p]]);
+        int e = p;
+        while (e < n && cls_of(quanta[(size_t)order[(size_t)e]]) == c) ++e;
+        Launch L;
+        L.first = p; L.count = e - p; L.qmax = KSWV_CLS_Q[c]; L.w0 = rm_off.size();
+        for (int w = p; w < e; w += 64) {
+            int mr = 1;
+            for (int k = w; k < e && k < w + 64; ++k) mr = std::max(mr, jobs[order[(size_t)k]].len1);
+            rm_off.push_back(rows_total);
+            rows_total += mr + 1;
+        }
+        launches.push_back(L);
+        p = e;
+    }
+    int rc;
+    DevBuf* K = ctx->kswv;      // 0 jobs, 1 order, 2 ref bytes, 3 query bytes, 4 results, 5 row maxima, 6 wavefront offsets
+    if ((rc = meme_buf_reserve(ctx, K[0], (size_t)n * sizeof(meme_kswv_job))) || (rc = meme_buf_reserve(ctx, K[1], (size_t)n * 4)) ||
+        (rc = meme_buf_reserve(ctx, K[2], (size_t)ref_bytes + 64)) || (rc = meme_buf_reserve(ctx, K[3], (size_t)qer_bytes + 64)) ||
+        (rc = meme_buf_reserve(ctx, K[4], (size_t)n * sizeof(meme_kswr))) || (rc = meme_buf_reserve(ctx, K[5], (size_t)rows_total * 128 + 256)) ||
+        (rc = meme_buf_reserve(ctx, K[6], rm_off.size() * 8 + 8))) return rc;
+    hipEvent_t* ev = ctx->ev_kswv;
+    for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    HIP_TRY(hipMemcpyAsync(K[0].p, jobs, (size_t)n * sizeof(meme_kswv_job), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(K[1].p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(K[2].p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(K[3].p, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(K[6].p, rm_off.data(), rm_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    for (const Launch& L : launches) {
+        KswvArgs A;
+        A.jobs = (const meme_kswv_job*)K[0].p; A.order = (const int*)K[1].p; A.first = L.first; A.count = L.count;
+        A.ref = (const uint8_t*)K[2].p; A.qer = (const uint8_t*)K[3].p; A.out = (meme_kswr*)K[4].p;
+        A.rowmax = (unsigned short*)K[5].p; A.rm_off = (const i64*)K[6].p + L.w0;
+        A.a = opt->a; A.b = opt->b; A.o_del = opt->o_del; A.e_del = opt->e_del; A.o_ins = opt->o_ins; A.e_ins = opt->e_ins;
+        const size_t lds = (size_t)(L.qmax + 1) * 256;
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_kswv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_kswv, dim3((unsigned)((L.count + 63) / 64)), dim3(64), lds, ctx->stream, A);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+    meme_ctx::HostBuf& Hb = ctx->h_kswv;
+    if ((rc = meme_hostbuf_reserve(ctx, Hb, (size_t)n * sizeof(meme_kswr)))) return rc;
+    HIP_TRY(hipMemcpyAsync(Hb.p, K[4].p, (size_t)n * sizeof(meme_kswr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    out->njobs = njobs; out->res = (const meme_kswr*)Hb.p; out->kernel_ms = ms;
+    return MEME_OK;
+}

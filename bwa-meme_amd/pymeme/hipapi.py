@@ -82,6 +82,12 @@ class GresHost(C.Structure):
     _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("cigars", C.c_void_p), ("total_ops", C.c_int64), ("kernel_ms", C.c_float)]
 
 
+class KswvHost(C.Structure):
+    _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("kernel_ms", C.c_float)]
+
+
+KSWV_JOB = np.dtype([("idr", "<i8"), ("idq", "<i8"), ("len1", "<i4"), ("len2", "<i4"), ("xtra", "<i4"), ("pad", "<i4")])
+KSWR = np.dtype([(n, "<i4") for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")])
 CHAIN = np.dtype({"names": ["pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"],
                   "formats": ["<i8", "<i4", "<i4", "<i4", "<i4", "<i2", "<i2", "<i4"], "offsets": [0, 8, 12, 16, 20, 24, 26, 28], "itemsize": 40})
 CHAIN_SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
@@ -112,7 +118,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -325,6 +331,21 @@ class Context:
             buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype, count=count).copy()
         return view(res.res, res.njobs, GRES), view(res.cigars, res.total_ops, np.uint32), float(res.kernel_ms)
+
+    def kswv_batch_host(self, jobs, ref, qer, opt=None):
+        """meme_kswv_batch_host: the mate-rescue Smith-Waterman batch (mem_sam_pe_batch with the kswv kernels).  jobs: KSWV_JOB records over the
+        byte arrays ref / qer.  Returns (KSWR records, kernel_ms)."""
+        opt = opt or default_bsw_opt()
+        jobs = np.ascontiguousarray(jobs, dtype=KSWV_JOB)
+        ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        qer = np.ascontiguousarray(qer, dtype=np.uint8)
+        res = KswvHost()
+        _check(lib().meme_kswv_batch_host(C.c_void_p(self.h), _p(jobs), C.c_int64(jobs.shape[0]), _p(ref), C.c_int64(ref.shape[0]), _p(qer),
+                                          C.c_int64(qer.shape[0]), C.byref(opt), C.byref(res)))
+        if res.njobs == 0:
+            return np.zeros(0, KSWR), float(res.kernel_ms)
+        buf = (C.c_char * (res.njobs * KSWR.itemsize)).from_address(res.res)
+        return np.frombuffer(buf, dtype=KSWR, count=res.njobs).copy(), float(res.kernel_ms)
 
     def chain_batch_host(self, smems, smem_off, hits, hit_off, read_len, contigs, opt):
         """meme_chain_batch_host: chains of seeds the caller brings (numpy arrays laid out as seed_batch_host returns them)."""

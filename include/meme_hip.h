@@ -274,6 +274,20 @@ typedef struct { int64_t njobs; const meme_gres* res; const uint32_t* cigars; in
 int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int64_t njobs, const meme_bsw_opt* opt /* o_del e_del o_ins e_ins a b */,
                            meme_gres_host* out);
 
+/* ---- mate-rescue Smith-Waterman: the other DP kernel of the SAM phase ---------------------------------------------------------------
+ * What mem_sam_pe_batch() (reference src/bwamem_pair.cpp:719-818) computes with kswv::getScores8 / getScores16 (src/kswv.cpp) for the
+ * SeqPair jobs mem_matesw_batch_pre() (src/bwamem_pair.cpp:1060-1223) posed: local alignment of a mate (query, len2 bases at qer + idq)
+ * inside a window of the reference (target, len1 bases at ref + idr), bases 0..3, 4 = N.  xtra = SeqPair.h0 = KSW_X* flags | threshold
+ * (src/ksw.h:31-34): KSW_XBYTE selects the int8 arithmetic of getScores8 (sort_classify, src/bwamem.cpp:1798-1825), KSW_XSUBO the
+ * second-best score, KSW_XSTART the second pass for the start.  Results are kswr_t records (src/ksw.h:44-50), field for field what the
+ * AVX-512 build of the reference produces (its stripe padding, tie rules and kept-row-maximum rule included).  opt: a, b, o_del, e_del,
+ * o_ins, e_ins (match a, mismatch -b, N -1).  Limits: len2 <= 512, len2 * a < 16384, len1 <= 32767 (the reference's own: int16 lanes). */
+typedef struct { int64_t idr, idq; int32_t len1, len2, xtra, pad; } meme_kswv_job;
+typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } meme_kswr;
+typedef struct { int64_t njobs; const meme_kswr* res; /* pinned, owned by the ctx, valid until its next kswv call */ float kernel_ms; } meme_kswv_host_result;
+int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer, int64_t qer_bytes,
+                         const meme_bsw_opt* opt, meme_kswv_host_result* out);
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * HIP-event timings of the kernels of the last *_device call, measured on the ctx's stream.          */
 typedef struct {

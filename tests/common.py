@@ -240,3 +240,30 @@ KSWV_GOLDEN_SETS = (
     ("long", dict(n=1500, seed=5, read_len=(200, 420)), {}),
     ("other", dict(n=1500, seed=6, read_len=(30, 300), a=2), dict(a=2, b=3, o_del=4, e_del=2, o_ins=5, e_ins=1)),
 )
+
+
+def kswv_edge_jobs():
+    """Ten edge jobs of the mate-rescue kernel, every job with bytes of its own (as mem_matesw_batch_pre lays them out): the plain case, a
+    one-base window, a window shorter than the read, a one-base query, no KSW_XSTART, no KSW_XSUBO, the int16 class, a caller-set KSW_XSTOP,
+    a threshold the score does not reach, a 3 000-base window.  KSWV_EDGE_WANT: the compiled reference's kswr_t records for them."""
+    from oracle_py import KSWV_JOB_DTYPE, KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART
+    rng = np.random.default_rng(3)
+    g = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    q = g[1000:1150].copy()
+    X = KSW_XSUBO | KSW_XSTART | KSW_XBYTE | 19
+    spec = [(900, 400, 0, 150, X), (1000, 1, 0, 150, X), (1020, 60, 0, 150, X), (900, 400, 70, 1, X), (900, 400, 0, 150, KSW_XSUBO | KSW_XBYTE | 19),
+            (900, 400, 0, 150, KSW_XSTART | KSW_XBYTE), (900, 400, 0, 150, KSW_XSTART | KSW_XSUBO | 19), (900, 400, 0, 150, KSW_XSTOP | KSW_XSUBO | 40),
+            (900, 400, 0, 150, KSW_XSTART | KSW_XSUBO | KSW_XBYTE | 200), (0, 3000, 0, 150, X)]
+    jobs = np.zeros(len(spec), KSWV_JOB_DTYPE)
+    rb, qb = [], []
+    ro = qo = 0
+    for k, (idr, l1, idq, l2, x) in enumerate(spec):
+        jobs[k] = (ro, qo, l1, l2, x, 0)
+        rb.append(g[idr:idr + l1]); qb.append(q[idq:idq + l2])
+        ro += l1; qo += l2
+    return jobs, np.concatenate(rb), np.concatenate(qb)
+
+
+KSWV_EDGE_WANT = [[150, 249, 149, -1, -1, 100, 0], [1, 0, 0, -1, -1, -1, -1], [60, 59, 79, -1, -1, 0, 20], [1, 4, 0, -1, -1, -1, -1], [150, 249, 149, -1, -1, -1, -1],
+                  [150, 249, 149, -1, -1, 100, 0], [150, 249, 149, -1, -1, 100, 0], [40, 139, 39, -1, -1, -1, -1], [150, 249, 149, -1, -1, -1, -1],
+                  [150, 1149, 149, -1, -1, 1000, 0]]

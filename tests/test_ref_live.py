@@ -97,6 +97,18 @@ def test_kswv_oracle_equals_reference_live():
         assert bad.size == 0, (kw, pen, int(bad[0]), got[bad[0]].tolist(), want[bad[0]].tolist())
 
 
+@needs_stage
+def test_kswv_edge_jobs_reference_live():
+    """The ten edge jobs of tests/common.py kswv_edge_jobs(): compiled reference == oracle == the records kept in KSWV_EDGE_WANT."""
+    from common import KSWV_EDGE_WANT, kswv_edge_jobs
+    if ref_py.stage_lib().ref_kswv_batch(None, 0, None, 0, None, 0, 1, 4, 6, 1, 6, 1, None) != 0:
+        pytest.skip("the compiled reference is not an AVX-512 build (no batched kswv kernels)")
+    jobs, rb, qb = kswv_edge_jobs()
+    want = ref_py.kswv_batch(jobs, rb, qb).view(np.int32).reshape(-1, 7)
+    assert np.array_equal(want, np.array(KSWV_EDGE_WANT, np.int32))
+    assert np.array_equal(O.kswv_batch(jobs, rb, qb)[0].view(np.int32).reshape(-1, 7), want)
+
+
 needs_aligner = pytest.mark.skipif(not (ref_py.have("bwa-meme_mode3") and ref_py.cpu_can_run()), reason="compiled reference (bwa-meme_mode3) not available")
 
 
