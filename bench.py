@@ -271,6 +271,59 @@ def bsw_reference_baseline(pairs, ref, qer, w, cores):
     return dt, out, int(small.sum())
 
 
+def kswv_leg(ctx):
+    """Mate-rescue Smith-Waterman of the SAM phase (mem_sam_pe_batch / kswv): jobs shaped like those of 150-bp pairs (a mate
+    against a window of a few hundred bases around where its partner says it should lie), results to the host as the binding takes them.
+    jobs/s through the C ABI call (transfers included), the kernel's own time, GCUPS with the DP cells from the oracle's counter; checked
+    against the oracle; CPU figure from the reference's own batch (sort_classify + mem_sam_pe_batch, AVX-512 kswv kernels) on all cores in
+    batches of the size worker_sam sees, the oracle's scalar restatement beside it."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_py, ref_py
+    from common import kswv_workload
+    njobs = int(os.environ.get("MEME_BENCH_KSWV_JOBS", "200000"))
+    base, ref, qer = kswv_workload(n=20000, seed=123, read_len=(150, 151))
+    reps = (njobs + base.shape[0] - 1) // base.shape[0]
+    jobs = np.concatenate([base] * reps)[:njobs].copy()                    # (the same bytes serve several jobs: the device does not modify them)
+    ms, walls = [], []
+    for it in range(3):
+        t0 = time.perf_counter()
+        got, k_ms = ctx.kswv_batch_host(jobs.view(hipapi.KSWV_JOB), ref, qer)
+        walls.append(time.perf_counter() - t0)
+        ms.append(k_ms)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    want, cells = oracle_py.kswv_batch(base, ref, qer, threads=cores)
+    port_dt = time.perf_counter() - t0
+    same = bool(np.array_equal(got[:base.shape[0]].view(np.int32), want.view(np.int32)) and np.array_equal(got[-base.shape[0]:].view(np.int32), got[:base.shape[0]].view(np.int32))) \
+        if njobs % base.shape[0] == 0 else bool(np.array_equal(got[:base.shape[0]].view(np.int32), want.view(np.int32)))
+    cells_per_job = cells / base.shape[0]
+    k = float(np.min(ms))
+    cpu = {"value": base.shape[0] / port_dt, "unit": "jobs/s", "cores": cores, "kind": "port",
+           "sample": "%d jobs, scalar restatement (orc_kswv_batch) on %d threads" % (base.shape[0], cores)}
+    if ref_py.have("libstage_ref.so") and ref_py.cpu_can_run() and ref_py.stage_lib().ref_kswv_batch(None, 0, None, 0, None, 0, 1, 4, 6, 1, 6, 1, None) == 0:
+        per = 64                                                            # jobs per call: what one worker batch of 256 pairs poses, give or take
+        parts = [(base[i:i + per], ) for i in range(0, base.shape[0], per)]
+        def run(p):
+            j = p[0].copy()
+            r0, q0 = int(j["idr"][0]), int(j["idq"][0])
+            r1, q1 = int(j["idr"][-1] + j["len1"][-1]), int(j["idq"][-1] + j["len2"][-1])
+            j["idr"] -= r0; j["idq"] -= q0
+            return ref_py.kswv_batch(j, ref[r0:r1], qer[q0:q1])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            outs = list(ex.map(run, parts))
+        r_dt = time.perf_counter() - t0
+        r_same = bool(np.array_equal(np.concatenate(outs).view(np.int32), got[:base.shape[0]].view(np.int32)))
+        cpu = {"value": base.shape[0] / r_dt, "unit": "jobs/s", "cores": cores, "kind": "reference",
+               "sample": "%d jobs: sort_classify + mem_sam_pe_batch (AVX-512 kswv kernels) in calls of %d jobs on %d threads" % (base.shape[0], per, cores),
+               "device_matches_reference": r_same, "port": cpu}
+    return {"metric": "kswv_jobs_per_sec", "value": njobs / float(np.min(walls)), "unit": "jobs/s", "jobs": njobs, "call_ms": float(np.min(walls)) * 1e3, "kernel_ms": k,
+            "cells_per_job": cells_per_job, "gcups_kernel": cells_per_job * njobs / (k * 1e-3) / 1e9, "matches_oracle": same, "checked_jobs": int(base.shape[0]),
+            "cpu_baseline": cpu}
+
+
 def bsw_leg(ctx, dev, world):
     """Second kernel of the path: banded seed extension on rank 0's GPU, pairs resident in HBM.
     Every pair is distinct (no tiling): lengths, targets and errors differ from pair to pair as in a real batch, so the
@@ -813,6 +866,12 @@ def main():
             except Exception as e:  # a secondary measurement: never lose the headline line over it
                 log("bsw leg failed: %r" % (e,))
                 out["bsw"] = None
+        if single and os.environ.get("MEME_BENCH_KSWV", "1") != "0":
+            try:
+                out["kswv"] = kswv_leg(ctx)
+            except Exception as e:
+                log("kswv leg failed: %r" % (e,))
+                out["kswv"] = None
         if single and os.environ.get("MEME_BENCH_CHAIN", "1") != "0":
             try:
                 out["chain"] = chain_leg(ctx, reads, l_pac)

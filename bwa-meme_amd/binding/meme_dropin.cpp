@@ -365,6 +365,7 @@ void ext_report();
 }
 void meme_dropin_report_matesw();
 void meme_dropin_report_cigar();
+void meme_dropin_report_mate();
 namespace {
 
 }  // namespace
@@ -409,6 +410,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
     if (verbose() && !g_ext_on_device) ext_report();
     if (verbose() && getenv("MEME_DROPIN_PROFILE_SAM")) meme_dropin_report_matesw();
     if (verbose()) meme_dropin_report_cigar();
+    if (verbose()) meme_dropin_report_mate();
 }
 
 namespace {
@@ -1320,19 +1322,154 @@ void BandedPairWiseSW::getScores8(SeqPair* p, uint8_t* r, uint8_t* q, int32_t n,
     bsw_forward(mat, o_del, e_del, o_ins, e_ins, zdrop, end_bonus, p, r, q, n, w);
 }
 
-// ---- measurement only (MEME_DROPIN_VERBOSE): time the worker threads spend in the mate-rescue Smith-Waterman batch ----------
+// ---- mate rescue of the SAM phase on the device -----------------------------------------------------------------------------
+// worker_sam (src/bwamem.cpp:1827-1902, AVX-512 build) handles a batch of read pairs in three steps: mem_sam_pe_batch_pre poses the
+// Smith-Waterman jobs of mate rescue (a mate against the window its partner's alignment points at), mem_sam_pe_batch runs them through
+// the kswv kernels, mem_sam_pe_batch_post turns the results into alignment records.  At the SAM phase's quiescent point (the interposed
+// third kt_for call, as for the CIGAR stage) the binding runs the reference's own mem_sam_pe_batch_pre for every batch of the chunk into
+// buffers of its own -- the step reads the alignment records and writes only to the mem_cache it is given --, sends the jobs of the whole
+// chunk to the GPU(s) in one meme_kswv_batch_host call each, and keeps the kswr_t records per batch; worker_sam then runs unchanged, and its
+// mem_sam_pe_batch call is answered from that table (same jobs in the same order: the step is deterministic).  A batch the table does
+// not hold goes to the reference's function.  MEME_DROPIN_MATESW=0 switches the stage off.
+#include <omp.h>
 #include "kswv.h"
-namespace { std::atomic<double> g_t_matesw{0}; std::atomic<int64_t> g_n_matesw{0}; }
+namespace {
+std::atomic<double> g_t_matesw{0};
+std::atomic<int64_t> g_n_matesw{0};
+bool matesw_on_device() { static const bool v = !(getenv("MEME_DROPIN_MATESW") && atoi(getenv("MEME_DROPIN_MATESW")) == 0); return v; }
+struct MateTable {
+    std::vector<int64_t> off;                    // first record of every worker batch (+ the total)
+    std::vector<kswr_t> aln;                     // records, batch after batch, in the order the jobs were posed (= regid)
+    uint64_t gen = 0;                            // chunk the table belongs to
+    double t_prepass = 0, t_kernel_ms = 0;
+    int64_t n_jobs = 0;
+    mem_cache* cache = nullptr;                  // the pre-pass's own buffers, one slot per helper thread
+    int slots = 0;
+} g_mate;
+std::atomic<int64_t> g_mate_hits{0}, g_mate_miss{0};
+thread_local long tl_sam_batch = -1;            // batch worker_sam is working on in this thread (set by sam_wrapper)
+void (*g_sam_func)(void*, long, long, int) = nullptr;
+void sam_wrapper(void* data, long st, long len, int tid) { tl_sam_batch = st / BATCH_SIZE; g_sam_func(data, st, len, tid); tl_sam_batch = -1; }
+int cig_threads();
+
+void mate_cache_init(int slots) {
+    // worst case of one batch: 256 pairs x 2 ends x max_matesw (50) alignments x 4 orientations (mem_matesw_batch_pre asserts room before it grows)
+    const int64_t cap = (int64_t)BATCH_SIZE / 2 * 2 * 50 * 4 + 1024;
+    mem_cache* C = (mem_cache*)calloc(1, sizeof(mem_cache));
+    if (!C) die("calloc");
+    for (int t = 0; t < slots; ++t) {
+        C->seqPairArrayAux[t] = (SeqPair*)malloc((size_t)(cap + MAX_LINE_LEN) * sizeof(SeqPair));
+        C->seqPairArrayLeft128[t] = (SeqPair*)malloc((size_t)(cap + MAX_LINE_LEN) * sizeof(SeqPair));
+        C->seqPairArrayRight128[t] = (SeqPair*)malloc((size_t)(cap + MAX_LINE_LEN) * sizeof(SeqPair));
+        C->wsize[t] = cap;
+        const int64_t rcap = 8 << 20, qcap = 2 << 20;
+        C->wsize_buf_ref[t * CACHE_LINE] = rcap; C->wsize_buf_qer[t * CACHE_LINE] = qcap;
+        C->seqBufLeftRef[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)rcap, 64); C->seqBufRightRef[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)rcap, 64);
+        C->seqBufLeftQer[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)qcap, 64); C->seqBufRightQer[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)qcap, 64);
+        if (!C->seqPairArrayAux[t] || !C->seqPairArrayLeft128[t] || !C->seqPairArrayRight128[t] || !C->seqBufLeftRef[t * CACHE_LINE] ||
+            !C->seqBufRightRef[t * CACHE_LINE] || !C->seqBufLeftQer[t * CACHE_LINE] || !C->seqBufRightQer[t * CACHE_LINE]) die("mate-rescue buffers");
+    }
+    g_mate.cache = C; g_mate.slots = slots;
+}
+
+void matesw_prepass() {
+    const double t0 = now_s();
+    worker_t* w = g_worker;
+    const mem_opt_t* opt = g_opt;
+    const int64_t n = g_chunk.n;
+    const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
+    const int nt = cig_threads();
+    if (!g_mate.cache) mate_cache_init(nt);
+    struct BatchJobs { std::vector<meme_kswv_job> jobs; std::vector<uint8_t> ref, qer; };
+    std::vector<BatchJobs> B((size_t)nb);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_mate.slots)
+    for (int64_t b = 0; b < nb; ++b) {
+        const int t = omp_get_thread_num();
+        const int64_t st = b * BATCH_SIZE, ed = (b + 1) * BATCH_SIZE < n ? (b + 1) * BATCH_SIZE : n;
+        int64_t pcnt = 0;
+        int32_t gcnt = 0, maxRef = 0, maxQer = 0;
+        int64_t pos = st >> 1;
+        for (int64_t i = st; i + 1 < ed; i += 2)                  // worker_sam's loop (src/bwamem.cpp:1855-1866)
+            mem_sam_pe_batch_pre(opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], g_mate.cache,
+                                 pcnt, gcnt, maxRef, maxQer, t);
+        BatchJobs& J = B[(size_t)b];
+        if (pcnt == 0) continue;
+        const SeqPair* sp = g_mate.cache->seqPairArrayLeft128[t];
+        const int64_t rbytes = (int64_t)sp[pcnt - 1].idr + sp[pcnt - 1].len1, qbytes = (int64_t)sp[pcnt - 1].idq + sp[pcnt - 1].len2;
+        J.ref.assign(g_mate.cache->seqBufLeftRef[t * CACHE_LINE], g_mate.cache->seqBufLeftRef[t * CACHE_LINE] + rbytes);
+        J.qer.assign(g_mate.cache->seqBufLeftQer[t * CACHE_LINE], g_mate.cache->seqBufLeftQer[t * CACHE_LINE] + qbytes);
+        J.jobs.resize((size_t)pcnt);
+        for (int64_t k = 0; k < pcnt; ++k) { meme_kswv_job& j = J.jobs[(size_t)k]; j.idr = sp[k].idr; j.idq = sp[k].idq; j.len1 = sp[k].len1; j.len2 = sp[k].len2; j.xtra = sp[k].h0; j.pad = 0; }
+    }
+    MateTable& T = g_mate;
+    T.off.assign((size_t)nb + 1, 0);
+    for (int64_t b = 0; b < nb; ++b) T.off[(size_t)b + 1] = T.off[(size_t)b] + (int64_t)B[(size_t)b].jobs.size();
+    const int64_t total = T.off[(size_t)nb];
+    T.aln.resize((size_t)total);
+    // the chunk's batches in contiguous runs over the GPUs, one call each
+    const int nd = (int)g_dev.size();
+    meme_bsw_opt bo;
+    memset(&bo, 0, sizeof(bo));
+    bo.o_del = opt->o_del; bo.e_del = opt->e_del; bo.o_ins = opt->o_ins; bo.e_ins = opt->e_ins; bo.a = opt->a; bo.b = opt->b;
+    std::vector<double> kms((size_t)nd, 0.0);
+    auto run_part = [&](int d) {
+        const int64_t b0 = nb * d / nd, b1 = nb * (d + 1) / nd;
+        const int64_t j0 = T.off[(size_t)b0], nj = T.off[(size_t)b1] - j0;
+        if (nj == 0) return;
+        std::vector<meme_kswv_job> jobs((size_t)nj);
+        int64_t rtot = 0, qtot = 0;
+        for (int64_t b = b0; b < b1; ++b) { rtot += (int64_t)B[(size_t)b].ref.size(); qtot += (int64_t)B[(size_t)b].qer.size(); }
+        std::vector<uint8_t> ref((size_t)rtot + 1), qer((size_t)qtot + 1);
+        int64_t ro = 0, qo = 0, k = 0;
+        for (int64_t b = b0; b < b1; ++b) {
+            const BatchJobs& J = B[(size_t)b];
+            if (!J.ref.empty()) memcpy(ref.data() + ro, J.ref.data(), J.ref.size());
+            if (!J.qer.empty()) memcpy(qer.data() + qo, J.qer.data(), J.qer.size());
+            for (const meme_kswv_job& j : J.jobs) { meme_kswv_job x = j; x.idr += ro; x.idq += qo; jobs[(size_t)k++] = x; }
+            ro += (int64_t)J.ref.size(); qo += (int64_t)J.qer.size();
+        }
+        meme_kswv_host_result R;
+        if (meme_kswv_batch_host(g_dev[(size_t)d].bsw, jobs.data(), nj, ref.data(), rtot, qer.data(), qtot, &bo, &R)) die("meme_kswv_batch_host");
+        static_assert(sizeof(kswr_t) == sizeof(meme_kswr) && offsetof(kswr_t, score) == 0 && offsetof(kswr_t, te) == 4 && offsetof(kswr_t, qe) == 8 &&
+                      offsetof(kswr_t, score2) == 12 && offsetof(kswr_t, te2) == 16 && offsetof(kswr_t, tb) == 20 && offsetof(kswr_t, qb) == 24, "kswr_t layout");
+        memcpy(&T.aln[(size_t)j0], R.res, (size_t)nj * sizeof(kswr_t));
+        kms[(size_t)d] = R.kernel_ms;
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < nd; ++d) th.emplace_back(run_part, d);
+    run_part(0);
+    for (auto& x : th) x.join();
+    double km = 0;
+    for (double v : kms) km = km > v ? km : v;
+    T.t_kernel_ms += km; T.n_jobs += total; T.t_prepass += now_s() - t0;
+    T.gen = g_chunk_gen;
+}
+}  // namespace
+
 typedef int (*sam_pe_batch_fn)(const mem_opt_t*, mem_cache*, int64_t&, int64_t&, kswr_t*, int32_t, int32_t, int);
 int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_t& pcnt8, kswr_t* aln, int32_t maxRefLen, int32_t maxQerLen, int tid) {
     static sam_pe_batch_fn next = (sam_pe_batch_fn)dlsym(RTLD_NEXT, "_Z16mem_sam_pe_batchPK9mem_opt_tP9mem_cacheRlS4_P6kswr_tiii");
     if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_sam_pe_batch was not found\n"); exit(1); }
+    const long b = tl_sam_batch;
+    const MateTable& T = g_mate;
+    if (matesw_on_device() && b >= 0 && T.gen == g_chunk_gen && g_chunk.seqs && (size_t)b + 1 < T.off.size() && T.off[(size_t)b + 1] - T.off[(size_t)b] == pcnt) {
+        if (pcnt) memcpy(aln, &T.aln[(size_t)T.off[(size_t)b]], (size_t)pcnt * sizeof(kswr_t));
+        g_mate_hits.fetch_add(pcnt, std::memory_order_relaxed);
+        return 1;
+    }
+    g_mate_miss.fetch_add(pcnt, std::memory_order_relaxed);
     const double t0 = now_s();
     const int64_t n = pcnt;
     const int rc = next(opt, mmc, pcnt, pcnt8, aln, maxRefLen, maxQerLen, tid);
     g_t_matesw = g_t_matesw + (now_s() - t0);
     g_n_matesw += n;
     return rc;
+}
+void meme_dropin_report_mate() {
+    if (!matesw_on_device()) return;
+    fprintf(stderr, "[meme-dropin] mate rescue on the device: %lld Smith-Waterman jobs posed so far (kernels %.3f s, whole pre-pass %.3f s); jobs answered from the table "
+            "%lld, run by the reference's kernels %lld\n", (long long)g_mate.n_jobs, g_mate.t_kernel_ms * 1e-3, g_mate.t_prepass, (long long)g_mate_hits.load(),
+            (long long)g_mate_miss.load());
 }
 namespace {
 std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0}, g_n_sam{0};
@@ -1590,10 +1727,27 @@ typedef void (*kt_for_fn)(void (*)(void*, long, long, int), void*, int);
 void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
     static kt_for_fn next = (kt_for_fn)dlsym(RTLD_NEXT, "_Z6kt_forPFvPvlliES_i");
     if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_for was not found\n"); exit(1); }
-    if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2 && cigar_on_device()) {
-        std::lock_guard<std::mutex> lk(g_cig.mu);
-        cig_prepass();
-        g_cig.gen = g_chunk_gen;
+    if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2) {
+        bool mate = false;
+#if __AVX512BW__          // (only this build of the reference batches mate rescue: src/bwamem.cpp:1838)
+        mate = matesw_on_device() && (g_opt->flag & MEM_F_PE) && !(g_opt->flag & MEM_F_NO_RESCUE) && !g_dev.empty();
+#endif
+        // the two pre-passes of the SAM phase side by side: both only read the chunk's alignment records; the CIGAR stage works on the
+        // seeding ctx of each GPU (it names the reads staged there), mate rescue on the other one
+        static const bool par = !(getenv("MEME_DROPIN_MATESW_PAR") && atoi(getenv("MEME_DROPIN_MATESW_PAR")) == 0);
+        std::thread mt;
+        if (mate && par) mt = std::thread(matesw_prepass);
+        if (cigar_on_device()) {
+            std::lock_guard<std::mutex> lk(g_cig.mu);
+            cig_prepass();
+            g_cig.gen = g_chunk_gen;
+        }
+        if (mate) {
+            if (par) mt.join(); else matesw_prepass();
+            g_sam_func = func;
+            next(sam_wrapper, data, n);
+            return;
+        }
     }
     next(func, data, n);
 }

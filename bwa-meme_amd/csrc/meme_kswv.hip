@@ -28,9 +28,9 @@
 namespace {
 
 constexpr int XBYTE = 0x10000, XSTOP = 0x20000, XSUBO = 0x40000, XSTART = 0x80000;      // src/ksw.h:31-34
-constexpr int KSWV_SCORE_LIMIT = 1 << 14;            // H and F fields of the column word
+constexpr int KSWV_SCORE_LIMIT = 1 << 12;            // H and F fields of the column word
 constexpr int N_KSWV_CLS = 6;
-constexpr int KSWV_CLS_Q[N_KSWV_CLS] = {64, 128, 160, 256, 384, 528};     // padded query columns per LDS size class: (q + 1) * 256 B per wavefront
+constexpr int KSWV_CLS_Q[N_KSWV_CLS] = {64, 128, 160, 256, 384, 528};     // padded query columns per LDS size class: (q + 2) * 256 B per wavefront
 
 struct KswvArgs {
     const meme_kswv_job* jobs;
@@ -45,6 +45,15 @@ struct KswvArgs {
 };
 
 typedef __attribute__((address_space(3))) unsigned int* lds_u32;
+
+__device__ __forceinline__ int max3_i32(int a, int b, int c) { int d; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// (f << 12 | h) in bits 8..31 above the low byte of the old word, two instructions
+__device__ __forceinline__ unsigned hf_repack(int h, int f, unsigned old) {
+    unsigned x, w;
+    asm("v_lshl_or_b32 %0, %1, 12, %2" : "=v"(x) : "v"(f), "v"(h));
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(w) : "v"(x), "v"(old), "s"(0x06050400u));
+    return w;
+}
 
 struct PassOut { int raw, score, te, qe, score2, te2; };
 
@@ -67,11 +76,11 @@ __device__ __forceinline__ PassOut kswv_pass(lds_u32 W, bool is8, const uint8_t*
     v = (xtra & XSTOP) ? (xtra & 0xffff) : 0x10000;
     const bool has_endsc = v <= (is8 ? 255 : 32767);
     const int endsc = v;
-    // column words: word j + 1 = {query code of column j (0..3, 4 = N, 5 = padding), H(i-1, j) = 0, F = 0}
+    // column words: word j + 1 = {query code of column j in the low byte (0..3, 4 = N, 5 = padding), H(i-1, j) = 0 in bits 8..19, F = 0 in 20..31}
     for (int j = 0; j < quanta; ++j) {
         unsigned c = 5u;
         if (j < qlen) { c = q[q_rev >= 0 ? q_rev - j : j]; c = c > 4u ? 4u : c; }
-        W[(j + 1) * 64] = c << 28;
+        W[(j + 1) * 64] = c;
     }
     int gmax = 0, te = -1, qe = 0, pimax = 0;
     bool mask = false, minsc_ok = false, exited = false;
@@ -80,36 +89,49 @@ __device__ __forceinline__ PassOut kswv_pass(lds_u32 W, bool is8, const uint8_t*
     int wave_rows = tlen;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int y = __shfl_xor(wave_rows, d); wave_rows = wave_rows > y ? wave_rows : y; }
+    const unsigned mm4 = (unsigned)(w_mismatch & 0xff) * 0x01010101u, am4 = (unsigned)(w_ambig & 0xff) * 0x01010101u;
+    const unsigned tab_hi = (unsigned)(w_ambig & 0xff);                        // code 4 (N): ambiguous; code 5 (padding): 0
     for (int i = 0; i < wave_rows; ++i) {
         const bool live = i < tlen && !exited;
         if (!__any(live)) break;
         if (live) {
             const int tb = tb_next;
             if (i + 1 < tlen) tb_next = t[i + 1 <= t_rev ? t_rev - (i + 1) : i + 1];
-            const int s_eq = tb > 3 ? w_ambig : w_match, s_ne = tb > 3 ? w_ambig : w_mismatch;
-            int e = 0, diag = 0, imax = 0, iqe = -1;
-            unsigned nxt = W[64];
-            for (int j = 0; j < quanta; ++j) {
-                const unsigned cur = nxt;
-                if (j + 1 < quanta) nxt = W[(j + 2) * 64];
-                const int hold = (int)(cur & 0x3fffu), f = (int)((cur >> 14) & 0x3fffu), qc = (int)(cur >> 28);
-                const int sc = qc > 4 ? 0 : (qc > 3 ? w_ambig : (qc == tb ? s_eq : s_ne));
-                int m = diag + sc;
-                m = m < cap ? m : cap;
-                int h = m > e ? m : e;
-                h = h > f ? h : f;
-                h = h > 0 ? h : 0;
-                iqe = h > imax ? j : iqe;
-                imax = h > imax ? h : imax;
-                int g = h - oe_ins, e2 = e - e_ins;
-                g = g > e2 ? g : e2;
-                e = g > 0 ? g : 0;
-                int dl = h - oe_del, f2 = f - e_del;
-                dl = dl > f2 ? dl : f2;
-                dl = dl > 0 ? dl : 0;
-                W[(j + 1) * 64] = (unsigned)h | ((unsigned)dl << 14) | (cur & (7u << 28));
-                diag = hold;
+            // the row's scores as a byte table indexed by the query code (v_perm_b32 picks byte `code` of {tab_hi, tab_lo})
+            const unsigned tab_lo = tb > 3 ? am4 : (mm4 & ~(0xffu << (8 * tb))) | ((unsigned)(w_match & 0xff) << (8 * tb));
+            int e = 0, diag = 0;
+            // Four columns per trip with rotating registers (the next word is requested a cell ahead); the row maximum and its FIRST column as
+            // one key (h << 10 | 1023 - column), one accumulator per unrolled position (mk - position, joined below)
+#define KSWV_CELL(cur_, nxt_, j_, mk_, jr_)                                                                   \
+            {                                                                                                  \
+                nxt_ = W[((j_) + 2) * 64];                     /* (one word of slack behind the last column) */  \
+                const int hold = (int)((cur_ >> 8) & 0xfffu), f = (int)(cur_ >> 20);                            \
+                const int sc = (int)(signed char)(__builtin_amdgcn_perm(tab_hi, tab_lo, cur_) & 0xffu);         \
+                int m = diag + sc;                                                                             \
+                m = m < cap ? m : cap;                                                                         \
+                const int h = max3_i32(m, e, f);               /* (e, f >= 0) */                               \
+                const int key = (h << 10) + (jr_);                                                             \
+                mk_ = mk_ > key ? mk_ : key;                                                                   \
+                e = max3_i32(h - oe_ins, e - e_ins, 0);                                                        \
+                const int f2 = max3_i32(h - oe_del, f - e_del, 0);                                             \
+                W[((j_) + 1) * 64] = hf_repack(h, f2, cur_);                                                   \
+                diag = hold;                                                                                   \
             }
+            unsigned wa = W[64], wb = 0u, wc = 0u, wd = 0u;
+            int mk0 = -8, mk1 = -8, mk2 = -8, mk3 = -8;
+            for (int j = 0; j < quanta; j += 4) {
+                const int jr = 1023 - j;
+                KSWV_CELL(wa, wb, j, mk0, jr)
+                KSWV_CELL(wb, wc, j + 1, mk1, jr)
+                KSWV_CELL(wc, wd, j + 2, mk2, jr)
+                KSWV_CELL(wd, wa, j + 3, mk3, jr)
+            }
+#undef KSWV_CELL
+            mk1 -= 1; mk2 -= 2; mk3 -= 3;
+            const int ka = mk0 > mk1 ? mk0 : mk1, kb = mk2 > mk3 ? mk2 : mk3;
+            const int key = ka > kb ? ka : kb;
+            const int imax = key < 0 ? 0 : key >> 10;
+            const int iqe = 1023 - (key & 1023);
             if (i > 0) {                                                   // Block I (src/kswv.cpp:505-518, :1063-1078)
                 const bool msk = imax > pimax || mask;
                 rm[(i64)(i - 1) * 64] = (unsigned short)((!msk && minsc_ok) ? pimax : none);
@@ -250,7 +272,7 @@ extern "C" int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, in
         A.ref = (const uint8_t*)K[2].p; A.qer = (const uint8_t*)K[3].p; A.out = (meme_kswr*)K[4].p;
         A.rowmax = (unsigned short*)K[5].p; A.rm_off = (const i64*)K[6].p + L.w0;
         A.a = opt->a; A.b = opt->b; A.o_del = opt->o_del; A.e_del = opt->e_del; A.o_ins = opt->o_ins; A.e_ins = opt->e_ins;
-        const size_t lds = (size_t)(L.qmax + 1) * 256;
+        const size_t lds = (size_t)(L.qmax + 2) * 256;
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_kswv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_kswv, dim3((unsigned)((L.count + 63) / 64)), dim3(64), lds, ctx->stream, A);
     }

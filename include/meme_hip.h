@@ -281,7 +281,7 @@ int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int64_t njobs, 
  * (src/ksw.h:31-34): KSW_XBYTE selects the int8 arithmetic of getScores8 (sort_classify, src/bwamem.cpp:1798-1825), KSW_XSUBO the
  * second-best score, KSW_XSTART the second pass for the start.  Results are kswr_t records (src/ksw.h:44-50), field for field what the
  * AVX-512 build of the reference produces (its stripe padding, tie rules and kept-row-maximum rule included).  opt: a, b, o_del, e_del,
- * o_ins, e_ins (match a, mismatch -b, N -1).  Limits: len2 <= 512, len2 * a < 16384, len1 <= 32767 (the reference's own: int16 lanes). */
+ * o_ins, e_ins (match a, mismatch -b, N -1).  Limits: len2 <= 512, len2 * a < 4096, len1 <= 32767 (the reference's own: reads of at most 500 bases, int16 lanes). */
 typedef struct { int64_t idr, idq; int32_t len1, len2, xtra, pad; } meme_kswv_job;
 typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } meme_kswr;
 typedef struct { int64_t njobs; const meme_kswr* res; /* pinned, owned by the ctx, valid until its next kswv call */ float kernel_ms; } meme_kswv_host_result;

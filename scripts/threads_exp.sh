@@ -1,8 +1,5 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_chain.py tests/test_gpu_ext.py -x -q -m gpu 2>&1 | tail -3
-for q in 8 4; do
-GPU_MAX_HW_QUEUES=$q rocprofv3 --kernel-trace --stats -d gpurun_out/chain_trace -o c -- python scripts/chain_probe.py 3100 2 > gpurun_out/chain_trace.log 2>&1
-echo "== GPU_MAX_HW_QUEUES=$q"; grep "chain kernels" gpurun_out/chain_trace.log
-python scripts/rocpd_timeline.py gpurun_out/chain_trace/c_results.db k_chain 10
-rm -rf gpurun_out/chain_trace
-done
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do
+for m in "MEME_DROPIN_MATESW=0" "MEME_DROPIN_MATESW_PAR=0"; do
+env $m E2E_SKIP_REF=1 E2E_READ_LEN=250 E2E_SUB=0.05 python scripts/e2e_bench.py 256 1 64 2>&1 | grep -E "WORKER_SAM|MEM_PROCESS_SEQ|whole pre-pass" | sed -e 's/.*WORKER_SAM avg: \([0-9.]*\).*/SAM \1/' -e 's/.*MEM_PROCESS_SEQ.*avg: \([0-9.]*\).*/PROC \1/' -e 's/.*mate rescue.*: \([0-9]*\) Smith.*kernels \([0-9.]*\) s, whole pre-pass \([0-9.]*\).*/MATE jobs \1 kern \2 pre \3/' -e 's/.*CIGAR.*whole pre-pass \([0-9.]*\).*/CIGPRE \1/' | tr '\n' ' '; echo " <- $m"
+done; done
