@@ -1328,18 +1328,29 @@ void BandedPairWiseSW::getScores8(SeqPair* p, uint8_t* r, uint8_t* q, int32_t n,
 // the kswv kernels, mem_sam_pe_batch_post turns the results into alignment records.  At the SAM phase's quiescent point (the interposed
 // third kt_for call, as for the CIGAR stage) the binding runs the reference's own mem_sam_pe_batch_pre for every batch of the chunk into
 // buffers of its own -- the step reads the alignment records and writes only to the mem_cache it is given --, sends the jobs of the whole
-// chunk to the GPU(s) in one meme_kswv_batch_host call each, and keeps the kswr_t records per batch; worker_sam then runs unchanged, and its
-// mem_sam_pe_batch call is answered from that table (same jobs in the same order: the step is deterministic).  A batch the table does
-// not hold goes to the reference's function.  MEME_DROPIN_MATESW=0 switches the stage off.
+// chunk to the GPU(s) in one meme_kswv_batch_host call each, and keeps per batch the kswr_t records and the job index array (`gar`) the
+// first step left for the third.  The kt_for call then runs sam_worker_dev instead of worker_sam: the third step of worker_sam's
+// paired-end branch as written there (src/bwamem.cpp:1879-1900: mem_sam_pe_batch_post per pair, which also writes the SAM text, then the
+// pair's alignment arrays are freed), fed from the table.
+// OFF unless MEME_DROPIN_MATESW=1: measured on 2 M pairs of 150-bp reads (-t 64, 185 406 jobs) the stage costs 0.2-0.4 s of the SAM phase's
+// 1.3 s instead of saving the ~0.1 s the host's 64 threads spend in the kswv kernels -- the jobs are few (one per ~22 reads; a 250-bp / 5 %
+// run poses 5 000 in all), their kernel time is small next to the pre-pass that has to pose them ahead of worker_sam (0.12 s, of which
+// kernels 0.03-0.05 s), and the third step then meets the alignment records cold.  SAM output is identical either way (tests).
 #include <omp.h>
 #include "kswv.h"
 namespace {
 std::atomic<double> g_t_matesw{0};
 std::atomic<int64_t> g_n_matesw{0};
-bool matesw_on_device() { static const bool v = !(getenv("MEME_DROPIN_MATESW") && atoi(getenv("MEME_DROPIN_MATESW")) == 0); return v; }
+bool matesw_on_device() { static const bool v = getenv("MEME_DROPIN_MATESW") && atoi(getenv("MEME_DROPIN_MATESW")) != 0; return v; }
+// One job per lane needs tens of thousands of jobs to fill the GPU (a chunk of 666 k reads poses ~31 k: 8 ms of kernel for what the host's
+// 64 threads do in about as long); below this many jobs per chunk the reference's own batch runs (the bigger chunks bwa-meme reads by
+// default -- 10 M bases x threads -- pose ~50 jobs per 1 000 reads: 200 k per chunk at -t 64).  MEME_DROPIN_MATESW_MIN overrides.
+int64_t matesw_min_jobs() { static const int64_t v = getenv("MEME_DROPIN_MATESW_MIN") ? atoll(getenv("MEME_DROPIN_MATESW_MIN")) : 65536; return v; }
+double g_mate_jobs_per_read = -1;                // of the last chunk whose jobs were posed
 struct MateTable {
     std::vector<int64_t> off;                    // first record of every worker batch (+ the total)
     std::vector<kswr_t> aln;                     // records, batch after batch, in the order the jobs were posed (= regid)
+    std::vector<std::vector<int32_t>> gar;       // per batch: job index (or -1) of every (alignment, orientation) mem_matesw_batch_pre looked at
     uint64_t gen = 0;                            // chunk the table belongs to
     double t_prepass = 0, t_kernel_ms = 0;
     int64_t n_jobs = 0;
@@ -1347,9 +1358,24 @@ struct MateTable {
     int slots = 0;
 } g_mate;
 std::atomic<int64_t> g_mate_hits{0}, g_mate_miss{0};
-thread_local long tl_sam_batch = -1;            // batch worker_sam is working on in this thread (set by sam_wrapper)
-void (*g_sam_func)(void*, long, long, int) = nullptr;
-void sam_wrapper(void* data, long st, long len, int tid) { tl_sam_batch = st / BATCH_SIZE; g_sam_func(data, st, len, tid); tl_sam_batch = -1; }
+// worker_sam's paired-end branch after its first two steps (src/bwamem.cpp:1879-1900), the results of those coming from the table
+void sam_worker_dev(void* data, long seqid, long batch_size, int tid) {
+    worker_t* w = (worker_t*)data;
+    const MateTable& T = g_mate;
+    const size_t b = (size_t)(seqid / BATCH_SIZE);
+    const std::vector<int32_t>& gar = T.gar[b];
+    if (!gar.empty()) memcpy(w->mmc.seqPairArrayAux[tid], gar.data(), gar.size() * sizeof(int32_t));     // where mem_sam_pe_batch_post reads it
+    kswr_t* myaln = const_cast<kswr_t*>(T.aln.data()) + T.off[b];
+    int32_t gcnt = 0;
+    int pos = (int)(seqid >> 1);
+    for (long i = seqid; i < seqid + batch_size; i += 2) {
+        mem_sam_pe_batch_post(w->opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], &myaln, &w->mmc,
+                              gcnt, tid);
+        free(w->regs[i].a);
+        free(w->regs[i + 1].a);
+    }
+    g_mate_hits.fetch_add(T.off[b + 1] - T.off[b], std::memory_order_relaxed);
+}
 int cig_threads();
 
 void mate_cache_init(int slots) {
@@ -1372,7 +1398,7 @@ void mate_cache_init(int slots) {
     g_mate.cache = C; g_mate.slots = slots;
 }
 
-void matesw_prepass() {
+bool matesw_prepass() {                          // false: too few jobs for the device, worker_sam runs as it is
     const double t0 = now_s();
     worker_t* w = g_worker;
     const mem_opt_t* opt = g_opt;
@@ -1382,6 +1408,7 @@ void matesw_prepass() {
     if (!g_mate.cache) mate_cache_init(nt);
     struct BatchJobs { std::vector<meme_kswv_job> jobs; std::vector<uint8_t> ref, qer; };
     std::vector<BatchJobs> B((size_t)nb);
+    g_mate.gar.assign((size_t)nb, std::vector<int32_t>());
 #pragma omp parallel for schedule(dynamic, 1) num_threads(g_mate.slots)
     for (int64_t b = 0; b < nb; ++b) {
         const int t = omp_get_thread_num();
@@ -1393,6 +1420,7 @@ void matesw_prepass() {
             mem_sam_pe_batch_pre(opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], g_mate.cache,
                                  pcnt, gcnt, maxRef, maxQer, t);
         BatchJobs& J = B[(size_t)b];
+        g_mate.gar[(size_t)b].assign((const int32_t*)g_mate.cache->seqPairArrayAux[t], (const int32_t*)g_mate.cache->seqPairArrayAux[t] + gcnt);
         if (pcnt == 0) continue;
         const SeqPair* sp = g_mate.cache->seqPairArrayLeft128[t];
         const int64_t rbytes = (int64_t)sp[pcnt - 1].idr + sp[pcnt - 1].len1, qbytes = (int64_t)sp[pcnt - 1].idq + sp[pcnt - 1].len2;
@@ -1405,6 +1433,8 @@ void matesw_prepass() {
     T.off.assign((size_t)nb + 1, 0);
     for (int64_t b = 0; b < nb; ++b) T.off[(size_t)b + 1] = T.off[(size_t)b] + (int64_t)B[(size_t)b].jobs.size();
     const int64_t total = T.off[(size_t)nb];
+    g_mate_jobs_per_read = n > 0 ? (double)total / (double)n : 0;
+    if (total < matesw_min_jobs()) { T.t_prepass += now_s() - t0; T.gen = 0; return false; }
     T.aln.resize((size_t)total);
     // the chunk's batches in contiguous runs over the GPUs, one call each
     const int nd = (int)g_dev.size();
@@ -1443,20 +1473,15 @@ void matesw_prepass() {
     for (double v : kms) km = km > v ? km : v;
     T.t_kernel_ms += km; T.n_jobs += total; T.t_prepass += now_s() - t0;
     T.gen = g_chunk_gen;
+    return true;
 }
 }  // namespace
 
+// (with the stage off: the reference's batch, timed)
 typedef int (*sam_pe_batch_fn)(const mem_opt_t*, mem_cache*, int64_t&, int64_t&, kswr_t*, int32_t, int32_t, int);
 int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_t& pcnt8, kswr_t* aln, int32_t maxRefLen, int32_t maxQerLen, int tid) {
     static sam_pe_batch_fn next = (sam_pe_batch_fn)dlsym(RTLD_NEXT, "_Z16mem_sam_pe_batchPK9mem_opt_tP9mem_cacheRlS4_P6kswr_tiii");
     if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_sam_pe_batch was not found\n"); exit(1); }
-    const long b = tl_sam_batch;
-    const MateTable& T = g_mate;
-    if (matesw_on_device() && b >= 0 && T.gen == g_chunk_gen && g_chunk.seqs && (size_t)b + 1 < T.off.size() && T.off[(size_t)b + 1] - T.off[(size_t)b] == pcnt) {
-        if (pcnt) memcpy(aln, &T.aln[(size_t)T.off[(size_t)b]], (size_t)pcnt * sizeof(kswr_t));
-        g_mate_hits.fetch_add(pcnt, std::memory_order_relaxed);
-        return 1;
-    }
     g_mate_miss.fetch_add(pcnt, std::memory_order_relaxed);
     const double t0 = now_s();
     const int64_t n = pcnt;
@@ -1467,7 +1492,7 @@ int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_
 }
 void meme_dropin_report_mate() {
     if (!matesw_on_device()) return;
-    fprintf(stderr, "[meme-dropin] mate rescue on the device: %lld Smith-Waterman jobs posed so far (kernels %.3f s, whole pre-pass %.3f s); jobs answered from the table "
+    fprintf(stderr, "[meme-dropin] mate rescue on the device: %lld Smith-Waterman jobs posed so far (kernels %.3f s, whole pre-pass %.3f s); jobs whose results worker_sam's third step took from the table "
             "%lld, run by the reference's kernels %lld\n", (long long)g_mate.n_jobs, g_mate.t_kernel_ms * 1e-3, g_mate.t_prepass, (long long)g_mate_hits.load(),
             (long long)g_mate_miss.load());
 }
@@ -1732,20 +1757,15 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
 #if __AVX512BW__          // (only this build of the reference batches mate rescue: src/bwamem.cpp:1838)
         mate = matesw_on_device() && (g_opt->flag & MEM_F_PE) && !(g_opt->flag & MEM_F_NO_RESCUE) && !g_dev.empty();
 #endif
-        // the two pre-passes of the SAM phase side by side: both only read the chunk's alignment records; the CIGAR stage works on the
-        // seeding ctx of each GPU (it names the reads staged there), mate rescue on the other one
-        static const bool par = !(getenv("MEME_DROPIN_MATESW_PAR") && atoi(getenv("MEME_DROPIN_MATESW_PAR")) == 0);
-        std::thread mt;
-        if (mate && par) mt = std::thread(matesw_prepass);
+        // (a chunk that will not reach the job threshold -- by the previous chunk's jobs per read -- is not posed at all)
+        if (mate && g_mate_jobs_per_read >= 0 && g_mate_jobs_per_read * (double)g_chunk.n < (double)matesw_min_jobs()) mate = false;
         if (cigar_on_device()) {
             std::lock_guard<std::mutex> lk(g_cig.mu);
             cig_prepass();
             g_cig.gen = g_chunk_gen;
         }
-        if (mate) {
-            if (par) mt.join(); else matesw_prepass();
-            g_sam_func = func;
-            next(sam_wrapper, data, n);
+        if (mate && matesw_prepass()) {
+            next(sam_worker_dev, data, n);
             return;
         }
     }

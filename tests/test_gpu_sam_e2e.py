@@ -15,6 +15,10 @@ from pymeme import synth
 pytestmark = pytest.mark.gpu
 
 REF = R.REF_DIR
+# the mate-rescue stage is opt-in (it does not pay at the job counts real chunks pose) and then only engages on chunks that pose tens of
+# thousands of Smith-Waterman jobs: here every paired-end run uses it
+os.environ.setdefault("MEME_DROPIN_MATESW", "1")
+os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
 
 
 def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000):
@@ -265,8 +269,10 @@ def test_sam_identical_mixed_250bp_high_error_paired(tmp_path):
     m = list(re.finditer(r"ksw_global2 calls answered from the table (\d+), computed by the reference's function (\d+)", err))
     assert m and int(m[-1].group(1)) > 5000 and int(m[-1].group(1)) > 20 * int(m[-1].group(2)), err[-1500:]   # the CIGAR table answers (nearly) all calls
     assert re.search(r"0 reads chained on the host", err)
-    # and with the CIGAR stage off the same SAM comes out (the table only ever replaces identical answers)
-    got2 = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CIGAR="0"), threads=8, chunk=700000)
+    m = list(re.finditer(r"mate rescue on the device: (\d+) Smith-Waterman jobs posed.*took from the table (\d+), run by the reference's kernels (\d+)", err))
+    assert m and int(m[-1].group(1)) > 200 and int(m[-1].group(2)) == int(m[-1].group(1)) and int(m[-1].group(3)) == 0, err[-1500:]
+    # and with the CIGAR stage / the mate-rescue stage off the same SAM comes out (the tables only ever replace identical answers)
+    got2 = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CIGAR="0", MEME_DROPIN_MATESW="0"), threads=8, chunk=700000)
     assert got2 == got
 
 

@@ -12,6 +12,8 @@ import ref_py as R
 from pymeme import hostapi, synth, workload
 
 pytestmark = pytest.mark.gpu
+os.environ.setdefault("MEME_DROPIN_MATESW", "1")          # (the opt-in mate-rescue stage too, whatever the number of jobs)
+os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
 
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
