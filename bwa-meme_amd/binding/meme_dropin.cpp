@@ -273,6 +273,7 @@ FILE* chain_dump() { static FILE* f = getenv("MEME_DROPIN_CHAIN_DUMP") ? fopen(g
 std::mutex g_dump_mu;
 std::atomic<int64_t> g_n_chain_fallback{0}, g_n_chain_reads{0};
 
+int cig_threads();
 meme_seed_opt seed_opt_of(const mem_opt_t* opt) {
     meme_seed_opt so;
     so.min_seed_len = opt->min_seed_len;
@@ -290,7 +291,9 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     for (int64_t i = 0; i < P.count; ++i) { P.off[i] = bytes; bytes += seqs[P.first + i].l_seq; }
     P.off[P.count] = bytes;
     if (bytes + 16 > P.flat_cap) { meme_host_free(P.flat); P.flat_cap = bytes + bytes / 4 + 4096; if (!(P.flat = (uint8_t*)meme_host_alloc(P.flat_cap))) die("meme_host_alloc"); }
-#pragma omp parallel for schedule(static)
+    // (a few dozen helper threads: an OpenMP team of all 256 host threads takes longer to start than the loop runs, and keeps spinning
+    // into the worker phases that follow)
+#pragma omp parallel for schedule(static) num_threads(cig_threads())
     for (int64_t i = 0; i < P.count; ++i) {
         // base codes in place, as the reference leaves them for the later stages (src/bwamem.cpp:1277-1279)
         bseq1_t& s = seqs[P.first + i];

@@ -61,7 +61,29 @@ __device__ inline int intv2rid(const ChainArgs& A, i64 rb, i64 re) {      // bns
     return rid_b == rid_e ? rid_b : -1;
 }
 
-__device__ inline int chain_weight(const DChain& c, const DSeed* row) {   // mem_chain_weight, src/bwamem.cpp:522-541
+// The lane-per-read tier keeps a read's chains and seeds in HBM scratch.  The 64 reads of a wavefront interleave their arrays element by
+// element (element i of lane L at [i * 64 + L]): when the lanes touch the same element of their own arrays -- which they mostly do, chain
+// 0 first -- the wavefront reads consecutive addresses instead of 64 scattered lines.  SPtr<T> is a pointer into such an array.
+template <typename T> struct SPtr {
+    T* p;
+    __device__ T& operator*() const { return *p; }
+    __device__ T* operator->() const { return p; }
+    __device__ T& operator[](int i) const { return p[(i64)i * 64]; }
+    __device__ SPtr operator+(int i) const { return SPtr{p + (i64)i * 64}; }
+    __device__ SPtr operator-(int i) const { return SPtr{p - (i64)i * 64}; }
+    __device__ int operator-(SPtr o) const { return (int)((p - o.p) >> 6); }
+    __device__ SPtr& operator++() { p += 64; return *this; }
+    __device__ SPtr& operator--() { p -= 64; return *this; }
+    __device__ bool operator<(SPtr o) const { return p < o.p; }
+    __device__ bool operator<=(SPtr o) const { return p <= o.p; }
+    __device__ bool operator>(SPtr o) const { return p > o.p; }
+    __device__ bool operator==(SPtr o) const { return p == o.p; }
+    __device__ bool operator!=(SPtr o) const { return p != o.p; }
+};
+typedef SPtr<DChain> ChP;
+typedef SPtr<DSeed> SdP;
+
+__device__ inline int chain_weight(const DChain& c, SdP row) {   // mem_chain_weight, src/bwamem.cpp:522-541
     i64 end = 0;
     int w = 0;
     for (int j = 0; j < c.n; ++j) {
@@ -88,33 +110,33 @@ __device__ inline void swap_chain(DChain& a, DChain& b) { const DChain t = a; a 
 // ks_introsort (klib ksort.h), restated: two elements are compared and swapped; otherwise quicksort around the median of first /
 // middle / last with an explicit stack, sub-ranges of at most 16 elements are left to the final insertion sort, comb sort takes
 // over when the depth budget is spent.  (Up to 16 elements this is ONE partition pass over the whole array + insertion sort.)
-__device__ inline void insert_sort(DChain* s, DChain* t) {
-    for (DChain* i = s + 1; i < t; ++i)
-        for (DChain* j = i; j > s && FLT_LT(*j, *(j - 1)); --j) swap_chain(*j, *(j - 1));
+__device__ inline void insert_sort(ChP s, ChP t) {
+    for (ChP i = s + 1; i < t; ++i)
+        for (ChP j = i; j > s && FLT_LT(*j, *(j - 1)); --j) swap_chain(*j, *(j - 1));
 }
-__device__ void comb_sort(int n, DChain* a) {
+__device__ void comb_sort(int n, ChP a) {
     const double shrink = 1.2473309501039786540366528676643;
     bool do_swap;
     int gap = n;
     do {
         if (gap > 2) { gap = (int)(gap / shrink); if (gap == 9 || gap == 10) gap = 11; }
         do_swap = false;
-        for (DChain* i = a; i < a + n - gap; ++i) { DChain* j = i + gap; if (FLT_LT(*j, *i)) { swap_chain(*i, *j); do_swap = true; } }
+        for (ChP i = a; i < a + (n - gap); ++i) { ChP j = i + gap; if (FLT_LT(*j, *i)) { swap_chain(*i, *j); do_swap = true; } }
     } while (do_swap || gap > 2);
     if (gap != 1) insert_sort(a, a + n);
 }
-__device__ void sort_by_weight(DChain* a, int n) {
+__device__ void sort_by_weight(ChP a, int n) {
     if (n < 1) return;
     if (n == 2) { if (FLT_LT(a[1], a[0])) swap_chain(a[0], a[1]); return; }
-    struct { DChain *left, *right; int depth; } stack[40], *top = stack;
+    struct { ChP left, right; int depth; } stack[40], *top = stack;
     int d;
     for (d = 2; (1 << d) < n; ++d) {}
-    DChain *s = a, *t = a + (n - 1);
+    ChP s = a, t = a + (n - 1);
     d <<= 1;
     for (;;) {
         if (s < t) {
-            if (--d == 0) { comb_sort((int)(t - s) + 1, s); t = s; continue; }
-            DChain *i = s, *j = t, *k = i + ((j - i) >> 1) + 1;
+            if (--d == 0) { comb_sort((t - s) + 1, s); t = s; continue; }
+            ChP i = s, j = t, k = i + (((j - i) >> 1) + 1);
             if (FLT_LT(*k, *i)) { if (FLT_LT(*k, *j)) k = j; }
             else k = FLT_LT(*j, *i) ? i : j;
             const DChain rp = *k;
@@ -157,8 +179,8 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
     const int ns = (int)(A.smem_off[r + 1] - A.smem_off[r]);
     const u64* ht = A.hits + A.hit_off[r];
     const int len = (int)(A.read_off[r + 1] - A.read_off[r]);
-    DChain* ch = A.ch + tid * CC;
-    DSeed* sd = A.sd + tid * (CC * SC);
+    const ChP ch{A.ch + (i64)blockIdx.x * 64 * CC + threadIdx.x};           // (interleaved over the wavefront's 64 reads: SPtr)
+    const SdP sd{A.sd + (i64)blockIdx.x * 64 * (CC * SC) + threadIdx.x};
     ReadHdr H = {0, 0, 0, 0, tid, 0};
     float frac = 0.f;
     int nc = 0;
@@ -207,7 +229,7 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
                 bool merged = false;
                 if (lower >= 0) {                                         // test_and_merge, src/bwamem.cpp:450-492
                     DChain& c = ch[lower];
-                    DSeed* row = sd + c.row * SC;
+                    const SdP row = sd + c.row * SC;
                     const DSeed last = row[c.n - 1], first = row[0];
                     const i64 qend = last.qbeg + last.len, rend = last.rbeg + last.len;
                     if (rid == c.rid) {
@@ -258,11 +280,11 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
             for (int i = 1; i < n; ++i) {
                 bool large_ovlp = false;
                 int k = 0;
-                const DSeed* ri = sd + ch[i].row * SC;
+                const SdP ri = sd + ch[i].row * SC;
                 const int beg_i = ri[0].qbeg, end_i = ri[ch[i].n - 1].qbeg + ri[ch[i].n - 1].len;
                 for (; k < nk; ++k) {
                     const int j = kept_idx[k];
-                    const DSeed* rj = sd + ch[j].row * SC;
+                    const SdP rj = sd + ch[j].row * SC;
                     const int beg_j = rj[0].qbeg, end_j = rj[ch[j].n - 1].qbeg + rj[ch[j].n - 1].len;
                     const int b_max = beg_j > beg_i ? beg_j : beg_i;
                     const int e_min = end_j < end_i ? end_j : end_i;
@@ -863,6 +885,8 @@ __device__ __forceinline__ unsigned dist_below(i64 pos, i64 rb) {
 // lane-per-read tier, which fills every SIMD, and are the long pole.  (Round 3 also had this tier with the chains in registers, slot =
 // k * 64 + lane, fields read through v_readlane: same speed as N = 256 here, three hundred lines more; removed.)
 
+constexpr int PAR_MIN_HITS = 3;         // hits of one SMEM batch from which on they may be tested against the chains at once
+
 template <int N>
 __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
     static_assert(N <= 2048, "the lookup key keeps the slot in 11 bits");
@@ -928,7 +952,16 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
             const bool have = c < cnt;
             const i64 h_rbeg = have ? (i64)ht[p.hitbeg + (i64)c * step] : 0;
             const int h_rid = have ? intv2rid(A, h_rbeg, h_rbeg + slen) : -1;
-            u64 todo = __ballot(h_rid >= 0);
+            u64 rem = __ballot(h_rid >= 0);                                 // (:1166: seeds bridging two sequences or the strands are dropped)
+            // The hits of one SMEM share query span and length; most of them fall far from each other.  With enough of them the 64 hits of the
+            // batch are tested against the chains AT ONCE (every lane its own hit, the chains read from LDS) and the longest prefix of them
+            // whose outcomes cannot depend on each other is committed in one step; the rest is tested again against the new state.  A hit's
+            // outcome depends on an earlier hit of the batch only if that one (a) appended to the chain this one is tested against, or
+            // (b) opened a new chain at a position between this hit's lower chain and the hit itself: then that chain becomes the lower one --
+            // a single seed of the same span, which this hit can only merge with when it starts within the band w behind it (or at the same
+            // position: the B-tree tier's case); farther away the outcome is "new chain" whatever the snapshot said.
+            const bool par_mode = __popcll(rem) >= PAR_MIN_HITS && __popcll(rem) * 16 > nchain + 16;   // (one round costs about a hit per 16 chains)
+            auto seq_hits = [&](u64 todo) {
             while (todo) {
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1;
@@ -983,6 +1016,83 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
                     WQ[id] = slen; EQ[id] = qb + slen; WR[id] = slen; ER[id] = slen;
                 }
             }
+            };
+            if (!par_mode) { seq_hits(rem); continue; }
+            while (rem && !bail) {
+                // 1. the lower chain of every remaining hit in the current state
+                const i64 rbj = h_rbeg;
+                i64 bp = -1;
+                int bs = 0;
+                for (int s2 = 0; s2 < nchain; ++s2) { const i64 ps = s_pos[s2]; if (ps <= rbj && ps > bp) { bp = ps; bs = s2; } }
+                // 2. test_and_merge against it (:450-492)
+                int out = 2;
+                if (bp >= 0) {
+                    const int c_rid = RID[bs], c_fqb = FQB[bs], c_lrb = LRB[bs], c_lqb = LQB[bs], c_lln = LLN[bs];
+                    const i64 l_rbeg = bp + c_lrb;
+                    if (h_rid == c_rid) {
+                        const i64 qend = c_lqb + c_lln, rend = l_rbeg + c_lln;
+                        if (qb >= c_fqb && qb + slen <= qend && rbj >= bp && rbj + slen <= rend) out = 0;
+                        else if ((l_rbeg < o.l_pac || bp < o.l_pac) && rbj >= o.l_pac) out = 2;
+                        else {
+                            const i64 x = qb - c_lqb, y = rbj - l_rbeg;
+                            if (y >= 0 && x - y <= o.w && y - x <= o.w && x - c_lln < o.max_chain_gap && y - c_lln < o.max_chain_gap) out = 1;
+                        }
+                    }
+                }
+                // 3. in hit order: which outcomes stand
+                const bool mine = (rem >> lane) & 1;
+                i64 mp = bp;
+                int conf = 0, newlow = 0;
+                u64 com = 0;
+                for (u64 scan = rem; scan;) {
+                    const int i = __builtin_ctzll(scan);
+                    scan &= scan - 1;
+                    if (rdl(conf, i)) break;
+                    com |= (u64)1 << i;
+                    const int oi = rdl(out, i);
+                    if (oi == 2) {
+                        const i64 rbi = rdl64(h_rbeg, i);
+                        if (mine && lane > i && mp < rbi && rbi <= rbj) {
+                            if (rbj - rbi <= (i64)(o.w > 0 ? o.w : 0)) conf = 1;
+                            else { out = 2; mp = rbi; newlow = 1; }
+                        }
+                    } else if (oi == 1) {
+                        const int ci = rdl(bs, i);
+                        if (mine && lane > i && !newlow && bp >= 0 && bs == ci) conf = 1;
+                    }
+                }
+                // 4. commit
+                const bool in = (com >> lane) & 1;
+                const u64 nzm = __ballot(in && out != 0), newm = __ballot(in && out == 2);
+                if (__ballot(in && out == 2 && !newlow && bp == rbj) != 0 || nchain + __popcll(newm) > N) { bail = 1; break; }   // equal positions / too many chains
+                const int sid = nseed + __popcll(nzm & below), id = nchain + __popcll(newm & below);
+                if (in && out != 0) { S2 sn; sn.rbeg = rbj; sn.qbeg = qb; sn.len = slen; sn.next = -1; sn.pad = 0; S[sid] = sn; }
+                if (in && out == 1) {
+                    S[TAIL[bs]].next = sid;
+                    const int rel = (int)(rbj - bp);
+                    CN[bs] += 1; LRB[bs] = rel; LQB[bs] = qb; LLN[bs] = slen; TAIL[bs] = sid;
+                    const int q_e = EQ[bs], r_e = ER[bs];
+                    if (qb >= q_e) WQ[bs] += slen; else if (qb + slen > q_e) WQ[bs] += qb + slen - q_e;
+                    EQ[bs] = q_e > qb + slen ? q_e : qb + slen;
+                    if (rel >= r_e) WR[bs] += slen; else if (rel + slen > r_e) WR[bs] += rel + slen - r_e;
+                    ER[bs] = r_e > rel + slen ? r_e : rel + slen;
+                } else if (in && out == 2) {
+                    C[id].head = sid;
+                    s_pos[id] = rbj; RID[id] = h_rid; CN[id] = 1; FQB[id] = qb; LRB[id] = 0; LQB[id] = qb; LLN[id] = slen; TAIL[id] = sid;
+                    WQ[id] = slen; EQ[id] = qb + slen; WR[id] = slen; ER[id] = slen;
+                }
+                nseed += __popcll(nzm); nchain += __popcll(newm);
+                rem &= ~com;
+                __syncthreads();
+                // a run of hits that depend on each other (tandem copies): a few of them one by one, then at once again
+                if (__popcll(com) <= 2 && rem) {
+                    u64 few = 0;
+                    for (int k = 0; k < 8 && (rem & ~few); ++k) few |= (rem & ~few) & (~(rem & ~few) + 1);
+                    seq_hits(few);
+                    rem &= ~few;
+                    __syncthreads();
+                }
+            }
         }
     }
     PROF(9);
@@ -1025,33 +1135,63 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
         __syncthreads();
         for (int e = lane; e < n; e += 64) { const int id = EID[e]; EBEG[e] = FQB[id]; EEND[e] = END[id]; EALT[e] = ALT[id]; EFIRST[e] = -1; EKEPT[e] = 0; }
         __syncthreads();
-        EKEPT[0] = 3;
-        for (int i = 1; i < n; ++i) {
-            const int bi = EBEG[i], ei = EEND[i], wi = EW[i], ai = EALT[i];
-            bool large = false;
-            int brk = -1;
-            for (int cb = 0; cb < i && brk < 0; cb += 64) {
-                const int e = cb + lane;
-                bool lo = false, br = false;
-                if (e < i && EKEPT[e] != 0) {
-                    const int be = EBEG[e], ee = EEND[e], we = EW[e];
-                    const int b_max = be > bi ? be : bi, e_min = ee < ei ? ee : ei;
-                    if (e_min > b_max && (!EALT[e] || ai)) {
-                        const int li = ei - bi, lj = ee - be;
-                        const int min_l = li < lj ? li : lj;
-                        if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
-                            lo = true;
-                            br = (float)wi < (float)we * o.drop_ratio && we - wi >= o.min_seed_len << 1;
+        {
+            // the filter's view of the 64 heaviest chains lives in the lanes (chain e in lane e): most chains are shadowed by one of those,
+            // and then the step costs no LDS round trip; chain i's own values are requested one step ahead
+            const int be0 = lane < n ? EBEG[lane] : 0, ee0 = lane < n ? EEND[lane] : 0, we0 = lane < n ? EW[lane] : 0, alt0 = lane < n ? EALT[lane] : 0;
+            int kept0 = lane == 0 ? 3 : 0, first0 = -1;
+            int nbi = n > 1 ? EBEG[1] : 0, nei = n > 1 ? EEND[1] : 0, nwi = n > 1 ? EW[1] : 0, nai = n > 1 ? EALT[1] : 0;
+            for (int i = 1; i < n; ++i) {
+                const int bi = nbi, ei = nei, wi = nwi, ai = nai;
+                if (i + 1 < n) { nbi = EBEG[i + 1]; nei = EEND[i + 1]; nwi = EW[i + 1]; nai = EALT[i + 1]; }
+                bool large = false;
+                int brk = -1;
+                {
+                    bool lo = false, br = false;
+                    if (lane < i && kept0 != 0) {
+                        const int b_max = be0 > bi ? be0 : bi, e_min = ee0 < ei ? ee0 : ei;
+                        if (e_min > b_max && (!alt0 || ai)) {
+                            const int li = ei - bi, lj = ee0 - be0;
+                            const int min_l = li < lj ? li : lj;
+                            if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
+                                lo = true;
+                                br = (float)wi < (float)we0 * o.drop_ratio && we0 - wi >= o.min_seed_len << 1;
+                            }
                         }
                     }
+                    const u64 lom = __ballot(lo), brm = __ballot(br);
+                    u64 upto = ~(u64)0;
+                    if (brm) { const int kx = __builtin_ctzll(brm); brk = kx; upto = ((u64)2 << kx) - 1; }
+                    if (lo && ((upto >> lane) & 1) && first0 < 0) first0 = i;
+                    if (lom & upto) large = true;
                 }
-                const u64 lom = __ballot(lo), brm = __ballot(br);
-                u64 upto = ~(u64)0;
-                if (brm) { const int kx = __builtin_ctzll(brm); brk = cb + kx; upto = ((u64)2 << kx) - 1; }
-                if (lo && ((upto >> lane) & 1) && EFIRST[e] < 0) EFIRST[e] = i;
-                if (lom & upto) large = true;
+                for (int cb = 64; cb < i && brk < 0; cb += 64) {
+                    const int e = cb + lane;
+                    bool lo = false, br = false;
+                    if (e < i && EKEPT[e] != 0) {
+                        const int be = EBEG[e], ee = EEND[e], we = EW[e];
+                        const int b_max = be > bi ? be : bi, e_min = ee < ei ? ee : ei;
+                        if (e_min > b_max && (!EALT[e] || ai)) {
+                            const int li = ei - bi, lj = ee - be;
+                            const int min_l = li < lj ? li : lj;
+                            if ((float)(e_min - b_max) >= (float)min_l * o.mask_level && min_l < o.max_chain_gap) {
+                                lo = true;
+                                br = (float)wi < (float)we * o.drop_ratio && we - wi >= o.min_seed_len << 1;
+                            }
+                        }
+                    }
+                    const u64 lom = __ballot(lo), brm = __ballot(br);
+                    u64 upto = ~(u64)0;
+                    if (brm) { const int kx = __builtin_ctzll(brm); brk = cb + kx; upto = ((u64)2 << kx) - 1; }
+                    if (lo && ((upto >> lane) & 1) && EFIRST[e] < 0) EFIRST[e] = i;
+                    if (lom & upto) large = true;
+                }
+                if (brk < 0) {
+                    if (i < 64) { if (lane == i) kept0 = large ? 2 : 3; }
+                    else EKEPT[i] = large ? 2 : 3;
+                }
             }
-            if (brk < 0) EKEPT[i] = large ? 2 : 3;
+            if (lane < n) { EFIRST[lane] = first0; EKEPT[lane] = kept0; }
         }
         PROF(13);
         __syncthreads();
@@ -1059,7 +1199,9 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
         __syncthreads();
         for (int e = lane; e < n; e += 64) { if (LIDX[e] != 0) { const int f = EFIRST[e]; if (f >= 0) EKEPT[f] = 1; } }
         __syncthreads();
-        {
+        int n12 = 0;                                                    // chains of kind 1 / 2: at most max_chain_extend of them are kept (default: no limit)
+        for (int cb = 0; cb < n; cb += 64) { const int e = cb + lane; n12 += __popcll(__ballot(e < n && (EKEPT[e] == 1 || EKEPT[e] == 2))); }
+        if (n12 >= o.max_chain_extend) {
             int i = 0, k = 0;
             for (; i < n; ++i) {
                 const int kp = EKEPT[i];
@@ -1110,8 +1252,8 @@ __global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ c
         i64 so = seed_off[r];
         const i64 s0 = so;
         if (set == 0) {
-            const DChain* ch = ch1 + slot * CHAIN_CAP;
-            const DSeed* sd = sd1 + slot * (i64)CHAIN_CAP * SEED_CAP;
+            const SPtr<const DChain> ch{ch1 + (slot >> 6) * 64 * CHAIN_CAP + (slot & 63)};       // (the lane tier's interleaved scratch)
+            const SPtr<const DSeed> sd{sd1 + (slot >> 6) * 64 * (i64)CHAIN_CAP * SEED_CAP + (slot & 63)};
             for (int k = 0; k < H.n_kept; ++k) {
                 const DChain c = ch[k];
                 meme_chain m;
@@ -1119,7 +1261,7 @@ __global__ void __launch_bounds__(256) k_chain_pack(const DChain* __restrict__ c
                 m.seed_beg = (int32_t)(so - s0);
                 m.pad = 0;
                 out_ch[chain_off[r] + k] = m;
-                const DSeed* row = sd + c.row * SEED_CAP;
+                const SPtr<const DSeed> row = sd + c.row * SEED_CAP;
                 for (int j = 0; j < c.n; ++j) { meme_chain_seed s; s.rbeg = row[j].rbeg; s.qbeg = row[j].qbeg; s.len = row[j].len; out_sd[so++] = s; }
             }
         } else {
@@ -1239,8 +1381,8 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
         }
     DevBuf* B = ctx->chain;     // 0 tier-1 chains, 1 tier-1 seeds, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
                                 // 8 lists + work + offsets of the five wavefront launches + read classes, 9 .. 13 their scratch sets
-    if ((rc = meme_buf_reserve(ctx, B[0], (size_t)n * CHAIN_CAP * sizeof(DChain)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, B[1], (size_t)n * CHAIN_CAP * SEED_CAP * sizeof(DSeed)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, B[0], (size_t)((n + 63) / 64 * 64) * CHAIN_CAP * sizeof(DChain)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, B[1], (size_t)((n + 63) / 64 * 64) * CHAIN_CAP * SEED_CAP * sizeof(DSeed)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[2], (size_t)n * sizeof(ReadHdr)))) return rc;
     if ((rc = meme_buf_reserve(ctx, B[3], (size_t)n * sizeof(float)))) return rc;
     const size_t ctab = (size_t)n_contigs * (8 + 4 + 1) + 64;

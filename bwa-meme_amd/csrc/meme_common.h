@@ -69,7 +69,7 @@ struct meme_ctx {
                                        // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
-    i64 chain_light_hits = 64;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it
+    i64 chain_light_hits = 32;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it
     i64 chain_lane_hits = 256;         // hits per read the lane-per-read chaining tier walks; reads with more go to the wavefront tiers at once
     i64 chain_wave_tiers = 1;          // 0: the chaining stage skips the LDS tier (everything beyond the lane tier through the B-tree tier; tests)
     i64 bsw_blocks = 0;

@@ -25,6 +25,7 @@ reads = workload.make_reads_fast(g, nreads, 150, seed=1000)
 off = np.arange(0, (nreads + 1) * 150, 150, dtype=np.int64)
 contigs = [(l_pac * k // 8, l_pac * (k + 1) // 8 - l_pac * k // 8, 0) for k in range(8)]
 opt = hipapi.default_chain_opt(l_pac)
+if os.environ.get("CHAIN_LIGHT_HITS"): ctx.set_tuning("chain_light_hits", int(os.environ["CHAIN_LIGHT_HITS"]))
 if os.environ.get("CHAIN_WAVE_TIERS"): ctx.set_tuning("chain_wave_tiers", int(os.environ["CHAIN_WAVE_TIERS"]))
 for it in range(3 if not os.environ.get("CHAIN_LANE_HITS") else 1):
     t0 = time.time(); smems, so, hits, ho = ctx.seed_batch_host(reads.reshape(-1), off); t1 = time.time()
