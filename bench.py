@@ -15,7 +15,7 @@ suffix-array entries in HBM -- and 10 M synthetic 150-bp single-end reads per GP
 -- suffix array, entries, P-RMI -- is built on the GPU in a few seconds (MEME_BENCH_SA=host: our host builders, minutes,
 cached in /dev/shm for the next invocation).
 
-Besides the headline line's `roofline` and `cpu_baseline` objects, rank 0 at N=1 adds `chain` (chaining of 2 M of the batch's reads on the device), `bsw` (the banded-SW kernel on 2 M
+Besides the headline line's `roofline` and `cpu_baseline` objects, rank 0 at N=1 adds `chain` (chaining of 2 M of the batch's reads on the device), `ext` (+ `cigar`), `kswv` (mate-rescue Smith-Waterman jobs), `bsw` (the banded-SW kernel on 2 M
 distinct extension jobs) and `e2e` (BASELINE.json's second metric: paired-end `mem -7` through the reference aligner
 with the HIP backend bound in, next to the unmodified reference on the same host cores, SAM md5 compared).
 
@@ -38,6 +38,9 @@ import time
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
+# The chaining stage runs four kernels side by side; the HIP runtime gives a process 4 hardware queues per device unless told otherwise
+# (libmeme_hip.so asks for 8 when it is loaded -- too late in a process where torch initialises the runtime first, as here).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.join(REPO, "bwa-meme_amd"))
 
 import torch  # noqa: E402
