@@ -1,0 +1,92 @@
+// Shared declarations of the binding's translation units (bwa-meme_amd/binding/meme_dropin*.cpp).  Written against the *reference's own
+// headers*; see meme_dropin.cpp for what the binding is and how it is linked.
+//   meme_dropin.cpp       devices, index to HBM (memoryAllocLearned), one seeding / chaining / extension call per chunk (mem_process_seqs),
+//                         mem_kernel1_core_Learned
+//   meme_dropin_ext.cpp   the extension stage on the host side (MEME_DROPIN_EXT=host), mem_chain2aln_across_reads_V2, the three
+//                         BandedPairWiseSW entry points with the group-commit combiner
+//   meme_dropin_sam.cpp   the SAM phase: kt_for interposer, CIGAR table (ksw_global2), opt-in mate-rescue table (worker_sam's third step)
+//   meme_dropin_io.cpp    FASTQ reader (bseq_read_orig)
+#ifndef MEME_DROPIN_H
+#define MEME_DROPIN_H
+#include <dlfcn.h>
+#include <sched.h>
+#include <time.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "fastmap.h"             // reference headers (-I$(REF)/src): ktp_aux_t, worker_t, mem_opt_t, bseq1_t ...
+#include "bandedSWA.h"
+#include "ksort.h"
+
+#include "meme_hip.h"            // our C ABI (-Iinclude)
+
+// reference functions used unchanged
+void mem_chain_Learned(const mem_opt_t* opt, const bntseq_t* bns, int len, mem_tlv* smems, mem_chain_v* chain,
+                       int seqid, u64v* hits, mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid);
+int mem_chain_flt(const mem_opt_t* opt, int n_chn_, mem_chain_t* a_, int tid);
+void mem_flt_chained_seeds(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int n_chn,
+                           mem_chain_t* a);
+
+namespace dropin {
+
+double now_s();
+[[noreturn]] void die(const char* what);
+bool verbose();
+
+struct Device {
+    meme_ctx* seed = nullptr;     // owns (device 0) or holds a replica of the index
+    meme_ctx* bsw = nullptr;      // second ctx of the GPU: BandedPairWiseSW calls (host extension stage), mate rescue
+};
+// (reached through an accessor: the early-start thread may run before the dynamic initialisers of meme_dropin.cpp)
+std::vector<Device>& device_slots();
+#define g_dev (dropin::device_slots())
+extern std::atomic<double> g_t_seed, g_t_bsw_gather, g_t_bsw_call, g_t_bsw_kernel;
+extern std::atomic<int64_t> g_n_bsw_calls, g_n_bsw_pairs, g_n_seed_reads;
+
+struct ChunkPart {                     // the slice of a chunk one GPU seeded
+    int64_t first = 0, count = 0;
+    meme_seed_host_result res;
+    meme_chain_host_result chains;                       // valid when g_chain_on_device (host extension stage)
+    meme_ext_host_result ext;                            // valid in device-extension mode: alignment records of the part's reads
+    bool has_ext = false;
+    uint8_t* flat = nullptr; int64_t flat_cap = 0;       // pinned staging (grow-only)
+    int64_t* off = nullptr; int64_t off_cap = 0;
+};
+struct Chunk {
+    const bseq1_t* seqs = nullptr;
+    int64_t n = 0;
+    std::vector<ChunkPart> part;
+};
+extern Chunk g_chunk;                          // the chunk mem_process_seqs is working on
+extern const bntseq_t* g_bns;                  // of the run (set by mem_process_seqs)
+extern std::vector<meme_contig> g_contigs;
+int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 1 host, 0 the reference's per-batch function
+extern bool g_ext_on_device;
+extern int g_team;                             // kt_for worker threads of the run (opt->n_threads)
+extern worker_t* g_worker;                     // of the chunk being processed
+extern const mem_opt_t* g_opt;
+std::atomic<int>& ktfor_calls();               // kt_for calls of the chunk so far (the third one is worker_sam)
+extern mem_chain_v* g_chunk_chain_ar;          // w.chain_ar of the chunk being processed
+extern uint64_t g_chunk_gen;                   // counts the chunks seeded
+void ext_prepare(int64_t chunk_reads, int threads);
+void ext_report();
+int cig_threads();                             // helper threads of the binding's own host loops
+
+}  // namespace dropin
+
+void meme_dropin_report_matesw();
+void meme_dropin_report_cigar();
+void meme_dropin_report_mate();
+#endif

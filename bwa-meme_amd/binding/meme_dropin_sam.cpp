@@ -1,0 +1,454 @@
+// Part of the reference-side binding of the MI355X backend (see meme_dropin.h / meme_dropin.cpp).
+#include "meme_dropin.h"
+
+using namespace dropin;
+
+// ---- mate rescue of the SAM phase on the device -----------------------------------------------------------------------------
+// worker_sam (src/bwamem.cpp:1827-1902, AVX-512 build) handles a batch of read pairs in three steps: mem_sam_pe_batch_pre poses the
+// Smith-Waterman jobs of mate rescue (a mate against the window its partner's alignment points at), mem_sam_pe_batch runs them through
+// the kswv kernels, mem_sam_pe_batch_post turns the results into alignment records.  At the SAM phase's quiescent point (the interposed
+// third kt_for call, as for the CIGAR stage) the binding runs the reference's own mem_sam_pe_batch_pre for every batch of the chunk into
+// buffers of its own -- the step reads the alignment records and writes only to the mem_cache it is given --, sends the jobs of the whole
+// chunk to the GPU(s) in one meme_kswv_batch_host call each, and keeps per batch the kswr_t records and the job index array (`gar`) the
+// first step left for the third.  The kt_for call then runs sam_worker_dev instead of worker_sam: the third step of worker_sam's
+// paired-end branch as written there (src/bwamem.cpp:1879-1900: mem_sam_pe_batch_post per pair, which also writes the SAM text, then the
+// pair's alignment arrays are freed), fed from the table.
+// OFF unless MEME_DROPIN_MATESW=1: measured on 2 M pairs of 150-bp reads (-t 64, 185 406 jobs) the stage costs 0.2-0.4 s of the SAM phase's
+// 1.3 s instead of saving the ~0.1 s the host's 64 threads spend in the kswv kernels -- the jobs are few (one per ~22 reads; a 250-bp / 5 %
+// run poses 5 000 in all), their kernel time is small next to the pre-pass that has to pose them ahead of worker_sam (0.12 s, of which
+// kernels 0.03-0.05 s), and the third step then meets the alignment records cold.  SAM output is identical either way (tests).
+#include <omp.h>
+#include "kswv.h"
+namespace dropin {
+std::atomic<double> g_t_matesw{0};
+std::atomic<int64_t> g_n_matesw{0};
+bool matesw_on_device() { static const bool v = getenv("MEME_DROPIN_MATESW") && atoi(getenv("MEME_DROPIN_MATESW")) != 0; return v; }
+// One job per lane needs tens of thousands of jobs to fill the GPU (a chunk of 666 k reads poses ~31 k: 8 ms of kernel for what the host's
+// 64 threads do in about as long); below this many jobs per chunk the reference's own batch runs (the bigger chunks bwa-meme reads by
+// default -- 10 M bases x threads -- pose ~50 jobs per 1 000 reads: 200 k per chunk at -t 64).  MEME_DROPIN_MATESW_MIN overrides.
+int64_t matesw_min_jobs() { static const int64_t v = getenv("MEME_DROPIN_MATESW_MIN") ? atoll(getenv("MEME_DROPIN_MATESW_MIN")) : 65536; return v; }
+double g_mate_jobs_per_read = -1;                // of the last chunk whose jobs were posed
+struct MateTable {
+    std::vector<int64_t> off;                    // first record of every worker batch (+ the total)
+    std::vector<kswr_t> aln;                     // records, batch after batch, in the order the jobs were posed (= regid)
+    std::vector<std::vector<int32_t>> gar;       // per batch: job index (or -1) of every (alignment, orientation) mem_matesw_batch_pre looked at
+    uint64_t gen = 0;                            // chunk the table belongs to
+    double t_prepass = 0, t_kernel_ms = 0;
+    int64_t n_jobs = 0;
+    mem_cache* cache = nullptr;                  // the pre-pass's own buffers, one slot per helper thread
+    int slots = 0;
+} g_mate;
+std::atomic<int64_t> g_mate_hits{0}, g_mate_miss{0};
+// worker_sam's paired-end branch after its first two steps (src/bwamem.cpp:1879-1900), the results of those coming from the table
+void sam_worker_dev(void* data, long seqid, long batch_size, int tid) {
+    worker_t* w = (worker_t*)data;
+    const MateTable& T = g_mate;
+    const size_t b = (size_t)(seqid / BATCH_SIZE);
+    const std::vector<int32_t>& gar = T.gar[b];
+    if (!gar.empty()) memcpy(w->mmc.seqPairArrayAux[tid], gar.data(), gar.size() * sizeof(int32_t));     // where mem_sam_pe_batch_post reads it
+    kswr_t* myaln = const_cast<kswr_t*>(T.aln.data()) + T.off[b];
+    int32_t gcnt = 0;
+    int pos = (int)(seqid >> 1);
+    for (long i = seqid; i < seqid + batch_size; i += 2) {
+        mem_sam_pe_batch_post(w->opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], &myaln, &w->mmc,
+                              gcnt, tid);
+        free(w->regs[i].a);
+        free(w->regs[i + 1].a);
+    }
+    g_mate_hits.fetch_add(T.off[b + 1] - T.off[b], std::memory_order_relaxed);
+}
+int cig_threads();
+
+void mate_cache_init(int slots) {
+    // worst case of one batch: 256 pairs x 2 ends x max_matesw (50) alignments x 4 orientations (mem_matesw_batch_pre asserts room before it grows)
+    const int64_t cap = (int64_t)BATCH_SIZE / 2 * 2 * 50 * 4 + 1024;
+    mem_cache* C = (mem_cache*)calloc(1, sizeof(mem_cache));
+    if (!C) die("calloc");
+    for (int t = 0; t < slots; ++t) {
+        C->seqPairArrayAux[t] = (SeqPair*)malloc((size_t)(cap + MAX_LINE_LEN) * sizeof(SeqPair));
+        C->seqPairArrayLeft128[t] = (SeqPair*)malloc((size_t)(cap + MAX_LINE_LEN) * sizeof(SeqPair));
+        C->seqPairArrayRight128[t] = (SeqPair*)malloc((size_t)(cap + MAX_LINE_LEN) * sizeof(SeqPair));
+        C->wsize[t] = cap;
+        const int64_t rcap = 8 << 20, qcap = 2 << 20;
+        C->wsize_buf_ref[t * CACHE_LINE] = rcap; C->wsize_buf_qer[t * CACHE_LINE] = qcap;
+        C->seqBufLeftRef[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)rcap, 64); C->seqBufRightRef[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)rcap, 64);
+        C->seqBufLeftQer[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)qcap, 64); C->seqBufRightQer[t * CACHE_LINE] = (uint8_t*)_mm_malloc((size_t)qcap, 64);
+        if (!C->seqPairArrayAux[t] || !C->seqPairArrayLeft128[t] || !C->seqPairArrayRight128[t] || !C->seqBufLeftRef[t * CACHE_LINE] ||
+            !C->seqBufRightRef[t * CACHE_LINE] || !C->seqBufLeftQer[t * CACHE_LINE] || !C->seqBufRightQer[t * CACHE_LINE]) die("mate-rescue buffers");
+    }
+    g_mate.cache = C; g_mate.slots = slots;
+}
+
+bool matesw_prepass() {                          // false: too few jobs for the device, worker_sam runs as it is
+    const double t0 = now_s();
+    worker_t* w = g_worker;
+    const mem_opt_t* opt = g_opt;
+    const int64_t n = g_chunk.n;
+    const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
+    const int nt = cig_threads();
+    if (!g_mate.cache) mate_cache_init(nt);
+    struct BatchJobs { std::vector<meme_kswv_job> jobs; std::vector<uint8_t> ref, qer; };
+    std::vector<BatchJobs> B((size_t)nb);
+    g_mate.gar.assign((size_t)nb, std::vector<int32_t>());
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_mate.slots)
+    for (int64_t b = 0; b < nb; ++b) {
+        const int t = omp_get_thread_num();
+        const int64_t st = b * BATCH_SIZE, ed = (b + 1) * BATCH_SIZE < n ? (b + 1) * BATCH_SIZE : n;
+        int64_t pcnt = 0;
+        int32_t gcnt = 0, maxRef = 0, maxQer = 0;
+        int64_t pos = st >> 1;
+        for (int64_t i = st; i + 1 < ed; i += 2)                  // worker_sam's loop (src/bwamem.cpp:1855-1866)
+            mem_sam_pe_batch_pre(opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], g_mate.cache,
+                                 pcnt, gcnt, maxRef, maxQer, t);
+        BatchJobs& J = B[(size_t)b];
+        g_mate.gar[(size_t)b].assign((const int32_t*)g_mate.cache->seqPairArrayAux[t], (const int32_t*)g_mate.cache->seqPairArrayAux[t] + gcnt);
+        if (pcnt == 0) continue;
+        const SeqPair* sp = g_mate.cache->seqPairArrayLeft128[t];
+        const int64_t rbytes = (int64_t)sp[pcnt - 1].idr + sp[pcnt - 1].len1, qbytes = (int64_t)sp[pcnt - 1].idq + sp[pcnt - 1].len2;
+        J.ref.assign(g_mate.cache->seqBufLeftRef[t * CACHE_LINE], g_mate.cache->seqBufLeftRef[t * CACHE_LINE] + rbytes);
+        J.qer.assign(g_mate.cache->seqBufLeftQer[t * CACHE_LINE], g_mate.cache->seqBufLeftQer[t * CACHE_LINE] + qbytes);
+        J.jobs.resize((size_t)pcnt);
+        for (int64_t k = 0; k < pcnt; ++k) { meme_kswv_job& j = J.jobs[(size_t)k]; j.idr = sp[k].idr; j.idq = sp[k].idq; j.len1 = sp[k].len1; j.len2 = sp[k].len2; j.xtra = sp[k].h0; j.pad = 0; }
+    }
+    MateTable& T = g_mate;
+    T.off.assign((size_t)nb + 1, 0);
+    for (int64_t b = 0; b < nb; ++b) T.off[(size_t)b + 1] = T.off[(size_t)b] + (int64_t)B[(size_t)b].jobs.size();
+    const int64_t total = T.off[(size_t)nb];
+    g_mate_jobs_per_read = n > 0 ? (double)total / (double)n : 0;
+    if (total < matesw_min_jobs()) { T.t_prepass += now_s() - t0; T.gen = 0; return false; }
+    T.aln.resize((size_t)total);
+    // the chunk's batches in contiguous runs over the GPUs, one call each
+    const int nd = (int)g_dev.size();
+    meme_bsw_opt bo;
+    memset(&bo, 0, sizeof(bo));
+    bo.o_del = opt->o_del; bo.e_del = opt->e_del; bo.o_ins = opt->o_ins; bo.e_ins = opt->e_ins; bo.a = opt->a; bo.b = opt->b;
+    std::vector<double> kms((size_t)nd, 0.0);
+    auto run_part = [&](int d) {
+        const int64_t b0 = nb * d / nd, b1 = nb * (d + 1) / nd;
+        const int64_t j0 = T.off[(size_t)b0], nj = T.off[(size_t)b1] - j0;
+        if (nj == 0) return;
+        std::vector<meme_kswv_job> jobs((size_t)nj);
+        int64_t rtot = 0, qtot = 0;
+        for (int64_t b = b0; b < b1; ++b) { rtot += (int64_t)B[(size_t)b].ref.size(); qtot += (int64_t)B[(size_t)b].qer.size(); }
+        std::vector<uint8_t> ref((size_t)rtot + 1), qer((size_t)qtot + 1);
+        int64_t ro = 0, qo = 0, k = 0;
+        for (int64_t b = b0; b < b1; ++b) {
+            const BatchJobs& J = B[(size_t)b];
+            if (!J.ref.empty()) memcpy(ref.data() + ro, J.ref.data(), J.ref.size());
+            if (!J.qer.empty()) memcpy(qer.data() + qo, J.qer.data(), J.qer.size());
+            for (const meme_kswv_job& j : J.jobs) { meme_kswv_job x = j; x.idr += ro; x.idq += qo; jobs[(size_t)k++] = x; }
+            ro += (int64_t)J.ref.size(); qo += (int64_t)J.qer.size();
+        }
+        meme_kswv_host_result R;
+        if (meme_kswv_batch_host(g_dev[(size_t)d].bsw, jobs.data(), nj, ref.data(), rtot, qer.data(), qtot, &bo, &R)) die("meme_kswv_batch_host");
+        static_assert(sizeof(kswr_t) == sizeof(meme_kswr) && offsetof(kswr_t, score) == 0 && offsetof(kswr_t, te) == 4 && offsetof(kswr_t, qe) == 8 &&
+                      offsetof(kswr_t, score2) == 12 && offsetof(kswr_t, te2) == 16 && offsetof(kswr_t, tb) == 20 && offsetof(kswr_t, qb) == 24, "kswr_t layout");
+        memcpy(&T.aln[(size_t)j0], R.res, (size_t)nj * sizeof(kswr_t));
+        kms[(size_t)d] = R.kernel_ms;
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < nd; ++d) th.emplace_back(run_part, d);
+    run_part(0);
+    for (auto& x : th) x.join();
+    double km = 0;
+    for (double v : kms) km = km > v ? km : v;
+    T.t_kernel_ms += km; T.n_jobs += total; T.t_prepass += now_s() - t0;
+    T.gen = g_chunk_gen;
+    return true;
+}
+}  // namespace dropin
+
+// (with the stage off: the reference's batch, timed)
+typedef int (*sam_pe_batch_fn)(const mem_opt_t*, mem_cache*, int64_t&, int64_t&, kswr_t*, int32_t, int32_t, int);
+int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_t& pcnt8, kswr_t* aln, int32_t maxRefLen, int32_t maxQerLen, int tid) {
+    static sam_pe_batch_fn next = (sam_pe_batch_fn)dlsym(RTLD_NEXT, "_Z16mem_sam_pe_batchPK9mem_opt_tP9mem_cacheRlS4_P6kswr_tiii");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_sam_pe_batch was not found\n"); exit(1); }
+    g_mate_miss.fetch_add(pcnt, std::memory_order_relaxed);
+    const double t0 = now_s();
+    const int64_t n = pcnt;
+    const int rc = next(opt, mmc, pcnt, pcnt8, aln, maxRefLen, maxQerLen, tid);
+    g_t_matesw = g_t_matesw + (now_s() - t0);
+    g_n_matesw += n;
+    return rc;
+}
+void meme_dropin_report_mate() {
+    if (!matesw_on_device()) return;
+    fprintf(stderr, "[meme-dropin] mate rescue on the device: %lld Smith-Waterman jobs posed so far (kernels %.3f s, whole pre-pass %.3f s); jobs whose results worker_sam's third step took from the table "
+            "%lld, run by the reference's kernels %lld\n", (long long)g_mate.n_jobs, g_mate.t_kernel_ms * 1e-3, g_mate.t_prepass, (long long)g_mate_hits.load(),
+            (long long)g_mate_miss.load());
+}
+namespace dropin {
+std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0}, g_n_sam{0};
+// per-record timing with shared counters costs a 256-thread run a third of its compute time: only on request
+bool profile_sam() { static const bool v = getenv("MEME_DROPIN_PROFILE_SAM") != nullptr; return v; }
+}
+// (measurement only, MEME_DROPIN_PROFILE_SAM=1) the two other candidates of the SAM phase: CIGAR generation and SAM formatting
+typedef uint32_t* (*gen_cigar2_fn)(const int8_t*, int, int, int, int, int, int64_t, const uint8_t*, int, uint8_t*, int64_t, int64_t, int*, int*, int*);
+extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t* pac, int l_query,
+                                    uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
+    static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
+    if (!profile_sam()) return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+    const double t0 = now_s();
+    uint32_t* r = next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+    g_t_cigar = g_t_cigar + (now_s() - t0);
+    g_n_cigar += 1;
+    return r;
+}
+typedef void (*aln2sam_fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
+void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
+    static aln2sam_fn next = (aln2sam_fn)dlsym(RTLD_NEXT, "_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
+    if (!profile_sam()) { next(opt, bns, str, s, n, list, which, m); return; }
+    const double t0 = now_s();
+    next(opt, bns, str, s, n, list, which, m);
+    g_t_sam = g_t_sam + (now_s() - t0);
+    g_n_sam += 1;
+}
+void meme_dropin_report_matesw() {
+    fprintf(stderr, "[meme-dropin] SAM phase on the host, thread-seconds so far: mate-rescue SW (kswv) %.3f for %lld pairs; CIGAR generation (bwa_gen_cigar2) %.3f "
+            "for %lld alignments; SAM formatting (mem_aln2sam) %.3f for %lld records\n", (double)g_t_matesw, (long long)g_n_matesw, (double)g_t_cigar,
+            (long long)g_n_cigar, (double)g_t_sam, (long long)g_n_sam);
+}
+
+// ---- CIGAR generation of the SAM phase on the device ---------------------------------------------------------------------
+// mem_reg2aln (src/bwamem.cpp:2314-2380) calls bwa_gen_cigar2 (src/bwa.cpp:274-362) up to three times per alignment written out, and
+// that runs ksw_global2 (src/ksw.cpp:560-670): banded global alignment with traceback, 42 % of the SAM phase's thread time on 250-bp
+// reads with 5 % errors.  Between the two kt_for phases -- worker_aln has joined, worker_sam has not started: the third kt_for call of
+// mem_process_seqs (src/bwamem.cpp:1941-1965) is interposed -- the binding poses the same alignments for EVERY alignment record of the
+// chunk (the records are complete and nobody touches them; same band arithmetic as mem_reg2aln / bwa_gen_cigar2), runs them
+// on the GPU(s) as one batch per band attempt (meme_global_batch_host) and keeps score + CIGAR; ksw_global2 calls are then answered
+// from that table after an exact comparison of both sequences.  Calls the table does not hold (alignments made later by mate rescue,
+// calls without traceback from mem_patch_reg) go to the reference's function.  MEME_DROPIN_CIGAR=0 switches the stage off.
+#include <omp.h>
+#include <parallel/algorithm>
+namespace dropin {
+
+struct CigEntry { int64_t g; int64_t rb; int32_t qb, qlen, tlen, w, rev, score, n_cigar; int64_t ops; };
+struct CigTable {
+    std::mutex mu;
+    uint64_t gen = 0;
+    std::vector<CigEntry> e;
+    std::vector<uint32_t> ops;
+    std::vector<std::pair<uint64_t, uint32_t>> idx;      // (key, entry), sorted
+    double t_prepass = 0, t_kernel_ms = 0;
+    int64_t n_jobs = 0;
+} g_cig;
+std::atomic<int64_t> g_cig_hits{0}, g_cig_miss{0};
+bool cigar_on_device() { static const bool v = !(getenv("MEME_DROPIN_CIGAR") && atoi(getenv("MEME_DROPIN_CIGAR")) == 0); return v; }
+
+inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
+inline uint64_t hash_bytes(const uint8_t* p, int n, bool rev) {
+    uint64_t h = 1469598103934665603ull;
+    if (!rev) for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    else for (int i = n - 1; i >= 0; --i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+inline uint64_t cig_key(int qlen, int tlen, int w, uint64_t hq, uint64_t ht) {
+    return mix64(mix64(mix64(mix64((uint64_t)qlen, (uint64_t)tlen), (uint64_t)w), hq), ht);
+}
+inline int infer_bw_(int l1, int l2, int score, int a, int q, int r) {        // infer_bw, src/bwamem.cpp:2151-2158
+    if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+    int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+    if (w < abs(l1 - l2)) w = abs(l1 - l2);
+    return w;
+}
+// the band bwa_gen_cigar2 hands to ksw_global2 for a call with w_ (src/bwa.cpp:306-316); false: no DP (rejected, or the gap-free shortcut)
+inline bool gen_cigar_band(const mem_opt_t* opt, int64_t l_pac, int l_query, int64_t rb, int64_t re, int w_, int* w_out) {
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
+    const int64_t rlen = re - rb;
+    if (l_query == rlen && w_ == 0) return false;
+    int max_ins = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
+    int max_del = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
+    int max_gap = max_ins > max_del ? max_ins : max_del;
+    max_gap = max_gap > 1 ? max_gap : 1;
+    int w = (max_gap + abs((int)rlen - l_query) + 1) >> 1;
+    w = w < w_ ? w : w_;
+    const int min_w = abs((int)rlen - l_query) + 3;
+    w = w > min_w ? w : min_w;
+    *w_out = w;
+    return true;
+}
+
+// helper threads of the pre-pass's host loops: a few dozen are enough, and an OpenMP team of 256 would still be spinning when worker_sam starts
+int cig_threads() { const int m = omp_get_max_threads(); return m < 32 ? m : 32; }
+
+void cig_prepass() {
+    const double t0 = now_s();
+    CigTable& T = g_cig;
+    T.e.clear(); T.ops.clear(); T.idx.clear();
+    const mem_opt_t* opt = g_opt;
+    const int64_t n = g_chunk.n, l_pac = g_bns->l_pac;
+    // per alignment record: where mem_reg2aln's loop stands (band of the next call, score of the last one)
+    struct Cand { int64_t g; int32_t reg, w2, last_sc, tries; };
+    std::vector<Cand> cand;
+    {
+        const int nt = cig_threads();
+        std::vector<std::vector<Cand>> part((size_t)nt);
+#pragma omp parallel num_threads(nt)
+        {
+            std::vector<Cand>& mine = part[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+            for (int64_t g = 0; g < n; ++g) {
+                const mem_alnreg_v& av = g_worker->regs[g];
+                for (size_t i = 0; i < av.n; ++i) {
+                    const mem_alnreg_t& p = av.a[i];
+                    if (p.rb < 0 || p.re < 0 || p.score < opt->T) continue;
+                    if (p.secondary >= 0 && p.secondary < (int)av.n && p.score < av.a[p.secondary].score * opt->XA_drop_ratio) continue;
+                    const int tmp = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_del, opt->e_del);
+                    int w2 = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_ins, opt->e_ins);
+                    w2 = w2 > tmp ? w2 : tmp;
+                    if (w2 > opt->w) w2 = w2 < p.w ? w2 : p.w;
+                    mine.push_back({g, (int32_t)i, w2, -(1 << 30), 0});
+                }
+            }
+        }
+        size_t tot = 0;
+        for (auto& v : part) tot += v.size();
+        cand.reserve(tot);
+        for (auto& v : part) cand.insert(cand.end(), v.begin(), v.end());      // (static schedule: still in read order)
+    }
+    const int nd = (int)g_dev.size();
+    meme_bsw_opt bo;
+    memset(&bo, 0, sizeof(bo));
+    bo.o_del = opt->o_del; bo.e_del = opt->e_del; bo.o_ins = opt->o_ins; bo.e_ins = opt->e_ins; bo.a = opt->a; bo.b = opt->b;
+    for (int round = 0; round < 3 && !cand.empty(); ++round) {
+        // this round's calls, per device part (candidates are in read order: a part's candidates are contiguous)
+        std::vector<std::vector<meme_gjob>> jobs((size_t)nd);
+        std::vector<std::vector<uint32_t>> who((size_t)nd);
+        for (size_t c = 0; c < cand.size(); ++c) {
+            Cand& C = cand[c];
+            const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
+            C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;
+            int w = 0;
+            if (!gen_cigar_band(opt, l_pac, p.qe - p.qb, p.rb, p.re, C.w2, &w)) { C.tries = 99; continue; }
+            int d = 0;
+            while (d + 1 < nd && C.g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
+            meme_gjob J;
+            J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w = w;
+            J.rev = p.rb >= l_pac ? 1 : 0;
+            jobs[(size_t)d].push_back(J);
+            who[(size_t)d].push_back((uint32_t)c);
+        }
+        std::vector<meme_gres_host> res((size_t)nd);
+        std::vector<std::thread> th;
+        auto run = [&](int d) {
+            memset(&res[(size_t)d], 0, sizeof(meme_gres_host));
+            if (jobs[(size_t)d].empty()) return;
+            if (meme_global_batch_host(g_dev[(size_t)d].seed, jobs[(size_t)d].data(), (int64_t)jobs[(size_t)d].size(), &bo, &res[(size_t)d])) die("meme_global_batch_host");
+        };
+        for (int d = 1; d < nd; ++d) th.emplace_back(run, d);
+        run(0);
+        for (auto& t : th) t.join();
+        std::vector<Cand> next;
+        for (int d = 0; d < nd; ++d) {
+            const meme_gres_host& R = res[(size_t)d];
+            if (R.njobs == 0) continue;
+            T.t_kernel_ms += R.kernel_ms;
+            T.n_jobs += R.njobs;
+            const size_t e0 = T.e.size(), o0 = T.ops.size();
+            T.ops.insert(T.ops.end(), R.cigars, R.cigars + R.total_ops);      // the device packs the operations in job order
+            T.e.resize(e0 + (size_t)R.njobs);
+#pragma omp parallel for schedule(static) num_threads(cig_threads())
+            for (int64_t k = 0; k < R.njobs; ++k) {
+                const meme_gjob& J = jobs[(size_t)d][(size_t)k];
+                CigEntry& E = T.e[e0 + (size_t)k];
+                E.g = cand[who[(size_t)d][(size_t)k]].g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev;
+                E.score = R.res[k].score; E.n_cigar = R.res[k].n_cigar; E.ops = (int64_t)o0 + R.res[k].cigar_off;
+            }
+            for (int64_t k = 0; k < R.njobs; ++k) {
+                // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
+                Cand& C = cand[who[(size_t)d][(size_t)k]];
+                const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
+                const int score = R.res[k].score;
+                if (score == C.last_sc || C.w2 == opt->w << 2) continue;
+                C.last_sc = score;
+                C.w2 <<= 1;
+                if (++C.tries < 3 && score < p.truesc - opt->a) next.push_back(C);
+            }
+        }
+        cand.swap(next);
+    }
+    // index: sequences hashed the way the hook will see them (both reversed on the reverse strand); sorted by key, looked up by bisection
+    const uint8_t* ref = g_worker->ref_string;
+    T.idx.resize(T.e.size());
+#pragma omp parallel for schedule(static) num_threads(cig_threads())
+    for (int64_t k = 0; k < (int64_t)T.e.size(); ++k) {
+        const CigEntry& E = T.e[(size_t)k];
+        const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
+        T.idx[(size_t)k] = {cig_key(E.qlen, E.tlen, E.w, hash_bytes(q, E.qlen, E.rev), hash_bytes(ref + E.rb, E.tlen, E.rev)), (uint32_t)k};
+    }
+    __gnu_parallel::sort(T.idx.begin(), T.idx.end(), __gnu_parallel::default_parallel_tag((unsigned)cig_threads()));
+    T.t_prepass += now_s() - t0;
+}
+
+typedef int (*ksw_global2_fn)(int, const uint8_t*, int, const uint8_t*, int, const int8_t*, int, int, int, int, int, int*, uint32_t**);
+}  // namespace dropin
+
+extern "C" int ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int m, const int8_t* mat, int o_del, int e_del, int o_ins,
+                           int e_ins, int w, int* n_cigar_, uint32_t** cigar_) {
+    static ksw_global2_fn next = (ksw_global2_fn)dlsym(RTLD_NEXT, "ksw_global2");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's ksw_global2 was not found\n"); exit(1); }
+    const mem_opt_t* opt = g_opt;
+    if (!cigar_on_device() || !n_cigar_ || !cigar_ || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || m != 5 || mat != opt->mat || o_del != opt->o_del ||
+        e_del != opt->e_del || o_ins != opt->o_ins || e_ins != opt->e_ins)
+        return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
+    CigTable& T = g_cig;
+    if (T.gen != g_chunk_gen) return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);   // (no table for this chunk)
+    const uint64_t key = cig_key(qlen, tlen, w, hash_bytes(query, qlen, false), hash_bytes(target, tlen, false));
+    const uint8_t* ref = g_worker->ref_string;
+    for (auto it = std::lower_bound(T.idx.begin(), T.idx.end(), std::make_pair(key, (uint32_t)0)); it != T.idx.end() && it->first == key; ++it) {
+        const CigEntry& E = T.e[it->second];
+        if (E.qlen != qlen || E.tlen != tlen || E.w != w) continue;
+        const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
+        const uint8_t* t = ref + E.rb;
+        bool same = true;
+        if (!E.rev) same = !memcmp(q, query, (size_t)qlen) && !memcmp(t, target, (size_t)tlen);
+        else {
+            for (int i = 0; same && i < qlen; ++i) same = q[qlen - 1 - i] == query[i];
+            for (int i = 0; same && i < tlen; ++i) same = t[tlen - 1 - i] == target[i];
+        }
+        if (!same) continue;
+        uint32_t* cg = (uint32_t*)malloc((size_t)(E.n_cigar > 0 ? E.n_cigar : 1) * 4);   // the caller owns (and grows) it, as with the reference's
+        if (!cg) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+        memcpy(cg, T.ops.data() + E.ops, (size_t)E.n_cigar * 4);
+        *cigar_ = cg;
+        *n_cigar_ = E.n_cigar;
+        g_cig_hits.fetch_add(1, std::memory_order_relaxed);
+        return E.score;
+    }
+    g_cig_miss.fetch_add(1, std::memory_order_relaxed);
+    return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
+}
+
+void meme_dropin_report_cigar() {
+    if (!cigar_on_device()) return;
+    fprintf(stderr, "[meme-dropin] CIGAR stage on the device: %lld global alignments with traceback posed so far (kernels %.3f s, whole pre-pass %.3f s); "
+            "ksw_global2 calls answered from the table %lld, computed by the reference's function %lld (alignments made by mate rescue, calls without traceback)\n",
+            (long long)g_cig.n_jobs, g_cig.t_kernel_ms * 1e-3, g_cig.t_prepass, (long long)g_cig_hits.load(), (long long)g_cig_miss.load());
+}
+
+// kt_for (src/kthread.cpp:79-114) is called three times per chunk by mem_process_seqs: worker_bwt, worker_aln, worker_sam.  Before the
+// third call every alignment record of the chunk exists and no worker thread is running: the CIGAR stage's quiescent point.
+namespace dropin { std::atomic<int> g_ktfor_calls{0}; std::atomic<int>& ktfor_calls() { return g_ktfor_calls; } }
+typedef void (*kt_for_fn)(void (*)(void*, long, long, int), void*, int);
+void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
+    static kt_for_fn next = (kt_for_fn)dlsym(RTLD_NEXT, "_Z6kt_forPFvPvlliES_i");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_for was not found\n"); exit(1); }
+    if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2) {
+        bool mate = false;
+#if __AVX512BW__          // (only this build of the reference batches mate rescue: src/bwamem.cpp:1838)
+        mate = matesw_on_device() && (g_opt->flag & MEM_F_PE) && !(g_opt->flag & MEM_F_NO_RESCUE) && !g_dev.empty();
+#endif
+        // (a chunk that will not reach the job threshold -- by the previous chunk's jobs per read -- is not posed at all)
+        if (mate && g_mate_jobs_per_read >= 0 && g_mate_jobs_per_read * (double)g_chunk.n < (double)matesw_min_jobs()) mate = false;
+        if (cigar_on_device()) {
+            std::lock_guard<std::mutex> lk(g_cig.mu);
+            cig_prepass();
+            g_cig.gen = g_chunk_gen;
+        }
+        if (mate && matesw_prepass()) {
+            next(sam_worker_dev, data, n);
+            return;
+        }
+    }
+    next(func, data, n);
+}

@@ -1,6 +1,6 @@
 """End-to-end acceptance test of the drop-in (the reference's own acceptance criterion, README.md:81-92):
 the reference aligner with seeding and extension interposed by the HIP backend (oracle/_ref/bwa-meme_dropin =
-reference main + libbwa_pic.so + bwa-meme_amd/binding/meme_dropin.cpp over include/meme_hip.h) must write the same SAM
+reference main + libbwa_pic.so + bwa-meme_amd/binding/meme_dropin*.cpp over include/meme_hip.h) must write the same SAM
 as the unmodified reference binary (`mem -7`), apart from the @PG line that embeds the command line."""
 import os
 import subprocess
