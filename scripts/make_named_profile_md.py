@@ -88,10 +88,10 @@ if RND == 2:
     md.append("\nSame kernel as round 1 except the 32-byte model records, the bounded partial-layer index and 128 first-pass SMEM slots per read; the one-lane-per-read kernel that was "
               "built to halve the lines is documented in `r02_seed_v2_experiment.md`.\n")
 else:
-    md.append("\n`k_seed` is the round-2 kernel (why the reference's ISA shortcut was not added: DESIGN.md section 8).  New in this trace: the chaining tiers (`k_chain`, `k_chain_reg`, "
-              "`k_chain_lds`, `k_chain_wave`), the extension stage (`k_ext_*` around `k_bsw_lane`) and the CIGAR kernel (`k_gcig`) of bench.py's `chain` / `ext` legs.\n")
+    md.append("\n`k_seed` is the round-2 kernel (why the reference's ISA shortcut was not added: DESIGN.md section 8).  New in this trace: the chaining tiers (`k_chain_route`, `k_chain`, "
+              "`k_chain_lds`, `k_chain_wave`), the extension stage (`k_ext_*` around `k_bsw_lane`) and the CIGAR kernel (`k_gcig`) and the mate-rescue kernel (`k_kswv`) of bench.py's `chain` / `ext` / `kswv` legs.\n")
     md.append("## 5. The kernels of the stages behind seeding in the same trace (2 M reads per leg)\n")
     md.append("| kernel | calls | avg_us | min_us | max_us | total_ms | pct |\n|---|---|---|---|---|---|---|")
-    md.append("\n".join(r for r in open(D + "trace.md").read().splitlines() if re.search(r"k_chain|k_ext|k_gcig|k_bsw|k_scan|k_gather|k_pack_reads|k_offsets", r)) + "\n")
+    md.append("\n".join(r for r in open(D + "trace.md").read().splitlines() if re.search(r"k_chain|k_ext|k_gcig|k_kswv|k_bsw|k_scan|k_gather|k_pack_reads|k_offsets", r)) + "\n")
 open(os.path.join(REPO, "profiles", "r%02d_named_config.md" % RND), "w").write("\n".join(md))
 print("k_seed %.2f ms/launch, traffic %.0f GB, miss lines/search %.2f, VALU %.0f %%" % (k_avg, (2 * fetch + write) * 1024 / 1e9, miss / searches, valu * 4 / 1024 / (k_avg * 1e-3 * 2.4e9) * 100))
