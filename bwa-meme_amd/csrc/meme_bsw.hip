@@ -7,7 +7,7 @@
 // Two kernels, one semantics:
 //  * k_bsw_lane -- one pair per lane (64 pairs per wavefront, pairs counting-sorted by query length so the lanes finish
 //    together): the inter-task parallelism of the reference's own SIMD code at wavefront width.  Takes every pair whose
-//    query fits the LDS classes (<= 600 bases) and whose scores fit 14 bits -- all short-read extensions.
+//    query fits the LDS classes (<= 600 bases) and whose scores fit 12 bits -- all short-read extensions.
 //  * k_bsw<LP>  -- 16 / 32 / 64 lanes per pair (by query length) for the rest (long queries, huge h0) and for small
 //    batches, where latency matters: a lone pair takes milliseconds on one lane (see bsw_lane_min_pairs).
 //
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(BSW_BLOCK) k_bsw(BswArgs A) {
 // lanes runs scalarBandedSWA on its own pair.  No cross-lane traffic at all; per DP cell a lane issues one LDS read,
 // one LDS write and ~16 integer ops.  The row state {H(i-1,j-1), E(i,j)} and the query base of column j share one
 // 32-bit LDS word (query code in the low byte, then 12 + 12 bits), laid out [column][lane] so every access is bank-conflict free whatever column
-// each lane is at.  Pairs whose scores could exceed 14 bits or whose query exceeds LANE_QMAX go to the
+// each lane is at.  Pairs whose scores could exceed 12 bits or whose query exceeds LANE_QMAX go to the
 // lanes-per-pair kernel above.
 constexpr int LANE_QMAX = 600;
 constexpr int LANE_SCORE_LIMIT = 1 << 12;
@@ -606,7 +606,7 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
             if (one_launch) break;
         }
     }
-    // ---- lanes-per-pair kernel: the pairs the lane kernel cannot take (long queries, scores beyond 14 bits), or the whole
+    // ---- lanes-per-pair kernel: the pairs the lane kernel cannot take (long queries, scores beyond 12 bits), or the whole
     // batch when it is small; 16 / 32 / 64 lanes per pair by query length (4 / 2 / 1 pairs per wavefront)
     {
         BswArgs A;

@@ -298,7 +298,7 @@ typedef struct {
     float seed_pack_ms;        /* read packing kernel */
     int64_t seed_windows;      /* suffix-array windows loaded by the SA-search kernel */
     float chain_kernel_ms;     /* chaining kernels of the last meme_chain_last_batch_host call (both passes + packing) */
-    float chain_pass2_ms;      /* of which the wavefront-per-read tiers (register tier + B-tree tier, incl. the host round trip between them) */
+    float chain_pass2_ms;      /* everything after the lane-per-read tier has finished (the routed LDS tiers run beside it), B-tree tier included */
     float chain_tier3_ms;      /* of which the B-tree tier (reads with chains at equal positions or more than 256 chains) */
     int64_t chain_tier2_reads, chain_tier3_reads;   /* reads beyond the lane-per-read tier; of which through the B-tree tier */
 } meme_timings;
