@@ -1018,6 +1018,7 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
             }
             };
             if (!par_mode) { seq_hits(rem); continue; }
+            __syncthreads();                                    // (seed records stored by lane 0 above are complete before another lane links to them)
             while (rem && !bail) {
                 // 1. the lower chain of every remaining hit in the current state
                 const i64 rbj = h_rbeg;
