@@ -24,7 +24,7 @@ for path in sys.argv[1:]:
             print("\n| kernel | counter | dispatches | avg per dispatch | sum |")
             print("|---|---|---|---|---|")
             for r in rows:
-                if 'k_seed' in r[0] or 'k_bsw' in r[0] or 'k_gather' in r[0]:
+                if any(k in r[0] for k in os.environ.get('ROCPD_KERNELS', 'k_seed,k_bsw,k_gather').split(',')):
                     print("| %s | %s | %d | %.4g | %.4g |" % (r[0][:40], r[1], r[2], r[3], r[4]))
     except Exception as e:
         print("counters view failed:", e)
