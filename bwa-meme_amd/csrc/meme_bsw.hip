@@ -402,6 +402,7 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
                 mj = key < 0 ? -1 : key & 1023;
             }
             he[end * 64] = he_pack(h1, 0, he[end * 64] & QMASK);    // :201
+            const unsigned w_front = he[beg * 64];             // (for the band trimming below: requested here, used after the row's bookkeeping)
             if ((beg < end ? end : beg) == qlen) {             // "if (j == qlen)" after the column loop, :202-205
                 max_ie = gscore > h1 ? max_ie : i;
                 gscore = gscore > h1 ? gscore : h1;
@@ -421,10 +422,16 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
             }
             // band trimming (:217-221): drop leading / trailing columns whose H and E are both zero
             int jt = beg;
-            while (jt < end && (he[jt * 64] & HE_MASK) == 0u) ++jt;
+            if (jt < end && (w_front & HE_MASK) == 0u) {
+                ++jt;
+                while (jt < end && (he[jt * 64] & HE_MASK) == 0u) ++jt;
+            }
             beg = jt;
             jt = end;
-            while (jt >= beg && (he[jt * 64] & HE_MASK) == 0u) --jt;
+            if (h1 == 0) {                                     // (column `end` was just written as {h1, 0}: only a zero there asks for the scan)
+                --jt;
+                while (jt >= beg && (he[jt * 64] & HE_MASK) == 0u) --jt;
+            }
             end = jt + 2 < qlen ? jt + 2 : qlen;
         }
         if (active) {
