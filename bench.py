@@ -49,7 +49,7 @@ import torch.distributed as dist  # noqa: E402
 from pymeme import hipapi, hostapi, synth, workload  # noqa: E402
 
 READ_LEN = 150
-BSW_VALU_PER_CELL = 24.5     # measured: profiles/r03_bsw.md (SQ_INSTS_VALU x 64 lanes / DP cells of 2 M distinct pairs, a committed PMC pass)
+BSW_VALU_PER_CELL = 24.3     # measured: profiles/r03_bsw.md (SQ_INSTS_VALU x 64 lanes / DP cells of 2 M distinct pairs, a committed PMC pass)
 T_START = time.time()
 
 
