@@ -269,8 +269,12 @@ __global__ void __launch_bounds__(64) k_chain(ChainArgs A) {
             DChain c = ch[i];
             c.first = -1; c.kept = 0;
             c.w = chain_weight(c, sd + c.row * SC);
+            // (all chains below the floor: the reference's compaction copies nothing, its count becomes 0, and the code behind it still
+            // makes one range of the array's stale first element (src/bwamem.cpp:604-643) -- the first chain in tree order survives)
             if (c.w >= o.min_chain_weight) ch[n++] = c;
+            else if (i == 0) ch[0] = c;
         }
+        if (n == 0) n = 1;
         if (n > 0) {
             sort_by_weight(ch, n);
             int kept_idx[CC];
@@ -610,6 +614,10 @@ __global__ void __launch_bounds__(64) k_chain_wave(ChainArgs A, WaveArgs W, i64 
         const u64 mk = __ballot(keep);
         if (keep) srt[n + __popcll(mk & (((u64)1 << lane) - 1))] = (u64)(unsigned)w << 32 | (unsigned)id;
         n += __popcll(mk);
+    }
+    if (n == 0 && nchain > 0) {                                 // all below the floor: the reference keeps the first chain in tree order (see k_chain)
+        if (lane == 0) { const int id0 = ib[0]; srt[0] = (u64)(unsigned)C[id0].w << 32 | (unsigned)id0; }
+        n = 1;
     }
     wave_fence();
     int n_kept = 0, n_seeds = 0;
@@ -1127,6 +1135,7 @@ __global__ void __launch_bounds__(64) k_chain_lds(ChainArgs A, WaveArgs W) {
     if (o.min_chain_weight > 0) {                               // (default 0: nothing is dropped)
         n = 0;
         for (int e = 0; e < nchain; ++e) { const int w = EW[e], id = EID[e]; if (w >= o.min_chain_weight) { EW[n] = w; EID[n] = id; ++n; } }
+        if (n == 0 && nchain > 0) n = 1;                        // all below the floor: the reference keeps the first chain in tree order (see k_chain)
     }
     int n_kept = 0, n_seeds = 0;
     if (n > 0) {

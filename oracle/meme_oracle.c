@@ -806,10 +806,16 @@ int orc_chain_read(const orc_mem_tl* smems_in, int n_smems, const uint64_t* hits
     if (rc == 0 && nc > 0) {                                  /* mem_chain_flt */
         int* kept_idx = (int*)malloc(sizeof(int) * (size_t)nc);
         int nk = 0, ns_out = 0;
+        /* (:604-619: chains below min_chain_weight are dropped by compaction.  When ALL of them are below it, nothing is copied, the count
+         * becomes 0 -- and the code that follows (:620-643) still builds one range [0, 1) from the array's stale first element: the
+         * reference returns the FIRST chain in tree order, kept = 3.  Restated as it behaves.) */
+        int below0 = 0;                                       /* chain 0 is below the floor and still sits in slot 0 */
         for (i = 0; i < nc; ++i) {
             ch[i].first = -1; ch[i].kept = 0; ch[i].w = o_weight(&ch[i]);
-            if (ch[i].w < o->min_chain_weight) free(ch[i].seeds); else ch[n++] = ch[i];
+            if (ch[i].w < o->min_chain_weight) { if (i == 0) below0 = 1; else free(ch[i].seeds); }
+            else { if (below0) { free(ch[0].seeds); below0 = 0; } ch[n++] = ch[i]; }
         }
+        if (n == 0) n = 1;                                    /* slot 0 untouched: the stale first element */
         nc = n;                                               /* (dropped chains are gone) */
         if (n > 0) {
             o_introsort((size_t)n, ch);

@@ -96,16 +96,21 @@ def test_device_chains_equal_reference_on_equal_positions_and_big_trees():
     assert np.array_equal(R["frac_rep"].view(np.uint32)[has], G["frac_rep_bits"][has])
 
 
-def test_device_chains_equal_oracle_on_adversarial_batch():
-    """5 000 made-up reads (tests/chain_gen.py) chained on the device and compared with the oracle by the batched checker."""
+def _adversarial(n, seed):
     import chain_gen
-    reads = chain_gen.workload(991, 5000, l_pac=200_000)
+    reads = chain_gen.workload(seed, n, l_pac=200_000)
     smem_off = np.zeros(len(reads) + 1, np.int64); hit_off = np.zeros(len(reads) + 1, np.int64)
     for r, (sm, h) in enumerate(reads):
         smem_off[r + 1] = smem_off[r] + sm.shape[0]; hit_off[r + 1] = hit_off[r] + h.shape[0]
     smems = np.concatenate([sm for sm, _ in reads]).astype(hipapi.MEM_TL)
     hits = np.concatenate([h for _, h in reads])
     read_len = np.array([250 if r % 5 == 2 else 150 for r in range(len(reads))], np.int32)
+    return smems, smem_off, hits, hit_off, read_len
+
+
+def test_device_chains_equal_oracle_on_adversarial_batch():
+    """5 000 made-up reads (tests/chain_gen.py) chained on the device and compared with the oracle by the batched checker."""
+    smems, smem_off, hits, hit_off, read_len = _adversarial(5000, 991)
     ctx = hipapi.Context(0)
     try:
         R = ctx.chain_batch_host(smems, smem_off, hits, hit_off, read_len, _contigs3(), hipapi.default_chain_opt(200_000))
@@ -115,6 +120,26 @@ def test_device_chains_equal_oracle_on_adversarial_batch():
     bad = O.chain_compare_batch(smems, smem_off, hits, hit_off, read_len, np.array([0, 70_000, 150_000], np.int64), np.array([0, 0, 1], np.uint8),
                                 O.default_chain_opt(200_000), R)
     assert bad == (0, -1), bad
+
+
+@pytest.mark.parametrize("name,change", [("narrow_band", dict(w=3)), ("wide_band", dict(w=2000)), ("short_gap", dict(max_chain_gap=40)),
+                                         ("few_hits", dict(max_occ=37)), ("strict_filter", dict(drop_ratio=0.9, mask_level=0.1)),
+                                         ("few_extended", dict(max_chain_extend=3)), ("weight_floor", dict(min_chain_weight=40))])
+def test_device_chains_equal_oracle_under_other_options(name, change):
+    """The same kind of batch under other chaining options: the band and gap limits enter test_and_merge and with it the rule by which the
+    wavefront tier commits a batch of hits at once; max_occ the sampling of the hits; the rest the filter."""
+    smems, smem_off, hits, hit_off, read_len = _adversarial(2500, 1200 + len(name))
+    do, oo = hipapi.default_chain_opt(200_000), O.default_chain_opt(200_000)
+    for k, v in change.items():
+        setattr(do, k, v); setattr(oo, k, v)
+    ctx = hipapi.Context(0)
+    try:
+        R = ctx.chain_batch_host(smems, smem_off, hits, hit_off, read_len, _contigs3(), do)
+    finally:
+        ctx.close()
+    assert R["n_fallback"] == 0
+    bad = O.chain_compare_batch(smems, smem_off, hits, hit_off, read_len, np.array([0, 70_000, 150_000], np.int64), np.array([0, 0, 1], np.uint8), oo, R)
+    assert bad == (0, -1), (name, bad)
 
 
 def test_chain_call_needs_a_seeded_batch_and_sane_options(tmp_path):
