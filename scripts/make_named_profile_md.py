@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """gpurun_out/prof_named_r<N>/ (written by scripts/profile_named_r<N>.sh) -> profiles/r0<N>_named_config.md + profiles/pmc_named.json.
-python scripts/make_named_profile_md.py [N]   (default 3; bench.json of round 3 = the plain default run kept as profiles/r03_bench_default_c.json)
+python scripts/make_named_profile_md.py [N]   (default 3; bench.json of round 3 = the plain default run kept as profiles/r03_bench_default_d.json)
 Per-launch figures: the PMC passes run --steps 2 --warmup 1 = 3 launches of 10 M reads + the 20 k-read parity sample."""
 import json
 import os
