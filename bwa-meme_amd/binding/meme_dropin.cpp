@@ -11,7 +11,7 @@
 //   memoryAllocLearned()            src/fastmap.cpp:351-641   worker buffers as before, but the index files stream to HBM
 //                                   (meme_index_load_files + meme_index_replicate per extra GPU) instead of being
 //                                   expanded on the host (13-byte suffix-array entries + ISA, ~200 s / ~120 GB at GRCh38)
-//   mem_process_seqs()              src/bwamem.cpp:1920-1972  ONE meme_seed_batch_host() per -K chunk (split over the
+//   mem_process_seqs()              src/bwamem.cpp:1920-1972  ONE meme_seed_batch_resident() / _host() per -K chunk (split over the
 //                                   visible GPUs) followed by meme_chain_last_batch_host() (mem_chain_Learned +
 //                                   mem_chain_flt on the device) before kt_for(worker_bwt); then the reference's own body
 //   mem_kernel1_core_Learned()      src/bwamem.cpp:1230-1413  per 512-read batch: takes the chunk's chains; the reference's
