@@ -42,6 +42,10 @@ struct DevIndex {
     const Rmi32* l1 = nullptr;
     i64 n_l2 = 0, n_l1 = 0;
     int shift = 64;            // key >> shift = leaf index
+    // plcp[u] = min(255, longest common prefix of the suffix at TEXT position u with either of its suffix-array neighbours): the depth
+    // down to which that suffix is not alone in its suffix-array interval.  Derived from sa + pac when an index is staged
+    // (k_build_plcp); what the re-seeding verifier (k_reseed) walks instead of searching.  1 byte per suffix.
+    const uint8_t* plcp = nullptr;
 };
 
 struct DevBuf {   // growable device workspace
@@ -56,9 +60,10 @@ struct meme_ctx {
     DevIndex idx;
     bool owns_index = false;
     std::vector<std::pair<void*, size_t>> owned;   // device allocations of the index (pointer, bytes)
+    void* plcp_aux = nullptr;                      // the plcp table of an attached index (meme_index_attach: the arrays are the caller's, this is ours)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[9], gcig[6], kswv[7];
+           scan_tmp, counters, redo, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[9], gcig[6], kswv[7];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2], h_kswv;
     i64 last_seed_max_len = 0;         // longest read of that batch
@@ -69,6 +74,7 @@ struct meme_ctx {
                                        // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
+    i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched
     i64 chain_light_hits = 32;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it
     i64 chain_lane_hits = 256;         // hits per read the lane-per-read chaining tier walks; reads with more go to the wavefront tiers at once
     i64 chain_wave_tiers = 1;          // 0: the chaining stage skips the LDS tier (everything beyond the lane tier through the B-tree tier; tests)
@@ -85,7 +91,7 @@ struct meme_ctx {
     hipEvent_t ev_side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_aux = nullptr;
     i64 chain_reads = 0, chain_tier2_reads = 0, chain_tier3_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
-    meme_timings tm = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    meme_timings tm = {};
 };
 
 void meme_set_error(const char* fmt, ...);

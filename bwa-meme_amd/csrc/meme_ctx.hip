@@ -62,10 +62,10 @@ extern "C" int meme_device_count(void) {
 
 // The chaining stage runs four kernels side by side (the lane tier and three sizes of the wavefront tier, each on a stream of its own);
 // the HIP runtime multiplexes a process's streams onto 4 hardware queues per device by default, and two kernels on one queue run one
-// after the other (measured: 7.9 ms per 2 M reads with 4 queues, 7.4 ms with 8).  Ask for 8 unless the user has set the variable; it
-// is read when the runtime initialises, so this only takes effect in a process whose first HIP call comes after this library is loaded
-// (the aligner with the binding; not a Python process that has already used torch).
-__attribute__((constructor)) static void meme_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// after the other (measured: 7.9 ms per 2 M reads with 4 queues, 7.4 ms with 8).  GPU_MAX_HW_QUEUES=8 is read when the runtime initialises.
+// (Round 3 set the variable from a library constructor; that changed the queue configuration of every HIP user in the host process and
+// raced getenv() in other threads.  Now the binding sets it in its own start-up code, before the first HIP call, and bench.py in its
+// environment; the library only documents it.)
 
 extern "C" meme_ctx* meme_ctx_create(int device) {
     int n = meme_device_count();
@@ -99,7 +99,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
-                      &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws};
+                      &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws, &ctx->redo};
     for (DevBuf* b : bufs) free_buf(*b);
     for (DevBuf& b : ctx->chain) free_buf(b);
     for (DevBuf& b : ctx->ext) free_buf(b);
@@ -110,6 +110,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (meme_ctx::HostBuf& h : ctx->h_gcig) if (h.p) (void)hipHostFree(h.p);
     if (ctx->h_kswv.p) (void)hipHostFree(ctx->h_kswv.p);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
+    if (ctx->plcp_aux) (void)hipFree(ctx->plcp_aux);
     for (meme_ctx::HostBuf* h : {&ctx->h_smems, &ctx->h_hits, &ctx->h_smem_off, &ctx->h_hit_off, &ctx->h_misc})
         if (h->p) (void)hipHostFree(h->p);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -142,6 +143,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return MEME_E_ARG;
     if (!strcmp(key, "seed_blocks")) ctx->seed_blocks = value;
     else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
+    else if (!strcmp(key, "seed_defer")) ctx->seed_defer = value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
     else if (!strcmp(key, "chain_wave_tiers")) ctx->chain_wave_tiers = value;
@@ -222,6 +224,55 @@ __global__ void __launch_bounds__(256) k_rmi32(const RmiRec* __restrict__ in, i6
   }
 }
 
+// Longest common prefix (capped at 255, and by the shorter suffix) of the suffixes in two adjacent suffix-array slots: the keys settle
+// it below 32 bases, the 2-bit text beyond.
+__device__ __forceinline__ int pair_lcp(const SaEnt a, const SaEnt b, i64 n, const u64* __restrict__ pac) {
+    i64 lim = n - (i64)(a.pos > b.pos ? a.pos : b.pos);
+    if (lim > 255) lim = 255;
+    const u64 x = a.key ^ b.key;
+    int l = x ? (__clzll((long long)x) >> 1) : 32;
+    if (!x) {
+        for (int m = 1; l < lim; ++m) {
+            const u64 y = extract32(pac, (i64)a.pos + 32 * m) ^ extract32(pac, (i64)b.pos + 32 * m);
+            if (y) { l += __clzll((long long)y) >> 1; break; }
+            l += 32;
+        }
+    }
+    return l < (int)lim ? l : (int)lim;
+}
+
+// plcp[text position of slot i] = min(255, max(lcp(slot i-1, slot i), lcp(slot i, slot i+1))): one thread per slot, the lcp with the
+// next slot computed once and handed to the neighbour thread through LDS.  The byte stores scatter over the text (one-off, at staging).
+__global__ void __launch_bounds__(256) k_build_plcp(const SaEnt* __restrict__ ent, i64 n, const u64* __restrict__ pac, uint8_t* __restrict__ plcp) {
+    __shared__ int sl[257];
+    for (i64 b0 = (i64)blockIdx.x * 256; b0 < n; b0 += (i64)gridDim.x * 256) {
+        const i64 i = b0 + threadIdx.x;
+        SaEnt e; e.key = 0; e.pos = 0;
+        int ln = 0;
+        if (i < n) {
+            e = ent[i];
+            if (i + 1 < n) ln = pair_lcp(e, ent[i + 1], n, pac);
+        }
+        sl[threadIdx.x + 1] = ln;
+        if (threadIdx.x == 0) sl[0] = b0 > 0 ? pair_lcp(ent[b0 - 1], e, n, pac) : 0;
+        __syncthreads();
+        if (i < n) {
+            const int a = sl[threadIdx.x], b = sl[threadIdx.x + 1];
+            plcp[e.pos] = (uint8_t)(a > b ? a : b);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int meme_stage_build_plcp(meme_ctx* ctx, const void* d_sa_ent, int64_t n, const void* d_pac64, void* d_plcp) {
+    if (!ctx || !d_sa_ent || !d_pac64 || !d_plcp || n <= 0) return MEME_E_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_build_plcp, dim3(stage_blocks(n)), dim3(256), 0, ctx->stream, (const SaEnt*)d_sa_ent, (i64)n, (const u64*)d_pac64,
+                       (uint8_t*)d_plcp);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
+
 extern "C" int meme_stage_pack_text(meme_ctx* ctx, const uint8_t* d_text, int64_t n, void* d_pac64) {
     if (!ctx || !d_text || !d_pac64 || n <= 0) return MEME_E_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -295,6 +346,7 @@ static void drop_index(meme_ctx* ctx) {
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     ctx->owned.clear();
     ctx->owns_index = false;
+    if (ctx->plcp_aux) { (void)hipFree(ctx->plcp_aux); ctx->plcp_aux = nullptr; }
     ctx->idx = DevIndex();
 }
 
@@ -382,6 +434,12 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
     lap("model records");
     HIP_TRY(hipFree(d_tmp));
     lap("free of the staging buffer");
+    void* d_plcp = nullptr;
+    if ((rc = own_alloc(ctx, &d_plcp, (size_t)n + 64))) return rc;
+    if ((rc = meme_stage_build_plcp(ctx, d_ent, n, d_pac, d_plcp))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    lap("plcp table");
+    ctx->idx.plcp = (const uint8_t*)d_plcp;
     ctx->idx.n = n;
     ctx->idx.sa = (const SaEnt*)d_ent;
     ctx->idx.pac = (const u64*)d_pac;
@@ -527,6 +585,12 @@ extern "C" int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* a) {
     ctx->idx.pac = (const u64*)a->d_pac64;
     ctx->idx.l2 = (const Rmi32*)a->d_l2;
     ctx->idx.l1 = (const Rmi32*)a->d_l1;
+    // the plcp table is derived data: built here into memory of the ctx (the caller's arrays stay the caller's)
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(&ctx->plcp_aux, (size_t)a->sa_num + 64));
+    if ((rc = meme_stage_build_plcp(ctx, a->d_sa_ent, a->sa_num, a->d_pac64, ctx->plcp_aux))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->idx.plcp = (const uint8_t*)ctx->plcp_aux;
     return MEME_OK;
 }
 
@@ -566,6 +630,7 @@ extern "C" int meme_index_replicate(meme_ctx* dst, meme_ctx* src) {
         if ((const void*)I.pac == o.first) I.pac = (const u64*)d;
         if ((const void*)I.l2 == o.first) I.l2 = (const Rmi32*)d;
         if ((const void*)I.l1 == o.first) I.l1 = (const Rmi32*)d;
+        if ((const void*)I.plcp == o.first) I.plcp = (const uint8_t*)d;
     }
     HIP_TRY(hipStreamSynchronize(dst->stream));
     dst->idx = I;

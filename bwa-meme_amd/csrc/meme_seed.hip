@@ -5,6 +5,7 @@
 // outputs are the mem_tl records and hit positions its unchanged consumer mem_chain_Learned() reads
 // (src/bwamem.cpp:1122-1204): hits of one SMEM in ascending suffix-array order.
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "meme_seed_kernel.h"
@@ -148,7 +149,8 @@ __global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, 
             const i64 hb = hb0 + incl - h;
             u64 first = 0;
             if (act) {
-                first = sa[s.sa_start].pos;
+                // an SMEM with one occurrence usually carries the position itself (the search had it in registers)
+                first = (s.sa_start & SLOT_POS) ? (u64)(s.sa_start & SLOT_VAL) : sa[s.sa_start].pos;
                 meme_mem_tl m;
                 m.start = s.start;
                 m.end = s.end;
@@ -183,13 +185,13 @@ int launch_k_seed(meme_ctx* ctx, const SeedArgs& A, size_t lds, i64 blocks) {
 
 int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i64 nreads, i64 max_len, i64 total_bytes,
                 const meme_seed_opt* opt, meme_seed_result* out) {
-    unsigned long long h_counters[12];
+    unsigned long long h_counters[16];
     int rc;
     ctx->last_seed_reads = 0;          // whatever batch meme_chain_last_batch_host could have chained is being overwritten
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 12 * sizeof(unsigned long long)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long)))) return rc;
     const int dev_cus = ctx->n_cus;
     // ---- pack the reads: 2 bits/base, both strands, N masks (k_pack_reads) ---------------------------------
     // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262): fail loudly, never seed part of a batch
@@ -217,8 +219,8 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-    float ms_total = 0.f;
-    i64 launches = 0, searches = 0, windows = 0;
+    float ms_total = 0.f, ms_reseed = 0.f, ms_resume = 0.f;
+    i64 launches = 0, searches = 0, windows = 0, redo_reads = 0;
     TierTable tiers;
     for (int t = 0; t < N_TIERS; ++t) { tiers.base[t] = nullptr; tiers.cap[t] = 0; }
     i64 n_todo = nreads;
@@ -244,7 +246,12 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         }
         if ((rc = meme_buf_reserve(ctx, sb, need))) return rc;
         if ((rc = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 12 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
+        // Tier 0 leaves the re-seeding regions of unique SMEMs to k_reseed (a walk on the plcp table, one lane per read) and a resume
+        // launch for the regions the walk cannot settle; the overflow tiers search everything themselves.
+        const bool defer = tier == 0 && ctx->seed_defer != 0 && ctx->idx.plcp != nullptr && opt->rounds >= 2 &&
+                           2 * lcap * (int)sizeof(int) >= 2 * PLCP_WIN;     // (the resume launch stages two table windows in the SMEM ring)
+        if (defer && (rc = meme_buf_reserve(ctx, ctx->redo, (size_t)n_todo * sizeof(RedoRec)))) return rc;
         SeedArgs A;
         A.I = ctx->idx;
         A.packed = (const u64*)ctx->packed.p;
@@ -262,6 +269,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.lcap = lcap;
         A.tier = tier;
         A.counters = (unsigned long long*)ctx->counters.p;
+        A.defer = defer ? 1 : 0;
+        A.redo = nullptr;
+        A.ticket_ctr = 0;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
         while (G < 32 && seed_lds_bytes(G, geo, lcap) > (size_t)160 * 1024) G *= 2;   // long reads: fewer reads per workgroup
@@ -282,12 +292,44 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         default: meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG;
         }
         if (rc) return rc;
+        if (defer) {
+            HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+            i64 rblocks = (n_todo + 255) / 256;
+            if (rblocks > (i64)dev_cus * 32) rblocks = (i64)dev_cus * 32;
+            hipLaunchKernelGGL(k_reseed, dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, ctx->idx.plcp, ctx->idx.n, (const SlotRec*)sb.p, cap,
+                               (const int*)ctx->slot_cnt.p, d_read_off, n_todo, *opt, (RedoRec*)ctx->redo.p, (unsigned long long*)ctx->counters.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
+            // the resume launch: same kernel, its reads and their regions come from the redo records (their number stays on the device)
+            SeedArgs R = A;
+            R.defer = 0;
+            R.redo = (const RedoRec*)ctx->redo.p;
+            R.ticket_ctr = 13;
+            switch (G) {
+            case 1: rc = launch_k_seed<1>(ctx, R, lds, blocks); break;
+            case 2: rc = launch_k_seed<2>(ctx, R, lds, blocks); break;
+            case 4: rc = launch_k_seed<4>(ctx, R, lds, blocks); break;
+            case 8: rc = launch_k_seed<8>(ctx, R, lds, blocks); break;
+            case 16: rc = launch_k_seed<16>(ctx, R, lds, blocks); break;
+            default: rc = launch_k_seed<32>(ctx, R, lds, blocks); break;
+            }
+            if (rc) return rc;
+        }
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ms_total += ms;
+        if (defer) {
+            float a = 0.f, b = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]));
+            HIP_TRY(hipEventElapsedTime(&b, ctx->ev[5], ctx->ev[1]));
+            ms_reseed += a; ms_resume += b;
+            redo_reads += (i64)h_counters[12];
+            if (getenv("MEME_SEED_TRACE")) fprintf(stderr, "[meme] seed tier 0: search launch %.2f ms, verifier %.2f ms, resume launch %.2f ms: %lld reads, %lld searches, %lld windows\n",
+                                                   ms - a - b, a, b, (long long)h_counters[12], (long long)h_counters[15], (long long)h_counters[14]);
+        }
         ++launches;
         searches += (i64)h_counters[1];
 #ifdef SEED_PROF
@@ -317,6 +359,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     ctx->tm.seed_kernel_ms = ms_total;
     ctx->tm.seed_launches = launches;
     ctx->tm.seed_windows = windows;
+    ctx->tm.seed_reseed_ms = ms_reseed;
+    ctx->tm.seed_resume_ms = ms_resume;
+    ctx->tm.seed_redo_reads = redo_reads;
     // offsets
     i64 ntiles = (nreads + SCAN_TILE - 1) / SCAN_TILE;
     if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, (size_t)(2 * ntiles + 2) * sizeof(i64)))) return rc;
@@ -468,7 +513,7 @@ extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_ba
     int rc;
     struct { DevBuf* b; size_t bytes; } dev[] = {
         {&ctx->reads, (size_t)total_bases + 16}, {&ctx->read_off, (n + 1) * 8}, {&ctx->slot_cnt, n * 4}, {&ctx->slot_hits, n * 8},
-        {&ctx->slot_loc, n * 8}, {&ctx->counters, 12 * 8}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
+        {&ctx->slot_loc, n * 8}, {&ctx->counters, 16 * 8}, {&ctx->redo, n * sizeof(RedoRec)}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
         {&ctx->smem_off, (n + 1) * 8}, {&ctx->hit_off, (n + 1) * 8}, {&ctx->smems, n * 12 * sizeof(meme_mem_tl)}, {&ctx->hits, n * 24 * 8},
         {&ctx->chain[0], n * 16 * 32}, {&ctx->chain[1], n * 16 * 8 * 16}, {&ctx->chain[2], n * 24}, {&ctx->chain[3], n * 4}, {&ctx->chain[8], n * 8},
         {&ctx->chain[5], (n + 1) * 32 + n * 5 + 64}, {&ctx->chain[6], n * 3 * sizeof(meme_chain)}, {&ctx->chain[7], n * 6 * sizeof(meme_chain_seed)}};

@@ -42,8 +42,19 @@ constexpr int MAX_READ_LEN = 500;        // LEARNED_MAX_READ_LEN (reference src/
 
 struct SlotRec {          // search-kernel output, one per SMEM
     int32_t start, end;
-    i64 sa_start;
+    i64 sa_start;         // first suffix-array slot of the interval, or SLOT_POS | text position of the only hit (+ SLOT_DEFER)
     i64 count;
+};
+// sa_start flags.  An SMEM with ONE occurrence whose text position the search already holds (it sits in the window that settled the
+// search) carries the position itself: the gather kernel need not fetch it again, and the position is what the re-seeding verifier needs.
+constexpr i64 SLOT_POS = 1ll << 62;
+constexpr i64 SLOT_DEFER = 1ll << 61;     // the SMEM's re-seeding region (round 2) was not searched here: k_reseed walks it on the plcp table
+constexpr i64 SLOT_VAL = (1ll << 48) - 1;
+constexpr int DEFER_MAX_K = 64;           // only the first 64 SMEMs of a read can be deferred (one bit each in RedoRec::mask)
+
+struct RedoRec {          // k_reseed -> the resume launch of k_seed: the re-seeding regions of read `rid` that need real searches
+    i64 rid;
+    u64 mask;             // bit k: SMEM k of the read
 };
 
 constexpr int N_TIERS = 3;
@@ -73,7 +84,10 @@ struct SeedArgs {
     const i64* pending;    // read ids to re-process in an overflow tier, else nullptr
     i64* ovf_list;
     int cap, lcap, tier;
-    unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads, [3] window loads
+    unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads, [3] window loads, [4..11] SEED_PROF, [12] redo records, [13] resume ticket
+    int defer;                      // 1: re-seeding regions of unique SMEMs are left to k_reseed (tier 0 only)
+    const RedoRec* redo;            // resume launch: the reads (and their regions) k_reseed could not settle; nreads is then read from counters[12]
+    int ticket_ctr;                 // which counter hands out this launch's tickets (0; 13 for the resume launch)
 };
 
 // ---- read packing -------------------------------------------------------------------------------------
@@ -209,7 +223,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
 // wait for each other and the only heavy code (window load + compare) exists once in the kernel.
 enum Pc : int {
     PC_FETCH, PC_ALLPOS_TOP, PC_ZZ_TOP, PC_ZZ_RIGHT, PC_ZZ_END, PC_AFTER_STEP1, PC_R2_LOOP, PC_R2_AFTER, PC_R3_INIT,
-    PC_R3_TOP, PC_DONE, PC_EXIT
+    PC_R3_TOP, PC_DONE, PC_EXIT, PC_RESUME
 };
 enum Kind : int { K_S1_RIGHT, K_ZZ_LEFT, K_ZZ_RIGHT, K_OP_MEM, K_OP_SMEM, K_R3 };
 // what the next window is for: the partition point of the query (first window at the model's prediction, later ones
@@ -252,6 +266,14 @@ __device__ __forceinline__ u64 ext_l(q_u64 w, int s) {
     return sh ? (a << sh) | (b >> (64 - sh)) : a;
 }
 
+// The re-seeding walks read the plcp table around a region's middle: two windows of PLCP_WIN bytes (the locus, its mirror on the other
+// strand), 16-byte aligned so that they can be fetched with aligned 16-byte loads.  The zig-zag moves at most min_seed_len - 1 bases
+// per step, so it rarely leaves them (then the byte comes from global memory).
+constexpr int PLCP_WIN = 64;
+typedef const __attribute__((address_space(3))) uint8_t* lds_u8;
+__device__ __forceinline__ i64 plcp_win_fwd(i64 T0, int mid) { const i64 a = T0 + mid - 24; return (a < 0 ? 0 : a) & ~15ll; }
+__device__ __forceinline__ i64 plcp_win_rev(i64 T0, int mid, i64 n) { const i64 a = n - 1 - (T0 + mid + 24); return (a < 0 ? 0 : a) & ~15ll; }
+
 __device__ __forceinline__ u64 lowmask(int k) { return k >= 64 ? ~0ull : (k <= 0 ? 0ull : ((1ull << k) - 1ull)); }
 
 // cold per-read state kept in LDS (group-uniform redundant stores; every lane reads back what it wrote)
@@ -262,6 +284,8 @@ enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_R2_SAVED, ST_ZZ_
                    ST_L, ST_SE_LO, ST_SE_HI, ST_EE_LO, ST_EE_HI, ST_NB_LO, ST_NB_HI, ST_LF, ST_CB_LO, ST_CB_HI,
                    ST_TICKET_LO, ST_TICKET_HI, ST_WORDS };
 // per-read words are cleared when a read is staged; the group's running totals live in registers
+// resume launch: the region being searched (its SMEM's span and diagonal); the words are free there (no first round, no ring)
+constexpr int ST_RS_SE = ST_R2_K, ST_RS_T_LO = ST_LAST_S_LO;   // (a 64-bit value takes two consecutive words; ST_LAST_* belong to the third round)
 enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2, F_REC = 4, F_LDS_OVF = 8 };
 enum LevelFlag : int { LF_NEED_LO = 1, LF_NEED_HI = 2, LF_HAVE_LAST = 4 };
 
@@ -472,6 +496,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     const glb_ent sa = (glb_ent)A.I.sa;
     const glb_u64 pac = (glb_u64)A.I.pac;
     const glb_rmi l2 = (glb_rmi)A.I.l2, l1 = (glb_rmi)A.I.l1;
+    const __attribute__((address_space(1))) uint8_t* plcp = (const __attribute__((address_space(1))) uint8_t*)A.I.plcp;
     const i64 n = A.I.n;
     const int hits_per_smem = A.opt.hits_per_smem;
 #define GBALLOT(p_) ((__ballot(p_) >> gbase) & GFULL)
@@ -515,6 +540,43 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             bool have = false;
 #define AT(pc_) (!have && pc == (pc_))
             do {
+                if (A.redo && (AT(PC_ZZ_TOP) || AT(PC_ZZ_RIGHT))) {
+                    // Resume launch: the zig-zag of a region k_reseed sent back.  Most of its searches are still answered by the plcp
+                    // table (reseed_walk's rules, one byte load each); only the one that leaves the SMEM, meets a saturated entry or
+                    // would emit becomes a window search, and the walk goes on behind it.
+                    const int se = st[ST_RS_SE];
+                    const int qbeg = se & 0xffff, qend = (int)((unsigned)se >> 16);
+                    const i64 T0 = LD64(ST_RS_T_LO);
+                    const int next = st[ST_ZZ_NEXT];
+                    int guard = st[ST_ZZ_GUARD], nh = 0;
+                    // the two 64-byte pieces of the table around the region's middle were staged in the (idle) SMEM ring by PC_RESUME
+                    const int mid = (qbeg + qend) >> 1;
+                    const i64 F0 = plcp_win_fwd(T0, mid), R0 = plcp_win_rev(T0, mid, n);
+                    const lds_u8 pw = (lds_u8)ring;
+#define PLC_AT(pos_, w0_, off_) (((pos_) - (w0_) >= 0 && (pos_) - (w0_) < PLCP_WIN) ? (int)pw[(off_) + (int)((pos_) - (w0_))] : (int)plcp[pos_])
+                    for (;;) {
+                        if (pc == PC_ZZ_TOP) {
+                            if (pivot >= next || ++guard > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
+                            const bool in = pivot >= qbeg && pivot < qend;
+                            const i64 up = n - 1 - (T0 + pivot);
+                            const int plc = in ? PLC_AT(up, R0, PLCP_WIN) : 0;
+                            if (plc == 0 || plc == 255 || plc >= pivot - qbeg + 1) { q_kind = K_ZZ_LEFT; have = true; break; }
+                            ++nh;
+                            pivot = pivot - plc + 1;
+                            if (next - pivot < msl) { pc = PC_ZZ_END; break; }
+                            pc = PC_ZZ_RIGHT;
+                        }
+                        const bool in = pivot >= qbeg && pivot < qend;
+                        const i64 uf = T0 + pivot;
+                        const int plc = in ? PLC_AT(uf, F0, 0) : 0;
+                        if (plc == 0 || plc == 255 || plc >= qend - pivot || plc >= msl) { q_kind = K_ZZ_RIGHT; have = true; break; }
+                        ++nh;
+                        pivot = pivot + plc;
+                        pc = PC_ZZ_TOP;
+                    }
+#undef PLC_AT
+                    st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = guard; st[ST_SEARCHES] = st[ST_SEARCHES] + nh;
+                }
                 if (AT(PC_ZZ_TOP)) {       // zig-zag loop head (:1724-1737, :1969)
                     if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) pc = PC_ZZ_END;
                     else if (FLAG(F_ZZ_CHECK) && has_n && is_n(nfw, st[ST_ZZ_SP])) {
@@ -537,7 +599,43 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 if (AT(PC_R2_AFTER)) {     // (:945-946)
                     min_intv = st[ST_R2_SAVED];
                     pivot = st[ST_R2_NEXT];
-                    pc = PC_R2_LOOP;
+                    pc = A.redo ? PC_RESUME : PC_R2_LOOP;
+                }
+                if (AT(PC_RESUME)) {       // resume launch: the next region of this read that k_reseed sent back (bits in ST_BEFORE/ST_AFTER)
+                    const unsigned mlo = (unsigned)st[ST_BEFORE], mhi = (unsigned)st[ST_AFTER];
+                    if ((mlo | mhi) == 0) pc = PC_DONE;
+                    else {
+                        const int k = mlo ? __ffs((int)mlo) - 1 : 32 + __ffs((int)mhi) - 1;
+                        if (mlo) st[ST_BEFORE] = (int)(mlo & (mlo - 1)); else st[ST_AFTER] = (int)(mhi & (mhi - 1));
+                        const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
+                        const SlotRec* srp = &A.slots[(i64)ticket * cap + k];                               // written by the first launch
+                        const u64 se = *reinterpret_cast<const u64*>(srp);                                   // {start, end}
+                        const int qbeg = (int)(unsigned)(se & 0xffffffffull), qend = (int)(se >> 32);
+                        const i64 T0 = (srp->sa_start & SLOT_VAL) - qbeg;
+                        st[ST_RS_SE] = qbeg | (qend << 16); ST64(ST_RS_T_LO, T0);
+                        // the region as PC_R2_LOOP enters it (:932-944, :1917-1969): one occurrence -> min_intv 2; the middle of an SMEM has
+                        // a base on either side, none of them ambiguous
+                        st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
+                        pivot = (qbeg + qend) >> 1;
+                        min_intv = 2;
+                        // stage the table around the middle: 64 bytes of the locus, 64 of its mirror (aligned 16-byte loads, all in flight together)
+                        {
+                            const i64 F0 = plcp_win_fwd(T0, pivot), R0 = plcp_win_rev(T0, pivot, n);
+                            for (int c = t; c < 2 * (PLCP_WIN / 16); c += G) {        // (the ring is only 8-byte aligned: dword stores)
+                                const i64 src = c < PLCP_WIN / 16 ? F0 + 16 * c : R0 + 16 * (c - PLCP_WIN / 16);
+                                const uint4 v = *reinterpret_cast<const uint4*>(A.I.plcp + src);
+                                ring[4 * c] = (int)v.x; ring[4 * c + 1] = (int)v.y; ring[4 * c + 2] = (int)v.z; ring[4 * c + 3] = (int)v.w;
+                            }
+                            LDS_HANDOFF();
+                        }
+                        const int plc = (int)((lds_u8)ring)[(int)(T0 + pivot - plcp_win_fwd(T0, pivot))];
+                        if (plc == 0 || plc == 255 || plc >= qend - pivot) { q_kind = K_OP_MEM; have = true; }
+                        else {                 // K_OP_MEM answered by the table (:1967-1969)
+                            st[ST_ZZ_NEXT] = pivot + plc; SETFLAG(F_ZZ_CHECK, false); SETFLAG(F_ZZ_RET_ONEPOS, true); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
+                            st[ST_SEARCHES] = st[ST_SEARCHES] + 1;
+                            pc = PC_ZZ_TOP;
+                        }
+                    }
                 }
                 if (AT(PC_R2_LOOP)) {      // (:923-947) + OnePos entry (:1917-1930)
                     int k = st[ST_R2_K];
@@ -626,7 +724,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         const int kreq = __popcll(mo), alloc = kreq > TICKET_CHUNK ? kreq : TICKET_CHUNK;
                         unsigned long long nb = 0;
                         if (lane == first) {
-                            nb = atomicAdd(&A.counters[0], (unsigned long long)alloc);
+                            nb = atomicAdd(&A.counters[A.ticket_ctr], (unsigned long long)alloc);
                             const unsigned long long wb = nb + (unsigned)(alloc - TICKET_CHUNK);
                             wv[0] = kreq - (alloc - TICKET_CHUNK); wv[2] = (int)(unsigned)(wb & 0xffffffffull); wv[3] = (int)(wb >> 32);
                         }
@@ -634,8 +732,11 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         if (over) ticket = nb + (unsigned)__popcll(mo & ((1ull << lane) - 1ull));
                     }
                     ticket = __shfl(ticket, gbase);
-                    if (ticket >= (unsigned long long)A.nreads) pc = PC_EXIT;
+                    const unsigned long long n_tickets = A.redo ? A.counters[12] : (unsigned long long)A.nreads;
+                    if (ticket >= n_tickets) pc = PC_EXIT;
                     else {
+                        u64 redo_mask = 0;
+                        if (A.redo) { redo_mask = A.redo[ticket].mask; ticket = (unsigned long long)A.redo[ticket].rid; }   // slot block = read id in tier 0
                         const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
                         const u64* src = A.packed + rid * stride;
 #if SEED_QUERY_LDS
@@ -668,6 +769,13 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                             st[ST_TICKET_HI] = (int)(ticket >> 32);
                             pivot = 0; msl = A.opt.min_seed_len; min_intv = 1;
                             pc = PC_ALLPOS_TOP;
+                            if (A.redo) {
+                                // the read was seeded by the first launch: go on behind its SMEMs, with the regions to search as a bit mask
+                                st[ST_N_SMEMS] = A.slot_cnt[rid];
+                                ST64(ST_HITS_LO, A.slot_hits[rid]);
+                                st[ST_BEFORE] = (int)(unsigned)(redo_mask & 0xffffffffull); st[ST_AFTER] = (int)(redo_mask >> 32);
+                                pc = PC_RESUME;
+                            } else
                             if (!(has_n && is_n(nfw, 0))) {                       // first step of PC_ALLPOS_TOP at pivot 0, inlined
                                 st[ST_AP_GUARD] = 1; SETFLAG(F_REC, true);
                                 q_kind = K_S1_RIGHT; have = true;
@@ -680,6 +788,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             if (pc == PC_EXIT) {
                 if (t == 0) {
                     atomicAdd(&A.counters[1], (unsigned long long)acc_searches); atomicAdd(&A.counters[3], (unsigned long long)acc_windows);
+                    if (A.redo) { atomicAdd(&A.counters[15], (unsigned long long)acc_searches); atomicAdd(&A.counters[14], (unsigned long long)acc_windows); }
 #ifdef SEED_PROF
                     for (int k = 0; k < 8; ++k) atomicAdd(&A.counters[4 + k], (unsigned long long)prof[k]);
 #endif
@@ -722,8 +831,9 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         const q_u64 s = q_rc ? rcs : fw;
         int lcp[E];
         bool less[E];
+        u64 ep[E];
         {
-            u64 ek[E], ep[E];
+            u64 ek[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) { ek[e] = sa[base + e * G + t].key; ep[e] = sa[base + e * G + t].pos; }
             st[ST_WINDOWS] = st[ST_WINDOWS] + 1;
@@ -750,7 +860,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         int L = 0, nb_lo = 0, nb_hi = 0, lf = 0;
         i64 s_edge = 0, e_edge = 0, cb = base;
         int r_L = 0;
-        i64 r_start = 0, r_count = 1;
+        i64 r_start = 0, r_count = 1, r_T = -1;   // r_T: text position of slot r_start when this window holds it (only used when r_count == 1)
         bool r_emit = false;
         int cl[E];                       // LCPs of the cached partition window (this lane's slots)
         bool cache_in_lds = phase != PH_PART;
@@ -764,6 +874,12 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 const int c = (lm >= lp) ? P - 1 : P;
                 L = lm >= lp ? lm : lp;
                 r_L = L; r_start = base + c; r_count = 1;
+                if (q_exact || q_kind == K_R3) {              // the kinds that emit: an interval of ONE suffix is this slot, and its position is here
+                    u64 tc = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) tc = (e * G + t == c) ? ep[e] : tc;
+                    r_T = (i64)(((u64)(unsigned)group_or<G>((int)(tc >> 32)) << 32) | (u64)(unsigned)group_or<G>((int)(unsigned)tc));
+                }
                 if (q_mode == 0 || (q_mode == 2 && L < msl)) finished = true;       // (:1204-1208)
                 else {
                     s_edge = e_edge = base + c;
@@ -904,10 +1020,18 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             }
             if (emit) {               // kv_push of mem_tl + hits (:2639-2657, :1266-1277)
                 const int ns = st[ST_N_SMEMS];
+                // One occurrence, and its text position is in this window's registers: the record carries the position.  If the SMEM
+                // would be re-seeded (:929-931: long enough, at most split_width occurrences) the region -- a zig-zag of ~20 searches
+                // around its middle that asks "how long a piece of this locus occurs twice" -- is left to k_reseed, which answers that
+                // from the plcp table, and is skipped below by giving the ring entry an occurrence count no split_width admits.
+                const bool have_pos = r_count == 1 && r_T >= 0 && !cache_in_lds;
+                const bool defer = have_pos && A.defer != 0 && FLAG(F_REC) && ns < DEFER_MAX_K && ns < cap && A.opt.rounds >= 2 &&
+                                   e_end - e_start >= A.opt.split_len && A.opt.split_width >= 1;
                 if (ns < cap && t == 0) {
                     const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
                     SlotRec sr;
-                    sr.start = e_start; sr.end = e_end; sr.sa_start = r_start; sr.count = r_count;
+                    sr.start = e_start; sr.end = e_end; sr.count = r_count;
+                    sr.sa_start = have_pos ? (SLOT_POS | (defer ? SLOT_DEFER : 0ll) | r_T) : r_start;
                     A.slots[(i64)ticket * cap + ns] = sr;
                 }
                 if (FLAG(F_REC)) {
@@ -915,7 +1039,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                     if (k < lcap) {
                         // group-uniform redundant LDS stores (every lane writes the same value): no hand-off needed
                         sm_se[k] = e_start | (e_end << 16);
-                        sm_cnt[k] = r_count > (i64)INT_MAX ? INT_MAX : (int)r_count;
+                        sm_cnt[k] = (defer || r_count > (i64)INT_MAX) ? INT_MAX : (int)r_count;
                     } else SETFLAG(F_LDS_OVF, true);
                 }
                 st[ST_N_SMEMS] = ns + 1;
@@ -945,6 +1069,118 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
 #undef FLAG
 #undef SETFLAG
 #undef LDS_HANDOFF
+}
+
+
+// ---- the re-seeding verifier ---------------------------------------------------------------------------------------------------
+// Round 2 (Learned_getSMEMsAllPosOneThread :923-947 -> Learned_getSMEMsOnePosOneThread :1897-2126) re-seeds every SMEM of at least
+// split_len bases and at most split_width occurrences from its middle, asking for matches with MORE occurrences than the SMEM has.  For
+// an SMEM with one occurrence -- nearly all of them -- every search of that zig-zag lies inside the SMEM, i.e. its query is a piece of
+// the text at a known position u, and the answer "the longest prefix of text[u..] that occurs at least twice" is a property of u alone:
+// plcp[u] = the longest common prefix of suffix u with its nearer suffix-array neighbour (valid while it stays inside the SMEM:
+// plcp[u] < bases left to the SMEM's end; beyond that other loci decide and only a search can tell).  Leftward searches run on the
+// reverse complement, i.e. on the mirror position n-1-u.  One lane walks the whole zig-zag of a region on that table (no suffix-array
+// access, ~20 dependent byte loads in two cache lines) where k_seed spends ~20 window searches -- 40 % of all searches of a 150-bp
+// read.  The walk cannot emit: a match of >= min_seed_len bases with two occurrences needs its suffix-array interval, so it ends the walk
+// like a query that leaves the SMEM or a saturated table entry does, and the region goes to the resume launch of k_seed, which
+// searches it the usual way.  Regions the walk finishes emit nothing in the reference either.
+struct PlcpView {           // the plcp table as one lane of k_reseed sees it: two staged windows in LDS, global memory beyond them
+    const uint8_t* __restrict__ plcp;
+    const uint32_t* win;    // this lane's column of the workgroup's window array: dword j at win[j * 256]
+    i64 F0, R0;
+    __device__ __forceinline__ int at(i64 pos, i64 w0, int dw0) const {
+        const i64 d = pos - w0;
+        if (d >= 0 && d < PLCP_WIN) return (int)((win[(dw0 + (int)(d >> 2)) * 256] >> (8 * (int)(d & 3))) & 0xffu);
+        return (int)plcp[pos];
+    }
+    __device__ __forceinline__ int fwd(i64 pos) const { return at(pos, F0, 0); }
+    __device__ __forceinline__ int rev(i64 pos) const { return at(pos, R0, PLCP_WIN / 4); }
+};
+
+__device__ __forceinline__ bool reseed_walk(const PlcpView& V, i64 n, i64 T0 /* text position of read base 0 on this diagonal */,
+                                            int qbeg, int qend, int l_seq, int msl, unsigned& hops) {
+    // OnePos entry (:1959-1969): mem_search to the right of the middle with min_intv = 2 -> next_pivot
+    int pivot = (qbeg + qend) >> 1;
+    unsigned h = 1;
+    int plc = V.fwd(T0 + pivot);
+    if (plc == 0 || plc == 255 || plc >= qend - pivot) return false;
+    const int next = pivot + plc;
+    int sp = pivot, guard = 0;
+    bool ok = true;
+    while (sp < next) {                                   // the zig-zag (:1969-2084)
+        if (++guard > 4 * l_seq + 16) break;
+        ++h;
+        plc = V.rev(n - 1 - (T0 + sp));                    // leftwards from sp: the mirror locus
+        if (plc == 0 || plc == 255 || plc >= sp - qbeg + 1) { ok = false; break; }
+        pivot = sp - plc + 1;
+        if (next - pivot < msl) break;
+        ++h;
+        plc = V.fwd(T0 + pivot);                           // rightwards from the new pivot; >= msl bases would be an SMEM to emit
+        if (plc == 0 || plc == 255 || plc >= qend - pivot || plc >= msl) { ok = false; break; }
+        sp = pivot + plc;
+    }
+    hops = h;
+    return ok;
+}
+
+__global__ void __launch_bounds__(256) k_reseed(const uint8_t* __restrict__ plcp, i64 n, const SlotRec* __restrict__ slots, int cap,
+                                                 const int* __restrict__ slot_cnt, const i64* __restrict__ read_off, i64 nreads,
+                                                 meme_seed_opt opt, RedoRec* __restrict__ redo, unsigned long long* __restrict__ counters) {
+    // per lane two PLCP_WIN-byte windows of the table; dword j of lane L at [j * 256 + L]: whatever bytes the lanes ask for, the
+    // bank is the lane's own
+    __shared__ uint32_t win[2 * (PLCP_WIN / 4) * 256];
+    __shared__ unsigned blk_n, blk_base;
+    __shared__ unsigned long long blk_hops;
+    for (i64 r0 = (i64)blockIdx.x * blockDim.x; r0 < nreads; r0 += (i64)gridDim.x * blockDim.x) {
+        if (threadIdx.x == 0) { blk_n = 0; blk_hops = 0; }
+        __syncthreads();
+        const i64 r = r0 + threadIdx.x;
+        u64 mask = 0;
+        unsigned hops = 0;
+        if (r < nreads) {
+            int c = slot_cnt[r];
+            if (c > DEFER_MAX_K) c = DEFER_MAX_K;
+            const int l_seq = (int)(read_off[r + 1] - read_off[r]);
+            const SlotRec* sl = slots + r * cap;
+            for (int k = 0; k < c; ++k) {
+                const i64 f = sl[k].sa_start;
+                if (!(f & SLOT_DEFER)) continue;
+                const int qbeg = sl[k].start, qend = sl[k].end;
+                const i64 T0 = (f & SLOT_VAL) - qbeg;
+                const int mid = (qbeg + qend) >> 1;
+                PlcpView V;
+                V.plcp = plcp; V.win = win + threadIdx.x; V.F0 = plcp_win_fwd(T0, mid); V.R0 = plcp_win_rev(T0, mid, n);
+                {   // eight aligned 16-byte loads in flight together, then into this lane's LDS column
+                    uint4 v[2 * (PLCP_WIN / 16)];
+#pragma unroll
+                    for (int q = 0; q < PLCP_WIN / 16; ++q) {
+                        v[q] = *reinterpret_cast<const uint4*>(plcp + V.F0 + 16 * q);
+                        v[PLCP_WIN / 16 + q] = *reinterpret_cast<const uint4*>(plcp + V.R0 + 16 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2 * (PLCP_WIN / 16); ++q) {
+                        win[(4 * q + 0) * 256 + threadIdx.x] = v[q].x; win[(4 * q + 1) * 256 + threadIdx.x] = v[q].y;
+                        win[(4 * q + 2) * 256 + threadIdx.x] = v[q].z; win[(4 * q + 3) * 256 + threadIdx.x] = v[q].w;
+                    }
+                }
+                unsigned h = 0;
+                if (reseed_walk(V, n, T0, qbeg, qend, l_seq, opt.min_seed_len, h)) hops += h;
+                else mask |= 1ull << k;
+            }
+        }
+        // one atomic per workgroup for the redo records, one for the search count
+        unsigned my = 0;
+        if (mask) my = atomicAdd(&blk_n, 1u);
+        if (hops) atomicAdd(&blk_hops, (unsigned long long)hops);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            blk_base = blk_n ? (unsigned)atomicAdd(&counters[12], (unsigned long long)blk_n) : 0u;
+            if (blk_hops) atomicAdd(&counters[1], blk_hops);
+        }
+        __syncthreads();
+        if (mask) { RedoRec rr; rr.rid = r; rr.mask = mask; redo[blk_base + my] = rr; }
+        __syncthreads();
+    }
 }
 
 }  // namespace seedk

@@ -109,7 +109,8 @@ class Timings(C.Structure):
     _fields_ = [("seed_kernel_ms", C.c_float), ("seed_gather_ms", C.c_float), ("bsw_kernel_ms", C.c_float),
                 ("seed_launches", C.c_int64), ("bsw_launches", C.c_int64), ("seed_pack_ms", C.c_float),
                 ("seed_windows", C.c_int64), ("chain_kernel_ms", C.c_float), ("chain_pass2_ms", C.c_float), ("chain_tier3_ms", C.c_float),
-                ("chain_tier2_reads", C.c_int64), ("chain_tier3_reads", C.c_int64)]
+                ("chain_tier2_reads", C.c_int64), ("chain_tier3_reads", C.c_int64),
+                ("seed_reseed_ms", C.c_float), ("seed_resume_ms", C.c_float), ("seed_redo_reads", C.c_int64)]
 
 
 # every symbol include/meme_hip.h declares (tests/test_abi.py checks the library exports them all)
@@ -117,7 +118,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_ctx_stream", "meme_index_load_host", "meme_index_load_files", "meme_index_pac64_words",
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
-           "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries",
+           "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries", "meme_stage_build_plcp",
            "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 

@@ -87,6 +87,7 @@ void* meme_ctx_stream(meme_ctx* ctx);          /* the hipStream_t every kernel o
  *   sa_ent[n]   16 B {u64 key (32 bases, first base in the top bits, T-filled), u64 text position}
  *   pac64[]     2-bit text, 32 bases per u64, first base in the top bits
  *   l2[], l1[]  P-RMI records padded to 32 bytes (a lookup never straddles a 128-byte line)
+ *   plcp[n]     1 B per text position: LCP of that suffix with its nearer suffix-array neighbour, capped at 255 (derived on the device)
  * Keys are generated on the device (replaces the OpenMP loop of src/fastmap.cpp:549-613; no inverse suffix array). */
 int meme_index_load_host(meme_ctx* ctx, const uint8_t* pos_packed, int64_t sa_num,
                          const uint8_t* text0123, const void* l1_params, int64_t l1_bytes,
@@ -121,6 +122,11 @@ int meme_stage_build_entries(meme_ctx* ctx, const uint8_t* d_pos_packed, int64_t
 int meme_stage_entries_from_sa(meme_ctx* ctx, const uint64_t* d_sa, int64_t sa_num, const void* d_pac64,
                                void* d_sa_ent);
 int meme_stage_rmi32(meme_ctx* ctx, const void* d_rmi24, int64_t records, void* d_rmi32);
+/* Derived table of the staged index, built by every load / attach call (1 byte per suffix, by TEXT position): how many bases the suffix
+ * shares with the closer of its two suffix-array neighbours, capped at 255.  It answers "how long a prefix of this text position occurs
+ * at least twice" without a search, which is what the re-seeding round (src/LearnedIndex_seeding.cpp:923-947, 1897-2126) asks of the
+ * middle of every unique SMEM. */
+int meme_stage_build_plcp(meme_ctx* ctx, const void* d_sa_ent, int64_t sa_num, const void* d_pac64, void* d_plcp /* sa_num + 64 B */);
 
 /* ---- suffix-array construction on the device (index building) -----------------------------------------
  * d_text0123: sa_num bytes, the forward strand followed by its reverse complement (codes 0..3, the reference's .0123 image);
@@ -301,9 +307,12 @@ typedef struct {
     float chain_pass2_ms;      /* everything after the lane-per-read tier has finished (the routed LDS tiers run beside it), B-tree tier included */
     float chain_tier3_ms;      /* of which the B-tree tier (reads with chains at equal positions or more than 256 chains) */
     int64_t chain_tier2_reads, chain_tier3_reads;   /* reads beyond the lane-per-read tier; of which through the B-tree tier */
+    float seed_reseed_ms;      /* of seed_kernel_ms: the re-seeding verifier (k_reseed, walks on the plcp table) */
+    float seed_resume_ms;      /* of seed_kernel_ms: the resume launch of the SA-search kernel (regions the verifier sent back) */
+    int64_t seed_redo_reads;   /* reads with at least one such region */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits" */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer" */
 
 #ifdef __cplusplus
 }

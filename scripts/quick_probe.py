@@ -31,9 +31,11 @@ torch.cuda.synchronize()
 for lanes in lanes_list:
     ctx.set_tuning("group_lanes", lanes)
     for rounds in [int(x) for x in os.environ.get("PROBE_ROUNDS", "1,3").split(",")]:
+      for defer in [int(x) for x in os.environ.get("PROBE_DEFER", "0,1").split(",")]:
+        ctx.set_tuning("seed_defer", defer)
         for it in range(2):
             res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * RL, hipapi.default_seed_opt(rounds=rounds))
             tm = ctx.timings()
-        log("%s len=%d sub=%.3f G=%d rounds=%d: kernel %.1f ms -> %.2f M reads/s; searches/read %.1f windows/search %.3f smems %d hits %d" % (
-            os.path.basename(lib), RL, SUB, lanes, rounds, tm.seed_kernel_ms, n / tm.seed_kernel_ms / 1e3, res.searches / n,
-            tm.seed_windows / max(res.searches, 1), res.total_smems, res.total_hits))
+        log("%s len=%d sub=%.3f G=%d rounds=%d defer=%d: kernel %.1f ms (verifier %.2f, resume %.2f; %d reads sent back) gather %.2f -> %.2f M reads/s; searches/read %.1f windows/read %.2f smems %d hits %d" % (
+            os.path.basename(lib), RL, SUB, lanes, rounds, defer, tm.seed_kernel_ms, tm.seed_reseed_ms, tm.seed_resume_ms, tm.seed_redo_reads, tm.seed_gather_ms,
+            n / tm.seed_kernel_ms / 1e3, res.searches / n, tm.seed_windows / n, res.total_smems, res.total_hits))
