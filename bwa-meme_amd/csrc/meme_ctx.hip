@@ -99,7 +99,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->reads, &ctx->read_off, &ctx->slots[0], &ctx->slots[1], &ctx->slots[2], &ctx->ovf[0],
                       &ctx->ovf[1], &ctx->slot_cnt, &ctx->slot_hits, &ctx->slot_loc, &ctx->smem_off, &ctx->hit_off,
                       &ctx->smems, &ctx->hits, &ctx->scan_tmp, &ctx->counters, &ctx->pairs, &ctx->refb, &ctx->qerb,
-                      &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws, &ctx->redo};
+                      &ctx->packed, &ctx->bsw_order, &ctx->bsw_ws, &ctx->pend, &ctx->blk};
     for (DevBuf* b : bufs) free_buf(*b);
     for (DevBuf& b : ctx->chain) free_buf(b);
     for (DevBuf& b : ctx->ext) free_buf(b);

@@ -7,6 +7,7 @@
 #include <limits.h>
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 
 #include "meme_seed_kernel.h"
 
@@ -219,8 +220,8 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ctx->ev[7], ctx->stream));
-    float ms_total = 0.f, ms_reseed = 0.f, ms_resume = 0.f;
-    i64 launches = 0, searches = 0, windows = 0, redo_reads = 0;
+    float ms_total = 0.f, ms_reseed = 0.f;
+    i64 launches = 0, searches = 0, windows = 0, lane_searches = 0;
     TierTable tiers;
     for (int t = 0; t < N_TIERS; ++t) { tiers.base[t] = nullptr; tiers.cap[t] = 0; }
     i64 n_todo = nreads;
@@ -249,9 +250,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
         // Tier 0 leaves the re-seeding regions of unique SMEMs to k_reseed (a walk on the plcp table, one lane per read) and a resume
         // launch for the regions the walk cannot settle; the overflow tiers search everything themselves.
-        const bool defer = tier == 0 && ctx->seed_defer != 0 && ctx->idx.plcp != nullptr && opt->rounds >= 2 &&
-                           2 * lcap * (int)sizeof(int) >= 2 * PLCP_WIN;     // (the resume launch stages two table windows in the SMEM ring)
-        if (defer && (rc = meme_buf_reserve(ctx, ctx->redo, (size_t)n_todo * sizeof(RedoRec)))) return rc;
+        const bool defer = tier == 0 && ctx->seed_defer != 0 && ctx->idx.plcp != nullptr && opt->rounds >= 2;
+        if (defer && (rc = meme_buf_reserve(ctx, ctx->pend, (size_t)n_todo * sizeof(i64)))) return rc;
+        if (defer && (rc = meme_buf_reserve(ctx, ctx->blk, (size_t)n_todo * BLK_PER_READ * 2 * sizeof(BlkRec)))) return rc;
         SeedArgs A;
         A.I = ctx->idx;
         A.packed = (const u64*)ctx->packed.p;
@@ -270,8 +271,6 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.tier = tier;
         A.counters = (unsigned long long*)ctx->counters.p;
         A.defer = defer ? 1 : 0;
-        A.redo = nullptr;
-        A.ticket_ctr = 0;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
         while (G < 32 && seed_lds_bytes(G, geo, lcap) > (size_t)160 * 1024) G *= 2;   // long reads: fewer reads per workgroup
@@ -293,27 +292,29 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         }
         if (rc) return rc;
         if (defer) {
+            // re-seeding of the unique SMEMs: one lane per read on the plcp table, with its own searches where the table ends
             HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+            ReseedArgs R;
+            R.I = ctx->idx; R.packed = (const u64*)ctx->packed.p; R.geo = geo; R.nreads = n_todo; R.opt = *opt;
+            R.slots = (SlotRec*)sb.p; R.cap = cap; R.slot_cnt = (int*)ctx->slot_cnt.p; R.slot_hits = (i64*)ctx->slot_hits.p;
+            R.ovf_list = (i64*)ob.p; R.counters = (unsigned long long*)ctx->counters.p; R.pend_list = (i64*)ctx->pend.p;
+            R.blk = (BlkRec*)ctx->blk.p; R.blk_out = R.blk + n_todo * BLK_PER_READ; R.blk_cap = n_todo * BLK_PER_READ;
+            R.blk_ctr = 14; R.blk_out_ctr = 15;
             i64 rblocks = (n_todo + 255) / 256;
             if (rblocks > (i64)dev_cus * 32) rblocks = (i64)dev_cus * 32;
-            hipLaunchKernelGGL(k_reseed, dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, ctx->idx.plcp, ctx->idx.n, (const SlotRec*)sb.p, cap,
-                               (const int*)ctx->slot_cnt.p, d_read_off, n_todo, *opt, (RedoRec*)ctx->redo.p, (unsigned long long*)ctx->counters.p);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(ctx->ev[5], ctx->stream));
-            // the resume launch: same kernel, its reads and their regions come from the redo records (their number stays on the device)
-            SeedArgs R = A;
-            R.defer = 0;
-            R.redo = (const RedoRec*)ctx->redo.p;
-            R.ticket_ctr = 13;
-            switch (G) {
-            case 1: rc = launch_k_seed<1>(ctx, R, lds, blocks); break;
-            case 2: rc = launch_k_seed<2>(ctx, R, lds, blocks); break;
-            case 4: rc = launch_k_seed<4>(ctx, R, lds, blocks); break;
-            case 8: rc = launch_k_seed<8>(ctx, R, lds, blocks); break;
-            case 16: rc = launch_k_seed<16>(ctx, R, lds, blocks); break;
-            default: rc = launch_k_seed<32>(ctx, R, lds, blocks); break;
+            hipLaunchKernelGGL(k_reseed, dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, R);
+            // the batch searches (list sizes stay on the device: fixed grids, grid-stride loops), then the blocked regions' second pass
+            const unsigned sblocks = (unsigned)(rblocks < (i64)dev_cus * 4 ? rblocks : (i64)dev_cus * 4);
+            hipLaunchKernelGGL(k_reseed_emit, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+            for (int round = 0; round < 3; ++round) {          // blocked regions ping-pong between two lists; the last pass searches for itself
+                hipLaunchKernelGGL(k_reseed_search, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+                if (round < 2) {
+                    hipLaunchKernelGGL(k_reseed_resume<false>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+                    HIP_TRY(hipMemsetAsync((unsigned long long*)ctx->counters.p + R.blk_ctr, 0, sizeof(unsigned long long), ctx->stream));
+                    std::swap(R.blk, R.blk_out); std::swap(R.blk_ctr, R.blk_out_ctr);
+                } else hipLaunchKernelGGL(k_reseed_resume<true>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
             }
-            if (rc) return rc;
+            HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
@@ -322,13 +323,16 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ms_total += ms;
         if (defer) {
-            float a = 0.f, b = 0.f;
-            HIP_TRY(hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[5]));
-            HIP_TRY(hipEventElapsedTime(&b, ctx->ev[5], ctx->ev[1]));
-            ms_reseed += a; ms_resume += b;
-            redo_reads += (i64)h_counters[12];
-            if (getenv("MEME_SEED_TRACE")) fprintf(stderr, "[meme] seed tier 0: search launch %.2f ms, verifier %.2f ms, resume launch %.2f ms: %lld reads, %lld searches, %lld windows\n",
-                                                   ms - a - b, a, b, (long long)h_counters[12], (long long)h_counters[15], (long long)h_counters[14]);
+            float a = 0.f;
+            HIP_TRY(hipEventElapsedTime(&a, ctx->ev[4], ctx->ev[1]));
+            ms_reseed += a;
+            lane_searches += (i64)h_counters[12];
+#ifdef RESEED_PROF
+            fprintf(stderr, "[reseed prof] (wave-time in 10 ns ticks, executions) stage windows %llu / %llu, table walk %llu / %llu, lane search %llu / %llu\n", h_counters[4], h_counters[5],
+                    h_counters[6], h_counters[7], h_counters[8], h_counters[9]);
+#endif
+            if (getenv("MEME_SEED_TRACE")) fprintf(stderr, "[meme] seed tier 0: search kernel %.2f ms, re-seeding kernel %.2f ms (%lld lane searches)\n",
+                                                   ms - a, a, (long long)h_counters[12]);
         }
         ++launches;
         searches += (i64)h_counters[1];
@@ -360,8 +364,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     ctx->tm.seed_launches = launches;
     ctx->tm.seed_windows = windows;
     ctx->tm.seed_reseed_ms = ms_reseed;
-    ctx->tm.seed_resume_ms = ms_resume;
-    ctx->tm.seed_redo_reads = redo_reads;
+    ctx->tm.seed_lane_searches = lane_searches;
     // offsets
     i64 ntiles = (nreads + SCAN_TILE - 1) / SCAN_TILE;
     if ((rc = meme_buf_reserve(ctx, ctx->scan_tmp, (size_t)(2 * ntiles + 2) * sizeof(i64)))) return rc;
@@ -513,7 +516,7 @@ extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_ba
     int rc;
     struct { DevBuf* b; size_t bytes; } dev[] = {
         {&ctx->reads, (size_t)total_bases + 16}, {&ctx->read_off, (n + 1) * 8}, {&ctx->slot_cnt, n * 4}, {&ctx->slot_hits, n * 8},
-        {&ctx->slot_loc, n * 8}, {&ctx->counters, 16 * 8}, {&ctx->redo, n * sizeof(RedoRec)}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
+        {&ctx->slot_loc, n * 8}, {&ctx->counters, 16 * 8}, {&ctx->pend, n * 8}, {&ctx->blk, n * BLK_PER_READ * 2 * sizeof(BlkRec)}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
         {&ctx->smem_off, (n + 1) * 8}, {&ctx->hit_off, (n + 1) * 8}, {&ctx->smems, n * 12 * sizeof(meme_mem_tl)}, {&ctx->hits, n * 24 * 8},
         {&ctx->chain[0], n * 16 * 32}, {&ctx->chain[1], n * 16 * 8 * 16}, {&ctx->chain[2], n * 24}, {&ctx->chain[3], n * 4}, {&ctx->chain[8], n * 8},
         {&ctx->chain[5], (n + 1) * 32 + n * 5 + 64}, {&ctx->chain[6], n * 3 * sizeof(meme_chain)}, {&ctx->chain[7], n * 6 * sizeof(meme_chain_seed)}};

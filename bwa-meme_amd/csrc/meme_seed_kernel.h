@@ -49,13 +49,10 @@ struct SlotRec {          // search-kernel output, one per SMEM
 // search) carries the position itself: the gather kernel need not fetch it again, and the position is what the re-seeding verifier needs.
 constexpr i64 SLOT_POS = 1ll << 62;
 constexpr i64 SLOT_DEFER = 1ll << 61;     // the SMEM's re-seeding region (round 2) was not searched here: k_reseed walks it on the plcp table
+constexpr i64 SLOT_PEND = 1ll << 59;      // (between k_reseed and k_reseed_emit) an SMEM whose suffix-array interval is still to be looked up
 constexpr i64 SLOT_VAL = (1ll << 48) - 1;
 constexpr int DEFER_MAX_K = 64;           // only the first 64 SMEMs of a read can be deferred (one bit each in RedoRec::mask)
 
-struct RedoRec {          // k_reseed -> the resume launch of k_seed: the re-seeding regions of read `rid` that need real searches
-    i64 rid;
-    u64 mask;             // bit k: SMEM k of the read
-};
 
 constexpr int N_TIERS = 3;
 constexpr int TIER_CAP[N_TIERS] = {64, 2048, 65536};   // global SMEM slots per read; tier 0 is tunable (meme_ctx::smem_cap, default 128)
@@ -84,10 +81,8 @@ struct SeedArgs {
     const i64* pending;    // read ids to re-process in an overflow tier, else nullptr
     i64* ovf_list;
     int cap, lcap, tier;
-    unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads, [3] window loads, [4..11] SEED_PROF, [12] redo records, [13] resume ticket
+    unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads, [3] window loads, [4..11] SEED_PROF, [12] lane searches of k_reseed
     int defer;                      // 1: re-seeding regions of unique SMEMs are left to k_reseed (tier 0 only)
-    const RedoRec* redo;            // resume launch: the reads (and their regions) k_reseed could not settle; nreads is then read from counters[12]
-    int ticket_ctr;                 // which counter hands out this launch's tickets (0; 13 for the resume launch)
 };
 
 // ---- read packing -------------------------------------------------------------------------------------
@@ -223,7 +218,7 @@ __global__ void __launch_bounds__(256) k_pack_reads(const uint8_t* __restrict__ 
 // wait for each other and the only heavy code (window load + compare) exists once in the kernel.
 enum Pc : int {
     PC_FETCH, PC_ALLPOS_TOP, PC_ZZ_TOP, PC_ZZ_RIGHT, PC_ZZ_END, PC_AFTER_STEP1, PC_R2_LOOP, PC_R2_AFTER, PC_R3_INIT,
-    PC_R3_TOP, PC_DONE, PC_EXIT, PC_RESUME
+    PC_R3_TOP, PC_DONE, PC_EXIT
 };
 enum Kind : int { K_S1_RIGHT, K_ZZ_LEFT, K_ZZ_RIGHT, K_OP_MEM, K_OP_SMEM, K_R3 };
 // what the next window is for: the partition point of the query (first window at the model's prediction, later ones
@@ -284,8 +279,6 @@ enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_R2_SAVED, ST_ZZ_
                    ST_L, ST_SE_LO, ST_SE_HI, ST_EE_LO, ST_EE_HI, ST_NB_LO, ST_NB_HI, ST_LF, ST_CB_LO, ST_CB_HI,
                    ST_TICKET_LO, ST_TICKET_HI, ST_WORDS };
 // per-read words are cleared when a read is staged; the group's running totals live in registers
-// resume launch: the region being searched (its SMEM's span and diagonal); the words are free there (no first round, no ring)
-constexpr int ST_RS_SE = ST_R2_K, ST_RS_T_LO = ST_LAST_S_LO;   // (a 64-bit value takes two consecutive words; ST_LAST_* belong to the third round)
 enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2, F_REC = 4, F_LDS_OVF = 8 };
 enum LevelFlag : int { LF_NEED_LO = 1, LF_NEED_HI = 2, LF_HAVE_LAST = 4 };
 
@@ -496,7 +489,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     const glb_ent sa = (glb_ent)A.I.sa;
     const glb_u64 pac = (glb_u64)A.I.pac;
     const glb_rmi l2 = (glb_rmi)A.I.l2, l1 = (glb_rmi)A.I.l1;
-    const __attribute__((address_space(1))) uint8_t* plcp = (const __attribute__((address_space(1))) uint8_t*)A.I.plcp;
     const i64 n = A.I.n;
     const int hits_per_smem = A.opt.hits_per_smem;
 #define GBALLOT(p_) ((__ballot(p_) >> gbase) & GFULL)
@@ -540,43 +532,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             bool have = false;
 #define AT(pc_) (!have && pc == (pc_))
             do {
-                if (A.redo && (AT(PC_ZZ_TOP) || AT(PC_ZZ_RIGHT))) {
-                    // Resume launch: the zig-zag of a region k_reseed sent back.  Most of its searches are still answered by the plcp
-                    // table (reseed_walk's rules, one byte load each); only the one that leaves the SMEM, meets a saturated entry or
-                    // would emit becomes a window search, and the walk goes on behind it.
-                    const int se = st[ST_RS_SE];
-                    const int qbeg = se & 0xffff, qend = (int)((unsigned)se >> 16);
-                    const i64 T0 = LD64(ST_RS_T_LO);
-                    const int next = st[ST_ZZ_NEXT];
-                    int guard = st[ST_ZZ_GUARD], nh = 0;
-                    // the two 64-byte pieces of the table around the region's middle were staged in the (idle) SMEM ring by PC_RESUME
-                    const int mid = (qbeg + qend) >> 1;
-                    const i64 F0 = plcp_win_fwd(T0, mid), R0 = plcp_win_rev(T0, mid, n);
-                    const lds_u8 pw = (lds_u8)ring;
-#define PLC_AT(pos_, w0_, off_) (((pos_) - (w0_) >= 0 && (pos_) - (w0_) < PLCP_WIN) ? (int)pw[(off_) + (int)((pos_) - (w0_))] : (int)plcp[pos_])
-                    for (;;) {
-                        if (pc == PC_ZZ_TOP) {
-                            if (pivot >= next || ++guard > 4 * l_seq + 16) { pc = PC_ZZ_END; break; }
-                            const bool in = pivot >= qbeg && pivot < qend;
-                            const i64 up = n - 1 - (T0 + pivot);
-                            const int plc = in ? PLC_AT(up, R0, PLCP_WIN) : 0;
-                            if (plc == 0 || plc == 255 || plc >= pivot - qbeg + 1) { q_kind = K_ZZ_LEFT; have = true; break; }
-                            ++nh;
-                            pivot = pivot - plc + 1;
-                            if (next - pivot < msl) { pc = PC_ZZ_END; break; }
-                            pc = PC_ZZ_RIGHT;
-                        }
-                        const bool in = pivot >= qbeg && pivot < qend;
-                        const i64 uf = T0 + pivot;
-                        const int plc = in ? PLC_AT(uf, F0, 0) : 0;
-                        if (plc == 0 || plc == 255 || plc >= qend - pivot || plc >= msl) { q_kind = K_ZZ_RIGHT; have = true; break; }
-                        ++nh;
-                        pivot = pivot + plc;
-                        pc = PC_ZZ_TOP;
-                    }
-#undef PLC_AT
-                    st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = guard; st[ST_SEARCHES] = st[ST_SEARCHES] + nh;
-                }
                 if (AT(PC_ZZ_TOP)) {       // zig-zag loop head (:1724-1737, :1969)
                     if (st[ST_ZZ_SP] >= st[ST_ZZ_NEXT] || ++st[ST_ZZ_GUARD] > 4 * l_seq + 16) pc = PC_ZZ_END;
                     else if (FLAG(F_ZZ_CHECK) && has_n && is_n(nfw, st[ST_ZZ_SP])) {
@@ -599,43 +554,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 if (AT(PC_R2_AFTER)) {     // (:945-946)
                     min_intv = st[ST_R2_SAVED];
                     pivot = st[ST_R2_NEXT];
-                    pc = A.redo ? PC_RESUME : PC_R2_LOOP;
-                }
-                if (AT(PC_RESUME)) {       // resume launch: the next region of this read that k_reseed sent back (bits in ST_BEFORE/ST_AFTER)
-                    const unsigned mlo = (unsigned)st[ST_BEFORE], mhi = (unsigned)st[ST_AFTER];
-                    if ((mlo | mhi) == 0) pc = PC_DONE;
-                    else {
-                        const int k = mlo ? __ffs((int)mlo) - 1 : 32 + __ffs((int)mhi) - 1;
-                        if (mlo) st[ST_BEFORE] = (int)(mlo & (mlo - 1)); else st[ST_AFTER] = (int)(mhi & (mhi - 1));
-                        const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
-                        const SlotRec* srp = &A.slots[(i64)ticket * cap + k];                               // written by the first launch
-                        const u64 se = *reinterpret_cast<const u64*>(srp);                                   // {start, end}
-                        const int qbeg = (int)(unsigned)(se & 0xffffffffull), qend = (int)(se >> 32);
-                        const i64 T0 = (srp->sa_start & SLOT_VAL) - qbeg;
-                        st[ST_RS_SE] = qbeg | (qend << 16); ST64(ST_RS_T_LO, T0);
-                        // the region as PC_R2_LOOP enters it (:932-944, :1917-1969): one occurrence -> min_intv 2; the middle of an SMEM has
-                        // a base on either side, none of them ambiguous
-                        st[ST_R2_NEXT] = pivot; st[ST_R2_SAVED] = min_intv;
-                        pivot = (qbeg + qend) >> 1;
-                        min_intv = 2;
-                        // stage the table around the middle: 64 bytes of the locus, 64 of its mirror (aligned 16-byte loads, all in flight together)
-                        {
-                            const i64 F0 = plcp_win_fwd(T0, pivot), R0 = plcp_win_rev(T0, pivot, n);
-                            for (int c = t; c < 2 * (PLCP_WIN / 16); c += G) {        // (the ring is only 8-byte aligned: dword stores)
-                                const i64 src = c < PLCP_WIN / 16 ? F0 + 16 * c : R0 + 16 * (c - PLCP_WIN / 16);
-                                const uint4 v = *reinterpret_cast<const uint4*>(A.I.plcp + src);
-                                ring[4 * c] = (int)v.x; ring[4 * c + 1] = (int)v.y; ring[4 * c + 2] = (int)v.z; ring[4 * c + 3] = (int)v.w;
-                            }
-                            LDS_HANDOFF();
-                        }
-                        const int plc = (int)((lds_u8)ring)[(int)(T0 + pivot - plcp_win_fwd(T0, pivot))];
-                        if (plc == 0 || plc == 255 || plc >= qend - pivot) { q_kind = K_OP_MEM; have = true; }
-                        else {                 // K_OP_MEM answered by the table (:1967-1969)
-                            st[ST_ZZ_NEXT] = pivot + plc; SETFLAG(F_ZZ_CHECK, false); SETFLAG(F_ZZ_RET_ONEPOS, true); st[ST_ZZ_SP] = pivot; st[ST_ZZ_GUARD] = 0;
-                            st[ST_SEARCHES] = st[ST_SEARCHES] + 1;
-                            pc = PC_ZZ_TOP;
-                        }
-                    }
+                    pc = PC_R2_LOOP;
                 }
                 if (AT(PC_R2_LOOP)) {      // (:923-947) + OnePos entry (:1917-1930)
                     int k = st[ST_R2_K];
@@ -724,7 +643,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         const int kreq = __popcll(mo), alloc = kreq > TICKET_CHUNK ? kreq : TICKET_CHUNK;
                         unsigned long long nb = 0;
                         if (lane == first) {
-                            nb = atomicAdd(&A.counters[A.ticket_ctr], (unsigned long long)alloc);
+                            nb = atomicAdd(&A.counters[0], (unsigned long long)alloc);
                             const unsigned long long wb = nb + (unsigned)(alloc - TICKET_CHUNK);
                             wv[0] = kreq - (alloc - TICKET_CHUNK); wv[2] = (int)(unsigned)(wb & 0xffffffffull); wv[3] = (int)(wb >> 32);
                         }
@@ -732,11 +651,8 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         if (over) ticket = nb + (unsigned)__popcll(mo & ((1ull << lane) - 1ull));
                     }
                     ticket = __shfl(ticket, gbase);
-                    const unsigned long long n_tickets = A.redo ? A.counters[12] : (unsigned long long)A.nreads;
-                    if (ticket >= n_tickets) pc = PC_EXIT;
+                    if (ticket >= (unsigned long long)A.nreads) pc = PC_EXIT;
                     else {
-                        u64 redo_mask = 0;
-                        if (A.redo) { redo_mask = A.redo[ticket].mask; ticket = (unsigned long long)A.redo[ticket].rid; }   // slot block = read id in tier 0
                         const i64 rid = A.pending ? A.pending[ticket] : (i64)ticket;
                         const u64* src = A.packed + rid * stride;
 #if SEED_QUERY_LDS
@@ -769,13 +685,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                             st[ST_TICKET_HI] = (int)(ticket >> 32);
                             pivot = 0; msl = A.opt.min_seed_len; min_intv = 1;
                             pc = PC_ALLPOS_TOP;
-                            if (A.redo) {
-                                // the read was seeded by the first launch: go on behind its SMEMs, with the regions to search as a bit mask
-                                st[ST_N_SMEMS] = A.slot_cnt[rid];
-                                ST64(ST_HITS_LO, A.slot_hits[rid]);
-                                st[ST_BEFORE] = (int)(unsigned)(redo_mask & 0xffffffffull); st[ST_AFTER] = (int)(redo_mask >> 32);
-                                pc = PC_RESUME;
-                            } else
                             if (!(has_n && is_n(nfw, 0))) {                       // first step of PC_ALLPOS_TOP at pivot 0, inlined
                                 st[ST_AP_GUARD] = 1; SETFLAG(F_REC, true);
                                 q_kind = K_S1_RIGHT; have = true;
@@ -788,7 +697,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             if (pc == PC_EXIT) {
                 if (t == 0) {
                     atomicAdd(&A.counters[1], (unsigned long long)acc_searches); atomicAdd(&A.counters[3], (unsigned long long)acc_windows);
-                    if (A.redo) { atomicAdd(&A.counters[15], (unsigned long long)acc_searches); atomicAdd(&A.counters[14], (unsigned long long)acc_windows); }
 #ifdef SEED_PROF
                     for (int k = 0; k < 8; ++k) atomicAdd(&A.counters[4 + k], (unsigned long long)prof[k]);
 #endif
@@ -1025,8 +933,10 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 // around its middle that asks "how long a piece of this locus occurs twice" -- is left to k_reseed, which answers that
                 // from the plcp table, and is skipped below by giving the ring entry an occurrence count no split_width admits.
                 const bool have_pos = r_count == 1 && r_T >= 0 && !cache_in_lds;
+                // (Not where the locus lies in repeated sequence -- its suffix shares min_seed_len bases or more with a neighbour in the suffix
+                // array: there the table would send nearly every search of the region back, and the searches are better done here.)
                 const bool defer = have_pos && A.defer != 0 && FLAG(F_REC) && ns < DEFER_MAX_K && ns < cap && A.opt.rounds >= 2 &&
-                                   e_end - e_start >= A.opt.split_len && A.opt.split_width >= 1;
+                                   e_end - e_start >= A.opt.split_len && A.opt.split_width >= 1 && nb_lo < msl && nb_hi < msl;
                 if (ns < cap && t == 0) {
                     const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
                     SlotRec sr;
@@ -1072,18 +982,195 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
 }
 
 
-// ---- the re-seeding verifier ---------------------------------------------------------------------------------------------------
+// ---- re-seeding of unique SMEMs: k_reseed --------------------------------------------------------------------------------------
 // Round 2 (Learned_getSMEMsAllPosOneThread :923-947 -> Learned_getSMEMsOnePosOneThread :1897-2126) re-seeds every SMEM of at least
 // split_len bases and at most split_width occurrences from its middle, asking for matches with MORE occurrences than the SMEM has.  For
 // an SMEM with one occurrence -- nearly all of them -- every search of that zig-zag lies inside the SMEM, i.e. its query is a piece of
 // the text at a known position u, and the answer "the longest prefix of text[u..] that occurs at least twice" is a property of u alone:
 // plcp[u] = the longest common prefix of suffix u with its nearer suffix-array neighbour (valid while it stays inside the SMEM:
 // plcp[u] < bases left to the SMEM's end; beyond that other loci decide and only a search can tell).  Leftward searches run on the
-// reverse complement, i.e. on the mirror position n-1-u.  One lane walks the whole zig-zag of a region on that table (no suffix-array
-// access, ~20 dependent byte loads in two cache lines) where k_seed spends ~20 window searches -- 40 % of all searches of a 150-bp
-// read.  The walk cannot emit: a match of >= min_seed_len bases with two occurrences needs its suffix-array interval, so it ends the walk
-// like a query that leaves the SMEM or a saturated table entry does, and the region goes to the resume launch of k_seed, which
-// searches it the usual way.  Regions the walk finishes emit nothing in the reference either.
+// reverse complement, i.e. on the mirror position n-1-u.  One LANE owns a read here and walks the zig-zag of each of its regions on
+// that table (two 64-byte pieces staged in LDS) where k_seed spends ~20 window searches -- 40 % of all searches of a 150-bp read.
+// What the table cannot answer -- a query that leaves the SMEM, a saturated entry, and a match of >= min_seed_len bases with two
+// occurrences, which is an SMEM to emit and needs its suffix-array interval -- the lane searches itself (lane_search: the model's
+// prediction, gallop + bisection on single entries, then the level walk; ~0.3 such searches per read), and the walk goes on behind it.
+// SMEMs found are appended to the read's slots; their order within a read is not observable (the consumer sorts them by (start, end),
+// src/bwamem.cpp:1397; equal keys have equal hit lists).
+__device__ __forceinline__ u64 ext_g(const u64* __restrict__ w, int s) {
+    const int k = s >> 5, sh = (s & 31) * 2;
+    const u64 a = w[k], b = w[k + 1];
+    return sh ? (a << sh) | (b >> (64 - sh)) : a;
+}
+
+struct LaneQuery {
+    const u64* s;      // packed words of the strand the query lies on
+    int off, vlen;     // query = bases [off, off + vlen) of it
+    u64 wq;            // its first 32 bases
+};
+
+// window_compare for one suffix-array entry: capped LCP with the query and "sorts before the query"
+__device__ __forceinline__ void lane_compare_ent(const DevIndex& I, const LaneQuery& q, int cap, const SaEnt e, int& lcp, bool& less) {
+    const i64 nlimit = I.n - (i64)cap;
+    int Lc = cap;
+    if ((i64)e.pos > nlimit) Lc = (int)(I.n - (i64)e.pos);
+    const u64 x = e.key ^ q.wq;
+    bool lt = e.key < q.wq;
+    int l = x ? (__clzll((long long)x) >> 1) : 32;
+    if (!x && 32 < Lc) {
+        const i64 p0 = (i64)e.pos + 32;
+        for (int k = 1;; ++k) {
+            const u64 wr = extract32(I.pac, p0 + 32 * (k - 1));
+            const u64 qq = ext_g(q.s, q.off + 32 * k);
+            const u64 y = wr ^ qq;
+            if (y) { l += __clzll((long long)y) >> 1; lt = wr < qq; break; }
+            l += 32;
+            if (l >= Lc) break;
+        }
+    }
+    if (l >= Lc) { lcp = Lc; less = (i64)e.pos < nlimit; }
+    else { lcp = l; less = lt; }
+}
+__device__ __forceinline__ void lane_compare(const DevIndex& I, const LaneQuery& q, int cap, i64 slot, int& lcp, bool& less) {
+    lane_compare_ent(I, q, cap, I.sa[slot], lcp, less);
+}
+
+// mem_search / right_smem_search with an occurrence floor (mode 1 of k_seed): L = the largest l <= maxLCP whose suffix-array interval
+// holds >= min_intv suffixes; [start, start + count) = that interval.  One lane, single-entry probes.
+// The common case costs two round trips: the model record, then LANE_W consecutive entries around its prediction fetched together; their
+// LCPs are parked in the lane's LDS column (lw: 16-bit values, two per dword, dword j of lane L at [j * 256 + L]) and both the partition
+// point and the interval usually lie inside.  Anything beyond that window is probed entry by entry (gallop, then bisection).
+constexpr int LANE_W = 16;
+struct LaneWin {
+    uint32_t* lw;          // this lane's column
+    i64 base;              // first slot of the cached window, -1: none
+    __device__ __forceinline__ bool has(i64 slot) const { return base >= 0 && slot >= base && slot < base + LANE_W; }
+    __device__ __forceinline__ int get(i64 slot) const { const int i = (int)(slot - base); return (int)((lw[(i >> 1) * 256] >> (16 * (i & 1))) & 0xffffu); }
+};
+// LCP of slot with the query, from the cached window when it holds the slot (values there are capped by the query length only,
+// which compares the same way against any level L <= that)
+__device__ __forceinline__ int lane_lcp(const DevIndex& I, const LaneQuery& q, const LaneWin& C, int cap, i64 slot) {
+    if (C.has(slot)) return C.get(slot);
+    int lc; bool ls;
+    lane_compare(I, q, cap, slot, lc, ls);
+    return lc;
+}
+
+__device__ __forceinline__ void lane_search(const DevIndex& I, const LaneQuery& q, int min_intv, uint32_t* lw, int& r_L, i64& r_start, i64& r_count) {
+    const i64 n = I.n;
+    u64 key = q.wq;
+    if (q.vlen < 32) key |= (~0ull) >> (2 * q.vlen);
+    u64 err;
+    const i64 p = rmi_lookup((glb_rmi)I.l2, (glb_rmi)I.l1, I.n_l1, I.shift, n, key, err);
+    LaneWin C; C.lw = lw; C.base = -1;
+    int L = 0;
+    i64 s = 0, e = 0;
+    bool located = false;
+    int lc; bool ls;
+    {
+        // first window, placed by the model's error bounds like k_seed's
+        const i64 below = (i64)((err >> 32) & 0x3fffffffull) + 1, above = (i64)(err & 0x7fffffffull);
+        const i64 span = below + above + 1;
+        i64 base = span <= LANE_W ? p - below - (LANE_W - span) / 2 : p - (below * LANE_W) / span;
+        if (base < 0) base = 0;
+        if (base > n - LANE_W) base = n - LANE_W;
+        SaEnt ent[LANE_W];
+#pragma unroll
+        for (int k = 0; k < LANE_W; ++k) ent[k] = I.sa[base + k];
+        unsigned lessm = 0;
+        int prev = 0;
+#pragma unroll
+        for (int k = 0; k < LANE_W; ++k) {
+            lane_compare_ent(I, q, q.vlen, ent[k], lc, ls);
+            lessm |= (ls ? 1u : 0u) << k;
+            if (k & 1) lw[(k >> 1) * 256] = (uint32_t)prev | ((uint32_t)lc << 16); else prev = lc;
+        }
+        C.base = base;
+        const int P = __popc(lessm);
+        if (lessm == ((1u << P) - 1u) && ((P > 0 && P < LANE_W) || (P == 0 && base == 0) || (P == LANE_W && base + LANE_W == n))) {
+            const int lm = P > 0 ? C.get(base + P - 1) : -1, lp = P < LANE_W ? C.get(base + P) : -1;
+            L = lm >= lp ? lm : lp;
+            s = e = base + (lm >= lp ? P - 1 : P);
+            located = true;
+        }
+    }
+    if (!located) {
+        // partition point by single probes: [0, P) sort before the query.  lo = highest slot known to, hi = lowest slot known not to.
+        i64 lo = -1, hi = n;
+        lane_compare(I, q, q.vlen, p, lc, ls);
+        if (ls) {
+            lo = p;
+            for (i64 st = 1; hi == n && lo < n - 1; st <<= 1) {
+                i64 pr = lo + st; if (pr > n - 1) pr = n - 1;
+                lane_compare(I, q, q.vlen, pr, lc, ls);
+                if (ls) lo = pr; else hi = pr;
+            }
+        } else {
+            hi = p;
+            for (i64 st = 1; lo == -1 && hi > 0; st <<= 1) {
+                i64 pr = hi - st; if (pr < 0) pr = 0;
+                lane_compare(I, q, q.vlen, pr, lc, ls);
+                if (ls) lo = pr; else hi = pr;
+            }
+        }
+        while (hi - lo > 1) {
+            const i64 mid = lo + (hi - lo) / 2;
+            lane_compare(I, q, q.vlen, mid, lc, ls);
+            if (ls) lo = mid; else hi = mid;
+        }
+        const i64 P = hi;
+        const int lm = P > 0 ? lane_lcp(I, q, C, q.vlen, P - 1) : -1, lp = P < n ? lane_lcp(I, q, C, q.vlen, P) : -1;
+        L = lm >= lp ? lm : lp;
+        s = e = lm >= lp ? P - 1 : P;
+    }
+    for (;;) {
+        // the run of slots around [s, e] that share >= L bases with the query: step by step through the cached window, beyond it
+        // gallop and bisect (the predicate is true on a run)
+        while (s > 0 && C.has(s - 1) && C.get(s - 1) >= L) --s;
+        if (s > 0 && !C.has(s - 1)) {
+            i64 good = s, bad = -1;
+            for (i64 st = 1; good > 0; st <<= 1) {
+                i64 pr = good - st; if (pr < 0) pr = 0;
+                if (lane_lcp(I, q, C, L, pr) >= L) good = pr; else { bad = pr; break; }
+            }
+            while (bad >= 0 && good - bad > 1) {
+                const i64 mid = bad + (good - bad) / 2;
+                if (lane_lcp(I, q, C, L, mid) >= L) good = mid; else bad = mid;
+            }
+            s = good;
+        }
+        while (e < n - 1 && C.has(e + 1) && C.get(e + 1) >= L) ++e;
+        if (e < n - 1 && !C.has(e + 1)) {
+            i64 good = e, bad = n;
+            for (i64 st = 1; good < n - 1; st <<= 1) {
+                i64 pr = good + st; if (pr > n - 1) pr = n - 1;
+                if (lane_lcp(I, q, C, L, pr) >= L) good = pr; else { bad = pr; break; }
+            }
+            while (bad < n && bad - good > 1) {
+                const i64 mid = good + (bad - good) / 2;
+                if (lane_lcp(I, q, C, L, mid) >= L) good = mid; else bad = mid;
+            }
+            e = good;
+        }
+        if (e - s + 1 >= (i64)min_intv) break;
+        const int nlo = s > 0 ? lane_lcp(I, q, C, L, s - 1) : 0, nhi = e < n - 1 ? lane_lcp(I, q, C, L, e + 1) : 0;
+        L = nlo > nhi ? nlo : nhi;
+    }
+    r_L = L; r_start = s; r_count = e - s + 1;
+}
+
+// first ambiguous base at/after `from` in a packed N mask (global memory)
+__device__ __forceinline__ int first_n_g(const u64* __restrict__ mask, bool has_n, int from, int l_seq) {
+    if (!has_n) return l_seq;
+    int w = from >> 6;
+    u64 m = mask[w] & (~0ull << (from & 63));
+    const int nw = (l_seq + 63) >> 6;
+    for (;;) {
+        if (m) { const int p = w * 64 + __ffsll((long long)m) - 1; return p < l_seq ? p : l_seq; }
+        if (++w >= nw) return l_seq;
+        m = mask[w];
+    }
+}
+
 struct PlcpView {           // the plcp table as one lane of k_reseed sees it: two staged windows in LDS, global memory beyond them
     const uint8_t* __restrict__ plcp;
     const uint32_t* win;    // this lane's column of the workgroup's window array: dword j at win[j * 256]
@@ -1097,89 +1184,346 @@ struct PlcpView {           // the plcp table as one lane of k_reseed sees it: t
     __device__ __forceinline__ int rev(i64 pos) const { return at(pos, R0, PLCP_WIN / 4); }
 };
 
-__device__ __forceinline__ bool reseed_walk(const PlcpView& V, i64 n, i64 T0 /* text position of read base 0 on this diagonal */,
-                                            int qbeg, int qend, int l_seq, int msl, unsigned& hops) {
-    // OnePos entry (:1959-1969): mem_search to the right of the middle with min_intv = 2 -> next_pivot
-    int pivot = (qbeg + qend) >> 1;
-    unsigned h = 1;
-    int plc = V.fwd(T0 + pivot);
-    if (plc == 0 || plc == 255 || plc >= qend - pivot) return false;
-    const int next = pivot + plc;
-    int sp = pivot, guard = 0;
-    bool ok = true;
-    while (sp < next) {                                   // the zig-zag (:1969-2084)
-        if (++guard > 4 * l_seq + 16) break;
-        ++h;
-        plc = V.rev(n - 1 - (T0 + sp));                    // leftwards from sp: the mirror locus
-        if (plc == 0 || plc == 255 || plc >= sp - qbeg + 1) { ok = false; break; }
-        pivot = sp - plc + 1;
-        if (next - pivot < msl) break;
-        ++h;
-        plc = V.fwd(T0 + pivot);                           // rightwards from the new pivot; >= msl bases would be an SMEM to emit
-        if (plc == 0 || plc == 255 || plc >= qend - pivot || plc >= msl) { ok = false; break; }
-        sp = pivot + plc;
+// A region whose walk met something the table cannot answer: where it stands, and (filled in by k_reseed_search) the search's result.
+struct BlkRec {
+    i64 rid;
+    int k;                  // the region's SMEM (slot index in the read)
+    int pivot, next, guard;
+    int stage;              // 0 right of the middle (-> next), 1 left of the pivot, 2 right of the new pivot; + BLK_MORE: the read's later regions follow
+    int r_L;
+    i64 r_start, r_count;
+};
+
+struct ReseedArgs {
+    DevIndex I;
+    const u64* packed;      // k_pack_reads output
+    PackGeom geo;
+    i64 nreads;
+    meme_seed_opt opt;
+    SlotRec* slots;         // tier 0: block r = read r
+    int cap;
+    int* slot_cnt;
+    i64* slot_hits;
+    i64* ovf_list;
+    unsigned long long* counters;   // [1] searches, [2] overflowed reads, [12] searches inside the walk kernels, [13] reads with pending SMEMs, [14] blocked regions
+    i64* pend_list;         // reads that hold SLOT_PEND records
+    BlkRec* blk;            // blocked regions: the list this launch reads (k_reseed: writes), capacity blk_cap, its length in counters[blk_ctr]
+    BlkRec* blk_out;        // k_reseed_resume<false>: the regions that block again, length in counters[blk_out_ctr]
+    i64 blk_cap;
+    int blk_ctr, blk_out_ctr;
+};
+
+// One SMEM more for a read.  OWNED: the calling lane is the only one working on the read (plain counter in a register, published by the
+// caller); otherwise regions of one read may be in different lanes and the read's counters are bumped atomically.
+template <bool OWNED>
+struct SmemAppender {
+    SlotRec* sl; int cap; int* cnt; i64* hits; i64* ovf_list; unsigned long long* counters; i64 rid; int hps;
+    int ns; i64 hits_add;   // OWNED only
+    __device__ __forceinline__ void push(int start, int end, i64 sa_start, i64 count) {
+        const i64 h = (hps > 0 && count > hps) ? (i64)hps : count;
+        if (OWNED) {
+            if (ns < cap) { SlotRec sr; sr.start = start; sr.end = end; sr.sa_start = sa_start; sr.count = count; sl[ns] = sr; }
+            ++ns; hits_add += h;
+        } else {
+            const int at = atomicAdd(cnt, 1);
+            if (at < cap) { SlotRec sr; sr.start = start; sr.end = end; sr.sa_start = sa_start; sr.count = count; sl[at] = sr; }
+            else if (at == cap) ovf_list[atomicAdd(&counters[2], 1ull)] = rid;     // the first one over: the read goes to the next tier (which rewrites its counters)
+            atomicAdd(reinterpret_cast<unsigned long long*>(hits), (unsigned long long)h);
+        }
     }
-    hops = h;
-    return ok;
+};
+
+struct RegionState { int pivot, next, guard, stage; };
+
+// The region (:1959-2084) as far as the table answers: stage 0 = mem_search to the right of the middle (-> next_pivot), then the zig-zag:
+// 1 = to the left of the pivot, 2 = to the right of the new pivot (emits an SMEM of >= min_seed_len bases); min_intv = 2 throughout.
+// Returns true when the search at (stage, pivot) has to be done for real; stage 3 = the region is finished.
+template <bool OWNED>
+__device__ __forceinline__ bool region_walk(const PlcpView& V, i64 n, i64 T0, int qbeg, int qend, int l_seq, int msl, RegionState& S, unsigned& hops,
+                                            SmemAppender<OWNED>& ap, int& n_pend) {
+    for (;;) {
+        if (S.stage == 0) {
+            const int plc = V.fwd(T0 + S.pivot);
+            if (plc == 0 || plc == 255 || plc >= qend - S.pivot) return true;
+            ++hops; S.next = S.pivot + plc; S.stage = 1;
+        }
+        if (S.stage == 1) {
+            if (S.pivot >= S.next || ++S.guard > 4 * l_seq + 16) { S.stage = 3; return false; }
+            const int plc = (S.pivot >= qbeg && S.pivot < qend) ? V.rev(n - 1 - (T0 + S.pivot)) : 0;
+            if (plc == 0 || plc == 255 || plc >= S.pivot - qbeg + 1) return true;
+            ++hops; S.pivot = S.pivot - plc + 1;
+            if (S.next - S.pivot < msl) { S.stage = 3; return false; }
+            S.stage = 2;
+        }
+        const int plc = (S.pivot >= qbeg && S.pivot < qend) ? V.fwd(T0 + S.pivot) : 0;
+        if (plc == 0 || plc == 255 || plc >= qend - S.pivot) return true;
+        if (plc >= msl) {
+            // an SMEM of plc bases with at least two occurrences (:2639-2657): its length is known, so the walk goes on; the
+            // suffix-array interval is looked up later, together with everybody else's (k_reseed_emit).  (The second pass has no
+            // such batch behind it: there the search is done on the spot.)
+            if (!OWNED) return true;
+            ap.push(S.pivot, S.pivot + plc, SLOT_PEND, 0);
+            ++n_pend;
+        }
+        ++hops; S.pivot = S.pivot + plc; S.stage = 1;
+    }
 }
 
-__global__ void __launch_bounds__(256) k_reseed(const uint8_t* __restrict__ plcp, i64 n, const SlotRec* __restrict__ slots, int cap,
-                                                 const int* __restrict__ slot_cnt, const i64* __restrict__ read_off, i64 nreads,
-                                                 meme_seed_opt opt, RedoRec* __restrict__ redo, unsigned long long* __restrict__ counters) {
+// the query of the search a blocked region waits for
+__device__ __forceinline__ LaneQuery region_query(const u64* __restrict__ rec, const PackGeom& geo, int l_seq, bool has_n, const RegionState& S) {
+    LaneQuery q;
+    const bool left = S.stage == 1;
+    q.s = rec + (left ? geo.W : 0);
+    q.off = left ? l_seq - 1 - S.pivot : S.pivot;
+    q.vlen = first_n_g(rec + 2 * geo.W + (left ? geo.MW : 0), has_n, q.off, l_seq) - q.off;
+    q.wq = ext_g(q.s, q.off);
+    return q;
+}
+
+// ... and what its result means for the region (:1967-1969, :1774-1777, :1846-1848)
+template <bool OWNED>
+__device__ __forceinline__ void region_apply(RegionState& S, int msl, int r_L, i64 r_start, i64 r_count, SmemAppender<OWNED>& ap) {
+    if (S.stage == 0) { S.next = S.pivot + r_L; S.stage = 1; }
+    else if (S.stage == 1) { S.pivot = S.pivot - r_L + 1; S.stage = (S.next - S.pivot < msl) ? 3 : 2; }
+    else {
+        if (r_L >= msl) ap.push(S.pivot, S.pivot + r_L, r_start, r_count);
+        S.pivot = S.pivot + r_L; S.stage = 1;
+    }
+}
+
+// the two table windows of a region into the lane's LDS column: eight aligned 16-byte loads in flight together
+__device__ __forceinline__ void stage_plcp_windows(const uint8_t* __restrict__ plcp, const PlcpView& V, uint32_t* win) {
+    uint4 v[2 * (PLCP_WIN / 16)];
+#pragma unroll
+    for (int q = 0; q < PLCP_WIN / 16; ++q) {
+        v[q] = *reinterpret_cast<const uint4*>(plcp + V.F0 + 16 * q);
+        v[PLCP_WIN / 16 + q] = *reinterpret_cast<const uint4*>(plcp + V.R0 + 16 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * (PLCP_WIN / 16); ++q) {
+        win[(4 * q + 0) * 256] = v[q].x; win[(4 * q + 1) * 256] = v[q].y; win[(4 * q + 2) * 256] = v[q].z; win[(4 * q + 3) * 256] = v[q].w;
+    }
+}
+
+constexpr int BLK_PER_READ = 1;      // blocked regions a read may leave behind in the first pass; its last record takes the rest of the read with it
+constexpr int BLK_MORE = 16;
+
+// Pass 1: one lane per read, all its regions.
+__global__ void __launch_bounds__(256) k_reseed(ReseedArgs A) {
     // per lane two PLCP_WIN-byte windows of the table; dword j of lane L at [j * 256 + L]: whatever bytes the lanes ask for, the
     // bank is the lane's own
     __shared__ uint32_t win[2 * (PLCP_WIN / 4) * 256];
-    __shared__ unsigned blk_n, blk_base;
-    __shared__ unsigned long long blk_hops;
-    for (i64 r0 = (i64)blockIdx.x * blockDim.x; r0 < nreads; r0 += (i64)gridDim.x * blockDim.x) {
-        if (threadIdx.x == 0) { blk_n = 0; blk_hops = 0; }
+    __shared__ unsigned long long blk_hops, blk_lane;
+    __shared__ unsigned blk_pend, blk_pend_base, blk_blk;
+    __shared__ unsigned long long blk_blk_base;
+    const uint8_t* __restrict__ plcp = A.I.plcp;
+    const i64 n = A.I.n;
+    const int msl = A.opt.min_seed_len, cap = A.cap;
+    for (i64 r0 = (i64)blockIdx.x * blockDim.x; r0 < A.nreads; r0 += (i64)gridDim.x * blockDim.x) {
+        if (threadIdx.x == 0) { blk_hops = 0; blk_lane = 0; blk_pend = 0; blk_blk = 0; }
         __syncthreads();
         const i64 r = r0 + threadIdx.x;
-        u64 mask = 0;
-        unsigned hops = 0;
-        if (r < nreads) {
-            int c = slot_cnt[r];
-            if (c > DEFER_MAX_K) c = DEFER_MAX_K;
-            const int l_seq = (int)(read_off[r + 1] - read_off[r]);
-            const SlotRec* sl = slots + r * cap;
-            for (int k = 0; k < c; ++k) {
-                const i64 f = sl[k].sa_start;
-                if (!(f & SLOT_DEFER)) continue;
+        unsigned hops = 0, lsearches = 0;
+        int n_pend = 0, n_blk = 0;
+        BlkRec held[BLK_PER_READ];
+        if (r < A.nreads) {
+            const int c0 = A.slot_cnt[r];
+            const int c = c0 > DEFER_MAX_K ? DEFER_MAX_K : c0;
+            SlotRec* sl = A.slots + r * cap;
+            const u64* rec = A.packed + r * A.geo.stride;           // fw[W] rc[W] nfw[MW] nrc[MW] len
+            SmemAppender<true> ap;
+            ap.sl = sl; ap.cap = cap; ap.hps = A.opt.hits_per_smem; ap.ns = c0; ap.hits_add = 0; ap.rid = r;
+            int l_seq = 0;
+            // the lanes of a wavefront take their j-th region together (a loop over the slot index would run the region code once per
+            // slot position with a few lanes each)
+            int k = -1;
+            for (;;) {
+                i64 f = 0;
+                for (++k; k < c; ++k) { f = sl[k].sa_start; if (f & SLOT_DEFER) break; }
+                if (k >= c) break;
+                if (l_seq == 0) { const u64 lw = rec[A.geo.stride - 1]; l_seq = (int)(lw & 0x7fffffffull); }
                 const int qbeg = sl[k].start, qend = sl[k].end;
                 const i64 T0 = (f & SLOT_VAL) - qbeg;
-                const int mid = (qbeg + qend) >> 1;
                 PlcpView V;
-                V.plcp = plcp; V.win = win + threadIdx.x; V.F0 = plcp_win_fwd(T0, mid); V.R0 = plcp_win_rev(T0, mid, n);
-                {   // eight aligned 16-byte loads in flight together, then into this lane's LDS column
-                    uint4 v[2 * (PLCP_WIN / 16)];
+                V.plcp = plcp; V.win = win + threadIdx.x;
+                RegionState S;
+                S.pivot = (qbeg + qend) >> 1; S.next = 0; S.guard = 0; S.stage = 0;
+                V.F0 = plcp_win_fwd(T0, S.pivot); V.R0 = plcp_win_rev(T0, S.pivot, n);
+                stage_plcp_windows(plcp, V, win + threadIdx.x);
+                if (region_walk<true>(V, n, T0, qbeg, qend, l_seq, msl, S, hops, ap, n_pend)) {
+                    // blocked: to the batch search (k_reseed_search), resumed by k_reseed_resume.  This kernel does no search itself (it
+                    // lives on its occupancy); a read's last record takes the read's remaining regions along.
+                    BlkRec b;
+                    b.rid = r; b.k = k; b.pivot = S.pivot; b.next = S.next; b.guard = S.guard; b.r_L = 0; b.r_start = 0; b.r_count = 0;
+                    b.stage = S.stage | (n_blk == BLK_PER_READ - 1 ? BLK_MORE : 0);
 #pragma unroll
-                    for (int q = 0; q < PLCP_WIN / 16; ++q) {
-                        v[q] = *reinterpret_cast<const uint4*>(plcp + V.F0 + 16 * q);
-                        v[PLCP_WIN / 16 + q] = *reinterpret_cast<const uint4*>(plcp + V.R0 + 16 * q);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2 * (PLCP_WIN / 16); ++q) {
-                        win[(4 * q + 0) * 256 + threadIdx.x] = v[q].x; win[(4 * q + 1) * 256 + threadIdx.x] = v[q].y;
-                        win[(4 * q + 2) * 256 + threadIdx.x] = v[q].z; win[(4 * q + 3) * 256 + threadIdx.x] = v[q].w;
-                    }
+                    for (int i = 0; i < BLK_PER_READ; ++i) if (i == n_blk) held[i] = b;
+                    if (++n_blk == BLK_PER_READ) break;
                 }
-                unsigned h = 0;
-                if (reseed_walk(V, n, T0, qbeg, qend, l_seq, opt.min_seed_len, h)) hops += h;
-                else mask |= 1ull << k;
+            }
+            if (ap.ns != c0) {
+                if (ap.ns > cap) {            // more SMEMs than the read's slots hold: the whole read goes to the next tier, as in k_seed
+                    A.slot_cnt[r] = 0; A.slot_hits[r] = 0;
+                    A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = r;
+                    n_pend = 0; n_blk = 0;
+                } else { A.slot_cnt[r] = ap.ns; A.slot_hits[r] = A.slot_hits[r] + ap.hits_add; }
             }
         }
-        // one atomic per workgroup for the redo records, one for the search count
-        unsigned my = 0;
-        if (mask) my = atomicAdd(&blk_n, 1u);
-        if (hops) atomicAdd(&blk_hops, (unsigned long long)hops);
+        // one global atomic per workgroup and list
+        unsigned my_pend = 0, my_blk = 0;
+        if (n_pend) my_pend = atomicAdd(&blk_pend, 1u);
+        if (n_blk) my_blk = atomicAdd(&blk_blk, (unsigned)n_blk);
+        if (hops | lsearches) { atomicAdd(&blk_hops, (unsigned long long)(hops + lsearches)); if (lsearches) atomicAdd(&blk_lane, (unsigned long long)lsearches); }
         __syncthreads();
         if (threadIdx.x == 0) {
-            blk_base = blk_n ? (unsigned)atomicAdd(&counters[12], (unsigned long long)blk_n) : 0u;
-            if (blk_hops) atomicAdd(&counters[1], blk_hops);
+            if (blk_hops) atomicAdd(&A.counters[1], blk_hops);
+            if (blk_lane) atomicAdd(&A.counters[12], blk_lane);
+            if (blk_pend) blk_pend_base = (unsigned)atomicAdd(&A.counters[13], (unsigned long long)blk_pend);
+            if (blk_blk) blk_blk_base = atomicAdd(&A.counters[A.blk_ctr], (unsigned long long)blk_blk);
         }
         __syncthreads();
-        if (mask) { RedoRec rr; rr.rid = r; rr.mask = mask; redo[blk_base + my] = rr; }
+        if (n_pend) A.pend_list[blk_pend_base + my_pend] = r;
+#pragma unroll
+        for (int i = 0; i < BLK_PER_READ; ++i)
+            if (i < n_blk) {
+                const unsigned long long at = blk_blk_base + my_blk + i;
+                if ((i64)at < A.blk_cap) A.blk[at] = held[i];
+            }
         __syncthreads();
+    }
+}
+
+// The suffix-array intervals of the SMEMs the walk found by their length alone: one lane per read of the pending list, every lane a
+// search of its own (the SMEM itself is the query: all of it matches, the interval is what shares all of it) -- a dense batch, the lanes
+// of a wavefront in step.
+__global__ void __launch_bounds__(256) k_reseed_emit(ReseedArgs A) {
+    __shared__ uint32_t lwin[(LANE_W / 2) * 256];
+    const i64 n_list = (i64)A.counters[13];
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += (i64)gridDim.x * blockDim.x) {
+        const i64 r = A.pend_list[i];
+        const int c = A.slot_cnt[r];
+        SlotRec* sl = A.slots + r * A.cap;
+        const u64* rec = A.packed + r * A.geo.stride;
+        i64 hits_add = 0;
+        int k = -1;
+        for (;;) {
+            for (++k; k < c; ++k) if (sl[k].sa_start & SLOT_PEND) break;
+            if (k >= c) break;
+            LaneQuery q;
+            q.s = rec; q.off = sl[k].start; q.vlen = sl[k].end - sl[k].start;
+            q.wq = ext_g(q.s, q.off);
+            int r_L; i64 r_start, r_count;
+            lane_search(A.I, q, 1, lwin + threadIdx.x, r_L, r_start, r_count);
+            sl[k].sa_start = r_start; sl[k].count = r_count;
+            hits_add += (A.opt.hits_per_smem > 0 && r_count > A.opt.hits_per_smem) ? (i64)A.opt.hits_per_smem : r_count;
+        }
+        A.slot_hits[r] = A.slot_hits[r] + hits_add;
+    }
+}
+
+// The searches the blocked regions wait for, as a dense batch: one lane per region.
+__global__ void __launch_bounds__(256) k_reseed_search(ReseedArgs A) {
+    __shared__ uint32_t lwin[(LANE_W / 2) * 256];
+    i64 n_blk = (i64)A.counters[A.blk_ctr];
+    if (n_blk > A.blk_cap) n_blk = A.blk_cap;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_blk; i += (i64)gridDim.x * blockDim.x) {
+        BlkRec b = A.blk[i];
+        const u64* rec = A.packed + b.rid * A.geo.stride;
+        const u64 lw = rec[A.geo.stride - 1];
+        RegionState S;
+        S.pivot = b.pivot; S.next = b.next; S.guard = b.guard; S.stage = b.stage & ~BLK_MORE;
+        const LaneQuery q = region_query(rec, A.geo, (int)(lw & 0x7fffffffull), ((lw >> 31) & 1ull) != 0, S);
+        lane_search(A.I, q, 2, lwin + threadIdx.x, b.r_L, b.r_start, b.r_count);
+        A.blk[i].r_L = b.r_L; A.blk[i].r_start = b.r_start; A.blk[i].r_count = b.r_count;
+    }
+}
+
+// Pass 2 (and 3, 4): one lane per blocked region: the search's result, then on with the table.  A region that blocks again goes to the
+// next list (and the next batch search) -- except in the LAST pass, which does its searches itself.  Two regions of one read may be in
+// different lanes here: SMEMs are appended with atomic counters.
+template <bool LAST>
+__global__ void __launch_bounds__(256) k_reseed_resume(ReseedArgs A) {
+    __shared__ uint32_t win[2 * (PLCP_WIN / 4) * 256];
+    __shared__ uint32_t lwin[(LANE_W / 2) * 256];
+    __shared__ unsigned long long acc_total, acc_lane, out_base;
+    __shared__ unsigned out_n;
+    const uint8_t* __restrict__ plcp = A.I.plcp;
+    const i64 n = A.I.n;
+    const int msl = A.opt.min_seed_len;
+    if (threadIdx.x == 0) { acc_total = 0; acc_lane = 0; }
+    i64 n_blk = (i64)A.counters[A.blk_ctr];
+    if (n_blk > A.blk_cap) n_blk = A.blk_cap;
+    unsigned total = 0, lsearches = 0;
+    for (i64 i0 = (i64)blockIdx.x * blockDim.x; i0 < n_blk; i0 += (i64)gridDim.x * blockDim.x) {
+        if (threadIdx.x == 0) out_n = 0;
+        __syncthreads();
+        const i64 i = i0 + threadIdx.x;
+        bool blocked = false;
+        BlkRec nb;
+        if (i < n_blk) {
+            const BlkRec b = A.blk[i];
+            const i64 r = b.rid;
+            SlotRec* sl = A.slots + r * A.cap;
+            const u64* rec = A.packed + r * A.geo.stride;
+            const u64 lw = rec[A.geo.stride - 1];
+            const int l_seq = (int)(lw & 0x7fffffffull);
+            const bool has_n = ((lw >> 31) & 1ull) != 0;
+            SmemAppender<false> ap;
+            ap.sl = sl; ap.cap = A.cap; ap.cnt = A.slot_cnt + r; ap.hits = A.slot_hits + r; ap.ovf_list = A.ovf_list; ap.counters = A.counters; ap.rid = r;
+            ap.hps = A.opt.hits_per_smem; ap.ns = 0; ap.hits_add = 0;
+            unsigned hops = 1;                   // the search k_reseed_search did
+            int k = b.k;
+            const int c = (b.stage & BLK_MORE) ? (A.slot_cnt[r] > DEFER_MAX_K ? DEFER_MAX_K : A.slot_cnt[r]) : 0;   // (SMEMs appended meanwhile are not deferred ones)
+            bool first = true;
+            for (;;) {
+                const int qbeg = sl[k].start, qend = sl[k].end;
+                const i64 T0 = (sl[k].sa_start & SLOT_VAL) - qbeg;
+                PlcpView V;
+                V.plcp = plcp; V.win = win + threadIdx.x;
+                V.F0 = plcp_win_fwd(T0, (qbeg + qend) >> 1); V.R0 = plcp_win_rev(T0, (qbeg + qend) >> 1, n);
+                stage_plcp_windows(plcp, V, win + threadIdx.x);
+                RegionState S;
+                if (first) {
+                    S.pivot = b.pivot; S.next = b.next; S.guard = b.guard; S.stage = b.stage & ~BLK_MORE;
+                    region_apply<false>(S, msl, b.r_L, b.r_start, b.r_count, ap);
+                    first = false;
+                } else { S.pivot = (qbeg + qend) >> 1; S.next = 0; S.guard = 0; S.stage = 0; }
+                while (S.stage != 3) {
+                    int n_pend = 0;
+                    if (!region_walk<false>(V, n, T0, qbeg, qend, l_seq, msl, S, hops, ap, n_pend)) break;
+                    if (!LAST) {
+                        nb.rid = r; nb.k = k; nb.pivot = S.pivot; nb.next = S.next; nb.guard = S.guard; nb.stage = S.stage | (b.stage & BLK_MORE);
+                        nb.r_L = 0; nb.r_start = 0; nb.r_count = 0;
+                        blocked = true;
+                        break;
+                    }
+                    const LaneQuery q = region_query(rec, A.geo, l_seq, has_n, S);
+                    int r_L; i64 r_start, r_count;
+                    lane_search(A.I, q, 2, lwin + threadIdx.x, r_L, r_start, r_count);
+                    ++lsearches; ++hops;
+                    region_apply<false>(S, msl, r_L, r_start, r_count, ap);
+                }
+                if (blocked) break;
+                // the read's later regions, if this record carries them
+                for (++k; k < c; ++k) if ((sl[k].sa_start & (SLOT_DEFER | SLOT_POS)) == (SLOT_DEFER | SLOT_POS)) break;
+                if (k >= c) break;
+            }
+            total += hops;
+        }
+        unsigned my = 0;
+        if (blocked) my = atomicAdd(&out_n, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && out_n) out_base = atomicAdd(&A.counters[A.blk_out_ctr], (unsigned long long)out_n);
+        __syncthreads();
+        if (blocked) A.blk_out[out_base + my] = nb;
+        __syncthreads();
+    }
+    if (total) atomicAdd(&acc_total, (unsigned long long)total);
+    if (lsearches) atomicAdd(&acc_lane, (unsigned long long)lsearches);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (acc_total) atomicAdd(&A.counters[1], acc_total);
+        if (acc_lane) atomicAdd(&A.counters[12], acc_lane);
     }
 }
 

@@ -307,9 +307,8 @@ typedef struct {
     float chain_pass2_ms;      /* everything after the lane-per-read tier has finished (the routed LDS tiers run beside it), B-tree tier included */
     float chain_tier3_ms;      /* of which the B-tree tier (reads with chains at equal positions or more than 256 chains) */
     int64_t chain_tier2_reads, chain_tier3_reads;   /* reads beyond the lane-per-read tier; of which through the B-tree tier */
-    float seed_reseed_ms;      /* of seed_kernel_ms: the re-seeding verifier (k_reseed, walks on the plcp table) */
-    float seed_resume_ms;      /* of seed_kernel_ms: the resume launch of the SA-search kernel (regions the verifier sent back) */
-    int64_t seed_redo_reads;   /* reads with at least one such region */
+    float seed_reseed_ms;      /* of seed_kernel_ms: the re-seeding kernel (k_reseed: unique SMEMs' regions walked on the plcp table) */
+    int64_t seed_lane_searches;   /* searches k_reseed did itself, one lane each (what the table cannot answer) */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
 int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer" */

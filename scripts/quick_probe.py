@@ -36,6 +36,6 @@ for lanes in lanes_list:
         for it in range(2):
             res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), n, n * RL, hipapi.default_seed_opt(rounds=rounds))
             tm = ctx.timings()
-        log("%s len=%d sub=%.3f G=%d rounds=%d defer=%d: kernel %.1f ms (verifier %.2f, resume %.2f; %d reads sent back) gather %.2f -> %.2f M reads/s; searches/read %.1f windows/read %.2f smems %d hits %d" % (
-            os.path.basename(lib), RL, SUB, lanes, rounds, defer, tm.seed_kernel_ms, tm.seed_reseed_ms, tm.seed_resume_ms, tm.seed_redo_reads, tm.seed_gather_ms,
+        log("%s len=%d sub=%.3f G=%d rounds=%d defer=%d: kernel %.1f ms (of which re-seeding kernel %.2f, %d lane searches) gather %.2f -> %.2f M reads/s; searches/read %.1f windows/read %.2f smems %d hits %d" % (
+            os.path.basename(lib), RL, SUB, lanes, rounds, defer, tm.seed_kernel_ms, tm.seed_reseed_ms, tm.seed_lane_searches, tm.seed_gather_ms,
             n / tm.seed_kernel_ms / 1e3, res.searches / n, tm.seed_windows / n, res.total_smems, res.total_hits))
