@@ -494,10 +494,12 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
             m = re.search(r"index staged in HBM in ([0-9.]+) s", err)
             if m:
                 info["hbm_index_staging_s"] = float(m.group(1))
-            for m in re.finditer(r"totals: seeding ([0-9.]+) s for (\d+) reads; bsw (\d+) calls, (\d+) pairs \(copy-in thread-seconds "
-                                 r"([0-9.]+), backend calls ([0-9.]+) s of which kernels ([0-9.]+) s\)", err):
-                info["backend"] = {"seeding_s": float(m.group(1)), "bsw_calls": int(m.group(3)), "bsw_pairs": int(m.group(4)),
-                                   "bsw_backend_s": float(m.group(6)), "bsw_kernel_s": float(m.group(7))}
+            for m in re.finditer(r"totals: chunk-level device stages \(gather \+ seeding \+ chaining \+ extension\) ([0-9.]+) s for (\d+) reads, of which the seeding calls "
+                                 r"([0-9.]+) s; bsw (\d+) calls, (\d+) pairs \(copy-in thread-seconds ([0-9.]+), backend calls ([0-9.]+) s of which kernels ([0-9.]+) s\)", err):
+                # device_stages_s: everything the binding does for a chunk ahead of the reference's own body -- gathering the reads, the seeding
+                # call, the chaining + extension call (extension_stage_s below); seeding_call_s: the seeding call alone (H2D + kernels)
+                info["backend"] = {"device_stages_s": float(m.group(1)), "seeding_call_s": float(m.group(3)), "bsw_calls": int(m.group(4)),
+                                   "bsw_pairs": int(m.group(5)), "bsw_backend_s": float(m.group(7)), "bsw_kernel_s": float(m.group(8))}
             for m in re.finditer(r"extension: this chunk .*?totals ([0-9.]+) s, (\d+) backend calls", err):
                 info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # host stage (MEME_DROPIN_EXT=host): jobs built + calls + fold + purge
             for m in re.finditer(r"CIGAR stage on the device: (\d+) global alignments with traceback posed so far \(kernels ([0-9.]+) s, whole pre-pass ([0-9.]+) s\); "

@@ -41,7 +41,7 @@ bool verbose() { static const bool v = getenv("MEME_DROPIN_VERBOSE") != nullptr;
 // ---- devices -------------------------------------------------------------------------------------------------
 std::vector<Device>& device_slots() { static std::vector<Device>* v = new std::vector<Device>(); return *v; }
 std::mutex g_mu;
-std::atomic<double> g_t_seed{0}, g_t_bsw_gather{0}, g_t_bsw_call{0}, g_t_bsw_kernel{0};
+std::atomic<double> g_t_seed{0}, g_t_seed_call{0}, g_t_bsw_gather{0}, g_t_bsw_call{0}, g_t_bsw_kernel{0};
 std::atomic<int64_t> g_n_bsw_calls{0}, g_n_bsw_pairs{0}, g_n_seed_reads{0};
 
 void init_devices(const char* prefix, int64_t chunk_reads) {
@@ -87,6 +87,10 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
 std::thread* g_early = nullptr;
 const char* g_early_prefix = nullptr;
 __attribute__((constructor)) void meme_dropin_early_start() {
+    // The chaining stage runs four kernels side by side on streams of their own; the HIP runtime multiplexes a process's streams onto 4
+    // hardware queues unless told otherwise when it initialises (7.9 -> 7.4 ms per 2 M reads with 8).  This is the aligner's own start-up
+    // code, before its first HIP call and before it has threads: the place for it (the backend library itself no longer touches the environment).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const char* p = getenv("MEME_INDEX_PREFIX");
     if (!p || !*p || (getenv("MEME_DROPIN_EARLY") && atoi(getenv("MEME_DROPIN_EARLY")) == 0)) return;
     FILE* f = fopen("/proc/self/cmdline", "rb");
@@ -245,22 +249,38 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     for (int64_t i = 0; i < P.count; ++i) { P.off[i] = bytes; bytes += seqs[P.first + i].l_seq; }
     P.off[P.count] = bytes;
     if (bytes + 16 > P.flat_cap) { meme_host_free(P.flat); P.flat_cap = bytes + bytes / 4 + 4096; if (!(P.flat = (uint8_t*)meme_host_alloc(P.flat_cap))) die("meme_host_alloc"); }
+    // Base codes in place, as the reference leaves them for the later stages (src/bwamem.cpp:1277-1279: mem_sort_dedup_patch in
+    // worker_aln is the first to read them).  With the extension stage on the device the GPU does not wait for that: the letters are
+    // gathered as they are and converted on the device (meme_seed_batch_resident_ascii), and the in-place conversion runs on a helper
+    // team beside the backend calls.
     // (a few dozen helper threads: an OpenMP team of all 256 host threads takes longer to start than the loop runs, and keeps spinning
     // into the worker phases that follow)
+    const bool raw = g_ext_on_device;
 #pragma omp parallel for schedule(static) num_threads(cig_threads())
     for (int64_t i = 0; i < P.count; ++i) {
-        // base codes in place, as the reference leaves them for the later stages (src/bwamem.cpp:1277-1279)
         bseq1_t& s = seqs[P.first + i];
         uint8_t* dst = P.flat + P.off[i];
-        for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
+        if (raw) memcpy(dst, s.seq, (size_t)s.l_seq);
+        else for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
     }
+    std::thread codes;
+    if (raw) codes = std::thread([&P, seqs] {
+#pragma omp parallel for schedule(static) num_threads(cig_threads() / 2 > 0 ? cig_threads() / 2 : 1)
+        for (int64_t i = 0; i < P.count; ++i) {
+            bseq1_t& s = seqs[P.first + i];
+            for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; }
+        }
+    });
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_codes{codes};
     const meme_seed_opt so = seed_opt_of(opt);
     memset(&P.chains, 0, sizeof(P.chains));
     P.has_ext = false;
+    const double ts0 = now_s();
     if (g_ext_on_device) {                               // seeds stay in HBM (nothing on the host reads them)
         memset(&P.res, 0, sizeof(P.res));
-        if (meme_seed_batch_resident(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, nullptr, nullptr)) die("meme_seed_batch_resident");
+        if (meme_seed_batch_resident_ascii(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, nullptr, nullptr)) die("meme_seed_batch_resident_ascii");
     } else if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
+    g_t_seed_call = g_t_seed_call + (now_s() - ts0);
     if (g_ext_on_device && P.count > 0) {                // chains + extension where the seeds lie: only alignment records come back
         meme_chain_opt co;
         co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;
@@ -345,9 +365,9 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
     if (verbose())
-        fprintf(stderr, "[meme-dropin] totals: seeding %.3f s for %lld reads; bsw %lld calls, %lld pairs "
+        fprintf(stderr, "[meme-dropin] totals: chunk-level device stages (gather + seeding + chaining + extension) %.3f s for %lld reads, of which the seeding calls %.3f s; bsw %lld calls, %lld pairs "
                 "(copy-in thread-seconds %.3f, backend calls %.3f s of which kernels %.3f s)\n",
-                (double)g_t_seed, (long long)g_n_seed_reads, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs,
+                (double)g_t_seed, (long long)g_n_seed_reads, (double)g_t_seed_call, (long long)g_n_bsw_calls, (long long)g_n_bsw_pairs,
                 (double)g_t_bsw_gather, (double)g_t_bsw_call, (double)g_t_bsw_kernel);
     if (verbose() && g_ext_on_device)
         fprintf(stderr, "[meme-dropin] chaining + extension on the device: %.3f s in the backend calls so far (HIP events: chaining %.3f s, extension stage %.3f s of "

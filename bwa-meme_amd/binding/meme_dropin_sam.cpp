@@ -306,67 +306,111 @@ void cig_prepass() {
         cand.reserve(tot);
         for (auto& v : part) cand.insert(cand.end(), v.begin(), v.end());      // (static schedule: still in read order)
     }
+    const double t_cand1 = now_s();
     const int nd = (int)g_dev.size();
     meme_bsw_opt bo;
     memset(&bo, 0, sizeof(bo));
     bo.o_del = opt->o_del; bo.e_del = opt->e_del; bo.o_ins = opt->o_ins; bo.e_ins = opt->e_ins; bo.a = opt->a; bo.b = opt->b;
+    double t_pose = 0, t_call = 0, t_take = 0;
+    bool warned = false;
     for (int round = 0; round < 3 && !cand.empty(); ++round) {
-        // this round's calls, per device part (candidates are in read order: a part's candidates are contiguous)
-        std::vector<std::vector<meme_gjob>> jobs((size_t)nd);
-        std::vector<std::vector<uint32_t>> who((size_t)nd);
-        for (size_t c = 0; c < cand.size(); ++c) {
-            Cand& C = cand[c];
+        // this round's calls, per device part (candidates are in read order: a part's candidates are contiguous).  Posed in parallel
+        // (the alignment records are scattered over the heap), compacted in order.
+        double tp = now_s();
+        const int64_t nc = (int64_t)cand.size();
+        std::vector<meme_gjob> posed((size_t)nc);
+        std::vector<int8_t> dev_of((size_t)nc);
+#pragma omp parallel for schedule(static) num_threads(cig_threads())
+        for (int64_t c = 0; c < nc; ++c) {
+            Cand& C = cand[(size_t)c];
             const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
             C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;
             int w = 0;
+            dev_of[(size_t)c] = -1;
             if (!gen_cigar_band(opt, l_pac, p.qe - p.qb, p.rb, p.re, C.w2, &w)) { C.tries = 99; continue; }
             int d = 0;
             while (d + 1 < nd && C.g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
-            meme_gjob J;
+            meme_gjob& J = posed[(size_t)c];
             J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w = w;
             J.rev = p.rb >= l_pac ? 1 : 0;
-            jobs[(size_t)d].push_back(J);
+            dev_of[(size_t)c] = (int8_t)d;
+        }
+        std::vector<std::vector<meme_gjob>> jobs((size_t)nd);
+        std::vector<std::vector<uint32_t>> who((size_t)nd);
+        for (int64_t c = 0; c < nc; ++c) {
+            const int d = dev_of[(size_t)c];
+            if (d < 0) continue;
+            jobs[(size_t)d].push_back(posed[(size_t)c]);
             who[(size_t)d].push_back((uint32_t)c);
         }
-        std::vector<meme_gres_host> res((size_t)nd);
+        t_pose += now_s() - tp; tp = now_s();
+        // One call per device; a call that the backend refuses for want of memory (MEME_E_CAPACITY: the backtrack matrices of the batch
+        // beside the resident index) is repeated in halves, and whatever cannot be computed at all is simply left out of the table:
+        // the ksw_global2 hook then runs the reference's function for those alignments.  The stage is an optimisation, never a reason to stop.
+        struct Part { std::vector<meme_gres> res; std::vector<uint32_t> ops; int64_t done = 0; double kernel_ms = 0; };
+        std::vector<Part> part((size_t)nd);
         std::vector<std::thread> th;
         auto run = [&](int d) {
-            memset(&res[(size_t)d], 0, sizeof(meme_gres_host));
-            if (jobs[(size_t)d].empty()) return;
-            if (meme_global_batch_host(g_dev[(size_t)d].seed, jobs[(size_t)d].data(), (int64_t)jobs[(size_t)d].size(), &bo, &res[(size_t)d])) die("meme_global_batch_host");
+            const std::vector<meme_gjob>& Jv = jobs[(size_t)d];
+            Part& P = part[(size_t)d];
+            const int64_t nj = (int64_t)Jv.size();
+            P.res.reserve((size_t)nj);
+            int64_t piece = nj;
+            while (P.done < nj) {
+                const int64_t m = piece < nj - P.done ? piece : nj - P.done;
+                meme_gres_host R;
+                const int rc = meme_global_batch_host(g_dev[(size_t)d].seed, Jv.data() + P.done, m, &bo, &R);
+                if (rc == MEME_E_CAPACITY && m > 4096) { piece = m / 2; continue; }
+                if (rc != MEME_OK) {
+                    static std::mutex warn_mu;
+                    std::lock_guard<std::mutex> lk(warn_mu);
+                    if (!warned) fprintf(stderr, "[meme-dropin] CIGAR stage: %lld of this chunk's alignments stay with the host (%s)\n", (long long)(nj - P.done), meme_last_error());
+                    warned = true;
+                    break;
+                }
+                const int64_t o0 = (int64_t)P.ops.size();
+                P.ops.insert(P.ops.end(), R.cigars, R.cigars + R.total_ops);          // the device packs the operations in job order
+                for (int64_t k = 0; k < m; ++k) { meme_gres g = R.res[k]; g.cigar_off += o0; P.res.push_back(g); }
+                P.kernel_ms += R.kernel_ms;
+                P.done += m;
+            }
         };
         for (int d = 1; d < nd; ++d) th.emplace_back(run, d);
         run(0);
         for (auto& t : th) t.join();
+        t_call += now_s() - tp; tp = now_s();
         std::vector<Cand> next;
         for (int d = 0; d < nd; ++d) {
-            const meme_gres_host& R = res[(size_t)d];
-            if (R.njobs == 0) continue;
+            const Part& R = part[(size_t)d];
+            if (R.done == 0) continue;
             T.t_kernel_ms += R.kernel_ms;
-            T.n_jobs += R.njobs;
+            T.n_jobs += R.done;
             const size_t e0 = T.e.size(), o0 = T.ops.size();
-            T.ops.insert(T.ops.end(), R.cigars, R.cigars + R.total_ops);      // the device packs the operations in job order
-            T.e.resize(e0 + (size_t)R.njobs);
+            T.ops.insert(T.ops.end(), R.ops.begin(), R.ops.end());
+            T.e.resize(e0 + (size_t)R.done);
+            std::vector<uint8_t> again((size_t)R.done);
 #pragma omp parallel for schedule(static) num_threads(cig_threads())
-            for (int64_t k = 0; k < R.njobs; ++k) {
+            for (int64_t k = 0; k < R.done; ++k) {
                 const meme_gjob& J = jobs[(size_t)d][(size_t)k];
                 CigEntry& E = T.e[e0 + (size_t)k];
-                E.g = cand[who[(size_t)d][(size_t)k]].g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev;
-                E.score = R.res[k].score; E.n_cigar = R.res[k].n_cigar; E.ops = (int64_t)o0 + R.res[k].cigar_off;
-            }
-            for (int64_t k = 0; k < R.njobs; ++k) {
-                // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
                 Cand& C = cand[who[(size_t)d][(size_t)k]];
+                E.g = C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev;
+                E.score = R.res[(size_t)k].score; E.n_cigar = R.res[(size_t)k].n_cigar; E.ops = (int64_t)o0 + R.res[(size_t)k].cigar_off;
+                // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
+                again[(size_t)k] = 0;
                 const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
-                const int score = R.res[k].score;
+                const int score = E.score;
                 if (score == C.last_sc || C.w2 == opt->w << 2) continue;
                 C.last_sc = score;
                 C.w2 <<= 1;
-                if (++C.tries < 3 && score < p.truesc - opt->a) next.push_back(C);
+                if (++C.tries < 3 && score < p.truesc - opt->a) again[(size_t)k] = 1;
             }
+            for (int64_t k = 0; k < R.done; ++k) if (again[(size_t)k]) next.push_back(cand[who[(size_t)d][(size_t)k]]);
         }
         cand.swap(next);
+        t_take += now_s() - tp;
     }
+    const double t_idx0 = now_s();
     // index: sequences hashed the way the hook will see them (both reversed on the reverse strand); sorted by key, looked up by bisection
     const uint8_t* ref = g_worker->ref_string;
     T.idx.resize(T.e.size());
@@ -378,6 +422,8 @@ void cig_prepass() {
     }
     __gnu_parallel::sort(T.idx.begin(), T.idx.end(), __gnu_parallel::default_parallel_tag((unsigned)cig_threads()));
     T.t_prepass += now_s() - t0;
+    if (verbose()) fprintf(stderr, "[meme-dropin] CIGAR pre-pass of this chunk %.3f s: candidates %.3f, jobs posed %.3f, backend calls %.3f, results taken %.3f, index %.3f\n", now_s() - t0,
+                           t_cand1 - t0, t_pose, t_call, t_take, now_s() - t_idx0);
 }
 
 typedef int (*ksw_global2_fn)(int, const uint8_t*, int, const uint8_t*, int, const int8_t*, int, int, int, int, int, int*, uint32_t**);

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         int f_in = MINUS_INF;                                         // F(i, first column of the chunk)
         int h_in = beg == 0 ? -(A.o.o_del + e_del * (i + 1)) : MINUS_INF;   // H(i, beg - 1): what the reference's h1 starts from
-        if (lane == 0) hn[beg] = h_in;
+        if (lane == 0 && beg <= qlen) hn[beg] = h_in;                 // (beg > qlen cannot happen for bands the host check admits: w >= |tlen - qlen|)
         uint8_t* zi = z + (i64)i * n_col;
         for (int cb = beg; cb < end; cb += 64) {
             const int j = cb + lane;
@@ -158,6 +158,14 @@ __global__ void __launch_bounds__(256) k_gcig_fix(meme_gres* __restrict__ res, c
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) res[jb].cigar_off = ooff[jb];
 }
 
+// what the host loop cannot see: a job's query span against the length of the read it names
+__global__ void __launch_bounds__(256) k_gcig_check(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, i64* __restrict__ bad) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
+        const meme_gjob J = jobs[jb];
+        if ((i64)J.qb + J.qlen > read_off[J.read + 1] - read_off[J.read]) atomicMin((unsigned long long*)bad, (unsigned long long)jb);
+    }
+}
+
 unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
 
 }  // namespace
@@ -173,7 +181,10 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
     int qmax = 0;
     for (i64 k = 0; k < njobs; ++k) {
         const meme_gjob& J = jobs[k];
-        if (J.read < 0 || J.read >= nreads || J.qb < 0 || J.qlen < 1 || J.tlen < 1 || J.w < 0 || J.rb < 0 || J.rb + J.tlen > ctx->idx.n || J.qlen > 65535 || J.tlen > 65535) {
+        // (the band must reach the matrix's last cell, w >= |tlen - qlen|, as every band bwa_gen_cigar2 computes does, src/bwa.cpp:306-316:
+        // below that ksw_global2 walks rows without cells, which this kernel does not restate)
+        if (J.read < 0 || J.read >= nreads || J.qb < 0 || J.qlen < 1 || J.tlen < 1 || J.w < 0 || J.rb < 0 || J.rb + J.tlen > ctx->idx.n || J.qlen > 65535 || J.tlen > 65535 ||
+            J.w < (J.tlen > J.qlen ? J.tlen - J.qlen : J.qlen - J.tlen)) {
             meme_set_error("meme_global_batch_host: job %lld is malformed (read %d, query %d+%d, target %lld+%d, band %d)", (long long)k, J.read, J.qb, J.qlen,
                            (long long)J.rb, J.tlen, J.w);
             return MEME_E_ARG;
@@ -182,7 +193,7 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
     }
     int rc;
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (4 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars
-    if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob))) || (rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 6)) ||
+    if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob))) || (rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 6 + 64)) ||
         (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     hipEvent_t* ev = ctx->ev_gcig;
     for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
@@ -194,12 +205,21 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
     i64* d_coff = d_zoff + (njobs + 1);
     i64* d_ncig = d_coff + (njobs + 1);
     i64* d_ooff = d_ncig + (njobs + 1);
+    i64* d_bad = d_ooff + (njobs + 1);
+    HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
+    hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
     hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, d_zsz, d_csz);
     if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs))) return rc;
     i64 tz = 0, tc = 0;
     HIP_TRY(hipMemcpyAsync(&tz, d_zoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&tc, d_coff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    i64 bad = -1;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (bad >= 0) {
+        meme_set_error("meme_global_batch_host: job %lld names a query span (%d+%d) beyond the end of read %d", (long long)bad, jobs[bad].qb, jobs[bad].qlen, jobs[bad].read);
+        return MEME_E_ARG;
+    }
     {
         size_t free_b = 0, total_b = 0;
         const size_t need = (size_t)tz + (size_t)tc * 4;

@@ -526,12 +526,44 @@ extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_ba
         {&ctx->h_chain[0], (n + 1) * 8}, {&ctx->h_chain[1], n * 3 * sizeof(meme_chain)}, {&ctx->h_chain[2], (n + 1) * 8},
         {&ctx->h_chain[3], n * 6 * sizeof(meme_chain_seed)}, {&ctx->h_chain[4], n * 4}, {&ctx->h_chain[5], n * 4}, {&ctx->h_chain[6], n}};
     for (auto& h : host) if ((rc = meme_hostbuf_reserve(ctx, *h.b, h.bytes))) return rc;
+    // the stages behind seeding (meme_extend_last_batch_host, meme_global_batch_host) at their usual sizes for short reads: 4 alignment
+    // records and 4 extension jobs of ~250 sequence bytes per read, one global alignment per 3 reads -- the first chunks of a run
+    // otherwise pay for growing these (pinned memory: ~0.4 s per GB)
+    struct { DevBuf* b; size_t bytes; } dev2[] = {
+        {&ctx->ext[0], n * 3 * 16}, {&ctx->ext[1], n * 4 * sizeof(meme_alnreg)}, {&ctx->ext[2], n * 4 * 4}, {&ctx->ext[3], (n + 1) * 48},
+        {&ctx->ext[4], n * 2 * sizeof(meme_seqpair)}, {&ctx->ext[5], n * 2 * sizeof(meme_seqpair)}, {&ctx->ext[6], n * 4 * sizeof(meme_seqpair)},
+        {&ctx->ext[7], n * 4 * 250}};
+    for (auto& d : dev2) if ((rc = meme_buf_reserve(ctx, *d.b, d.bytes))) return rc;
+    if ((rc = meme_hostbuf_reserve(ctx, ctx->h_ext[0], (n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, ctx->h_ext[1], n * 4 * sizeof(meme_alnreg))) ||
+        (rc = meme_hostbuf_reserve(ctx, ctx->h_gcig[0], n / 2 * sizeof(meme_gres))) || (rc = meme_hostbuf_reserve(ctx, ctx->h_gcig[1], n * 4))) return rc;
     return MEME_OK;
+}
+
+// FASTQ letters (or codes) -> base codes in place, as mem_kernel1_core_Learned does it on the host (src/bwamem.cpp:1277-1279:
+// c < 4 ? c : nst_nt4_table[c]); 16 bytes per lane (the buffer is padded to a multiple of 16)
+__global__ void __launch_bounds__(256) k_ascii_to_codes(uint4* __restrict__ p, i64 nvec) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (i64)gridDim.x * blockDim.x) {
+        uint4 v = p[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t c = (w[k] >> (8 * b)) & 0xffu, u = c & 0xdfu;        // u: upper case
+                const uint32_t code = c < 4 ? c : (u == 'A' ? 0u : u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 4u);
+                o |= code << (8 * b);
+            }
+            w[k] = o;
+        }
+        v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        p[i] = v;
+    }
 }
 
 // reads from the host into HBM + the seeding kernels; `out` (may be null) receives the results in the ctx's pinned buffers
 static int seed_host_reads(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads, const meme_seed_opt* opt, const char* who,
-                           meme_seed_host_result* out, int64_t* totals) {
+                           meme_seed_host_result* out, int64_t* totals, bool ascii = false) {
     if (!ctx || !reads || !read_off || nreads < 0) return MEME_E_ARG;
     int rc = check_opt(opt);
     if (rc) return rc;
@@ -553,6 +585,13 @@ static int seed_host_reads(meme_ctx* ctx, const uint8_t* reads, const int64_t* r
     if ((rc = meme_buf_reserve(ctx, ctx->read_off, (size_t)(nreads + 1) * sizeof(i64)))) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->reads.p, reads, (size_t)bases, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->read_off.p, read_off, (size_t)(nreads + 1) * sizeof(i64), hipMemcpyHostToDevice, ctx->stream));
+    if (ascii) {
+        const i64 nvec = (bases + 15) / 16;
+        i64 cb = (nvec + 255) / 256;
+        if (cb > (i64)ctx->n_cus * 16) cb = (i64)ctx->n_cus * 16;
+        hipLaunchKernelGGL(k_ascii_to_codes, dim3((unsigned)(cb < 1 ? 1 : cb)), dim3(256), 0, ctx->stream, (uint4*)ctx->reads.p, nvec);
+        HIP_TRY(hipGetLastError());
+    }
     i64 max_len = 0;
     for (i64 i = 0; i < nreads; ++i) max_len = read_off[i + 1] - read_off[i] > max_len ? read_off[i + 1] - read_off[i] : max_len;
     meme_seed_result res;
@@ -587,6 +626,17 @@ extern "C" int meme_seed_batch_resident(meme_ctx* ctx, const uint8_t* reads, con
                                         const meme_seed_opt* opt, int64_t* total_smems, int64_t* total_hits) {
     int64_t tot[2] = {0, 0};
     const int rc = seed_host_reads(ctx, reads, read_off, nreads, opt, "meme_seed_batch_resident", nullptr, tot);
+    if (total_smems) *total_smems = tot[0];
+    if (total_hits) *total_hits = tot[1];
+    return rc;
+}
+
+// Same, for reads as they stand in the FASTQ file (letters; bytes below 4 are taken as codes): the conversion of
+// mem_kernel1_core_Learned (src/bwamem.cpp:1277-1279) runs on the device, so a caller only has to gather the bytes.
+extern "C" int meme_seed_batch_resident_ascii(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                                              const meme_seed_opt* opt, int64_t* total_smems, int64_t* total_hits) {
+    int64_t tot[2] = {0, 0};
+    const int rc = seed_host_reads(ctx, reads, read_off, nreads, opt, "meme_seed_batch_resident_ascii", nullptr, tot, true);
     if (total_smems) *total_smems = tot[0];
     if (total_hits) *total_hits = tot[1];
     return rc;

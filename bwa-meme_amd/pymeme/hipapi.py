@@ -119,7 +119,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries", "meme_stage_build_plcp",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -287,6 +287,16 @@ class Context:
         ts, th = C.c_int64(0), C.c_int64(0)
         _check(lib().meme_seed_batch_resident(C.c_void_p(self.h), _p(reads), _p(read_off), C.c_int64(read_off.shape[0] - 1), C.byref(opt),
                                               C.byref(ts), C.byref(th)))
+        return ts.value, th.value
+
+    def seed_batch_resident_ascii(self, reads_ascii, read_off, opt=None):
+        """meme_seed_batch_resident_ascii: like seed_batch_resident, for FASTQ letters (converted to codes on the device)."""
+        opt = opt or default_seed_opt()
+        reads = np.ascontiguousarray(reads_ascii, dtype=np.uint8).reshape(-1)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        ts, th = C.c_int64(0), C.c_int64(0)
+        _check(lib().meme_seed_batch_resident_ascii(C.c_void_p(self.h), _p(reads), _p(read_off), C.c_int64(read_off.shape[0] - 1), C.byref(opt),
+                                                    C.byref(ts), C.byref(th)))
         return ts.value, th.value
 
     def seed_reserve(self, nreads, total_bases):

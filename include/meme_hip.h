@@ -150,8 +150,10 @@ int meme_prmi_train_device(meme_ctx* ctx, const void* d_sa_ent, int64_t sa_num, 
  * reads: concatenated base codes 0..3, >=4 = ambiguous (what mem_kernel1_core_Learned leaves in
  * bseq1_t.seq, src/bwamem.cpp:1277-1279); read_off[nreads+1].  A read longer than 500 bases
  * (LEARNED_MAX_READ_LEN; the reference exits, src/bwamem.cpp:1259-1262) fails the whole call with MEME_E_ARG.
- * Outputs, per read r: smems[smem_off[r] .. smem_off[r+1]) in emission order (the caller sorts them,
- * src/bwamem.cpp:1397) and hits[hit_off[r] .. hit_off[r+1]) in ascending SA order per SMEM.          */
+ * Outputs, per read r: smems[smem_off[r] .. smem_off[r+1]) -- the reference's SMEMs of the read in an unspecified order (the caller
+ * sorts them by (start, end), src/bwamem.cpp:1397, and records with equal keys carry equal hit lists, so the order is not observable;
+ * the first round's come first, the re-seeding round's are appended by the kernels that find them) -- and
+ * hits[hit_off[r] .. hit_off[r+1]) in ascending SA order per SMEM.          */
 int meme_seed_batch(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
                     const meme_seed_opt* opt,
                     meme_mem_tl* smems, int64_t smem_capacity, int64_t* smem_off,
@@ -174,6 +176,11 @@ int meme_seed_batch_host(meme_ctx* ctx, const uint8_t* reads, const int64_t* rea
  * meme_extend_last_batch_host): what a binding uses that only wants chains or alignment records back.  Only the totals return. */
 int meme_seed_batch_resident(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
                              const meme_seed_opt* opt, int64_t* total_smems, int64_t* total_hits);
+
+/* Same, for reads as they stand in the FASTQ records (letters; bytes below 4 are taken as base codes): the conversion of
+ * mem_kernel1_core_Learned (src/bwamem.cpp:1277-1279, c < 4 ? c : nst_nt4_table[c]) runs on the device. */
+int meme_seed_batch_resident_ascii(meme_ctx* ctx, const uint8_t* reads, const int64_t* read_off, int64_t nreads,
+                                   const meme_seed_opt* opt, int64_t* total_smems, int64_t* total_hits);
 
 /* Optional: allocate the workspaces and pinned result buffers of a meme_seed_batch_host() (+ meme_chain_last_batch_host()) call of
  * this size ahead of time, e.g. on a helper thread while the index loads (pinned memory is slow to allocate). */
@@ -273,7 +280,10 @@ int meme_bsw_batch_device(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d
  * [rb, rb+tlen) of the fwd+rc reference within band w.  Sequences are not shipped: `read` indexes the batch the last
  * meme_seed_batch_host() call staged on this ctx, the text is the 2-bit image in HBM; rev != 0 (alignments on the reverse strand,
  * rb >= l_pac) reverses both sequences as bwa_gen_cigar2 does.  CIGAR operations in the BAM encoding (len << 4 | op, op 0 M, 1 I, 2 D),
- * ties broken as the reference breaks them (M over E over F), so gaps sit where the reference puts them. */
+ * ties broken as the reference breaks them (M over E over F), so gaps sit where the reference puts them.  A job's band must reach the
+ * last cell of its matrix, w >= |tlen - qlen| (every band bwa_gen_cigar2 computes does), and its query span must lie inside the read:
+ * anything else fails the call with MEME_E_ARG.  MEME_E_CAPACITY (the batch's backtrack matrices do not fit beside the index): submit
+ * fewer jobs per call. */
 typedef struct { int64_t rb; int32_t read, qb, qlen, tlen, w, rev; } meme_gjob;
 typedef struct { int32_t score, n_cigar; int64_t cigar_off; /* first operation in meme_gres_host::cigars */ } meme_gres;
 typedef struct { int64_t njobs; const meme_gres* res; const uint32_t* cigars; int64_t total_ops; float kernel_ms; } meme_gres_host;

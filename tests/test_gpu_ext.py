@@ -12,14 +12,23 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
-def _device_records(tmp_path, I, ext_opt=None):
+def _device_records(tmp_path, I, ext_opt=None, ascii=False):
     fa = str(tmp_path / "c.fa")
     synth.write_fasta(fa, I["genome"], name="cg", contigs=3)
     prefix = build_index(fa, bits=14)
     ctx = hipapi.Context(0)
     try:
         ctx.load_index_files(prefix)
-        ctx.seed_batch_resident(I["reads"], I["read_off"])
+        if ascii:       # the reads as FASTQ letters (mixed case, N and other IUPAC letters for ambiguous bases): converted on the device
+            letters = np.frombuffer(b"ACGTN", np.uint8)[np.minimum(I["reads"], 4)].copy()
+            rng = np.random.default_rng(3)
+            low = rng.random(letters.shape[0]) < 0.3
+            letters[low] |= 0x20
+            amb = I["reads"] >= 4
+            letters[amb] = rng.choice(np.frombuffer(b"NnRYK.-", np.uint8), size=int(amb.sum()))
+            ctx.seed_batch_resident_ascii(letters, I["read_off"])
+        else:
+            ctx.seed_batch_resident(I["reads"], I["read_off"])
         contigs = [(int(o), int(l), 0) for o, l in zip(I["contig_off"], I["contig_len"])]
         return ctx.extend_last_batch_host(contigs, hipapi.default_chain_opt(I["l_pac"]), ext_opt)
     finally:
@@ -44,6 +53,15 @@ def test_device_records_equal_reference_golden(tmp_path):
     assert R["n_retried"] > 300 and R["n_pairs"] > R["regs"].shape[0]
     purged = (R["regs"]["qb"] == -1) & (R["regs"]["qe"] == -1)
     assert int(purged.sum()) == int(((G["regs"][:, 2] == -1) & (G["regs"][:, 3] == -1)).sum()) > 5000
+
+
+def test_reads_as_fastq_letters_give_the_same_records(tmp_path):
+    """meme_seed_batch_resident_ascii: the base-code conversion of mem_kernel1_core_Learned (src/bwamem.cpp:1277-1279) on the device."""
+    I = ext_golden_inputs()
+    G = np.load(os.path.join(GOLDEN, "ext_golden.npz"))
+    R = _device_records(tmp_path, I, ascii=True)
+    assert np.array_equal(R["reg_off"], G["reg_off"])
+    _assert_same(R["regs"], G["regs"], G["frac_rep_bits"])
 
 
 @pytest.mark.parametrize("w,clip,zdrop", [(20, 5, 100), (100, 0, 30)])

@@ -53,5 +53,17 @@ def test_device_cigars_equal_oracle_with_other_penalties(tmp_path):
         bad["read"][2] = len(reads) + 5
         with pytest.raises(hipapi.MemeError, match="malformed"):
             ctx.global_batch_host(bad)
+        # a band that does not reach the matrix's last cell, and a query span that runs past its read: refused, not computed on garbage
+        narrow = jobs[:4].copy()
+        narrow["tlen"][1] = narrow["qlen"][1] + 40
+        narrow["w"][1] = 10
+        with pytest.raises(hipapi.MemeError, match="malformed"):
+            ctx.global_batch_host(narrow)
+        long_q = jobs[:4].copy()
+        long_q["qb"][3] = 5
+        long_q["qlen"][3] = len(reads[int(long_q["read"][3])])
+        long_q["w"][3] = 500
+        with pytest.raises(hipapi.MemeError, match="beyond the end of read"):
+            ctx.global_batch_host(long_q)
     finally:
         ctx.close()
