@@ -427,6 +427,9 @@ def wait_for_free_gpus(n, timeout=120.0):
         time.sleep(1.0)
 
 
+MALLOC_TUNABLES = "glibc.malloc.tcache_count=4000:glibc.malloc.trim_threshold=1073741824:glibc.malloc.top_pad=67108864:glibc.malloc.mmap_threshold=33554432"
+
+
 def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
     """BASELINE.json's end-to-end metric: `mem -7` on paired-end 150-bp reads through the reference aligner with the HIP
     backend bound in (oracle/_ref/bwa-meme_dropin = reference main + reference objects + bwa-meme_amd/binding) and
@@ -467,6 +470,10 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                 continue
             sam = os.path.join(d, exe + ".sam")
             env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_DEVICES=str(devices))
+            # Both binaries run on glibc malloc (the reference's default build would link mimalloc, a submodule that is not in the tree), and
+            # the SAM phase is allocator-bound: both get the same allocator settings -- freed memory stays in the arenas, a deep per-thread
+            # cache (profiles/r04_e2e.md: 2.4 -> 1.3 s of mem_process_seqs per 4 M reads for the drop-in)
+            env.setdefault("GLIBC_TUNABLES", MALLOC_TUNABLES)
             if torch.cuda.device_count() < devices:      # fewer GPUs than asked for (the 1-GPU test box): device slots share the GPUs
                 env["MEME_DROPIN_VIRTUAL"] = str(devices)
             t0 = time.time()

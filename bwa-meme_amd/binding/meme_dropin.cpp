@@ -23,6 +23,7 @@
 //                                   -> meme_bsw_batch(); concurrent calls of the kt_for workers combined into one backend
 //                                   call per GPU (group commit) -- the path when the chunk-wide stage is switched off
 #include "meme_dropin.h"
+#include <malloc.h>
 
 #define dropin_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
 KSORT_INIT(meme_dropin_smem, mem_tl, dropin_smem_lt)
@@ -91,6 +92,14 @@ __attribute__((constructor)) void meme_dropin_early_start() {
     // hardware queues unless told otherwise when it initialises (7.9 -> 7.4 ms per 2 M reads with 8).  This is the aligner's own start-up
     // code, before its first HIP call and before it has threads: the place for it (the backend library itself no longer touches the environment).
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // The SAM phase is allocator-bound (the reference's default build links mimalloc for that reason; this build, like the reference binary
+    // it is compared with, runs on glibc malloc): keep freed memory in the arenas instead of handing it back to the kernel between chunks
+    // and grow the heaps in large steps.  MEME_DROPIN_MALLOPT=0: glibc's defaults.
+    if (!(getenv("MEME_DROPIN_MALLOPT") && atoi(getenv("MEME_DROPIN_MALLOPT")) == 0)) {
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 64 << 20);
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    }
     const char* p = getenv("MEME_INDEX_PREFIX");
     if (!p || !*p || (getenv("MEME_DROPIN_EARLY") && atoi(getenv("MEME_DROPIN_EARLY")) == 0)) return;
     FILE* f = fopen("/proc/self/cmdline", "rb");
@@ -205,7 +214,8 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
 // ---- chunk-level seeding ----------------------------------------------------------------------------------------------
 namespace dropin {
 
-Chunk g_chunk;
+Chunk g_chunks[2];
+Chunk* g_cur_chunk = &g_chunks[0];
 
 const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process_seqs)
 std::vector<meme_contig> g_contigs;
@@ -244,6 +254,7 @@ meme_seed_opt seed_opt_of(const mem_opt_t* opt) {
 }
 
 void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
+    meme_ctx* const ctx = P.ctx;
     if (P.count + 1 > P.off_cap) { meme_host_free(P.off); P.off_cap = P.count + P.count / 4 + 64; if (!(P.off = (int64_t*)meme_host_alloc(P.off_cap * 8))) die("meme_host_alloc"); }
     int64_t bytes = 0;
     for (int64_t i = 0; i < P.count; ++i) { P.off[i] = bytes; bytes += seqs[P.first + i].l_seq; }
@@ -278,8 +289,8 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     const double ts0 = now_s();
     if (g_ext_on_device) {                               // seeds stay in HBM (nothing on the host reads them)
         memset(&P.res, 0, sizeof(P.res));
-        if (meme_seed_batch_resident_ascii(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, nullptr, nullptr)) die("meme_seed_batch_resident_ascii");
-    } else if (meme_seed_batch_host(g_dev[(size_t)d].seed, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
+        if (meme_seed_batch_resident_ascii(ctx, P.flat, P.off, P.count, &so, nullptr, nullptr)) die("meme_seed_batch_resident_ascii");
+    } else if (meme_seed_batch_host(ctx, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
     g_t_seed_call = g_t_seed_call + (now_s() - ts0);
     if (g_ext_on_device && P.count > 0) {                // chains + extension where the seeds lie: only alignment records come back
         meme_chain_opt co;
@@ -290,7 +301,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         eo.a = opt->a; eo.b = opt->b; eo.o_del = opt->o_del; eo.e_del = opt->e_del; eo.o_ins = opt->o_ins; eo.e_ins = opt->e_ins;
         eo.pen_clip5 = opt->pen_clip5; eo.pen_clip3 = opt->pen_clip3; eo.w = opt->w; eo.zdrop = opt->zdrop;
         const double t0 = now_s();
-        if (meme_extend_last_batch_host(g_dev[(size_t)d].seed, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, &P.ext)) die("meme_extend_last_batch_host");
+        if (meme_extend_last_batch_host(ctx, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, &P.ext)) die("meme_extend_last_batch_host");
         g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
         g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
         g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
@@ -302,21 +313,33 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;
         co.min_chain_weight = opt->min_chain_weight; co.max_chain_extend = opt->max_chain_extend;
         co.mask_level = opt->mask_level; co.drop_ratio = opt->drop_ratio; co.l_pac = g_bns->l_pac;
-        if (meme_chain_last_batch_host(g_dev[(size_t)d].seed, g_contigs.data(), (int32_t)g_contigs.size(), &co, &P.chains)) die("meme_chain_last_batch_host");
+        if (meme_chain_last_batch_host(ctx, g_contigs.data(), (int32_t)g_contigs.size(), &co, &P.chains)) die("meme_chain_last_batch_host");
     }
 }
 
-void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n) {
+void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n, int slot) {
     const double t0 = now_s();
     const int nd = (int)g_dev.size();
-    g_chunk.seqs = seqs;
-    g_chunk.n = n;
-    if (g_chunk.part.size() != (size_t)nd) g_chunk.part.resize((size_t)nd);
+    Chunk& C = g_chunks[slot];
+    C.seqs = seqs;
+    C.n = n;
+    if (C.part.size() != (size_t)nd) C.part.resize((size_t)nd);
+    if (slot == 1)
+        for (int d = 0; d < nd; ++d)
+            if (!g_dev[(size_t)d].seed2) {                        // the second slot's ctxs: same index, buffers of their own
+                Device& D = g_dev[(size_t)d];
+                meme_index_arrays ia;
+                if (meme_index_describe(D.seed, &ia)) die("meme_index_describe");
+                int dev_id = 0;
+                { int nreal = meme_device_count(); dev_id = nreal > 0 ? d % nreal : 0; }
+                if (!(D.seed2 = meme_ctx_create(dev_id)) || meme_index_share(D.seed2, D.seed)) die("second seeding ctx");
+            }
     // consecutive 512-read batches of the chunk go to consecutive GPUs: contiguous ranges, batch-aligned
     const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
     std::vector<std::thread> th;
     for (int d = 0; d < nd; ++d) {
-        ChunkPart& P = g_chunk.part[(size_t)d];
+        ChunkPart& P = C.part[(size_t)d];
+        P.ctx = slot ? g_dev[(size_t)d].seed2 : g_dev[(size_t)d].seed;
         const int64_t b0 = nb * d / nd, b1 = nb * (d + 1) / nd;
         P.first = b0 * BATCH_SIZE;
         P.count = (b1 * BATCH_SIZE < n ? b1 * BATCH_SIZE : n) - P.first;
@@ -328,6 +351,73 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n) {
     g_t_seed = g_t_seed + (now_s() - t0);
     g_n_seed_reads += n;
     if (verbose()) fprintf(stderr, "[meme-dropin] chunk of %lld reads seeded on %d GPU(s) in %.3f s\n", (long long)n, nd, now_s() - t0);
+}
+
+// ---- the next chunk ahead of its turn -------------------------------------------------------------------------------------------
+// The aligner's pipeline (kt_pipeline, two threads for read / process / write) reads chunk k+1 while chunk k is processed, and the GPUs
+// are idle for most of chunk k's SAM phase.  When the FASTQ reader hands chunk k+1 out, a helper thread takes it through the device
+// stages (gather, seeding, chaining, extension) on the other slot's ctxs; mem_process_seqs then finds its alignment records waiting.
+// Chunks alternate between the two slots: chunk k+2 is read only after chunk k has been written (the pipeline's two threads), so its
+// slot is free by then.  The helper and its state live until the process ends (no destructor runs against a waiting thread).
+// MEME_DROPIN_PREFETCH=0: off.
+struct Prefetcher {
+    std::mutex m;
+    std::condition_variable cv;
+    bseq1_t* seqs = nullptr; int64_t n = 0; int slot = 0;      // the job
+    int state = 0;                                              // 0 idle, 1 submitted, 2 running, 3 done
+    const mem_opt_t* opt = nullptr;
+    bool started = false;
+};
+Prefetcher* g_pf = nullptr;
+int g_next_slot = 0;                    // slot of the next chunk to be processed
+std::atomic<double> g_t_prefetched{0};
+bool prefetch_on() { static const bool v = !(getenv("MEME_DROPIN_PREFETCH") && atoi(getenv("MEME_DROPIN_PREFETCH")) == 0); return v; }
+
+void prefetch_submit(bseq1_t* seqs, int64_t n) {
+    if (!prefetch_on() || !g_pf || !g_ext_on_device || !g_opt || g_dev.empty()) return;      // (known after the first chunk has been processed)
+    Prefetcher& F = *g_pf;
+    std::unique_lock<std::mutex> lk(F.m);
+    if (F.state != 0) return;                                   // a chunk is already ahead (or nobody took the last one): this one is seeded in its turn
+    F.seqs = seqs; F.n = n; F.slot = g_next_slot ^ 0; F.state = 1;
+    if (!F.started) {
+        F.started = true;
+        std::thread([] {
+            Prefetcher& F = *g_pf;
+            for (;;) {
+                bseq1_t* seqs; int64_t n; int slot;
+                {
+                    std::unique_lock<std::mutex> lk(F.m);
+                    F.cv.wait(lk, [&] { return F.state == 1; });
+                    F.state = 2; seqs = F.seqs; n = F.n; slot = F.slot;
+                }
+                const double t0 = now_s();
+                seed_chunk(F.opt, seqs, n, slot);
+                g_t_prefetched = g_t_prefetched + (now_s() - t0);
+                { std::lock_guard<std::mutex> lk(F.m); F.state = 3; }
+                F.cv.notify_all();
+            }
+        }).detach();
+    }
+    F.cv.notify_all();
+}
+
+// true: chunk `seqs` has been through the device stages already (waits for the helper when it is still at it)
+bool prefetch_take(bseq1_t* seqs, int64_t n, int* slot) {
+    if (!g_pf) return false;
+    Prefetcher& F = *g_pf;
+    std::unique_lock<std::mutex> lk(F.m);
+    if (F.state == 0) return false;
+    if (F.seqs != seqs || F.n != n) {                           // somebody else's chunk: let it finish, forget it
+        F.cv.wait(lk, [&] { return F.state == 3 || F.state == 1; });
+        if (F.state == 1) { F.state = 0; return false; }        // (never started)
+        F.state = 0;
+        return false;
+    }
+    if (F.state == 1 && !F.started) { F.state = 0; return false; }
+    F.cv.wait(lk, [&] { return F.state == 3; });
+    *slot = F.slot;
+    F.state = 0;
+    return true;
 }
 
 int g_team = 1;                        // kt_for worker threads of the run (opt->n_threads)
@@ -359,11 +449,17 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         g_worker = &w;
         g_opt = opt;
         ktfor_calls() = 0;
-        seed_chunk(opt, seqs, n);
+        if (!g_pf) { g_pf = new Prefetcher; }
+        g_pf->opt = opt;
+        int slot = g_next_slot;
+        if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
+        g_cur_chunk = &g_chunks[slot];
+        g_next_slot = slot ^ 1;
         ++g_chunk_gen;
     }
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
+    if (verbose() && (double)g_t_prefetched > 0) fprintf(stderr, "[meme-dropin] device stages run ahead of their chunk's turn (beside the previous chunk's SAM phase): %.3f s so far\n", (double)g_t_prefetched);
     if (verbose())
         fprintf(stderr, "[meme-dropin] totals: chunk-level device stages (gather + seeding + chaining + extension) %.3f s for %lld reads, of which the seeding calls %.3f s; bsw %lld calls, %lld pairs "
                 "(copy-in thread-seconds %.3f, backend calls %.3f s of which kernels %.3f s)\n",

@@ -47,6 +47,8 @@ bool verbose();
 
 struct Device {
     meme_ctx* seed = nullptr;     // owns (device 0) or holds a replica of the index
+    meme_ctx* seed2 = nullptr;    // shares seed's index: chunks alternate between the two, so that the next chunk's device stages can run
+                                  // while this chunk's reads, seeds and alignment records are still in use (created with the first prefetch)
     meme_ctx* bsw = nullptr;      // second ctx of the GPU: BandedPairWiseSW calls (host extension stage), mate rescue
 };
 // (reached through an accessor: the early-start thread may run before the dynamic initialisers of meme_dropin.cpp)
@@ -57,6 +59,7 @@ extern std::atomic<int64_t> g_n_bsw_calls, g_n_bsw_pairs, g_n_seed_reads;
 
 struct ChunkPart {                     // the slice of a chunk one GPU seeded
     int64_t first = 0, count = 0;
+    meme_ctx* ctx = nullptr;                             // the ctx that holds the slice's reads (the CIGAR stage names them)
     meme_seed_host_result res;
     meme_chain_host_result chains;                       // valid when g_chain_on_device (host extension stage)
     meme_ext_host_result ext;                            // valid in device-extension mode: alignment records of the part's reads
@@ -69,7 +72,10 @@ struct Chunk {
     int64_t n = 0;
     std::vector<ChunkPart> part;
 };
-extern Chunk g_chunk;                          // the chunk mem_process_seqs is working on
+extern Chunk* g_cur_chunk;                     // the chunk mem_process_seqs is working on (one of two slots)
+#define g_chunk (*dropin::g_cur_chunk)
+// the device stages of a chunk ahead of its turn (started when the FASTQ reader hands the chunk out; meme_dropin.cpp)
+void prefetch_submit(bseq1_t* seqs, int64_t n);
 extern const bntseq_t* g_bns;                  // of the run (set by mem_process_seqs)
 extern std::vector<meme_contig> g_contigs;
 int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 1 host, 0 the reference's per-batch function

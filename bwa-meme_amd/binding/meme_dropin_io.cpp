@@ -131,5 +131,6 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
     }
     *n_ = (int)n;
     *s = size;
+    if (n > 0) prefetch_submit(seqs, n);                            // the chunk's device stages start now, beside the previous chunk's SAM phase
     return seqs;
 }

@@ -359,7 +359,7 @@ void cig_prepass() {
             while (P.done < nj) {
                 const int64_t m = piece < nj - P.done ? piece : nj - P.done;
                 meme_gres_host R;
-                const int rc = meme_global_batch_host(g_dev[(size_t)d].seed, Jv.data() + P.done, m, &bo, &R);
+                const int rc = meme_global_batch_host(g_chunk.part[(size_t)d].ctx, Jv.data() + P.done, m, &bo, &R);
                 if (rc == MEME_E_CAPACITY && m > 4096) { piece = m / 2; continue; }
                 if (rc != MEME_OK) {
                     static std::mutex warn_mu;

@@ -37,17 +37,23 @@ f1, f2 = os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")
 t0 = time.time(); fastq(r1, f1); fastq(r2, f2); log("fastq %.1f s" % (time.time() - t0))
 res = {}
 runs = [("bwa-meme_mode3", None)] + [("bwa-meme_dropin", m) for m in os.environ.get("E2E_EXT_MODES", "device").split(",")]
+if os.environ.get("E2E_REF_SWEEP"):              # the unmodified reference at several thread counts (its best is the honest baseline)
+    runs = [("bwa-meme_mode3", "t" + t) for t in os.environ["E2E_REF_SWEEP"].split(",")]
 if os.environ.get("E2E_SKIP_REF"): runs = runs[1:]
 for exe, mode in runs:
     out = os.path.join(d, exe + ".sam")
     env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1")
-    if mode: env["MEME_DROPIN_EXT"] = mode
+    if not os.environ.get("E2E_NO_TUNABLES"):      # the allocator settings bench.py gives both binaries
+        env.setdefault("GLIBC_TUNABLES", "glibc.malloc.tcache_count=4000:glibc.malloc.trim_threshold=1073741824:glibc.malloc.top_pad=67108864:glibc.malloc.mmap_threshold=33554432")
+    nthr = threads
+    if mode and mode.startswith("t"): nthr = int(mode[1:])
+    elif mode: env["MEME_DROPIN_EXT"] = mode
     if os.environ.get("E2E_BSW_TRACE"): env["MEME_BSW_TRACE"] = "1"
     t0 = time.time()
     with open(out, "wb") as fh:
         chunk = os.environ.get("E2E_CHUNK", "100000000")       # E2E_CHUNK=default: the aligner's own chunking (10 M bases x threads)
         kopt = [] if chunk == "default" else ["-K", chunk]
-        r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y"] + kopt + ["-t", str(threads), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
+        r = subprocess.run([os.path.join(REPO, "oracle", "_ref", exe), "mem", "-7", "-Y"] + kopt + ["-t", str(nthr), prefix, f1, f2], stdout=fh, stderr=subprocess.PIPE, env=env)
     wall = time.time() - t0
     err = r.stderr.decode()
     if os.environ.get("E2E_STDERR_DIR"):

@@ -248,3 +248,92 @@ def test_reserved_buffers_change_nothing(g1):
             assert O.format_seed_dump(slots, counts, hl) == open(os.path.join(GOLDEN, "g1_seeds_150.txt")).read()
         finally:
             c.close()
+
+
+def test_reseeding_on_the_plcp_table_equals_searching(tmp_path):
+    """The re-seeding round of unique SMEMs runs off the search kernel (k_reseed: walks on the plcp table; k_reseed_emit / _search /
+    _resume: batches of lane searches for what the table cannot answer) or, with seed_defer = 0, inside it as in round 3.  Same seeds
+    either way and as the oracle: on a repeat-rich genome (regions that block at every step), on noisy 250-bp reads (many short
+    SMEMs, regions that reach their SMEM's ends), on reads with N, with 16 SMEM slots per read (appended SMEMs overflow: the read goes
+    to the next tier from the re-seeding kernels), and with the occurrence floors of other option sets."""
+    from pymeme import workload
+    g = synth.make_genome(8_000_000, seed=17, repeat_frac=0.10, repeat_len=350, n_families=6, divergence=0.02, n_dups=30, dup_len=3000, poly_runs=8)
+    prefix = workload.build_index_on_disk(g, str(tmp_path), bits=0)
+    idx = O.load_index_files(prefix)
+    c = hipapi.Context(0)
+    try:
+        c.load_index_files(prefix)
+        for L, kw in ((150, dict(n_frac=0.05)), (250, dict(sub_rate=0.05, indel_rate=0.0075)), (101, dict(exact_frac=0.3))):
+            reads, _, _ = synth.make_reads(g, 4000, L, seed=500 + L, **kw)
+            off = np.arange(0, (reads.shape[0] + 1) * L, L, dtype=np.int64)
+            sm, ns, hits, nh, _ = O.seed_batch(idx, reads, off, smem_cap=1024, hit_cap=1 << 16, threads=0)
+            want = O.format_seed_dump(sm, ns, hits)
+            for defer, cap in ((1, 128), (0, 128), (1, 16)):
+                c.set_tuning("seed_defer", defer)
+                c.set_tuning("smem_cap", cap)
+                assert _gpu_dump(c, reads, off) == want, (L, defer, cap)
+                tm = c.timings()
+                assert (tm.seed_reseed_ms > 0) == bool(defer)
+        # other floors: min_seed_len / split factor / split width change which SMEMs are re-seeded and what a walk may emit
+        reads, _, _ = synth.make_reads(g, 3000, 150, seed=77)
+        off = np.arange(0, (reads.shape[0] + 1) * 150, 150, dtype=np.int64)
+        c.set_tuning("smem_cap", 128)
+        for msl, split_len, split_width in ((15, 20, 10), (25, 40, 3), (19, 28, 1)):
+            opt = hipapi.default_seed_opt(rounds=3)
+            opt.min_seed_len, opt.split_len, opt.split_width = msl, split_len, split_width
+            p = O.default_seed_params(3)
+            p.min_seed_len, p.split_len, p.split_width = msl, split_len, split_width
+            sm, ns, hits, nh, _ = O.seed_batch(idx, reads, off, smem_cap=1024, hit_cap=1 << 16, threads=0, params=p)
+            want = O.format_seed_dump(sm, ns, hits)
+            for defer in (1, 0):
+                c.set_tuning("seed_defer", defer)
+                smems, smem_off, h, hit_off = c.seed_batch(reads, off, opt)
+                slots, counts, hl = hipapi.smems_to_slots(smems, smem_off, h, hit_off)
+                assert O.format_seed_dump(slots, counts, hl) == want, (msl, split_len, split_width, defer)
+    finally:
+        c.close()
+
+
+def test_plcp_table_equals_definition(tmp_path):
+    """meme_stage_build_plcp: plcp[u] = min(255, LCP of suffix u with the nearer of its two suffix-array neighbours), LCPs bounded by the
+    text's end -- against a direct computation from the suffix array on a genome with long exact duplications (saturated entries)."""
+    import torch
+    g = synth.make_genome(400_000, seed=5, repeat_frac=0.05, n_dups=6, dup_len=600, poly_runs=4)
+    fa = str(tmp_path / "p.fa")
+    synth.write_fasta(fa, g, contigs=2)
+    prefix = build_index(fa, bits=12)
+    idx = O.load_index_files(prefix)
+    text, sa = idx.text, idx.sa.astype(np.int64)
+    n = text.shape[0]
+    # LCP of adjacent suffixes by doubling comparison windows (capped at 256 > 255)
+    lcp = np.zeros(n + 1, np.int64)                     # lcp[i] = LCP(slot i-1, slot i); lcp[0] = lcp[n] = 0
+    a, b = sa[:-1], sa[1:]
+    alive = np.ones(n - 1, bool)
+    cur = np.zeros(n - 1, np.int64)
+    pad = np.concatenate([text, np.full(300, 9, np.uint8)])
+    pad2 = np.concatenate([text, np.full(300, 8, np.uint8)])  # different pads: running off the end never matches
+    for k in range(256):
+        ia = np.nonzero(alive)[0]
+        if ia.size == 0:
+            break
+        same = pad[a[ia] + k] == pad2[b[ia] + k]
+        cur[ia[same]] += 1
+        alive[ia[~same]] = False
+    lcp[1:n] = cur
+    want = np.minimum(255, np.maximum(lcp[:-1], lcp[1:]))
+    plcp_by_pos = np.zeros(n, np.int64)
+    plcp_by_pos[sa] = want
+    c = hipapi.Context(0)
+    try:
+        c.load_index_files(prefix)
+        ia = c.describe_index()
+        out = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        hipapi._check(hipapi.lib().meme_stage_build_plcp(hipapi.C.c_void_p(c.h), hipapi.C.c_void_p(ia.d_sa_ent), hipapi.C.c_int64(n), hipapi.C.c_void_p(ia.d_pac64),
+                                                         hipapi.C.c_void_p(out.data_ptr())))
+        c.sync()
+        got = out[:n].cpu().numpy().astype(np.int64)
+    finally:
+        c.close()
+    bad = np.nonzero(got != plcp_by_pos)[0]
+    assert bad.size == 0, (int(bad[0]), int(got[bad[0]]), int(plcp_by_pos[bad[0]]))
+    assert (got == 255).sum() > 500 and (got < 30).sum() > n // 2
