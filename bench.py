@@ -138,6 +138,41 @@ def cpu_baseline_port(text, sa, l1, l2, reads, cores):
                       % reads.shape[0]}
 
 
+def _canon_seeds(rid, start, end, hitbeg, hitcount, hits, hit_base):
+    """SMEMs in the reference harness's dump order (per read by start ascending, end descending) with their hit lists flattened in
+    that order.  hit_base[i] = index in `hits` of SMEM i's read's first hit."""
+    order = np.lexsort((-end.astype(np.int64), start.astype(np.int64), rid))
+    rid, start, end, hitbeg, hitcount, hit_base = rid[order], start[order], end[order], hitbeg[order], hitcount[order], hit_base[order]
+    tot = int(hitcount.sum())
+    first = np.zeros(hitcount.shape[0] + 1, np.int64)
+    first[1:] = np.cumsum(hitcount)
+    src = np.repeat(hit_base + hitbeg - first[:-1], hitcount) + np.arange(tot, dtype=np.int64)
+    return rid, start, end, hitcount, hits[src]
+
+
+def seeds_equal_oracle(ctx, O, o_idx, part, opt):
+    """The GPU's seeds of `part` (through the C ABI) against oracle/meme_oracle.c orc_seed_batch: every SMEM, every hit position."""
+    n = part.shape[0]
+    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    g_sm, g_so, g_h, g_ho = ctx.seed_batch(part, off, opt)
+    cap, hcap = 256, 2048
+    while True:
+        try:
+            o_sm, o_ns, o_h, o_nh, _ = O.seed_batch(o_idx, part, off, smem_cap=cap, hit_cap=hcap, threads=0)
+            break
+        except RuntimeError:                                  # a read with more SMEMs / hits than the slice's arrays hold
+            cap, hcap = cap * 4, hcap * 8
+    if not np.array_equal(np.diff(g_so), o_ns.astype(np.int64)):
+        return False
+    g_rid = np.repeat(np.arange(n, dtype=np.int64), np.diff(g_so))
+    a = _canon_seeds(g_rid, g_sm["start"], g_sm["end"], g_sm["hitbeg"].astype(np.int64), g_sm["hitcount"].astype(np.int64), g_h, g_ho[:-1][g_rid])
+    mask = np.arange(cap)[None, :] < o_ns[:, None]
+    o_flat = o_sm[mask]
+    b = _canon_seeds(g_rid, o_flat["start"], o_flat["end"], o_flat["hitbeg"].astype(np.int64), o_flat["hitcount"].astype(np.int64), o_h.reshape(-1),
+                     (g_rid * hcap))
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
     """SURVEY 8(d) per-read figure from the instrumented restatement, on a sample of the same reads."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -427,6 +462,7 @@ def wait_for_free_gpus(n, timeout=120.0):
         time.sleep(1.0)
 
 
+REF_BEST_THREADS = int(os.environ.get("MEME_BENCH_REF_THREADS", "64"))
 MALLOC_TUNABLES = "glibc.malloc.tcache_count=4000:glibc.malloc.trim_threshold=1073741824:glibc.malloc.top_pad=67108864:glibc.malloc.mmap_threshold=33554432"
 
 
@@ -478,9 +514,10 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                 env["MEME_DROPIN_VIRTUAL"] = str(devices)
             t0 = time.time()
             with open(sam, "wb") as fh:
-                # the reference does its seeding and extension on the host threads: all of them; with the backend bound the host threads only
-                # do the SAM phase and 64 of them are faster than 256 (allocator contention in worker_sam, profiles/r03_e2e_threads.md)
-                nthr = threads if exe == "bwa-meme_mode3" else min(threads, int(os.environ.get("MEME_BENCH_E2E_DROPIN_THREADS", "64")))
+                # both binaries at the thread count that is best for them on this box -- 64 for either: the unmodified reference's
+                # mem_process_seqs takes 11.86 / 11.86 / 11.95 / 13.64 s at 32 / 64 / 128 / 256 threads (2 M pairs, 512 Mbp,
+                # profiles/r04_ref_thread_sweeps.md), the drop-in's SAM phase stops scaling at 32
+                nthr = min(threads, REF_BEST_THREADS) if exe == "bwa-meme_mode3" else min(threads, int(os.environ.get("MEME_BENCH_E2E_DROPIN_THREADS", "64")))
                 r = subprocess.run([os.path.join(ref_dir, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(nthr),
                                     prefix] + fqs, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=3000)
             wall = time.time() - t0
@@ -527,7 +564,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
             log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
         ref, drop = out["bwa-meme_mode3"], out["bwa-meme_dropin"]
         return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
-                "workload": "mem -7 (reference: -t %d; with the backend bound: -t %d), %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the "
+                "workload": "mem -7 (reference: -t %d, its best of a 32-256 sweep; with the backend bound: -t %d; same allocator settings for both), %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the "
                             "benchmark genome (%d bp), wall time incl. index loading" % (ref["threads"], drop["threads"], npairs, READ_LEN, genome.shape[0]),
                 "threads": threads, "pairs": npairs, "gpus_driven_by_the_one_aligner_process": devices, "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]),
                 "dropin": drop, "reference": ref, "speedup_wall": ref["wall_s"] / drop["wall_s"],
@@ -755,7 +792,7 @@ def main():
     for _ in range(a.steps):
         res = step()
         tm = ctx.timings()
-        kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms))
+        kernel_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms, tm.seed_reseed_ms))
         windows = tm.seed_windows
     barrier()
     dt = time.perf_counter() - t0
@@ -781,8 +818,9 @@ def main():
             sys.exit(0)
 
     if rank == 0:
-        k_ms = float(np.mean([k for k, _ in kernel_ms]))
-        g_ms = float(np.mean([g for _, g in kernel_ms]))
+        k_ms = float(np.mean([k[0] for k in kernel_ms]))
+        g_ms = float(np.mean([k[1] for k in kernel_ms]))
+        rs_ms = float(np.mean([k[2] for k in kernel_ms]))
         sample = reads[:20000]
         bpr, per_read = algorithmic_bytes_per_read(text, sa, l1, l2, sample)
         # parity at the benchmark's own size (index of n suffixes), by CONTENT: the GPU seeds the sample on its own and its
@@ -790,15 +828,19 @@ def main():
         # (oracle/meme_oracle.c orc_seed_batch; the checker only -- nothing timed goes through it)
         sys.path.insert(0, os.path.join(REPO, "tests"))
         import oracle_py as O
-        ns = sample.shape[0]
-        s_off = np.arange(0, (ns + 1) * READ_LEN, READ_LEN, dtype=np.int64)
-        g_sm, g_so, g_h, g_ho = ctx.seed_batch(sample, s_off, opt)
-        g_slots, g_counts, g_hl = hipapi.smems_to_slots(g_sm, g_so, g_h, g_ho)
-        o_sm, o_ns, o_h, o_nh, _ = O.seed_batch(O.Index(text, sa), sample, s_off, smem_cap=1024, hit_cap=1 << 15, threads=0)
-        sample_parity = O.format_seed_dump(g_slots, g_counts, g_hl) == O.format_seed_dump(o_sm, o_ns, o_h)
-        del g_sm, g_h, g_slots, g_hl, o_sm, o_h
-        if not sample_parity:
-            log("PARITY MISMATCH on the %d-read sample: the GPU seed dump differs from the oracle's" % ns)
+        # (round 4: 1 M reads instead of 20 000, in slices the oracle's fixed-capacity output arrays can hold; every SMEM and every hit
+        # position compared after the dump format's ordering -- SMEMs by (start asc, end desc), hits in suffix-array order)
+        ns = min(nreads, int(os.environ.get("MEME_BENCH_PARITY_READS", "1000000")))
+        t_par = time.time()
+        sample_parity, o_idx = True, O.Index(text, sa)
+        SL = 50000
+        for p0 in range(0, ns, SL):
+            part = reads[p0:p0 + SL]
+            if not seeds_equal_oracle(ctx, O, o_idx, part, opt):
+                sample_parity = False
+                log("PARITY MISMATCH in reads %d..%d of the benchmark's batch: the GPU's seeds differ from the oracle's" % (p0, p0 + part.shape[0]))
+                break
+        log("parity: %d of the benchmark's reads against orc_seed_batch in %.1f s: %s" % (ns, time.time() - t_par, "identical" if sample_parity else "DIFFERENT"))
         achieved = bpr * nreads / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "seeding_reads_per_sec", "value": (sum(per_rank) / dt) if sample_parity else None,
@@ -816,9 +858,11 @@ def main():
                        "searches_per_read": res.searches / nreads,
                        "windows_per_search": windows / max(res.searches, 1),
                        "sample_parity_with_oracle": bool(sample_parity),
-                       "sample_parity_check": "full seed dump of %d of the benchmark's reads vs orc_seed_batch" % ns},
+                       "sample_parity_check": "every SMEM and hit position of %d of the benchmark's reads vs orc_seed_batch" % ns},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "k_seed", "kernel_ms": k_ms, "gather_ms": g_ms,
+                         "traffic": None, "kernel": "the SA-search stage: k_seed (rounds 1 and 3, re-seeding of repeated SMEMs) + k_reseed / _emit / _search / _resume "
+                                                    "(re-seeding of unique SMEMs on the plcp table); HIP events around the whole stage",
+                         "kernel_ms": k_ms, "of_which_reseed_kernels_ms": rs_ms, "gather_ms": g_ms,
                          "algorithmic_bytes_per_read": bpr, "work_per_read": per_read},
         }
         # HBM traffic per launch from the committed PMC passes of this very configuration (rocprofv3 counters cannot be
@@ -865,7 +909,9 @@ def main():
                 cpu["sample"] += " (timed by the N=1 run on this box, cached in /dev/shm)"
             elif cpu_mode == "reference" and ref_prefix and time.time() - T_START < budget - 400:
                 try:
-                    cpu = cpu_baseline_reference(ref_prefix, reads[:nsamp], os.cpu_count() or 1)
+                    # the reference's best thread count on this box: a sweep of the same harness (32 / 64 / 128 / 256 threads: 459 / 485 /
+                    # 459 / 447 k reads/s at 512 Mbp, profiles/r04_ref_thread_sweeps.md) -- it stops scaling at 32 threads
+                    cpu = cpu_baseline_reference(ref_prefix, reads[:nsamp], min(os.cpu_count() or 1, REF_BEST_THREADS))
                     refcache.put("cpu_baseline_%d" % nsamp, cpu)
                 except Exception as e:  # the baseline is a reported extra, never the measured value
                     log("cpu_baseline (reference) failed: %r -- falling back to the port" % (e,))

@@ -369,16 +369,25 @@ struct Prefetcher {
     bool started = false;
 };
 Prefetcher* g_pf = nullptr;
-int g_next_slot = 0;                    // slot of the next chunk to be processed
+// Chunks are numbered where they are read (the binding's FASTQ reader calls prefetch_submit for every chunk, in order): chunk s lives in
+// slot s & 1, whoever seeds it.  Chunks from any other reader are not numbered: they take the slots in turn, and nothing runs ahead.
+std::mutex g_seq_mu;
+int64_t g_seq_next = 0;
+struct SeqTag { const bseq1_t* seqs; int64_t seq; };
+SeqTag g_seq_tags[8] = {};
+int g_next_slot = 0;                    // slot of the next un-numbered chunk
 std::atomic<double> g_t_prefetched{0};
 bool prefetch_on() { static const bool v = !(getenv("MEME_DROPIN_PREFETCH") && atoi(getenv("MEME_DROPIN_PREFETCH")) == 0); return v; }
 
 void prefetch_submit(bseq1_t* seqs, int64_t n) {
+    int64_t seq;
+    { std::lock_guard<std::mutex> lk(g_seq_mu); seq = g_seq_next++; g_seq_tags[seq & 7] = {seqs, seq}; }
     if (!prefetch_on() || !g_pf || !g_ext_on_device || !g_opt || g_dev.empty()) return;      // (known after the first chunk has been processed)
     Prefetcher& F = *g_pf;
     std::unique_lock<std::mutex> lk(F.m);
     if (F.state != 0) return;                                   // a chunk is already ahead (or nobody took the last one): this one is seeded in its turn
-    F.seqs = seqs; F.n = n; F.slot = g_next_slot ^ 0; F.state = 1;
+    // (slot seq & 1 is free: the pipeline reads chunk s only after chunk s - 2 has been written)
+    F.seqs = seqs; F.n = n; F.slot = (int)(seq & 1); F.state = 1;
     if (!F.started) {
         F.started = true;
         std::thread([] {
@@ -407,13 +416,7 @@ bool prefetch_take(bseq1_t* seqs, int64_t n, int* slot) {
     Prefetcher& F = *g_pf;
     std::unique_lock<std::mutex> lk(F.m);
     if (F.state == 0) return false;
-    if (F.seqs != seqs || F.n != n) {                           // somebody else's chunk: let it finish, forget it
-        F.cv.wait(lk, [&] { return F.state == 3 || F.state == 1; });
-        if (F.state == 1) { F.state = 0; return false; }        // (never started)
-        F.state = 0;
-        return false;
-    }
-    if (F.state == 1 && !F.started) { F.state = 0; return false; }
+    if (F.seqs != seqs || F.n != n) return false;               // a later chunk is ahead, in the other slot: this one is seeded now, in its own
     F.cv.wait(lk, [&] { return F.state == 3; });
     *slot = F.slot;
     F.state = 0;
@@ -451,10 +454,15 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         ktfor_calls() = 0;
         if (!g_pf) { g_pf = new Prefetcher; }
         g_pf->opt = opt;
-        int slot = g_next_slot;
-        if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
+        int slot = -1;
+        {
+            std::lock_guard<std::mutex> lk(g_seq_mu);
+            for (const SeqTag& t : g_seq_tags) if (t.seqs == seqs && t.seq >= g_seq_next - 8 && g_seq_next > 0) slot = (int)(t.seq & 1);
+            if (slot >= 0) for (SeqTag& t : g_seq_tags) if (t.seqs == seqs) t.seqs = nullptr;      // (the array is freed and its address may come back)
+        }
+        if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
+        else if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
         g_cur_chunk = &g_chunks[slot];
-        g_next_slot = slot ^ 1;
         ++g_chunk_gen;
     }
     next(opt, n_processed, n, seqs, pes0, w);

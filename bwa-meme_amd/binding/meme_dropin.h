@@ -75,7 +75,7 @@ struct Chunk {
 extern Chunk* g_cur_chunk;                     // the chunk mem_process_seqs is working on (one of two slots)
 #define g_chunk (*dropin::g_cur_chunk)
 // the device stages of a chunk ahead of its turn (started when the FASTQ reader hands the chunk out; meme_dropin.cpp)
-void prefetch_submit(bseq1_t* seqs, int64_t n);
+void prefetch_submit(bseq1_t* seqs, int64_t n);      // (called by the binding's FASTQ reader: chunks get their sequence number there)
 extern const bntseq_t* g_bns;                  // of the run (set by mem_process_seqs)
 extern std::vector<meme_contig> g_contigs;
 int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 1 host, 0 the reference's per-batch function
