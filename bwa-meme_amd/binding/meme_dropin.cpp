@@ -379,9 +379,22 @@ int g_next_slot = 0;                    // slot of the next un-numbered chunk
 std::atomic<double> g_t_prefetched{0};
 bool prefetch_on() { static const bool v = !(getenv("MEME_DROPIN_PREFETCH") && atoi(getenv("MEME_DROPIN_PREFETCH")) == 0); return v; }
 
+// a chunk read before the run's options were known (the parser threads are ahead while the index loads: the second chunk is usually
+// read before the first one is processed): submitted again by mem_process_seqs once it has seeded its own chunk
+bseq1_t* g_late_seqs = nullptr; int64_t g_late_n = 0, g_late_seq = -1;
+void prefetch_start(bseq1_t* seqs, int64_t n, int64_t seq);
+
 void prefetch_submit(bseq1_t* seqs, int64_t n) {
     int64_t seq;
-    { std::lock_guard<std::mutex> lk(g_seq_mu); seq = g_seq_next++; g_seq_tags[seq & 7] = {seqs, seq}; }
+    {
+        std::lock_guard<std::mutex> lk(g_seq_mu);
+        seq = g_seq_next++; g_seq_tags[seq & 7] = {seqs, seq};
+        if (!g_pf || !g_opt) { if (seq == 1) { g_late_seqs = seqs; g_late_n = n; g_late_seq = seq; } return; }
+    }
+    prefetch_start(seqs, n, seq);
+}
+
+void prefetch_start(bseq1_t* seqs, int64_t n, int64_t seq) {
     if (!prefetch_on() || !g_pf || !g_ext_on_device || !g_opt || g_dev.empty()) return;      // (known after the first chunk has been processed)
     Prefetcher& F = *g_pf;
     std::unique_lock<std::mutex> lk(F.m);
@@ -463,6 +476,11 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
         else if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
         g_cur_chunk = &g_chunks[slot];
+        {   // the chunk that was read before the options were known goes ahead now, beside this chunk's host phases
+            bseq1_t* ls = nullptr; int64_t ln = 0, lq = -1;
+            { std::lock_guard<std::mutex> lk(g_seq_mu); ls = g_late_seqs; ln = g_late_n; lq = g_late_seq; g_late_seqs = nullptr; }
+            if (ls && ls != seqs) prefetch_start(ls, ln, lq);
+        }
         ++g_chunk_gen;
     }
     next(opt, n_processed, n, seqs, pes0, w);

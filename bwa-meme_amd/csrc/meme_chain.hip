@@ -1389,6 +1389,9 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
                            (long long)opt->l_pac);
             return MEME_E_ARG;
         }
+    // however this function is left (the error returns below included), the kernels on the side streams have finished: a caller that
+    // retries with a smaller batch or destroys the ctx must not race them
+    struct SideGuard { meme_ctx* c; ~SideGuard() { for (auto st : c->stream_side) if (st) (void)hipStreamSynchronize(st); } } side_guard{ctx};
     DevBuf* B = ctx->chain;     // 0 tier-1 chains, 1 tier-1 seeds, 2 headers, 3 frac, 4 contig table, 5 counts/offsets, 6 packed chains, 7 packed seeds,
                                 // 8 lists + work + offsets of the five wavefront launches + read classes, 9 .. 13 their scratch sets
     if ((rc = meme_buf_reserve(ctx, B[0], (size_t)((n + 63) / 64 * 64) * CHAIN_CAP * sizeof(DChain)))) return rc;
@@ -1602,6 +1605,7 @@ extern "C" int meme_chain_batch_host(meme_ctx* ctx, const meme_mem_tl* smems, co
     HIP_TRY(hipMemcpyAsync(ctx->read_off.p, roff.data(), (size_t)(nreads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->last_seed_reads = nreads;
+    ctx->reads_resident = false;       // (the seeds are the caller's; whatever bases an earlier seeding call left here do not belong to them)
     ctx->last_seed_max_len = 0;
     for (i64 i = 0; i < nreads; ++i) ctx->last_seed_max_len = read_len[i] > ctx->last_seed_max_len ? read_len[i] : ctx->last_seed_max_len;
     return meme_chain_last_batch_host(ctx, contigs, n_contigs, opt, out);

@@ -68,6 +68,7 @@ struct meme_ctx {
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2], h_kswv;
     i64 last_seed_max_len = 0;         // longest read of that batch
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
+    bool reads_resident = false;       // ctx->reads holds the bases of that batch (false after meme_chain_batch_host: seeds brought by the caller)
     // tuning
     i64 seed_blocks = 0;               // 0 = auto
     i64 smem_cap = 128;                // per-read SMEM slots in the search kernel's scratch (tier 0; 3 KB per read.  With 64 a handful of

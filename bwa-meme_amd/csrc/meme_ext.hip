@@ -318,7 +318,10 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     HIP_TRY(hipSetDevice(ctx->device));
     memset(out, 0, sizeof(*out));
     const i64 n = ctx->last_seed_reads;
-    if (n <= 0 || !ctx->smem_off.p || !ctx->read_off.p || !ctx->reads.p) { meme_set_error("meme_extend_last_batch_host: no seeded batch on this ctx"); return MEME_E_STATE; }
+    if (n <= 0 || !ctx->smem_off.p || !ctx->read_off.p || !ctx->reads.p || !ctx->reads_resident) {
+        meme_set_error("meme_extend_last_batch_host: no seeded batch on this ctx (a seeding call has to stage the reads; meme_chain_batch_host brings seeds only)");
+        return MEME_E_STATE;
+    }
     if (copt->l_pac * 2 != ctx->idx.n) { meme_set_error("meme_extend_last_batch_host: l_pac does not match the loaded index"); return MEME_E_ARG; }
     int rc;
     i64 tot[2];

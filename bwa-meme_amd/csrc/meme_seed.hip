@@ -612,6 +612,7 @@ static int seed_host_reads(meme_ctx* ctx, const uint8_t* reads, const int64_t* r
     HIP_TRY(hipStreamSynchronize(ctx->stream));             // (the caller's read buffer is free again)
     if (totals) { totals[0] = res.total_smems; totals[1] = res.total_hits; }
     ctx->last_seed_reads = nreads;
+    ctx->reads_resident = true;
     ctx->last_seed_max_len = max_len;
     return MEME_OK;
 }

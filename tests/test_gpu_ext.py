@@ -101,3 +101,26 @@ def test_extend_call_needs_a_seeded_batch_and_the_right_genome(tmp_path):
         assert np.all(a["qe"][live] > a["qb"][live]) and np.all(a["re"][live] > a["rb"][live]) and np.all(a["score"][live] >= 19)
     finally:
         ctx.close()
+
+
+def test_extension_refuses_seeds_without_their_reads(tmp_path):
+    """meme_chain_batch_host brings seeds from the caller and leaves whatever bases an earlier seeding call staged: the calls that read the
+    batch's bases (extension, global alignment) must refuse instead of working on stale bytes."""
+    I = ext_golden_inputs()
+    fa = str(tmp_path / "c.fa")
+    synth.write_fasta(fa, I["genome"], name="cg", contigs=3)
+    prefix = build_index(fa, bits=14)
+    ctx = hipapi.Context(0)
+    try:
+        ctx.load_index_files(prefix)
+        smems, smem_off, hits, hit_off = ctx.seed_batch_host(I["reads"], I["read_off"])
+        contigs = [(int(o), int(l), 0) for o, l in zip(I["contig_off"], I["contig_len"])]
+        read_len = np.diff(I["read_off"]).astype(np.int32)
+        ctx.chain_batch_host(smems, smem_off, hits, hit_off, read_len, contigs, hipapi.default_chain_opt(I["l_pac"]))
+        with pytest.raises(hipapi.MemeError, match="no seeded batch"):
+            ctx.extend_last_batch_host(contigs, hipapi.default_chain_opt(I["l_pac"]), None)
+        ctx.seed_batch_resident(I["reads"], I["read_off"])          # a seeding call makes the ctx whole again
+        R = ctx.extend_last_batch_host(contigs, hipapi.default_chain_opt(I["l_pac"]), None)
+        assert R["regs"].shape[0] > 0
+    finally:
+        ctx.close()
