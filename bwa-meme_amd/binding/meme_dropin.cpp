@@ -63,6 +63,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         // small combined calls keep the lanes-per-pair kernels; combined calls of the whole thread team are big enough
         // for the lane-per-pair kernel much earlier than a lone caller's
         if (getenv("MEME_DROPIN_BSW_LANE_MIN")) meme_set_tuning(g_dev[(size_t)d].bsw, "bsw_lane_min_pairs", atoll(getenv("MEME_DROPIN_BSW_LANE_MIN")));
+        if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));   // a memory bound (and the tests' way to the split-and-retry paths)
     }
     // while the index streams in: the seeding / chaining buffers of a chunk on every device slot (pinned memory is slow to allocate)
     std::thread reserve([n, chunk_reads] {
@@ -287,12 +288,13 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     memset(&P.chains, 0, sizeof(P.chains));
     P.has_ext = false;
     const double ts0 = now_s();
-    if (g_ext_on_device) {                               // seeds stay in HBM (nothing on the host reads them)
+    P.reads_on_ctx = true;
+    if (!g_ext_on_device) {
+        if (meme_seed_batch_host(ctx, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
+        g_t_seed_call = g_t_seed_call + (now_s() - ts0);
+    }
+    if (g_ext_on_device && P.count > 0) {                // seeds stay in HBM; chains + extension where the seeds lie: only alignment records come back
         memset(&P.res, 0, sizeof(P.res));
-        if (meme_seed_batch_resident_ascii(ctx, P.flat, P.off, P.count, &so, nullptr, nullptr)) die("meme_seed_batch_resident_ascii");
-    } else if (meme_seed_batch_host(ctx, P.flat, P.off, P.count, &so, &P.res)) die("meme_seed_batch_host");
-    g_t_seed_call = g_t_seed_call + (now_s() - ts0);
-    if (g_ext_on_device && P.count > 0) {                // chains + extension where the seeds lie: only alignment records come back
         meme_chain_opt co;
         co.w = opt->w; co.max_chain_gap = opt->max_chain_gap; co.max_occ = opt->max_occ; co.min_seed_len = opt->min_seed_len;
         co.min_chain_weight = opt->min_chain_weight; co.max_chain_extend = opt->max_chain_extend;
@@ -300,8 +302,43 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         meme_ext_opt eo;
         eo.a = opt->a; eo.b = opt->b; eo.o_del = opt->o_del; eo.e_del = opt->e_del; eo.o_ins = opt->o_ins; eo.e_ins = opt->e_ins;
         eo.pen_clip5 = opt->pen_clip5; eo.pen_clip3 = opt->pen_clip3; eo.w = opt->w; eo.zdrop = opt->zdrop;
+        // The whole part in one go -- or, when the backend refuses it for want of memory (MEME_E_CAPACITY: a stage's scratch beside the
+        // resident index), in halves, quarters, ...: reads are independent, the pieces' records are merged on the host.  Only a piece
+        // of one 512-read batch that still does not fit stops the run.
+        auto run_piece = [&](int64_t first, int64_t count, meme_ext_host_result* R) -> int {
+            std::vector<int64_t> off;
+            const int64_t* poff = P.off + first;
+            if (first > 0) { off.resize((size_t)count + 1); for (int64_t i = 0; i <= count; ++i) off[(size_t)i] = P.off[first + i] - P.off[first]; poff = off.data(); }
+            int rc = meme_seed_batch_resident_ascii(ctx, P.flat + P.off[first], poff, count, &so, nullptr, nullptr);
+            if (rc == MEME_OK) rc = meme_extend_last_batch_host(ctx, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, R);
+            return rc;
+        };
         const double t0 = now_s();
-        if (meme_extend_last_batch_host(ctx, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, &P.ext)) die("meme_extend_last_batch_host");
+        int rc = run_piece(0, P.count, &P.ext);
+        if (rc == MEME_E_CAPACITY) {
+            fprintf(stderr, "[meme-dropin] the backend cannot take %lld reads at once (%s): in pieces\n", (long long)P.count, meme_last_error());
+            P.own_regs.clear(); P.own_reg_off.assign(1, 0);
+            meme_ext_host_result tot;
+            memset(&tot, 0, sizeof(tot));
+            int64_t piece = (P.count / 2 + BATCH_SIZE - 1) / BATCH_SIZE * BATCH_SIZE, done = 0;
+            while (done < P.count) {
+                const int64_t m = piece < P.count - done ? piece : P.count - done;
+                meme_ext_host_result R;
+                rc = run_piece(done, m, &R);
+                if (rc == MEME_E_CAPACITY && m > BATCH_SIZE) { piece = (m / 2 + BATCH_SIZE - 1) / BATCH_SIZE * BATCH_SIZE; continue; }
+                if (rc) die("chunk-level device stages");
+                const int64_t base = (int64_t)P.own_regs.size();
+                P.own_regs.insert(P.own_regs.end(), R.regs, R.regs + R.total_regs);
+                for (int64_t i = 1; i <= m; ++i) P.own_reg_off.push_back(base + R.reg_off[i]);
+                tot.total_regs += R.total_regs; tot.total_chains += R.total_chains; tot.n_pairs += R.n_pairs; tot.n_retried += R.n_retried; tot.n_bsw_calls += R.n_bsw_calls;
+                tot.n_tier2 += R.n_tier2; tot.chain_ms += R.chain_ms; tot.ext_ms += R.ext_ms; tot.bsw_ms += R.bsw_ms;
+                done += m;
+            }
+            tot.nreads = P.count; tot.regs = P.own_regs.data(); tot.reg_off = P.own_reg_off.data();
+            P.ext = tot;
+            P.reads_on_ctx = false;                       // (the CIGAR stage names reads of the batch resident on the ctx: not for this part)
+        } else if (rc) die("chunk-level device stages (meme_seed_batch_resident_ascii / meme_extend_last_batch_host)");
+        g_t_seed_call = g_t_seed_call + (now_s() - ts0) - (double)P.ext.ext_ms * 1e-3 - (double)P.ext.chain_ms * 1e-3;
         g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
         g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
         g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
@@ -333,6 +370,7 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n, int slot) {
                 int dev_id = 0;
                 { int nreal = meme_device_count(); dev_id = nreal > 0 ? d % nreal : 0; }
                 if (!(D.seed2 = meme_ctx_create(dev_id)) || meme_index_share(D.seed2, D.seed)) die("second seeding ctx");
+                if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(D.seed2, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));
             }
     // consecutive 512-read batches of the chunk go to consecutive GPUs: contiguous ranges, batch-aligned
     const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;

@@ -64,6 +64,8 @@ struct ChunkPart {                     // the slice of a chunk one GPU seeded
     meme_chain_host_result chains;                       // valid when g_chain_on_device (host extension stage)
     meme_ext_host_result ext;                            // valid in device-extension mode: alignment records of the part's reads
     bool has_ext = false;
+    // a part the backend could only take in pieces (MEME_E_CAPACITY): the pieces' records, merged; the ctx then holds the LAST piece's reads only
+    std::vector<meme_alnreg> own_regs; std::vector<int64_t> own_reg_off; bool reads_on_ctx = true;
     uint8_t* flat = nullptr; int64_t flat_cap = 0;       // pinned staging (grow-only)
     int64_t* off = nullptr; int64_t off_cap = 0;
 };

@@ -330,6 +330,7 @@ void cig_prepass() {
             if (!gen_cigar_band(opt, l_pac, p.qe - p.qb, p.rb, p.re, C.w2, &w)) { C.tries = 99; continue; }
             int d = 0;
             while (d + 1 < nd && C.g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
+            if (!g_chunk.part[(size_t)d].reads_on_ctx) { C.tries = 99; continue; }       // (a part seeded in pieces: its reads are not all on the ctx; the hook computes these)
             meme_gjob& J = posed[(size_t)c];
             J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w = w;
             J.rev = p.rb >= l_pac ? 1 : 0;

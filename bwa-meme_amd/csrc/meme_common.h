@@ -75,6 +75,8 @@ struct meme_ctx {
                                        // the benchmark's 10 M reads overflowed and their sequential re-run cost every step 1.9 ms)
     i64 group_lanes = 4;               // lanes per read in the search kernel (4, 8, 16, 32)
     i64 seed_blocks_per_cu = 5;
+    i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
+                                       // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
     i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched
     i64 chain_light_hits = 32;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it
     i64 chain_lane_hits = 256;         // hits per read the lane-per-read chaining tier walks; reads with more go to the wavefront tiers at once

@@ -323,6 +323,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
         return MEME_E_STATE;
     }
     if (copt->l_pac * 2 != ctx->idx.n) { meme_set_error("meme_extend_last_batch_host: l_pac does not match the loaded index"); return MEME_E_ARG; }
+    if (ctx->max_batch > 0 && n > ctx->max_batch) { meme_set_error("meme_extend_last_batch_host: %lld reads exceed the ctx's max_batch of %lld", (long long)n, (long long)ctx->max_batch); return MEME_E_CAPACITY; }
     int rc;
     i64 tot[2];
     if ((rc = meme_chain_run(ctx, contigs, n_contigs, copt, tot))) return rc;

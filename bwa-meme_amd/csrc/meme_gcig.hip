@@ -178,6 +178,7 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
     const i64 nreads = ctx->last_seed_reads;
     if (nreads <= 0 || !ctx->reads.p || !ctx->read_off.p || !ctx->idx.pac || !ctx->reads_resident) { meme_set_error("meme_global_batch_host: no seeded batch on this ctx (the jobs name its reads)"); return MEME_E_STATE; }
     if (opt->e_del < 1 || opt->e_ins < 1) { meme_set_error("meme_global_batch_host: gap extension penalties must be positive"); return MEME_E_ARG; }
+    if (ctx->max_batch > 0 && njobs > ctx->max_batch) { meme_set_error("meme_global_batch_host: %lld jobs exceed the ctx's max_batch of %lld", (long long)njobs, (long long)ctx->max_batch); return MEME_E_CAPACITY; }
     int qmax = 0;
     for (i64 k = 0; k < njobs; ++k) {
         const meme_gjob& J = jobs[k];

@@ -306,9 +306,10 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
             // the batch searches (list sizes stay on the device: fixed grids, grid-stride loops), then the blocked regions' second pass
             const unsigned sblocks = (unsigned)(rblocks < (i64)dev_cus * 4 ? rblocks : (i64)dev_cus * 4);
             hipLaunchKernelGGL(k_reseed_emit, dim3(sblocks), dim3(256), 0, ctx->stream, R);
-            for (int round = 0; round < 3; ++round) {          // blocked regions ping-pong between two lists; the last pass searches for itself
+            constexpr int ROUNDS = 4;                           // (named configuration: 3 rounds leave 2.2 ms of one-by-one searches to the last pass)
+            for (int round = 0; round < ROUNDS; ++round) {     // blocked regions ping-pong between two lists; the last pass searches for itself
                 hipLaunchKernelGGL(k_reseed_search, dim3(sblocks), dim3(256), 0, ctx->stream, R);
-                if (round < 2) {
+                if (round < ROUNDS - 1) {
                     hipLaunchKernelGGL(k_reseed_resume<false>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
                     HIP_TRY(hipMemsetAsync((unsigned long long*)ctx->counters.p + R.blk_ctr, 0, sizeof(unsigned long long), ctx->stream));
                     std::swap(R.blk, R.blk_out); std::swap(R.blk_ctr, R.blk_out_ctr);

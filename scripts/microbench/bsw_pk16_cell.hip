@@ -39,7 +39,8 @@ PK2(pk_max_i16, "v_pk_max_i16")
 PK2(pk_add_u16, "v_pk_add_u16")
 PK2(pk_sub_i16, "v_pk_sub_i16")
 PK2(pk_mul_u16, "v_pk_mul_lo_u16")
-__device__ __forceinline__ unsigned pk_ashr15(unsigned a) { unsigned d; asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(d) : "v"(a)); return d; }
+// (an inline constant feeds only the low half of a packed operand: the shift count comes from a register holding 15 in both halves)
+__device__ __forceinline__ unsigned pk_ashr15(unsigned a) { unsigned d; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "v"(0x000f000fu), "v"(a)); return d; }
 __device__ __forceinline__ unsigned pk_mad_u16(unsigned a, unsigned b, unsigned c) { unsigned d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 // one pair per lane; out[p] = (max score << 16) | (row of the maximum << 8 ... ) simplified: max score and its rightmost column summed over rows
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(64) k_cell16(const uint8_t* __restrict__ q, co
             if (h1i < 0) h1i = 0;
             W32 h1; h1.u = (unsigned)h1i * 0x00010001u;
             W32 f = zero, m, mj, jpk = zero;
-            m.u = 0x80008000u; mj.u = 0;
+            m.u = 0xffffffffu; mj.u = 0;             // (-1: below every H, and h - m cannot overflow 16 bits)
             v2u cur = he[0];
 #pragma unroll 4
             for (int j = 0; j < QL; ++j) {

@@ -66,7 +66,11 @@ def test_sam_identical_to_reference(tmp_path, paired):
     small = {}
     # Round 3: the DEFAULT is chaining + extension on the device (meme_extend_last_batch_host: the host only receives alignment records);
     # MEME_DROPIN_EXT=host is the arrangement described above, kept for -W runs and as a cross-check.
+    # Round 4: the device stages of chunk k+1 run beside the SAM phase of chunk k (prefetch; also switched off), and a backend that refuses
+    # a batch for want of memory (MEME_DROPIN_MAX_BATCH: max_batch of the ctxs) is fed in pieces -- extension stage and CIGAR stage alike.
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}), (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
+                                  (8, 400000, {"MEME_DROPIN_PREFETCH": "0"}), (8, 100000000, {"MEME_DROPIN_MAX_BATCH": "1500"}),
+                                  (8, 400000, {"MEME_DROPIN_MAX_BATCH": "700", "MEME_DROPIN_VIRTUAL": "2"}),
                                   (8, 100000000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
                                   (8, 400000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_VIRTUAL": "3"}),
