@@ -741,13 +741,19 @@ def main():
             d_l2.copy_(torch.from_numpy(l2.view(np.uint8).reshape(-1)))
             if n_l1:
                 d_l1[:n_l1 * 24].copy_(torch.from_numpy(l1.view(np.uint8).reshape(-1)))
+    t_bcast = 0.0
     if world > 1:
         # one-off RCCL broadcast of the raw index images over xGMI (5 B per suffix + 1 B per base + the model tables);
         # no collective in steady state
+        torch.cuda.synchronize()
+        tb0 = time.time()
         for t in (d_text, d_pos5, d_l2, d_l1):
             dist.broadcast(t, 0)
             bcast_bytes += t.numel() * t.element_size()
+        torch.cuda.synchronize()
+        t_bcast = time.time() - tb0
     torch.cuda.synchronize()
+    t_stage0 = time.time()
     if pre is not None:
         keep = (pre[4], pre[5]) + hipapi.attach_index_torch(ctx, n, pre[4], pre[5], d_l2, n_l2, d_l1, n_l1)
     else:
@@ -755,7 +761,8 @@ def main():
     del d_text, d_l2, d_l1, d_pos5
     pre = None
     torch.cuda.empty_cache()
-    log("index staged in HBM in %.1f s (%.2f GB entries)" % (time.time() - t0, 16 * n / 1e9))
+    t_stage = time.time() - t_stage0                 # this rank's staging kernels (entries, model records, plcp table) behind the broadcast
+    log("index staged in HBM in %.1f s (%.2f GB entries; broadcast %.1f s, staging kernels %.1f s)" % (time.time() - t0, 16 * n / 1e9, t_bcast, t_stage))
 
     # ---- reads: every rank samples its own batch ------------------------------------------------------
     genome_t = torch.empty(l_pac, dtype=torch.uint8, device=dev)
@@ -808,8 +815,18 @@ def main():
         got = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(got, cnt)
         per_rank = [int(g[0]) for g in got]
+        # what a reader of the N > 1 line needs to tell start-up from steady state: the broadcast, every rank's staging and kernel times
+        mine = torch.tensor([t_bcast, t_stage, float(np.mean([k[0] for k in kernel_ms])), float(np.mean([k[1] for k in kernel_ms])), time.time() - T_START],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
         collective = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "ranks_seen": dist.get_world_size(),
-                      "ranks_per_device": ranks_per_device, "index_broadcast_bytes": int(bcast_bytes)}
+                      "ranks_per_device": ranks_per_device, "index_broadcast_bytes": int(bcast_bytes),
+                      "index_broadcast_s": max(float(x[0]) for x in allr),
+                      "index_broadcast_GBps": (bcast_bytes / 1e9 / max(float(x[0]) for x in allr)) if max(float(x[0]) for x in allr) > 0 else None,
+                      "per_rank": [{"staging_s": float(x[1]), "search_stage_ms": float(x[2]), "pack_gather_ms": float(x[3]), "startup_s": float(x[4])} for x in allr],
+                      "startup_budget": "start-up = genome + index build on rank 0, broadcast, staging on every rank: %.0f s on the slowest rank before the timed "
+                                        "region of %d steps" % (max(float(x[4]) for x in allr), a.steps)}
         dist.barrier()
         dist.destroy_process_group()                 # no collective in steady state, none after the timed region either
         if rank != 0:                                # rank 0 goes on alone with the reported extras (baseline, legs)

@@ -28,6 +28,10 @@ def test_gpus_2_self_started_one_json_line():
     assert d["config"]["reads_per_gpu_per_step"] == 200000 and d["config"]["sample_parity_with_oracle"] is True
     assert d["config"]["reads_per_rank"] == [400000, 400000] and d["config"]["collective"]["ranks_seen"] == 2
     assert d["config"]["collective"]["index_broadcast_bytes"] > 5 * 2 * 64e6
+    # what makes a real 8-GPU run interpretable: the broadcast's time and rate, every rank's staging and kernel times, the start-up budget
+    col = d["config"]["collective"]
+    assert col["index_broadcast_s"] > 0 and col["index_broadcast_GBps"] > 0 and len(col["per_rank"]) == 2
+    assert all(r["staging_s"] > 0 and r["search_stage_ms"] > 0 and r["startup_s"] < 1800 for r in col["per_rank"]) and "start-up" in col["startup_budget"]
     # whole-job aggregate: both ranks' reads over the slower rank's time
     assert abs(d["value"] - 2 * 200000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     # the N>1 line keeps the reported extras
