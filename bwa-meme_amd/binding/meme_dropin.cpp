@@ -309,7 +309,9 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
             std::vector<int64_t> off;
             const int64_t* poff = P.off + first;
             if (first > 0) { off.resize((size_t)count + 1); for (int64_t i = 0; i <= count; ++i) off[(size_t)i] = P.off[first + i] - P.off[first]; poff = off.data(); }
+            const double tc0 = now_s();
             int rc = meme_seed_batch_resident_ascii(ctx, P.flat + P.off[first], poff, count, &so, nullptr, nullptr);
+            g_t_seed_call = g_t_seed_call + (now_s() - tc0);
             if (rc == MEME_OK) rc = meme_extend_last_batch_host(ctx, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, R);
             return rc;
         };
@@ -338,7 +340,6 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
             P.ext = tot;
             P.reads_on_ctx = false;                       // (the CIGAR stage names reads of the batch resident on the ctx: not for this part)
         } else if (rc) die("chunk-level device stages (meme_seed_batch_resident_ascii / meme_extend_last_batch_host)");
-        g_t_seed_call = g_t_seed_call + (now_s() - ts0) - (double)P.ext.ext_ms * 1e-3 - (double)P.ext.chain_ms * 1e-3;
         g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
         g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
         g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
