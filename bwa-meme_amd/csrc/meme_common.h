@@ -93,6 +93,8 @@ struct meme_ctx {
     hipStream_t stream_side[3] = {nullptr, nullptr, nullptr};   // the routed chaining tiers run beside the lane-per-read tier
     hipEvent_t ev_side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_aux = nullptr;
+    hipStream_t stream_emit = nullptr;                          // k_reseed_emit runs beside the blocked regions' rounds
+    hipEvent_t ev_emit[2] = {nullptr, nullptr};
     i64 chain_reads = 0, chain_tier2_reads = 0, chain_tier3_reads = 0;   // of the last meme_chain_run(): reads chained, of which by the wavefront-per-read tier
     meme_timings tm = {};
 };

@@ -119,6 +119,8 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (auto& e : ctx->ev_gcig) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_kswv) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
+    for (auto& e : ctx->ev_emit) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream_emit) { (void)hipStreamSynchronize(ctx->stream_emit); (void)hipStreamDestroy(ctx->stream_emit); }
     for (auto& e : ctx->ev_side) if (e) (void)hipEventDestroy(e);
     for (auto& st : ctx->stream_side) if (st) (void)hipStreamDestroy(st);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

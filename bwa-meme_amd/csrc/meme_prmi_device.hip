@@ -9,14 +9,15 @@
 //
 //   k_prmi_bounds     first suffix-array slot of every leaf (leaf m serves the keys with key >> (64 - bits) == m)
 //   k_prmi_partials   leaves with more than `partial_threshold` keys get round(count / 20) third-layer records
-//   (hipCUB scan)     where each leaf's third-layer records start
+//   (rocPRIM scan)     where each leaf's third-layer records start
 //   k_prmi_leaves     one lane per leaf: the leaf's line and error bounds, or its routing line into the third layer
 //   k_prmi_third      one lane per third-layer record: its key range (the routing line is monotone), line and bounds
 //
 // Record semantics as in the host trainer: a line anchored on the neighbouring keys outside the segment, errors measured
 // over the segment including runs of equal keys, +2 slack; the model is a search hint -- results never depend
 // on it, only the number of windows a search needs.
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
 
 #include "meme_common.h"
 
@@ -196,9 +197,9 @@ extern "C" int meme_prmi_train_device(meme_ctx* ctx, const void* d_sa_ent, int64
     hipLaunchKernelGGL(k_prmi_partials, dim3(blocks_for(nleaf)), dim3(256), 0, ctx->stream, d_start, nleaf, partial_threshold, d_np);
     if (hipMemsetAsync(d_np + nleaf, 0, 8, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     size_t scan_bytes = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_np, d_pstart, (int)(nleaf + 1), ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if (rocprim::exclusive_scan(nullptr, scan_bytes, d_np, d_pstart, 0, (size_t)(nleaf + 1), rocprim::plus<>(), ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     if (hipMalloc(&d_scan, scan_bytes ? scan_bytes : 8) != hipSuccess) return fail(MEME_E_HIP);
-    if (hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_np, d_pstart, (int)(nleaf + 1), ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
+    if (rocprim::exclusive_scan(d_scan, scan_bytes, d_np, d_pstart, 0, (size_t)(nleaf + 1), rocprim::plus<>(), ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     i64 total = 0;
     if (hipMemcpyAsync(&total, d_pstart + nleaf, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return fail(MEME_E_HIP);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(MEME_E_HIP);

@@ -5,14 +5,17 @@
 //
 //   1. 2-bit text (k_pack_text, meme_ctx.hip), histogram of the first four bases;
 //   2. the 256 four-base buckets are sorted one group of buckets at a time (bounded workspace): gather (key, position),
-//      hipCUB radix sort, emit SA, group heads and ranks (rank = suffix-array position of the group's first member);
+//      rocPRIM radix sort (rocprim::radix_sort_pairs, called directly), emit SA, group heads and ranks (rank = suffix-array position of the group's first member);
 //   3. while tied groups remain: sort them by (rank of the suffix, rank of the suffix h bases further on), h = 32, 64, ...;
 //      a suffix that ends before h more bases sorts first, shorter before longer (the '$' of a classic suffix array).
 // Order convention = the reference's (src/Learnedindex.cpp:157-229, 242, 456-548; host/meme_sa.cpp): the text is followed by
 // k = max(longest A run, longest T run) + 1 bases T and then the end sentinel; the suffix array of that padded text is built
 // and the k entries that point into the padding are dropped.  The result equals the reference's `.pos_packed` order
 // (checked against the host builder by tests/test_gpu_sa.py).
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/functional.hpp>
 
 #include "meme_common.h"
 
@@ -258,10 +261,10 @@ extern "C" int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, in
         (rc = S.get(&gst, (size_t)biggest)) || (rc = S.get(&vv, (size_t)biggest))) return rc;
     size_t tmp_bytes = 0, t1 = 0, t2 = 0, t3 = 0;
     {
-        hipcub::DoubleBuffer<u64> dk(ka, kb), dv(va, vb);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, dk, dv, (i64)biggest, 0, 64, st));
-        HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, t2, vv, gst, hipcub::Max(), (i64)biggest, st));
-        HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, t3, (u64*)nullptr, tied, (u64*)nullptr, (unsigned long long*)nullptr, (i64)biggest, st));
+        rocprim::double_buffer<u64> dk(ka, kb), dv(va, vb);
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, t1, dk, dv, (i64)biggest, 0, 64, st));
+        HIP_TRY(rocprim::inclusive_scan(nullptr, t2, vv, gst, (size_t)((i64)biggest), rocprim::maximum<i64>(), st));
+        HIP_TRY(rocprim::select(nullptr, t3, (u64*)nullptr, tied, (u64*)nullptr, (unsigned long long*)nullptr, (i64)biggest, st));
         tmp_bytes = t1 > t2 ? t1 : t2;
         if (t3 > tmp_bytes) tmp_bytes = t3;
     }
@@ -276,17 +279,17 @@ extern "C" int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, in
         for (unsigned b = g.first; b < g.second; ++b) m += (i64)h_hist[b];
         HIP_TRY(hipMemsetAsync(d_nsel, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_sa_gather, dim3(grid_for((N + GATHER_ITEMS - 1) / GATHER_ITEMS)), dim3(256), 0, st, (const u64*)pac, N, g.first, g.second, d_nsel, ka, va);
-        hipcub::DoubleBuffer<u64> dk(ka, kb), dv(va, vb);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, dk, dv, m, 0, 64, st));
-        hipLaunchKernelGGL(k_sa_heads, dim3(grid_for(m)), dim3(256), 0, st, (const u64*)dk.Current(), (const u64*)nullptr, m, head, vv);
-        HIP_TRY(hipcub::DeviceScan::InclusiveScan(tmp, tmp_bytes, vv, gst, hipcub::Max(), m, st));
-        hipLaunchKernelGGL(k_sa_emit, dim3(grid_for(m)), dim3(256), 0, st, (const u64*)dv.Current(), (const unsigned char*)head,
+        rocprim::double_buffer<u64> dk(ka, kb), dv(va, vb);
+        HIP_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, dk, dv, m, 0, 64, st));
+        hipLaunchKernelGGL(k_sa_heads, dim3(grid_for(m)), dim3(256), 0, st, (const u64*)dk.current(), (const u64*)nullptr, m, head, vv);
+        HIP_TRY(rocprim::inclusive_scan(tmp, tmp_bytes, vv, gst, (size_t)(m), rocprim::maximum<i64>(), st));
+        hipLaunchKernelGGL(k_sa_emit, dim3(grid_for(m)), dim3(256), 0, st, (const u64*)dv.current(), (const unsigned char*)head,
                            (const i64*)gst, m, off, sa, rank, tied);
         // positions of the tied slots of this run
-        u64* iota = dk.Alternate();                       // (the key buffers are free again)
+        u64* iota = dk.alternate();                       // (the key buffers are free again)
         hipLaunchKernelGGL(k_iota_off, dim3(grid_for(m)), dim3(256), 0, st, iota, m, off);
-        u64* sel = dv.Alternate();
-        HIP_TRY(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, iota, tied, sel, d_nsel, m, st));
+        u64* sel = dv.alternate();
+        HIP_TRY(rocprim::select(tmp, tmp_bytes, iota, tied, sel, d_nsel, m, st));
         unsigned long long h_sel = 0;
         HIP_TRY(hipMemcpyAsync(&h_sel, d_nsel, sizeof(h_sel), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -325,9 +328,9 @@ extern "C" int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, in
             (rc = R.get(&idx, (size_t)m)) || (rc = R.get(&idx2, (size_t)m)) || (rc = R.get(&idx3, (size_t)m)) || (rc = R.get(&hd, (size_t)m)) ||
             (rc = R.get(&td, (size_t)m)) || (rc = R.get(&gs, (size_t)m)) || (rc = R.get(&v2, (size_t)m))) return rc;
         size_t r1 = 0, r2 = 0, r3 = 0;
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, r1, (const u64*)sec, k2, (const unsigned*)idx, idx2, m, 0, 64, st));
-        HIP_TRY(hipcub::DeviceScan::InclusiveScan(nullptr, r2, v2, gs, hipcub::Max(), m, st));
-        HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, r3, upos, td, upos2, (unsigned long long*)nullptr, m, st));
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, r1, (const u64*)sec, k2, (const unsigned*)idx, idx2, m, 0, 64, st));
+        HIP_TRY(rocprim::inclusive_scan(nullptr, r2, v2, gs, (size_t)(m), rocprim::maximum<i64>(), st));
+        HIP_TRY(rocprim::select(nullptr, r3, upos, td, upos2, (unsigned long long*)nullptr, m, st));
         size_t rb = r1 > r2 ? r1 : r2;
         if (r3 > rb) rb = r3;
         unsigned char* rtmp = nullptr;
@@ -335,18 +338,18 @@ extern "C" int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, in
         const unsigned g = grid_for(m);
         hipLaunchKernelGGL(k_sa_prep, dim3(g), dim3(256), 0, st, (const u64*)upos, m, (const u64*)sa, (const u64*)rank, N, h, prim, sec, val, idx);
         // stable LSD: by the second rank, then by the first
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(rtmp, rb, (const u64*)sec, k2, (const unsigned*)idx, idx2, m, 0, 44, st));
+        HIP_TRY(rocprim::radix_sort_pairs(rtmp, rb, (const u64*)sec, k2, (const unsigned*)idx, idx2, m, 0, 44, st));
         hipLaunchKernelGGL(k_gather_by<u64>, dim3(g), dim3(256), 0, st, (const u64*)prim, (const unsigned*)idx2, m, prim_s);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(rtmp, rb, (const u64*)prim_s, k2, (const unsigned*)idx2, idx3, m, 0, 44, st));
+        HIP_TRY(rocprim::radix_sort_pairs(rtmp, rb, (const u64*)prim_s, k2, (const unsigned*)idx2, idx3, m, 0, 44, st));
         hipLaunchKernelGGL(k_gather_by<u64>, dim3(g), dim3(256), 0, st, (const u64*)prim, (const unsigned*)idx3, m, prim_s);
         hipLaunchKernelGGL(k_gather_by<u64>, dim3(g), dim3(256), 0, st, (const u64*)sec, (const unsigned*)idx3, m, sec_s);
         hipLaunchKernelGGL(k_gather_by<u64>, dim3(g), dim3(256), 0, st, (const u64*)val, (const unsigned*)idx3, m, val_s);
         hipLaunchKernelGGL(k_sa_heads, dim3(g), dim3(256), 0, st, (const u64*)prim_s, (const u64*)sec_s, m, hd, v2);
-        HIP_TRY(hipcub::DeviceScan::InclusiveScan(rtmp, rb, v2, gs, hipcub::Max(), m, st));
+        HIP_TRY(rocprim::inclusive_scan(rtmp, rb, v2, gs, (size_t)(m), rocprim::maximum<i64>(), st));
         hipLaunchKernelGGL(k_sa_apply, dim3(g), dim3(256), 0, st, (const u64*)upos, (const u64*)val_s, (const unsigned char*)hd, (const i64*)gs, m,
                            sa, rank, td);
         HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-        HIP_TRY(hipcub::DeviceSelect::Flagged(rtmp, rb, upos, td, upos2, d_cnt, m, st));
+        HIP_TRY(rocprim::select(rtmp, rb, upos, td, upos2, d_cnt, m, st));
         unsigned long long h_sel = 0;
         HIP_TRY(hipMemcpyAsync(&h_sel, d_cnt, sizeof(h_sel), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -365,14 +368,14 @@ extern "C" int meme_sa_build_device(meme_ctx* ctx, const uint8_t* d_text0123, in
         const i64 piece = (i64)1 << 28;
         if ((rc = S.get(&flag, (size_t)piece)) || (rc = S.get(&iota, (size_t)piece))) return rc;
         size_t sb = 0;
-        HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, sb, iota, flag, pad_slots, d_cnt, piece, st));
+        HIP_TRY(rocprim::select(nullptr, sb, iota, flag, pad_slots, d_cnt, piece, st));
         if ((rc = S.get(&stmp, sb))) return rc;
         i64 found = 0;
         for (i64 o = 0; o < N; o += piece) {
             const i64 mlen = N - o < piece ? N - o : piece;
             hipLaunchKernelGGL(k_sa_flag_padding, dim3(grid_for(mlen)), dim3(256), 0, st, (const u64*)(sa + o), mlen, (i64)n, flag);
             hipLaunchKernelGGL(k_iota_off, dim3(grid_for(mlen)), dim3(256), 0, st, iota, mlen, o);
-            HIP_TRY(hipcub::DeviceSelect::Flagged(stmp, sb, iota, flag, pad_slots + found, d_cnt, mlen, st));
+            HIP_TRY(rocprim::select(stmp, sb, iota, flag, pad_slots + found, d_cnt, mlen, st));
             unsigned long long h_sel = 0;
             HIP_TRY(hipMemcpyAsync(&h_sel, d_cnt, sizeof(h_sel), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

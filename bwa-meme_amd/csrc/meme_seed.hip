@@ -305,7 +305,13 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
             hipLaunchKernelGGL(k_reseed, dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, R);
             // the batch searches (list sizes stay on the device: fixed grids, grid-stride loops), then the blocked regions' second pass
             const unsigned sblocks = (unsigned)(rblocks < (i64)dev_cus * 4 ? rblocks : (i64)dev_cus * 4);
-            hipLaunchKernelGGL(k_reseed_emit, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+            // the pending intervals on a stream of their own, beside the blocked regions' rounds (both are latency-bound lane-per-item
+            // kernels; they touch different slots of the reads they share)
+            if (!ctx->stream_emit) { HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_emit, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_emit[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_emit[1], hipEventDisableTiming)); }
+            HIP_TRY(hipEventRecord(ctx->ev_emit[0], ctx->stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream_emit, ctx->ev_emit[0], 0));
+            hipLaunchKernelGGL(k_reseed_emit, dim3(sblocks), dim3(256), 0, ctx->stream_emit, R);
+            HIP_TRY(hipEventRecord(ctx->ev_emit[1], ctx->stream_emit));
             constexpr int ROUNDS = 4;                           // (named configuration: 3 rounds leave 2.2 ms of one-by-one searches to the last pass)
             for (int round = 0; round < ROUNDS; ++round) {     // blocked regions ping-pong between two lists; the last pass searches for itself
                 hipLaunchKernelGGL(k_reseed_search, dim3(sblocks), dim3(256), 0, ctx->stream, R);
@@ -315,6 +321,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
                     std::swap(R.blk, R.blk_out); std::swap(R.blk_ctr, R.blk_out_ctr);
                 } else hipLaunchKernelGGL(k_reseed_resume<true>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
             }
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_emit[1], 0));
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));

@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void stage_plcp_windows(const uint8_t* __restrict__ p
 #pragma unroll
     for (int q = 0; q < 2 * (PLCP_WIN / 16); ++q) {
         win[(4 * q + 0) * 256] = v[q].x; win[(4 * q + 1) * 256] = v[q].y; win[(4 * q + 2) * 256] = v[q].z; win[(4 * q + 3) * 256] = v[q].w;
-    }
+    }   // (all eight loads in flight together: staging in two halves saves 16 VGPRs but adds a round trip per region)
 }
 
 constexpr int BLK_PER_READ = 1;      // blocked regions a read may leave behind in the first pass; its last record takes the rest of the read with it
@@ -1324,7 +1324,7 @@ __global__ void __launch_bounds__(256) k_reseed(ReseedArgs A) {
         __syncthreads();
         const i64 r = r0 + threadIdx.x;
         unsigned hops = 0, lsearches = 0;
-        int n_pend = 0, n_blk = 0;
+        int n_pend = 0, n_blk = 0, pend_ns = 0;
         BlkRec held[BLK_PER_READ];
         if (r < A.nreads) {
             const int c0 = A.slot_cnt[r];
@@ -1366,7 +1366,7 @@ __global__ void __launch_bounds__(256) k_reseed(ReseedArgs A) {
                     A.slot_cnt[r] = 0; A.slot_hits[r] = 0;
                     A.ovf_list[atomicAdd(&A.counters[2], 1ull)] = r;
                     n_pend = 0; n_blk = 0;
-                } else { A.slot_cnt[r] = ap.ns; A.slot_hits[r] = A.slot_hits[r] + ap.hits_add; }
+                } else { A.slot_cnt[r] = ap.ns; A.slot_hits[r] = A.slot_hits[r] + ap.hits_add; pend_ns = ap.ns; }
             }
         }
         // one global atomic per workgroup and list
@@ -1382,7 +1382,7 @@ __global__ void __launch_bounds__(256) k_reseed(ReseedArgs A) {
             if (blk_blk) blk_blk_base = atomicAdd(&A.counters[A.blk_ctr], (unsigned long long)blk_blk);
         }
         __syncthreads();
-        if (n_pend) A.pend_list[blk_pend_base + my_pend] = r;
+        if (n_pend) A.pend_list[blk_pend_base + my_pend] = r | ((i64)pend_ns << 40);     // the read, and how many of its slots this pass filled
 #pragma unroll
         for (int i = 0; i < BLK_PER_READ; ++i)
             if (i < n_blk) {
@@ -1400,8 +1400,11 @@ __global__ void __launch_bounds__(256) k_reseed_emit(ReseedArgs A) {
     __shared__ uint32_t lwin[(LANE_W / 2) * 256];
     const i64 n_list = (i64)A.counters[13];
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += (i64)gridDim.x * blockDim.x) {
-        const i64 r = A.pend_list[i];
-        const int c = A.slot_cnt[r];
+        // (runs beside the blocked regions' passes, which append to the same reads: only the slots the first pass filled are looked
+        // at, and the hit count is bumped atomically)
+        const i64 ent = A.pend_list[i];
+        const i64 r = ent & ((1ll << 40) - 1);
+        const int c = (int)(ent >> 40);
         SlotRec* sl = A.slots + r * A.cap;
         const u64* rec = A.packed + r * A.geo.stride;
         i64 hits_add = 0;
@@ -1417,7 +1420,7 @@ __global__ void __launch_bounds__(256) k_reseed_emit(ReseedArgs A) {
             sl[k].sa_start = r_start; sl[k].count = r_count;
             hits_add += (A.opt.hits_per_smem > 0 && r_count > A.opt.hits_per_smem) ? (i64)A.opt.hits_per_smem : r_count;
         }
-        A.slot_hits[r] = A.slot_hits[r] + hits_add;
+        atomicAdd(reinterpret_cast<unsigned long long*>(A.slot_hits + r), (unsigned long long)hits_add);
     }
 }
 

@@ -59,6 +59,25 @@ def test_sam_identical_512mbp_paired(tmp_path):
         assert len(a) == len(b) and len(b) > 2 * n
         diff = [(x, y) for x, y in zip(a, b) if x != y]
         assert not diff, "first differing SAM line:\n%s\n%s" % (diff[0][0].decode(), diff[0][1].decode())
+        # BASELINE configs[2] names BWA-MEM2 as the yardstick: the reference WITHOUT -7 (FM-index SMEMs) on its own `index -a mem2` files of the
+        # same 512 Mbp genome.  The index build takes the reference several minutes at this size, so this leg runs on request
+        # (MEME_TEST_FMI_512=1; the log of such a run is kept under profiles/).
+        if os.environ.get("MEME_TEST_FMI_512") == "1":
+            import time
+            t0 = time.time()
+            r = subprocess.run([os.path.join(R.REF_DIR, "bwa-meme_mode3"), "index", "-a", "mem2", prefix], capture_output=True, timeout=3000)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            print("[fmi-512] `index -a mem2` of the 512 Mbp genome: %.0f s" % (time.time() - t0))
+            sam = os.path.join(d, "fmi.sam")
+            t0 = time.time()
+            with open(sam, "wb") as fh:
+                r = subprocess.run([os.path.join(R.REF_DIR, "bwa-meme_mode3"), "mem", "-Y", "-K", "20000000", "-t", str(min(128, os.cpu_count() or 8)), prefix, f1, f2],
+                                   stdout=fh, stderr=subprocess.PIPE, timeout=3000)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
+            fmi = [l for l in open(sam, "rb") if not l.startswith(b"@PG")]
+            diff = [(x, y) for x, y in zip(a, fmi) if x != y]
+            print("[fmi-512] `mem` (FM-index engine) on %d pairs: %.0f s; SAM lines %d vs %d, differing %d" % (n, time.time() - t0, len(a), len(fmi), len(diff)))
+            assert len(a) == len(fmi) and not diff, "first SAM line that differs from the FM-index engine's:\n%s\n%s" % (diff[0][0].decode(), diff[0][1].decode())
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
