@@ -10,7 +10,23 @@ using namespace dropin;
 // of its own that keeps a bounded queue filled (records travel in batches of 4 096), and the pipeline's step 0 takes what is ready.
 // MEME_DROPIN_IO=0 switches it off (the reference's reader).
 #include <deque>
+#include <map>
+#include <sys/uio.h>
+#include <unistd.h>
+#include <omp.h>
+#include "profiling.h"
 namespace dropin {
+
+// ---- record strings without a malloc each (round 4) ---------------------------------------------------------------------------------
+// The reference's output step (kt_pipeline step 2, src/fastmap.cpp:843-862) writes a chunk's SAM text record by record and frees five
+// strings per read in ONE thread: 1.67 s per 4 M reads, three times the compute stages of the bound aligner -- what a run's wall time was
+// made of.  The binding interposes that step (below).  Name, bases and qualities of a record then never needed to be strings of their own:
+// they stay where the parser thread put them, in the batch's text arena, and the arenas of a chunk are released together when the chunk
+// has been written.  (Comments stay malloc'ed strings: step 0 frees them one by one unless -C is given.)
+bool fast_out() { static const bool v = !(getenv("MEME_DROPIN_OUT") && atoi(getenv("MEME_DROPIN_OUT")) == 0); return v; }
+struct ArenaRef { std::vector<std::shared_ptr<void>> batches; };
+std::mutex g_arena_mu;
+std::map<const bseq1_t*, ArenaRef> g_arenas;         // chunk (its record array) -> the text arenas its records point into
 
 struct ReadQueue {
     // Records travel in batches: one lock + one wake-up per BATCH records (per-record locking cost more than the parsing it was meant to
@@ -28,7 +44,7 @@ struct ReadQueue {
     kseq_t* ks = nullptr;
     std::thread th;
     int64_t LIMIT = 100000000;                                 // bases parsed ahead per stream (set to the chunk size on the first call)
-    Batch cur;                                                  // the consumer's current batch
+    std::shared_ptr<Batch> cur;                                 // the consumer's current batch (shared: a batch may straddle two chunks)
     size_t cur_i = 0;
     static uint32_t put(std::vector<char>& t, const char* p, size_t l) { const uint32_t o = (uint32_t)t.size(); t.insert(t.end(), p, p + l); t.push_back(0); return o; }
     void run() {
@@ -61,24 +77,30 @@ struct ReadQueue {
         }
     }
     static char* dup(const char* p, uint32_t l) { char* s = (char*)malloc((size_t)l + 1); if (!s) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); } memcpy(s, p, (size_t)l + 1); return s; }
-    bool pop(bseq1_t& out) {                                     // false: the stream is exhausted.  kseq2bseq1, src/bwa.cpp:82-89
-        if (cur_i == cur.recs.size()) {
+    // `arena` != null: name / seq / qual point into the batch's text (kept alive through *arena); else they are strings of their own
+    bool pop(bseq1_t& out, ArenaRef* arena) {                    // false: the stream is exhausted.  kseq2bseq1, src/bwa.cpp:82-89
+        if (!cur || cur_i == cur->recs.size()) {
             std::unique_lock<std::mutex> lk(m);
             cv_get.wait(lk, [&] { return !q.empty() || eof; });
             if (q.empty()) return false;
-            cur = std::move(q.front());
+            cur = std::make_shared<Batch>(std::move(q.front()));
             q.pop_front();
             cur_i = 0;
-            bases -= cur.bases;
+            bases -= cur->bases;
             cv_put.notify_one();
         }
-        const Rec& r = cur.recs[cur_i++];
-        const char* t = cur.text.data();
+        const Rec& r = cur->recs[cur_i++];
+        char* t = cur->text.data();
         memset(&out, 0, sizeof(out));
-        out.name = dup(t + r.name, r.name_l);
         out.comment = r.comment_l == UINT32_MAX ? 0 : dup(t + r.comment, r.comment_l);
-        out.seq = dup(t + r.seq, r.seq_l);
-        out.qual = r.qual_l == UINT32_MAX ? 0 : dup(t + r.qual, r.qual_l);
+        if (arena) {
+            if (arena->batches.empty() || arena->batches.back().get() != (void*)cur.get()) arena->batches.push_back(std::static_pointer_cast<void>(cur));
+            out.name = t + r.name; out.seq = t + r.seq; out.qual = r.qual_l == UINT32_MAX ? 0 : t + r.qual;
+        } else {
+            out.name = dup(t + r.name, r.name_l);
+            out.seq = dup(t + r.seq, r.seq_l);
+            out.qual = r.qual_l == UINT32_MAX ? 0 : dup(t + r.qual, r.qual_l);
+        }
         out.l_seq = (int)(r.seq_l < (uint32_t)ERT_MAX_READ_LEN ? r.seq_l : (uint32_t)ERT_MAX_READ_LEN);   // strnlen_s(s->seq, ERT_MAX_READ_LEN)
         return true;
     }
@@ -111,8 +133,9 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
     int64_t size = 0, m = 0, n = 0;
     bseq1_t* seqs = 0;
     bseq1_t a, b;
-    while (g_rq[0]->pop(a)) {
-        if (g_rq[1] && !g_rq[1]->pop(b)) {                          // the 2nd file has fewer reads (:190-193)
+    ArenaRef arena_store, *arena = fast_out() ? &arena_store : nullptr;
+    while (g_rq[0]->pop(a, arena)) {
+        if (g_rq[1] && !g_rq[1]->pop(b, arena)) {                   // the 2nd file has fewer reads (:190-193)
             fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", __func__);
             break;
         }
@@ -122,15 +145,72 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
         if (size >= chunk_size && (n & 1) == 0) break;
     }
     if (size == 0) {                                                // test if the 2nd file is finished (:223-226)
-        if (g_rq[1] && g_rq[1]->pop(b)) fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", __func__);
+        if (g_rq[1] && g_rq[1]->pop(b, nullptr)) { fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", __func__); free(b.name); free(b.comment); free(b.seq); free(b.qual); }
         for (int k = 0; k < 2; ++k)                                 // end of the input: the parsers finish before the caller destroys the streams
             if (g_rq[k] && g_rq[k]->th.joinable()) {
-                while (g_rq[k]->pop(b)) { free(b.name); free(b.comment); free(b.seq); free(b.qual); }
+                while (g_rq[k]->pop(b, nullptr)) { free(b.name); free(b.comment); free(b.seq); free(b.qual); }
                 g_rq[k]->th.join();
             }
     }
     *n_ = (int)n;
     *s = size;
+    if (arena && seqs) { std::lock_guard<std::mutex> lk(g_arena_mu); g_arenas[seqs] = std::move(arena_store); }
     if (n > 0) prefetch_submit(seqs, n);                            // the chunk's device stages start now, beside the previous chunk's SAM phase
     return seqs;
+}
+
+// ---- the output step ---------------------------------------------------------------------------------------------------------------
+// kt_pipeline(shared, 2, data) (src/fastmap.cpp:843-862): the chunk's SAM records to the output stream in read order, then the chunk's
+// memory back.  Here: the records' lengths by a few helper threads, the text straight from the records to the file descriptor with
+// writev() (no copy through stdio's buffer), the SAM strings freed by the helper threads (they come from the arenas of all the worker
+// threads), name / bases / qualities released with their text arenas.  Steps 0 and 1 are the reference's.  MEME_DROPIN_OUT=0: all of it.
+typedef ktp_data_t* (*ktp_step_fn)(void*, int, void*, mem_opt_t*, worker_t&);
+ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, worker_t& w) {
+    static ktp_step_fn next = (ktp_step_fn)dlsym(RTLD_NEXT, "_Z11kt_pipelinePviS_P9mem_opt_tR8worker_t");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_pipeline step function was not found\n"); exit(1); }
+    if (step != 2 || !fast_out()) return next(shared, step, data, opt, w);
+    ktp_aux_t* aux = (ktp_aux_t*)shared;
+    ktp_data_t* ret = (ktp_data_t*)data;
+    aux->n_processed += ret->n_seqs;
+    const uint64_t tim = __rdtsc();
+    const int n = ret->n_seqs;
+    bseq1_t* seqs = ret->seqs;
+    ArenaRef arena;
+    bool in_arena = false;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        auto it = g_arenas.find(seqs);
+        if (it != g_arenas.end()) { arena = std::move(it->second); g_arenas.erase(it); in_arena = true; }
+    }
+    const int nt = cig_threads() < 8 ? cig_threads() : 8;
+    const double t0 = now_s();
+    std::vector<struct iovec> iov((size_t)n);
+    size_t n_iov = 0;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int i = 0; i < n; ++i) { iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0; }
+    for (int i = 0; i < n; ++i) if (iov[(size_t)i].iov_len) iov[n_iov++] = iov[(size_t)i];
+    const double t1 = now_s();
+    fflush(aux->fp);                                                // (whatever stdio still holds goes first)
+    const int fd = fileno(aux->fp);
+    for (size_t k = 0; k < n_iov;) {
+        const int cnt = (int)(n_iov - k < 1024 ? n_iov - k : 1024);
+        ssize_t wr = writev(fd, &iov[k], cnt);
+        if (wr < 0) { if (errno == EINTR) continue; perror("[meme-dropin] writing the SAM output"); exit(1); }
+        while (wr > 0 && k < n_iov) {                               // (a short write: go on inside the record it stopped in)
+            if ((size_t)wr >= iov[k].iov_len) { wr -= (ssize_t)iov[k].iov_len; ++k; }
+            else { iov[k].iov_base = (char*)iov[k].iov_base + wr; iov[k].iov_len -= (size_t)wr; wr = 0; }
+        }
+    }
+    const double t2 = now_s();
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int i = 0; i < n; ++i) {
+        free(seqs[i].sam); free(seqs[i].comment);
+        if (!in_arena) { free(seqs[i].name); free(seqs[i].seq); free(seqs[i].qual); }
+    }
+    arena.batches.clear();
+    free(seqs);
+    free(ret);
+    if (verbose()) fprintf(stderr, "[meme-dropin] output step of %d reads: lengths %.3f s, writev %.3f s, frees %.3f s\n", n, t1 - t0, t2 - t1, now_s() - t2);
+    tprof[SAM_IO][0] += __rdtsc() - tim;
+    return 0;
 }
