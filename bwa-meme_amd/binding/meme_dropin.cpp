@@ -3,25 +3,24 @@
 // are built position-independent into libbwa_pic.so; the definitions below live in the executable and therefore win
 // symbol resolution (ELF interposition) -- no reference source is modified or copied, the calls below go to functions
 // the reference exports.  The binding is four translation units around meme_dropin.h (this file: devices, index, the chunk-level
-// calls, mem_kernel1_core_Learned; meme_dropin_ext.cpp: the host-side extension stage and the BandedPairWiseSW entry points;
-// meme_dropin_sam.cpp: the SAM phase's tables; meme_dropin_io.cpp: the FASTQ reader); reference_Makefile.patch adds a `dropin`
-// target to the reference's own Makefile.  A maintainer integrating the backend would put the same code behind an #ifdef at the
-// places named here:
+// calls, mem_kernel1_core_Learned; meme_dropin_ext.cpp: the BandedPairWiseSW entry points and the hand-over of the device's alignment
+// records; meme_dropin_sam.cpp: the SAM phase's tables; meme_dropin_io.cpp: the FASTQ reader and the output step);
+// reference_Makefile.patch adds a `dropin` target to the reference's own Makefile.  A maintainer integrating the backend would put the
+// same code behind an #ifdef at the places named here:
 //
 //   memoryAllocLearned()            src/fastmap.cpp:351-641   worker buffers as before, but the index files stream to HBM
 //                                   (meme_index_load_files + meme_index_replicate per extra GPU) instead of being
 //                                   expanded on the host (13-byte suffix-array entries + ISA, ~200 s / ~120 GB at GRCh38)
-//   mem_process_seqs()              src/bwamem.cpp:1920-1972  ONE meme_seed_batch_resident() / _host() per -K chunk (split over the
-//                                   visible GPUs) followed by meme_chain_last_batch_host() (mem_chain_Learned +
-//                                   mem_chain_flt on the device) before kt_for(worker_bwt); then the reference's own body
-//   mem_kernel1_core_Learned()      src/bwamem.cpp:1230-1413  per 512-read batch: takes the chunk's chains; the reference's
-//                                   ks_introsort / mem_chain_Learned / mem_chain_flt only for reads the device flagged;
-//                                   mem_flt_chained_seeds as before
-//   mem_chain2aln_across_reads_V2() src/bwamem.cpp:2573-3497  the extension jobs of the WHOLE chunk, stage by stage: one
-//                                   meme_bsw_batch() per direction and band width (the first batch to arrive does it)
+//   mem_process_seqs()              src/bwamem.cpp:1920-1972  per -K chunk (split over the visible GPUs), before kt_for(worker_bwt):
+//                                   meme_seed_batch_resident_ascii() + meme_extend_last_batch_host() -- seeding, mem_chain_Learned,
+//                                   mem_chain_flt, mem_flt_chained_seeds and mem_chain2aln_across_reads_V2 on the device; the next
+//                                   chunk's run ahead beside this chunk's SAM phase; then the reference's own body
+//   mem_kernel1_core_Learned()      src/bwamem.cpp:1230-1413  per 512-read batch: nothing left to do (MEME_DROPIN_EXT=0, the
+//                                   cross-check: takes the chunk's chains from the device, mem_flt_chained_seeds as before)
+//   mem_chain2aln_across_reads_V2() src/bwamem.cpp:2573-3497  per batch: takes its reads' alignment records
 //   BandedPairWiseSW::getScores8 / getScores16 / scalarBandedSWAWrapper   src/bandedSWA.cpp:242-260,1970-,2664-
 //                                   -> meme_bsw_batch(); concurrent calls of the kt_for workers combined into one backend
-//                                   call per GPU (group commit) -- the path when the chunk-wide stage is switched off
+//                                   call per GPU (group commit) -- the path of MEME_DROPIN_EXT=0
 #include "meme_dropin.h"
 #include <malloc.h>
 
@@ -127,12 +126,6 @@ __attribute__((constructor)) void meme_dropin_early_start() {
 // Worker buffers exactly as the reference sizes them (they are indexed by the kt_for thread id all over
 // mem_chain2aln_across_reads_V2 and freed by process(), src/fastmap.cpp:1098-1110); the host-side index expansion is gone.
 
-uint8_t bitrev8(uint8_t b) {
-    b = (uint8_t)(((b & 0xF0) >> 4) | ((b & 0x0F) << 4));
-    b = (uint8_t)(((b & 0xCC) >> 2) | ((b & 0x33) << 2));
-    return (uint8_t)(((b & 0xAA) >> 1) | ((b & 0x55) << 1));
-}
-
 }  // namespace dropin
 
 void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nthreads, char* idx_prefix) {
@@ -176,9 +169,9 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
             int c = 0;
             if (p < l_pac) c = pac[p >> 2] >> ((~p & 3) << 1) & 3;
             else if (p < 2 * l_pac) { const int64_t q = 2 * l_pac - 1 - p; c = 3 - (pac[q >> 2] >> ((~q & 3) << 1) & 3); }
-            b = (uint8_t)(b | (c << ((~j & 3) << 1)));
-        }
-        w.rc_pac[k] = bitrev8(b);
+            b = (uint8_t)(b | (c << (j << 1)));                 // base j of the byte in bits 2j, 2j + 1: what the reference's "BitReverseTable256"
+        }                                                       // (src/LearnedIndex_seeding.h:129-137: it reverses the 2-bit groups) makes of _set_pac's byte
+        w.rc_pac[k] = b;
     }
     w.sa_position = nullptr;                                   // the suffix array lives in HBM
     w.ref2sa = nullptr;
@@ -197,11 +190,10 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     const char* prefix = getenv("MEME_INDEX_PREFIX") ? getenv("MEME_INDEX_PREFIX") : idx_prefix;
     if (strcmp(prefix, idx_prefix) != 0)
         fprintf(stderr, "[meme-dropin] note: the HBM index comes from MEME_INDEX_PREFIX=%s, bns / pac / .0123 from %s (checked below: same number of suffixes)\n", prefix, idx_prefix);
-    std::thread prep([nreads, nthreads] { if (ext_mode() == 1) ext_prepare((int64_t)nreads, (int)nthreads); });   // host stage: pinned staging + helper threads, while the index loads
+    (void)ext_mode();                                                            // (a bad MEME_DROPIN_EXT stops the run before the index loads)
     if (g_early_prefix && strcmp(g_early_prefix, prefix) != 0) { fprintf(stderr, "[meme-dropin] MEME_INDEX_PREFIX changed after start-up\n"); exit(1); }
     init_devices(prefix, (int64_t)nreads);                                       // (returns at once when the early load below has done it)
     if (g_early) { g_early->join(); delete g_early; g_early = nullptr; }
-    prep.join();
     {   // the suffix array in HBM must describe the genome whose bns / pac the aligner loaded
         meme_index_arrays ia;
         if (meme_index_describe(g_dev[0].seed, &ia)) die("meme_index_describe");
@@ -223,21 +215,21 @@ Chunk* g_cur_chunk = &g_chunks[0];
 
 const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process_seqs)
 std::vector<meme_contig> g_contigs;
-// MEME_DROPIN_EXT: "device" (default) = chaining AND seed extension on the GPU, the host receives alignment records;
-// "host" = chains from the device, extension jobs built / folded / purged by the binding's thread team (round 2's arrangement, and
-// what runs when -W min_chain_weight makes mem_flt_chained_seeds more than a no-op); "0" = the reference's own per-batch function.
+// MEME_DROPIN_EXT: "device" (default) = chaining, the seed filter (mem_flt_chained_seeds) AND seed extension on the GPU, the host receives
+// alignment records; "0" = the reference's own per-batch functions on chains brought back from the device (the cross-check).
 int ext_mode() {
     static const int v = [] {
         const char* e = getenv("MEME_DROPIN_EXT");
         if (!e || !strcmp(e, "device") || !strcmp(e, "2")) return 2;
         if (!strcmp(e, "0")) return 0;
-        return 1;
+        fprintf(stderr, "[meme-dropin] MEME_DROPIN_EXT=%s: the values are device and 0 (the host-side extension stage is gone: the device runs the seed filter too)\n", e);
+        exit(1);
     }();
     return v;
 }
 bool g_ext_on_device = false;           // decided per run in mem_process_seqs (needs opt)
 std::atomic<double> g_t_ext_dev{0}, g_t_ext_chain_ms{0}, g_t_ext_ms{0}, g_t_ext_bsw_ms{0};
-std::atomic<int64_t> g_n_ext_pairs{0}, g_n_ext_retried{0}, g_n_ext_regs{0}, g_n_ext_tier2{0};
+std::atomic<int64_t> g_n_ext_pairs{0}, g_n_ext_retried{0}, g_n_ext_regs{0}, g_n_ext_tier2{0}, g_n_flt_jobs{0}, g_n_flt_dropped{0};
 bool chain_on_device() { static const bool v = !(getenv("MEME_DROPIN_CHAIN") && atoi(getenv("MEME_DROPIN_CHAIN")) == 0); return v; }
 bool chain_check() { static const bool v = getenv("MEME_DROPIN_CHAIN_CHECK") != nullptr; return v; }
 // MEME_DROPIN_CHAIN_DUMP=<file> (fixture generation, tests/golden/make_chain_golden.py): every read's seeds and the chains the
@@ -337,6 +329,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
                 for (int64_t i = 1; i <= m; ++i) P.own_reg_off.push_back(base + R.reg_off[i]);
                 tot.total_regs += R.total_regs; tot.total_chains += R.total_chains; tot.n_pairs += R.n_pairs; tot.n_retried += R.n_retried; tot.n_bsw_calls += R.n_bsw_calls;
                 tot.n_tier2 += R.n_tier2; tot.chain_ms += R.chain_ms; tot.ext_ms += R.ext_ms; tot.bsw_ms += R.bsw_ms;
+                tot.n_flt_jobs += R.n_flt_jobs; tot.n_flt_dropped += R.n_flt_dropped;
                 done += m;
             }
             tot.nreads = P.count; tot.regs = P.own_regs.data(); tot.reg_off = P.own_reg_off.data();
@@ -346,6 +339,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
         g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
         g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
+        g_n_flt_jobs += P.ext.n_flt_jobs; g_n_flt_dropped += P.ext.n_flt_dropped;
         P.has_ext = true;
         return;
     }
@@ -500,9 +494,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         for (int i = 0; i < g_bns->n_seqs; ++i) g_contigs.push_back({g_bns->anns[i].offset, g_bns->anns[i].len, g_bns->anns[i].is_alt});
     }
     if (w.useLearned) {
-        // mem_flt_chained_seeds (src/bwamem.cpp:565-598) sits between chaining and extension; it is a no-op unless
-        // 1.1 * min_chain_weight <= 0.05 * read length (never with the default min_chain_weight 0 and reads of at most 500 bases)
-        g_ext_on_device = ext_mode() == 2 && opt->min_chain_weight == 0;
+        g_ext_on_device = ext_mode() == 2;
         g_chunk_chain_ar = w.chain_ar;
         g_worker = &w;
         g_opt = opt;
@@ -538,10 +530,11 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
                 "which banded SW %.3f s); %lld alignment records, %lld extension jobs (%lld of them again with the doubled band), %lld reads chained by the "
                 "wavefront-per-read tier, 0 reads chained on the host\n", (double)g_t_ext_dev, (double)g_t_ext_chain_ms * 1e-3, (double)g_t_ext_ms * 1e-3,
                 (double)g_t_ext_bsw_ms * 1e-3, (long long)g_n_ext_regs, (long long)g_n_ext_pairs, (long long)g_n_ext_retried, (long long)g_n_ext_tier2);
+    if (verbose() && g_ext_on_device && g_n_flt_jobs > 0)
+        fprintf(stderr, "[meme-dropin] seed filter (mem_flt_chained_seeds) on the device: %lld alignments, %lld chained seeds removed\n", (long long)g_n_flt_jobs, (long long)g_n_flt_dropped);
     if (verbose() && !g_ext_on_device && chain_on_device())
         fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead\n",
                 (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
-    if (verbose() && !g_ext_on_device) ext_report();
     if (verbose() && getenv("MEME_DROPIN_PROFILE_SAM")) meme_dropin_report_matesw();
     if (verbose()) meme_dropin_report_cigar();
     if (verbose()) meme_dropin_report_mate();

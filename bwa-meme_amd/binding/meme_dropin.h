@@ -88,8 +88,6 @@ extern const mem_opt_t* g_opt;
 std::atomic<int>& ktfor_calls();               // kt_for calls of the chunk so far (the third one is worker_sam)
 extern mem_chain_v* g_chunk_chain_ar;          // w.chain_ar of the chunk being processed
 extern uint64_t g_chunk_gen;                   // counts the chunks seeded
-void ext_prepare(int64_t chunk_reads, int threads);
-void ext_report();
 int cig_threads();                             // helper threads of the binding's own host loops
 
 }  // namespace dropin

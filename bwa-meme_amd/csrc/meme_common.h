@@ -63,7 +63,7 @@ struct meme_ctx {
     void* plcp_aux = nullptr;                      // the plcp table of an attached index (meme_index_attach: the arrays are the caller's, this is ours)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[9], gcig[6], kswv[7];
+           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[15], gcig[6], kswv[7];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[2], h_kswv;
     i64 last_seed_max_len = 0;         // longest read of that batch
@@ -107,6 +107,11 @@ int meme_scan_exclusive(meme_ctx* ctx, const i64* d_in, i64* d_out, i64 n);
 // the banded-SW kernels on device-resident pairs, no host synchronisation (meme_bsw.hip); host_maxq = an upper bound of the query lengths or -1
 int meme_bsw_launch(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const uint8_t* d_qer, int npairs, int w, const meme_bsw_opt* opt,
                     int host_maxq);
+// local alignment scores of the jobs mem_flt_chained_seeds poses (meme_kswv.hip): window [rb, rb + tlen) of the text against the tlen x qlen
+// bases at reads[qoff]; sc[seed] = score.  The job count is read on the device; max_jobs sizes the launch.
+constexpr int MEME_SEEDSW_MAX = 200;    // MEM_SHORT_LEN, src/bwamem.cpp:250: windows are shorter
+struct meme_seedsw_job { i64 rb; i64 qoff; int seed; short tlen, qlen; };
+int meme_seedsw_launch(meme_ctx* ctx, const meme_seedsw_job* d_jobs, const unsigned long long* d_njobs, i64 max_jobs, int* d_sc, const meme_ext_opt* o);
 // chains of the batch just seeded, left in HBM (meme_chain.hip); totals[0..1] = chains, chained seeds
 int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt, i64* totals);
 

@@ -1,6 +1,8 @@
 // Seed extension of a whole batch on the device: mem_chain2aln_across_reads_V2 (reference src/bwamem.cpp:2573-3497) behind the chaining
 // kernels -- seeds, chains, extension jobs and their sequences never leave HBM; the host receives mem_alnreg_t records.
 //
+//   k_flt_pose / k_seedsw / k_flt_count / k_flt_move   mem_flt_chained_seeds (:565-598), only for reads it is not a no-op for (long
+//                      reads, -W): seeds whose neighbourhood aligns poorly leave their chains before anything is extended
 //   k_ext_jobs<false>  per read: the reference span of every chain (:2648-2690 + bns_fetch_seq_v2, src/bntseq.cpp:479-512), the
 //                      number of left / right extension jobs and of sequence bytes                                  -> scans
 //   k_ext_jobs<true>   per read: one alignment record per chained seed in extension order (best seed of a chain first, :2692-2702),
@@ -13,6 +15,7 @@
 //
 // One wavefront per read in the kernels that walk a read's chains (a read has 1 to a few hundred chained seeds: lanes take seeds, the
 // wavefront reduces / scans across them, and a repeat-rich read cannot hold 63 others back); one lane per job in the others.
+#include <math.h>
 #include <string.h>
 
 #include "meme_common.h"
@@ -25,6 +28,7 @@ constexpr int EXT_BAND_TRIES = 2;          // MAX_BAND_TRY, src/bwamem.cpp:62
 struct ExtArgs {
     const uint8_t* reads; const i64* read_off; i64 g0, ns;            // reads [g0, g0 + ns) of the batch
     const i64* chain_off; const meme_chain* chains; const i64* seed_off; const meme_chain_seed* seeds; const float* frac_rep;
+    const int* seed_score;            // per chained seed, or null: score = length (what chaining leaves, src/bwamem.cpp:1163)
     const u64* pac; i64 l_pac;
     const i64* contig_off; const int* contig_len;
     meme_ext_opt o;
@@ -132,9 +136,14 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
             bsum = __shfl(x, 63);
         }
         if (WRITE && valid) {
-            // rank among the chain's seeds by (score = length, index): ks_introsort_64 on score << 32 | index, keys unique (:2692-2699)
+            // rank among the chain's seeds by (score, index): ks_introsort_64 on score << 32 | index, keys unique (:2692-2699)
             int rank = 0;
-            for (int k = 0; k < ch.n_seeds; ++k) { const int lk = sd[k].len; rank += (lk < t.len || (lk == t.len && k < il)) ? 1 : 0; }
+            if (A.seed_score) {
+                const int* ss = A.seed_score + s0 + ch.seed_beg;
+                const int mine = ss[il];
+                for (int k = 0; k < ch.n_seeds; ++k) { const int lk = ss[k]; rank += (lk < mine || (lk == mine && k < il)) ? 1 : 0; }
+            } else
+                for (int k = 0; k < ch.n_seeds; ++k) { const int lk = sd[k].len; rank += (lk < t.len || (lk == t.len && k < il)) ? 1 : 0; }
             A.order[s0 + ch.seed_beg + rank] = il;
             const i64 reg = s0 + ch.seed_beg + (ch.n_seeds - 1 - rank);        // best seed first
             meme_alnreg a;
@@ -197,6 +206,114 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
         nL += __popcll(mL); nR += __popcll(mR); nB += bsum;
     }
     if (!WRITE && lane == 0) { A.cntL[rl] = nL; A.cntR[rl] = nR; A.cntB[rl] = nB; }
+}
+
+// ---- mem_flt_chained_seeds (src/bwamem.cpp:565-598) ---------------------------------------------------------------------------------
+struct FltArgs {
+    const i64* read_off; i64 n;
+    const i64* chain_off; meme_chain* chains; const i64* seed_off; const meme_chain_seed* seeds;
+    i64 l_pac; const i64* contig_off; const int* contig_len; int n_contigs;
+    const int* hsp;                  // per read length: min_HSP_score (:582), -1 where the filter does not run (:583)
+    int a;
+    int* sc;                         // per chained seed: FLT_OFF, -1 (kept without alignment, :502 / :515) or mem_seed_sw's score
+    meme_seedsw_job* jobs; unsigned long long* n_jobs;
+    i64* cnt;                        // per read: seeds that stay
+    const i64* off2;                 // its exclusive scan = the new seed_off
+    meme_chain_seed* seeds2; int* score2;
+};
+constexpr int FLT_OFF = INT32_MIN;
+constexpr int SEEDSW_EXT = 50;      // MEM_SHORT_EXT, src/bwamem.cpp:249
+
+// the alignments mem_seed_sw would run (src/bwamem.cpp:494-520, bns_fetch_seq src/bntseq.cpp:541-570): one lane per chained seed
+__global__ void __launch_bounds__(64) k_flt_pose(FltArgs A) {
+    const i64 r = blockIdx.x;
+    if (r >= A.n) return;
+    const int lane = threadIdx.x;
+    const i64 s0 = A.seed_off[r];
+    const int S = (int)(A.seed_off[r + 1] - s0);
+    const i64 q0 = A.read_off[r];
+    const int l_query = (int)(A.read_off[r + 1] - q0);
+    const int hsp = A.hsp[l_query];
+    for (int jb = 0; jb < S; jb += 64) {
+        const int j = jb + lane;
+        bool job = false;
+        meme_seedsw_job J;
+        if (j < S) {
+            int v = FLT_OFF;
+            if (hsp >= 0) {
+                v = -1;
+                const meme_chain_seed t = A.seeds[s0 + j];
+                if (t.len < MEME_SEEDSW_MAX) {
+                    int qb = t.qbeg, qe = t.qbeg + t.len;
+                    i64 rb = t.rbeg, re = t.rbeg + t.len;
+                    const i64 mid = (rb + re) >> 1;
+                    qb -= SEEDSW_EXT; qb = qb > 0 ? qb : 0;
+                    qe += SEEDSW_EXT; qe = qe < l_query ? qe : l_query;
+                    rb -= SEEDSW_EXT; rb = rb > 0 ? rb : 0;
+                    re += SEEDSW_EXT; re = re < A.l_pac << 1 ? re : A.l_pac << 1;
+                    if (rb < A.l_pac && A.l_pac < re) { if (mid < A.l_pac) re = A.l_pac; else rb = A.l_pac; }
+                    if (!(qe - qb >= MEME_SEEDSW_MAX || re - rb >= MEME_SEEDSW_MAX)) {
+                        // the window stays inside the reference sequence of the seed's midpoint, on its strand
+                        const bool rev = mid >= A.l_pac;
+                        const i64 fpos = rev ? (A.l_pac << 1) - 1 - mid : mid;
+                        int lo = 0, hi = A.n_contigs - 1;
+                        while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (A.contig_off[m] <= fpos) lo = m; else hi = m - 1; }
+                        i64 far_beg = A.contig_off[lo], far_end = far_beg + A.contig_len[lo];
+                        if (rev) { const i64 x = far_beg; far_beg = (A.l_pac << 1) - far_end; far_end = (A.l_pac << 1) - x; }
+                        rb = rb > far_beg ? rb : far_beg;
+                        re = re < far_end ? re : far_end;
+                        J.rb = rb; J.qoff = q0 + qb; J.seed = (int)(s0 + j); J.tlen = (short)(re - rb); J.qlen = (short)(qe - qb);
+                        job = true;
+                    }
+                }
+            }
+            A.sc[s0 + j] = v;
+        }
+        const u64 m = __ballot(job);
+        if (m) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(A.n_jobs, (unsigned long long)__popcll(m));
+            base = __shfl(base, 0);
+            if (job) A.jobs[base + __popcll(m & (((u64)1 << lane) - 1))] = J;
+        }
+    }
+}
+
+__device__ __forceinline__ bool flt_keeps(int v, int hsp) { return v == FLT_OFF || v < 0 || v >= hsp; }      // (:589)
+
+// seeds that stay: per read (-> scan -> the new seed_off), per chain (n_seeds; seed_beg = the kept seeds of the read's earlier chains)
+template <bool MOVE>
+__global__ void __launch_bounds__(64) k_flt_apply(FltArgs A) {
+    const i64 r = blockIdx.x;
+    if (r >= A.n) return;
+    const int lane = threadIdx.x;
+    const i64 c0 = A.chain_off[r];
+    const int nc = (int)(A.chain_off[r + 1] - c0);
+    const i64 s0 = A.seed_off[r];
+    const int hsp = A.hsp[(int)(A.read_off[r + 1] - A.read_off[r])];
+    const i64 d0 = MOVE ? A.off2[r] : 0;
+    int kept = 0;                                     // of the read so far (uniform)
+    for (int c = 0; c < nc; ++c) {
+        const meme_chain ch = A.chains[c0 + c];
+        int kc = 0;
+        for (int jb = 0; jb < ch.n_seeds; jb += 64) {
+            const int j = jb + lane;
+            const i64 g = s0 + ch.seed_beg + (j < ch.n_seeds ? j : 0);
+            const int v = A.sc[g];
+            const bool keep = j < ch.n_seeds && flt_keeps(v, hsp);
+            const u64 m = __ballot(keep);
+            if (MOVE && keep) {
+                const meme_chain_seed t = A.seeds[g];
+                const i64 d = d0 + kept + kc + __popcll(m & (((u64)1 << lane) - 1));
+                A.seeds2[d] = t;
+                A.score2[d] = v == FLT_OFF ? t.len : (v < 0 ? t.len * A.a : v);       // (:591)
+            }
+            kc += __popcll(m);
+        }
+        if (MOVE && lane == 0) { A.chains[c0 + c].seed_beg = kept; A.chains[c0 + c].n_seeds = kc; }
+        kept += kc;
+    }
+    if (!MOVE && lane == 0) A.cnt[r] = kept;
 }
 
 struct FoldArgs {
@@ -331,17 +448,58 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
     HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     DevBuf* B = ctx->chain;
-    DevBuf* E = ctx->ext;       // 0 rmax, 1 regs, 2 order, 3 counts + scans, 4 L pairs, 5 R pairs, 6 retry pairs (two halves), 7 sequences, 8 counter
+    DevBuf* E = ctx->ext;       // 0 rmax, 1 regs, 2 order, 3 counts + scans, 4 L pairs, 5 R pairs, 6 retry pairs (two halves), 7 sequences, 8 counters,
+                                // 9 .. 14 the seed filter's: scores, jobs, counts + new seed offsets, kept seeds, their scores, thresholds
     const i64* d_choff = (const i64*)B[5].p;
     const i64* d_sdoff = d_choff + (n + 1);
-    const i64 n_chains = tot[0], n_seeds = tot[1];
+    const i64 n_chains = tot[0];
+    i64 n_seeds = tot[1];
+    if ((rc = meme_buf_reserve(ctx, E[8], 64))) return rc;
+    // ---- mem_flt_chained_seeds: the read lengths it runs for and their thresholds, evaluated the way the reference's host code does
+    // (:579-583: float coefficients, double min_l, libm's log).  Never with reads below ~760 bases unless -W is given.
+    const meme_chain_seed* d_seeds = (const meme_chain_seed*)B[7].p;
+    const int* d_score = nullptr;
+    unsigned long long* d_fltcnt = (unsigned long long*)E[8].p + 2;
+    bool flt = false;
+    {
+        const i64 max_len = ctx->last_seed_max_len;
+        std::vector<int> hsp((size_t)max_len + 2, -1);
+        for (i64 l = 2; l <= max_len; ++l) {
+            const int l_query = (int)l;
+            const double min_l = copt->min_chain_weight ? 1.1f * copt->min_chain_weight : 5.5f * log(l_query);     // MEM_HSP_COEF, MEM_MINSC_COEF (:252-253)
+            if (min_l > 0.05f * l_query) continue;                                                                  // MEM_SEEDSW_COEF (:254)
+            hsp[(size_t)l] = (int)(eopt->a * min_l + .499);
+            if (hsp[(size_t)l] < 0) hsp[(size_t)l] = 0;
+            flt = true;
+        }
+        if (flt && n_seeds > 0) {
+            if (n_seeds >= 0x7fffffff) { meme_set_error("meme_extend_last_batch_host: %lld chained seeds in one batch", (long long)n_seeds); return MEME_E_CAPACITY; }
+            if ((rc = meme_buf_reserve(ctx, E[9], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[10], (size_t)(n_seeds + 1) * sizeof(meme_seedsw_job))) ||
+                (rc = meme_buf_reserve(ctx, E[11], (size_t)(n + 1) * 16)) || (rc = meme_buf_reserve(ctx, E[12], (size_t)(n_seeds + 1) * sizeof(meme_chain_seed))) ||
+                (rc = meme_buf_reserve(ctx, E[13], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[14], hsp.size() * 4))) return rc;
+            HIP_TRY(hipMemcpyAsync(E[14].p, hsp.data(), hsp.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemsetAsync(d_fltcnt, 0, 8, ctx->stream));
+            FltArgs F;
+            memset(&F, 0, sizeof(F));
+            F.read_off = (const i64*)ctx->read_off.p; F.n = n; F.chain_off = d_choff; F.chains = (meme_chain*)B[6].p; F.seed_off = d_sdoff; F.seeds = d_seeds;
+            F.l_pac = copt->l_pac; F.contig_off = (const i64*)B[4].p; F.contig_len = (const int*)((unsigned char*)B[4].p + (size_t)n_contigs * 8); F.n_contigs = n_contigs;
+            F.hsp = (const int*)E[14].p; F.a = eopt->a; F.sc = (int*)E[9].p; F.jobs = (meme_seedsw_job*)E[10].p; F.n_jobs = d_fltcnt;
+            F.cnt = (i64*)E[11].p; F.off2 = F.cnt + (n + 1); F.seeds2 = (meme_chain_seed*)E[12].p; F.score2 = (int*)E[13].p;
+            hipLaunchKernelGGL(k_flt_pose, dim3((unsigned)n), dim3(64), 0, ctx->stream, F);
+            if ((rc = meme_seedsw_launch(ctx, F.jobs, d_fltcnt, n_seeds, F.sc, eopt))) return rc;
+            hipLaunchKernelGGL((k_flt_apply<false>), dim3((unsigned)n), dim3(64), 0, ctx->stream, F);
+            if ((rc = meme_scan_exclusive(ctx, F.cnt, (i64*)F.off2, n))) return rc;
+            hipLaunchKernelGGL((k_flt_apply<true>), dim3((unsigned)n), dim3(64), 0, ctx->stream, F);
+            HIP_TRY(hipGetLastError());
+            d_sdoff = F.off2; d_seeds = F.seeds2; d_score = F.score2;
+        } else flt = false;
+    }
     if ((rc = meme_buf_reserve(ctx, E[0], (size_t)(n_chains + 1) * 16)) || (rc = meme_buf_reserve(ctx, E[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg))) ||
-        (rc = meme_buf_reserve(ctx, E[2], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[3], (size_t)(n + 1) * 8 * 6)) ||
-        (rc = meme_buf_reserve(ctx, E[8], 64))) return rc;
+        (rc = meme_buf_reserve(ctx, E[2], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[3], (size_t)(n + 1) * 8 * 6))) return rc;
     ExtArgs A;
     memset(&A, 0, sizeof(A));
     A.reads = (const uint8_t*)ctx->reads.p; A.read_off = (const i64*)ctx->read_off.p; A.g0 = 0; A.ns = n;
-    A.chain_off = d_choff; A.chains = (const meme_chain*)B[6].p; A.seed_off = d_sdoff; A.seeds = (const meme_chain_seed*)B[7].p; A.frac_rep = (const float*)B[3].p;
+    A.chain_off = d_choff; A.chains = (const meme_chain*)B[6].p; A.seed_off = d_sdoff; A.seeds = d_seeds; A.seed_score = d_score; A.frac_rep = (const float*)B[3].p;
     A.pac = ctx->idx.pac; A.l_pac = copt->l_pac;
     A.contig_off = (const i64*)B[4].p; A.contig_len = (const int*)((unsigned char*)B[4].p + (size_t)n_contigs * 8);
     A.o = *eopt;
@@ -354,7 +512,14 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     for (int k = 0; k < 3; ++k) if ((rc = meme_scan_exclusive(ctx, d_cnt + k * (n + 1), d_off + k * (n + 1), n))) return rc;
     std::vector<i64> h_off((size_t)(3 * (n + 1)));
     HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, h_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    i64 h_flt[2] = {n_seeds, 0};                    // chained seeds after the filter, alignments it ran
+    if (flt) {
+        HIP_TRY(hipMemcpyAsync(&h_flt[0], d_sdoff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&h_flt[1], d_fltcnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const i64 n_flt_dropped = n_seeds - h_flt[0];
+    n_seeds = h_flt[0];
     const i64* oL = h_off.data();
     const i64* oR = oL + (n + 1);
     const i64* oB = oR + (n + 1);
@@ -432,6 +597,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
     out->nreads = n; out->reg_off = (const int64_t*)Hb[0].p; out->regs = (const meme_alnreg*)Hb[1].p; out->total_regs = n_seeds;
     out->total_chains = n_chains; out->n_pairs = n_pairs; out->n_retried = n_retried; out->n_bsw_calls = n_calls;
+    out->n_flt_jobs = h_flt[1]; out->n_flt_dropped = n_flt_dropped;
     out->n_tier2 = ctx->chain_tier2_reads; out->chain_ms = ctx->tm.chain_kernel_ms; out->ext_ms = ms; out->bsw_ms = bsw_ms;
     return MEME_OK;
 }

@@ -197,7 +197,102 @@ __global__ void __launch_bounds__(64) k_kswv(KswvArgs A) {
     if (active) A.out[jid] = R;
 }
 
+// ---- mem_seed_sw (reference src/bwamem.cpp:494-520): the local alignment score of a chained seed's neighbourhood, at most 199 x 199 bases,
+// as ksw_align2 without KSW_XBYTE computes it -- ksw_i16 (src/ksw.cpp:236-320; only .score is used).  One job per lane, the window straight
+// from the 2-bit text, the query from the resident read; column word = {query code, H(i-1, j), E(i, j)} as above.
+//
+// ksw_i16 is Farrar's striped recurrence; its "lazy F" loop raises H where an insertion crosses a lane boundary of the striping but not
+// the E the main loop has already stored for the next row (:280-283 vs :289-299), i.e. it loses some insertion -> deletion transitions.
+// That is not observable: the same two gaps in the other order (deletion, then insertion: E feeds h, h feeds F, both exact) reach the same
+// cell with the same score, so every H equals the plain Gotoh value and the kernel computes that (the oracle restates the striping lane
+// by lane and agrees; tests/test_ref_live.py pins it on the compiled reference).  Columns past qlen score 0 in the reference's profile and
+// can only repeat values already counted; they are not computed.
+//
+// The window's bases are the ones the REFERENCE's call reads, which are not the genome's: mem_kernel1_core_Learned is handed worker_t::rc_pac
+// as `pac` (src/bwamem.cpp:1770) -- the 2-bit fwd + rc text with the four bases of every BYTE in reverse order, as the learned index's key
+// extraction wants them (src/fastmap.cpp:440-457; "BitReverseTable256", src/LearnedIndex_seeding.h:129-137, reverses 2-bit groups) -- and
+// bns_get_seq (src/bntseq.cpp:515-539) reads it with the plain _get_pac: within every aligned group of four bases the order is reversed;
+// windows on the reverse strand are fetched from the forward half and complemented (:526-531).  SAM output depends on it (under -W), so
+// it is reproduced, not corrected.
+__device__ __forceinline__ int flt_window_base(const u64* __restrict__ pac, i64 l_pac, i64 p) {
+    const i64 k = p < l_pac ? p : (l_pac << 1) - 1 - p;
+    const i64 kk = (k & ~3ll) + 3 - (k & 3);
+    const int c = kk < l_pac << 1 ? (int)(pac[kk >> 5] >> (62 - 2 * (int)(kk & 31))) & 3 : 0;
+    return p < l_pac ? c : 3 - c;
+}
+
+__device__ __forceinline__ int seedsw_score(lds_u32 W, const u64* __restrict__ pac, i64 l_pac, i64 rb, int tlen, const uint8_t* __restrict__ q, int qlen, const KswvArgs& A) {
+    const int w_match = A.a, w_mismatch = -A.b, w_ambig = -1;
+    const int oe_del = A.o_del + A.e_del, oe_ins = A.o_ins + A.e_ins, e_del = A.e_del, e_ins = A.e_ins;
+    int wave_q = qlen, wave_rows = tlen;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int y = __shfl_xor(wave_q, d), z = __shfl_xor(wave_rows, d);
+        wave_q = wave_q > y ? wave_q : y;
+        wave_rows = wave_rows > z ? wave_rows : z;
+    }
+    for (int j = 0; j <= wave_q; ++j) {                      // (one word of slack behind the last column)
+        unsigned c = 5u;
+        if (j < qlen) { c = q[j]; c = c > 4u ? 4u : c; }
+        W[(j + 1) * 64] = c;
+    }
+    const unsigned mm4 = (unsigned)(w_mismatch & 0xff) * 0x01010101u;
+    const unsigned tab_hi = (unsigned)(w_ambig & 0xff);     // code 4 (N): ambiguous; code 5 (past the query): 0
+    int gmax = 0;
+    for (int i = 0; i < wave_rows; ++i) {
+        if (i < tlen) {
+            const int tb = flt_window_base(pac, l_pac, rb + i);
+            const unsigned tab_lo = (mm4 & ~(0xffu << (8 * tb))) | ((unsigned)(w_match & 0xff) << (8 * tb));
+            int f = 0, diag = 0, rmax = 0;
+            unsigned cur = W[64];
+            for (int j = 0; j < qlen; ++j) {
+                const unsigned nxt = W[(j + 2) * 64];
+                const int hold = (int)((cur >> 8) & 0xfffu), e = (int)(cur >> 20);
+                const int sc = (int)(signed char)(__builtin_amdgcn_perm(tab_hi, tab_lo, cur) & 0xffu);
+                const int h = max3_i32(diag + sc, e, f);        // (:274-277; e, f >= 0: _mm_subs_epu16)
+                rmax = rmax > h ? rmax : h;
+                const int e2 = max3_i32(h - oe_del, e - e_del, 0);
+                f = max3_i32(h - oe_ins, f - e_ins, 0);
+                W[(j + 1) * 64] = hf_repack(h, e2, cur);
+                diag = hold;
+                cur = nxt;
+            }
+            gmax = gmax > rmax ? gmax : rmax;
+        }
+    }
+    return gmax;
+}
+
+__global__ void __launch_bounds__(64) k_seedsw(const meme_seedsw_job* __restrict__ jobs, const unsigned long long* __restrict__ n_jobs, const u64* __restrict__ pac,
+                                               i64 l_pac, const uint8_t* __restrict__ reads, int* __restrict__ sc, KswvArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int w_raw[];
+    const int lane = threadIdx.x;
+    const lds_u32 W = (lds_u32)w_raw + lane;
+    const i64 n = (i64)*n_jobs;
+    if ((i64)blockIdx.x * 64 >= n) return;
+    const i64 slot = (i64)blockIdx.x * 64 + lane;
+    const bool active = slot < n;
+    const meme_seedsw_job J = jobs[active ? slot : 0];
+    const int score = seedsw_score(W, pac, l_pac, J.rb, active ? (int)J.tlen : 0, reads + J.qoff, active ? (int)J.qlen : 0, A);
+    if (active) sc[J.seed] = score;
+}
+
 }  // namespace
+
+int meme_seedsw_launch(meme_ctx* ctx, const meme_seedsw_job* d_jobs, const unsigned long long* d_njobs, i64 max_jobs, int* d_sc, const meme_ext_opt* o) {
+    if (max_jobs <= 0) return MEME_OK;
+    if ((i64)(MEME_SEEDSW_MAX - 1) * o->a >= KSWV_SCORE_LIMIT || o->b > 127 || o->a > 127) {
+        meme_set_error("seed filter (mem_flt_chained_seeds): match score %d / mismatch penalty %d beyond the kernel's limits (199 x match < %d)", o->a, o->b, KSWV_SCORE_LIMIT);
+        return MEME_E_ARG;
+    }
+    KswvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.a = o->a; A.b = o->b; A.o_del = o->o_del; A.e_del = o->e_del; A.o_ins = o->o_ins; A.e_ins = o->e_ins;
+    const size_t lds = (size_t)(MEME_SEEDSW_MAX + 2) * 256;
+    hipLaunchKernelGGL(k_seedsw, dim3((unsigned)((max_jobs + 63) / 64)), dim3(64), lds, ctx->stream, d_jobs, d_njobs, ctx->idx.pac, ctx->idx.n >> 1, (const uint8_t*)ctx->reads.p, d_sc, A);
+    HIP_TRY(hipGetLastError());
+    return MEME_OK;
+}
 
 extern "C" int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer,
                                     int64_t qer_bytes, const meme_bsw_opt* opt, meme_kswv_host_result* out) {

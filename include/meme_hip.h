@@ -246,6 +246,7 @@ typedef struct {
     int64_t n_pairs, n_retried, n_bsw_calls;   /* extension jobs run, of which with the doubled band; backend launches */
     int64_t n_tier2;                 /* reads chained by the wavefront-per-read tier */
     float chain_ms, ext_ms, bsw_ms;  /* HIP-event times: chaining kernels; the extension stage (incl. its host round trips); of which banded SW */
+    int64_t n_flt_jobs, n_flt_dropped;   /* mem_flt_chained_seeds: alignments run (mem_seed_sw), chained seeds removed (0 / 0 where it is a no-op) */
 } meme_ext_host_result;
 int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* chain_opt,
                                 const meme_ext_opt* ext_opt, meme_ext_host_result* out);

@@ -12,6 +12,7 @@
 #include "meme_oracle.h"
 
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -936,6 +937,12 @@ static int o_u64_cmp(const void* a, const void* b) { const uint64_t x = *(const 
 int orc_extend_read(const uint8_t* read, int l_query, const orc_chain* chains, int n_chains, const orc_cseed* seeds, float frac_rep,
                     const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o,
                     orc_alnreg* out, int64_t* n_jobs, int64_t* n_retried) {
+    return orc_extend_read_scored(read, l_query, chains, n_chains, seeds, NULL, frac_rep, text, l_pac, contig_off, contig_len, o, out, n_jobs, n_retried);
+}
+
+int orc_extend_read_scored(const uint8_t* read, int l_query, const orc_chain* chains, int n_chains, const orc_cseed* seeds, const int32_t* seed_score,
+                           float frac_rep, const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o,
+                           orc_alnreg* out, int64_t* n_jobs, int64_t* n_retried) {
     int c, i, k, n_reg = 0, total = 0, max_n = 1, kept = 0, cur = 0;
     orc_bsw_params bl, br;
     uint64_t* srt;
@@ -971,7 +978,8 @@ int orc_extend_read(const uint8_t* read, int l_query, const orc_chain* chains, i
         if (rmax0 < far_beg) rmax0 = far_beg;
         if (rmax1 > far_end) rmax1 = far_end;
         rs = (uint8_t*)realloc(rs, (size_t)(rmax1 - rmax0) + 8);
-        for (i = 0; i < ch->n_seeds; ++i) srt[i] = (uint64_t)sd[i].len << 32 | (uint32_t)i;      /* score = length; keys unique */
+        for (i = 0; i < ch->n_seeds; ++i)                     /* score = length unless mem_flt_chained_seeds has set it; keys unique */
+            srt[i] = (uint64_t)(seed_score ? seed_score[ch->seed_beg + i] : sd[i].len) << 32 | (uint32_t)i;
         qsort(srt, (size_t)ch->n_seeds, 8, o_u64_cmp);
         for (i = 0; i < ch->n_seeds; ++i) co[i] = (int)(uint32_t)srt[i];
         for (k = ch->n_seeds - 1; k >= 0; --k) {              /* best seed first (:2702-2850) */
@@ -1069,19 +1077,171 @@ int orc_extend_read(const uint8_t* read, int l_query, const orc_chain* chains, i
 int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const orc_chain* chains,
                      const int64_t* seed_off, const orc_cseed* seeds, const float* frac_rep, const uint8_t* text, int64_t l_pac,
                      const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats) {
+    return orc_extend_batch_scored(reads, read_off, nreads, chain_off, chains, seed_off, seeds, NULL, frac_rep, text, l_pac, contig_off, contig_len, o, out, threads, stats);
+}
+
+int orc_extend_batch_scored(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const orc_chain* chains,
+                            const int64_t* seed_off, const orc_cseed* seeds, const int32_t* seed_score, const float* frac_rep, const uint8_t* text, int64_t l_pac,
+                            const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats) {
     int64_t r, jobs = 0, retried = 0;
     int bad = 0;
     if (threads < 1) threads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : jobs, retried) reduction(| : bad)
     for (r = 0; r < nreads; ++r) {
         int64_t j = 0, t = 0;
-        const int n = orc_extend_read(reads + read_off[r], (int)(read_off[r + 1] - read_off[r]), chains + chain_off[r], (int)(chain_off[r + 1] - chain_off[r]),
-                                      seeds + seed_off[r], frac_rep[r], text, l_pac, contig_off, contig_len, o, out + seed_off[r], &j, &t);
+        const int n = orc_extend_read_scored(reads + read_off[r], (int)(read_off[r + 1] - read_off[r]), chains + chain_off[r], (int)(chain_off[r + 1] - chain_off[r]),
+                                      seeds + seed_off[r], seed_score ? seed_score + seed_off[r] : NULL, frac_rep[r], text, l_pac, contig_off, contig_len, o, out + seed_off[r], &j, &t);
         if (n != seed_off[r + 1] - seed_off[r]) bad = 1;
         jobs += j; retried += t;
     }
     if (stats) { stats[0] = jobs; stats[1] = retried; }
     return bad ? -1 : 0;
+}
+
+/* ---- mem_flt_chained_seeds (reference src/bwamem.cpp:565-598) with mem_seed_sw (:494-520) ----------------------------------------------
+ * The alignment is ksw_align2 without KSW_XBYTE = ksw_i16 (src/ksw.cpp:236-320), of which only the score is used.  Restated with the
+ * eight 16-bit lanes as arrays, lane by lane and statement by statement (the lazy-F loop raises H but not the E the main loop has already
+ * stored, :280-283 vs :289-299 -- which never shows in a score: the two gaps in the other order reach the same cell). */
+static int o_ksw_i16_score(int qlen, const uint8_t* query, int tlen, const uint8_t* target, const orc_ext_opt* o) {
+    const int slen = (qlen + 7) / 8;                         /* ksw_qinit, :68-69 */
+    const int oe_del = o->o_del + o->e_del, oe_ins = o->o_ins + o->e_ins;
+    int i, j, k, l, gmax = 0;
+    int *H0 = (int*)calloc((size_t)slen * 8 * 3, sizeof(int)), *H1 = H0 + slen * 8, *E = H1 + slen * 8;    /* [segment][lane] */
+#define O_SUBS(x, y) ((x) > (y) ? (x) - (y) : 0)            /* _mm_subs_epu16 */
+    for (i = 0; i < tlen; ++i) {
+        int f[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 0, h[8], live;
+        int* t;
+        for (l = 7; l > 0; --l) h[l] = H0[(slen - 1) * 8 + l - 1];        /* _mm_slli_si128(H0[slen - 1], 2), :271-272 */
+        h[0] = 0;
+        for (j = 0; j < slen; ++j) {
+            for (l = 0; l < 8; ++l) {
+                const int col = j + l * slen;                                  /* the profile's segmentation, :87-88, :104-107 */
+                int sc = 0, e = E[j * 8 + l], hh;
+                if (col < qlen) { const int qc = query[col], tc = target[i]; sc = (qc > 3 || tc > 3) ? -1 : (qc == tc ? o->a : -o->b); }
+                hh = h[l] + sc;
+                if (hh < e) hh = e;
+                if (hh < f[l]) hh = f[l];
+                if (hh > mx) mx = hh;
+                H1[j * 8 + l] = hh;
+                e = O_SUBS(e, o->e_del);
+                { const int t2 = O_SUBS(hh, oe_del); if (e < t2) e = t2; }
+                E[j * 8 + l] = e;
+                f[l] = O_SUBS(f[l], o->e_ins);
+                { const int t2 = O_SUBS(hh, oe_ins); if (f[l] < t2) f[l] = t2; }
+                h[l] = H0[j * 8 + l];
+            }
+        }
+        for (k = 0, live = 1; k < 16 && live; ++k) {                          /* lazy F, :289-299 */
+            for (l = 7; l > 0; --l) f[l] = f[l - 1];
+            f[0] = 0;
+            for (j = 0; j < slen && live; ++j) {
+                live = 0;
+                for (l = 0; l < 8; ++l) {
+                    int hh = H1[j * 8 + l];
+                    if (hh < f[l]) hh = f[l];
+                    H1[j * 8 + l] = hh;
+                    hh = O_SUBS(hh, oe_ins);
+                    f[l] = O_SUBS(f[l], o->e_ins);
+                    if (f[l] > hh) live = 1;
+                }
+            }
+        }
+        if (mx > gmax) gmax = mx;
+        t = H0; H0 = H1; H1 = t;
+    }
+#undef O_SUBS
+    free(H0 < H1 ? H0 : H1);
+    return gmax;
+}
+
+/* The bases mem_seed_sw's bns_fetch_seq returns in the aligner: mem_kernel1_core_Learned is handed worker_t::rc_pac as `pac`
+ * (src/bwamem.cpp:1770), the 2-bit fwd + rc text with the four bases of every BYTE in reverse order for the learned index
+ * (src/fastmap.cpp:440-457; the table of src/LearnedIndex_seeding.h:129-137 reverses 2-bit groups), and bns_get_seq
+ * (src/bntseq.cpp:515-539) reads it with the plain _get_pac -- within every aligned four bases the order is reversed; reverse-strand
+ * windows come from the forward half, complemented.  text = the true fwd + rc codes. */
+static int o_flt_window_base(const uint8_t* text, int64_t l_pac, int64_t p) {
+    const int64_t k = p < l_pac ? p : (l_pac << 1) - 1 - p;
+    const int64_t kk = (k & ~(int64_t)3) + 3 - (k & 3);
+    const int c = kk < l_pac << 1 ? text[kk] & 3 : 0;
+    return p < l_pac ? c : 3 - c;
+}
+
+int orc_seed_sw(const uint8_t* read, int l_query, const orc_cseed* s, const uint8_t* text, int64_t l_pac, const int64_t* contig_off,
+                const int32_t* contig_len, int n_contigs, const orc_ext_opt* o) {
+    int qb, qe, lo, hi, i, sc;
+    uint8_t win[200];
+    int64_t rb, re, mid, fpos, far_beg, far_end;
+    if (s->len >= 200) return -1;                            /* MEM_SHORT_LEN, :250, :502 */
+    qb = s->qbeg; qe = s->qbeg + s->len;
+    rb = s->rbeg; re = s->rbeg + s->len;
+    mid = (rb + re) >> 1;
+    qb -= 50; qb = qb > 0 ? qb : 0;                          /* MEM_SHORT_EXT, :249 */
+    qe += 50; qe = qe < l_query ? qe : l_query;
+    rb -= 50; rb = rb > 0 ? rb : 0;
+    re += 50; re = re < l_pac << 1 ? re : l_pac << 1;
+    if (rb < l_pac && l_pac < re) { if (mid < l_pac) re = l_pac; else rb = l_pac; }
+    if (qe - qb >= 200 || re - rb >= 200) return -1;
+    /* bns_fetch_seq (src/bntseq.cpp:541-570): inside the reference sequence of the midpoint, on its strand */
+    fpos = mid >= l_pac ? (l_pac << 1) - 1 - mid : mid;
+    lo = 0; hi = n_contigs - 1;
+    while (lo < hi) { const int m = (lo + hi + 1) >> 1; if (contig_off[m] <= fpos) lo = m; else hi = m - 1; }
+    far_beg = contig_off[lo]; far_end = far_beg + contig_len[lo];
+    if (mid >= l_pac) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+    if (rb < far_beg) rb = far_beg;
+    if (re > far_end) re = far_end;
+    for (i = 0; i < (int)(re - rb); ++i) win[i] = (uint8_t)o_flt_window_base(text, l_pac, rb + i);
+    sc = o_ksw_i16_score(qe - qb, read + qb, (int)(re - rb), win, o);
+    return sc;
+}
+
+/* One read: seeds that fail the test leave their chains (the read's seeds are packed to the front, chain after chain; seed_beg / n_seeds
+ * of its chains follow); score[] receives what the reference leaves in mem_seed_t::score.  Returns the number of seeds that stay;
+ * *n_sw counts the alignments run. */
+int orc_flt_chained_seeds(const uint8_t* read, int l_query, orc_chain* chains, int n_chains, orc_cseed* seeds, int32_t* score, const uint8_t* text,
+                          int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs, const orc_ext_opt* o, int min_chain_weight,
+                          int64_t* n_sw) {
+    const double min_l = min_chain_weight ? 1.1f * min_chain_weight : 5.5f * log(l_query);      /* MEM_HSP_COEF, MEM_MINSC_COEF, :252-253, :579-580 */
+    const int min_hsp = (int)(o->a * min_l + .499);
+    const int off = min_l > 0.05f * l_query;                                                     /* MEM_SEEDSW_COEF, :254, :583 */
+    int c, j, kept = 0;
+    for (c = 0; c < n_chains; ++c) {
+        orc_chain* ch = &chains[c];
+        const int beg = ch->seed_beg;
+        int k = 0;
+        for (j = 0; j < ch->n_seeds; ++j) {
+            const orc_cseed s = seeds[beg + j];
+            int sc = s.len;
+            if (!off) {
+                sc = orc_seed_sw(read, l_query, &s, text, l_pac, contig_off, contig_len, n_contigs, o);
+                if (n_sw && !(s.len >= 200) && sc >= 0) ++*n_sw;
+                if (!(sc < 0 || sc >= min_hsp)) continue;
+                sc = sc < 0 ? s.len * o->a : sc;
+            }
+            seeds[kept + k] = s;
+            score[kept + k] = sc;
+            ++k;
+        }
+        ch->seed_beg = kept;
+        ch->n_seeds = k;
+        kept += k;
+    }
+    return kept;
+}
+
+int orc_flt_batch(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, orc_chain* chains, const int64_t* seed_off,
+                  orc_cseed* seeds, int32_t* score, const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs,
+                  const orc_ext_opt* o, int min_chain_weight, int64_t* kept, int threads, int64_t* n_sw_) {
+    int64_t r, n_sw = 0;
+    if (threads < 1) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+ : n_sw)
+    for (r = 0; r < nreads; ++r) {
+        int64_t k = 0;
+        kept[r] = orc_flt_chained_seeds(reads + read_off[r], (int)(read_off[r + 1] - read_off[r]), chains + chain_off[r], (int)(chain_off[r + 1] - chain_off[r]),
+                                        seeds + seed_off[r], score + seed_off[r], text, l_pac, contig_off, contig_len, n_contigs, o, min_chain_weight, &k);
+        n_sw += k;
+    }
+    if (n_sw_) *n_sw_ = n_sw;
+    return 0;
 }
 
 /* ---- banded global alignment with traceback: ksw_global2 (reference src/ksw.cpp:560-670) --------------------------------------------

@@ -119,6 +119,29 @@ int orc_extend_batch(const uint8_t* reads, const int64_t* read_off, int64_t nrea
                      const int64_t* seed_off, const orc_cseed* seeds, const float* frac_rep, const uint8_t* text, int64_t l_pac,
                      const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats);
 
+/* the same with the seeds' scores as mem_flt_chained_seeds leaves them (NULL: score = length) */
+int orc_extend_read_scored(const uint8_t* read, int l_query, const orc_chain* chains, int n_chains, const orc_cseed* seeds, const int32_t* seed_score,
+                           float frac_rep, const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o,
+                           orc_alnreg* out, int64_t* n_jobs, int64_t* n_retried);
+int orc_extend_batch_scored(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const orc_chain* chains,
+                            const int64_t* seed_off, const orc_cseed* seeds, const int32_t* seed_score, const float* frac_rep, const uint8_t* text, int64_t l_pac,
+                            const int64_t* contig_off, const int32_t* contig_len, const orc_ext_opt* o, orc_alnreg* out, int threads, int64_t* stats);
+
+/* ---- mem_flt_chained_seeds (reference src/bwamem.cpp:565-598) and mem_seed_sw (:494-520, ksw_i16 src/ksw.cpp:236-320) ----------------
+ * orc_seed_sw: -1 (no alignment needed) or the local alignment score of the seed's neighbourhood.  orc_flt_chained_seeds: one read --
+ * seeds that fail leave their chains: the read's seeds are packed to the front chain after chain, seed_beg / n_seeds follow, score[] =
+ * mem_seed_t::score afterwards; returns the number of seeds that stay. */
+int orc_seed_sw(const uint8_t* read, int l_query, const orc_cseed* s, const uint8_t* text, int64_t l_pac, const int64_t* contig_off,
+                const int32_t* contig_len, int n_contigs, const orc_ext_opt* o);
+int orc_flt_chained_seeds(const uint8_t* read, int l_query, orc_chain* chains, int n_chains, orc_cseed* seeds, int32_t* score, const uint8_t* text,
+                          int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs, const orc_ext_opt* o, int min_chain_weight,
+                          int64_t* n_sw);
+
+/* every read of a batch (flat layout of orc_extend_batch; seeds / score indexed by the OLD seed_off, kept[r] = seeds of read r that stay) */
+int orc_flt_batch(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, orc_chain* chains, const int64_t* seed_off,
+                  orc_cseed* seeds, int32_t* score, const uint8_t* text, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs,
+                  const orc_ext_opt* o, int min_chain_weight, int64_t* kept, int threads, int64_t* n_sw);
+
 /* ---- banded global alignment with traceback (ksw_global2, reference src/ksw.cpp:560-670) ------------------------------------------ */
 int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w,
                     int* n_cigar, uint32_t* cigar /* capacity qlen + tlen + 2 */);

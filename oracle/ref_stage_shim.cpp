@@ -5,6 +5,7 @@
 //                       (klib B-tree src/kbtree.h, ks_introsort src/ksort.h included -- whatever they do with equal keys)
 //   ref_extend_reads    mem_chain2aln_across_reads_V2()                    reference src/bwamem.cpp:2573-3497
 //                       with the reference's own BandedPairWiseSW kernels
+//   ref_flt_chained_seeds  mem_flt_chained_seeds() with mem_seed_sw()      reference src/bwamem.cpp:565-598, 494-520 (ksw_align2, src/ksw.cpp)
 //   ref_kswv_batch      sort_classify() + mem_sam_pe_batch()                reference src/bwamem.cpp:1798-1825, src/bwamem_pair.cpp:719-818
 //                       (the AVX-512 mate-rescue kernels kswv::getScores8 / getScores16, src/kswv.cpp)
 //   ref_gen_cigar       bwa_gen_cigar2()                                   reference src/bwa.cpp:274-362 (ksw_global2, src/ksw.cpp:560-670)
@@ -30,6 +31,7 @@ void mem_chain_Learned(const mem_opt_t* opt, const bntseq_t* bns, int len, mem_t
                        mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid);
 int mem_chain_flt(const mem_opt_t* opt, int n_chn_, mem_chain_t* a_, int tid);
 int64_t sort_classify(mem_cache* mmc, int64_t pcnt, int tid);
+void mem_flt_chained_seeds(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int n_chn, mem_chain_t* a);
 
 #define shim_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
 KSORT_INIT(shim_smem, mem_tl, shim_smem_lt)
@@ -117,10 +119,75 @@ struct shim_alnreg {        // the fields of mem_alnreg_t the stage sets
     float frac_rep; int32_t pad;
 };
 
+int ref_extend_reads_scored(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const shim_chain* chains,
+                            const int64_t* seed_off, const shim_cseed* seeds, const int32_t* seed_score, const uint32_t* frac_rep_bits, uint8_t* text0123,
+                            const int64_t* contig_off, const int32_t* contig_len, const uint8_t* contig_alt, int n_contigs, int64_t l_pac,
+                            const shim_ext_opt* eo, shim_alnreg* out);
 int ref_extend_reads(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const shim_chain* chains,
                      const int64_t* seed_off, const shim_cseed* seeds, const uint32_t* frac_rep_bits, uint8_t* text0123,
                      const int64_t* contig_off, const int32_t* contig_len, const uint8_t* contig_alt, int n_contigs, int64_t l_pac,
                      const shim_ext_opt* eo, shim_alnreg* out) {
+    return ref_extend_reads_scored(reads, read_off, nreads, chain_off, chains, seed_off, seeds, nullptr, frac_rep_bits, text0123, contig_off, contig_len, contig_alt,
+                                   n_contigs, l_pac, eo, out);
+}
+
+// mem_flt_chained_seeds on chains the caller brings (layout as above).  In place: a read's surviving seeds are packed to the front of its
+// range chain after chain, seed_beg / n_seeds of its chains follow, score[] = mem_seed_t::score afterwards, kept[r] = seeds that stay.
+int ref_flt_chained_seeds(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, shim_chain* chains,
+                          const int64_t* seed_off, shim_cseed* seeds, int32_t* score, const uint8_t* text0123, const int64_t* contig_off,
+                          const int32_t* contig_len, const uint8_t* contig_alt, int n_contigs, int64_t l_pac, const shim_ext_opt* eo, int min_chain_weight,
+                          int64_t* kept) {
+    mem_opt_t* opt = mem_opt_init();
+    opt->a = eo->a; opt->b = eo->b; opt->o_del = eo->o_del; opt->e_del = eo->e_del; opt->o_ins = eo->o_ins; opt->e_ins = eo->e_ins;
+    opt->min_chain_weight = min_chain_weight;
+    bwa_fill_scmat(opt->a, opt->b, opt->mat);
+    Bns bns(contig_off, contig_len, contig_alt, n_contigs, l_pac);
+    // what the aligner hands the function as `pac` (src/bwamem.cpp:1770): worker_t::rc_pac -- forward + reverse complement, 2 bits per base,
+    // every byte through the reference's own BitReverseTable256 (src/LearnedIndex_seeding.h:129-137; the recipe of src/fastmap.cpp:440-457,
+    // followed here on the caller's text)
+    std::vector<uint8_t> pac((size_t)((2 * l_pac + 3) / 4 + 2), 0);
+    for (int64_t i = 0; i < 2 * l_pac; ++i) pac[(size_t)(i >> 2)] |= (uint8_t)((text0123[i] & 3) << ((~i & 3) << 1));
+    for (uint8_t& b : pac) b = BitReverseTable256[b];
+    for (int64_t r = 0; r < nreads; ++r) {
+        bseq1_t seq;
+        memset(&seq, 0, sizeof(seq));
+        seq.l_seq = (int)(read_off[r + 1] - read_off[r]);
+        seq.seq = (char*)(reads + read_off[r]);
+        const int64_t c0 = chain_off[r], nc = chain_off[r + 1] - c0;
+        std::vector<mem_chain_t> a((size_t)(nc ? nc : 1));
+        for (int64_t k = 0; k < nc; ++k) {
+            const shim_chain& sc = chains[c0 + k];
+            mem_chain_t& c = a[(size_t)k];
+            memset(&c, 0, sizeof(c));
+            c.seqid = 0; c.n = c.m = sc.n_seeds; c.rid = sc.rid; c.pos = sc.pos;
+            c.seeds = (mem_seed_t*)calloc((size_t)(sc.n_seeds ? sc.n_seeds : 1), sizeof(mem_seed_t));
+            for (int j = 0; j < sc.n_seeds; ++j) {
+                const shim_cseed& sd = seeds[seed_off[r] + sc.seed_beg + j];
+                c.seeds[j].rbeg = sd.rbeg; c.seeds[j].qbeg = sd.qbeg; c.seeds[j].len = sd.len; c.seeds[j].score = sd.len;
+            }
+        }
+        mem_flt_chained_seeds(opt, &bns.b, pac.data(), &seq, (int)nc, a.data());
+        int64_t n = 0;
+        for (int64_t k = 0; k < nc; ++k) {
+            const mem_chain_t& c = a[(size_t)k];
+            chains[c0 + k].seed_beg = (int32_t)n; chains[c0 + k].n_seeds = c.n;
+            for (int j = 0; j < c.n; ++j, ++n) {
+                shim_cseed& sd = seeds[seed_off[r] + n];
+                sd.rbeg = c.seeds[j].rbeg; sd.qbeg = c.seeds[j].qbeg; sd.len = c.seeds[j].len;
+                score[seed_off[r] + n] = c.seeds[j].score;
+            }
+            free(c.seeds);
+        }
+        kept[r] = n;
+    }
+    free(opt);
+    return 0;
+}
+
+int ref_extend_reads_scored(const uint8_t* reads, const int64_t* read_off, int64_t nreads, const int64_t* chain_off, const shim_chain* chains,
+                            const int64_t* seed_off, const shim_cseed* seeds, const int32_t* seed_score, const uint32_t* frac_rep_bits, uint8_t* text0123,
+                            const int64_t* contig_off, const int32_t* contig_len, const uint8_t* contig_alt, int n_contigs, int64_t l_pac,
+                            const shim_ext_opt* eo, shim_alnreg* out) {
     mem_opt_t* opt = mem_opt_init();
     opt->a = eo->a; opt->b = eo->b; opt->o_del = eo->o_del; opt->e_del = eo->e_del; opt->o_ins = eo->o_ins; opt->e_ins = eo->e_ins;
     opt->pen_clip5 = eo->pen_clip5; opt->pen_clip3 = eo->pen_clip3; opt->w = eo->w; opt->zdrop = eo->zdrop;
@@ -167,7 +234,8 @@ int ref_extend_reads(const uint8_t* reads, const int64_t* read_off, int64_t nrea
                 c.seeds = (mem_seed_t*)calloc((size_t)sc.n_seeds, sizeof(mem_seed_t));
                 for (int j = 0; j < sc.n_seeds; ++j) {
                     const shim_cseed& sd = seeds[seed_off[r] + sc.seed_beg + j];
-                    c.seeds[j].rbeg = sd.rbeg; c.seeds[j].qbeg = sd.qbeg; c.seeds[j].len = sd.len; c.seeds[j].score = sd.len;
+                    c.seeds[j].rbeg = sd.rbeg; c.seeds[j].qbeg = sd.qbeg; c.seeds[j].len = sd.len;
+                    c.seeds[j].score = seed_score ? seed_score[seed_off[r] + sc.seed_beg + j] : sd.len;
                 }
             }
         }

@@ -128,6 +128,71 @@ def ext_golden_inputs():
             "contig_off": G["contig_off"], "contig_len": G["contig_len"], "n_fixture_reads": n0}
 
 
+def long_noisy_reads(g, n, seed, lo=800, hi=1300):
+    """Reads of 800-1 300 bases from either strand with 4 % substitutions, short indels, an occasional N and -- what the seed filter's
+    alignment is sensitive to -- stretches of 6-14 replaced bases (scored best as an insertion next to a deletion)."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        p = int(rng.integers(0, g.shape[0] - L - 200))
+        src = g[p:p + L + 200]
+        out, i = [], 0
+        while len(out) < L and i < src.shape[0]:
+            u = rng.random()
+            if u < 0.004:                                          # replaced stretch
+                k = int(rng.integers(6, 15))
+                out += list(rng.integers(0, 4, size=k)); i += k
+            elif u < 0.006:
+                out += list(rng.integers(0, 4, size=int(rng.integers(1, 6))))
+            elif u < 0.008:
+                i += int(rng.integers(1, 6))
+            else:
+                c = int(src[i])
+                if rng.random() < 0.04:
+                    c = (c + int(rng.integers(1, 4))) & 3
+                if rng.random() < 0.002:
+                    c = 4
+                out.append(c); i += 1
+        r = np.array(out[:L], np.uint8)
+        if rng.random() < 0.5:
+            r = np.where(r < 4, 3 - r, 4)[::-1].astype(np.uint8)
+        rows.append(np.ascontiguousarray(r))
+    return rows
+
+
+def flt_workload(min_chain_weight=0, n_long=120, n_short=400, lo=800, hi=1300):
+    """Inputs for the seed filter (mem_flt_chained_seeds, src/bwamem.cpp:565-598): long noisy reads + 150 / 250-base reads of the chain
+    fixture, on the chain fixture's genome; seeds and chains from the oracle (pinned on the reference elsewhere), chained with the given
+    weight floor.  Without -W the filter runs for reads of ~790 bases and more -- which the function takes, but the learned-index path does
+    not (LEARNED_MAX_READ_LEN 500, src/bwamem.cpp:1259-1262): lo / hi = 420 / 500 with -W 20 is the longest the aligner itself can meet.
+    Layout of ext_golden_inputs()."""
+    import oracle_py as O
+    from pymeme import hipapi, hostapi
+    g, fixture_reads = chain_golden_workload()
+    G = np.load(os.path.join(GOLDEN, "chain_golden.npz"))
+    text = hipapi.fwd_rc_text(g)
+    l_pac = int(G["l_pac"])
+    reads = long_noisy_reads(g, n_long, seed=311, lo=lo, hi=hi) + [fixture_reads[i] for i in list(range(0, n_short // 2)) + list(range(2000, 2000 + n_short // 2))]
+    _, sa = hostapi.build_sa(g)
+    idx = O.Index(text, sa)
+    read_off = np.zeros(len(reads) + 1, np.int64)
+    read_off[1:] = np.cumsum([len(r) for r in reads])
+    sm, nsm, hits, nh, _ = O.seed_batch(idx, np.concatenate(reads), read_off, smem_cap=2048, hit_cap=1 << 15)
+    copt = O.default_chain_opt(l_pac)
+    copt.min_chain_weight = min_chain_weight
+    alt = np.zeros(G["contig_off"].shape[0], np.uint8)
+    ch_list, sd_list, frac, coff, soff = [], [], [], [0], [0]
+    for r in range(len(reads)):
+        rc, ch, sd, tree, fr = O.chain_read(sm[r, :nsm[r]], hits[r, :nh[r]], len(reads[r]), G["contig_off"], alt, copt)
+        assert rc >= 0
+        ch_list.append(ch); sd_list.append(sd); frac.append(fr)
+        coff.append(coff[-1] + rc); soff.append(soff[-1] + sd.shape[0])
+    return {"genome": g, "reads_list": reads, "reads": np.concatenate(reads), "read_off": read_off, "chain_off": np.array(coff, np.int64),
+            "chains": np.concatenate(ch_list), "seed_off": np.array(soff, np.int64), "seeds": np.concatenate(sd_list), "frac_rep": np.array(frac, np.float32),
+            "text": text, "l_pac": l_pac, "contig_off": G["contig_off"], "contig_len": G["contig_len"]}
+
+
 def gcig_workload(n=3000, seed=77):
     """Inputs of the CIGAR-kernel tests (tests/golden/gcig_golden.npz): a 300 kbp genome, reads of 40-250 bases sampled with
     substitutions, indels (up to 30 bases) and an occasional N, from both strands; per read one or two global-alignment jobs the way

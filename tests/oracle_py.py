@@ -267,10 +267,11 @@ def chains_as_orc(chains):
     return out
 
 
-def extend_batch(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, text, l_pac, contig_off, contig_len, opt=None, threads=0):
-    """orc_extend_batch: records of every read's chained seeds (ORC_ALNREG_DTYPE, indexed by seed_off) + (jobs, retried)."""
+def extend_batch(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, text, l_pac, contig_off, contig_len, opt=None, threads=0, seed_score=None):
+    """orc_extend_batch[_scored]: records of every read's chained seeds (ORC_ALNREG_DTYPE, indexed by seed_off) + (jobs, retried).
+    seed_score: the seeds' scores as the seed filter leaves them (None: score = length)."""
     L = lib()
-    L.orc_extend_batch.restype = C.c_int
+    L.orc_extend_batch_scored.restype = C.c_int
     opt = opt or default_ext_opt()
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
     read_off = np.ascontiguousarray(read_off, dtype=np.int64)
@@ -285,10 +286,46 @@ def extend_batch(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, 
     out = np.zeros(int(seed_off[-1]), ORC_ALNREG_DTYPE)
     stats = np.zeros(2, np.int64)
     p = lambda a: C.c_void_p(a.ctypes.data)
-    rc = L.orc_extend_batch(p(reads), p(read_off), C.c_int64(read_off.shape[0] - 1), p(chain_off), p(chains), p(seed_off), p(seeds), p(frac_rep), p(text),
+    if seed_score is not None:
+        seed_score = np.ascontiguousarray(seed_score, dtype=np.int32)
+    rc = L.orc_extend_batch_scored(p(reads), p(read_off), C.c_int64(read_off.shape[0] - 1), p(chain_off), p(chains), p(seed_off), p(seeds),
+                            p(seed_score) if seed_score is not None else C.c_void_p(0), p(frac_rep), p(text),
                             C.c_int64(int(l_pac)), p(contig_off), p(contig_len), C.byref(opt), p(out), C.c_int(threads), p(stats))
     assert rc == 0
     return out, (int(stats[0]), int(stats[1]))
+
+
+def _repack_filtered(chains, seed_off, seeds, score, kept):
+    """What the in-place filters leave (a read's surviving seeds at the front of its old range) -> (chains, seed_off, seeds, score) packed."""
+    new_off = np.zeros(seed_off.shape[0], np.int64)
+    new_off[1:] = np.cumsum(kept)
+    idx = np.repeat(seed_off[:-1] - new_off[:-1], kept) + np.arange(int(new_off[-1]))
+    return chains, new_off, seeds[idx].copy(), score[idx].copy()
+
+
+def flt_batch(reads, read_off, chain_off, chains, seed_off, seeds, text, l_pac, contig_off, contig_len, opt=None, min_chain_weight=0, threads=0):
+    """orc_flt_batch (mem_flt_chained_seeds): (chains, seed_off, seeds, score) after the filter + the number of alignments it ran."""
+    L = lib()
+    L.orc_flt_batch.restype = C.c_int
+    opt = opt or default_ext_opt()
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    chain_off = np.ascontiguousarray(chain_off, dtype=np.int64)
+    chains = np.array(chains, dtype=ORC_CHAIN_DTYPE)
+    seed_off = np.ascontiguousarray(seed_off, dtype=np.int64)
+    seeds = np.array(seeds, dtype=ORC_CSEED_DTYPE)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+    n = read_off.shape[0] - 1
+    score = np.zeros(seeds.shape[0], np.int32)
+    kept = np.zeros(n, np.int64)
+    n_sw = np.zeros(1, np.int64)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = L.orc_flt_batch(p(reads), p(read_off), C.c_int64(n), p(chain_off), p(chains), p(seed_off), p(seeds), p(score), p(text), C.c_int64(int(l_pac)), p(contig_off),
+                         p(contig_len), C.c_int(contig_off.shape[0]), C.byref(opt), C.c_int(int(min_chain_weight)), p(kept), C.c_int(threads), p(n_sw))
+    assert rc == 0
+    return _repack_filtered(chains, seed_off, seeds, score, kept) + (int(n_sw[0]),)
 
 
 def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):

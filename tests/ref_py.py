@@ -99,7 +99,32 @@ def chain_read(smems, hits, read_len, contig_off, contig_len, contig_alt, opt, c
     return rc, out[:n], sd[:ns], tree.value, np.uint32(frac.value).view(np.float32)
 
 
-def extend_reads(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, text, l_pac, contig_off, contig_len, contig_alt, opt):
+def flt_chained_seeds(reads, read_off, chain_off, chains, seed_off, seeds, text, l_pac, contig_off, contig_len, contig_alt, opt, min_chain_weight=0):
+    """mem_flt_chained_seeds of the compiled reference on chains the caller brings: (chains, seed_off, seeds, score) after the filter."""
+    from oracle_py import ORC_CHAIN_DTYPE, ORC_CSEED_DTYPE, _repack_filtered
+    L = stage_lib()
+    L.ref_flt_chained_seeds.restype = C.c_int
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    chain_off = np.ascontiguousarray(chain_off, dtype=np.int64)
+    chains = np.array(chains, dtype=ORC_CHAIN_DTYPE)
+    seed_off = np.ascontiguousarray(seed_off, dtype=np.int64)
+    seeds = np.array(seeds, dtype=ORC_CSEED_DTYPE)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+    contig_alt = np.ascontiguousarray(contig_alt, dtype=np.uint8)
+    n = read_off.shape[0] - 1
+    score = np.zeros(seeds.shape[0], np.int32)
+    kept = np.zeros(n, np.int64)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = L.ref_flt_chained_seeds(p(reads), p(read_off), C.c_int64(n), p(chain_off), p(chains), p(seed_off), p(seeds), p(score), p(text), p(contig_off), p(contig_len),
+                                 p(contig_alt), C.c_int(contig_off.shape[0]), C.c_int64(int(l_pac)), C.byref(opt), C.c_int(int(min_chain_weight)), p(kept))
+    assert rc == 0, rc
+    return _repack_filtered(chains, seed_off, seeds, score, kept)
+
+
+def extend_reads(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, text, l_pac, contig_off, contig_len, contig_alt, opt, seed_score=None):
     """mem_chain2aln_across_reads_V2 of the compiled reference (its own BandedPairWiseSW kernels) on chains the caller brings; same
     layout as oracle_py.extend_batch."""
     from oracle_py import ORC_ALNREG_DTYPE, ORC_CHAIN_DTYPE, ORC_CSEED_DTYPE
@@ -118,7 +143,11 @@ def extend_reads(reads, read_off, chain_off, chains, seed_off, seeds, frac_rep, 
     contig_alt = np.ascontiguousarray(contig_alt, dtype=np.uint8)
     out = np.zeros(int(seed_off[-1]), ORC_ALNREG_DTYPE)
     p = lambda a: C.c_void_p(a.ctypes.data)
-    rc = L.ref_extend_reads(p(reads), p(read_off), C.c_int64(read_off.shape[0] - 1), p(chain_off), p(chains), p(seed_off), p(seeds), p(frac_bits), p(text),
+    L.ref_extend_reads_scored.restype = C.c_int
+    if seed_score is not None:
+        seed_score = np.ascontiguousarray(seed_score, dtype=np.int32)
+    rc = L.ref_extend_reads_scored(p(reads), p(read_off), C.c_int64(read_off.shape[0] - 1), p(chain_off), p(chains), p(seed_off), p(seeds),
+                            p(seed_score) if seed_score is not None else C.c_void_p(0), p(frac_bits), p(text),
                             p(contig_off), p(contig_len), p(contig_alt), C.c_int(contig_off.shape[0]), C.c_int64(int(l_pac)), C.byref(opt), p(out))
     assert rc == 0, rc
     return out

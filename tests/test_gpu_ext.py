@@ -12,7 +12,7 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
-def _device_records(tmp_path, I, ext_opt=None, ascii=False):
+def _device_records(tmp_path, I, ext_opt=None, ascii=False, chain_opt=None):
     fa = str(tmp_path / "c.fa")
     synth.write_fasta(fa, I["genome"], name="cg", contigs=3)
     prefix = build_index(fa, bits=14)
@@ -30,7 +30,7 @@ def _device_records(tmp_path, I, ext_opt=None, ascii=False):
         else:
             ctx.seed_batch_resident(I["reads"], I["read_off"])
         contigs = [(int(o), int(l), 0) for o, l in zip(I["contig_off"], I["contig_len"])]
-        return ctx.extend_last_batch_host(contigs, hipapi.default_chain_opt(I["l_pac"]), ext_opt)
+        return ctx.extend_last_batch_host(contigs, chain_opt or hipapi.default_chain_opt(I["l_pac"]), ext_opt)
     finally:
         ctx.close()
 
@@ -78,6 +78,38 @@ def test_device_records_equal_oracle_with_other_options(tmp_path, w, clip, zdrop
                              I["contig_off"], I["contig_len"], oo)
     assert np.array_equal(R["reg_off"], I["seed_off"])
     _assert_same(R["regs"], want, want["frac_rep"].view(np.uint32))
+
+
+@pytest.mark.parametrize("W,penalties", [(5, None), (10, None), (20, None), (20, (2, 9, 3, 2, 5, 1))])
+def test_seed_filter_on_the_device_equals_oracle(tmp_path, W, penalties):
+    """mem_flt_chained_seeds (src/bwamem.cpp:565-598) between chaining and extension.  It runs where 1.1 W <= 0.05 x read length: for every
+    read of the batch under -W 5, for the 250-base and longer ones under -W 10, for the noisy 440-500-base reads (LEARNED_MAX_READ_LEN is
+    500) under -W 20, where seeds below the bar (22; 44 with match score 2) leave their chains; everywhere the seeds' scores -- the order
+    the seeds of a chain are extended in -- become alignment scores.  Records, their number per read and the filter's counters against the
+    oracle (pinned on the compiled reference's mem_flt_chained_seeds + extension in tests/test_ref_live.py)."""
+    from common import flt_workload
+    I = flt_workload(W, lo=420, hi=500)
+    co = hipapi.default_chain_opt(I["l_pac"])
+    co.min_chain_weight = W
+    eo, oo = hipapi.default_ext_opt(), O.default_ext_opt()
+    if penalties:
+        for o in (eo, oo):
+            o.a, o.b, o.o_del, o.e_del, o.o_ins, o.e_ins = penalties
+    R = _device_records(tmp_path, I, eo, chain_opt=co)
+    chains, soff, seeds, score, n_sw = O.flt_batch(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["text"], I["l_pac"],
+                                                   I["contig_off"], I["contig_len"], oo, W)
+    want, _ = O.extend_batch(I["reads"], I["read_off"], I["chain_off"], chains, soff, seeds, I["frac_rep"], I["text"], I["l_pac"], I["contig_off"], I["contig_len"],
+                             oo, seed_score=score)
+    assert np.array_equal(R["reg_off"], soff)
+    _assert_same(R["regs"], want, want["frac_rep"].view(np.uint32))
+    assert R["n_flt_jobs"] == n_sw > 500 and R["n_flt_dropped"] == int(I["seed_off"][-1] - soff[-1])
+    assert W < 20 or R["n_flt_dropped"] > 0
+
+
+def test_seed_filter_is_off_for_short_reads(tmp_path):
+    I = ext_golden_inputs()
+    R = _device_records(tmp_path, I)
+    assert R["n_flt_jobs"] == 0 and R["n_flt_dropped"] == 0
 
 
 def test_extend_call_needs_a_seeded_batch_and_the_right_genome(tmp_path):

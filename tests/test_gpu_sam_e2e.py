@@ -21,10 +21,12 @@ os.environ.setdefault("MEME_DROPIN_MATESW", "1")
 os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
 
 
-def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000):
-    cmd = [os.path.join(REF, exe), "mem", "-7", "-Y", "-K", str(chunk), "-t", str(threads), prefix] + fqs
+def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000, opts=(), stderr=None):
+    cmd = [os.path.join(REF, exe), "mem", "-7", "-Y", "-K", str(chunk), "-t", str(threads)] + list(opts) + [prefix] + fqs
     r = subprocess.run(cmd, capture_output=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
+    if stderr is not None:
+        stderr.append(r.stderr.decode())
     return [l for l in r.stdout.decode().split("\n") if not l.startswith("@PG")]
 
 
@@ -55,26 +57,22 @@ def test_sam_identical_to_reference(tmp_path, paired):
     want = _sam("bwa-meme_mode3", prefix, fqs)
     # chunk-level seeding + combined extension calls: the SAM must not depend on how many worker threads feed the
     # combiner, nor on the -K chunk size (several chunks per run, the last one ragged)
-    # The extension stage has two implementations in the binding: chunk-wide (default; here also with slabs of 1 000 reads
-    # whose staging starts too small and is rebuilt, and with every stage split in three backend calls as on three GPUs)
-    # and the reference's own per-batch function over the combiner (MEME_DROPIN_EXT=0).  MEME_DROPIN_VIRTUAL=3 runs the
+    # Chaining + seed filter + extension run on the device for the whole chunk (default); the cross-check is the reference's own
+    # per-batch function over the combiner (MEME_DROPIN_EXT=0).  MEME_DROPIN_VIRTUAL=3 runs the
     # multi-GPU arrangement (three device slots: reads of a chunk split three ways, index replicas, one extension call per slot)
     # on however many GPUs the box has.  Chaining runs on the device (mem_chain_Learned + mem_chain_flt) with
     # MEME_DROPIN_CHAIN_CHECK set: every read is also chained by the reference's host functions and any difference in any
     # chain or seed is fatal; MEME_DROPIN_CHAIN=0 keeps chaining on the host, MEME_DROPIN_IO=1 lets the binding parse the two
     # FASTQ files on two threads.
     small = {}
-    # Round 3: the DEFAULT is chaining + extension on the device (meme_extend_last_batch_host: the host only receives alignment records);
-    # MEME_DROPIN_EXT=host is the arrangement described above, kept for -W runs and as a cross-check.
+    # Round 3: the DEFAULT is chaining + extension on the device (meme_extend_last_batch_host: the host only receives alignment records).
     # Round 4: the device stages of chunk k+1 run beside the SAM phase of chunk k (prefetch; also switched off), and a backend that refuses
     # a batch for want of memory (MEME_DROPIN_MAX_BATCH: max_batch of the ctxs) is fed in pieces -- extension stage and CIGAR stage alike.
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}), (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
                                   (8, 400000, {"MEME_DROPIN_PREFETCH": "0"}), (8, 100000000, {"MEME_DROPIN_MAX_BATCH": "1500"}),
                                   (8, 400000, {"MEME_DROPIN_MAX_BATCH": "700", "MEME_DROPIN_VIRTUAL": "2"}),
-                                  (8, 100000000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_EXT_SLAB": "1000", "MEME_DROPIN_EXT_SPLIT": "3", "MEME_DROPIN_EXT_UNDERSIZE": "1"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
-                                  (8, 400000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_VIRTUAL": "3"}),
-                                  (4, 100000000, {"MEME_DROPIN_EXT": "host", "MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
+                                  (4, 100000000, {"MEME_DROPIN_EXT": "0", "MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
         env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", **extra)
         got = _sam("bwa-meme_dropin", prefix, fqs, env=env, threads=threads, chunk=chunk)
         if chunk == 100000000: ref = want
@@ -158,6 +156,45 @@ def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
     m = re.search(r"\((\d+) of them again with the doubled band\)", r.stderr.decode())
     assert m and int(m.group(1)) > 100, r.stderr.decode()[-1500:]
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_where_the_seed_filter_runs(tmp_path):
+    """mem_flt_chained_seeds (src/bwamem.cpp:565-598) is a no-op unless 1.1 x the -W chain weight floor <= 0.05 x read length -- never
+    without -W for reads the aligner takes (its reader keeps 301 bases of a longer read).  Here it is not: 150 / 250-base reads under
+    -W 5 and -W 10 and noisy long reads under -W 13 (also with 12-base seeds and other penalties).  In the aligner the function reads its
+    windows from the bit-reversed rc_pac (see flt_window_base in csrc/meme_kswv.hip), so the alignments score what unrelated sequences
+    score: above the bar of -W 5 (the seeds stay, with that score: the order they are extended in changes), below the others (seeds short
+    enough to be aligned leave their chains).  On the device by default -- the run reports the filter's alignments -- and through the
+    reference's own function (MEME_DROPIN_EXT=0) as the cross-check."""
+    import re
+    from common import long_noisy_reads
+    g = synth.make_genome(600_000, seed=61, repeat_frac=0.08, n_families=4, n_dups=6, dup_len=1500)
+    fa = str(tmp_path / "flt.fa")
+    synth.write_fasta(fa, g, contigs=3)
+    prefix = build_index(fa, bits=14)
+    long_fq, short_fq = str(tmp_path / "long.fq"), str(tmp_path / "short.fq")
+    with open(long_fq, "w") as fh:
+        for k, r in enumerate(long_noisy_reads(g, 1500, seed=62, lo=301, hi=420)):
+            fh.write("@L%d\n%s\n+\n%s\n" % (k, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    r150, _, _ = synth.make_reads(g, 2500, 150, seed=63, n_frac=0.02)
+    r250, _, _ = synth.make_reads(g, 1500, 250, seed=64, sub_rate=0.05, indel_rate=0.0075, n_frac=0.02)
+    with open(short_fq, "w") as fh:
+        for k, r in enumerate(list(r150) + list(r250)):
+            fh.write("@s%d\n%s\n+\n%s\n" % (k, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    for fq, opts, drops in ((short_fq, ("-W", "5"), None), (short_fq, ("-W", "10"), True), (long_fq, ("-W", "13", "-k", "12"), True),
+                            (long_fq, ("-W", "13", "-k", "12", "-A", "2", "-B", "7"), True)):
+        want = _sam("bwa-meme_mode3", prefix, [fq], threads=8, opts=opts)
+        for extra in ({}, {"MEME_DROPIN_EXT": "0"}):
+            err = []
+            got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", **extra), threads=8, opts=opts, stderr=err)
+            assert len(got) == len(want) and len(want) > 1500
+            diff = [(a, b) for a, b in zip(got, want) if a != b]
+            assert not diff, "%r %r: first differing SAM line:\n%s\n%s" % ((opts, extra) + diff[0])
+            if not extra:
+                m = re.search(r"seed filter \(mem_flt_chained_seeds\) on the device: (\d+) alignments, (\d+) chained seeds removed", err[0])
+                assert m and int(m.group(1)) > 1000 and (drops is None or (int(m.group(2)) > 0) == drops), (opts, err[0][-1500:])
 
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),

@@ -98,6 +98,44 @@ def test_ext_oracle_equals_reference_on_other_options(w, clip, zdrop):
 
 
 @needs_stage
+@pytest.mark.parametrize("W,penalties,span", [(0, None, (800, 1300)), (5, None, (800, 1300)), (10, None, (800, 1300)), (0, (2, 9, 3, 2, 5, 1), (800, 1300)),
+                                              (20, None, (420, 500)), (20, (2, 9, 3, 2, 5, 1), (420, 500))])
+def test_seed_filter_oracle_equals_reference(W, penalties, span):
+    """orc_flt_batch == the compiled reference's mem_flt_chained_seeds (mem_seed_sw -> ksw_align2 -> ksw_i16) on long noisy reads (the
+    filter runs without -W for reads the function takes although the learned-index path stops at 500 bases), on 150 / 250-base reads under
+    -W 5 / -W 10 (at 10 it runs for the 250-base reads of the batch only) and on 420-500-base reads under -W 20 (the GPU tests' workload);
+    then the extension with the scores the filter leaves, oracle against reference.  Other penalties: match 2, mismatch 9, asymmetric gaps."""
+    from common import flt_workload
+    I = flt_workload(W, lo=span[0], hi=span[1])
+    opt = O.default_ext_opt()
+    if penalties:
+        opt.a, opt.b, opt.o_del, opt.e_del, opt.o_ins, opt.e_ins = penalties
+    alt = np.zeros(I["contig_off"].shape[0], np.uint8)
+    want = ref_py.flt_chained_seeds(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["text"], I["l_pac"], I["contig_off"],
+                                    I["contig_len"], alt, opt, W)
+    got = O.flt_batch(I["reads"], I["read_off"], I["chain_off"], I["chains"], I["seed_off"], I["seeds"], I["text"], I["l_pac"], I["contig_off"], I["contig_len"],
+                      opt, W)
+    assert got[4] > 500                                            # alignments run
+    assert np.array_equal(got[1], want[1])
+    assert W in (5, 10) or 0 < int(got[1][-1]) < int(I["seed_off"][-1])  # some seeds left their chains (under -W 5 / 10 the bar is 5 / 11: below any seed's own score)
+    for f in ("seed_beg", "n_seeds"):
+        assert np.array_equal(got[0][f], want[0][f]), f
+    for f in ("rbeg", "qbeg", "len"):
+        assert np.array_equal(got[2][f], want[2][f]), f
+    assert np.array_equal(got[3], want[3])
+    # (the windows the aligner's call reads are scrambled -- see orc_seed_sw -- so an alignment scores what two unrelated sequences score:
+    # above the bar of -W 5 / 10, where such a seed stays with that score, below the others, where it leaves)
+    assert W not in (5, 10) or (got[3] != got[2]["len"] * opt.a).any()
+    r_want = ref_py.extend_reads(I["reads"], I["read_off"], I["chain_off"], want[0], want[1], want[2], I["frac_rep"], I["text"], I["l_pac"], I["contig_off"],
+                                 I["contig_len"], alt, opt, seed_score=want[3])
+    r_got, _ = O.extend_batch(I["reads"], I["read_off"], I["chain_off"], got[0], got[1], got[2], I["frac_rep"], I["text"], I["l_pac"], I["contig_off"],
+                              I["contig_len"], opt, seed_score=got[3])
+    for f in O.ALNREG_FIELDS:
+        bad = np.nonzero(r_got[f] != r_want[f])[0]
+        assert bad.size == 0, (f, int(bad[0]), int(r_got[f][bad[0]]), int(r_want[f][bad[0]]))
+
+
+@needs_stage
 def test_ksw_global2_oracle_equals_reference_on_other_penalties():
     """orc_ksw_global2 == the compiled reference's ksw_global2 with other scores (asymmetric gap penalties, cheap gaps: the case the
     reference's comment warns about, insertion next to deletion) on a sample of the fixture's alignments."""
