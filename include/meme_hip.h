@@ -229,8 +229,11 @@ int meme_chain_batch_host(meme_ctx* ctx, const meme_mem_tl* smems, const int64_t
  * doubled once where the reference doubles it (MAX_BAND_TRY 2), records of seeds an earlier alignment already covers marked qb = qe = -1
  * (:3389-3485).  regs[reg_off[r] .. reg_off[r+1]) = what the reference leaves in av_v[r] (n = m = the number of chained seeds).
  * meme_alnreg = mem_alnreg_t (src/bwamem.h:143-165, 112 bytes); its `c` (a chain pointer in the reference, dead after the stage)
- * holds the chain's index in the batch.  Reads are at most 500 bases here, so mem_flt_chained_seeds (src/bwamem.cpp:565-598) between
- * the two stages is the no-op it is in the reference; callers that set min_chain_weight must run that filter themselves. */
+ * holds the chain's index in the batch.  Between the two stages runs mem_flt_chained_seeds (src/bwamem.cpp:565-598) -- a no-op for reads
+ * of at most 500 bases unless chain_opt->min_chain_weight (-W) is set; then, for reads of 22 x W bases and more, chained seeds whose
+ * neighbourhood aligns below the bar (mem_seed_sw, :494-520) leave their chains and the others are extended in the order of those scores.
+ * The alignment reads its windows as the aligner's call does: from the byte-reversed fwd + rc text through the plain _get_pac
+ * (src/bwamem.cpp:1770, src/fastmap.cpp:440-457, src/bntseq.cpp:515-539) -- the bases of every aligned group of four in reverse order. */
 typedef struct {
     int64_t rb, re; int32_t qb, qe; int32_t rid; int32_t pad0; uint64_t c;
     int32_t score, truesc, sub, alt_sc, csub, sub_n, w, seedcov, secondary, secondary_all, seedlen0;
