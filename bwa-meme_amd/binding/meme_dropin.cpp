@@ -390,21 +390,23 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n, int slot) {
 }
 
 // ---- the next chunk ahead of its turn -------------------------------------------------------------------------------------------
-// The aligner's pipeline (kt_pipeline, two threads for read / process / write) reads chunk k+1 while chunk k is processed, and the GPUs
-// are idle for most of chunk k's SAM phase.  When the FASTQ reader hands chunk k+1 out, a helper thread takes it through the device
-// stages (gather, seeding, chaining, extension) on the other slot's ctxs; mem_process_seqs then finds its alignment records waiting.
-// Chunks alternate between the two slots: chunk k+2 is read only after chunk k has been written (the pipeline's two threads), so its
-// slot is free by then.  The helper and its state live until the process ends (no destructor runs against a waiting thread).
-// MEME_DROPIN_PREFETCH=0: off.
+// The aligner's pipeline (kt_pipeline, two threads for read / process / write) processes one chunk at a time, and the GPUs are idle for
+// most of a chunk's SAM phase.  The binding's FASTQ reader assembles chunk k+1 as soon as chunk k has been handed out and submits it
+// here; a helper thread takes the submitted chunks, in order, through the device stages (gather, seeding, chaining, seed filter,
+// extension) on the other slot's ctxs, and mem_process_seqs finds its chunk's alignment records waiting.  Chunk s lives in slot s & 1:
+// its device stages start when chunk s - 2 has left mem_process_seqs (whose CIGAR stage still names reads resident on that slot's ctxs),
+// i.e. they run beside the whole of chunk s - 1's host phases.  The helper and its state live until the process ends (no destructor
+// runs against a waiting thread).  MEME_DROPIN_PREFETCH=0: off.
 struct Prefetcher {
     std::mutex m;
     std::condition_variable cv;
-    bseq1_t* seqs = nullptr; int64_t n = 0; int slot = 0;      // the job
-    int state = 0;                                              // 0 idle, 1 submitted, 2 running, 3 done
+    struct Job { bseq1_t* seqs; int64_t n, seq; int state; };   // state: 1 queued, 2 running, 3 done
+    std::deque<Job> jobs;                                       // in chunk order
+    int64_t processed = -1;                                     // highest chunk number that has left mem_process_seqs
     const mem_opt_t* opt = nullptr;
     bool started = false;
 };
-Prefetcher* g_pf = nullptr;
+Prefetcher* g_pf = new Prefetcher;
 // Chunks are numbered where they are read (the binding's FASTQ reader calls prefetch_submit for every chunk, in order): chunk s lives in
 // slot s & 1, whoever seeds it.  Chunks from any other reader are not numbered: they take the slots in turn, and nothing runs ahead.
 std::mutex g_seq_mu;
@@ -415,43 +417,38 @@ int g_next_slot = 0;                    // slot of the next un-numbered chunk
 std::atomic<double> g_t_prefetched{0};
 bool prefetch_on() { static const bool v = !(getenv("MEME_DROPIN_PREFETCH") && atoi(getenv("MEME_DROPIN_PREFETCH")) == 0); return v; }
 
-// a chunk read before the run's options were known (the parser threads are ahead while the index loads: the second chunk is usually
-// read before the first one is processed): submitted again by mem_process_seqs once it has seeded its own chunk
-bseq1_t* g_late_seqs = nullptr; int64_t g_late_n = 0, g_late_seq = -1;
-void prefetch_start(bseq1_t* seqs, int64_t n, int64_t seq);
-
 void prefetch_submit(bseq1_t* seqs, int64_t n) {
     int64_t seq;
     {
         std::lock_guard<std::mutex> lk(g_seq_mu);
         seq = g_seq_next++; g_seq_tags[seq & 7] = {seqs, seq};
-        if (!g_pf || !g_opt) { if (seq == 1) { g_late_seqs = seqs; g_late_n = n; g_late_seq = seq; } return; }
     }
-    prefetch_start(seqs, n, seq);
-}
-
-void prefetch_start(bseq1_t* seqs, int64_t n, int64_t seq) {
-    if (!prefetch_on() || !g_pf || !g_ext_on_device || !g_opt || g_dev.empty()) return;      // (known after the first chunk has been processed)
     Prefetcher& F = *g_pf;
-    std::unique_lock<std::mutex> lk(F.m);
-    if (F.state != 0) return;                                   // a chunk is already ahead (or nobody took the last one): this one is seeded in its turn
-    // (slot seq & 1 is free: the pipeline reads chunk s only after chunk s - 2 has been written)
-    F.seqs = seqs; F.n = n; F.slot = (int)(seq & 1); F.state = 1;
-    if (!F.started) {
+    std::lock_guard<std::mutex> lk(F.m);
+    F.jobs.push_back({seqs, n, seq, 1});
+    if (!F.started && prefetch_on()) {
         F.started = true;
         std::thread([] {
             Prefetcher& F = *g_pf;
             for (;;) {
-                bseq1_t* seqs; int64_t n; int slot;
+                bseq1_t* seqs = nullptr; int64_t n = 0, seq = 0;
                 {
+                    // the first queued chunk, once the run's options are known (the first mem_process_seqs call) and its slot is free
                     std::unique_lock<std::mutex> lk(F.m);
-                    F.cv.wait(lk, [&] { return F.state == 1; });
-                    F.state = 2; seqs = F.seqs; n = F.n; slot = F.slot;
+                    F.cv.wait(lk, [&] {
+                        if (!F.opt || !g_ext_on_device || g_dev.empty()) return false;
+                        for (Prefetcher::Job& J : F.jobs)
+                            if (J.state == 1) { if (F.processed < J.seq - 2) return false; J.state = 2; seqs = J.seqs; n = J.n; seq = J.seq; return true; }
+                        return false;
+                    });
                 }
                 const double t0 = now_s();
-                seed_chunk(F.opt, seqs, n, slot);
+                seed_chunk(F.opt, seqs, n, (int)(seq & 1));
                 g_t_prefetched = g_t_prefetched + (now_s() - t0);
-                { std::lock_guard<std::mutex> lk(F.m); F.state = 3; }
+                {
+                    std::lock_guard<std::mutex> lk(F.m);
+                    for (Prefetcher::Job& J : F.jobs) if (J.seq == seq) J.state = 3;
+                }
                 F.cv.notify_all();
             }
         }).detach();
@@ -459,17 +456,24 @@ void prefetch_start(bseq1_t* seqs, int64_t n, int64_t seq) {
     F.cv.notify_all();
 }
 
-// true: chunk `seqs` has been through the device stages already (waits for the helper when it is still at it)
+// true: chunk `seqs` has been through the device stages already (waits for the helper when it is at it); false: it is the caller's to seed
 bool prefetch_take(bseq1_t* seqs, int64_t n, int* slot) {
-    if (!g_pf) return false;
     Prefetcher& F = *g_pf;
     std::unique_lock<std::mutex> lk(F.m);
-    if (F.state == 0) return false;
-    if (F.seqs != seqs || F.n != n) return false;               // a later chunk is ahead, in the other slot: this one is seeded now, in its own
-    F.cv.wait(lk, [&] { return F.state == 3; });
-    *slot = F.slot;
-    F.state = 0;
+    auto find = [&] { for (size_t i = 0; i < F.jobs.size(); ++i) if (F.jobs[i].seqs == seqs && F.jobs[i].n == n) return (int)i; return -1; };
+    int i = find();
+    if (i < 0) return false;
+    if (F.jobs[(size_t)i].state == 1) { F.jobs.erase(F.jobs.begin() + i); return false; }
+    F.cv.wait(lk, [&] { i = find(); return i >= 0 && F.jobs[(size_t)i].state == 3; });
+    *slot = (int)(F.jobs[(size_t)i].seq & 1);
+    F.jobs.erase(F.jobs.begin() + i);
     return true;
+}
+// chunk number `seq` has left mem_process_seqs: its slot may be seeded again
+void prefetch_processed(int64_t seq) {
+    Prefetcher& F = *g_pf;
+    { std::lock_guard<std::mutex> lk(F.m); if (seq > F.processed) F.processed = seq; }
+    F.cv.notify_all();
 }
 
 int g_team = 1;                        // kt_for worker threads of the run (opt->n_threads)
@@ -488,6 +492,8 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         next = (process_fn)dlsym(RTLD_NEXT, "_Z16mem_process_seqsP9mem_opt_tliP7bseq1_tPK12mem_pestat_tR8worker_t");
         if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_process_seqs was not found: %s\n", dlerror()); exit(1); }
     }
+    const double t_enter = now_s();
+    int64_t chunk_seq = -1;                                      // the chunk's number when it came from the binding's reader
     g_team = opt->n_threads > 0 ? opt->n_threads : 1;
     if (w.useLearned && !g_bns) {
         g_bns = w.fmi->idx->bns;
@@ -499,26 +505,24 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         g_worker = &w;
         g_opt = opt;
         ktfor_calls() = 0;
-        if (!g_pf) { g_pf = new Prefetcher; }
-        g_pf->opt = opt;
+        { std::lock_guard<std::mutex> lk(g_pf->m); g_pf->opt = opt; }
+        g_pf->cv.notify_all();                                   // (chunks submitted before the options were known may go ahead now)
         int slot = -1;
         {
             std::lock_guard<std::mutex> lk(g_seq_mu);
-            for (const SeqTag& t : g_seq_tags) if (t.seqs == seqs && t.seq >= g_seq_next - 8 && g_seq_next > 0) slot = (int)(t.seq & 1);
+            for (const SeqTag& t : g_seq_tags) if (t.seqs == seqs && t.seq >= g_seq_next - 8 && g_seq_next > 0) { slot = (int)(t.seq & 1); chunk_seq = t.seq; }
             if (slot >= 0) for (SeqTag& t : g_seq_tags) if (t.seqs == seqs) t.seqs = nullptr;      // (the array is freed and its address may come back)
         }
         if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
         else if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
         g_cur_chunk = &g_chunks[slot];
-        {   // the chunk that was read before the options were known goes ahead now, beside this chunk's host phases
-            bseq1_t* ls = nullptr; int64_t ln = 0, lq = -1;
-            { std::lock_guard<std::mutex> lk(g_seq_mu); ls = g_late_seqs; ln = g_late_n; lq = g_late_seq; g_late_seqs = nullptr; }
-            if (ls && ls != seqs) prefetch_start(ls, ln, lq);
-        }
         ++g_chunk_gen;
     }
+    const double t_body = now_s();
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
+    if (chunk_seq >= 0) prefetch_processed(chunk_seq);
+    if (verbose()) fprintf(stderr, "[meme-dropin] mem_process_seqs of this chunk: %.3f s until its device records were there, %.3f s in the reference's body\n", t_body - t_enter, now_s() - t_body);
     if (verbose() && (double)g_t_prefetched > 0) fprintf(stderr, "[meme-dropin] device stages run ahead of their chunk's turn (beside the previous chunk's SAM phase): %.3f s so far\n", (double)g_t_prefetched);
     if (verbose())
         fprintf(stderr, "[meme-dropin] totals: chunk-level device stages (gather + seeding + chaining + extension) %.3f s for %lld reads, of which the seeding calls %.3f s; bsw %lld calls, %lld pairs "

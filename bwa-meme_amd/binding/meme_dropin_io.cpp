@@ -111,6 +111,49 @@ typedef bseq1_t* (*bseq_read_fn)(int64_t, int*, void*, void*, int64_t*);
 
 }  // namespace dropin
 
+namespace dropin {
+// One chunk as bseq_read_orig (src/bwa.cpp:184-230) forms it: whole pairs until `chunk_size` bases are reached.
+bseq1_t* assemble_chunk(int64_t chunk_size, int64_t* n_, int64_t* size_) {
+    int64_t size = 0, m = 0, n = 0;
+    bseq1_t* seqs = 0;
+    bseq1_t a, b;
+    ArenaRef arena_store, *arena = fast_out() ? &arena_store : nullptr;
+    while (g_rq[0]->pop(a, arena)) {
+        if (g_rq[1] && !g_rq[1]->pop(b, arena)) {                   // the 2nd file has fewer reads (:190-193)
+            fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", "bseq_read_orig");
+            break;
+        }
+        if (n + 1 >= m) { m = m ? m << 1 : 256; seqs = (bseq1_t*)realloc(seqs, (size_t)m * sizeof(bseq1_t)); }
+        a.id = (int)n; seqs[n] = a; size += seqs[n++].l_seq;
+        if (g_rq[1]) { b.id = (int)n; seqs[n] = b; size += seqs[n++].l_seq; }
+        if (size >= chunk_size && (n & 1) == 0) break;
+    }
+    if (size == 0) {                                                // test if the 2nd file is finished (:223-226)
+        if (g_rq[1] && g_rq[1]->pop(b, nullptr)) { fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", "bseq_read_orig"); free(b.name); free(b.comment); free(b.seq); free(b.qual); }
+        for (int k = 0; k < 2; ++k)                                 // end of the input: the parsers finish before the caller destroys the streams
+            if (g_rq[k] && g_rq[k]->th.joinable()) {
+                while (g_rq[k]->pop(b, nullptr)) { free(b.name); free(b.comment); free(b.seq); free(b.qual); }
+                g_rq[k]->th.join();
+            }
+    }
+    *n_ = n; *size_ = size;
+    if (arena && seqs) { std::lock_guard<std::mutex> lk(g_arena_mu); g_arenas[seqs] = std::move(arena_store); }
+    if (n > 0) prefetch_submit(seqs, n);                            // the chunk's device stages may start as soon as its slot is free
+    return seqs;
+}
+
+// The NEXT chunk is formed as soon as the current one has been handed out (the pipeline asks for it only after it has written the chunk
+// before the current one): its device stages then have the whole of the current chunk's host phases to run beside, and the pipeline's
+// read step finds the record array ready.  The chunk size of a run is one number (aux->task_size, src/fastmap.cpp:743).
+struct Ahead {
+    std::mutex m; std::condition_variable cv;
+    std::thread th;
+    int64_t chunk_size = 0;
+    bool ready = false;
+    bseq1_t* seqs = nullptr; int64_t n = 0, size = 0;
+} g_ahead;
+}  // namespace dropin
+
 extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void* ks2_, int64_t* s) {
     static const bool on = !(getenv("MEME_DROPIN_IO") && atoi(getenv("MEME_DROPIN_IO")) == 0);
     static bseq_read_fn next = (bseq_read_fn)dlsym(RTLD_NEXT, "bseq_read_orig");
@@ -125,37 +168,36 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
             g_rq[k]->LIMIT = chunk_size > 1000000 ? chunk_size : 1000000;
             g_rq[k]->th = std::thread([k] { g_rq[k]->run(); });
         }
+        g_ahead.chunk_size = chunk_size;
+        g_ahead.th = std::thread([] {
+            Ahead& A = g_ahead;
+            for (;;) {
+                int64_t n = 0, size = 0;
+                bseq1_t* seqs = assemble_chunk(A.chunk_size, &n, &size);
+                std::unique_lock<std::mutex> lk(A.m);
+                A.seqs = seqs; A.n = n; A.size = size; A.ready = true;
+                A.cv.notify_all();
+                if (size == 0) return;                              // (the end of the input: handed out once, then the thread is joined)
+                A.cv.wait(lk, [&] { return !A.ready; });
+            }
+        });
     }
     if (!on || ks1_ != g_rq_ks[0] || ks2_ != g_rq_ks[1]) {
         if (!next) { fprintf(stderr, "[meme-dropin] the reference's bseq_read_orig was not found\n"); exit(1); }
         return next(chunk_size, n_, ks1_, ks2_, s);
     }
-    int64_t size = 0, m = 0, n = 0;
-    bseq1_t* seqs = 0;
-    bseq1_t a, b;
-    ArenaRef arena_store, *arena = fast_out() ? &arena_store : nullptr;
-    while (g_rq[0]->pop(a, arena)) {
-        if (g_rq[1] && !g_rq[1]->pop(b, arena)) {                   // the 2nd file has fewer reads (:190-193)
-            fprintf(stderr, "[W::%s] the 2nd file has fewer sequences.\n", __func__);
-            break;
-        }
-        if (n + 1 >= m) { m = m ? m << 1 : 256; seqs = (bseq1_t*)realloc(seqs, (size_t)m * sizeof(bseq1_t)); }
-        a.id = (int)n; seqs[n] = a; size += seqs[n++].l_seq;
-        if (g_rq[1]) { b.id = (int)n; seqs[n] = b; size += seqs[n++].l_seq; }
-        if (size >= chunk_size && (n & 1) == 0) break;
+    Ahead& A = g_ahead;
+    if (chunk_size != A.chunk_size) { fprintf(stderr, "[meme-dropin] bseq_read_orig: the chunk size changed during the run (%lld, was %lld)\n", (long long)chunk_size, (long long)A.chunk_size); exit(1); }
+    bseq1_t* seqs;
+    {
+        std::unique_lock<std::mutex> lk(A.m);
+        if (!A.th.joinable() && !A.ready) { *n_ = 0; *s = 0; return 0; }      // (asked again after the end of the input)
+        A.cv.wait(lk, [&] { return A.ready; });
+        seqs = A.seqs; *n_ = (int)A.n; *s = A.size;
+        A.ready = false;
+        A.cv.notify_all();
     }
-    if (size == 0) {                                                // test if the 2nd file is finished (:223-226)
-        if (g_rq[1] && g_rq[1]->pop(b, nullptr)) { fprintf(stderr, "[W::%s] the 1st file has fewer sequences.\n", __func__); free(b.name); free(b.comment); free(b.seq); free(b.qual); }
-        for (int k = 0; k < 2; ++k)                                 // end of the input: the parsers finish before the caller destroys the streams
-            if (g_rq[k] && g_rq[k]->th.joinable()) {
-                while (g_rq[k]->pop(b, nullptr)) { free(b.name); free(b.comment); free(b.seq); free(b.qual); }
-                g_rq[k]->th.join();
-            }
-    }
-    *n_ = (int)n;
-    *s = size;
-    if (arena && seqs) { std::lock_guard<std::mutex> lk(g_arena_mu); g_arenas[seqs] = std::move(arena_store); }
-    if (n > 0) prefetch_submit(seqs, n);                            // the chunk's device stages start now, beside the previous chunk's SAM phase
+    if (*s == 0 && A.th.joinable()) A.th.join();
     return seqs;
 }
 

@@ -480,6 +480,17 @@ typedef void (*kt_for_fn)(void (*)(void*, long, long, int), void*, int);
 void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
     static kt_for_fn next = (kt_for_fn)dlsym(RTLD_NEXT, "_Z6kt_forPFvPvlliES_i");
     if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_for was not found\n"); exit(1); }
+    // (verbose runs: where a chunk's time inside mem_process_seqs goes -- the three worker phases and what lies between them)
+    static double t_ph[8];
+    const int call = (g_chunk.seqs && data == (void*)g_worker) ? g_ktfor_calls.load() : -1;
+    struct Phase { int c; double* t; ~Phase() {
+        if (c < 0 || c > 2) return;
+        t[2 * c + 1] = now_s();
+        if (c == 2 && verbose())
+            fprintf(stderr, "[meme-dropin] phases of this chunk: worker_bwt %.3f s, worker_aln %.3f s, between them and worker_sam (mem_pestat, CIGAR pre-pass) %.3f s, worker_sam %.3f s (incl. pre-pass)\n",
+                    t[1] - t[0], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+    } } phase{call, t_ph};
+    if (call >= 0 && call <= 2) t_ph[2 * call] = now_s();
     if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2) {
         bool mate = false;
 #if __AVX512BW__          // (only this build of the reference batches mate rescue: src/bwamem.cpp:1838)
