@@ -22,11 +22,13 @@ using namespace dropin;
 namespace dropin {
 std::atomic<double> g_t_matesw{0};
 std::atomic<int64_t> g_n_matesw{0};
-bool matesw_on_device() { static const bool v = getenv("MEME_DROPIN_MATESW") && atoi(getenv("MEME_DROPIN_MATESW")) != 0; return v; }
-// One job per lane needs tens of thousands of jobs to fill the GPU (a chunk of 666 k reads poses ~31 k: 8 ms of kernel for what the host's
-// 64 threads do in about as long); below this many jobs per chunk the reference's own batch runs (the bigger chunks bwa-meme reads by
-// default -- 10 M bases x threads -- pose ~50 jobs per 1 000 reads: 200 k per chunk at -t 64).  MEME_DROPIN_MATESW_MIN overrides.
-int64_t matesw_min_jobs() { static const int64_t v = getenv("MEME_DROPIN_MATESW_MIN") ? atoll(getenv("MEME_DROPIN_MATESW_MIN")) : 65536; return v; }
+// On by default since round 4 (MEME_DROPIN_MATESW=0: the reference's own batches).  Round 3 measured the stage as a loss on a host that
+// was allocator-bound; with the allocator settled and the host's threads the scarce resource (the reference's kswv batches hold ~17 jobs
+// each: 45 thread-microseconds per job, 6 thread-seconds per 4 M reads) it wins: profiles/r04_mate_rescue_ab.md.
+bool matesw_on_device() { static const bool v = !(getenv("MEME_DROPIN_MATESW") && atoi(getenv("MEME_DROPIN_MATESW")) == 0); return v; }
+// One job per lane needs thousands of jobs to fill the GPU (a chunk of 666 k reads of 150 bases poses 22-31 k: 8 ms of kernel); below this
+// many jobs per chunk (250-base reads with 5 % errors pose under a thousand) the reference's own batch runs.  MEME_DROPIN_MATESW_MIN overrides.
+int64_t matesw_min_jobs() { static const int64_t v = getenv("MEME_DROPIN_MATESW_MIN") ? atoll(getenv("MEME_DROPIN_MATESW_MIN")) : 8192; return v; }
 double g_mate_jobs_per_read = -1;                // of the last chunk whose jobs were posed
 struct MateTable {
     std::vector<int64_t> off;                    // first record of every worker batch (+ the total)
