@@ -56,6 +56,18 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
     if (getenv("MEME_DROPIN_VIRTUAL") && atoi(getenv("MEME_DROPIN_VIRTUAL")) > n) n = atoi(getenv("MEME_DROPIN_VIRTUAL"));
     g_dev.resize((size_t)n);
     const double t0 = now_s();
+    // A thread that waits for the GPU sleeps instead of spinning (the HIP runtime's default for a lightly threaded process is to spin):
+    // the aligner's worker threads want every core the host gives the process -- and under a CPU quota (the boxes this was measured on
+    // give a process 16 CPUs' worth of a 256-thread machine) a spinning waiter is paid for with the workers' time.  The flag belongs to
+    // the device's primary context and has to be set before the first ctx creates it.  MEME_DROPIN_BLOCKING_SYNC=0: the runtime's default.
+    if (!(getenv("MEME_DROPIN_BLOCKING_SYNC") && atoi(getenv("MEME_DROPIN_BLOCKING_SYNC")) == 0)) {
+        typedef int (*set_dev_fn)(int);
+        typedef int (*set_flags_fn)(unsigned);
+        const set_dev_fn set_dev = (set_dev_fn)dlsym(RTLD_DEFAULT, "hipSetDevice");
+        const set_flags_fn set_flags = (set_flags_fn)dlsym(RTLD_DEFAULT, "hipSetDeviceFlags");
+        if (set_dev && set_flags)
+            for (int d = 0; d < n_real; ++d) if (set_dev(d) == 0) (void)set_flags(0x4u /* hipDeviceScheduleBlockingSync */);
+    }
     for (int d = 0; d < n; ++d) {
         if (!(g_dev[(size_t)d].seed = meme_ctx_create(d % n_real))) die("meme_ctx_create");
         if (!(g_dev[(size_t)d].bsw = meme_ctx_create(d % n_real))) die("meme_ctx_create");
@@ -386,7 +398,10 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n, int slot) {
     for (auto& t : th) t.join();
     g_t_seed = g_t_seed + (now_s() - t0);
     g_n_seed_reads += n;
-    if (verbose()) fprintf(stderr, "[meme-dropin] chunk of %lld reads seeded on %d GPU(s) in %.3f s\n", (long long)n, nd, now_s() - t0);
+    if (verbose()) {
+        timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        fprintf(stderr, "[meme-dropin] chunk of %lld reads seeded on %d GPU(s) in %.3f s (this thread's CPU so far %.2f s)\n", (long long)n, nd, now_s() - t0, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+    }
 }
 
 // ---- the next chunk ahead of its turn -------------------------------------------------------------------------------------------

@@ -275,6 +275,7 @@ int cig_threads() { const int m = omp_get_max_threads(); return m < 32 ? m : 32;
 
 void cig_prepass() {
     const double t0 = now_s();
+    double cpu0; { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); cpu0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     CigTable& T = g_cig;
     T.e.clear(); T.ops.clear(); T.idx.clear();
     const mem_opt_t* opt = g_opt;
@@ -425,8 +426,11 @@ void cig_prepass() {
     }
     __gnu_parallel::sort(T.idx.begin(), T.idx.end(), __gnu_parallel::default_parallel_tag((unsigned)cig_threads()));
     T.t_prepass += now_s() - t0;
-    if (verbose()) fprintf(stderr, "[meme-dropin] CIGAR pre-pass of this chunk %.3f s: candidates %.3f, jobs posed %.3f, backend calls %.3f, results taken %.3f, index %.3f\n", now_s() - t0,
-                           t_cand1 - t0, t_pose, t_call, t_take, now_s() - t_idx0);
+    if (verbose()) {
+        timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+        fprintf(stderr, "[meme-dropin] CIGAR pre-pass of this chunk %.3f s (process CPU %.2f s): candidates %.3f, jobs posed %.3f, backend calls %.3f, results taken %.3f, index %.3f\n", now_s() - t0,
+                (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec - cpu0, t_cand1 - t0, t_pose, t_call, t_take, now_s() - t_idx0);
+    }
 }
 
 typedef int (*ksw_global2_fn)(int, const uint8_t*, int, const uint8_t*, int, const int8_t*, int, int, int, int, int, int*, uint32_t**);
@@ -483,16 +487,18 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
     static kt_for_fn next = (kt_for_fn)dlsym(RTLD_NEXT, "_Z6kt_forPFvPvlliES_i");
     if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_for was not found\n"); exit(1); }
     // (verbose runs: where a chunk's time inside mem_process_seqs goes -- the three worker phases and what lies between them)
-    static double t_ph[8];
+    // (wall seconds and, in brackets, CPU seconds of the whole process -- helper threads of the binding included: what a host with a CPU quota is short of)
+    static double t_ph[8], c_ph[8];
     const int call = (g_chunk.seqs && data == (void*)g_worker) ? g_ktfor_calls.load() : -1;
-    struct Phase { int c; double* t; ~Phase() {
+    auto cpu_s = [] { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    struct Phase { int c; double *t, *u; double (*cpu)(); ~Phase() {
         if (c < 0 || c > 2) return;
-        t[2 * c + 1] = now_s();
+        t[2 * c + 1] = now_s(); u[2 * c + 1] = cpu();
         if (c == 2 && verbose())
-            fprintf(stderr, "[meme-dropin] phases of this chunk: worker_bwt %.3f s, worker_aln %.3f s, between them and worker_sam (mem_pestat, CIGAR pre-pass) %.3f s, worker_sam %.3f s (incl. pre-pass)\n",
-                    t[1] - t[0], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
-    } } phase{call, t_ph};
-    if (call >= 0 && call <= 2) t_ph[2 * call] = now_s();
+            fprintf(stderr, "[meme-dropin] phases of this chunk, wall (process CPU) s: worker_bwt %.3f (%.2f), worker_aln %.3f (%.2f), mem_pestat %.3f (%.2f), CIGAR + mate-rescue pre-passes and worker_sam %.3f (%.2f)\n",
+                    t[1] - t[0], u[1] - u[0], t[3] - t[2], u[3] - u[2], t[4] - t[3], u[4] - u[3], t[5] - t[4], u[5] - u[4]);
+    } } phase{call, t_ph, c_ph, +cpu_s};
+    if (call >= 0 && call <= 2) { t_ph[2 * call] = now_s(); c_ph[2 * call] = cpu_s(); }
     if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2) {
         bool mate = false;
 #if __AVX512BW__          // (only this build of the reference batches mate rescue: src/bwamem.cpp:1838)
