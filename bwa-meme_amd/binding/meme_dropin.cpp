@@ -75,12 +75,19 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         // for the lane-per-pair kernel much earlier than a lone caller's
         if (getenv("MEME_DROPIN_BSW_LANE_MIN")) meme_set_tuning(g_dev[(size_t)d].bsw, "bsw_lane_min_pairs", atoll(getenv("MEME_DROPIN_BSW_LANE_MIN")));
         if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));   // a memory bound (and the tests' way to the split-and-retry paths)
+        // the second slot's ctx (chunks alternate between two, see "the next chunk ahead of its turn"): created and given its buffers
+        // now, while the index loads -- its first chunk otherwise pays 0.25 s of allocations in the middle of the run
+        if (prefetch_on() && ext_mode() == 2) {
+            if (!(g_dev[(size_t)d].seed2 = meme_ctx_create(d % n_real))) die("meme_ctx_create");
+            if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed2, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));
+        }
     }
     // while the index streams in: the seeding / chaining buffers of a chunk on every device slot (pinned memory is slow to allocate)
     std::thread reserve([n, chunk_reads] {
         int64_t per = chunk_reads / n + BATCH_SIZE;
         if (per > (1 << 20)) per = 1 << 20;                  // beyond a million reads per device the buffers grow on first use
         for (int d = 0; d < n; ++d) if (meme_seed_reserve(g_dev[(size_t)d].seed, per, per * READ_LEN)) die("meme_seed_reserve");
+        for (int d = 0; d < n; ++d) if (g_dev[(size_t)d].seed2 && meme_seed_reserve(g_dev[(size_t)d].seed2, per, per * READ_LEN)) die("meme_seed_reserve");
     });
     if (meme_index_load_files(g_dev[0].seed, prefix)) die("meme_index_load_files");
     reserve.join();
@@ -89,6 +96,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
     for (int d = 1; d < n; ++d)                                 // device-to-device over xGMI, all replicas at once
         th.emplace_back([d] { if (meme_index_replicate(g_dev[(size_t)d].seed, g_dev[0].seed)) die("meme_index_replicate"); });
     for (auto& t : th) t.join();
+    for (int d = 0; d < n; ++d) if (g_dev[(size_t)d].seed2 && meme_index_share(g_dev[(size_t)d].seed2, g_dev[(size_t)d].seed)) die("meme_index_share");
     fprintf(stderr, "[meme-dropin] index staged in HBM in %.2f s, replicated to %d more GPU(s) in %.2f s\n", t1 - t0, n - 1,
             now_s() - t1);
 }

@@ -81,7 +81,8 @@ extern Chunk* g_cur_chunk;                     // the chunk mem_process_seqs is 
 void prefetch_submit(bseq1_t* seqs, int64_t n);      // (called by the binding's FASTQ reader: chunks get their sequence number there)
 extern const bntseq_t* g_bns;                  // of the run (set by mem_process_seqs)
 extern std::vector<meme_contig> g_contigs;
-int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 1 host, 0 the reference's per-batch function
+int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 0 the reference's per-batch functions (the cross-check)
+bool prefetch_on();                            // MEME_DROPIN_PREFETCH: chunks go through the device stages ahead of their turn
 extern bool g_ext_on_device;
 extern int g_team;                             // kt_for worker threads of the run (opt->n_threads)
 extern worker_t* g_worker;                     // of the chunk being processed
