@@ -151,7 +151,8 @@ struct Ahead {
     int64_t chunk_size = 0;
     bool ready = false;
     bseq1_t* seqs = nullptr; int64_t n = 0, size = 0;
-} g_ahead;
+};
+Ahead& g_ahead = *new Ahead;        // (on the heap for good: a run that stops early must not meet a joinable thread's destructor)
 }  // namespace dropin
 
 extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void* ks2_, int64_t* s) {

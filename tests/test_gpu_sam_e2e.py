@@ -82,6 +82,10 @@ def test_sam_identical_to_reference(tmp_path, paired):
         assert len(got) == len(ref) and len(ref) > n
         diff = [(a, b) for a, b in zip(got, ref) if a != b]
         assert not diff, "threads=%d chunk=%d %r, first differing SAM line:\n%s\n%s" % ((threads, chunk, extra) + diff[0])
+    # a value of MEME_DROPIN_EXT that no longer exists (the host-side extension stage of rounds 2-3) stops the run before the index loads
+    r = subprocess.run([os.path.join(REF, "bwa-meme_dropin"), "mem", "-7", "-t", "2", prefix] + fqs, capture_output=True,
+                       env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_EXT="host"), timeout=300)
+    assert r.returncode == 1 and b"the values are device and 0" in r.stderr, r.stderr.decode()[-500:]
 
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
