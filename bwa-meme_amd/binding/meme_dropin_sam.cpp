@@ -479,6 +479,78 @@ void meme_dropin_report_cigar() {
             (long long)g_cig.n_jobs, g_cig.t_kernel_ms * 1e-3, g_cig.t_prepass, (long long)g_cig_hits.load(), (long long)g_cig_miss.load());
 }
 
+// ---- insert-size statistics: mem_pestat (src/bwamem_pair.cpp:81-148) ------------------------------------------------------------------
+// Between worker_aln and worker_sam the reference walks the alignment records of every pair of the chunk in ONE thread -- 667 k scattered
+// heap records, a cache miss each -- collects the insert sizes of the uniquely aligned pairs and sorts them: 0.03-0.045 s of a chunk's
+// 0.19 s with every other thread idle.  The binding decides in parallel which pairs the function would take (its four `continue` tests,
+// :96-99, with cal_sub :67-79) and hands the reference's own function a compact stand-in array: per such pair two one-record vectors with
+// the pair's rid / rb (one record: cal_sub returns the floor and the score is set above it, so every stand-in passes the tests the
+// pre-pass has already applied), ordered by orientation and insert size so that the function's sort meets sorted input.  What it then
+// computes -- the `is <= max_ins` test, the sort, percentiles, mean, standard deviation, bounds, its messages -- is its own code on the
+// same multiset of insert sizes.  MEME_DROPIN_PESTAT=0: the reference's walk.
+namespace dropin {
+bool pestat_fast() { static const bool v = !(getenv("MEME_DROPIN_PESTAT") && atoi(getenv("MEME_DROPIN_PESTAT")) == 0); return v; }
+inline int pestat_cal_sub(const mem_opt_t* opt, const mem_alnreg_v* r) {          // cal_sub, :67-79
+    int j;
+    for (j = 1; j < (int)r->n; ++j) {
+        const int b_max = r->a[j].qb > r->a[0].qb ? r->a[j].qb : r->a[0].qb;
+        const int e_min = r->a[j].qe < r->a[0].qe ? r->a[j].qe : r->a[0].qe;
+        if (e_min > b_max) {
+            const int min_l = r->a[j].qe - r->a[j].qb < r->a[0].qe - r->a[0].qb ? r->a[j].qe - r->a[j].qb : r->a[0].qe - r->a[0].qb;
+            if (e_min - b_max >= min_l * opt->mask_level) break;
+        }
+    }
+    return j < (int)r->n ? r->a[j].score : opt->min_seed_len * opt->a;
+}
+typedef void (*pestat_fn)(const mem_opt_t*, int64_t, int, const mem_alnreg_v*, mem_pestat_t*);
+}  // namespace dropin
+void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* regs, mem_pestat_t pes[4]) {
+    static pestat_fn next = (pestat_fn)dlsym(RTLD_NEXT, "_Z10mem_pestatPK9mem_opt_tliPK12mem_alnreg_vP12mem_pestat_t");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_pestat was not found\n"); exit(1); }
+    const int np = n >> 1;
+    if (!pestat_fast() || np < 64) { next(opt, l_pac, n, regs, pes); return; }
+    struct Key { uint64_t k; int32_t i; };                       // (orientation << 60 | insert size, pair): the order of the stand-ins
+    const int nt = cig_threads();
+    std::vector<std::vector<Key>> part((size_t)nt);
+#pragma omp parallel num_threads(nt)
+    {
+        std::vector<Key>& mine = part[(size_t)omp_get_thread_num()];
+#pragma omp for schedule(static)
+        for (int i = 0; i < np; ++i) {
+            const mem_alnreg_v* r0 = &regs[i << 1 | 0];
+            const mem_alnreg_v* r1 = &regs[i << 1 | 1];
+            if (r0->n == 0 || r1->n == 0) continue;                                       // :96
+            if (pestat_cal_sub(opt, r0) > 0.8 * r0->a[0].score) continue;                 // :97 (MIN_RATIO, :49)
+            if (pestat_cal_sub(opt, r1) > 0.8 * r1->a[0].score) continue;                 // :98
+            if (r0->a[0].rid != r1->a[0].rid) continue;                                   // :99
+            // (only the order below depends on these two: mem_infer_dir, :58-65)
+            const int64_t b1 = r0->a[0].rb, b2 = r1->a[0].rb;
+            const int s1 = b1 >= l_pac, s2 = b2 >= l_pac;
+            const int64_t p2 = s1 == s2 ? b2 : (l_pac << 1) - 1 - b2;
+            const uint64_t dist = (uint64_t)(p2 > b1 ? p2 - b1 : b1 - p2);
+            const int dir = (s1 == s2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+            mine.push_back({(uint64_t)dir << 60 | (dist & ((1ull << 60) - 1)), i});
+        }
+    }
+    std::vector<Key> keys;
+    { size_t tot = 0; for (auto& v : part) tot += v.size(); keys.reserve(tot); for (auto& v : part) keys.insert(keys.end(), v.begin(), v.end()); }
+    __gnu_parallel::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.k < y.k; }, __gnu_parallel::default_parallel_tag((unsigned)nt));
+    const int64_t m = (int64_t)keys.size();
+    mem_alnreg_t* a = (mem_alnreg_t*)malloc((size_t)(2 * m + 1) * sizeof(mem_alnreg_t));
+    mem_alnreg_v* v = (mem_alnreg_v*)malloc((size_t)(2 * m + 1) * sizeof(mem_alnreg_v));
+    if (!a || !v) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t k = 0; k < m; ++k)
+        for (int e = 0; e < 2; ++e) {
+            const mem_alnreg_t& src = regs[keys[(size_t)k].i << 1 | e].a[0];
+            mem_alnreg_t& d = a[2 * k + e];
+            d.rb = src.rb; d.rid = src.rid; d.score = 1 << 28;
+            v[2 * k + e].n = v[2 * k + e].m = 1; v[2 * k + e].a = &d;
+        }
+    next(opt, l_pac, (int)(2 * m), v, pes);
+    free(a); free(v);
+}
+
 // kt_for (src/kthread.cpp:79-114) is called three times per chunk by mem_process_seqs: worker_bwt, worker_aln, worker_sam.  Before the
 // third call every alignment record of the chunk exists and no worker thread is running: the CIGAR stage's quiescent point.
 namespace dropin { std::atomic<int> g_ktfor_calls{0}; std::atomic<int>& ktfor_calls() { return g_ktfor_calls; } }
