@@ -578,12 +578,20 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
 #endif
         // (a chunk that will not reach the job threshold -- by the previous chunk's jobs per read -- is not posed at all)
         if (mate && g_mate_jobs_per_read >= 0 && g_mate_jobs_per_read * (double)g_chunk.n < (double)matesw_min_jobs()) mate = false;
+        // The two pre-passes side by side (they read the same alignment records, write tables of their own and use different ctxs): while
+        // one waits for its kernels the other poses its jobs -- host time that nobody used.  MEME_DROPIN_PREPASS_OVERLAP=0: one after the other.
+        static const bool overlap = !(getenv("MEME_DROPIN_PREPASS_OVERLAP") && atoi(getenv("MEME_DROPIN_PREPASS_OVERLAP")) == 0);
+        bool mate_ok = false;
+        std::thread mate_th;
+        if (mate && overlap && cigar_on_device()) mate_th = std::thread([&mate_ok] { mate_ok = matesw_prepass(); });
         if (cigar_on_device()) {
             std::lock_guard<std::mutex> lk(g_cig.mu);
             cig_prepass();
             g_cig.gen = g_chunk_gen;
         }
-        if (mate && matesw_prepass()) {
+        if (mate_th.joinable()) mate_th.join();
+        else if (mate) mate_ok = matesw_prepass();
+        if (mate_ok) {
             next(sam_worker_dev, data, n);
             return;
         }

@@ -65,6 +65,16 @@ def test_sam_identical_512mbp_paired(tmp_path):
         if os.environ.get("MEME_TEST_FMI_512") == "1":
             import time
             t0 = time.time()
+            with open(prefix, "wb") as fh:                      # the genome as FASTA, the eight sequences the index above was written with
+                alpha = np.frombuffer(b"ACGT", np.uint8)
+                for c in range(8):
+                    lo, hi = l_pac * c // 8, l_pac * (c + 1) // 8
+                    seq = alpha[g[lo:hi]]
+                    fh.write(b">chrS%d\n" % (c + 1))
+                    rows = seq.shape[0] // 80
+                    np.concatenate([seq[:rows * 80].reshape(rows, 80), np.full((rows, 1), 10, np.uint8)], axis=1).tofile(fh)
+                    if seq.shape[0] > rows * 80:
+                        fh.write(seq[rows * 80:].tobytes() + b"\n")
             r = subprocess.run([os.path.join(R.REF_DIR, "bwa-meme_mode3"), "index", "-a", "mem2", prefix], capture_output=True, timeout=3000)
             assert r.returncode == 0, r.stderr.decode()[-2000:]
             print("[fmi-512] `index -a mem2` of the 512 Mbp genome: %.0f s" % (time.time() - t0))
