@@ -175,11 +175,12 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     }
     // forward + reverse-complement 2-bit text in the byte order the reference's seeding code uses (src/fastmap.cpp:441-457).
     // The reference hands this array -- not idx->pac -- to mem_flt_chained_seeds (src/bwamem.cpp:1407, 1768), so the
-    // binding has to provide the very same bytes for the SAM output to be identical.
+    // binding has to provide the very same bytes for the SAM output to be identical.  Only the cross-check mode calls that function on the
+    // host (MEME_DROPIN_EXT=0); with the seed filter on the device nothing reads the array, and its 0.4 s at GRCh38 size are saved.
     const int64_t l_pac = aux->fmi->idx->bns->l_pac;
-    const int64_t ll_pac = (l_pac * 2 + 3) / 4 * 4;
-    w.rc_pac = (uint8_t*)malloc((size_t)(ll_pac / 4));
-    if (!w.rc_pac) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
+    const int64_t ll_pac = ext_mode() == 0 ? (l_pac * 2 + 3) / 4 * 4 : 0;
+    w.rc_pac = ll_pac ? (uint8_t*)malloc((size_t)(ll_pac / 4)) : nullptr;                    // (process() frees it, src/fastmap.cpp:1109)
+    if (ll_pac && !w.rc_pac) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
     const uint8_t* pac = aux->fmi->idx->pac;
 #pragma omp parallel for schedule(static)
     for (int64_t k = 0; k < ll_pac / 4; ++k) {
