@@ -53,6 +53,21 @@ BSW_VALU_PER_CELL = 24.3     # measured: profiles/r03_bsw.md (SQ_INSTS_VALU x 64
 T_START = time.time()
 
 
+def host_cpu_quota():
+    """CPUs' worth of time the cgroup gives this process (cpu.max = "<quota> <period>" in cgroup v2; cfs_quota_us / cfs_period_us in v1); None: unlimited or unknown."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def log(msg):
     print("[bench r%s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
 
@@ -937,6 +952,11 @@ def main():
                 cpu = port
             else:
                 cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
+        if cpu is not None:
+            # what the host gives this process: the hardware threads it may run on and, where a cgroup limits it, the CPUs' worth of time it
+            # gets (the boxes this was developed on: 256 threads visible, 16 by quota) -- every host-side figure of this line runs against that
+            cpu["host_threads_visible"] = os.cpu_count() or 1
+            cpu["host_cpu_quota"] = host_cpu_quota()
         out["cpu_baseline"] = cpu
         if single and os.environ.get("MEME_BENCH_BSW", "1") != "0":
             try:
