@@ -176,7 +176,9 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     // forward + reverse-complement 2-bit text in the byte order the reference's seeding code uses (src/fastmap.cpp:441-457).
     // The reference hands this array -- not idx->pac -- to mem_flt_chained_seeds (src/bwamem.cpp:1407, 1768), so the
     // binding has to provide the very same bytes for the SAM output to be identical.  Only the cross-check mode calls that function on the
-    // host (MEME_DROPIN_EXT=0); with the seed filter on the device nothing reads the array, and its 0.4 s at GRCh38 size are saved.
+    // host (MEME_DROPIN_EXT=0); with the seed filter on the device nothing reads the array and it is not built.  At GRCh38 size that is 0.38 s
+    // less host work in this function (0.49 -> 0.11 s) but no wall time: the function then waits that much longer for the index stream to
+    // HBM (0.63 -> 1.08 s), which is the critical path of the start-up (profiles/r04_e2e_dropin_c/_d.stderr).
     const int64_t l_pac = aux->fmi->idx->bns->l_pac;
     const int64_t ll_pac = ext_mode() == 0 ? (l_pac * 2 + 3) / 4 * 4 : 0;
     w.rc_pac = ll_pac ? (uint8_t*)malloc((size_t)(ll_pac / 4)) : nullptr;                    // (process() frees it, src/fastmap.cpp:1109)
