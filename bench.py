@@ -514,7 +514,11 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
             del r
         out = {}
         ckey = "e2e_reference_%d_t%d" % (npairs, threads)
-        cached = refcache.get(ckey) if (refcache is not None and devices > 1) else None
+        # (an N=1 run times the reference itself -- its line must not lean on another run's baseline -- unless a probe that launches the
+        # bound aligner several times on one box asks for the entry explicitly: MEME_BENCH_E2E_REUSE_REF=1, scripts/startup_probe.sh; the
+        # object then says "cached")
+        reuse = devices > 1 or os.environ.get("MEME_BENCH_E2E_REUSE_REF") == "1"
+        cached = refcache.get(ckey) if (refcache is not None and reuse) else None
         for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
             if exe == "bwa-meme_mode3" and cached:
                 out[exe] = dict(cached, cached="timed by the N=1 run on this box")

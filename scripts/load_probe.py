@@ -7,8 +7,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "bwa-meme_amd"))
 if len(sys.argv) > 2 and sys.argv[1] == "--load":
     from pymeme import hipapi
+    # PROBE_BLOCKING=1: the device's waits sleep instead of spinning (hipDeviceScheduleBlockingSync, what the binding sets before its
+    # first ctx: INTEGRATION 2e) -- the loader waits on the GPU a few times per 16 MB piece
+    if os.environ.get("PROBE_BLOCKING") == "1":
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        print("[load probe] hipSetDevice %d, hipSetDeviceFlags(blocking) %d" % (hip.hipSetDevice(0), hip.hipSetDeviceFlags(ctypes.c_uint(4))), flush=True)
     ctx = hipapi.Context(0)
-    t0 = time.time(); ctx.load_index_files(sys.argv[2]); print("[load probe] threads %s: %.2f s" % (os.environ.get("MEME_LOAD_THREADS", "default"), time.time() - t0), flush=True)
+    t0 = time.time(); ctx.load_index_files(sys.argv[2]); print("[load probe] threads %s, blocking waits %s: %.2f s" % (os.environ.get("MEME_LOAD_THREADS", "default"), os.environ.get("PROBE_BLOCKING", "0"), time.time() - t0), flush=True)
     sys.exit(0)
 import numpy as np, torch
 from pymeme import hipapi, hostapi, synth
@@ -30,6 +36,8 @@ prefix = "/dev/shm/loadprobe/ref.fa"
 hostapi.write_index(prefix, g, text, sa, l1, l2, n_contigs=4)
 total = sum(os.path.getsize(prefix + e) for e in (".0123", ".pos_packed", ".suffixarray_uint64_L1_PARAMETERS", ".suffixarray_uint64_L2_PARAMETERS"))
 print("[load probe] %.1f GB of index files" % (total / 1e9), flush=True)
-for thr in ("8", "8"):
-    subprocess.run([sys.executable, __file__, "--load", prefix], env=dict(os.environ, MEME_LOAD_THREADS=thr, MEME_LOAD_TRACE="1"))
+for blocking in os.environ.get("PROBE_SEQUENCE", "0,1,0,1,0,1").split(","):
+    env = dict(os.environ, PROBE_BLOCKING=blocking)
+    if os.environ.get("PROBE_TRACE"): env["MEME_LOAD_TRACE"] = "1"
+    subprocess.run([sys.executable, __file__, "--load", prefix], env=env)
 import shutil; shutil.rmtree("/dev/shm/loadprobe")
