@@ -247,6 +247,9 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
     copt = hipapi.default_chain_opt(l_pac)
     R = ctx.extend_last_batch_host(contigs, copt)
     R = ctx.extend_last_batch_host(contigs, copt)          # (second call: buffers exist)
+    ctx.set_tuning("ext_census", 1)                        # (a third, untimed call: how many of the jobs a closed form could answer)
+    census = ctx.extend_last_batch_host(contigs, copt)["n_exact_prefix"]
+    ctx.set_tuning("ext_census", 0)
     ch = ctx.chain_last_batch_host(contigs, copt)
     text = hipapi.fwd_rc_text(genome)
     want, (jobs, retried) = oracle_py.extend_batch(reads[:n].reshape(-1), off, ch["chain_off"], oracle_py.chains_as_orc(ch["chains"]), ch["seed_off"],
@@ -255,7 +258,8 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
     same = np.array_equal(R["reg_off"], ch["seed_off"]) and all(np.array_equal(R["regs"][f].astype(np.int64), want[f].astype(np.int64)) for f in oracle_py.ALNREG_FIELDS)
     out = {"metric": "extend_reads_per_sec", "value": n / ((R["chain_ms"] + R["ext_ms"]) * 1e-3) if same else None, "unit": "reads/s", "reads": n,
            "chain_ms": R["chain_ms"], "ext_ms": R["ext_ms"], "bsw_ms": R["bsw_ms"], "alignment_records": int(R["regs"].shape[0]), "extension_jobs": R["n_pairs"],
-           "jobs_with_doubled_band": R["n_retried"], "reads_in_wavefront_tiers": R["n_tier2"], "matches_oracle": bool(same), "checked_records": int(want.shape[0])}
+           "jobs_with_doubled_band": R["n_retried"], "reads_in_wavefront_tiers": R["n_tier2"], "matches_oracle": bool(same), "checked_records": int(want.shape[0]),
+           "exact_prefix_jobs": int(census), "exact_prefix_share": census / max(R["n_pairs"] - R["n_retried"], 1)}
     # CIGAR kernel: the global alignment mem_reg2aln would pose for every read's best live record (band as bwa_gen_cigar2 sets it for w_ = 100)
     regs, ro = R["regs"], R["reg_off"]
     rid = np.repeat(np.arange(n), np.diff(ro))
@@ -481,50 +485,52 @@ REF_BEST_THREADS = int(os.environ.get("MEME_BENCH_REF_THREADS", "64"))
 MALLOC_TUNABLES = "glibc.malloc.tcache_count=4000:glibc.malloc.trim_threshold=1073741824:glibc.malloc.top_pad=67108864:glibc.malloc.mmap_threshold=33554432"
 
 
-def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
-    """BASELINE.json's end-to-end metric: `mem -7` on paired-end 150-bp reads through the reference aligner with the HIP
+def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=READ_LEN, sub=0.01, indel=0.0, seed=5):
+    """BASELINE.json's end-to-end metric: `mem -7` on paired-end reads through the reference aligner with the HIP
     backend bound in (oracle/_ref/bwa-meme_dropin = reference main + reference objects + bwa-meme_amd/binding) and
     through the unmodified reference (oracle/_ref/bwa-meme_mode3, AVX-512) on the same host cores, same index files,
     same FASTQ; SAM files compared by md5 (minus @PG).  Walls include index loading; `process_s` sums the reference's own
-    per-chunk "Processed N reads in X real sec" lines (seeding + chaining + extension + SAM formation, no I/O)."""
+    per-chunk "Processed N reads in X real sec" lines (seeding + chaining + extension + SAM formation, no I/O).
+    Defaults: BASELINE configs[2]'s reads (150 bp, 1 % substitutions); configs[4]'s class passes read_len 250, sub 0.05, indel 0.0075."""
     import re
     ref_dir = os.path.join(REPO, "oracle", "_ref")
-    for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+    # (a probe may name several builds of the bound aligner, e.g. "bwa-meme_dropin,bwa-meme_dropin_prof" -- the second with SAM-phase timers:
+    # the first is the one reported, the others land under "extra_runs")
+    dropin_exes = os.environ.get("MEME_BENCH_E2E_DROPIN_EXE", "bwa-meme_dropin").split(",")
+    dropin_exe = dropin_exes[0]
+    skip_ref = os.environ.get("MEME_BENCH_E2E_SKIP_REF") == "1"                       # probes of the bound aligner alone: sam_identical is then null
+    for exe in ("bwa-meme_mode3", dropin_exe):
         if not os.path.exists(os.path.join(ref_dir, exe)):
             raise RuntimeError("%s not built" % exe)
     d = tempfile.mkdtemp(prefix="meme_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
-        rng = np.random.default_rng(5)
-        pos = rng.integers(0, genome.shape[0] - 700, size=npairs)
-        ins = rng.integers(300, 500, size=npairs)
-        ar = np.arange(READ_LEN)
-
-        def mut(x):
-            sub = rng.random(x.shape) < 0.01
-            return np.where(sub, (x + rng.integers(1, 4, size=x.shape, dtype=np.uint8)) & 3, x).astype(np.uint8)
-        fqs = []
-        for k in range(2):
-            if k == 0:
-                r = mut(genome[pos[:, None] + ar[None, :]])
-            else:
-                r = mut(3 - genome[(pos + ins - READ_LEN)[:, None] + ar[None, :]][:, ::-1])
-            f = os.path.join(d, "r%d.fq" % (k + 1))
-            workload.write_fastq_fast(f, r, prefix="p")
-            fqs.append(f)
-            del r
+        rng = np.random.default_rng(seed)
+        fqs = [os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")]
+        t_gen = time.time()
+        step = 1 << 20
+        for p0 in range(0, npairs, step):                        # pairs are sampled and written a million at a time
+            m = min(step, npairs - p0)
+            r1, r2 = workload.make_pairs_chunk(genome, m, read_len, rng, sub, indel)
+            workload.write_fastq_fast(fqs[0], r1, prefix="p", first=p0, append=p0 > 0)
+            workload.write_fastq_fast(fqs[1], r2, prefix="p", first=p0, append=p0 > 0)
+            del r1, r2
+        log("e2e: %d pairs of %d-bp reads written in %.1f s" % (npairs, read_len, time.time() - t_gen))
         out = {}
-        ckey = "e2e_reference_%d_t%d" % (npairs, threads)
+        ckey = "e2e_reference_%d_%d_t%d" % (npairs, read_len, threads)
         # (an N=1 run times the reference itself -- its line must not lean on another run's baseline -- unless a probe that launches the
-        # bound aligner several times on one box asks for the entry explicitly: MEME_BENCH_E2E_REUSE_REF=1, scripts/startup_probe.sh; the
-        # object then says "cached")
+        # bound aligner several times on one box asks for the entry explicitly: MEME_BENCH_E2E_REUSE_REF=1; the object then says "cached")
         reuse = devices > 1 or os.environ.get("MEME_BENCH_E2E_REUSE_REF") == "1"
         cached = refcache.get(ckey) if (refcache is not None and reuse) else None
-        for exe in ("bwa-meme_mode3", "bwa-meme_dropin"):
+        for exe in ["bwa-meme_mode3"] + dropin_exes:
             if exe == "bwa-meme_mode3" and cached:
                 out[exe] = dict(cached, cached="timed by the N=1 run on this box")
                 continue
+            if exe == "bwa-meme_mode3" and skip_ref:
+                continue
             sam = os.path.join(d, exe + ".sam")
             env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_DEVICES=str(devices))
+            if exe.endswith("_prof"):
+                env["MEME_DROPIN_PROFILE_SAM"] = "1"
             # Both binaries run on glibc malloc (the reference's default build would link mimalloc, a submodule that is not in the tree), and
             # the SAM phase is allocator-bound: both get the same allocator settings -- freed memory stays in the arenas, a deep per-thread
             # cache (profiles/r04_e2e.md: 2.4 -> 1.3 s of mem_process_seqs per 4 M reads for the drop-in)
@@ -543,13 +549,14 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
             err = r.stderr.decode(errors="replace")
             if os.environ.get("MEME_BENCH_E2E_STDERR"):            # keep the aligner's own profile / the binding's per-chunk report
                 os.makedirs(os.environ["MEME_BENCH_E2E_STDERR"], exist_ok=True)
-                open(os.path.join(os.environ["MEME_BENCH_E2E_STDERR"], exe + ".stderr"), "w").write(err)
+                open(os.path.join(os.environ["MEME_BENCH_E2E_STDERR"], "%s_%dbp.stderr" % (exe, read_len)), "w").write(err)
             if r.returncode != 0:
                 raise RuntimeError("%s failed: %s" % (exe, err[-800:]))
             proc = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
+            proc_cpu = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in ([0-9.]+) CPU sec", err))
             md5, nlines = sam_md5(sam)
             os.remove(sam)
-            info = {"threads": nthr, "wall_s": wall, "process_s": proc, "reads_per_s_wall": 2 * npairs / wall,
+            info = {"threads": nthr, "wall_s": wall, "process_s": proc, "process_cpu_s": proc_cpu, "reads_per_s_wall": 2 * npairs / wall,
                     "reads_per_s_process": 2 * npairs / proc if proc > 0 else None, "sam_md5": md5, "sam_lines": nlines}
             m = re.search(r"Runtime-build-index took ([0-9.]+) sec", err)
             if m:
@@ -565,10 +572,12 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                                    "bsw_pairs": int(m.group(5)), "bsw_backend_s": float(m.group(7)), "bsw_kernel_s": float(m.group(8))}
             for m in re.finditer(r"extension: this chunk .*?totals ([0-9.]+) s, (\d+) backend calls", err):
                 info.setdefault("backend", {})["extension_stage_s"] = float(m.group(1))      # host stage (MEME_DROPIN_EXT=host): jobs built + calls + fold + purge
-            for m in re.finditer(r"CIGAR stage on the device: (\d+) global alignments with traceback posed so far \(kernels ([0-9.]+) s, whole pre-pass ([0-9.]+) s\); "
-                                 r"ksw_global2 calls answered from the table (\d+), computed by the reference's function (\d+)", err):
+            for m in re.finditer(r"CIGAR stage on the device: (\d+) alignments posed so far \(kernels ([0-9.]+) s, whole pre-pass ([0-9.]+) s\); "
+                                 r"bwa_gen_cigar2 calls answered from the table (\d+), computed by the reference's function (\d+)", err):
                 info.setdefault("backend", {}).update({"cigar_jobs": int(m.group(1)), "cigar_kernels_s": float(m.group(2)), "cigar_prepass_s": float(m.group(3)),
                                                         "cigar_calls_from_table": int(m.group(4)), "cigar_calls_by_reference": int(m.group(5))})
+            for m in re.finditer(r"mate rescue on the device: (\d+) Smith-Waterman jobs posed so far \(kernels ([0-9.]+) s, whole pre-pass ([0-9.]+) s\)", err):
+                info.setdefault("backend", {}).update({"mate_rescue_jobs": int(m.group(1)), "mate_rescue_kernels_s": float(m.group(2)), "mate_rescue_prepass_s": float(m.group(3))})
             for m in re.finditer(r"chaining \+ extension on the device: ([0-9.]+) s in the backend calls so far \(HIP events: chaining ([0-9.]+) s, extension stage "
                                  r"([0-9.]+) s of which banded SW ([0-9.]+) s\); (\d+) alignment records, (\d+) extension jobs \((\d+) of them again with the doubled "
                                  r"band\), (\d+) reads chained by the wavefront-per-read tier, (\d+) reads chained on the host", err):
@@ -577,17 +586,24 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None):
                     "chain_kernels_s": float(m.group(2)), "ext_kernels_s": float(m.group(3)), "bsw_kernel_s": float(m.group(4)),
                     "alignment_records": int(m.group(5)), "bsw_pairs": int(m.group(6)), "bsw_pairs_doubled_band": int(m.group(7)),
                     "reads_chained_on_host": int(m.group(9))})
+            prof = re.findall(r"\[meme-dropin-prof\]   (.+?)\s+([0-9.]+) s\s+(\d+) calls", err)
+            if prof:
+                info["sam_phase_thread_seconds"] = {k.strip(): {"s": float(v), "calls": int(c)} for k, v, c in prof}
             out[exe] = info
             if exe == "bwa-meme_mode3" and refcache is not None:
                 refcache.put(ckey, info)
             log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
-        ref, drop = out["bwa-meme_mode3"], out["bwa-meme_dropin"]
+        ref, drop = out.get("bwa-meme_mode3"), out[dropin_exe]
         return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
-                "workload": "mem -7 (reference: -t %d, its best of a 32-256 sweep; with the backend bound: -t %d; same allocator settings for both), %d pairs of %d-bp reads (1 %% substitutions, 300-500 bp inserts) vs the "
-                            "benchmark genome (%d bp), wall time incl. index loading" % (ref["threads"], drop["threads"], npairs, READ_LEN, genome.shape[0]),
-                "threads": threads, "pairs": npairs, "gpus_driven_by_the_one_aligner_process": devices, "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]),
-                "dropin": drop, "reference": ref, "speedup_wall": ref["wall_s"] / drop["wall_s"],
-                "speedup_process": (ref["process_s"] / drop["process_s"]) if drop["process_s"] > 0 else None}
+                "workload": "mem -7 (reference: -t %s, its best of a 32-256 sweep; with the backend bound: -t %d), %d pairs of %d-bp reads (%g %% substitutions, %g %% indels, "
+                            "300-500 bp inserts%s) vs the benchmark genome (%d bp), wall time incl. index loading"
+                            % (ref["threads"] if ref else "-", drop["threads"], npairs, read_len, 100 * sub, 100 * indel, " + %d" % (read_len - 150) if read_len != 150 else "", genome.shape[0]),
+                "allocator": "both binaries on glibc malloc with GLIBC_TUNABLES=%s; the bound aligner also calls mallopt (trim threshold 1 GB, top pad 64 MB, "
+                             "mmap threshold 32 MB) and buffers stdout (16 MB)" % MALLOC_TUNABLES,
+                "threads": threads, "pairs": npairs, "read_len": read_len, "gpus_driven_by_the_one_aligner_process": devices,
+                "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]) if ref else None,
+                "dropin": drop, "reference": ref, "extra_runs": {e: out[e] for e in dropin_exes[1:]} or None, "speedup_wall": ref["wall_s"] / drop["wall_s"] if ref else None,
+                "speedup_process": (ref["process_s"] / drop["process_s"]) if ref and drop["process_s"] > 0 else None}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 

@@ -179,6 +179,7 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     // host (MEME_DROPIN_EXT=0); with the seed filter on the device nothing reads the array and it is not built.  At GRCh38 size that is 0.38 s
     // less host work in this function (0.49 -> 0.11 s) but no wall time: the function then waits that much longer for the index stream to
     // HBM (0.63 -> 1.08 s), which is the critical path of the start-up (profiles/r04_e2e_dropin_c/_d.stderr).
+    ext_mode_decide(aux->opt);
     const int64_t l_pac = aux->fmi->idx->bns->l_pac;
     const int64_t ll_pac = ext_mode() == 0 ? (l_pac * 2 + 3) / 4 * 4 : 0;
     w.rc_pac = ll_pac ? (uint8_t*)malloc((size_t)(ll_pac / 4)) : nullptr;                    // (process() frees it, src/fastmap.cpp:1109)
@@ -240,7 +241,19 @@ const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process
 std::vector<meme_contig> g_contigs;
 // MEME_DROPIN_EXT: "device" (default) = chaining, the seed filter (mem_flt_chained_seeds) AND seed extension on the GPU, the host receives
 // alignment records; "0" = the reference's own per-batch functions on chains brought back from the device (the cross-check).
+int g_ext_mode_override = -1;           // set once by ext_mode_decide(), before the first chunk
+// The device's seed filter (mem_flt_chained_seeds under -W) packs scores in 12 bits and penalties in a signed byte (csrc/meme_kswv.hip:
+// 199 x match < 4096, match / mismatch <= 127).  A run outside those limits keeps the reference's own per-batch functions on chains
+// brought back from the device (the MEME_DROPIN_EXT=0 arrangement) instead of stopping in the middle of its first chunk.
+void ext_mode_decide(const mem_opt_t* opt) {
+    if (ext_mode() != 2 || opt->min_chain_weight <= 0) return;
+    if ((int64_t)199 * opt->a < 4096 && opt->a <= 127 && opt->b <= 127) return;
+    fprintf(stderr, "[meme-dropin] -W with match score %d / mismatch penalty %d is beyond the device seed filter's limits: the extension stage of this run "
+            "uses the reference's per-batch functions (as MEME_DROPIN_EXT=0)\n", opt->a, opt->b);
+    g_ext_mode_override = 0;
+}
 int ext_mode() {
+    if (g_ext_mode_override >= 0) return g_ext_mode_override;
     static const int v = [] {
         const char* e = getenv("MEME_DROPIN_EXT");
         if (!e || !strcmp(e, "device") || !strcmp(e, "2")) return 2;
@@ -429,8 +442,10 @@ struct Prefetcher {
     struct Job { bseq1_t* seqs; int64_t n, seq; int state; };   // state: 1 queued, 2 running, 3 done
     std::deque<Job> jobs;                                       // in chunk order
     int64_t processed = -1;                                     // highest chunk number that has left mem_process_seqs
-    const mem_opt_t* opt = nullptr;
+    mem_opt_t opt;                                              // the run's options BY VALUE (mem -p hands mem_process_seqs a stack-local copy, src/fastmap.cpp:790-828)
+    bool has_opt = false;
     bool started = false;
+    bool disabled = false;                                      // the chunks mem_process_seqs receives are not the arrays the reader handed out (mem -p): nothing runs ahead
 };
 Prefetcher* g_pf = new Prefetcher;
 // Chunks are numbered where they are read (the binding's FASTQ reader calls prefetch_submit for every chunk, in order): chunk s lives in
@@ -451,6 +466,7 @@ void prefetch_submit(bseq1_t* seqs, int64_t n) {
     }
     Prefetcher& F = *g_pf;
     std::lock_guard<std::mutex> lk(F.m);
+    if (F.disabled) return;
     F.jobs.push_back({seqs, n, seq, 1});
     if (!F.started && prefetch_on()) {
         F.started = true;
@@ -462,14 +478,14 @@ void prefetch_submit(bseq1_t* seqs, int64_t n) {
                     // the first queued chunk, once the run's options are known (the first mem_process_seqs call) and its slot is free
                     std::unique_lock<std::mutex> lk(F.m);
                     F.cv.wait(lk, [&] {
-                        if (!F.opt || !g_ext_on_device || g_dev.empty()) return false;
+                        if (!F.has_opt || F.disabled || !g_ext_on_device || g_dev.empty()) return false;
                         for (Prefetcher::Job& J : F.jobs)
                             if (J.state == 1) { if (F.processed < J.seq - 2) return false; J.state = 2; seqs = J.seqs; n = J.n; seq = J.seq; return true; }
                         return false;
                     });
                 }
                 const double t0 = now_s();
-                seed_chunk(F.opt, seqs, n, (int)(seq & 1));
+                seed_chunk(&F.opt, seqs, n, (int)(seq & 1));
                 g_t_prefetched = g_t_prefetched + (now_s() - t0);
                 {
                     std::lock_guard<std::mutex> lk(F.m);
@@ -502,6 +518,19 @@ void prefetch_processed(int64_t seq) {
     F.cv.notify_all();
 }
 
+// mem_process_seqs was handed an array the reader never gave out (mem -p: every chunk is split into two arrays of its own, each
+// processed with a stack-local copy of the options, src/fastmap.cpp:790-828), or smart pairing is on: the helper must never touch
+// such a run's chunks.  Queued chunks are dropped, a chunk the helper is at is waited for (its slot is then simply overwritten by
+// the caller's own seed_chunk), later submissions are ignored.
+void prefetch_disable() {
+    Prefetcher& F = *g_pf;
+    std::unique_lock<std::mutex> lk(F.m);
+    if (F.disabled) return;
+    F.disabled = true;
+    F.cv.wait(lk, [&] { for (const Prefetcher::Job& J : F.jobs) if (J.state == 2) return false; return true; });
+    F.jobs.clear();
+}
+
 int g_team = 1;                        // kt_for worker threads of the run (opt->n_threads)
 worker_t* g_worker = nullptr;             // of the chunk being processed (alignment records, ref_string: the CIGAR stage reads them)
 const mem_opt_t* g_opt = nullptr;
@@ -531,13 +560,18 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         g_worker = &w;
         g_opt = opt;
         ktfor_calls() = 0;
-        { std::lock_guard<std::mutex> lk(g_pf->m); g_pf->opt = opt; }
-        g_pf->cv.notify_all();                                   // (chunks submitted before the options were known may go ahead now)
         int slot = -1;
         {
             std::lock_guard<std::mutex> lk(g_seq_mu);
             for (const SeqTag& t : g_seq_tags) if (t.seqs == seqs && t.seq >= g_seq_next - 8 && g_seq_next > 0) { slot = (int)(t.seq & 1); chunk_seq = t.seq; }
             if (slot >= 0) for (SeqTag& t : g_seq_tags) if (t.seqs == seqs) t.seqs = nullptr;      // (the array is freed and its address may come back)
+        }
+        // Chunks run ahead of their turn only when mem_process_seqs receives exactly the arrays the reader handed out, with the run's
+        // own options: not under mem -p (MEM_F_SMARTPE), and not for an array without a tag.
+        if (slot < 0 || (opt->flag & MEM_F_SMARTPE)) { prefetch_disable(); slot = -1; chunk_seq = -1; }
+        else {
+            { std::lock_guard<std::mutex> lk(g_pf->m); if (!g_pf->has_opt) { g_pf->opt = *opt; g_pf->has_opt = true; } }
+            g_pf->cv.notify_all();                               // (chunks submitted before the options were known may go ahead now)
         }
         if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
         else if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);

@@ -82,6 +82,7 @@ void prefetch_submit(bseq1_t* seqs, int64_t n);      // (called by the binding's
 extern const bntseq_t* g_bns;                  // of the run (set by mem_process_seqs)
 extern std::vector<meme_contig> g_contigs;
 int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 0 the reference's per-batch functions (the cross-check)
+void ext_mode_decide(const mem_opt_t* opt);    // options beyond the device seed filter's limits: mode 0 for the run
 bool prefetch_on();                            // MEME_DROPIN_PREFETCH: chunks go through the device stages ahead of their turn
 extern bool g_ext_on_device;
 extern int g_team;                             // kt_for worker threads of the run (opt->n_threads)

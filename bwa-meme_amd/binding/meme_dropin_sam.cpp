@@ -184,18 +184,7 @@ std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0},
 // per-record timing with shared counters costs a 256-thread run a third of its compute time: only on request
 bool profile_sam() { static const bool v = getenv("MEME_DROPIN_PROFILE_SAM") != nullptr; return v; }
 }
-// (measurement only, MEME_DROPIN_PROFILE_SAM=1) the two other candidates of the SAM phase: CIGAR generation and SAM formatting
-typedef uint32_t* (*gen_cigar2_fn)(const int8_t*, int, int, int, int, int, int64_t, const uint8_t*, int, uint8_t*, int64_t, int64_t, int*, int*, int*);
-extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t* pac, int l_query,
-                                    uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
-    static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
-    if (!profile_sam()) return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
-    const double t0 = now_s();
-    uint32_t* r = next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
-    g_t_cigar = g_t_cigar + (now_s() - t0);
-    g_n_cigar += 1;
-    return r;
-}
+// (measurement only, MEME_DROPIN_PROFILE_SAM=1) SAM formatting on the host
 typedef void (*aln2sam_fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
 void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
     static aln2sam_fn next = (aln2sam_fn)dlsym(RTLD_NEXT, "_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
@@ -206,31 +195,36 @@ void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq
     g_n_sam += 1;
 }
 void meme_dropin_report_matesw() {
-    fprintf(stderr, "[meme-dropin] SAM phase on the host, thread-seconds so far: mate-rescue SW (kswv) %.3f for %lld pairs; CIGAR generation (bwa_gen_cigar2) %.3f "
-            "for %lld alignments; SAM formatting (mem_aln2sam) %.3f for %lld records\n", (double)g_t_matesw, (long long)g_n_matesw, (double)g_t_cigar,
-            (long long)g_n_cigar, (double)g_t_sam, (long long)g_n_sam);
+    fprintf(stderr, "[meme-dropin] SAM phase on the host, thread-seconds so far: mate-rescue SW (kswv) %.3f for %lld pairs; CIGAR generation (the bwa_gen_cigar2 hook: "
+            "table look-ups and the reference's function for the rest) %.3f for %lld calls; SAM formatting (mem_aln2sam) %.3f for %lld records\n", (double)g_t_matesw,
+            (long long)g_n_matesw, (double)g_t_cigar, (long long)g_n_cigar, (double)g_t_sam, (long long)g_n_sam);
 }
 
 // ---- CIGAR generation of the SAM phase on the device ---------------------------------------------------------------------
-// mem_reg2aln (src/bwamem.cpp:2314-2380) calls bwa_gen_cigar2 (src/bwa.cpp:274-362) up to three times per alignment written out, and
-// that runs ksw_global2 (src/ksw.cpp:560-670): banded global alignment with traceback, 42 % of the SAM phase's thread time on 250-bp
-// reads with 5 % errors.  Between the two kt_for phases -- worker_aln has joined, worker_sam has not started: the third kt_for call of
-// mem_process_seqs (src/bwamem.cpp:1941-1965) is interposed -- the binding poses the same alignments for EVERY alignment record of the
-// chunk (the records are complete and nobody touches them; same band arithmetic as mem_reg2aln / bwa_gen_cigar2), runs them
-// on the GPU(s) as one batch per band attempt (meme_global_batch_host) and keeps score + CIGAR; ksw_global2 calls are then answered
-// from that table after an exact comparison of both sequences.  Calls the table does not hold (alignments made later by mate rescue,
-// calls without traceback from mem_patch_reg) go to the reference's function.  MEME_DROPIN_CIGAR=0 switches the stage off.
+// mem_reg2aln (src/bwamem.cpp:2314-2380) calls bwa_gen_cigar2 (src/bwa.cpp:274-362) up to three times per alignment written out: that
+// function unpacks the target from the 2-bit reference (bns_get_seq: a malloc and a base-by-base loop), reverses both sequences on the
+// reverse strand, runs ksw_global2 (src/ksw.cpp:560-670: banded global alignment with traceback, 42 % of the SAM phase's thread time on 250-bp
+// reads with 5 % errors) unless the alignment is gap-free, and walks the CIGAR once more for NM and the MD string.  Between the two kt_for
+// phases -- worker_aln has joined, worker_sam has not started: the kt_for call that carries worker_sam is interposed -- the binding poses
+// those very calls for EVERY alignment record of the chunk (the records are complete and nobody touches them; mem_reg2aln's band loop is
+// followed round by round), runs them on the GPU(s) as one batch per round (meme_gen_cigar_batch_host: the text and the reads are already
+// in HBM) and keeps score, CIGAR, NM and MD; bwa_gen_cigar2 itself is interposed and answers from that table after an exact comparison of
+// its arguments and of the query bases.  Calls the table does not hold (alignments made later by mate rescue, calls from other places)
+// go to the reference's function.  MEME_DROPIN_CIGAR=0 switches the stage off.  Round 4 hooked ksw_global2 only: the target unpacking,
+// the reversals, two sequence hashes per call and the NM / MD loop stayed on the host.
 #include <omp.h>
 #include <parallel/algorithm>
 namespace dropin {
 
-struct CigEntry { int64_t g; int64_t rb; int32_t qb, qlen, tlen, w, rev, score, n_cigar; int64_t ops; };
+struct CigEntry { int64_t g; int64_t rb; int32_t qb, qlen, tlen, w_, score, n_cigar, nm, md_len; int64_t ops, md; };
 struct CigTable {
     std::mutex mu;
     uint64_t gen = 0;
     std::vector<CigEntry> e;
     std::vector<uint32_t> ops;
-    std::vector<std::pair<uint64_t, uint32_t>> idx;      // (key, entry), sorted
+    std::vector<char> md;
+    std::vector<uint32_t> slot;                          // open addressing: entry + 1, 0 = empty; size a power of two
+    uint64_t mask = 0;
     double t_prepass = 0, t_kernel_ms = 0;
     int64_t n_jobs = 0;
 } g_cig;
@@ -238,36 +232,12 @@ std::atomic<int64_t> g_cig_hits{0}, g_cig_miss{0};
 bool cigar_on_device() { static const bool v = !(getenv("MEME_DROPIN_CIGAR") && atoi(getenv("MEME_DROPIN_CIGAR")) == 0); return v; }
 
 inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
-inline uint64_t hash_bytes(const uint8_t* p, int n, bool rev) {
-    uint64_t h = 1469598103934665603ull;
-    if (!rev) for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
-    else for (int i = n - 1; i >= 0; --i) h = (h ^ p[i]) * 1099511628211ull;
-    return h;
-}
-inline uint64_t cig_key(int qlen, int tlen, int w, uint64_t hq, uint64_t ht) {
-    return mix64(mix64(mix64(mix64((uint64_t)qlen, (uint64_t)tlen), (uint64_t)w), hq), ht);
-}
+inline uint64_t cig_key(int64_t rb, int qlen, int tlen, int w_) { const uint64_t h = mix64(mix64((uint64_t)rb, (uint64_t)(uint32_t)qlen << 32 | (uint32_t)tlen), (uint64_t)w_); return h ^ (h >> 29); }
 inline int infer_bw_(int l1, int l2, int score, int a, int q, int r) {        // infer_bw, src/bwamem.cpp:2151-2158
     if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
     int w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
     if (w < abs(l1 - l2)) w = abs(l1 - l2);
     return w;
-}
-// the band bwa_gen_cigar2 hands to ksw_global2 for a call with w_ (src/bwa.cpp:306-316); false: no DP (rejected, or the gap-free shortcut)
-inline bool gen_cigar_band(const mem_opt_t* opt, int64_t l_pac, int l_query, int64_t rb, int64_t re, int w_, int* w_out) {
-    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac)) return false;
-    const int64_t rlen = re - rb;
-    if (l_query == rlen && w_ == 0) return false;
-    int max_ins = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_ins) / opt->e_ins + 1.);
-    int max_del = (int)((double)(((l_query + 1) >> 1) * opt->mat[0] - opt->o_del) / opt->e_del + 1.);
-    int max_gap = max_ins > max_del ? max_ins : max_del;
-    max_gap = max_gap > 1 ? max_gap : 1;
-    int w = (max_gap + abs((int)rlen - l_query) + 1) >> 1;
-    w = w < w_ ? w : w_;
-    const int min_w = abs((int)rlen - l_query) + 3;
-    w = w > min_w ? w : min_w;
-    *w_out = w;
-    return true;
 }
 
 // helper threads of the pre-pass's host loops: a few dozen are enough, and an OpenMP team of 256 would still be spinning when worker_sam starts
@@ -277,10 +247,10 @@ void cig_prepass() {
     const double t0 = now_s();
     double cpu0; { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); cpu0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     CigTable& T = g_cig;
-    T.e.clear(); T.ops.clear(); T.idx.clear();
+    T.e.clear(); T.ops.clear(); T.md.clear();
     const mem_opt_t* opt = g_opt;
     const int64_t n = g_chunk.n, l_pac = g_bns->l_pac;
-    // per alignment record: where mem_reg2aln's loop stands (band of the next call, score of the last one)
+    // per alignment record: where mem_reg2aln's loop stands (band argument of the next call, score of the last one)
     struct Cand { int64_t g; int32_t reg, w2, last_sc, tries; };
     std::vector<Cand> cand;
     {
@@ -296,6 +266,8 @@ void cig_prepass() {
                     const mem_alnreg_t& p = av.a[i];
                     if (p.rb < 0 || p.re < 0 || p.score < opt->T) continue;
                     if (p.secondary >= 0 && p.secondary < (int)av.n && p.score < av.a[p.secondary].score * opt->XA_drop_ratio) continue;
+                    // what bwa_gen_cigar2 rejects, or would unpack from beyond the text, is left to it (src/bwa.cpp:285-287)
+                    if (p.qe <= p.qb || p.rb >= p.re || (p.rb < l_pac && p.re > l_pac) || p.re > 2 * l_pac) continue;
                     const int tmp = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_del, opt->e_del);
                     int w2 = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_ins, opt->e_ins);
                     w2 = w2 > tmp ? w2 : tmp;
@@ -321,25 +293,22 @@ void cig_prepass() {
         // (the alignment records are scattered over the heap), compacted in order.
         double tp = now_s();
         const int64_t nc = (int64_t)cand.size();
-        std::vector<meme_gjob> posed((size_t)nc);
+        std::vector<meme_cjob> posed((size_t)nc);
         std::vector<int8_t> dev_of((size_t)nc);
 #pragma omp parallel for schedule(static) num_threads(cig_threads())
         for (int64_t c = 0; c < nc; ++c) {
             Cand& C = cand[(size_t)c];
             const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
-            C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;
-            int w = 0;
+            C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;                         // (:2342)
             dev_of[(size_t)c] = -1;
-            if (!gen_cigar_band(opt, l_pac, p.qe - p.qb, p.rb, p.re, C.w2, &w)) { C.tries = 99; continue; }
             int d = 0;
             while (d + 1 < nd && C.g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
-            if (!g_chunk.part[(size_t)d].reads_on_ctx) { C.tries = 99; continue; }       // (a part seeded in pieces: its reads are not all on the ctx; the hook computes these)
-            meme_gjob& J = posed[(size_t)c];
-            J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w = w;
-            J.rev = p.rb >= l_pac ? 1 : 0;
+            if (!g_chunk.part[(size_t)d].reads_on_ctx) { C.tries = 99; continue; }       // (a part seeded in pieces: its reads are not all on the ctx; the reference's function computes these)
+            meme_cjob& J = posed[(size_t)c];
+            J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w_ = C.w2; J.pad = 0;
             dev_of[(size_t)c] = (int8_t)d;
         }
-        std::vector<std::vector<meme_gjob>> jobs((size_t)nd);
+        std::vector<std::vector<meme_cjob>> jobs((size_t)nd);
         std::vector<std::vector<uint32_t>> who((size_t)nd);
         for (int64_t c = 0; c < nc; ++c) {
             const int d = dev_of[(size_t)c];
@@ -350,20 +319,20 @@ void cig_prepass() {
         t_pose += now_s() - tp; tp = now_s();
         // One call per device; a call that the backend refuses for want of memory (MEME_E_CAPACITY: the backtrack matrices of the batch
         // beside the resident index) is repeated in halves, and whatever cannot be computed at all is simply left out of the table:
-        // the ksw_global2 hook then runs the reference's function for those alignments.  The stage is an optimisation, never a reason to stop.
-        struct Part { std::vector<meme_gres> res; std::vector<uint32_t> ops; int64_t done = 0; double kernel_ms = 0; };
+        // the hook then runs the reference's function for those alignments.  The stage is an optimisation, never a reason to stop.
+        struct Part { std::vector<meme_cres> res; std::vector<uint32_t> ops; std::vector<char> md; int64_t done = 0; double kernel_ms = 0; };
         std::vector<Part> part((size_t)nd);
         std::vector<std::thread> th;
         auto run = [&](int d) {
-            const std::vector<meme_gjob>& Jv = jobs[(size_t)d];
+            const std::vector<meme_cjob>& Jv = jobs[(size_t)d];
             Part& P = part[(size_t)d];
             const int64_t nj = (int64_t)Jv.size();
             P.res.reserve((size_t)nj);
             int64_t piece = nj;
             while (P.done < nj) {
                 const int64_t m = piece < nj - P.done ? piece : nj - P.done;
-                meme_gres_host R;
-                const int rc = meme_global_batch_host(g_chunk.part[(size_t)d].ctx, Jv.data() + P.done, m, &bo, &R);
+                meme_cres_host R;
+                const int rc = meme_gen_cigar_batch_host(g_chunk.part[(size_t)d].ctx, Jv.data() + P.done, m, &bo, &R);
                 if (rc == MEME_E_CAPACITY && m > 4096) { piece = m / 2; continue; }
                 if (rc != MEME_OK) {
                     static std::mutex warn_mu;
@@ -372,9 +341,10 @@ void cig_prepass() {
                     warned = true;
                     break;
                 }
-                const int64_t o0 = (int64_t)P.ops.size();
-                P.ops.insert(P.ops.end(), R.cigars, R.cigars + R.total_ops);          // the device packs the operations in job order
-                for (int64_t k = 0; k < m; ++k) { meme_gres g = R.res[k]; g.cigar_off += o0; P.res.push_back(g); }
+                const int64_t o0 = (int64_t)P.ops.size(), m0 = (int64_t)P.md.size();
+                P.ops.insert(P.ops.end(), R.cigars, R.cigars + R.total_ops);          // the device packs operations and MD strings in job order
+                P.md.insert(P.md.end(), R.md, R.md + R.md_bytes);
+                for (int64_t k = 0; k < m; ++k) { meme_cres g = R.res[k]; g.cigar_off += o0; g.md_off += m0; P.res.push_back(g); }
                 P.kernel_ms += R.kernel_ms;
                 P.done += m;
             }
@@ -389,25 +359,29 @@ void cig_prepass() {
             if (R.done == 0) continue;
             T.t_kernel_ms += R.kernel_ms;
             T.n_jobs += R.done;
-            const size_t e0 = T.e.size(), o0 = T.ops.size();
+            const size_t e0 = T.e.size(), o0 = T.ops.size(), m0 = T.md.size();
             T.ops.insert(T.ops.end(), R.ops.begin(), R.ops.end());
+            T.md.insert(T.md.end(), R.md.begin(), R.md.end());
             T.e.resize(e0 + (size_t)R.done);
             std::vector<uint8_t> again((size_t)R.done);
 #pragma omp parallel for schedule(static) num_threads(cig_threads())
             for (int64_t k = 0; k < R.done; ++k) {
-                const meme_gjob& J = jobs[(size_t)d][(size_t)k];
+                const meme_cjob& J = jobs[(size_t)d][(size_t)k];
+                const meme_cres& X = R.res[(size_t)k];
                 CigEntry& E = T.e[e0 + (size_t)k];
                 Cand& C = cand[who[(size_t)d][(size_t)k]];
-                E.g = C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w = J.w; E.rev = J.rev;
-                E.score = R.res[(size_t)k].score; E.n_cigar = R.res[(size_t)k].n_cigar; E.ops = (int64_t)o0 + R.res[(size_t)k].cigar_off;
+                E.g = C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w_ = J.w_;
+                E.score = X.score; E.n_cigar = X.n_cigar; E.nm = X.nm; E.md_len = X.md_len; E.ops = (int64_t)o0 + X.cigar_off; E.md = (int64_t)m0 + X.md_off;
                 // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
                 again[(size_t)k] = 0;
                 const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
                 const int score = E.score;
                 if (score == C.last_sc || C.w2 == opt->w << 2) continue;
                 C.last_sc = score;
+                const int prev = C.w2;
                 C.w2 <<= 1;
-                if (++C.tries < 3 && score < p.truesc - opt->a) again[(size_t)k] = 1;
+                // (a doubled 0 is the same call again: its answer is in the table already, and it ends the loop -- score == last_sc)
+                if (++C.tries < 3 && score < p.truesc - opt->a && (C.w2 < opt->w << 2 ? C.w2 : opt->w << 2) != prev) again[(size_t)k] = 1;
             }
             for (int64_t k = 0; k < R.done; ++k) if (again[(size_t)k]) next.push_back(cand[who[(size_t)d][(size_t)k]]);
         }
@@ -415,67 +389,70 @@ void cig_prepass() {
         t_take += now_s() - tp;
     }
     const double t_idx0 = now_s();
-    // index: sequences hashed the way the hook will see them (both reversed on the reverse strand); sorted by key, looked up by bisection
-    const uint8_t* ref = g_worker->ref_string;
-    T.idx.resize(T.e.size());
+    // the table: open addressing over (rb, lengths, w_); the hook verifies the query bases of what it finds
+    {
+        uint64_t cap = 64;
+        while (cap < 2 * T.e.size() + 16) cap <<= 1;
+        T.slot.assign((size_t)cap, 0u);
+        T.mask = cap - 1;
+        uint32_t* sl = T.slot.data();
 #pragma omp parallel for schedule(static) num_threads(cig_threads())
-    for (int64_t k = 0; k < (int64_t)T.e.size(); ++k) {
-        const CigEntry& E = T.e[(size_t)k];
-        const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
-        T.idx[(size_t)k] = {cig_key(E.qlen, E.tlen, E.w, hash_bytes(q, E.qlen, E.rev), hash_bytes(ref + E.rb, E.tlen, E.rev)), (uint32_t)k};
+        for (int64_t k = 0; k < (int64_t)T.e.size(); ++k) {
+            const CigEntry& E = T.e[(size_t)k];
+            uint64_t h = cig_key(E.rb, E.qlen, E.tlen, E.w_) & T.mask;
+            for (;;) {
+                uint32_t empty = 0;
+                if (__atomic_compare_exchange_n(&sl[h], &empty, (uint32_t)k + 1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                h = (h + 1) & T.mask;
+            }
+        }
     }
-    __gnu_parallel::sort(T.idx.begin(), T.idx.end(), __gnu_parallel::default_parallel_tag((unsigned)cig_threads()));
     T.t_prepass += now_s() - t0;
     if (verbose()) {
         timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
-        fprintf(stderr, "[meme-dropin] CIGAR pre-pass of this chunk %.3f s (process CPU %.2f s): candidates %.3f, jobs posed %.3f, backend calls %.3f, results taken %.3f, index %.3f\n", now_s() - t0,
+        fprintf(stderr, "[meme-dropin] CIGAR pre-pass of this chunk %.3f s (process CPU %.2f s): candidates %.3f, jobs posed %.3f, backend calls %.3f, results taken %.3f, table %.3f\n", now_s() - t0,
                 (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec - cpu0, t_cand1 - t0, t_pose, t_call, t_take, now_s() - t_idx0);
     }
 }
 
-typedef int (*ksw_global2_fn)(int, const uint8_t*, int, const uint8_t*, int, const int8_t*, int, int, int, int, int, int*, uint32_t**);
+typedef uint32_t* (*gen_cigar2_fn)(const int8_t*, int, int, int, int, int, int64_t, const uint8_t*, int, uint8_t*, int64_t, int64_t, int*, int*, int*);
 }  // namespace dropin
 
-extern "C" int ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int m, const int8_t* mat, int o_del, int e_del, int o_ins,
-                           int e_ins, int w, int* n_cigar_, uint32_t** cigar_) {
-    static ksw_global2_fn next = (ksw_global2_fn)dlsym(RTLD_NEXT, "ksw_global2");
-    if (!next) { fprintf(stderr, "[meme-dropin] the reference's ksw_global2 was not found\n"); exit(1); }
+extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t* pac, int l_query,
+                                    uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
+    static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
+    if (!next) { fprintf(stderr, "[meme-dropin] the reference's bwa_gen_cigar2 was not found\n"); exit(1); }
+    const double t0 = profile_sam() ? now_s() : 0;
+    struct Timer { double t0; ~Timer() { if (t0 > 0) { g_t_cigar = g_t_cigar + (now_s() - t0); g_n_cigar += 1; } } } timer{t0};
     const mem_opt_t* opt = g_opt;
-    if (!cigar_on_device() || !n_cigar_ || !cigar_ || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || m != 5 || mat != opt->mat || o_del != opt->o_del ||
-        e_del != opt->e_del || o_ins != opt->o_ins || e_ins != opt->e_ins)
-        return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
-    CigTable& T = g_cig;
-    if (T.gen != g_chunk_gen) return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);   // (no table for this chunk)
-    const uint64_t key = cig_key(qlen, tlen, w, hash_bytes(query, qlen, false), hash_bytes(target, tlen, false));
-    const uint8_t* ref = g_worker->ref_string;
-    for (auto it = std::lower_bound(T.idx.begin(), T.idx.end(), std::make_pair(key, (uint32_t)0)); it != T.idx.end() && it->first == key; ++it) {
-        const CigEntry& E = T.e[it->second];
-        if (E.qlen != qlen || E.tlen != tlen || E.w != w) continue;
-        const uint8_t* q = (const uint8_t*)g_chunk.seqs[E.g].seq + E.qb;
-        const uint8_t* t = ref + E.rb;
-        bool same = true;
-        if (!E.rev) same = !memcmp(q, query, (size_t)qlen) && !memcmp(t, target, (size_t)tlen);
-        else {
-            for (int i = 0; same && i < qlen; ++i) same = q[qlen - 1 - i] == query[i];
-            for (int i = 0; same && i < tlen; ++i) same = t[tlen - 1 - i] == target[i];
-        }
-        if (!same) continue;
-        uint32_t* cg = (uint32_t*)malloc((size_t)(E.n_cigar > 0 ? E.n_cigar : 1) * 4);   // the caller owns (and grows) it, as with the reference's
+    const CigTable& T = g_cig;
+    if (!cigar_on_device() || !score || !n_cigar || !NM || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || T.gen != g_chunk_gen || mat != opt->mat || o_del != opt->o_del ||
+        e_del != opt->e_del || o_ins != opt->o_ins || e_ins != opt->e_ins || !g_bns || l_pac != g_bns->l_pac || l_query <= 0 || rb >= re || re - rb > 0x7fffffff)
+        return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+    const int tlen = (int)(re - rb);
+    for (uint64_t h = cig_key(rb, l_query, tlen, w_) & T.mask;; h = (h + 1) & T.mask) {
+        const uint32_t s = T.slot[(size_t)h];
+        if (!s) break;
+        const CigEntry& E = T.e[s - 1];
+        if (E.rb != rb || E.qlen != l_query || E.tlen != tlen || E.w_ != w_) continue;
+        if (memcmp(g_chunk.seqs[E.g].seq + E.qb, query, (size_t)l_query) != 0) continue;        // (the read's bases are codes by now, as the caller's copy is)
+        // the block the reference's function returns: the operations, the MD string right behind them (src/bwa.cpp:324, 352-354)
+        uint32_t* cg = (uint32_t*)malloc((size_t)E.n_cigar * 4 + (size_t)E.md_len + 1);
         if (!cg) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
         memcpy(cg, T.ops.data() + E.ops, (size_t)E.n_cigar * 4);
-        *cigar_ = cg;
-        *n_cigar_ = E.n_cigar;
+        memcpy((char*)(cg + E.n_cigar), T.md.data() + E.md, (size_t)E.md_len + 1);
+        *score = E.score; *n_cigar = E.n_cigar; *NM = E.nm;
         g_cig_hits.fetch_add(1, std::memory_order_relaxed);
-        return E.score;
+        return cg;
     }
     g_cig_miss.fetch_add(1, std::memory_order_relaxed);
-    return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
+    return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
 }
 
 void meme_dropin_report_cigar() {
     if (!cigar_on_device()) return;
-    fprintf(stderr, "[meme-dropin] CIGAR stage on the device: %lld global alignments with traceback posed so far (kernels %.3f s, whole pre-pass %.3f s); "
-            "ksw_global2 calls answered from the table %lld, computed by the reference's function %lld (alignments made by mate rescue, calls without traceback)\n",
+    fprintf(stderr, "[meme-dropin] CIGAR stage on the device: %lld alignments posed so far (kernels %.3f s, whole pre-pass %.3f s); "
+            "bwa_gen_cigar2 calls answered from the table %lld, computed by the reference's function %lld (alignments made by mate rescue)\n",
             (long long)g_cig.n_jobs, g_cig.t_kernel_ms * 1e-3, g_cig.t_prepass, (long long)g_cig_hits.load(), (long long)g_cig_miss.load());
 }
 

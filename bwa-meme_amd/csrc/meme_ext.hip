@@ -426,6 +426,22 @@ __global__ void __launch_bounds__(64) k_ext_purge(PurgeArgs P) {
 
 unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
 
+// measurement (tuning "ext_census"): jobs whose query equals the first len2 bases of the target (no ambiguous base) -- the jobs a closed form
+// could answer without the DP (score = h0 + len2 * a).  SMEM seeds end on a mismatch or at a read end, so few are expected.
+__global__ void __launch_bounds__(256) k_ext_census(const meme_seqpair* __restrict__ pairs, i64 n, const uint8_t* __restrict__ seq, unsigned long long* __restrict__ cnt) {
+    i64 mine = 0;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
+        const meme_seqpair P = pairs[k];
+        if (P.len2 > P.len1) continue;
+        const uint8_t* q = seq + P.idq;
+        const uint8_t* t = seq + P.idr;
+        bool same = true;
+        for (int i = 0; same && i < P.len2; ++i) same = q[i] == t[i] && q[i] < 4;
+        mine += same;
+    }
+    if (mine) atomicAdd(cnt, (unsigned long long)mine);
+}
+
 }  // namespace
 
 extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* copt,
@@ -530,6 +546,8 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     bl.end_bonus = eopt->pen_clip5;                   // bswLeft / bswRight, src/bwamem.cpp:2953-2959
     br.end_bonus = eopt->pen_clip3;
     unsigned long long* d_nretry = (unsigned long long*)E[8].p;
+    unsigned long long* d_census = (unsigned long long*)E[8].p + 4;
+    if (ctx->ext_census) HIP_TRY(hipMemsetAsync(d_census, 0, 8, ctx->stream));
     i64 n_pairs = 0, n_retried = 0, n_calls = 0;
     float bsw_ms = 0.f;
     // ---- slabs of reads whose jobs' sequences fit 32-bit offsets (SeqPair::idr / idq)
@@ -555,6 +573,10 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
         S.L = (meme_seqpair*)E[4].p; S.R = (meme_seqpair*)E[5].p; S.seq = (uint8_t*)E[7].p;
         hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)(g1 - g0)), dim3(64), 0, ctx->stream, S);
         HIP_TRY(hipGetLastError());
+        if (ctx->ext_census) {
+            if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, d_census);
+            if (nR) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nR, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.R, nR, (const uint8_t*)S.seq, d_census);
+        }
         for (int dir = 0; dir < 2; ++dir) {
             meme_seqpair* P = dir == 0 ? S.L : S.R;
             i64 np = dir == 0 ? nL : nR;
@@ -592,7 +614,10 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg)))) return rc;
     HIP_TRY(hipMemcpyAsync(Hb[0].p, d_sdoff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_seeds) HIP_TRY(hipMemcpyAsync(Hb[1].p, A.regs, (size_t)n_seeds * sizeof(meme_alnreg), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long h_census = 0;
+    if (ctx->ext_census) HIP_TRY(hipMemcpyAsync(&h_census, d_census, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    out->n_exact_prefix = ctx->ext_census ? (int64_t)h_census : -1;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
     out->nreads = n; out->reg_off = (const int64_t*)Hb[0].p; out->regs = (const meme_alnreg*)Hb[1].p; out->total_regs = n_seeds;

@@ -25,6 +25,9 @@ struct GcigArgs {
     const i64* zoff; uint8_t* z;             // backtrack matrices: n_col * tlen bytes per job
     const i64* coff; uint32_t* cig;          // CIGAR scratch: qlen + tlen + 2 operations per job, filled from the back
     meme_gres* res;                          // score, n_cigar, (cigar_off = first operation inside the job's scratch, for the pack kernel)
+    // bwa_gen_cigar2 whole (meme_gen_cigar_batch_host): NM and the MD string of every job; null for the plain ksw_global2 call
+    const i64* mdoff; char* md;              // MD scratch: 2 * (qlen + tlen) + 16 bytes per job
+    int32_t* nm; int32_t* mdlen;
 };
 
 __device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(pac[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3; }
@@ -42,6 +45,23 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     uint8_t* qs = reinterpret_cast<uint8_t*>(eE + (qlen + 2));
     const uint8_t* rd = A.reads + A.read_off[J.read] + J.qb;
     for (int j = lane; j < qlen; j += 64) qs[j] = J.rev ? rd[qlen - 1 - j] : rd[j];
+    uint32_t* cg = A.cig + A.coff[jb];
+    const int cap = qlen + tlen + 2;
+    int n = 0;                               // operations so far; cg[cap - 1 - k] = k-th pushed
+    int score;
+    if (w < 0) {
+        // bwa_gen_cigar2's gap-free shortcut (src/bwa.cpp:295-304: equal lengths and w_ == 0): one M operation, the score summed
+        __syncthreads();
+        int part = 0;
+        for (int j = lane; j < qlen; j += 64) {
+            const int tb = text_base(A.pac, J.rev ? J.rb + tlen - 1 - j : J.rb + j), qb = qs[j];
+            part += qb > 3 ? -1 : (tb == qb ? A.o.a : -A.o.b);
+        }
+        for (int d = 32; d; d >>= 1) part += __shfl_xor(part, d);
+        score = part;
+        cg[cap - 1] = (unsigned)qlen << 4;
+        n = 1;
+    } else {
     const int oe_del = A.o.o_del + A.o.e_del, oe_ins = A.o.o_ins + A.o.e_ins, e_del = A.o.e_del, e_ins = A.o.e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     uint8_t* z = A.z + A.zoff[jb];
@@ -101,11 +121,8 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
         __syncthreads();
         int* tsw = hp; hp = hn; hn = tsw;
     }
-    const int score = hp[qlen];
+    score = hp[qlen];
     // backtrack (src/ksw.cpp:650-664), every lane the same walk; the operations are written from the back of the job's scratch
-    uint32_t* cg = A.cig + A.coff[jb];
-    const int cap = qlen + tlen + 2;
-    int n = 0;                               // operations so far; cg[cap - 1 - k] = k-th pushed
     {
         __threadfence();
         __syncthreads();
@@ -130,7 +147,60 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
         if (k >= 0) push(1, k + 1);
         if (last_op >= 0) { cg[cap - 1 - n] = cur; ++n; }
     }
+    }
     if (lane == 0) { meme_gres R; R.score = score; R.n_cigar = n; R.cigar_off = cap - n; A.res[jb] = R; }
+    if (!A.md) return;
+    // NM and MD (src/bwa.cpp:322-355): the operations in CIGAR order over the (possibly reversed) query and target.  Matches are compared 64
+    // bases at a time -- one ballot, then only the mismatches are visited --, deleted bases are written by the lanes side by side; the text
+    // of the string is identical on every lane, lane 0 stores it.
+    __threadfence();
+    __syncthreads();
+    char* out = A.md + A.mdoff[jb];
+    const char* const b2c = J.rev ? "TGCAN" : "ACGTN";
+    int len = 0, x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+    auto put_num = [&](int v) {              // kputw
+        char buf[12];
+        int l = 0;
+        do { buf[l++] = (char)('0' + v % 10); v /= 10; } while (v);
+        if (lane == 0) for (int i = 0; i < l; ++i) out[len + i] = buf[l - 1 - i];
+        len += l;
+    };
+    for (int k = 0; k < n; ++k) {
+        const unsigned c = cg[cap - n + k];
+        const int op = (int)(c & 0xf), l = (int)(c >> 4);
+        if (op == 0) {
+            for (int i0 = 0; i0 < l; i0 += 64) {
+                const int i = i0 + lane;
+                const bool in = i < l;
+                int tb = 0, qb = 0;
+                if (in) { tb = text_base(A.pac, J.rev ? J.rb + tlen - 1 - (y + i) : J.rb + y + i); qb = qs[x + i]; }
+                unsigned long long mask = __ballot(in && tb != qb);
+                int pos0 = 0;
+                while (mask) {
+                    const int b = __builtin_ctzll(mask);
+                    u += b - pos0;
+                    put_num(u);
+                    const int t = __shfl(tb, b);
+                    if (lane == 0) out[len] = b2c[t];
+                    ++len; ++n_mm; u = 0; pos0 = b + 1;
+                    mask &= mask - 1;
+                }
+                u += (l - i0 < 64 ? l - i0 : 64) - pos0;
+            }
+            x += l; y += l;
+        } else if (op == 2) {
+            if (k > 0 && k < n - 1) {        // (a deletion at either end of the CIGAR is not reported: mem_reg2aln squeezes it out)
+                put_num(u);
+                if (lane == 0) out[len] = '^';
+                ++len;
+                for (int i = lane; i < l; i += 64) out[len + i] = b2c[text_base(A.pac, J.rev ? J.rb + tlen - 1 - (y + i) : J.rb + y + i)];
+                len += l; u = 0; n_gap += l;
+            }
+            y += l;
+        } else { x += l; n_gap += l; }
+    }
+    put_num(u);
+    if (lane == 0) { out[len] = 0; A.nm[jb] = n_mm + n_gap; A.mdlen[jb] = len; }
 }
 
 // the operations of every job, densely packed in job order (they were pushed back to front: already in CIGAR order)
@@ -143,12 +213,13 @@ __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__
         for (int k = 0; k < R.n_cigar; ++k) dst[k] = src[k];
     }
 }
-__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, i64* __restrict__ zsz, i64* __restrict__ csz) {
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, i64* __restrict__ zsz, i64* __restrict__ csz, i64* __restrict__ msz) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         const meme_gjob J = jobs[jb];
         const i64 n_col = J.qlen < 2 * J.w + 1 ? J.qlen : 2 * J.w + 1;
-        zsz[jb] = (n_col * J.tlen + 15) & ~(i64)15;
+        zsz[jb] = J.w < 0 ? 0 : (n_col * J.tlen + 15) & ~(i64)15;           // (w < 0: the gap-free shortcut, no matrix)
         csz[jb] = J.qlen + J.tlen + 2;
+        if (msz) msz[jb] = 2 * ((i64)J.qlen + J.tlen) + 16;                // an MD string never has more than two characters per base
     }
 }
 __global__ void __launch_bounds__(256) k_gcig_ncig(const meme_gres* __restrict__ res, i64 njobs, i64* __restrict__ ncig) {
@@ -166,19 +237,146 @@ __global__ void __launch_bounds__(256) k_gcig_check(const meme_gjob* __restrict_
     }
 }
 
+// bwa_gen_cigar2's own preamble (src/bwa.cpp:288-316) for a batch of its calls: the strand from rb, the gap-free shortcut (equal lengths,
+// w_ == 0: band -1 here) or the band it hands to ksw_global2
+__global__ void __launch_bounds__(256) k_cjob_prep(const meme_cjob* __restrict__ cj, i64 njobs, i64 l_pac, meme_bsw_opt o, meme_gjob* __restrict__ jobs) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
+        const meme_cjob C = cj[jb];
+        meme_gjob J;
+        J.rb = C.rb; J.read = C.read; J.qb = C.qb; J.qlen = C.qlen; J.tlen = C.tlen; J.rev = C.rb >= l_pac ? 1 : 0;
+        if (C.qlen == C.tlen && C.w_ == 0) J.w = -1;
+        else {
+            const int max_ins = (int)((double)(((C.qlen + 1) >> 1) * o.a - o.o_ins) / o.e_ins + 1.);
+            const int max_del = (int)((double)(((C.qlen + 1) >> 1) * o.a - o.o_del) / o.e_del + 1.);
+            int max_gap = max_ins > max_del ? max_ins : max_del;
+            max_gap = max_gap > 1 ? max_gap : 1;
+            const int dl = C.tlen > C.qlen ? C.tlen - C.qlen : C.qlen - C.tlen;
+            int w = (max_gap + dl + 1) >> 1;
+            w = w < C.w_ ? w : C.w_;
+            w = w > dl + 3 ? w : dl + 3;
+            J.w = w;
+        }
+        jobs[jb] = J;
+    }
+}
+// packed MD strings (NUL-terminated, job order) + the per-job result records of meme_gen_cigar_batch_host
+__global__ void __launch_bounds__(256) k_md_sizes(const int32_t* __restrict__ mdlen, i64 njobs, i64* __restrict__ sz) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) sz[jb] = (i64)mdlen[jb] + 1;
+}
+__global__ void __launch_bounds__(256) k_md_pack(const meme_gres* __restrict__ res, const int32_t* __restrict__ nm, const int32_t* __restrict__ mdlen, const i64* __restrict__ mdoff,
+                                                  const char* __restrict__ md, const i64* __restrict__ poff, i64 njobs, char* __restrict__ out, meme_cres* __restrict__ cres) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
+        const int l = mdlen[jb];
+        const char* src = md + mdoff[jb];
+        char* dst = out + poff[jb];
+        for (int k = 0; k <= l; ++k) dst[k] = src[k];
+        meme_cres R;
+        R.score = res[jb].score; R.n_cigar = res[jb].n_cigar; R.nm = nm[jb]; R.md_len = l; R.cigar_off = res[jb].cigar_off; R.md_off = poff[jb];
+        cres[jb] = R;
+    }
+}
+
 unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
+
+// The batch from the jobs in G[0] (device) to packed results: scratch sizes, the alignment kernel, the packed operations (and MD strings).
+// with_md: NM + MD of every job (meme_gen_cigar_batch_host); host_jobs (may be null) only serves the error message of a bad query span.
+struct GcigRun { i64 tops = 0, tmd = 0; };
+int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool with_md, const char* who, GcigRun* out) {
+    int rc;
+    DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
+    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 10 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
+    i64* d_zsz = (i64*)G[1].p;
+    i64* d_csz = d_zsz + (njobs + 1);
+    i64* d_zoff = d_csz + (njobs + 1);
+    i64* d_coff = d_zoff + (njobs + 1);
+    i64* d_ncig = d_coff + (njobs + 1);
+    i64* d_ooff = d_ncig + (njobs + 1);
+    i64* d_msz = d_ooff + (njobs + 1);
+    i64* d_moff = d_msz + (njobs + 1);
+    i64* d_psz = d_moff + (njobs + 1);
+    i64* d_poff = d_psz + (njobs + 1);
+    i64* d_bad = d_poff + (njobs + 1);
+    HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
+    hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, d_zsz, d_csz, with_md ? d_msz : (i64*)nullptr);
+    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs))) return rc;
+    if (with_md && (rc = meme_scan_exclusive(ctx, d_msz, d_moff, njobs))) return rc;
+    i64 tz = 0, tc = 0, tm = 0;
+    HIP_TRY(hipMemcpyAsync(&tz, d_zoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&tc, d_coff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (with_md) HIP_TRY(hipMemcpyAsync(&tm, d_moff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    i64 bad = -1;
+    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (bad >= 0) {
+        meme_set_error("%s: job %lld names a query span beyond the end of read it refers to", who, (long long)bad);
+        return MEME_E_ARG;
+    }
+    {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)tz + (size_t)tc * 4 + (size_t)tm;
+        const size_t have = G[2].cap + G[3].cap + G[6].cap;
+        if (need > have && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2 + have) {
+            meme_set_error("%s: %lld alignments need %.1f GB of backtrack matrices, more than half of the free HBM: submit fewer at a time", who, (long long)njobs, need / 1e9);
+            return MEME_E_CAPACITY;
+        }
+    }
+    if ((rc = meme_buf_reserve(ctx, G[2], (size_t)tz + 64)) || (rc = meme_buf_reserve(ctx, G[3], (size_t)(tc + 1) * 4))) return rc;
+    if (with_md && ((rc = meme_buf_reserve(ctx, G[6], (size_t)tm + 64)) || (rc = meme_buf_reserve(ctx, G[7], (size_t)njobs * 8 + 64)))) return rc;
+    GcigArgs A;
+    A.jobs = (const meme_gjob*)G[0].p; A.njobs = njobs; A.reads = (const uint8_t*)ctx->reads.p; A.read_off = (const i64*)ctx->read_off.p; A.pac = ctx->idx.pac;
+    A.o = *opt; A.zoff = d_zoff; A.z = (uint8_t*)G[2].p; A.coff = d_coff; A.cig = (uint32_t*)G[3].p; A.res = (meme_gres*)G[4].p;
+    A.mdoff = d_moff; A.md = with_md ? (char*)G[6].p : nullptr;
+    A.nm = with_md ? (int32_t*)G[7].p : nullptr; A.mdlen = with_md ? (int32_t*)G[7].p + njobs : nullptr;
+    const size_t lds = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3);
+    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_gcig, dim3((unsigned)njobs), dim3(64), lds, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_gcig_ncig, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (i64)njobs, d_ncig);
+    if ((rc = meme_scan_exclusive(ctx, d_ncig, d_ooff, njobs))) return rc;
+    if (with_md) {
+        hipLaunchKernelGGL(k_md_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const int32_t*)A.mdlen, (i64)njobs, d_psz);
+        if ((rc = meme_scan_exclusive(ctx, d_psz, d_poff, njobs))) return rc;
+    }
+    i64 tops = 0, tmd = 0;
+    HIP_TRY(hipMemcpyAsync(&tops, d_ooff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (with_md) HIP_TRY(hipMemcpyAsync(&tmd, d_poff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if ((rc = meme_buf_reserve(ctx, G[5], (size_t)(tops + 1) * 4))) return rc;
+    hipLaunchKernelGGL(k_gcig_pack, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (const i64*)d_coff, (const uint32_t*)G[3].p,
+                       (const i64*)d_ooff, (i64)njobs, (uint32_t*)G[5].p);
+    hipLaunchKernelGGL(k_gcig_fix, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (meme_gres*)G[4].p, (const i64*)d_ooff, (i64)njobs);
+    if (with_md) {
+        if ((rc = meme_buf_reserve(ctx, G[8], (size_t)tmd + 64)) || (rc = meme_buf_reserve(ctx, G[10], (size_t)njobs * sizeof(meme_cres)))) return rc;
+        hipLaunchKernelGGL(k_md_pack, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (const int32_t*)A.nm, (const int32_t*)A.mdlen,
+                           (const i64*)d_moff, (const char*)G[6].p, (const i64*)d_poff, (i64)njobs, (char*)G[8].p, (meme_cres*)G[10].p);
+    }
+    HIP_TRY(hipGetLastError());
+    out->tops = tops; out->tmd = tmd;
+    return MEME_OK;
+}
+
+int gcig_preamble(meme_ctx* ctx, const void* jobs, int64_t njobs, const meme_bsw_opt* opt, const void* out, const char* who) {
+    if (!ctx || !jobs || njobs < 0 || !opt || !out) { meme_set_error("%s: null argument", who); return MEME_E_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (njobs == 0) return MEME_OK;
+    const i64 nreads = ctx->last_seed_reads;
+    if (nreads <= 0 || !ctx->reads.p || !ctx->read_off.p || !ctx->idx.pac || !ctx->reads_resident) { meme_set_error("%s: no seeded batch on this ctx (the jobs name its reads)", who); return MEME_E_STATE; }
+    if (opt->e_del < 1 || opt->e_ins < 1) { meme_set_error("%s: gap extension penalties must be positive", who); return MEME_E_ARG; }
+    if (ctx->max_batch > 0 && njobs > ctx->max_batch) { meme_set_error("%s: %lld jobs exceed the ctx's max_batch of %lld", who, (long long)njobs, (long long)ctx->max_batch); return MEME_E_CAPACITY; }
+    for (int i = 0; i < 2; ++i) if (!ctx->ev_gcig[i]) HIP_TRY(hipEventCreate(&ctx->ev_gcig[i]));
+    return MEME_OK;
+}
 
 }  // namespace
 
 extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int64_t njobs, const meme_bsw_opt* opt, meme_gres_host* out) {
-    if (!ctx || !jobs || njobs < 0 || !opt || !out) { meme_set_error("meme_global_batch_host: null argument"); return MEME_E_ARG; }
-    HIP_TRY(hipSetDevice(ctx->device));
+    static const char* const who = "meme_global_batch_host";
+    int rc;
+    if ((rc = gcig_preamble(ctx, jobs, njobs, opt, out, who))) return rc;
     memset(out, 0, sizeof(*out));
     if (njobs == 0) return MEME_OK;
     const i64 nreads = ctx->last_seed_reads;
-    if (nreads <= 0 || !ctx->reads.p || !ctx->read_off.p || !ctx->idx.pac || !ctx->reads_resident) { meme_set_error("meme_global_batch_host: no seeded batch on this ctx (the jobs name its reads)"); return MEME_E_STATE; }
-    if (opt->e_del < 1 || opt->e_ins < 1) { meme_set_error("meme_global_batch_host: gap extension penalties must be positive"); return MEME_E_ARG; }
-    if (ctx->max_batch > 0 && njobs > ctx->max_batch) { meme_set_error("meme_global_batch_host: %lld jobs exceed the ctx's max_batch of %lld", (long long)njobs, (long long)ctx->max_batch); return MEME_E_CAPACITY; }
     int qmax = 0;
     for (i64 k = 0; k < njobs; ++k) {
         const meme_gjob& J = jobs[k];
@@ -186,76 +384,65 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
         // below that ksw_global2 walks rows without cells, which this kernel does not restate)
         if (J.read < 0 || J.read >= nreads || J.qb < 0 || J.qlen < 1 || J.tlen < 1 || J.w < 0 || J.rb < 0 || J.rb + J.tlen > ctx->idx.n || J.qlen > 65535 || J.tlen > 65535 ||
             J.w < (J.tlen > J.qlen ? J.tlen - J.qlen : J.qlen - J.tlen)) {
-            meme_set_error("meme_global_batch_host: job %lld is malformed (read %d, query %d+%d, target %lld+%d, band %d)", (long long)k, J.read, J.qb, J.qlen,
-                           (long long)J.rb, J.tlen, J.w);
+            meme_set_error("%s: job %lld is malformed (read %d, query %d+%d, target %lld+%d, band %d)", who, (long long)k, J.read, J.qb, J.qlen, (long long)J.rb, J.tlen, J.w);
             return MEME_E_ARG;
         }
         qmax = J.qlen > qmax ? J.qlen : qmax;
     }
-    int rc;
-    DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (4 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars
-    if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob))) || (rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 6 + 64)) ||
-        (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
-    hipEvent_t* ev = ctx->ev_gcig;
-    for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
+    DevBuf* G = ctx->gcig;
+    if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob)))) return rc;
     HIP_TRY(hipMemcpyAsync(G[0].p, jobs, (size_t)njobs * sizeof(meme_gjob), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    i64* d_zsz = (i64*)G[1].p;
-    i64* d_csz = d_zsz + (njobs + 1);
-    i64* d_zoff = d_csz + (njobs + 1);
-    i64* d_coff = d_zoff + (njobs + 1);
-    i64* d_ncig = d_coff + (njobs + 1);
-    i64* d_ooff = d_ncig + (njobs + 1);
-    i64* d_bad = d_ooff + (njobs + 1);
-    HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
-    hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
-    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, d_zsz, d_csz);
-    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs))) return rc;
-    i64 tz = 0, tc = 0;
-    HIP_TRY(hipMemcpyAsync(&tz, d_zoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(&tc, d_coff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
-    i64 bad = -1;
-    HIP_TRY(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (bad >= 0) {
-        meme_set_error("meme_global_batch_host: job %lld names a query span (%d+%d) beyond the end of read %d", (long long)bad, jobs[bad].qb, jobs[bad].qlen, jobs[bad].read);
-        return MEME_E_ARG;
-    }
-    {
-        size_t free_b = 0, total_b = 0;
-        const size_t need = (size_t)tz + (size_t)tc * 4;
-        if (need > G[2].cap + G[3].cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b / 2 + G[2].cap + G[3].cap) {
-            meme_set_error("meme_global_batch_host: %lld alignments need %.1f GB of backtrack matrices, more than half of the free HBM: submit fewer at a time",
-                           (long long)njobs, need / 1e9);
-            return MEME_E_CAPACITY;
-        }
-    }
-    if ((rc = meme_buf_reserve(ctx, G[2], (size_t)tz + 64)) || (rc = meme_buf_reserve(ctx, G[3], (size_t)(tc + 1) * 4))) return rc;
-    GcigArgs A;
-    A.jobs = (const meme_gjob*)G[0].p; A.njobs = njobs; A.reads = (const uint8_t*)ctx->reads.p; A.read_off = (const i64*)ctx->read_off.p; A.pac = ctx->idx.pac;
-    A.o = *opt; A.zoff = d_zoff; A.z = (uint8_t*)G[2].p; A.coff = d_coff; A.cig = (uint32_t*)G[3].p; A.res = (meme_gres*)G[4].p;
-    const size_t lds = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3);
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_gcig, dim3((unsigned)njobs), dim3(64), lds, ctx->stream, A);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_gcig_ncig, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (i64)njobs, d_ncig);
-    if ((rc = meme_scan_exclusive(ctx, d_ncig, d_ooff, njobs))) return rc;
-    i64 tops = 0;
-    HIP_TRY(hipMemcpyAsync(&tops, d_ooff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if ((rc = meme_buf_reserve(ctx, G[5], (size_t)(tops + 1) * 4))) return rc;
-    hipLaunchKernelGGL(k_gcig_pack, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (const i64*)d_coff, (const uint32_t*)G[3].p,
-                       (const i64*)d_ooff, (i64)njobs, (uint32_t*)G[5].p);
-    hipLaunchKernelGGL(k_gcig_fix, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (meme_gres*)G[4].p, (const i64*)d_ooff, (i64)njobs);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev[1], ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_gcig[0], ctx->stream));
+    GcigRun R;
+    if ((rc = gcig_run(ctx, njobs, qmax, opt, false, who, &R))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_gcig[1], ctx->stream));
     meme_ctx::HostBuf* Hb = ctx->h_gcig;
-    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)njobs * sizeof(meme_gres))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(tops + 1) * 4))) return rc;
+    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)njobs * sizeof(meme_gres))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(R.tops + 1) * 4))) return rc;
     HIP_TRY(hipMemcpyAsync(Hb[0].p, G[4].p, (size_t)njobs * sizeof(meme_gres), hipMemcpyDeviceToHost, ctx->stream));
-    if (tops) HIP_TRY(hipMemcpyAsync(Hb[1].p, G[5].p, (size_t)tops * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (R.tops) HIP_TRY(hipMemcpyAsync(Hb[1].p, G[5].p, (size_t)R.tops * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
-    out->njobs = njobs; out->res = (const meme_gres*)Hb[0].p; out->cigars = (const uint32_t*)Hb[1].p; out->total_ops = tops; out->kernel_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_gcig[0], ctx->ev_gcig[1]));
+    out->njobs = njobs; out->res = (const meme_gres*)Hb[0].p; out->cigars = (const uint32_t*)Hb[1].p; out->total_ops = R.tops; out->kernel_ms = ms;
+    return MEME_OK;
+}
+
+extern "C" int meme_gen_cigar_batch_host(meme_ctx* ctx, const meme_cjob* jobs, int64_t njobs, const meme_bsw_opt* opt, meme_cres_host* out) {
+    static const char* const who = "meme_gen_cigar_batch_host";
+    int rc;
+    if ((rc = gcig_preamble(ctx, jobs, njobs, opt, out, who))) return rc;
+    memset(out, 0, sizeof(*out));
+    if (njobs == 0) return MEME_OK;
+    const i64 nreads = ctx->last_seed_reads, l_pac = ctx->idx.n >> 1;
+    int qmax = 0;
+    for (i64 k = 0; k < njobs; ++k) {
+        const meme_cjob& J = jobs[k];
+        // what bwa_gen_cigar2 itself rejects (src/bwa.cpp:285: empty spans, a target bridging the two strands) is not a job
+        if (J.read < 0 || J.read >= nreads || J.qb < 0 || J.qlen < 1 || J.tlen < 1 || J.w_ < 0 || J.rb < 0 || J.rb + J.tlen > ctx->idx.n || J.qlen > 65535 || J.tlen > 65535 ||
+            (J.rb < l_pac && J.rb + J.tlen > l_pac)) {
+            meme_set_error("%s: job %lld is malformed (read %d, query %d+%d, target %lld+%d, w_ %d)", who, (long long)k, J.read, J.qb, J.qlen, (long long)J.rb, J.tlen, J.w_);
+            return MEME_E_ARG;
+        }
+        qmax = J.qlen > qmax ? J.qlen : qmax;
+    }
+    DevBuf* G = ctx->gcig;
+    if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob))) || (rc = meme_buf_reserve(ctx, G[9], (size_t)njobs * sizeof(meme_cjob)))) return rc;
+    HIP_TRY(hipMemcpyAsync(G[9].p, jobs, (size_t)njobs * sizeof(meme_cjob), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_gcig[0], ctx->stream));
+    hipLaunchKernelGGL(k_cjob_prep, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_cjob*)G[9].p, (i64)njobs, l_pac, *opt, (meme_gjob*)G[0].p);
+    GcigRun R;
+    if ((rc = gcig_run(ctx, njobs, qmax, opt, true, who, &R))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_gcig[1], ctx->stream));
+    meme_ctx::HostBuf* Hb = ctx->h_gcig;
+    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)njobs * sizeof(meme_cres))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(R.tops + 1) * 4)) ||
+        (rc = meme_hostbuf_reserve(ctx, Hb[2], (size_t)R.tmd + 64))) return rc;
+    HIP_TRY(hipMemcpyAsync(Hb[0].p, G[10].p, (size_t)njobs * sizeof(meme_cres), hipMemcpyDeviceToHost, ctx->stream));
+    if (R.tops) HIP_TRY(hipMemcpyAsync(Hb[1].p, G[5].p, (size_t)R.tops * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (R.tmd) HIP_TRY(hipMemcpyAsync(Hb[2].p, G[8].p, (size_t)R.tmd, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_gcig[0], ctx->ev_gcig[1]));
+    out->njobs = njobs; out->res = (const meme_cres*)Hb[0].p; out->cigars = (const uint32_t*)Hb[1].p; out->total_ops = R.tops; out->md = (const char*)Hb[2].p; out->md_bytes = R.tmd;
+    out->kernel_ms = ms;
     return MEME_OK;
 }

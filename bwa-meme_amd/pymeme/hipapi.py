@@ -59,7 +59,7 @@ class ExtOpt(C.Structure):
 class ExtHostResult(C.Structure):
     _fields_ = [("nreads", C.c_int64), ("reg_off", C.c_void_p), ("regs", C.c_void_p), ("total_regs", C.c_int64), ("total_chains", C.c_int64),
                 ("n_pairs", C.c_int64), ("n_retried", C.c_int64), ("n_bsw_calls", C.c_int64), ("n_tier2", C.c_int64), ("chain_ms", C.c_float),
-                ("ext_ms", C.c_float), ("bsw_ms", C.c_float), ("n_flt_jobs", C.c_int64), ("n_flt_dropped", C.c_int64)]
+                ("ext_ms", C.c_float), ("bsw_ms", C.c_float), ("n_flt_jobs", C.c_int64), ("n_flt_dropped", C.c_int64), ("n_exact_prefix", C.c_int64)]
 
 
 def default_ext_opt(w=100):
@@ -80,6 +80,16 @@ assert GJOB.itemsize == 32 and GRES.itemsize == 16
 
 class GresHost(C.Structure):
     _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("cigars", C.c_void_p), ("total_ops", C.c_int64), ("kernel_ms", C.c_float)]
+
+
+CJOB = np.dtype([("rb", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qlen", "<i4"), ("tlen", "<i4"), ("w_", "<i4"), ("pad", "<i4")])
+CRES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("nm", "<i4"), ("md_len", "<i4"), ("cigar_off", "<i8"), ("md_off", "<i8")])
+assert CJOB.itemsize == 32 and CRES.itemsize == 32
+
+
+class CresHost(C.Structure):
+    _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("cigars", C.c_void_p), ("total_ops", C.c_int64), ("md", C.c_void_p), ("md_bytes", C.c_int64),
+                ("kernel_ms", C.c_float)]
 
 
 class KswvHost(C.Structure):
@@ -119,7 +129,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries", "meme_stage_build_plcp",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_gen_cigar_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -327,7 +337,7 @@ class Context:
         return {"reg_off": view(res.reg_off, n + 1, np.int64), "regs": view(res.regs, res.total_regs, ALNREG), "total_chains": int(res.total_chains),
                 "n_pairs": int(res.n_pairs), "n_retried": int(res.n_retried), "n_bsw_calls": int(res.n_bsw_calls), "n_tier2": int(res.n_tier2),
                 "chain_ms": float(res.chain_ms), "ext_ms": float(res.ext_ms), "bsw_ms": float(res.bsw_ms),
-                "n_flt_jobs": int(res.n_flt_jobs), "n_flt_dropped": int(res.n_flt_dropped)}
+                "n_flt_jobs": int(res.n_flt_jobs), "n_flt_dropped": int(res.n_flt_dropped), "n_exact_prefix": int(res.n_exact_prefix)}
 
     def global_batch_host(self, jobs, opt=None):
         """meme_global_batch_host: banded global alignments with traceback (ksw_global2) of query spans of the batch's reads against
@@ -343,6 +353,21 @@ class Context:
             buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype, count=count).copy()
         return view(res.res, res.njobs, GRES), view(res.cigars, res.total_ops, np.uint32), float(res.kernel_ms)
+
+    def gen_cigar_batch_host(self, jobs, opt=None):
+        """meme_gen_cigar_batch_host: bwa_gen_cigar2 whole for a batch of its calls (CJOB records: query span of a resident read, text span,
+        w_).  Returns (CRES records, cigars uint32, MD bytes (NUL-terminated strings at md_off), kernel_ms)."""
+        opt = opt or default_bsw_opt()
+        jobs = np.ascontiguousarray(jobs, dtype=CJOB)
+        res = CresHost()
+        _check(lib().meme_gen_cigar_batch_host(C.c_void_p(self.h), _p(jobs), C.c_int64(jobs.shape[0]), C.byref(opt), C.byref(res)))
+
+        def view(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return view(res.res, res.njobs, CRES), view(res.cigars, res.total_ops, np.uint32), view(res.md, res.md_bytes, np.uint8), float(res.kernel_ms)
 
     def kswv_batch_host(self, jobs, ref, qer, opt=None):
         """meme_kswv_batch_host: the mate-rescue Smith-Waterman batch (mem_sam_pe_batch with the kswv kernels).  jobs: KSWV_JOB records over the

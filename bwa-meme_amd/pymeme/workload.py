@@ -150,16 +150,82 @@ def make_bsw_pairs_distinct(n_pairs: int, seed: int, read_len: int = 150, sub=0.
     return pairs, np.concatenate(refs), np.concatenate(qers)
 
 
-def write_fastq_fast(path: str, reads: np.ndarray, prefix: str = "r") -> None:
-    """Vectorised FASTQ writer for millions of fixed-length reads (names <prefix><index>, constant qualities)."""
+def write_fastq_fast(path: str, reads: np.ndarray, prefix: str = "r", first: int = 0, append: bool = False) -> None:
+    """Vectorised FASTQ writer for millions of fixed-length reads (names <prefix><first + index>, constant qualities): reads whose
+    numbers have the same count of digits form one fixed-width byte matrix."""
     n, L = reads.shape
     alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    q = b"I" * L
-    with open(path, "wb") as fh:
-        step = 1 << 18
+    pre = np.frombuffer(b"@" + prefix.encode(), dtype=np.uint8)
+    with open(path, "ab" if append else "wb") as fh:
+        step = 1 << 20
         for s0 in range(0, n, step):
-            seqs = alpha[reads[s0:s0 + step]]
-            out = bytearray()
-            for i in range(seqs.shape[0]):
-                out += b"@" + prefix.encode() + str(s0 + i).encode() + b"\n" + seqs[i].tobytes() + b"\n+\n" + q + b"\n"
-            fh.write(out)
+            ids = np.arange(first + s0, first + min(n, s0 + step), dtype=np.int64)
+            nd = np.where(ids > 0, np.floor(np.log10(np.maximum(ids, 1))).astype(np.int64) + 1, 1)
+            nd = np.where(10 ** (nd - 1) > ids, nd - 1, nd)                       # (guards against log10 rounding at powers of ten)
+            nd = np.maximum(np.where(10 ** nd <= ids, nd + 1, nd), 1)
+            lo = 0
+            while lo < ids.shape[0]:                                              # ids ascend: runs of equal digit count are contiguous
+                d = int(nd[lo])
+                hi = lo + int(np.searchsorted(nd[lo:], d, side="right"))
+                m = hi - lo
+                row = np.empty((m, pre.shape[0] + d + 1 + L + 3 + L + 1), dtype=np.uint8)
+                c = pre.shape[0]
+                row[:, :c] = pre
+                for k in range(d):
+                    row[:, c + k] = (ids[lo:hi] // 10 ** (d - 1 - k)) % 10 + 48
+                c += d
+                row[:, c] = 10
+                row[:, c + 1:c + 1 + L] = alpha[reads[s0 + lo:s0 + hi]]
+                c += 1 + L
+                row[:, c:c + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+                row[:, c + 3:c + 3 + L] = ord("I")
+                row[:, c + 3 + L] = 10
+                fh.write(row.tobytes())
+                lo = hi
+
+
+def apply_errors(frag: np.ndarray, read_len: int, rng, sub_rate: float, indel_rate: float) -> np.ndarray:
+    """Rows of `frag` ([m, span], span > read_len: slack for deletions) -> reads [m, read_len] with substitutions (rate per base) and
+    single-base insertions / deletions (indel_rate per base, half each; neighbouring events make longer gaps).  Events are drawn sparsely
+    (their expected number of random places), so the cost is a few passes over the matrix whatever the rates."""
+    m, span = frag.shape
+    frag = np.ascontiguousarray(frag, dtype=np.uint8)
+    flat = frag.reshape(-1)
+    k = int(rng.binomial(flat.shape[0], sub_rate))
+    at = rng.integers(0, flat.shape[0], size=k)
+    flat[at] = (flat[at] + rng.integers(1, 4, size=k, dtype=np.uint8)) & 3
+    if indel_rate <= 0:
+        return np.ascontiguousarray(frag[:, :read_len])
+    n_ev = rng.binomial(read_len, indel_rate, size=m)
+    idx = np.broadcast_to(np.arange(read_len, dtype=np.int16)[None, :], (m, read_len)).copy()       # source column of every read base
+    ar = np.arange(read_len, dtype=np.int16)[None, :]
+    ins_r, ins_c = [], []
+    for e in range(int(n_ev.max()) if m else 0):
+        rows = np.nonzero(n_ev > e)[0]
+        col = rng.integers(1, read_len - 1, size=rows.shape[0]).astype(np.int16)
+        is_del = rng.random(rows.shape[0]) < 0.5
+        # deletion in front of read column c: the tail comes from one base further; insertion at c: the tail from one base nearer
+        idx[rows] += np.where(ar >= col[:, None], np.where(is_del, 1, 0)[:, None], 0).astype(np.int16)
+        idx[rows] -= np.where(ar > col[:, None], np.where(is_del, 0, 1)[:, None], 0).astype(np.int16)
+        ins_r.append(rows[~is_del]); ins_c.append(col[~is_del])
+    np.clip(idx, 0, span - 1, out=idx)
+    out = np.take_along_axis(frag, idx.astype(np.int64), axis=1)
+    if ins_r:
+        r, c = np.concatenate(ins_r), np.concatenate(ins_c).astype(np.int64)
+        out[r, c] = rng.integers(0, 4, size=r.shape[0], dtype=np.uint8)
+    return out
+
+
+def make_pairs_chunk(genome: np.ndarray, m: int, read_len: int, rng, sub_rate: float, indel_rate: float = 0.0, ins_lo: int = 300, ins_hi: int = 500):
+    """m read pairs (FR orientation, insert ins_lo..ins_hi + (read_len - 150)) of the forward strand of `genome`: (r1, r2) codes [m, read_len]."""
+    slack = 0 if indel_rate <= 0 else max(16, int(read_len * indel_rate * 4) + 8)
+    span = read_len + slack
+    extra = read_len - 150
+    pos = rng.integers(0, genome.shape[0] - ins_hi - extra - 2 * span - 8, size=m)
+    ins = rng.integers(ins_lo, ins_hi, size=m) + extra
+    win = np.lib.stride_tricks.sliding_window_view(genome, span)                 # row p = genome[p : p + span]: a gather of contiguous rows
+    r1 = apply_errors(win[pos], read_len, rng, sub_rate, indel_rate)
+    # the mate: reverse complement of the fragment's far end; its slack extends into the fragment
+    end = pos + ins                                                              # one past the fragment's last base
+    r2 = apply_errors(3 - win[end - span][:, ::-1], read_len, rng, sub_rate, indel_rate)
+    return r1, r2

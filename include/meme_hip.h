@@ -14,6 +14,7 @@
  *   meme_chain_last_batch_host      <- mem_chain_Learned() + mem_chain_flt()          src/bwamem.cpp:1122-1204, 599-717
  *   meme_extend_last_batch_host     <- mem_chain2aln_across_reads_V2()              src/bwamem.cpp:2573-3497 (behind the chaining stage)
  *   meme_global_batch_host          <- ksw_global2() under bwa_gen_cigar2()         src/ksw.cpp:560-670, src/bwa.cpp:274-362
+ *   meme_gen_cigar_batch_host       <- bwa_gen_cigar2() whole: CIGAR + NM + MD       src/bwa.cpp:274-362
  *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
  *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
  *
@@ -250,6 +251,7 @@ typedef struct {
     int64_t n_tier2;                 /* reads chained by the wavefront-per-read tier */
     float chain_ms, ext_ms, bsw_ms;  /* HIP-event times: chaining kernels; the extension stage (incl. its host round trips); of which banded SW */
     int64_t n_flt_jobs, n_flt_dropped;   /* mem_flt_chained_seeds: alignments run (mem_seed_sw), chained seeds removed (0 / 0 where it is a no-op) */
+    int64_t n_exact_prefix;          /* measurement (tuning "ext_census" = 1, else -1): first-attempt jobs whose query equals the first qlen target bases */
 } meme_ext_host_result;
 int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* chain_opt,
                                 const meme_ext_opt* ext_opt, meme_ext_host_result* out);
@@ -294,6 +296,22 @@ typedef struct { int64_t njobs; const meme_gres* res; const uint32_t* cigars; in
 int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int64_t njobs, const meme_bsw_opt* opt /* o_del e_del o_ins e_ins a b */,
                            meme_gres_host* out);
 
+/* ---- bwa_gen_cigar2 whole: CIGAR + NM + MD of a batch of its calls -----------------------------------------------------------------
+ * What bwa_gen_cigar2() (reference src/bwa.cpp:274-362) returns for a call that it does not reject: the query is qlen bases of read
+ * `read` of the batch resident on the ctx starting at qb (the `&query[qb]` mem_reg2aln passes, src/bwamem.cpp:2314-2380), the target the
+ * span [rb, rb + tlen) of the fwd+rc text (what bns_get_seq unpacks, :286), w_ the band argument as mem_reg2aln passes it.  As in the
+ * reference: both sequences reversed when rb >= l_pac (:288-293), the gap-free shortcut for equal lengths and w_ == 0 (:295-304: one M
+ * operation, the score summed over the scoring matrix), else the band of :306-316 and ksw_global2 with traceback; then NM and the MD string
+ * (:322-355, "ACGTN" / "TGCAN" by strand, a deletion at either end of the CIGAR left out).  Results in job order: operations packed in
+ * `cigars`, MD strings NUL-terminated in `md`.  The hook a binding writes for bwa_gen_cigar2 copies n_cigar operations followed by
+ * md_len + 1 bytes into one malloc'd block -- the layout the reference's caller expects (cigar, then MD behind it).  Jobs that the
+ * reference's function rejects (empty spans, a target bridging the strands) fail the call with MEME_E_ARG; MEME_E_CAPACITY as above. */
+typedef struct { int64_t rb; int32_t read, qb, qlen, tlen, w_, pad; } meme_cjob;
+typedef struct { int32_t score, n_cigar, nm, md_len; int64_t cigar_off, md_off; } meme_cres;
+typedef struct { int64_t njobs; const meme_cres* res; const uint32_t* cigars; int64_t total_ops; const char* md; int64_t md_bytes; float kernel_ms; } meme_cres_host;
+int meme_gen_cigar_batch_host(meme_ctx* ctx, const meme_cjob* jobs, int64_t njobs, const meme_bsw_opt* opt /* o_del e_del o_ins e_ins a b */,
+                              meme_cres_host* out);
+
 /* ---- mate-rescue Smith-Waterman: the other DP kernel of the SAM phase ---------------------------------------------------------------
  * What mem_sam_pe_batch() (reference src/bwamem_pair.cpp:719-818) computes with kswv::getScores8 / getScores16 (src/kswv.cpp) for the
  * SeqPair jobs mem_matesw_batch_pre() (src/bwamem_pair.cpp:1060-1223) posed: local alignment of a mate (query, len2 bases at qer + idq)
@@ -325,7 +343,7 @@ typedef struct {
     int64_t seed_lane_searches;   /* searches k_reseed did itself, one lane each (what the table cannot answer) */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY) */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY) */
 
 #ifdef __cplusplus
 }

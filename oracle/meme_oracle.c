@@ -11,6 +11,7 @@
  */
 #include "meme_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
@@ -1309,6 +1310,64 @@ int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* tar
     }
     free(eh_h); free(eh_e); free(z);
     return score;
+}
+
+/* ---- bwa_gen_cigar2 whole (reference src/bwa.cpp:274-362): CIGAR + NM + MD of one call ---------------------------------------------------
+ * text = fwd+rc codes (what bns_get_seq unpacks for [rb, re)), query = l_query codes 0..4 (the `&query[qb]` of mem_reg2aln).  Both sequences
+ * reversed when rb >= l_pac (:288-293); equal lengths with w_ == 0 take the gap-free shortcut (:295-304), everything else the band of
+ * :306-316 and ksw_global2; NM / MD as :322-355 (a deletion at either end of the CIGAR is not reported; "TGCAN" on the reverse strand).
+ * cigar: capacity l_query + (re - rb) + 2; md: capacity 2 * (l_query + re - rb) + 16.  Returns 0, -1 for a call the function rejects. */
+int orc_gen_cigar2(const uint8_t* text, int64_t l_pac, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w_, int l_query, const uint8_t* query,
+                   int64_t rb, int64_t re, int* score, int* n_cigar, uint32_t* cigar, int* NM, char* md) {
+    *n_cigar = 0; *NM = -1; *score = 0;
+    if (l_query <= 0 || rb >= re || (rb < l_pac && re > l_pac) || rb < 0 || re > 2 * l_pac) return -1;
+    const int rlen = (int)(re - rb), rev = rb >= l_pac;
+    uint8_t* q = (uint8_t*)malloc((size_t)l_query);
+    uint8_t* t = (uint8_t*)malloc((size_t)rlen);
+    int i, k;
+    for (i = 0; i < l_query; ++i) q[i] = rev ? query[l_query - 1 - i] : query[i];
+    for (i = 0; i < rlen; ++i) t[i] = rev ? text[re - 1 - i] : text[rb + i];
+    if (l_query == rlen && w_ == 0) {
+        cigar[0] = (uint32_t)l_query << 4;
+        *n_cigar = 1;
+        for (i = 0; i < l_query; ++i) *score += (t[i] > 3 || q[i] > 3) ? -1 : (t[i] == q[i] ? a : -b);
+    } else {
+        int max_ins = (int)((double)(((l_query + 1) >> 1) * a - o_ins) / e_ins + 1.);
+        int max_del = (int)((double)(((l_query + 1) >> 1) * a - o_del) / e_del + 1.);
+        int max_gap = max_ins > max_del ? max_ins : max_del;
+        max_gap = max_gap > 1 ? max_gap : 1;
+        int w = (max_gap + abs(rlen - l_query) + 1) >> 1;
+        w = w < w_ ? w : w_;
+        int min_w = abs(rlen - l_query) + 3;
+        w = w > min_w ? w : min_w;
+        *score = orc_ksw_global2(l_query, q, rlen, t, a, b, o_del, e_del, o_ins, e_ins, w, n_cigar, cigar);
+    }
+    {
+        const char* int2base = rev ? "TGCAN" : "ACGTN";
+        int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0, l = 0;
+        for (k = 0; k < *n_cigar; ++k) {
+            const int op = (int)(cigar[k] & 0xf), len = (int)(cigar[k] >> 4);
+            if (op == 0) {
+                for (i = 0; i < len; ++i) {
+                    if (q[x + i] != t[y + i]) { l += sprintf(md + l, "%d%c", u, int2base[t[y + i]]); ++n_mm; u = 0; }
+                    else ++u;
+                }
+                x += len; y += len;
+            } else if (op == 2) {
+                if (k > 0 && k < *n_cigar - 1) {
+                    l += sprintf(md + l, "%d^", u);
+                    for (i = 0; i < len; ++i) md[l++] = int2base[t[y + i]];
+                    u = 0; n_gap += len;
+                }
+                y += len;
+            } else if (op == 1) { x += len; n_gap += len; }
+        }
+        l += sprintf(md + l, "%d", u);
+        md[l] = 0;
+        *NM = n_mm + n_gap;
+    }
+    free(q); free(t);
+    return 0;
 }
 
 /* ---- mate-rescue Smith-Waterman of the SAM phase (kswv, reference src/kswv.cpp; driver mem_sam_pe_batch, src/bwamem_pair.cpp:719-818) --------

@@ -145,6 +145,9 @@ int orc_flt_batch(const uint8_t* reads, const int64_t* read_off, int64_t nreads,
 /* ---- banded global alignment with traceback (ksw_global2, reference src/ksw.cpp:560-670) ------------------------------------------ */
 int orc_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w,
                     int* n_cigar, uint32_t* cigar /* capacity qlen + tlen + 2 */);
+/* bwa_gen_cigar2 whole (reference src/bwa.cpp:274-362): CIGAR + NM + MD; see meme_oracle.c */
+int orc_gen_cigar2(const uint8_t* text, int64_t l_pac, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w_, int l_query, const uint8_t* query,
+                   int64_t rb, int64_t re, int* score, int* n_cigar, uint32_t* cigar, int* NM, char* md);
 
 /* ---- mate-rescue Smith-Waterman of the SAM phase (kswv::getScores8 / getScores16 as driven by mem_sam_pe_batch; reference
  * src/kswv.cpp:372-712, 934-1199, src/bwamem_pair.cpp:719-818): forward pass, second-best score, reverse pass for the start ---------- */

@@ -8,7 +8,7 @@
 //   ref_flt_chained_seeds  mem_flt_chained_seeds() with mem_seed_sw()      reference src/bwamem.cpp:565-598, 494-520 (ksw_align2, src/ksw.cpp)
 //   ref_kswv_batch      sort_classify() + mem_sam_pe_batch()                reference src/bwamem.cpp:1798-1825, src/bwamem_pair.cpp:719-818
 //                       (the AVX-512 mate-rescue kernels kswv::getScores8 / getScores16, src/kswv.cpp)
-//   ref_gen_cigar       bwa_gen_cigar2()                                   reference src/bwa.cpp:274-362 (ksw_global2, src/ksw.cpp:560-670)
+//   ref_ksw_global2 / ref_gen_cigar2   ksw_global2(), bwa_gen_cigar2() whole (CIGAR + NM + MD)   reference src/ksw.cpp:560-670, src/bwa.cpp:274-362
 //
 // Linked against oracle/_ref/libbwa_pic.so (the reference's objects, built where the sources lie by oracle/Makefile.ref) into
 // oracle/_ref/libstage_ref.so.  Contains no reference code: structures are filled through the reference's headers.
@@ -274,6 +274,35 @@ int ref_ksw_global2(int qlen, const uint8_t* query, int tlen, const uint8_t* tar
     free(cg);
     *n_cigar = n;
     return score;
+}
+
+// bwa_gen_cigar2 whole (src/bwa.cpp:274-362): `fwd` = the forward strand as codes 0..3 (packed here into the reference's pac array, 4 bases per
+// byte, first base in the top bits -- _set_pac, src/bntseq.cpp), query codes 0..4.  out[0..3] = score, n_cigar, NM, length of the MD string;
+// cigar / md receive the operations and the string (NUL included).  Returns 0, or -1 when the function returned no CIGAR (a rejected call).
+int ref_gen_cigar2(const uint8_t* fwd, int64_t l_pac, int a, int b, int o_del, int e_del, int o_ins, int e_ins, int w_, int l_query, const uint8_t* query, int64_t rb,
+                   int64_t re, int32_t* out, uint32_t* cigar, int cap, char* md, int md_cap) {
+    static const uint8_t* pac_of = nullptr;
+    static std::vector<uint8_t> pac;
+    if (pac_of != fwd || (int64_t)pac.size() != l_pac / 4 + 1) {
+        pac.assign((size_t)(l_pac / 4 + 1), 0);
+        for (int64_t i = 0; i < l_pac; ++i) pac[(size_t)(i >> 2)] |= (uint8_t)((fwd[i] & 3) << ((~i & 3) << 1));
+        pac_of = fwd;
+    }
+    int8_t mat[25];
+    bwa_fill_scmat(a, b, mat);
+    std::vector<uint8_t> q(query, query + l_query);
+    int score = 0, n_cigar = 0, NM = 0;
+    uint32_t* cg = bwa_gen_cigar2(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac.data(), l_query, q.data(), rb, re, &score, &n_cigar, &NM);
+    if (memcmp(q.data(), query, (size_t)l_query) != 0) { free(cg); return -2; }      // (the function reverses the query in place and must put it back)
+    if (!cg) { out[0] = score; out[1] = n_cigar; out[2] = NM; out[3] = -1; return -1; }
+    const char* m = (const char*)(cg + n_cigar);
+    const int l = (int)strlen(m);
+    out[0] = score; out[1] = n_cigar; out[2] = NM; out[3] = l;
+    if (n_cigar > cap || l + 1 > md_cap) { free(cg); return -3; }
+    memcpy(cigar, cg, (size_t)n_cigar * 4);
+    memcpy(md, m, (size_t)l + 1);
+    free(cg);
+    return 0;
 }
 
 

@@ -332,3 +332,29 @@ def kswv_edge_jobs():
 KSWV_EDGE_WANT = [[150, 249, 149, -1, -1, 100, 0], [1, 0, 0, -1, -1, -1, -1], [60, 59, 79, -1, -1, 0, 20], [1, 4, 0, -1, -1, -1, -1], [150, 249, 149, -1, -1, -1, -1],
                   [150, 249, 149, -1, -1, 100, 0], [150, 249, 149, -1, -1, 100, 0], [40, 139, 39, -1, -1, -1, -1], [150, 249, 149, -1, -1, -1, -1],
                   [150, 1149, 149, -1, -1, 1000, 0]]
+
+
+def gencig_workload(n=2500, seed=177):
+    """Inputs of the bwa_gen_cigar2 tests (tests/golden/gencig_golden.npz): the reads and genome of gcig_workload's kind, but the jobs are CALLS of
+    bwa_gen_cigar2 as mem_reg2aln makes them (src/bwamem.cpp:2340-2347) -- w_ is the band ARGUMENT (0 .. 400, the function derives the band),
+    a share of the calls have equal lengths and w_ = 0 (the gap-free shortcut), spans start and end inside the read, both strands.
+    Returns (genome, reads list, calls as hipapi.CJOB records)."""
+    from pymeme import hipapi
+    g, reads, jobs, _ = gcig_workload(n=n, seed=seed)
+    rng = np.random.default_rng(seed + 5)
+    l_pac = g.shape[0]
+    calls = np.zeros(jobs.shape[0], dtype=hipapi.CJOB)
+    for k, J in enumerate(jobs):
+        qlen, tlen, rb = int(J["qlen"]), int(J["tlen"]), int(J["rb"])
+        u = rng.random()
+        if u < 0.35:                                   # equal lengths, w_ = 0: no DP
+            tlen = qlen
+            w_ = 0
+        elif u < 0.5:                                  # equal lengths but a band: DP all the same
+            tlen = qlen
+            w_ = int(rng.choice([1, 5, 100]))
+        else:
+            w_ = int(rng.choice([0, 1, 3, 10, 30, 100, 200, 400]))
+        tlen = max(1, min(tlen, (l_pac - rb) if rb < l_pac else 2 * l_pac - rb))
+        calls[k] = (rb, int(J["read"]), int(J["qb"]), qlen, tlen, w_, 0)
+    return g, reads, calls

@@ -341,6 +341,24 @@ def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
     return sc, cig[:n.value].copy()
 
 
+def gen_cigar2(text, l_pac, query, rb, re, w_, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
+    """orc_gen_cigar2 (bwa_gen_cigar2 whole): (score, cigar uint32 array, NM, MD bytes) or None for a call the function rejects."""
+    L = lib()
+    L.orc_gen_cigar2.restype = C.c_int
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    n = query.shape[0] + max(int(re - rb), 0)
+    cig = np.zeros(n + 2, np.uint32)
+    md = np.zeros(2 * n + 16, np.uint8)
+    sc, nc, nm = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = L.orc_gen_cigar2(C.c_void_p(text.ctypes.data), C.c_int64(int(l_pac)), C.c_int(a), C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins),
+                          C.c_int(int(w_)), C.c_int(query.shape[0]), C.c_void_p(query.ctypes.data), C.c_int64(int(rb)), C.c_int64(int(re)), C.byref(sc), C.byref(nc),
+                          C.c_void_p(cig.ctypes.data), C.byref(nm), C.c_void_p(md.ctypes.data))
+    if rc != 0:
+        return None
+    return sc.value, cig[:nc.value].copy(), nm.value, md[:int(np.argmin(md != 0))].tobytes()
+
+
 KSWV_JOB_DTYPE = np.dtype([("idr", "<i8"), ("idq", "<i8"), ("len1", "<i4"), ("len2", "<i4"), ("xtra", "<i4"), ("pad", "<i4")])
 KSWR_DTYPE = np.dtype([(n, "<i4") for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")])
 KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000

@@ -169,6 +169,26 @@ def ksw_global2(query, target, w, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
     return sc, cig[:n.value].copy()
 
 
+def gen_cigar2(fwd, query, rb, re, w_, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
+    """bwa_gen_cigar2 of the compiled reference on the genome `fwd` (codes 0..3; the shim packs it once per array):
+    (score, cigar, NM, MD bytes) or None when the function returns no CIGAR."""
+    L = stage_lib()
+    L.ref_gen_cigar2.restype = C.c_int
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+    query = np.ascontiguousarray(query, dtype=np.uint8)
+    n = query.shape[0] + max(int(re - rb), 0)
+    cig = np.zeros(n + 2, np.uint32)
+    md = np.zeros(2 * n + 16, np.uint8)
+    out = np.zeros(4, np.int32)
+    rc = L.ref_gen_cigar2(C.c_void_p(fwd.ctypes.data), C.c_int64(fwd.shape[0]), C.c_int(a), C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins),
+                          C.c_int(int(w_)), C.c_int(query.shape[0]), C.c_void_p(query.ctypes.data), C.c_int64(int(rb)), C.c_int64(int(re)), C.c_void_p(out.ctypes.data),
+                          C.c_void_p(cig.ctypes.data), C.c_int(cig.shape[0]), C.c_void_p(md.ctypes.data), C.c_int(md.shape[0]))
+    if rc == -1:
+        return None
+    assert rc == 0, rc
+    return int(out[0]), cig[:int(out[1])].copy(), int(out[2]), md[:int(out[3])].tobytes()
+
+
 def kswv_batch(jobs, ref, qer, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
     """sort_classify + mem_sam_pe_batch of the compiled reference (its AVX-512 kswv kernels) on the jobs: KSWR_DTYPE records."""
     from oracle_py import KSWV_JOB_DTYPE, KSWR_DTYPE

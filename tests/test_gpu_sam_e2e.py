@@ -311,7 +311,7 @@ def test_sam_identical_mixed_250bp_high_error_paired(tmp_path):
     diff = [(x, y) for x, y in zip(got, want) if x != y]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
     err = r.stderr.decode()
-    m = list(re.finditer(r"ksw_global2 calls answered from the table (\d+), computed by the reference's function (\d+)", err))
+    m = list(re.finditer(r"bwa_gen_cigar2 calls answered from the table (\d+), computed by the reference's function (\d+)", err))
     assert m and int(m[-1].group(1)) > 5000 and int(m[-1].group(1)) > 20 * int(m[-1].group(2)), err[-1500:]   # the CIGAR table answers (nearly) all calls
     assert re.search(r"0 reads chained on the host", err)
     m = list(re.finditer(r"mate rescue on the device: (\d+) Smith-Waterman jobs posed.*took from the table (\d+), run by the reference's kernels (\d+)", err))
@@ -319,6 +319,46 @@ def test_sam_identical_mixed_250bp_high_error_paired(tmp_path):
     # and with the CIGAR stage / the mate-rescue stage off the same SAM comes out (the tables only ever replace identical answers)
     got2 = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CIGAR="0", MEME_DROPIN_MATESW="0"), threads=8, chunk=700000)
     assert got2 == got
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_with_smart_pairing_and_with_scores_beyond_the_seed_filter(tmp_path):
+    """(1) `mem -p` (MEM_F_SMARTPE, src/fastmap.cpp:790-828): one interleaved file with a few unpaired reads in it; every chunk is split in
+    two arrays of the aligner's own, each processed with a stack-local copy of the options -- nothing the binding's reader handed out, so
+    nothing may run ahead of its turn (the chunk prefetcher of round 4 raced here).  Several chunks, with the binding's reader on and off.
+    (2) -W with a match score beyond the device seed filter's 12-bit packing (199 x 25 >= 4096): the run falls back to the reference's
+    per-batch extension functions instead of stopping in its first chunk."""
+    g = synth.make_genome(400_000, seed=141, repeat_frac=0.06, n_families=5, n_dups=5, dup_len=1200)
+    fa = str(tmp_path / "p.fa")
+    synth.write_fasta(fa, g, contigs=3)
+    prefix = build_index(fa, bits=14)
+    a, b = _pe_reads(g, 3000, 150, 142, 0.01, 0.0015)
+    rng = np.random.default_rng(143)
+    fq = str(tmp_path / "inter.fq")
+    with open(fq, "w") as fh:
+        for k in range(a.shape[0]):
+            mates = ((a[k], "/1"), (b[k], "/2")) if rng.random() > 0.04 else ((a[k], ""),)        # ~4 % singletons between the pairs
+            for r, suf in mates:
+                fh.write("@i%d%s\n%s\n+\n%s\n" % (k, suf, "".join("ACGTN"[c] for c in r), "I" * len(r)))
+    for chunk in (100000000, 250000):
+        want = _sam("bwa-meme_mode3", prefix, [fq], threads=8, chunk=chunk, opts=("-p",))
+        for extra in ({}, {"MEME_DROPIN_IO": "0"}, {"MEME_DROPIN_VIRTUAL": "2"}):
+            got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, **extra), threads=8, chunk=chunk, opts=("-p",))
+            assert len(got) == len(want) and len(want) > 5500
+            diff = [(x, y) for x, y in zip(got, want) if x != y]
+            assert not diff, "-p chunk=%d %r: first differing SAM line:\n%s\n%s" % ((chunk, extra) + diff[0])
+    f1, f2 = str(tmp_path / "w1.fq"), str(tmp_path / "w2.fq")
+    synth.write_fastq(f1, a[:1500], prefix="w")
+    synth.write_fastq(f2, b[:1500], prefix="w")
+    opts = ("-W", "5", "-A", "25", "-B", "60", "-O", "90", "-E", "20", "-L", "80", "-U", "200", "-T", "600")
+    want = _sam("bwa-meme_mode3", prefix, [f1, f2], threads=8, opts=opts)
+    err = []
+    got = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix), threads=8, opts=opts, stderr=err)
+    assert "beyond the device seed filter's limits" in err[0]
+    assert len(got) == len(want) and len(want) > 3000
+    diff = [(x, y) for x, y in zip(got, want) if x != y]
+    assert not diff, "-A 25: first differing SAM line:\n%s\n%s" % diff[0]
 
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),

@@ -236,6 +236,28 @@ def test_ksw_global2_oracle_equals_reference_golden():
         assert sc == int(G["score"][k]) and np.array_equal(cg, G["cigars"][off[k]:off[k + 1]]), (k, sc, int(G["score"][k]))
 
 
+def test_gen_cigar2_oracle_equals_reference_golden():
+    """orc_gen_cigar2 (bwa_gen_cigar2 whole) against score, CIGAR, NM and MD string of the compiled reference's function
+    (tests/golden/gencig_golden.npz, 3 334 calls: both strands, the gap-free shortcut, band arguments 0..400, indels up to 30 bases, N)."""
+    import numpy as np
+    from common import gencig_workload
+    from pymeme import hipapi
+    g, reads, calls = gencig_workload()
+    text = hipapi.fwd_rc_text(g)
+    G = np.load(os.path.join(GOLDEN, "gencig_golden.npz"))
+    off = np.concatenate([[0], np.cumsum(G["n_cigar"])])
+    mds = G["md"].tobytes().split(b"\0")
+    assert G["score"].shape[0] == calls.shape[0]
+    for k, J in enumerate(calls):
+        q = reads[int(J["read"])][int(J["qb"]):int(J["qb"]) + int(J["qlen"])]
+        sc, cg, nm, md = O.gen_cigar2(text, g.shape[0], q, int(J["rb"]), int(J["rb"]) + int(J["tlen"]), int(J["w_"]))
+        assert sc == int(G["score"][k]) and np.array_equal(cg, G["cigars"][off[k]:off[k + 1]]) and nm == int(G["nm"][k]) and md == mds[k], (k, sc, nm, md, mds[k])
+    # calls the function rejects: empty spans, a target bridging the two strands
+    l_pac = g.shape[0]
+    assert O.gen_cigar2(text, l_pac, reads[0][:50], l_pac - 20, l_pac + 30, 10) is None
+    assert O.gen_cigar2(text, l_pac, reads[0][:50], 100, 100, 10) is None
+
+
 def test_kswv_oracle_equals_reference_golden():
     """orc_kswv_batch against the kswr_t records of the compiled reference's mate-rescue batch (sort_classify + mem_sam_pe_batch with the AVX-512
     kswv kernels; tests/golden/kswv_golden.npz): 5 500 jobs in three sets -- int8 and int16 classes, reads inside / hanging over / missing

@@ -149,6 +149,24 @@ def test_ksw_global2_oracle_equals_reference_on_other_penalties():
 
 
 @needs_stage
+def test_gen_cigar2_oracle_equals_reference_on_other_penalties():
+    """orc_gen_cigar2 == the compiled reference's bwa_gen_cigar2 (score, CIGAR, NM, MD) with other scores: the band derivation
+    (src/bwa.cpp:306-316) depends on match score and gap penalties."""
+    from common import gencig_workload
+    from pymeme import hipapi
+    g, reads, calls = gencig_workload(n=500, seed=211)
+    text = hipapi.fwd_rc_text(g)
+    for pen in ((2, 3, 4, 2, 7, 1), (1, 9, 1, 1, 1, 1), (3, 1, 5, 3, 2, 2)):
+        for J in calls:
+            q = reads[int(J["read"])][int(J["qb"]):int(J["qb"]) + int(J["qlen"])]
+            rb, re = int(J["rb"]), int(J["rb"]) + int(J["tlen"])
+            want = ref_py.gen_cigar2(g, q, rb, re, int(J["w_"]), *pen)
+            got = O.gen_cigar2(text, g.shape[0], q, rb, re, int(J["w_"]), *pen)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]) and got[2:] == want[2:], (pen, J, got[0], want[0], got[2:], want[2:])
+    assert ref_py.gen_cigar2(g, reads[0][:50], g.shape[0] - 20, g.shape[0] + 30, 10) is None
+
+
+@needs_stage
 def test_kswv_oracle_equals_reference_live():
     """orc_kswv_batch == the compiled reference's mate-rescue batch (ref_kswv_batch: sort_classify + mem_sam_pe_batch, AVX-512 kswv kernels) on
     fresh job sets: other seeds, short reads, extreme penalties (free gap opens; mismatch 9), windows shorter than the read."""
