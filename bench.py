@@ -24,7 +24,7 @@ per step, default 10,000,000), MEME_BENCH_BITS (P-RMI leaves = 2^bits, default: 
 MEME_BENCH_LANES (lanes per read in the SA-search kernel), MEME_BENCH_CPU (reference | port | 0; default: the
 compiled reference, timed in this run), MEME_BENCH_CPU_READS (sample size), MEME_BENCH_CACHE (0 disables the /dev/shm caches),
 MEME_BENCH_SA (device | host: where the suffix array is built), MEME_BENCH_CHAIN / MEME_BENCH_BSW / MEME_BENCH_E2E (0 disables the leg), MEME_BENCH_E2E_PAIRS (read pairs of the end-to-end leg, default
-2,000,000), MEME_BENCH_BUDGET_S (wall budget in seconds after which optional legs are skipped, default 1500).
+10,000,000 = BASELINE configs[2]), MEME_BENCH_C4 / MEME_BENCH_C4_E2E (0 disables the configs[4]-class leg / its end-to-end part), MEME_BENCH_BUDGET_S (wall budget in seconds after which optional legs are skipped, default 1500).
 """
 import argparse
 import json
@@ -167,8 +167,8 @@ def _canon_seeds(rid, start, end, hitbeg, hitcount, hits, hit_base):
 
 def seeds_equal_oracle(ctx, O, o_idx, part, opt):
     """The GPU's seeds of `part` (through the C ABI) against oracle/meme_oracle.c orc_seed_batch: every SMEM, every hit position."""
-    n = part.shape[0]
-    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    n, rl = part.shape
+    off = np.arange(0, (n + 1) * rl, rl, dtype=np.int64)
     g_sm, g_so, g_h, g_ho = ctx.seed_batch(part, off, opt)
     cap, hcap = 256, 2048
     while True:
@@ -193,10 +193,10 @@ def algorithmic_bytes_per_read(text, sa, l1, l2, reads):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_py as O
     idx = O.Index(text, sa)
-    n = reads.shape[0]
-    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    n, rl = reads.shape
+    off = np.arange(0, (n + 1) * rl, rl, dtype=np.int64)
     _, _, ctr = O.refpath_seed_batch(idx, l1, l2, reads, off, threads=0, keep_smems=False)
-    return O.algorithmic_bytes(ctr, n * READ_LEN) / n, {k: v / n for k, v in ctr.items()}
+    return O.algorithmic_bytes(ctr, n * rl) / n, {k: v / n for k, v in ctr.items()}
 
 
 def leg_contigs(l_pac, k=4):
@@ -211,8 +211,8 @@ def chain_leg(ctx, reads, l_pac, nsub=2000000):
     against the oracle's restatement (pinned on the compiled reference's chains, tests/golden/chain_golden.npz)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_py
-    n = min(nsub, reads.shape[0])
-    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    n, rl = min(nsub, reads.shape[0]), reads.shape[1]
+    off = np.arange(0, (n + 1) * rl, rl, dtype=np.int64)
     smems, smem_off, hits, hit_off = ctx.seed_batch_host(reads[:n].reshape(-1), off)
     contigs = leg_contigs(l_pac)
     res = ctx.chain_last_batch_host(contigs, hipapi.default_chain_opt(l_pac))
@@ -220,7 +220,7 @@ def chain_leg(ctx, reads, l_pac, nsub=2000000):
     tm = ctx.timings()
     # every read of the leg against the oracle's restatement (batched C call, all host cores)
     copt = oracle_py.default_chain_opt(l_pac)
-    n_bad, first_bad = oracle_py.chain_compare_batch(smems, smem_off, hits, hit_off, np.full(n, READ_LEN, np.int32), np.array([c[0] for c in contigs], np.int64),
+    n_bad, first_bad = oracle_py.chain_compare_batch(smems, smem_off, hits, hit_off, np.full(n, rl, np.int32), np.array([c[0] for c in contigs], np.int64),
                                                      np.zeros(len(contigs), np.uint8), copt, res)
     same, checked = n_bad == 0 and res["n_fallback"] == 0, n
     if not same:
@@ -232,23 +232,30 @@ def chain_leg(ctx, reads, l_pac, nsub=2000000):
             "checked_reads": checked}
 
 
+def infer_bw(l1, l2, score, a, q, r):
+    """infer_bw (src/bwamem.cpp:2151-2158), vectorised"""
+    w = ((np.minimum(l1, l2) * a - score - q) / float(r) + 2.).astype(np.int64)          # (the C cast truncates toward zero, as astype does)
+    w = np.maximum(w, np.abs(l1 - l2))
+    return np.where((l1 == l2) & (l1 * a - score < ((q + r - a) << 1)), 0, w)
+
+
 def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
-    """The stages behind seeding, on the device: chaining + seed extension of `nsub` of the benchmark's reads without leaving
-    HBM (meme_extend_last_batch_host: the host receives alignment records), then the CIGAR kernel (meme_global_batch_host) on the best
-    record of `ncig` reads.  Kernel times by HIP events; EVERY record is compared with the oracle's restatement of
-    mem_chain2aln_across_reads_V2 (orc_extend_batch on the device's chains, themselves checked by the chain leg), and the CIGARs of a
-    sample with orc_ksw_global2."""
+    """The stages behind seeding, on the device: chaining + seed extension of `nsub` of the reads without leaving
+    HBM (meme_extend_last_batch_host: the host receives alignment records), then bwa_gen_cigar2 whole (meme_gen_cigar_batch_host: CIGAR, NM,
+    MD) for the best record of `ncig` reads, called with the band argument mem_reg2aln would pass first.  Kernel times by HIP events; EVERY
+    record is compared with the oracle's restatement of mem_chain2aln_across_reads_V2 (orc_extend_batch on the device's chains, themselves
+    checked by the chain leg), and CIGAR / NM / MD of a sample with orc_gen_cigar2 (pinned on the compiled reference's function)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_py
-    n = min(nsub, reads.shape[0])
-    off = np.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=np.int64)
+    n, rl = min(nsub, reads.shape[0]), reads.shape[1]
+    off = np.arange(0, (n + 1) * rl, rl, dtype=np.int64)
     ctx.seed_batch_host(reads[:n].reshape(-1), off)
     contigs = leg_contigs(l_pac)
     copt = hipapi.default_chain_opt(l_pac)
     R = ctx.extend_last_batch_host(contigs, copt)
     R = ctx.extend_last_batch_host(contigs, copt)          # (second call: buffers exist)
-    ctx.set_tuning("ext_census", 1)                        # (a third, untimed call: how many of the jobs a closed form could answer)
-    census = ctx.extend_last_batch_host(contigs, copt)["n_exact_prefix"]
+    ctx.set_tuning("ext_census", 1)                        # (a third, untimed call: what the jobs are -- LDS classes, band cells, how many a closed form could answer)
+    C3 = ctx.extend_last_batch_host(contigs, copt)
     ctx.set_tuning("ext_census", 0)
     ch = ctx.chain_last_batch_host(contigs, copt)
     text = hipapi.fwd_rc_text(genome)
@@ -256,37 +263,44 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
                                                   ch["seeds"], ch["frac_rep"], text, l_pac, np.array([c[0] for c in contigs], np.int64),
                                                   np.array([c[1] for c in contigs], np.int32))
     same = np.array_equal(R["reg_off"], ch["seed_off"]) and all(np.array_equal(R["regs"][f].astype(np.int64), want[f].astype(np.int64)) for f in oracle_py.ALNREG_FIELDS)
-    out = {"metric": "extend_reads_per_sec", "value": n / ((R["chain_ms"] + R["ext_ms"]) * 1e-3) if same else None, "unit": "reads/s", "reads": n,
+    first = max(R["n_pairs"] - R["n_retried"], 1)
+    cls = C3["census_class"]
+    out = {"metric": "extend_reads_per_sec", "value": n / ((R["chain_ms"] + R["ext_ms"]) * 1e-3) if same else None, "unit": "reads/s", "reads": n, "read_len": rl,
            "chain_ms": R["chain_ms"], "ext_ms": R["ext_ms"], "bsw_ms": R["bsw_ms"], "alignment_records": int(R["regs"].shape[0]), "extension_jobs": R["n_pairs"],
            "jobs_with_doubled_band": R["n_retried"], "reads_in_wavefront_tiers": R["n_tier2"], "matches_oracle": bool(same), "checked_records": int(want.shape[0]),
-           "exact_prefix_jobs": int(census), "exact_prefix_share": census / max(R["n_pairs"] - R["n_retried"], 1)}
-    # CIGAR kernel: the global alignment mem_reg2aln would pose for every read's best live record (band as bwa_gen_cigar2 sets it for w_ = 100)
+           "exact_prefix_jobs": int(C3["n_exact_prefix"]), "exact_prefix_share": C3["n_exact_prefix"] / first,
+           # cells of the jobs' band-limited matrices (first attempts; the kernel trims rows and stops at z-drop, so it evaluates fewer)
+           "band_cells_per_job": C3["census_band_cells"] / first, "gcups_band_cells": (C3["census_band_cells"] / 1e9) / (R["bsw_ms"] * 1e-3) if R["bsw_ms"] > 0 else None,
+           "jobs_by_lds_class": {"query<=%d" % q: cls[i] / first for i, q in enumerate((30, 62, 94, 126, 158, 222, 318, 600))} | {"query>600": cls[8] / first}}
+    # bwa_gen_cigar2 for every read's best live record, called as mem_reg2aln calls it first (src/bwamem.cpp:2333-2342 with a 1, o 6, e 1, w 100)
     regs, ro = R["regs"], R["reg_off"]
     rid = np.repeat(np.arange(n), np.diff(ro))
-    live = np.nonzero((regs["qe"] > regs["qb"]) & (regs["rb"] >= 0) & (rid < ncig) & ((regs["rb"] < l_pac) == (regs["re"] <= l_pac)))[0]
+    live = np.nonzero((regs["qe"] > regs["qb"]) & (regs["rb"] >= 0) & (regs["re"] > regs["rb"]) & (rid < ncig) & ((regs["rb"] < l_pac) == (regs["re"] <= l_pac)))[0]
     live = live[np.lexsort((-regs["score"][live].astype(np.int64), rid[live]))]
     best = live[np.concatenate([[True], rid[live][1:] != rid[live][:-1]])] if live.shape[0] else live
     ql = (regs["qe"][best] - regs["qb"][best]).astype(np.int64)
     tl = (regs["re"][best] - regs["rb"][best]).astype(np.int64)
-    max_gap = np.maximum(1, (((ql + 1) >> 1) * 1 - 6) // 1 + 1)                     # src/bwa.cpp:308-311 with a 1, o 6, e 1
-    w = np.maximum(np.minimum((max_gap + np.abs(tl - ql) + 1) >> 1, 100), np.abs(tl - ql) + 3)
-    J = np.zeros(best.shape[0], dtype=hipapi.GJOB)
-    J["rb"], J["read"], J["qb"], J["qlen"], J["tlen"], J["w"] = regs["rb"][best], rid[best], regs["qb"][best], ql, tl, w
-    J["rev"] = regs["rb"][best] >= l_pac
-    res, cig, ms = ctx.global_batch_host(J)
-    res, cig, ms = ctx.global_batch_host(J)
+    sc = regs["truesc"][best].astype(np.int64)
+    w2 = np.maximum(infer_bw(ql, tl, sc, 1, 6, 1), infer_bw(ql, tl, sc, 1, 6, 1))
+    w2 = np.where(w2 > 100, np.minimum(w2, regs["w"][best].astype(np.int64)), w2)
+    w2 = np.minimum(w2, 400)
+    J = np.zeros(best.shape[0], dtype=hipapi.CJOB)
+    J["rb"], J["read"], J["qb"], J["qlen"], J["tlen"], J["w_"] = regs["rb"][best], rid[best], regs["qb"][best], ql, tl, w2
+    res, cig, md, ms = ctx.gen_cigar_batch_host(J)
+    res, cig, md, ms = ctx.gen_cigar_batch_host(J)
     ok = True
-    for k in range(0, J.shape[0], max(1, J.shape[0] // 20000)):
+    step = max(1, J.shape[0] // 20000)
+    for k in range(0, J.shape[0], step):
         j = J[k]
         q = reads[int(j["read"])][int(j["qb"]):int(j["qb"]) + int(j["qlen"])]
-        t = text[int(j["rb"]):int(j["rb"]) + int(j["tlen"])]
-        if j["rev"]:
-            q, t = q[::-1], t[::-1]
-        sc, cg = oracle_py.ksw_global2(q, t, int(j["w"]))
-        o0 = int(res["cigar_off"][k])
-        ok = ok and sc == int(res["score"][k]) and np.array_equal(cg, cig[o0:o0 + int(res["n_cigar"][k])])
+        o_sc, o_cg, o_nm, o_md = oracle_py.gen_cigar2(text, l_pac, q, int(j["rb"]), int(j["rb"]) + int(j["tlen"]), int(j["w_"]))
+        r = res[k]
+        o0, m0 = int(r["cigar_off"]), int(r["md_off"])
+        ok = ok and o_sc == int(r["score"]) and o_nm == int(r["nm"]) and np.array_equal(o_cg, cig[o0:o0 + int(r["n_cigar"])]) and o_md == md[m0:m0 + int(r["md_len"])].tobytes()
+    nogap = int(np.sum((ql == tl) & (w2 == 0)))
     out["cigar"] = {"metric": "cigar_alignments_per_sec", "value": J.shape[0] / (ms * 1e-3) if ok and ms > 0 else None, "unit": "alignments/s", "alignments": int(J.shape[0]),
-                    "kernel_ms": ms, "operations": int(cig.shape[0]), "matches_oracle": bool(ok), "checked": int(len(range(0, J.shape[0], max(1, J.shape[0] // 20000))))}
+                    "what": "bwa_gen_cigar2 whole (meme_gen_cigar_batch_host): CIGAR + NM + MD", "gap_free_shortcut_share": nogap / max(J.shape[0], 1),
+                    "kernel_ms": ms, "operations": int(cig.shape[0]), "md_bytes": int(md.shape[0]), "matches_oracle": bool(ok), "checked": int(len(range(0, J.shape[0], step)))}
     return out
 
 
@@ -436,15 +450,77 @@ def bsw_leg(ctx, dev, world):
             "cpu_baseline": cpu}
 
 
+def config4_class_leg(ctx, dev, genome, text, sa, l1, l2, l_pac, steps=3):
+    """BASELINE configs[4]'s read class on the benchmark index, one GPU: 250-bp reads with 5 % substitutions and 0.75 % single-base indels
+    (both mates of synthetic pairs, so both strands).  Seeding reads/s with its own algorithmic bytes per read and roofline fraction, then
+    the stages behind it (chaining, extension with the banded-SW jobs' LDS classes and band cells, bwa_gen_cigar2 whole), every stage
+    checked against the oracle as the 150-bp legs are.  The end-to-end part of the class is run by main() after the HBM is free."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py as O
+    rl, sub, indel = 250, 0.05, 0.0075
+    nreads = int(os.environ.get("MEME_BENCH_C4_READS", "2000000"))
+    rng = np.random.default_rng(4004)
+    parts = []
+    for p0 in range(0, nreads // 2, 1 << 18):
+        r1, r2 = workload.make_pairs_chunk(genome, min(1 << 18, nreads // 2 - p0), rl, rng, sub, indel)
+        parts += [r1, r2]
+    reads = np.ascontiguousarray(np.concatenate(parts))
+    nreads = reads.shape[0]
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(0, (nreads + 1) * rl, rl, dtype=torch.int64, device=dev)
+    opt = hipapi.default_seed_opt(rounds=3)
+    res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), nreads, nreads * rl, opt)
+    ctx.sync()
+    k_ms, wall = [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        res = ctx.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), nreads, nreads * rl, opt)
+        ctx.sync()
+        wall.append(time.perf_counter() - t0)
+        tm = ctx.timings()
+        k_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms, tm.seed_reseed_ms, tm.seed_windows))
+    del d_reads, d_off
+    stage_ms = float(np.mean([k[0] for k in k_ms]))
+    bpr, per_read = algorithmic_bytes_per_read(text, sa, l1, l2, reads[:8000])
+    o_idx = O.Index(text, sa)
+    npar = min(nreads, int(os.environ.get("MEME_BENCH_C4_PARITY_READS", "100000")))
+    parity = all(seeds_equal_oracle(ctx, O, o_idx, reads[p0:p0 + 25000], opt) for p0 in range(0, npar, 25000))
+    achieved = bpr * nreads / (stage_ms * 1e-3) / 1e9
+    out = {"workload": "%d reads of %d bp, %g %% substitutions, %g %% single-base indels, both strands, vs the benchmark genome (%d bp); reads resident in HBM"
+                       % (nreads, rl, 100 * sub, 100 * indel, l_pac),
+           "seeding": {"metric": "seeding_reads_per_sec", "value": nreads / float(np.mean(wall)) if parity else None, "unit": "reads/s", "reads": nreads, "steps": steps,
+                       "ms_per_step": float(np.mean(wall)) * 1e3, "search_stage_ms": stage_ms, "of_which_reseed_kernels_ms": float(np.mean([k[2] for k in k_ms])),
+                       "pack_gather_ms": float(np.mean([k[1] for k in k_ms])), "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
+                       "searches_per_read": res.searches / nreads, "windows_per_read": k_ms[-1][3] / nreads,
+                       "algorithmic_bytes_per_read": bpr, "work_per_read": per_read,
+                       "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0},
+                       "matches_oracle": bool(parity), "checked_reads": npar}}
+    out["chain"] = chain_leg(ctx, reads, l_pac, nsub=nreads)
+    out["ext"] = ext_leg(ctx, reads, genome, l_pac, nsub=nreads, ncig=min(nreads, 400000))
+    return out
+
+
 def sam_md5(path):
+    """md5 and line count of a SAM file without its @PG line (it holds the command line).  Header lines are read one by one, the records in blocks."""
     import hashlib
     h = hashlib.md5()
     nlines = 0
     with open(path, "rb") as fh:
-        for line in fh:
+        while True:
+            pos = fh.tell()
+            line = fh.readline()
+            if not line.startswith(b"@"):
+                fh.seek(pos)
+                break
             if not line.startswith(b"@PG"):
                 h.update(line)
                 nlines += 1
+        while True:
+            blk = fh.read(1 << 24)
+            if not blk:
+                break
+            h.update(blk)
+            nlines += blk.count(b"\n")
     return h.hexdigest(), nlines
 
 
@@ -496,11 +572,13 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
     ref_dir = os.path.join(REPO, "oracle", "_ref")
     # (a probe may name several builds of the bound aligner, e.g. "bwa-meme_dropin,bwa-meme_dropin_prof" -- the second with SAM-phase timers:
     # the first is the one reported, the others land under "extra_runs")
+    # (an entry may carry environment settings of its own: "bwa-meme_dropin@MEME_DROPIN_CIGAR=0"; a path below oracle/_ref is allowed:
+    # "r04/bwa-meme_dropin_r04", a build of an earlier round with its own libraries beside it, for an A/B on one box)
     dropin_exes = os.environ.get("MEME_BENCH_E2E_DROPIN_EXE", "bwa-meme_dropin").split(",")
     dropin_exe = dropin_exes[0]
     skip_ref = os.environ.get("MEME_BENCH_E2E_SKIP_REF") == "1"                       # probes of the bound aligner alone: sam_identical is then null
-    for exe in ("bwa-meme_mode3", dropin_exe):
-        if not os.path.exists(os.path.join(ref_dir, exe)):
+    for exe in ["bwa-meme_mode3"] + dropin_exes:
+        if not os.path.exists(os.path.join(ref_dir, exe.split("@")[0])):
             raise RuntimeError("%s not built" % exe)
     d = tempfile.mkdtemp(prefix="meme_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
@@ -527,10 +605,11 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
                 continue
             if exe == "bwa-meme_mode3" and skip_ref:
                 continue
-            sam = os.path.join(d, exe + ".sam")
+            sam = os.path.join(d, re.sub(r"[^A-Za-z0-9_.=-]", "_", exe) + ".sam")
             env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_DEVICES=str(devices))
-            if exe.endswith("_prof"):
-                env["MEME_DROPIN_PROFILE_SAM"] = "1"
+            spec, exe = exe, exe.split("@")[0]
+            for kv in spec.split("@")[1:]:
+                env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
             # Both binaries run on glibc malloc (the reference's default build would link mimalloc, a submodule that is not in the tree), and
             # the SAM phase is allocator-bound: both get the same allocator settings -- freed memory stays in the arenas, a deep per-thread
             # cache (profiles/r04_e2e.md: 2.4 -> 1.3 s of mem_process_seqs per 4 M reads for the drop-in)
@@ -549,12 +628,28 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
             err = r.stderr.decode(errors="replace")
             if os.environ.get("MEME_BENCH_E2E_STDERR"):            # keep the aligner's own profile / the binding's per-chunk report
                 os.makedirs(os.environ["MEME_BENCH_E2E_STDERR"], exist_ok=True)
-                open(os.path.join(os.environ["MEME_BENCH_E2E_STDERR"], "%s_%dbp.stderr" % (exe, read_len)), "w").write(err)
+                open(os.path.join(os.environ["MEME_BENCH_E2E_STDERR"], "%s_%dbp.stderr" % (re.sub(r"[^A-Za-z0-9_.=-]", "_", spec), read_len)), "w").write(err)
             if r.returncode != 0:
                 raise RuntimeError("%s failed: %s" % (exe, err[-800:]))
             proc = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
             proc_cpu = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in ([0-9.]+) CPU sec", err))
             md5, nlines = sam_md5(sam)
+            # (probes of run-to-run stability: MEME_BENCH_E2E_KEEP_DIFF=1 keeps the first SAM file and writes the records in which a later
+            # run differs from it next to the aligners' stderr)
+            if os.environ.get("MEME_BENCH_E2E_KEEP_DIFF") and os.environ.get("MEME_BENCH_E2E_STDERR"):
+                first_sam = os.path.join(d, "first.sam")
+                if not os.path.exists(first_sam):
+                    os.rename(sam, first_sam)
+                    open(sam, "wb").close()
+                else:
+                    nd = 0
+                    with open(first_sam, "rb") as fa, open(sam, "rb") as fb, open(os.path.join(os.environ["MEME_BENCH_E2E_STDERR"], "diff_%s.txt" % re.sub(r"[^A-Za-z0-9_.=-]", "_", spec)), "wb") as fo:
+                        for la, lb in zip(fa, fb):
+                            if la != lb and not la.startswith(b"@PG"):
+                                nd += 1
+                                if nd <= 200:
+                                    fo.write(b"< " + la + b"> " + lb)
+                    log("e2e: %s differs from the first run in %d records" % (spec, nd))
             os.remove(sam)
             info = {"threads": nthr, "wall_s": wall, "process_s": proc, "process_cpu_s": proc_cpu, "reads_per_s_wall": 2 * npairs / wall,
                     "reads_per_s_process": 2 * npairs / proc if proc > 0 else None, "sam_md5": md5, "sam_lines": nlines}
@@ -589,10 +684,10 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
             prof = re.findall(r"\[meme-dropin-prof\]   (.+?)\s+([0-9.]+) s\s+(\d+) calls", err)
             if prof:
                 info["sam_phase_thread_seconds"] = {k.strip(): {"s": float(v), "calls": int(c)} for k, v, c in prof}
-            out[exe] = info
+            out[spec] = info
             if exe == "bwa-meme_mode3" and refcache is not None:
                 refcache.put(ckey, info)
-            log("e2e: %s wall %.1f s, process %.1f s, %d SAM lines" % (exe, wall, proc, nlines))
+            log("e2e: %s wall %.1f s, process %.1f s (CPU %.1f s), %d SAM lines" % (spec, wall, proc, proc_cpu, nlines))
         ref, drop = out.get("bwa-meme_mode3"), out[dropin_exe]
         return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
                 "workload": "mem -7 (reference: -t %s, its best of a 32-256 sweep; with the backend bound: -t %d), %d pairs of %d-bp reads (%g %% substitutions, %g %% indels, "
@@ -602,6 +697,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
                              "mmap threshold 32 MB) and buffers stdout (16 MB)" % MALLOC_TUNABLES,
                 "threads": threads, "pairs": npairs, "read_len": read_len, "gpus_driven_by_the_one_aligner_process": devices,
                 "sam_identical": bool(ref["sam_md5"] == drop["sam_md5"]) if ref else None,
+                "extra_runs_sam_identical_to_the_first": all(out[e]["sam_md5"] == drop["sam_md5"] for e in dropin_exes[1:]) if len(dropin_exes) > 1 else None,
                 "dropin": drop, "reference": ref, "extra_runs": {e: out[e] for e in dropin_exes[1:]} or None, "speedup_wall": ref["wall_s"] / drop["wall_s"] if ref else None,
                 "speedup_process": (ref["process_s"] / drop["process_s"]) if ref and drop["process_s"] > 0 else None}
     finally:
@@ -1002,6 +1098,16 @@ def main():
             except Exception as e:
                 log("ext leg failed: %r" % (e,))
                 out["ext"] = None
+        # ---- BASELINE configs[4]'s read class (250 bp, 5 % substitutions, 0.75 % indels) through the same stages -------------------------------
+        if single and os.environ.get("MEME_BENCH_C4", "1") != "0":
+            if time.time() - T_START > budget - 700:
+                out["config4_class"] = {"skipped": "wall budget (%d s) nearly used up after %.0f s" % (budget, time.time() - T_START)}
+            else:
+                try:
+                    out["config4_class"] = config4_class_leg(ctx, dev, fwd, text, sa, l1, l2, l_pac)
+                except Exception as e:
+                    log("config4_class leg failed: %r" % (e,))
+                    out["config4_class"] = {"failed": repr(e)[:300]}
         # ---- e2e: BASELINE.json's second metric, the drop-in next to the unmodified reference (last: it needs the HBM) --------
         if single and os.environ.get("MEME_BENCH_E2E", "1") != "0":
             if not ref_prefix:
@@ -1017,11 +1123,23 @@ def main():
                     torch.cuda.empty_cache()
                     if world > 1:                    # the other ranks' processes release their GPUs when they exit
                         wait_for_free_gpus(world)
-                    out["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_E2E_PAIRS", "2000000")), cores, devices=world,
+                    # BASELINE configs[2] at its stated size: 10 M pairs (MEME_BENCH_E2E_PAIRS is the opt-down for probes)
+                    out["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_E2E_PAIRS", "10000000")), cores, devices=world,
                                          refcache=refcache)
                 except Exception as e:
                     log("e2e leg failed: %r" % (e,))
                     out["e2e"] = {"failed": repr(e)[:300]}
+                c4 = out.get("config4_class")
+                if isinstance(c4, dict) and "seeding" in c4 and os.environ.get("MEME_BENCH_C4_E2E", "1") != "0":
+                    if time.time() - T_START > budget - 450:
+                        c4["e2e"] = {"skipped": "wall budget (%d s) nearly used up after %.0f s" % (budget, time.time() - T_START)}
+                    else:
+                        try:
+                            c4["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_C4_E2E_PAIRS", "500000")), cores, devices=world, refcache=refcache,
+                                                read_len=250, sub=0.05, indel=0.0075, seed=4005)
+                        except Exception as e:
+                            log("config4_class e2e failed: %r" % (e,))
+                            c4["e2e"] = {"failed": repr(e)[:300]}
         print(json.dumps(out), flush=True)
         if not sample_parity:
             rc_exit = 1

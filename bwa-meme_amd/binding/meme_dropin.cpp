@@ -38,6 +38,54 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }
 bool verbose() { static const bool v = getenv("MEME_DROPIN_VERBOSE") != nullptr; return v; }
 
+// ---- the helper team (see meme_dropin.h) ----------------------------------------------------------------------------------------
+namespace {
+struct TeamJob { const std::function<void(int)>* f; int nt; std::atomic<int> next{0}, done{0}; };
+struct Team {
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<TeamJob*> q;
+    int threads = 0;
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_work.wait(lk, [&] { return !q.empty(); });
+            TeamJob* J = q.front();
+            const int t = J->next.fetch_add(1);
+            if (t >= J->nt) { if (!q.empty() && q.front() == J) q.pop_front(); continue; }
+            if (t + 1 == J->nt && !q.empty() && q.front() == J) q.pop_front();      // the last share is taken: nobody else needs to look at this job
+            lk.unlock();
+            (*J->f)(t);
+            lk.lock();
+            if (J->done.fetch_add(1) + 1 == J->nt) cv_done.notify_all();
+        }
+    }
+};
+Team& team() { static Team* T = new Team; return *T; }                          // (never destroyed: its threads sleep until the process ends)
+}  // namespace
+void team_run(int nt, const std::function<void(int)>& f) {
+    if (nt <= 1) { if (nt == 1) f(0); return; }
+    Team& T = team();
+    TeamJob J;
+    J.f = &f; J.nt = nt;
+    {
+        std::lock_guard<std::mutex> lk(T.m);
+        const int want = nt - 1 < 48 ? nt - 1 : 48;
+        while (T.threads < want) { std::thread([&T] { T.worker(); }).detach(); ++T.threads; }
+        T.q.push_back(&J);
+    }
+    T.cv_work.notify_all();
+    for (;;) {                                                       // the submitter takes shares of its own job
+        const int t = J.next.fetch_add(1);
+        if (t >= nt) break;
+        f(t);
+        J.done.fetch_add(1);
+    }
+    std::unique_lock<std::mutex> lk(T.m);
+    for (auto it = T.q.begin(); it != T.q.end(); ++it) if (*it == &J) { T.q.erase(it); break; }    // (all shares are out: no helper may pick the job up any more)
+    T.cv_done.wait(lk, [&] { return J.done.load() >= nt; });
+}
+
 // ---- devices -------------------------------------------------------------------------------------------------
 std::vector<Device>& device_slots() { static std::vector<Device>* v = new std::vector<Device>(); return *v; }
 std::mutex g_mu;
@@ -185,8 +233,8 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
     w.rc_pac = ll_pac ? (uint8_t*)malloc((size_t)(ll_pac / 4)) : nullptr;                    // (process() frees it, src/fastmap.cpp:1109)
     if (ll_pac && !w.rc_pac) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
     const uint8_t* pac = aux->fmi->idx->pac;
-#pragma omp parallel for schedule(static)
-    for (int64_t k = 0; k < ll_pac / 4; ++k) {
+    team_for(ll_pac / 4, cig_threads(), [&](int64_t k0, int64_t k1, int) {
+    for (int64_t k = k0; k < k1; ++k) {
         uint8_t b = 0;
         for (int j = 0; j < 4; ++j) {
             const int64_t p = 4 * k + j;
@@ -197,6 +245,7 @@ void memoryAllocLearned(ktp_aux_t* aux, worker_t& w, int32_t nreads, int32_t nth
         }                                                       // (src/LearnedIndex_seeding.h:129-137: it reverses the 2-bit groups) makes of _set_pac's byte
         w.rc_pac[k] = b;
     }
+    });
     w.sa_position = nullptr;                                   // the suffix array lives in HBM
     w.ref2sa = nullptr;
     w.smemBufSize = MAX_LINE_LEN * sizeof(mem_tlv);
@@ -299,20 +348,22 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     // (a few dozen helper threads: an OpenMP team of all 256 host threads takes longer to start than the loop runs, and keeps spinning
     // into the worker phases that follow)
     const bool raw = g_ext_on_device;
-#pragma omp parallel for schedule(static) num_threads(cig_threads())
-    for (int64_t i = 0; i < P.count; ++i) {
-        bseq1_t& s = seqs[P.first + i];
-        uint8_t* dst = P.flat + P.off[i];
-        if (raw) memcpy(dst, s.seq, (size_t)s.l_seq);
-        else for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
-    }
+    team_for(P.count, cig_threads(), [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; ++i) {
+            bseq1_t& s = seqs[P.first + i];
+            uint8_t* dst = P.flat + P.off[i];
+            if (raw) memcpy(dst, s.seq, (size_t)s.l_seq);
+            else for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
+        }
+    });
     std::thread codes;
     if (raw) codes = std::thread([&P, seqs] {
-#pragma omp parallel for schedule(static) num_threads(cig_threads() / 2 > 0 ? cig_threads() / 2 : 1)
-        for (int64_t i = 0; i < P.count; ++i) {
-            bseq1_t& s = seqs[P.first + i];
-            for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; }
-        }
+        team_for(P.count, cig_threads() / 2 > 0 ? cig_threads() / 2 : 1, [&](int64_t i0, int64_t i1, int) {
+            for (int64_t i = i0; i < i1; ++i) {
+                bseq1_t& s = seqs[P.first + i];
+                for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; }
+            }
+        });
     });
     struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join_codes{codes};
     const meme_seed_opt so = seed_opt_of(opt);
@@ -599,7 +650,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
     if (verbose() && !g_ext_on_device && chain_on_device())
         fprintf(stderr, "[meme-dropin] chaining on the device: %lld of %lld reads so far were chained on the host instead\n",
                 (long long)g_n_chain_fallback, (long long)g_n_chain_reads);
-    if (verbose() && getenv("MEME_DROPIN_PROFILE_SAM")) meme_dropin_report_matesw();
+    if (verbose()) meme_dropin_report_matesw();
     if (verbose()) meme_dropin_report_cigar();
     if (verbose()) meme_dropin_report_mate();
 }

@@ -93,6 +93,31 @@ extern mem_chain_v* g_chunk_chain_ar;          // w.chain_ar of the chunk being 
 extern uint64_t g_chunk_gen;                   // counts the chunks seeded
 int cig_threads();                             // helper threads of the binding's own host loops
 
+// The binding's own host loops (gathering reads, posing jobs, taking results, the output step) run on a team of helper threads that SLEEP
+// between jobs.  They were OpenMP regions until round 5: libgomp's idle threads spin before they sleep, and under the CPU quota of the
+// boxes this was measured on (16 CPUs' worth for a process) a spinning helper is paid for with the aligner's worker threads' time --
+// a chunk's mem_pestat phase cost 0.3-0.4 CPU-seconds for 0.03 s of work.  Any thread may submit; the submitter works along.
+//   team_run(nt, f)             f(t) for t in [0, nt), on up to nt threads at once; returns when all are done
+//   team_for(n, nt, f)          f(lo, hi, t): [0, n) in nt contiguous ranges
+void team_run(int nt, const std::function<void(int)>& f);
+template <class F> inline void team_for(int64_t n, int nt, F&& f) {
+    if (nt > n) nt = n > 0 ? (int)n : 1;
+    if (nt <= 1) { f((int64_t)0, n, 0); return; }
+    team_run(nt, [&](int t) { f(n * t / nt, n * (t + 1) / nt, t); });
+}
+// ascending sort of v by `less` on nt threads: runs sorted side by side, merged pairwise
+template <class T, class Less> inline void team_sort(std::vector<T>& v, int nt, Less less) {
+    const int64_t n = (int64_t)v.size();
+    if (n < 65536 || nt < 2) { std::sort(v.begin(), v.end(), less); return; }
+    int runs = 1;
+    while (runs * 2 <= nt && runs < 16) runs *= 2;
+    std::vector<int64_t> cut((size_t)runs + 1);
+    for (int r = 0; r <= runs; ++r) cut[(size_t)r] = n * r / runs;
+    team_run(runs, [&](int r) { std::sort(v.begin() + cut[(size_t)r], v.begin() + cut[(size_t)r + 1], less); });
+    for (int w = 1; w < runs; w *= 2)
+        team_run(runs / (2 * w), [&](int k) { std::inplace_merge(v.begin() + cut[(size_t)(2 * w * k)], v.begin() + cut[(size_t)(2 * w * k + w)], v.begin() + cut[(size_t)(2 * w * k + 2 * w)], less); });
+}
+
 }  // namespace dropin
 
 void meme_dropin_report_matesw();

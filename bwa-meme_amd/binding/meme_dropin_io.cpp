@@ -13,7 +13,6 @@ using namespace dropin;
 #include <map>
 #include <sys/uio.h>
 #include <unistd.h>
-#include <omp.h>
 #include "profiling.h"
 namespace dropin {
 
@@ -229,8 +228,9 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
     const double t0 = now_s();
     std::vector<struct iovec> iov((size_t)n);
     size_t n_iov = 0;
-#pragma omp parallel for schedule(static) num_threads(nt)
-    for (int i = 0; i < n; ++i) { iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0; }
+    team_for(n, nt, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; ++i) { iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0; }
+    });
     for (int i = 0; i < n; ++i) if (iov[(size_t)i].iov_len) iov[n_iov++] = iov[(size_t)i];
     const double t1 = now_s();
     fflush(aux->fp);                                                // (whatever stdio still holds goes first)
@@ -245,11 +245,12 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
         }
     }
     const double t2 = now_s();
-#pragma omp parallel for schedule(static) num_threads(nt)
-    for (int i = 0; i < n; ++i) {
-        free(seqs[i].sam); free(seqs[i].comment);
-        if (!in_arena) { free(seqs[i].name); free(seqs[i].seq); free(seqs[i].qual); }
-    }
+    team_for(n, nt, [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; ++i) {
+            free(seqs[i].sam); free(seqs[i].comment);
+            if (!in_arena) { free(seqs[i].name); free(seqs[i].seq); free(seqs[i].qual); }
+        }
+    });
     arena.batches.clear();
     free(seqs);
     free(ret);

@@ -3,36 +3,29 @@
 // function of that phase that the reference exports is interposed by a timer (TSC ticks per thread, flushed when a worker thread ends, one
 // report when the process exits).  Times are INCLUSIVE: mem_sam_pe_batch_post contains everything below it, mem_reg2sam contains
 // mem_reg2aln + mem_aln2sam, mem_reg2aln contains bwa_gen_cigar2 (which the binding answers from its table; its own counter is in
-// meme_dropin_sam.cpp under MEME_DROPIN_PROFILE_SAM).  The report (profiles/r05_sam_phase_split.md) decides what moves to the device next.
-#include <x86intrin.h>
+// meme_dropin_sam.cpp, compiled with the same switch).  The report (profiles/r05_sam_phase_split.md) decides what moves to the device next.
+#define MEME_DROPIN_PROF 1
+#include "meme_dropin_prof.h"
 
 #include "meme_dropin.h"
 #include "kswv.h"
 
+using namespace dropin_prof;
+
 namespace {
 
-enum { P_POST, P_PRE, P_MATESW_POST, P_MATESW_POST_MS, P_MARK_PRIMARY, P_PAIR, P_GEN_ALT, P_REG2ALN, P_REG2SAM, P_SORT_DEDUP, P_SORT_DEDUP_MS, P_APPROX_MAPQ, P_N };
 const char* const NAMES[P_N] = {"mem_sam_pe_batch_post (whole third step)", "mem_sam_pe_batch_pre (job posing, the binding's pre-pass)", "mem_matesw_batch_post",
                                 "mem_matesw_batch_post_mate_sort", "mem_mark_primary_se", "mem_pair", "mem_gen_alt", "mem_reg2aln", "mem_reg2sam", "mem_sort_dedup_patch",
-                                "mem_sort_dedup_patch_mate_sort", "mem_approx_mapq_se"};
+                                "mem_sort_dedup_patch_mate_sort", "mem_approx_mapq_se", "bwa_gen_cigar2 (the binding's hook)", "mem_aln2sam"};
 std::atomic<uint64_t> g_ticks[P_N], g_calls[P_N];
-struct Local {
-    uint64_t t[P_N] = {}, n[P_N] = {};
-    ~Local() { for (int i = 0; i < P_N; ++i) if (n[i]) { g_ticks[i] += t[i]; g_calls[i] += n[i]; } }
-};
-thread_local Local tl;
-struct Scope { int id; uint64_t t0; explicit Scope(int i) : id(i), t0(__rdtsc()) {} ~Scope() { tl.t[id] += __rdtsc() - t0; ++tl.n[id]; } };
-
-double g_tsc_hz = 0;
 uint64_t g_tsc0 = 0;
 double g_wall0 = 0;
 double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 __attribute__((constructor)) void prof_start() { g_tsc0 = __rdtsc(); g_wall0 = wall(); }
 __attribute__((destructor)) void prof_report() {
     const double hz = (double)(__rdtsc() - g_tsc0) / (wall() - g_wall0);
-    g_tsc_hz = hz;
-    { Local& l = tl; for (int i = 0; i < P_N; ++i) if (l.n[i]) { g_ticks[i] += l.t[i]; g_calls[i] += l.n[i]; l.n[i] = 0; } }
-    fprintf(stderr, "[meme-dropin-prof] SAM phase, inclusive thread-seconds (TSC at %.2f GHz):\n", hz * 1e-9);
+    { Local& l = local(); flush(l.t, l.n); for (int i = 0; i < P_N; ++i) l.n[i] = l.t[i] = 0; }
+    fprintf(stderr, "[meme-dropin-prof] SAM phase, inclusive thread-seconds (TSC at %.2f GHz; a thread that is descheduled keeps counting):\n", hz * 1e-9);
     for (int i = 0; i < P_N; ++i)
         fprintf(stderr, "[meme-dropin-prof]   %-62s %9.3f s  %12llu calls\n", NAMES[i], (double)g_ticks[i].load() / hz, (unsigned long long)g_calls[i].load());
 }
@@ -45,79 +38,87 @@ template <typename F> F next_of(const char* sym) {
 
 }  // namespace
 
+void dropin_prof::flush(const uint64_t* t, const uint64_t* n) { for (int i = 0; i < P_N; ++i) if (n[i]) { g_ticks[i] += t[i]; g_calls[i] += n[i]; } }
+
 int mem_sam_pe_batch_post(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2], mem_alnreg_v a[2], kswr_t** myaln,
                           mem_cache* mmc, int32_t& gcnt, int tid) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, const mem_pestat_t*, uint64_t, bseq1_t*, mem_alnreg_v*, kswr_t**, mem_cache*, int32_t&, int);
     static fn next = next_of<fn>("_Z21mem_sam_pe_batch_postPK9mem_opt_tPK8bntseq_tPKhPK12mem_pestat_tmP7bseq1_tP12mem_alnreg_vPP6kswr_tP9mem_cacheRii");
-    Scope sc(P_POST);
+    PROF_SCOPE(P_POST);
     return next(opt, bns, pac, pes, id, s, a, myaln, mmc, gcnt, tid);
 }
 int mem_sam_pe_batch_pre(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2], mem_alnreg_v a[2], mem_cache* mmc,
                          int64_t& pcnt, int32_t& gcnt, int32_t& maxRefLen, int32_t& maxQerLen, int tid) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, const mem_pestat_t*, uint64_t, bseq1_t*, mem_alnreg_v*, mem_cache*, int64_t&, int32_t&, int32_t&, int32_t&, int);
     static fn next = next_of<fn>("_Z20mem_sam_pe_batch_prePK9mem_opt_tPK8bntseq_tPKhPK12mem_pestat_tmP7bseq1_tP12mem_alnreg_vP9mem_cacheRlRiSH_SH_i");
-    Scope sc(P_PRE);
+    PROF_SCOPE(P_PRE);
     return next(opt, bns, pac, pes, id, s, a, mmc, pcnt, gcnt, maxRefLen, maxQerLen, tid);
 }
 int mem_matesw_batch_post(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_pestat_t pes[4], const mem_alnreg_t* a, int l_ms, const uint8_t* ms, mem_alnreg_v* ma,
                           kswr_t** myaln, int32_t gcnt, int32_t* gar, mem_cache* mmc) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, const mem_pestat_t*, const mem_alnreg_t*, int, const uint8_t*, mem_alnreg_v*, kswr_t**, int32_t, int32_t*, mem_cache*);
     static fn next = next_of<fn>("_Z21mem_matesw_batch_postPK9mem_opt_tPK8bntseq_tPKhPK12mem_pestat_tPK12mem_alnreg_tiS6_P12mem_alnreg_vPP6kswr_tiPiP9mem_cache");
-    Scope sc(P_MATESW_POST);
+    PROF_SCOPE(P_MATESW_POST);
     return next(opt, bns, pac, pes, a, l_ms, ms, ma, myaln, gcnt, gar, mmc);
 }
 int mem_matesw_batch_post_mate_sort(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_pestat_t pes[4], const mem_alnreg_t* a, int l_ms, const uint8_t* ms,
                                     mem_alnreg_v* ma, kswr_t** myaln, int32_t gcnt, int32_t* gar, mem_cache* mmc) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, const mem_pestat_t*, const mem_alnreg_t*, int, const uint8_t*, mem_alnreg_v*, kswr_t**, int32_t, int32_t*, mem_cache*);
     static fn next = next_of<fn>("_Z31mem_matesw_batch_post_mate_sortPK9mem_opt_tPK8bntseq_tPKhPK12mem_pestat_tPK12mem_alnreg_tiS6_P12mem_alnreg_vPP6kswr_tiPiP9mem_cache");
-    Scope sc(P_MATESW_POST_MS);
+    PROF_SCOPE(P_MATESW_POST_MS);
     return next(opt, bns, pac, pes, a, l_ms, ms, ma, myaln, gcnt, gar, mmc);
 }
 int mem_mark_primary_se(const mem_opt_t* opt, int n, mem_alnreg_t* a, int64_t id) {
     typedef int (*fn)(const mem_opt_t*, int, mem_alnreg_t*, int64_t);
     static fn next = next_of<fn>("_Z19mem_mark_primary_sePK9mem_opt_tiP12mem_alnreg_tl");
-    Scope sc(P_MARK_PRIMARY);
+    PROF_SCOPE(P_MARK_PRIMARY);
     return next(opt, n, a, id);
 }
 int mem_pair(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_pestat_t pes[4], bseq1_t s[2], mem_alnreg_v a[2], int id, int* sub, int* n_sub, int z[2], int n_pri[2]) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, const mem_pestat_t*, bseq1_t*, mem_alnreg_v*, int, int*, int*, int*, int*);
     static fn next = next_of<fn>("_Z8mem_pairPK9mem_opt_tPK8bntseq_tPKhPK12mem_pestat_tP7bseq1_tP12mem_alnreg_viPiSE_SE_SE_");
-    Scope sc(P_PAIR);
+    PROF_SCOPE(P_PAIR);
     return next(opt, bns, pac, pes, s, a, id, sub, n_sub, z, n_pri);
 }
 char** mem_gen_alt(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_alnreg_v* a, int l_query, const char* query) {
     typedef char** (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, const mem_alnreg_v*, int, const char*);
     static fn next = next_of<fn>("_Z11mem_gen_altPK9mem_opt_tPK8bntseq_tPKhPK12mem_alnreg_viPKc");
-    Scope sc(P_GEN_ALT);
+    PROF_SCOPE(P_GEN_ALT);
     return next(opt, bns, pac, a, l_query, query);
 }
 mem_aln_t mem_reg2aln(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, int l_query, const char* query, const mem_alnreg_t* ar) {
     typedef mem_aln_t (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, int, const char*, const mem_alnreg_t*);
     static fn next = next_of<fn>("_Z11mem_reg2alnPK9mem_opt_tPK8bntseq_tPKhiPKcPK12mem_alnreg_t");
-    Scope sc(P_REG2ALN);
+    PROF_SCOPE(P_REG2ALN);
     return next(opt, bns, pac, l_query, query, ar);
 }
 void mem_reg2sam(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* s, mem_alnreg_v* a, int extra_flag, const mem_aln_t* m) {
     typedef void (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, bseq1_t*, mem_alnreg_v*, int, const mem_aln_t*);
     static fn next = next_of<fn>("_Z11mem_reg2samPK9mem_opt_tPK8bntseq_tPKhP7bseq1_tP12mem_alnreg_viPK9mem_aln_t");
-    Scope sc(P_REG2SAM);
+    PROF_SCOPE(P_REG2SAM);
     next(opt, bns, pac, s, a, extra_flag, m);
 }
 int mem_sort_dedup_patch(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, uint8_t* query, int n, mem_alnreg_t* a) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, uint8_t*, int, mem_alnreg_t*);
     static fn next = next_of<fn>("_Z20mem_sort_dedup_patchPK9mem_opt_tPK8bntseq_tPKhPhiP12mem_alnreg_t");
-    Scope sc(P_SORT_DEDUP);
+    PROF_SCOPE(P_SORT_DEDUP);
     return next(opt, bns, pac, query, n, a);
 }
 int mem_sort_dedup_patch_mate_sort(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, uint8_t* query, int n, mem_alnreg_t* a, bool* useMateSort) {
     typedef int (*fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, uint8_t*, int, mem_alnreg_t*, bool*);
     static fn next = next_of<fn>("_Z30mem_sort_dedup_patch_mate_sortPK9mem_opt_tPK8bntseq_tPKhPhiP12mem_alnreg_tPb");
-    Scope sc(P_SORT_DEDUP_MS);
+    PROF_SCOPE(P_SORT_DEDUP_MS);
     return next(opt, bns, pac, query, n, a, useMateSort);
 }
 int mem_approx_mapq_se(const mem_opt_t* opt, const mem_alnreg_t* a) {
     typedef int (*fn)(const mem_opt_t*, const mem_alnreg_t*);
     static fn next = next_of<fn>("_Z18mem_approx_mapq_sePK9mem_opt_tPK12mem_alnreg_t");
-    Scope sc(P_APPROX_MAPQ);
+    PROF_SCOPE(P_APPROX_MAPQ);
     return next(opt, a);
+}
+void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
+    typedef void (*fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
+    static fn next = next_of<fn>("_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
+    PROF_SCOPE(P_ALN2SAM);
+    next(opt, bns, str, s, n, list, which, m);
 }

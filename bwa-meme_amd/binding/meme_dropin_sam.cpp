@@ -1,5 +1,6 @@
 // Part of the reference-side binding of the MI355X backend (see meme_dropin.h / meme_dropin.cpp).
 #include "meme_dropin.h"
+#include "meme_dropin_prof.h"
 
 using namespace dropin;
 
@@ -17,7 +18,6 @@ using namespace dropin;
 // 1.3 s instead of saving the ~0.1 s the host's 64 threads spend in the kswv kernels -- the jobs are few (one per ~22 reads; a 250-bp / 5 %
 // run poses 5 000 in all), their kernel time is small next to the pre-pass that has to pose them ahead of worker_sam (0.12 s, of which
 // kernels 0.03-0.05 s), and the third step then meets the alignment records cold.  SAM output is identical either way (tests).
-#include <omp.h>
 #include "kswv.h"
 namespace dropin {
 std::atomic<double> g_t_matesw{0};
@@ -92,9 +92,9 @@ bool matesw_prepass() {                          // false: too few jobs for the 
     struct BatchJobs { std::vector<meme_kswv_job> jobs; std::vector<uint8_t> ref, qer; };
     std::vector<BatchJobs> B((size_t)nb);
     g_mate.gar.assign((size_t)nb, std::vector<int32_t>());
-#pragma omp parallel for schedule(dynamic, 1) num_threads(g_mate.slots)
-    for (int64_t b = 0; b < nb; ++b) {
-        const int t = omp_get_thread_num();
+    std::atomic<int64_t> next_b{0};
+    team_run(g_mate.slots, [&](int t) {                             // (one buffer slot per share; batches handed out one by one)
+    for (int64_t b = next_b.fetch_add(1); b < nb; b = next_b.fetch_add(1)) {
         const int64_t st = b * BATCH_SIZE, ed = (b + 1) * BATCH_SIZE < n ? (b + 1) * BATCH_SIZE : n;
         int64_t pcnt = 0;
         int32_t gcnt = 0, maxRef = 0, maxQer = 0;
@@ -112,6 +112,7 @@ bool matesw_prepass() {                          // false: too few jobs for the 
         J.jobs.resize((size_t)pcnt);
         for (int64_t k = 0; k < pcnt; ++k) { meme_kswv_job& j = J.jobs[(size_t)k]; j.idr = sp[k].idr; j.idq = sp[k].idq; j.len1 = sp[k].len1; j.len2 = sp[k].len2; j.xtra = sp[k].h0; j.pad = 0; }
     }
+    });
     MateTable& T = g_mate;
     T.off.assign((size_t)nb + 1, 0);
     for (int64_t b = 0; b < nb; ++b) T.off[(size_t)b + 1] = T.off[(size_t)b] + (int64_t)B[(size_t)b].jobs.size();
@@ -179,25 +180,8 @@ void meme_dropin_report_mate() {
             "%lld, run by the reference's kernels %lld\n", (long long)g_mate.n_jobs, g_mate.t_kernel_ms * 1e-3, g_mate.t_prepass, (long long)g_mate_hits.load(),
             (long long)g_mate_miss.load());
 }
-namespace dropin {
-std::atomic<double> g_t_cigar{0}, g_t_sam{0}; std::atomic<int64_t> g_n_cigar{0}, g_n_sam{0};
-// per-record timing with shared counters costs a 256-thread run a third of its compute time: only on request
-bool profile_sam() { static const bool v = getenv("MEME_DROPIN_PROFILE_SAM") != nullptr; return v; }
-}
-// (measurement only, MEME_DROPIN_PROFILE_SAM=1) SAM formatting on the host
-typedef void (*aln2sam_fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
-void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
-    static aln2sam_fn next = (aln2sam_fn)dlsym(RTLD_NEXT, "_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
-    if (!profile_sam()) { next(opt, bns, str, s, n, list, which, m); return; }
-    const double t0 = now_s();
-    next(opt, bns, str, s, n, list, which, m);
-    g_t_sam = g_t_sam + (now_s() - t0);
-    g_n_sam += 1;
-}
 void meme_dropin_report_matesw() {
-    fprintf(stderr, "[meme-dropin] SAM phase on the host, thread-seconds so far: mate-rescue SW (kswv) %.3f for %lld pairs; CIGAR generation (the bwa_gen_cigar2 hook: "
-            "table look-ups and the reference's function for the rest) %.3f for %lld calls; SAM formatting (mem_aln2sam) %.3f for %lld records\n", (double)g_t_matesw,
-            (long long)g_n_matesw, (double)g_t_cigar, (long long)g_n_cigar, (double)g_t_sam, (long long)g_n_sam);
+    fprintf(stderr, "[meme-dropin] mate rescue by the reference's kernels (chunks below the job threshold): %.3f thread-seconds for %lld pairs\n", (double)g_t_matesw, (long long)g_n_matesw);
 }
 
 // ---- CIGAR generation of the SAM phase on the device ---------------------------------------------------------------------
@@ -212,23 +196,24 @@ void meme_dropin_report_matesw() {
 // its arguments and of the query bases.  Calls the table does not hold (alignments made later by mate rescue, calls from other places)
 // go to the reference's function.  MEME_DROPIN_CIGAR=0 switches the stage off.  Round 4 hooked ksw_global2 only: the target unpacking,
 // the reversals, two sequence hashes per call and the NM / MD loop stayed on the host.
-#include <omp.h>
-#include <parallel/algorithm>
 namespace dropin {
 
-struct CigEntry { int64_t g; int64_t rb; int32_t qb, qlen, tlen, w_, score, n_cigar, nm, md_len; int64_t ops, md; };
+struct CigEntry { int64_t rb; int64_t blob; int32_t g, qb, qlen, tlen, w_, score, n_cigar, nm, md_len, pad; };     // blob: the entry's n_cigar operations, then its MD string + NUL
 struct CigTable {
     std::mutex mu;
     uint64_t gen = 0;
     std::vector<CigEntry> e;
-    std::vector<uint32_t> ops;
-    std::vector<char> md;
+    std::vector<char> blob;                              // per entry what the hook returns: operations + MD, back to back
     std::vector<uint32_t> slot;                          // open addressing: entry + 1, 0 = empty; size a power of two
     uint64_t mask = 0;
     double t_prepass = 0, t_kernel_ms = 0;
     int64_t n_jobs = 0;
 } g_cig;
 std::atomic<int64_t> g_cig_hits{0}, g_cig_miss{0};
+// (the hook's counters per thread, added to the totals when a worker thread ends: two shared atomics touched four million times per
+// 4 M reads by 64 threads cost more than the look-ups they count)
+struct CigTally { int64_t hits = 0, miss = 0; ~CigTally() { if (hits) g_cig_hits += hits; if (miss) g_cig_miss += miss; } };
+thread_local CigTally tl_cig;
 bool cigar_on_device() { static const bool v = !(getenv("MEME_DROPIN_CIGAR") && atoi(getenv("MEME_DROPIN_CIGAR")) == 0); return v; }
 
 inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
@@ -241,13 +226,13 @@ inline int infer_bw_(int l1, int l2, int score, int a, int q, int r) {        //
 }
 
 // helper threads of the pre-pass's host loops: a few dozen are enough, and an OpenMP team of 256 would still be spinning when worker_sam starts
-int cig_threads() { const int m = omp_get_max_threads(); return m < 32 ? m : 32; }
+int cig_threads() { static const int m = (int)std::thread::hardware_concurrency(); return m < 1 ? 1 : (m < 32 ? m : 32); }
 
 void cig_prepass() {
     const double t0 = now_s();
     double cpu0; { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); cpu0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     CigTable& T = g_cig;
-    T.e.clear(); T.ops.clear(); T.md.clear();
+    T.e.clear(); T.blob.clear();
     const mem_opt_t* opt = g_opt;
     const int64_t n = g_chunk.n, l_pac = g_bns->l_pac;
     // per alignment record: where mem_reg2aln's loop stands (band argument of the next call, score of the last one)
@@ -256,11 +241,9 @@ void cig_prepass() {
     {
         const int nt = cig_threads();
         std::vector<std::vector<Cand>> part((size_t)nt);
-#pragma omp parallel num_threads(nt)
-        {
-            std::vector<Cand>& mine = part[(size_t)omp_get_thread_num()];
-#pragma omp for schedule(static)
-            for (int64_t g = 0; g < n; ++g) {
+        team_for(n, nt, [&](int64_t g_lo, int64_t g_hi, int t) {
+            std::vector<Cand>& mine = part[(size_t)t];
+            for (int64_t g = g_lo; g < g_hi; ++g) {
                 const mem_alnreg_v& av = g_worker->regs[g];
                 for (size_t i = 0; i < av.n; ++i) {
                     const mem_alnreg_t& p = av.a[i];
@@ -275,7 +258,7 @@ void cig_prepass() {
                     mine.push_back({g, (int32_t)i, w2, -(1 << 30), 0});
                 }
             }
-        }
+        });
         size_t tot = 0;
         for (auto& v : part) tot += v.size();
         cand.reserve(tot);
@@ -295,8 +278,8 @@ void cig_prepass() {
         const int64_t nc = (int64_t)cand.size();
         std::vector<meme_cjob> posed((size_t)nc);
         std::vector<int8_t> dev_of((size_t)nc);
-#pragma omp parallel for schedule(static) num_threads(cig_threads())
-        for (int64_t c = 0; c < nc; ++c) {
+        team_for(nc, cig_threads(), [&](int64_t c_lo, int64_t c_hi, int) {
+        for (int64_t c = c_lo; c < c_hi; ++c) {
             Cand& C = cand[(size_t)c];
             const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
             C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;                         // (:2342)
@@ -308,6 +291,7 @@ void cig_prepass() {
             J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w_ = C.w2; J.pad = 0;
             dev_of[(size_t)c] = (int8_t)d;
         }
+        });
         std::vector<std::vector<meme_cjob>> jobs((size_t)nd);
         std::vector<std::vector<uint32_t>> who((size_t)nd);
         for (int64_t c = 0; c < nc; ++c) {
@@ -320,7 +304,7 @@ void cig_prepass() {
         // One call per device; a call that the backend refuses for want of memory (MEME_E_CAPACITY: the backtrack matrices of the batch
         // beside the resident index) is repeated in halves, and whatever cannot be computed at all is simply left out of the table:
         // the hook then runs the reference's function for those alignments.  The stage is an optimisation, never a reason to stop.
-        struct Part { std::vector<meme_cres> res; std::vector<uint32_t> ops; std::vector<char> md; int64_t done = 0; double kernel_ms = 0; };
+        struct Part { std::vector<meme_cres> res; std::vector<char> blob; int64_t done = 0; double kernel_ms = 0; };      // res[k].cigar_off: the job's place in blob
         std::vector<Part> part((size_t)nd);
         std::vector<std::thread> th;
         auto run = [&](int d) {
@@ -341,10 +325,22 @@ void cig_prepass() {
                     warned = true;
                     break;
                 }
-                const int64_t o0 = (int64_t)P.ops.size(), m0 = (int64_t)P.md.size();
-                P.ops.insert(P.ops.end(), R.cigars, R.cigars + R.total_ops);          // the device packs operations and MD strings in job order
-                P.md.insert(P.md.end(), R.md, R.md + R.md_bytes);
-                for (int64_t k = 0; k < m; ++k) { meme_cres g = R.res[k]; g.cigar_off += o0; g.md_off += m0; P.res.push_back(g); }
+                // operations and MD string of every job back to back: the device packs both in job order, so 4 x cigar_off + md_off is a packing too
+                const int64_t b0 = (int64_t)P.blob.size();
+                P.blob.resize((size_t)(b0 + 4 * R.total_ops + R.md_bytes));
+                const size_t r0 = P.res.size();
+                P.res.resize(r0 + (size_t)m);
+                char* const bl = P.blob.data() + b0;
+                team_for(m, cig_threads() / (nd > 1 ? 2 : 1), [&](int64_t k_lo, int64_t k_hi, int) {
+                for (int64_t k = k_lo; k < k_hi; ++k) {
+                    meme_cres g = R.res[k];
+                    const int64_t o = 4 * g.cigar_off + g.md_off;
+                    memcpy(bl + o, R.cigars + g.cigar_off, (size_t)g.n_cigar * 4);
+                    memcpy(bl + o + (int64_t)g.n_cigar * 4, R.md + g.md_off, (size_t)g.md_len + 1);
+                    g.cigar_off = b0 + o;
+                    P.res[r0 + (size_t)k] = g;
+                }
+                });
                 P.kernel_ms += R.kernel_ms;
                 P.done += m;
             }
@@ -359,30 +355,30 @@ void cig_prepass() {
             if (R.done == 0) continue;
             T.t_kernel_ms += R.kernel_ms;
             T.n_jobs += R.done;
-            const size_t e0 = T.e.size(), o0 = T.ops.size(), m0 = T.md.size();
-            T.ops.insert(T.ops.end(), R.ops.begin(), R.ops.end());
-            T.md.insert(T.md.end(), R.md.begin(), R.md.end());
+            const size_t e0 = T.e.size(), b0 = T.blob.size();
+            T.blob.insert(T.blob.end(), R.blob.begin(), R.blob.end());
             T.e.resize(e0 + (size_t)R.done);
             std::vector<uint8_t> again((size_t)R.done);
-#pragma omp parallel for schedule(static) num_threads(cig_threads())
-            for (int64_t k = 0; k < R.done; ++k) {
+            team_for(R.done, cig_threads(), [&](int64_t k_lo, int64_t k_hi, int) {
+            for (int64_t k = k_lo; k < k_hi; ++k) {
                 const meme_cjob& J = jobs[(size_t)d][(size_t)k];
                 const meme_cres& X = R.res[(size_t)k];
                 CigEntry& E = T.e[e0 + (size_t)k];
                 Cand& C = cand[who[(size_t)d][(size_t)k]];
-                E.g = C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w_ = J.w_;
-                E.score = X.score; E.n_cigar = X.n_cigar; E.nm = X.nm; E.md_len = X.md_len; E.ops = (int64_t)o0 + X.cigar_off; E.md = (int64_t)m0 + X.md_off;
+                E.g = (int32_t)C.g; E.rb = J.rb; E.qb = J.qb; E.qlen = J.qlen; E.tlen = J.tlen; E.w_ = J.w_; E.pad = 0;
+                E.score = X.score; E.n_cigar = X.n_cigar; E.nm = X.nm; E.md_len = X.md_len; E.blob = (int64_t)b0 + X.cigar_off;
                 // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
                 again[(size_t)k] = 0;
                 const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
                 const int score = E.score;
-                if (score == C.last_sc || C.w2 == opt->w << 2) continue;
+                if (score == C.last_sc || C.w2 == opt->w << 2) continue;        // (inside the share's loop: the next alignment)
                 C.last_sc = score;
                 const int prev = C.w2;
                 C.w2 <<= 1;
                 // (a doubled 0 is the same call again: its answer is in the table already, and it ends the loop -- score == last_sc)
                 if (++C.tries < 3 && score < p.truesc - opt->a && (C.w2 < opt->w << 2 ? C.w2 : opt->w << 2) != prev) again[(size_t)k] = 1;
             }
+            });
             for (int64_t k = 0; k < R.done; ++k) if (again[(size_t)k]) next.push_back(cand[who[(size_t)d][(size_t)k]]);
         }
         cand.swap(next);
@@ -396,8 +392,8 @@ void cig_prepass() {
         T.slot.assign((size_t)cap, 0u);
         T.mask = cap - 1;
         uint32_t* sl = T.slot.data();
-#pragma omp parallel for schedule(static) num_threads(cig_threads())
-        for (int64_t k = 0; k < (int64_t)T.e.size(); ++k) {
+        team_for((int64_t)T.e.size(), cig_threads(), [&](int64_t k_lo, int64_t k_hi, int) {
+        for (int64_t k = k_lo; k < k_hi; ++k) {
             const CigEntry& E = T.e[(size_t)k];
             uint64_t h = cig_key(E.rb, E.qlen, E.tlen, E.w_) & T.mask;
             for (;;) {
@@ -406,6 +402,7 @@ void cig_prepass() {
                 h = (h + 1) & T.mask;
             }
         }
+        });
     }
     T.t_prepass += now_s() - t0;
     if (verbose()) {
@@ -422,8 +419,7 @@ extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, 
                                     uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
     static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
     if (!next) { fprintf(stderr, "[meme-dropin] the reference's bwa_gen_cigar2 was not found\n"); exit(1); }
-    const double t0 = profile_sam() ? now_s() : 0;
-    struct Timer { double t0; ~Timer() { if (t0 > 0) { g_t_cigar = g_t_cigar + (now_s() - t0); g_n_cigar += 1; } } } timer{t0};
+    PROF_SCOPE(P_GEN_CIGAR2_HOOK);
     const mem_opt_t* opt = g_opt;
     const CigTable& T = g_cig;
     if (!cigar_on_device() || !score || !n_cigar || !NM || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || T.gen != g_chunk_gen || mat != opt->mat || o_del != opt->o_del ||
@@ -437,15 +433,15 @@ extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, 
         if (E.rb != rb || E.qlen != l_query || E.tlen != tlen || E.w_ != w_) continue;
         if (memcmp(g_chunk.seqs[E.g].seq + E.qb, query, (size_t)l_query) != 0) continue;        // (the read's bases are codes by now, as the caller's copy is)
         // the block the reference's function returns: the operations, the MD string right behind them (src/bwa.cpp:324, 352-354)
-        uint32_t* cg = (uint32_t*)malloc((size_t)E.n_cigar * 4 + (size_t)E.md_len + 1);
+        const size_t bytes = (size_t)E.n_cigar * 4 + (size_t)E.md_len + 1;
+        uint32_t* cg = (uint32_t*)malloc(bytes);
         if (!cg) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
-        memcpy(cg, T.ops.data() + E.ops, (size_t)E.n_cigar * 4);
-        memcpy((char*)(cg + E.n_cigar), T.md.data() + E.md, (size_t)E.md_len + 1);
+        memcpy(cg, T.blob.data() + E.blob, bytes);
         *score = E.score; *n_cigar = E.n_cigar; *NM = E.nm;
-        g_cig_hits.fetch_add(1, std::memory_order_relaxed);
+        ++tl_cig.hits;
         return cg;
     }
-    g_cig_miss.fetch_add(1, std::memory_order_relaxed);
+    ++tl_cig.miss;
     return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
 }
 
@@ -489,11 +485,9 @@ void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* 
     struct Key { uint64_t k; int32_t i; };                       // (orientation << 60 | insert size, pair): the order of the stand-ins
     const int nt = cig_threads();
     std::vector<std::vector<Key>> part((size_t)nt);
-#pragma omp parallel num_threads(nt)
-    {
-        std::vector<Key>& mine = part[(size_t)omp_get_thread_num()];
-#pragma omp for schedule(static)
-        for (int i = 0; i < np; ++i) {
+    team_for(np, nt, [&](int64_t i_lo, int64_t i_hi, int t) {
+        std::vector<Key>& mine = part[(size_t)t];
+        for (int i = (int)i_lo; i < (int)i_hi; ++i) {
             const mem_alnreg_v* r0 = &regs[i << 1 | 0];
             const mem_alnreg_v* r1 = &regs[i << 1 | 1];
             if (r0->n == 0 || r1->n == 0) continue;                                       // :96
@@ -508,22 +502,24 @@ void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* 
             const int dir = (s1 == s2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
             mine.push_back({(uint64_t)dir << 60 | (dist & ((1ull << 60) - 1)), i});
         }
-    }
+    });
     std::vector<Key> keys;
     { size_t tot = 0; for (auto& v : part) tot += v.size(); keys.reserve(tot); for (auto& v : part) keys.insert(keys.end(), v.begin(), v.end()); }
-    __gnu_parallel::sort(keys.begin(), keys.end(), [](const Key& x, const Key& y) { return x.k < y.k; }, __gnu_parallel::default_parallel_tag((unsigned)nt));
+    // (pairs with equal keys are interchangeable stand-ins for the function -- same orientation, same insert size --, so the order among them does not matter)
+    team_sort(keys, nt, [](const Key& x, const Key& y) { return x.k < y.k; });
     const int64_t m = (int64_t)keys.size();
     mem_alnreg_t* a = (mem_alnreg_t*)malloc((size_t)(2 * m + 1) * sizeof(mem_alnreg_t));
     mem_alnreg_v* v = (mem_alnreg_v*)malloc((size_t)(2 * m + 1) * sizeof(mem_alnreg_v));
     if (!a || !v) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); }
-#pragma omp parallel for schedule(static) num_threads(nt)
-    for (int64_t k = 0; k < m; ++k)
+    team_for(m, nt, [&](int64_t k_lo, int64_t k_hi, int) {
+    for (int64_t k = k_lo; k < k_hi; ++k)
         for (int e = 0; e < 2; ++e) {
             const mem_alnreg_t& src = regs[keys[(size_t)k].i << 1 | e].a[0];
             mem_alnreg_t& d = a[2 * k + e];
             d.rb = src.rb; d.rid = src.rid; d.score = 1 << 28;
             v[2 * k + e].n = v[2 * k + e].m = 1; v[2 * k + e].a = &d;
         }
+    });
     next(opt, l_pac, (int)(2 * m), v, pes);
     free(a); free(v);
 }

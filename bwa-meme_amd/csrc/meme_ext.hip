@@ -428,18 +428,33 @@ unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i6
 
 // measurement (tuning "ext_census"): jobs whose query equals the first len2 bases of the target (no ambiguous base) -- the jobs a closed form
 // could answer without the DP (score = h0 + len2 * a).  SMEM seeds end on a mismatch or at a read end, so few are expected.
-__global__ void __launch_bounds__(256) k_ext_census(const meme_seqpair* __restrict__ pairs, i64 n, const uint8_t* __restrict__ seq, unsigned long long* __restrict__ cnt) {
-    i64 mine = 0;
+__global__ void __launch_bounds__(256) k_ext_census(const meme_seqpair* __restrict__ pairs, i64 n, const uint8_t* __restrict__ seq, int w, unsigned long long* __restrict__ cnt) {
+    __shared__ unsigned long long acc[11];
+    if (threadIdx.x < 11) acc[threadIdx.x] = 0;
+    __syncthreads();
     for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
         const meme_seqpair P = pairs[k];
+        // [1] cells of the band-limited matrix (rows = target bases, columns = query bases within w of the diagonal)
+        unsigned long long cells = 0;
+        for (int i = 0; i < P.len1; ++i) {
+            const int beg = i > w ? i - w : 0, end = i + w + 1 < P.len2 ? i + w + 1 : P.len2;
+            if (end > beg) cells += (unsigned)(end - beg);
+        }
+        atomicAdd(&acc[1], cells);
+        // [2..10] LDS size class of the lane-per-pair kernel (LANE_CLS_Q, meme_bsw.hip)
+        const int q = P.len2;
+        const int c = q <= 30 ? 0 : q <= 62 ? 1 : q <= 94 ? 2 : q <= 126 ? 3 : q <= 158 ? 4 : q <= 222 ? 5 : q <= 318 ? 6 : q <= 600 ? 7 : 8;
+        atomicAdd(&acc[2 + c], 1ull);
+        // [0] query == first len2 target bases
         if (P.len2 > P.len1) continue;
-        const uint8_t* q = seq + P.idq;
-        const uint8_t* t = seq + P.idr;
+        const uint8_t* qq = seq + P.idq;
+        const uint8_t* tt = seq + P.idr;
         bool same = true;
-        for (int i = 0; same && i < P.len2; ++i) same = q[i] == t[i] && q[i] < 4;
-        mine += same;
+        for (int i = 0; same && i < P.len2; ++i) same = qq[i] == tt[i] && qq[i] < 4;
+        if (same) atomicAdd(&acc[0], 1ull);
     }
-    if (mine) atomicAdd(cnt, (unsigned long long)mine);
+    __syncthreads();
+    if (threadIdx.x < 11 && acc[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], acc[threadIdx.x]);
 }
 
 }  // namespace
@@ -470,7 +485,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     const i64* d_sdoff = d_choff + (n + 1);
     const i64 n_chains = tot[0];
     i64 n_seeds = tot[1];
-    if ((rc = meme_buf_reserve(ctx, E[8], 64))) return rc;
+    if ((rc = meme_buf_reserve(ctx, E[8], 256))) return rc;
     // ---- mem_flt_chained_seeds: the read lengths it runs for and their thresholds, evaluated the way the reference's host code does
     // (:579-583: float coefficients, double min_l, libm's log).  Never with reads below ~760 bases unless -W is given.
     const meme_chain_seed* d_seeds = (const meme_chain_seed*)B[7].p;
@@ -546,8 +561,8 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     bl.end_bonus = eopt->pen_clip5;                   // bswLeft / bswRight, src/bwamem.cpp:2953-2959
     br.end_bonus = eopt->pen_clip3;
     unsigned long long* d_nretry = (unsigned long long*)E[8].p;
-    unsigned long long* d_census = (unsigned long long*)E[8].p + 4;
-    if (ctx->ext_census) HIP_TRY(hipMemsetAsync(d_census, 0, 8, ctx->stream));
+    unsigned long long* d_census = (unsigned long long*)E[8].p + 8;
+    if (ctx->ext_census) HIP_TRY(hipMemsetAsync(d_census, 0, 11 * 8, ctx->stream));
     i64 n_pairs = 0, n_retried = 0, n_calls = 0;
     float bsw_ms = 0.f;
     // ---- slabs of reads whose jobs' sequences fit 32-bit offsets (SeqPair::idr / idq)
@@ -574,8 +589,8 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
         hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)(g1 - g0)), dim3(64), 0, ctx->stream, S);
         HIP_TRY(hipGetLastError());
         if (ctx->ext_census) {
-            if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, d_census);
-            if (nR) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nR, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.R, nR, (const uint8_t*)S.seq, d_census);
+            if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, eopt->w, d_census);
+            if (nR) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nR, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.R, nR, (const uint8_t*)S.seq, eopt->w, d_census);
         }
         for (int dir = 0; dir < 2; ++dir) {
             meme_seqpair* P = dir == 0 ? S.L : S.R;
@@ -614,10 +629,12 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg)))) return rc;
     HIP_TRY(hipMemcpyAsync(Hb[0].p, d_sdoff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_seeds) HIP_TRY(hipMemcpyAsync(Hb[1].p, A.regs, (size_t)n_seeds * sizeof(meme_alnreg), hipMemcpyDeviceToHost, ctx->stream));
-    unsigned long long h_census = 0;
-    if (ctx->ext_census) HIP_TRY(hipMemcpyAsync(&h_census, d_census, 8, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long h_census[11] = {0};
+    if (ctx->ext_census) HIP_TRY(hipMemcpyAsync(h_census, d_census, 11 * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    out->n_exact_prefix = ctx->ext_census ? (int64_t)h_census : -1;
+    out->n_exact_prefix = ctx->ext_census ? (int64_t)h_census[0] : -1;
+    out->census_band_cells = ctx->ext_census ? (int64_t)h_census[1] : -1;
+    for (int c = 0; c < 9; ++c) out->census_class[c] = ctx->ext_census ? (int64_t)h_census[2 + c] : -1;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
     out->nreads = n; out->reg_off = (const int64_t*)Hb[0].p; out->regs = (const meme_alnreg*)Hb[1].p; out->total_regs = n_seeds;

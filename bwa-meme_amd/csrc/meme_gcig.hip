@@ -28,14 +28,16 @@ struct GcigArgs {
     // bwa_gen_cigar2 whole (meme_gen_cigar_batch_host): NM and the MD string of every job; null for the plain ksw_global2 call
     const i64* mdoff; char* md;              // MD scratch: 2 * (qlen + tlen) + 16 bytes per job
     int32_t* nm; int32_t* mdlen;
+    const i64* dp_list;                      // jobs that need the kernel below (the rest were answered by k_gcig_nogap), or null: all
+    const u64* packed; int pW, pMW, pstride; // the batch's packed reads (2 bits per base + N masks, k_pack_reads): what k_gcig_nogap compares
 };
 
 __device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(pac[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3; }
 
 __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     extern __shared__ int lds[];             // hA[qlen + 2] | hB[qlen + 2] | e[qlen + 2] | query bytes (as ints, 4 per word)
-    const i64 jb = blockIdx.x;
-    if (jb >= A.njobs) return;
+    if ((i64)blockIdx.x >= A.njobs) return;
+    const i64 jb = A.dp_list ? A.dp_list[blockIdx.x] : (i64)blockIdx.x;
     const int lane = threadIdx.x;
     const meme_gjob J = A.jobs[jb];
     const int qlen = J.qlen, tlen = J.tlen, w = J.w;
@@ -203,6 +205,72 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     if (lane == 0) { out[len] = 0; A.nm[jb] = n_mm + n_gap; A.mdlen[jb] = len; }
 }
 
+// bwa_gen_cigar2's gap-free shortcut (src/bwa.cpp:295-304) for the jobs of a batch that take it, ONE LANE per job: the query span against
+// the text 32 bases per XOR on the packed reads k_pack_reads left on the ctx (2 bits per base, N as A with a mask beside it) and the 2-bit
+// text -- score, the one M operation, NM and the MD string (visited mismatch by mismatch, in the reversed order on the reverse strand).
+// A batch of 150-bp reads with 1 % errors poses 70 % of its calls this way; a wavefront-wide block each (k_gcig) cost 70 ns per job.
+constexpr int NOGAP_MAX_LEN = 500;           // reads beyond LEARNED_MAX_READ_LEN are not packed: k_gcig takes their jobs
+__device__ __forceinline__ bool nogap_fast(const meme_gjob& J, const i64* read_off) {
+    return J.w < 0 && read_off[J.read + 1] - read_off[J.read] <= NOGAP_MAX_LEN;
+}
+__global__ void __launch_bounds__(256) k_gcig_nogap(GcigArgs A) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < A.njobs; jb += (i64)gridDim.x * blockDim.x) {
+        const meme_gjob J = A.jobs[jb];
+        if (!nogap_fast(J, A.read_off)) continue;
+        const int qlen = J.qlen;
+        const u64* fw = A.packed + (i64)J.read * A.pstride;
+        const u64* nmask = fw + 2 * A.pW;
+        const bool has_n = (fw[A.pstride - 1] >> 31) & 1ull;
+        char* out = A.md ? A.md + A.mdoff[jb] : nullptr;
+        const char* const b2c = J.rev ? "TGCA" : "ACGT";
+        const int nblk = (qlen + 31) >> 5;
+        int len = 0, n_mm = 0, n_n = 0, last = J.rev ? qlen : -1;
+        auto put_run = [&](int run) {
+            char buf[12];
+            int l = 0;
+            do { buf[l++] = (char)('0' + run % 10); run /= 10; } while (run);
+            for (int i = 0; i < l; ++i) out[len + i] = buf[l - 1 - i];
+            len += l;
+        };
+        for (int kk = 0; kk < nblk; ++kk) {
+            const int k = J.rev ? nblk - 1 - kk : kk;
+            const int p0 = J.qb + 32 * k, nvalid = qlen - 32 * k < 32 ? qlen - 32 * k : 32;
+            const int wi = p0 >> 5, sh = (p0 & 31) * 2;
+            const u64 q = sh ? (fw[wi] << sh) | (fw[wi + 1] >> (64 - sh)) : fw[wi];
+            const u64 t = extract32(A.pac, J.rb + 32 * k);
+            const u64 x = q ^ t;
+            u64 y = (x | (x >> 1)) & 0x5555555555555555ull;                     // bit 62 - 2i: base i of the block differs
+            if (has_n) {
+                const int mw = p0 >> 6, ms = p0 & 63;
+                u64 nb = nmask[mw] >> ms;
+                if (ms > 32 && mw + 1 < A.pMW) nb |= nmask[mw + 1] << (64 - ms);
+                unsigned nbits = (unsigned)(nb & 0xffffffffull);
+                if (nvalid < 32) nbits &= (1u << nvalid) - 1u;
+                n_n += __popc(nbits);
+                while (nbits) { const int i = __ffs((int)nbits) - 1; nbits &= nbits - 1; y |= 1ull << (62 - 2 * i); }
+            }
+            if (nvalid < 32) y &= ~0ull << (2 * (32 - nvalid));
+            n_mm += __popcll(y);
+            if (out)
+                while (y) {
+                    const int i = J.rev ? 31 - (__builtin_ctzll(y) >> 1) : (__clzll((long long)y) >> 1);
+                    y &= ~(1ull << (62 - 2 * i));
+                    const int j = 32 * k + i;
+                    put_run(J.rev ? last - j - 1 : j - last - 1);
+                    out[len++] = b2c[(int)(t >> (62 - 2 * i)) & 3];
+                    last = j;
+                }
+        }
+        if (out) { put_run(J.rev ? last : qlen - last - 1); out[len] = 0; A.nm[jb] = n_mm; A.mdlen[jb] = len; }
+        const int cap = qlen + J.tlen + 2;
+        A.cig[A.coff[jb] + cap - 1] = (unsigned)qlen << 4;
+        meme_gres R;
+        R.score = A.o.a * (qlen - n_mm) - A.o.b * (n_mm - n_n) - n_n;            // bwa_fill_scmat: match a, mismatch -b, an ambiguous base -1
+        R.n_cigar = 1; R.cigar_off = cap - 1;
+        A.res[jb] = R;
+    }
+}
+
 // the operations of every job, densely packed in job order (they were pushed back to front: already in CIGAR order)
 __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__ res, const i64* __restrict__ coff, const uint32_t* __restrict__ cig,
                                                     const i64* __restrict__ ooff, i64 njobs, uint32_t* __restrict__ out) {
@@ -213,14 +281,19 @@ __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__
         for (int k = 0; k < R.n_cigar; ++k) dst[k] = src[k];
     }
 }
-__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, i64* __restrict__ zsz, i64* __restrict__ csz, i64* __restrict__ msz) {
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, i64* __restrict__ zsz,
+                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         const meme_gjob J = jobs[jb];
+        isdp[jb] = !(fast && nogap_fast(J, read_off));                       // 1: the job goes to k_gcig
         const i64 n_col = J.qlen < 2 * J.w + 1 ? J.qlen : 2 * J.w + 1;
         zsz[jb] = J.w < 0 ? 0 : (n_col * J.tlen + 15) & ~(i64)15;           // (w < 0: the gap-free shortcut, no matrix)
         csz[jb] = J.qlen + J.tlen + 2;
         if (msz) msz[jb] = 2 * ((i64)J.qlen + J.tlen) + 16;                // an MD string never has more than two characters per base
     }
+}
+__global__ void __launch_bounds__(256) k_gcig_dplist(const i64* __restrict__ isdp, const i64* __restrict__ dpoff, i64 njobs, i64* __restrict__ list) {
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) if (isdp[jb]) list[dpoff[jb]] = jb;
 }
 __global__ void __launch_bounds__(256) k_gcig_ncig(const meme_gres* __restrict__ res, i64 njobs, i64* __restrict__ ncig) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) ncig[jb] = res[jb].n_cigar;
@@ -284,7 +357,7 @@ struct GcigRun { i64 tops = 0, tmd = 0; };
 int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool with_md, const char* who, GcigRun* out) {
     int rc;
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
-    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 10 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 13 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     i64* d_zsz = (i64*)G[1].p;
     i64* d_csz = d_zsz + (njobs + 1);
     i64* d_zoff = d_csz + (njobs + 1);
@@ -295,13 +368,22 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool w
     i64* d_moff = d_msz + (njobs + 1);
     i64* d_psz = d_moff + (njobs + 1);
     i64* d_poff = d_psz + (njobs + 1);
-    i64* d_bad = d_poff + (njobs + 1);
+    i64* d_isdp = d_poff + (njobs + 1);
+    i64* d_dpoff = d_isdp + (njobs + 1);
+    i64* d_dplist = d_dpoff + (njobs + 1);
+    i64* d_bad = d_dplist + (njobs + 1);
+    // the gap-free shortcut on the packed reads the seeding call left on the ctx (reads of at most 500 bases)
+    const bool fast = ctx->packed.p != nullptr && ctx->last_seed_max_len > 0;
+    const int pW = (int)((ctx->last_seed_max_len + 31) / 32) + 2, pMW = (int)((ctx->last_seed_max_len + 63) / 64);      // PackGeom of that batch (meme_seed.hip)
     HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
-    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, d_zsz, d_csz, with_md ? d_msz : (i64*)nullptr);
-    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs))) return rc;
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, d_zsz, d_csz,
+                       with_md ? d_msz : (i64*)nullptr, d_isdp);
+    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs)) || (rc = meme_scan_exclusive(ctx, d_isdp, d_dpoff, njobs))) return rc;
+    hipLaunchKernelGGL(k_gcig_dplist, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const i64*)d_isdp, (const i64*)d_dpoff, (i64)njobs, d_dplist);
     if (with_md && (rc = meme_scan_exclusive(ctx, d_msz, d_moff, njobs))) return rc;
-    i64 tz = 0, tc = 0, tm = 0;
+    i64 tz = 0, tc = 0, tm = 0, ndp = 0;
+    HIP_TRY(hipMemcpyAsync(&ndp, d_dpoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&tz, d_zoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&tc, d_coff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (with_md) HIP_TRY(hipMemcpyAsync(&tm, d_moff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -328,9 +410,15 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool w
     A.o = *opt; A.zoff = d_zoff; A.z = (uint8_t*)G[2].p; A.coff = d_coff; A.cig = (uint32_t*)G[3].p; A.res = (meme_gres*)G[4].p;
     A.mdoff = d_moff; A.md = with_md ? (char*)G[6].p : nullptr;
     A.nm = with_md ? (int32_t*)G[7].p : nullptr; A.mdlen = with_md ? (int32_t*)G[7].p + njobs : nullptr;
-    const size_t lds = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3);
-    if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_gcig, dim3((unsigned)njobs), dim3(64), lds, ctx->stream, A);
+    A.dp_list = nullptr; A.packed = (const u64*)ctx->packed.p; A.pW = pW; A.pMW = pMW; A.pstride = 2 * pW + 2 * pMW + 1;
+    if (ndp < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
+    if (ndp > 0) {
+        GcigArgs D = A;
+        D.dp_list = d_dplist; D.njobs = ndp;
+        const size_t lds = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3);
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_gcig, dim3((unsigned)ndp), dim3(64), lds, ctx->stream, D);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_gcig_ncig, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (i64)njobs, d_ncig);
     if ((rc = meme_scan_exclusive(ctx, d_ncig, d_ooff, njobs))) return rc;

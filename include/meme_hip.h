@@ -252,6 +252,8 @@ typedef struct {
     float chain_ms, ext_ms, bsw_ms;  /* HIP-event times: chaining kernels; the extension stage (incl. its host round trips); of which banded SW */
     int64_t n_flt_jobs, n_flt_dropped;   /* mem_flt_chained_seeds: alignments run (mem_seed_sw), chained seeds removed (0 / 0 where it is a no-op) */
     int64_t n_exact_prefix;          /* measurement (tuning "ext_census" = 1, else -1): first-attempt jobs whose query equals the first qlen target bases */
+    int64_t census_band_cells;       /* ... the DP cells of their band-limited matrices (no trimming, no z-drop: an upper bound of the cells evaluated) */
+    int64_t census_class[9];         /* ... jobs per LDS size class of the lane-per-pair kernel (query <= 30, 62, 94, 126, 158, 222, 318, 600 bases), [8]: longer queries */
 } meme_ext_host_result;
 int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* chain_opt,
                                 const meme_ext_opt* ext_opt, meme_ext_host_result* out);

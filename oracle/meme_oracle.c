@@ -150,7 +150,84 @@ typedef struct {
     int64_t hit_cap, n_hits;
     int overflow;
     orc_counters* ctr;
+    /* measurement only (orc_diag_census_*): the diagonals (text position of read base 0) of the unique loci this read has met so far */
+    int n_diag_smem, n_diag_any, round_tag;
+    int64_t diag_smem[8], diag_any[8];
 } rstate;
+
+/* ---- measurement: how many searches a "diagonal + plcp" shortcut could answer (profiles/r05_diag_census.md) -------------------------------
+ * A read that has met a locus with ONE occurrence knows where on the text each of its bases should lie (the diagonal d: read base p at text
+ * position d + p; a search to the left of p is a search to the right of the mirror position n - 1 - (d + p)).  Let L_d be the number of bases
+ * the query shares with the text at that candidate u.  Every other suffix v shares lcp(u, v) <= plcp[u] bases with suffix u, so if
+ * plcp[u] < L_d no other suffix reaches L_d bases of the query: the search's answer is (L_d, one occurrence, u) -- no model look-up, no window.
+ * The census counts, per round, the searches for which that holds with a diagonal from (a) an earlier emitted SMEM of one occurrence, (b) any
+ * earlier search of the read that ended on one occurrence, and checks the claimed answer against the search's real one. */
+static const uint8_t* g_census_plcp = NULL;
+static long long g_census[4][6];     /* [round 1, re-seeding, third round][searches, eligible (a), eligible (b), wrong claims, L_d < min_seed_len among eligible (b), spare] */
+void orc_diag_census_enable(const uint8_t* plcp) { g_census_plcp = plcp; memset(g_census, 0, sizeof(g_census)); }
+void orc_diag_census_get(long long* out) { memcpy(out, g_census, sizeof(g_census)); }
+/* plcp[u] = min(255, LCP of the suffix at text position u with the nearer of its two suffix-array neighbours) -- the table k_build_plcp makes on the device */
+void orc_build_plcp(const uint8_t* text, const uint64_t* sa, int64_t n, uint8_t* plcp) {
+    uint8_t* adj = (uint8_t*)malloc((size_t)n + 1);          /* adj[i] = min(255, lcp(sa[i-1], sa[i])) */
+    adj[0] = 0; adj[n] = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 1; i < n; ++i) {
+        const int64_t a = (int64_t)sa[i - 1], b = (int64_t)sa[i];
+        int l = 0;
+        while (l < 255 && a + l < n && b + l < n && text[a + l] == text[b + l]) ++l;
+        adj[i] = (uint8_t)l;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) plcp[sa[i]] = adj[i] > adj[i + 1] ? adj[i] : adj[i + 1];
+    free(adj);
+}
+static void census_search(rstate* r, int right, const uint8_t* q, int64_t valid, uint32_t L, int64_t s, int64_t c) {
+    if (!g_census_plcp) return;
+    const orc_index* idx = r->idx;
+    const int64_t n = idx->n;
+    const int p = right ? r->pivot : r->pivot;           /* read position the query starts at (right) / ends at (left) */
+    int elig[2] = {0, 0}, wrong = 0, shortd = 0;
+    for (int kind = 0; kind < 2; ++kind) {
+        const int nd = kind ? r->n_diag_any : r->n_diag_smem;
+        const int64_t* dg = kind ? r->diag_any : r->diag_smem;
+        for (int k = 0; k < nd && !elig[kind]; ++k) {
+            const int64_t u = right ? dg[k] + p : n - 1 - (dg[k] + p);
+            if (u < 0 || u >= n) continue;
+            int64_t Ld = 0;
+            while (Ld < valid && u + Ld < n && idx->text[u + Ld] == q[Ld]) ++Ld;
+            const int pl = g_census_plcp[u];
+            if (pl != 255 && pl < Ld) {
+                elig[kind] = 1;
+                if ((uint32_t)Ld != L || c != 1 || (int64_t)idx->sa[s] != u) wrong = 1;
+                if (kind == 1 && Ld < r->min_seed_len) shortd = 1;
+            }
+        }
+    }
+    long long* g = g_census[r->round_tag];
+#pragma omp atomic
+    g[0] += 1;
+#pragma omp atomic
+    g[1] += elig[0];
+#pragma omp atomic
+    g[2] += elig[1];
+#pragma omp atomic
+    g[3] += wrong;
+#pragma omp atomic
+    g[4] += shortd;
+    if (c == 1 && r->n_diag_any < 8) {                   /* what this search teaches the read */
+        const int64_t v = (int64_t)idx->sa[s];
+        const int64_t d = right ? v - p : n - 1 - v - p;
+        int seen = 0;
+        for (int k = 0; k < r->n_diag_any; ++k) seen |= r->diag_any[k] == d;
+        if (!seen) r->diag_any[r->n_diag_any++] = d;
+    }
+}
+static void census_smem(rstate* r, int start, int64_t pos, int64_t c) {
+    if (!g_census_plcp || c != 1 || r->n_diag_smem >= 8) return;
+    const int64_t d = pos - start;
+    for (int k = 0; k < r->n_diag_smem; ++k) if (r->diag_smem[k] == d) return;
+    r->diag_smem[r->n_diag_smem++] = d;
+}
 
 static void set_pivot(rstate* r, int pivot) {   /* set_forward_pivot, :68-71 */
     r->pivot = pivot;
@@ -169,8 +246,10 @@ static uint32_t right_smem(rstate* r) {
     int amb = first_n(r->fw, r->pivot, r->l_seq);
     int64_t valid = amb - r->pivot, s, c;
     uint32_t L = orc_search(r->idx, r->fw + r->pivot, valid, r->min_intv_limit, &s, &c, r->ctr);
+    census_search(r, 1, r->fw + r->pivot, valid, L, s, c);
     if ((int)L >= r->min_seed_len) {
         if (r->n_smems >= r->smem_cap || r->n_hits + c > r->hit_cap) { r->overflow = 1; return L; }
+        census_smem(r, r->pivot, (int64_t)r->idx->sa[s], c);
         orc_mem_tl* m = &r->smems[r->n_smems++];
         m->start = r->pivot;
         m->end = r->pivot + (int)L;
@@ -189,10 +268,14 @@ static uint32_t mem_only(rstate* r, int right) {
     int64_t s, c;
     if (right) {
         int amb = first_n(r->fw, r->pivot, r->l_seq);
-        return orc_search(r->idx, r->fw + r->pivot, amb - r->pivot, r->min_intv_limit, &s, &c, r->ctr);
+        uint32_t L = orc_search(r->idx, r->fw + r->pivot, amb - r->pivot, r->min_intv_limit, &s, &c, r->ctr);
+        census_search(r, 1, r->fw + r->pivot, amb - r->pivot, L, s, c);
+        return L;
     }
     int amb = first_n(r->rc, r->l_pivot, r->l_seq);
-    return orc_search(r->idx, r->rc + r->l_pivot, amb - r->l_pivot, r->min_intv_limit, &s, &c, r->ctr);
+    uint32_t L = orc_search(r->idx, r->rc + r->l_pivot, amb - r->l_pivot, r->min_intv_limit, &s, &c, r->ctr);
+    census_search(r, 0, r->rc + r->l_pivot, amb - r->l_pivot, L, s, c);
+    return L;
 }
 
 /* the zig-zag shared by step1 and OnePos: from search_pivot extend left to the MEM start, then right
@@ -279,7 +362,9 @@ static void all_pos(rstate* r, int split_len, int split_width, int with_round2) 
             }
             set_pivot(r, (qbeg + qend) >> 1);
             r->min_intv_limit = r->smems[k].hitcount + 1;
+            r->round_tag = 1;
             one_pos(r);
+            r->round_tag = 0;
             r->min_intv_limit = saved;
             set_pivot(r, next_pivot);
         }
@@ -301,6 +386,12 @@ static void seed_strategy(rstate* r) {
         int64_t best;
         uint32_t L = locate(idx, q, valid, &best);
         if (r->ctr) r->ctr->searches++;
+        if (g_census_plcp) {                 /* third round: the longest match and whether it is alone -- what a diagonal with plcp[u] < L_d also tells */
+            int64_t s1 = extend_down(idx, q, L, best), e1 = extend_up(idx, q, L, best);
+            r->round_tag = 2;
+            census_search(r, 1, q, valid, L, s1, e1 - s1 + 1);
+            r->round_tag = 0;
+        }
         if ((int)L < msl) { set_pivot(r, r->pivot + msl); continue; }
         int64_t s = best, e = best, last_s = best, last_cnt = 0, cnt, emit_s;
         uint32_t match_len;

@@ -58,6 +58,11 @@ int orc_seed_batch(const orc_index* idx, const uint8_t* reads, const int64_t* re
                    uint64_t* hits, int64_t hit_cap_per_read, int64_t* n_hits, orc_counters* ctr,
                    int threads);
 
+/* measurement only: census of the searches a diagonal + plcp shortcut could answer (see meme_oracle.c); plcp[u] per TEXT position, out = 4 x 6 counters */
+void orc_diag_census_enable(const uint8_t* plcp);
+void orc_diag_census_get(long long* out);
+void orc_build_plcp(const uint8_t* text, const uint64_t* sa, int64_t n, uint8_t* plcp);
+
 /* single primitives, exposed for unit tests */
 int orc_compare(const orc_index* idx, uint64_t sa_slot, const uint8_t* q, int64_t valid_len,
                 uint32_t* match_len, int* exact);
