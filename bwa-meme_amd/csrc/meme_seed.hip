@@ -176,10 +176,10 @@ __global__ void __launch_bounds__(BLOCK) k_gather(const SaEnt* __restrict__ sa, 
 }
 
 template <int G>
-int launch_k_seed(meme_ctx* ctx, const SeedArgs& A, size_t lds, i64 blocks) {
+int launch_k_seed(hipStream_t stream, const SeedArgs& A, size_t lds, i64 blocks) {
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_seed<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_seed<G>, dim3((unsigned)blocks), dim3(BLOCK), lds, ctx->stream, A);
+    hipLaunchKernelGGL(k_seed<G>, dim3((unsigned)blocks), dim3(BLOCK), lds, stream, A);
     HIP_TRY(hipGetLastError());
     return MEME_OK;
 }
@@ -192,7 +192,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
-    if ((rc = meme_buf_reserve(ctx, ctx->counters, 16 * sizeof(unsigned long long)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, ctx->counters, 2 * 16 * sizeof(unsigned long long)))) return rc;     // two sets: an overflow tier may run beside the re-seeding kernels
     const int dev_cus = ctx->n_cus;
     // ---- pack the reads: 2 bits/base, both strands, N masks (k_pack_reads) ---------------------------------
     // the reference exits on reads longer than LEARNED_MAX_READ_LEN (src/bwamem.cpp:1259-1262): fail loudly, never seed part of a batch
@@ -224,9 +224,9 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     i64 launches = 0, searches = 0, windows = 0, lane_searches = 0;
     TierTable tiers;
     for (int t = 0; t < N_TIERS; ++t) { tiers.base[t] = nullptr; tiers.cap[t] = 0; }
-    i64 n_todo = nreads;
-    const i64* pending = nullptr;
-    for (int tier = 0;; ++tier) {
+    // One k_seed launch of a tier: `n_todo` reads (tier 0: the batch; overflow tiers: the reads named in `pending`), SMEM slots in
+    // ctx->slots[tier], the reads that overflow THIS tier appended to ctx->ovf[tier & 1], counters in set `cset`.
+    auto launch_tier = [&](int tier, i64 n_todo, const i64* pending, int cset, hipStream_t stream, bool defer) -> int {
         // overflow tiers hold a 512-entry SMEM ring per read in LDS: run them 32 lanes per read (8 reads per block)
         int G = tier == 0 ? (int)ctx->group_lanes : 32;
         const int cap = tier == 0 ? (int)ctx->smem_cap : TIER_CAP[tier];
@@ -245,14 +245,11 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
                 return MEME_E_CAPACITY;
             }
         }
-        if ((rc = meme_buf_reserve(ctx, sb, need))) return rc;
-        if ((rc = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc;
-        HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), ctx->stream));
-        // Tier 0 leaves the re-seeding regions of unique SMEMs to k_reseed (a walk on the plcp table, one lane per read) and a resume
-        // launch for the regions the walk cannot settle; the overflow tiers search everything themselves.
-        const bool defer = tier == 0 && ctx->seed_defer != 0 && ctx->idx.plcp != nullptr && opt->rounds >= 2;
-        if (defer && (rc = meme_buf_reserve(ctx, ctx->pend, (size_t)n_todo * sizeof(i64)))) return rc;
-        if (defer && (rc = meme_buf_reserve(ctx, ctx->blk, (size_t)n_todo * BLK_PER_READ * 2 * sizeof(BlkRec)))) return rc;
+        int rc2;
+        if ((rc2 = meme_buf_reserve(ctx, sb, need))) return rc2;
+        if ((rc2 = meme_buf_reserve(ctx, ob, (size_t)n_todo * sizeof(i64)))) return rc2;
+        unsigned long long* counters = (unsigned long long*)ctx->counters.p + 16 * cset;
+        HIP_TRY(hipMemsetAsync(counters, 0, 16 * sizeof(unsigned long long), stream));
         SeedArgs A;
         A.I = ctx->idx;
         A.packed = (const u64*)ctx->packed.p;
@@ -269,7 +266,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.cap = cap;
         A.lcap = lcap;
         A.tier = tier;
-        A.counters = (unsigned long long*)ctx->counters.p;
+        A.counters = counters;
         A.defer = defer ? 1 : 0;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
@@ -280,53 +277,95 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         i64 blocks = ctx->seed_blocks > 0 ? ctx->seed_blocks : (i64)dev_cus * ctx->seed_blocks_per_cu;
         if (blocks > want) blocks = want;
         if (blocks < 1) blocks = 1;
-        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        if (tier == 0) HIP_TRY(hipEventRecord(ctx->ev[0], stream));
         switch (G) {
-        case 1: rc = launch_k_seed<1>(ctx, A, lds, blocks); break;
-        case 2: rc = launch_k_seed<2>(ctx, A, lds, blocks); break;
-        case 4: rc = launch_k_seed<4>(ctx, A, lds, blocks); break;
-        case 8: rc = launch_k_seed<8>(ctx, A, lds, blocks); break;
-        case 16: rc = launch_k_seed<16>(ctx, A, lds, blocks); break;
-        case 32: rc = launch_k_seed<32>(ctx, A, lds, blocks); break;
+        case 1: return launch_k_seed<1>(stream, A, lds, blocks);
+        case 2: return launch_k_seed<2>(stream, A, lds, blocks);
+        case 4: return launch_k_seed<4>(stream, A, lds, blocks);
+        case 8: return launch_k_seed<8>(stream, A, lds, blocks);
+        case 16: return launch_k_seed<16>(stream, A, lds, blocks);
+        case 32: return launch_k_seed<32>(stream, A, lds, blocks);
         default: meme_set_error("group_lanes must be 1, 2, 4, 8, 16 or 32"); return MEME_E_ARG;
         }
-        if (rc) return rc;
-        if (defer) {
-            // re-seeding of the unique SMEMs: one lane per read on the plcp table, with its own searches where the table ends
-            HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
-            ReseedArgs R;
-            R.I = ctx->idx; R.packed = (const u64*)ctx->packed.p; R.geo = geo; R.nreads = n_todo; R.opt = *opt;
-            R.slots = (SlotRec*)sb.p; R.cap = cap; R.slot_cnt = (int*)ctx->slot_cnt.p; R.slot_hits = (i64*)ctx->slot_hits.p;
-            R.ovf_list = (i64*)ob.p; R.counters = (unsigned long long*)ctx->counters.p; R.pend_list = (i64*)ctx->pend.p;
-            R.blk = (BlkRec*)ctx->blk.p; R.blk_out = R.blk + n_todo * BLK_PER_READ; R.blk_cap = n_todo * BLK_PER_READ;
-            R.blk_ctr = 14; R.blk_out_ctr = 15;
-            i64 rblocks = (n_todo + 255) / 256;
-            if (rblocks > (i64)dev_cus * 32) rblocks = (i64)dev_cus * 32;
-            hipLaunchKernelGGL(k_reseed, dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, R);
-            // the batch searches (list sizes stay on the device: fixed grids, grid-stride loops), then the blocked regions' second pass
-            const unsigned sblocks = (unsigned)(rblocks < (i64)dev_cus * 4 ? rblocks : (i64)dev_cus * 4);
-            // the pending intervals on a stream of their own, beside the blocked regions' rounds (both are latency-bound lane-per-item
-            // kernels; they touch different slots of the reads they share)
-            if (!ctx->stream_emit) { HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_emit, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_emit[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_emit[1], hipEventDisableTiming)); }
-            HIP_TRY(hipEventRecord(ctx->ev_emit[0], ctx->stream));
-            HIP_TRY(hipStreamWaitEvent(ctx->stream_emit, ctx->ev_emit[0], 0));
-            hipLaunchKernelGGL(k_reseed_emit, dim3(sblocks), dim3(256), 0, ctx->stream_emit, R);
-            HIP_TRY(hipEventRecord(ctx->ev_emit[1], ctx->stream_emit));
-            constexpr int ROUNDS = 4;                           // (named configuration: 3 rounds leave 2.2 ms of one-by-one searches to the last pass)
-            for (int round = 0; round < ROUNDS; ++round) {     // blocked regions ping-pong between two lists; the last pass searches for itself
-                hipLaunchKernelGGL(k_reseed_search, dim3(sblocks), dim3(256), 0, ctx->stream, R);
-                if (round < ROUNDS - 1) {
-                    hipLaunchKernelGGL(k_reseed_resume<false>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
-                    HIP_TRY(hipMemsetAsync((unsigned long long*)ctx->counters.p + R.blk_ctr, 0, sizeof(unsigned long long), ctx->stream));
-                    std::swap(R.blk, R.blk_out); std::swap(R.blk_ctr, R.blk_out_ctr);
-                } else hipLaunchKernelGGL(k_reseed_resume<true>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
-            }
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_emit[1], 0));
-            HIP_TRY(hipGetLastError());
+    };
+    auto tally = [&](const unsigned long long* h) {
+        ++launches;
+        searches += (i64)h[1];
+        windows += (i64)h[3];
+#ifdef SEED_PROF
+        {
+            double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)h[4 + k];
+            fprintf(stderr, "[seed prof]:");
+            const char* nm[6] = {"control", "request+rmi", "window+compare", "resolve", "level", "apply"};
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)h[4 + k] / (tot > 0 ? tot : 1));
+            fprintf(stderr, "\n");
         }
-        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-        HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+#endif
+    };
+    // ---- tier 0: the whole batch.  It leaves the re-seeding regions of unique SMEMs to k_reseed (a walk on the plcp table, one lane per
+    // read) and the batches of searches behind it; the overflow tiers search everything themselves.
+    const bool defer = ctx->seed_defer != 0 && ctx->idx.plcp != nullptr && opt->rounds >= 2;
+    if (defer && (rc = meme_buf_reserve(ctx, ctx->pend, (size_t)nreads * sizeof(i64)))) return rc;
+    if (defer && (rc = meme_buf_reserve(ctx, ctx->blk, (size_t)nreads * BLK_PER_READ * 2 * sizeof(BlkRec)))) return rc;
+    if ((rc = launch_tier(0, nreads, nullptr, 0, ctx->stream, defer))) return rc;
+    i64 n_early = -1;                  // reads of the tier-1 launch that ran beside the re-seeding kernels (-1: none did)
+    if (!ctx->stream_side[0]) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_side[0], hipStreamNonBlocking));
+    if (!ctx->ev_side[0]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_side[0], hipEventDisableTiming));
+    if (!ctx->ev_aux) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+    if (defer) {
+        const int cap = (int)ctx->smem_cap;
+        HIP_TRY(hipEventRecord(ctx->ev[4], ctx->stream));
+        ReseedArgs R;
+        R.I = ctx->idx; R.packed = (const u64*)ctx->packed.p; R.geo = geo; R.nreads = nreads; R.opt = *opt;
+        R.slots = (SlotRec*)ctx->slots[0].p; R.cap = cap; R.slot_cnt = (int*)ctx->slot_cnt.p; R.slot_hits = (i64*)ctx->slot_hits.p;
+        R.ovf_list = (i64*)ctx->ovf[0].p; R.counters = (unsigned long long*)ctx->counters.p; R.pend_list = (i64*)ctx->pend.p;
+        R.blk = (BlkRec*)ctx->blk.p; R.blk_out = R.blk + nreads * BLK_PER_READ; R.blk_cap = nreads * BLK_PER_READ;
+        R.blk_ctr = 14; R.blk_out_ctr = 15;
+        i64 rblocks = (nreads + 255) / 256;
+        if (rblocks > (i64)dev_cus * 32) rblocks = (i64)dev_cus * 32;
+        hipLaunchKernelGGL(k_reseed, dim3((unsigned)rblocks), dim3(256), 0, ctx->stream, R);
+        HIP_TRY(hipEventRecord(ctx->ev_aux, ctx->stream));
+        // the batch searches (list sizes stay on the device: fixed grids, grid-stride loops), then the blocked regions' passes
+        const unsigned sblocks = (unsigned)(rblocks < (i64)dev_cus * 4 ? rblocks : (i64)dev_cus * 4);
+        // the pending intervals on a stream of their own, beside the blocked regions' rounds (both are latency-bound lane-per-item
+        // kernels; they touch different slots of the reads they share)
+        if (!ctx->stream_emit) { HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_emit, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_emit[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_emit[1], hipEventDisableTiming)); }
+        HIP_TRY(hipEventRecord(ctx->ev_emit[0], ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream_emit, ctx->ev_emit[0], 0));
+        hipLaunchKernelGGL(k_reseed_emit, dim3(sblocks), dim3(256), 0, ctx->stream_emit, R);
+        HIP_TRY(hipEventRecord(ctx->ev_emit[1], ctx->stream_emit));
+        constexpr int ROUNDS = 4;                           // (named configuration: 3 rounds leave 2.2 ms of one-by-one searches to the last pass)
+        for (int round = 0; round < ROUNDS; ++round) {     // blocked regions ping-pong between two lists; the last pass searches for itself
+            hipLaunchKernelGGL(k_reseed_search, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+            if (round < ROUNDS - 1) {
+                hipLaunchKernelGGL(k_reseed_resume<false>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+                HIP_TRY(hipMemsetAsync((unsigned long long*)ctx->counters.p + R.blk_ctr, 0, sizeof(unsigned long long), ctx->stream));
+                std::swap(R.blk, R.blk_out); std::swap(R.blk_ctr, R.blk_out_ctr);
+            } else hipLaunchKernelGGL(k_reseed_resume<true>, dim3(sblocks), dim3(256), 0, ctx->stream, R);
+        }
+        HIP_TRY(hipGetLastError());
+        // The reads that overflowed their slots in k_seed or in k_reseed's pass are known once k_reseed has finished -- the only re-seeding
+        // kernel that looks at every read; the ones behind it work from lists of reads that did NOT overflow.  Their tier-1 launch (a few
+        // homopolymer reads of thousands of SMEMs each: 2.5 ms at the named configuration however few they are) runs beside the batches
+        // of searches instead of behind them.  Reads that overflow later (appended by a resume pass: rare) get a second launch below.
+        if (ctx->seed_early_tier != 0) {
+            unsigned long long h_ovf = 0;
+            HIP_TRY(hipStreamWaitEvent(ctx->stream_side[0], ctx->ev_aux, 0));
+            HIP_TRY(hipMemcpyAsync(&h_ovf, (unsigned long long*)ctx->counters.p + 2, 8, hipMemcpyDeviceToHost, ctx->stream_side[0]));
+            HIP_TRY(hipStreamSynchronize(ctx->stream_side[0]));
+            if (h_ovf > 0) {
+                n_early = (i64)h_ovf;
+                if ((rc = launch_tier(1, n_early, (const i64*)ctx->ovf[0].p, 1, ctx->stream_side[0], false))) return rc;
+                HIP_TRY(hipEventRecord(ctx->ev_side[0], ctx->stream_side[0]));
+                HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_side[0], 0));
+            }
+        }
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_emit[1], 0));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h_counters, ctx->counters.p, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ms_total += ms;
@@ -339,29 +378,38 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
             fprintf(stderr, "[reseed prof] (wave-time in 10 ns ticks, executions) stage windows %llu / %llu, table walk %llu / %llu, lane search %llu / %llu\n", h_counters[4], h_counters[5],
                     h_counters[6], h_counters[7], h_counters[8], h_counters[9]);
 #endif
-            if (getenv("MEME_SEED_TRACE")) fprintf(stderr, "[meme] seed tier 0: search kernel %.2f ms, re-seeding kernel %.2f ms (%lld lane searches)\n",
-                                                   ms - a, a, (long long)h_counters[12]);
+            if (getenv("MEME_SEED_TRACE")) fprintf(stderr, "[meme] seed tier 0: search kernel + re-seeding kernels %.2f ms, of which behind k_seed %.2f ms (%lld lane searches; %lld reads of the "
+                                                   "overflow tier beside them)\n", ms, a, (long long)h_counters[12], (long long)(n_early < 0 ? 0 : n_early));
         }
-        ++launches;
-        searches += (i64)h_counters[1];
-#ifdef SEED_PROF
-        {
-            double tot = 0; for (int k = 0; k < 8; ++k) tot += (double)h_counters[4 + k];
-            fprintf(stderr, "[seed prof] tier %d:", tier);
-            const char* nm[6] = {"control", "request+rmi", "window+compare", "resolve", "level", "apply"};
-            for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)h_counters[4 + k] / (tot > 0 ? tot : 1));
-            fprintf(stderr, "\n");
-        }
-#endif
-        windows += (i64)h_counters[3];
-        if (h_counters[2] == 0) break;
-        // some reads produced more SMEMs than their slots hold (pathological repeats): re-run only those
-        if (tier + 1 >= N_TIERS) {
+    }
+    tally(h_counters);
+    // ---- overflow tiers: reads that produced more SMEMs than their slots hold (pathological repeats) are re-run alone
+    i64 n_todo = (i64)h_counters[2];
+    const i64* pending = (const i64*)ctx->ovf[0].p;
+    for (int tier = 1; n_todo > 0; ++tier) {
+        if (tier >= N_TIERS) {
             meme_set_error("a read produced more than %d SMEMs", TIER_CAP[N_TIERS - 1]);
             return MEME_E_CAPACITY;
         }
+        const int cset = tier & 1;
+        if (tier == 1 && n_early == n_todo) {
+            // the launch beside the re-seeding kernels took them all: only its counters are left to read
+            HIP_TRY(hipMemcpyAsync(h_counters, (unsigned long long*)ctx->counters.p + 16 * cset, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else {
+            // (tier 1 after an early launch that did not see every overflowed read: all of them again -- rare, and simple)
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            if ((rc = launch_tier(tier, n_todo, pending, cset, ctx->stream, false))) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_TRY(hipMemcpyAsync(h_counters, (unsigned long long*)ctx->counters.p + 16 * cset, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ms_total += ms;
+        }
+        tally(h_counters);
         n_todo = (i64)h_counters[2];
-        pending = (const i64*)ob.p;
+        pending = (const i64*)ctx->ovf[tier & 1].p;
     }
     {
         float pms = 0.f;
@@ -524,7 +572,7 @@ extern "C" int meme_seed_reserve(meme_ctx* ctx, int64_t nreads, int64_t total_ba
     int rc;
     struct { DevBuf* b; size_t bytes; } dev[] = {
         {&ctx->reads, (size_t)total_bases + 16}, {&ctx->read_off, (n + 1) * 8}, {&ctx->slot_cnt, n * 4}, {&ctx->slot_hits, n * 8},
-        {&ctx->slot_loc, n * 8}, {&ctx->counters, 16 * 8}, {&ctx->pend, n * 8}, {&ctx->blk, n * BLK_PER_READ * 2 * sizeof(BlkRec)}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
+        {&ctx->slot_loc, n * 8}, {&ctx->counters, 2 * 16 * 8}, {&ctx->pend, n * 8}, {&ctx->blk, n * BLK_PER_READ * 2 * sizeof(BlkRec)}, {&ctx->packed, n * stride * 8}, {&ctx->slots[0], n * (size_t)ctx->smem_cap * sizeof(SlotRec)},
         {&ctx->smem_off, (n + 1) * 8}, {&ctx->hit_off, (n + 1) * 8}, {&ctx->smems, n * 12 * sizeof(meme_mem_tl)}, {&ctx->hits, n * 24 * 8},
         {&ctx->chain[0], n * 16 * 32}, {&ctx->chain[1], n * 16 * 8 * 16}, {&ctx->chain[2], n * 24}, {&ctx->chain[3], n * 4}, {&ctx->chain[8], n * 8},
         {&ctx->chain[5], (n + 1) * 32 + n * 5 + 64}, {&ctx->chain[6], n * 3 * sizeof(meme_chain)}, {&ctx->chain[7], n * 6 * sizeof(meme_chain_seed)}};

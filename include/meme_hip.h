@@ -15,6 +15,7 @@
  *   meme_extend_last_batch_host     <- mem_chain2aln_across_reads_V2()              src/bwamem.cpp:2573-3497 (behind the chaining stage)
  *   meme_global_batch_host          <- ksw_global2() under bwa_gen_cigar2()         src/ksw.cpp:560-670, src/bwa.cpp:274-362
  *   meme_gen_cigar_batch_host       <- bwa_gen_cigar2() whole: CIGAR + NM + MD       src/bwa.cpp:274-362
+ *   meme_sam_format_batch_host      <- mem_aln2sam() for a chunk's plain records     src/bwamem.cpp:2174-2312
  *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
  *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
  *
@@ -314,6 +315,36 @@ typedef struct { int64_t njobs; const meme_cres* res; const uint32_t* cigars; in
 int meme_gen_cigar_batch_host(meme_ctx* ctx, const meme_cjob* jobs, int64_t njobs, const meme_bsw_opt* opt /* o_del e_del o_ins e_ins a b */,
                               meme_cres_host* out);
 
+/* ---- SAM text: mem_aln2sam() for the plain records of a chunk --------------------------------------------------------------------------
+ * What mem_aln2sam() (reference src/bwamem.cpp:2174-2312, with add_cigar :2161-2172 and get_rlen :2402-2410) appends to its kstring for
+ * one alignment record of a read, for the records that need nothing but the record itself, its mate's record and the read: the only
+ * record of its read (n == 1: no SA tag), no read comment (-C), no pa tag (alt_sc == 0), no XR tag (-V).  Flags, coordinates swapped in
+ * from the mate for an unmapped end, hard / soft clipping by `which`, template length from both CIGARs, SEQ / QUAL reversed on the reverse
+ * strand, NM, MD, MC, AS, XS, RG, XA as in the reference, byte for byte.  The read's bases are those of the batch resident on the ctx
+ * (codes: a base prints as "ACGTN"[code]); names and qualities are staged beside them once per batch (meme_sam_stage_text).
+ * A record names its variable-length parts by offsets into `blob`: its n_cigar operations with the MD string right behind them (as
+ * bwa_gen_cigar2 / mem_reg2aln leave them), the mate's operations, the XA string.  Results: the records' texts back to back in record
+ * order (text_off[k] .. text_off[k+1]), in pinned memory owned by the ctx, valid until its next call of this function. */
+typedef struct {
+    int64_t pos, m_pos;          /* mem_aln_t::pos of the record and of its mate */
+    int64_t cigar_off;           /* blob: n_cigar x uint32, then the NUL-terminated MD string (only read when n_cigar > 0) */
+    int64_t m_cigar_off;         /* blob: the mate's m_n_cigar x uint32 */
+    int64_t xa_off;              /* blob: the NUL-terminated XA string, or -1 */
+    int32_t read;                /* read of the batch resident on the ctx */
+    int32_t flag;                /* mem_aln_t::flag as handed to mem_aln2sam */
+    int32_t rid, is_rev, is_alt, mapq, NM, score, sub, n_cigar;
+    int32_t has_mate, m_rid, m_is_rev, m_is_alt, m_n_cigar;
+    int32_t which;               /* index of the record among its read's (clipping style) */
+} meme_sam_rec;
+typedef struct { int64_t nrecs; const int64_t* text_off; const char* text; int64_t text_bytes; float kernel_ms; } meme_sam_host_result;
+/* names (name_off[r] .. name_off[r+1], no terminator) and qualities (same offsets as the reads' bases; NULL: no qualities, '*') of the
+ * batch the last seeding call left on the ctx */
+int meme_sam_stage_text(meme_ctx* ctx, const char* names, const int64_t* name_off /* nreads + 1 */, const char* quals);
+int meme_sam_format_batch_host(meme_ctx* ctx, const meme_sam_rec* recs, int64_t nrecs, const uint8_t* blob, int64_t blob_bytes,
+                               const char* contig_names, const int32_t* contig_name_off /* n_contigs + 1 */, int32_t n_contigs,
+                               int32_t softclip /* opt->flag & MEM_F_SOFTCLIP */, const char* rg_id /* bwa_rg_id, may be empty */,
+                               meme_sam_host_result* out);
+
 /* ---- mate-rescue Smith-Waterman: the other DP kernel of the SAM phase ---------------------------------------------------------------
  * What mem_sam_pe_batch() (reference src/bwamem_pair.cpp:719-818) computes with kswv::getScores8 / getScores16 (src/kswv.cpp) for the
  * SeqPair jobs mem_matesw_batch_pre() (src/bwamem_pair.cpp:1060-1223) posed: local alignment of a mate (query, len2 bases at qer + idq)
@@ -345,7 +376,7 @@ typedef struct {
     int64_t seed_lane_searches;   /* searches k_reseed did itself, one lane each (what the table cannot answer) */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY) */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "seed_early_tier" (0: overflow tiers strictly behind the re-seeding kernels), "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY) */
 
 #ifdef __cplusplus
 }

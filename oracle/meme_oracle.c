@@ -1461,6 +1461,106 @@ int orc_gen_cigar2(const uint8_t* text, int64_t l_pac, int a, int b, int o_del, 
     return 0;
 }
 
+/* ---- SAM text of one record: mem_aln2sam (reference src/bwamem.cpp:2174-2312) for the only record of a read (no SA / pa / XR tag, no comment) ------
+ * rec = the fields of the record and of its mate (meme_sam_rec of include/meme_hip.h, restated here as orc_sam_rec), cigars / MD / XA in `blob`;
+ * name, seq (codes), qual (or NULL) of the read; contig names.  out: capacity as the caller likes (a record is < l_name + 2 l_seq + 16 n_cigar + |MD| +
+ * |XA| + 256 bytes).  Returns the text length (no terminator written). */
+static int o_putw(char* o, long long v) {            /* kputw / kputl */
+    char buf[24];
+    int l = 0, n = 0;
+    unsigned long long x = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+    do { buf[l++] = (char)('0' + x % 10); x /= 10; } while (x);
+    if (v < 0) o[n++] = '-';
+    while (l) o[n++] = buf[--l];
+    return n;
+}
+static int o_add_cigar(char* o, const uint32_t* cg, int n_cigar, int softclip, int is_alt, int which) {     /* add_cigar, :2161-2172 */
+    int n = 0;
+    if (!n_cigar) { o[n++] = '*'; return n; }
+    for (int i = 0; i < n_cigar; ++i) {
+        int c = (int)(cg[i] & 0xf);
+        if (!softclip && !is_alt && (c == 3 || c == 4)) c = which ? 4 : 3;
+        n += o_putw(o + n, cg[i] >> 4);
+        o[n++] = "MIDSH"[c];
+    }
+    return n;
+}
+static long long o_rlen(int n_cigar, const uint32_t* cg) {          /* get_rlen, :2402-2410 */
+    long long l = 0;
+    for (int k = 0; k < n_cigar; ++k) { const int op = (int)(cg[k] & 0xf); if (op == 0 || op == 2) l += cg[k] >> 4; }
+    return l;
+}
+int64_t orc_aln2sam(const orc_sam_rec* r, const uint8_t* blob, const char* name, int l_name, const uint8_t* seq, int l_seq, const char* qual,
+                    const char* contig_names, const int32_t* contig_name_off, int softclip, const char* rg_id, char* o) {
+    int64_t n = 0;
+    int flag = r->flag, rid = r->rid, is_rev = r->is_rev, n_cigar = r->n_cigar;
+    int64_t pos = r->pos;
+    const int has_m = r->has_mate;
+    int m_rid = r->m_rid, m_is_rev = r->m_is_rev, m_n_cigar = r->m_n_cigar;
+    int64_t m_pos = r->m_pos;
+    uint32_t cgb[1], mcb[1];
+    const uint32_t* cg = r->n_cigar > 0 ? (const uint32_t*)(blob + r->cigar_off) : cgb;       /* (blob offsets are 4-byte aligned by the caller) */
+    const uint32_t* mcg = r->m_n_cigar > 0 ? (const uint32_t*)(blob + r->m_cigar_off) : mcb;
+    const char* md = r->n_cigar > 0 ? (const char*)(blob + r->cigar_off + 4 * (int64_t)r->n_cigar) : "";
+    flag |= has_m ? 0x1 : 0;
+    flag |= rid < 0 ? 0x4 : 0;
+    flag |= has_m && m_rid < 0 ? 0x8 : 0;
+    if (rid < 0 && has_m && m_rid >= 0) { rid = m_rid; pos = m_pos; is_rev = m_is_rev; n_cigar = 0; }
+    if (has_m && m_rid < 0 && rid >= 0) { m_rid = rid; m_pos = pos; m_is_rev = is_rev; m_n_cigar = 0; }
+    flag |= is_rev ? 0x10 : 0;
+    flag |= has_m && m_is_rev ? 0x20 : 0;
+    memcpy(o + n, name, (size_t)l_name); n += l_name; o[n++] = '\t';
+    n += o_putw(o + n, (flag & 0xffff) | (flag & 0x10000 ? 0x100 : 0)); o[n++] = '\t';
+    if (rid >= 0) {
+        const int ln = contig_name_off[rid + 1] - contig_name_off[rid];
+        memcpy(o + n, contig_names + contig_name_off[rid], (size_t)ln); n += ln; o[n++] = '\t';
+        n += o_putw(o + n, pos + 1); o[n++] = '\t';
+        n += o_putw(o + n, r->mapq); o[n++] = '\t';
+        n += o_add_cigar(o + n, cg, n_cigar, softclip, r->is_alt, r->which);
+    } else { memcpy(o + n, "*\t0\t0\t*", 7); n += 7; }
+    o[n++] = '\t';
+    if (has_m && m_rid >= 0) {
+        if (rid == m_rid) o[n++] = '=';
+        else { const int ln = contig_name_off[m_rid + 1] - contig_name_off[m_rid]; memcpy(o + n, contig_names + contig_name_off[m_rid], (size_t)ln); n += ln; }
+        o[n++] = '\t';
+        n += o_putw(o + n, m_pos + 1); o[n++] = '\t';
+        if (rid == m_rid) {
+            const long long p0 = pos + (is_rev ? o_rlen(n_cigar, cg) - 1 : 0);
+            const long long p1 = m_pos + (m_is_rev ? o_rlen(m_n_cigar, mcg) - 1 : 0);
+            if (m_n_cigar == 0 || n_cigar == 0) o[n++] = '0';
+            else n += o_putw(o + n, -(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
+        } else o[n++] = '0';
+    } else { memcpy(o + n, "*\t0\t0", 5); n += 5; }
+    o[n++] = '\t';
+    if (flag & 0x100) { memcpy(o + n, "*\t*", 3); n += 3; }
+    else {
+        int qb = 0, qe = l_seq;
+        if (n_cigar && r->which && !softclip && !r->is_alt) {
+            const int c0 = (int)(cg[0] & 0xf), c1 = (int)(cg[n_cigar - 1] & 0xf);
+            if (!is_rev) { if (c0 == 4 || c0 == 3) qb += (int)(cg[0] >> 4); if (c1 == 4 || c1 == 3) qe -= (int)(cg[n_cigar - 1] >> 4); }
+            else { if (c0 == 4 || c0 == 3) qe -= (int)(cg[0] >> 4); if (c1 == 4 || c1 == 3) qb += (int)(cg[n_cigar - 1] >> 4); }
+        }
+        if (!is_rev) for (int i = qb; i < qe; ++i) o[n++] = "ACGTN"[seq[i] > 4 ? 4 : seq[i]];
+        else for (int i = qe - 1; i >= qb; --i) o[n++] = "TGCAN"[seq[i] > 4 ? 4 : seq[i]];
+        o[n++] = '\t';
+        if (qual) {
+            if (!is_rev) for (int i = qb; i < qe; ++i) o[n++] = qual[i];
+            else for (int i = qe - 1; i >= qb; --i) o[n++] = qual[i];
+        } else o[n++] = '*';
+    }
+    if (n_cigar) {
+        memcpy(o + n, "\tNM:i:", 6); n += 6; n += o_putw(o + n, r->NM);
+        memcpy(o + n, "\tMD:Z:", 6); n += 6; { const size_t l = strlen(md); memcpy(o + n, md, l); n += (int64_t)l; }
+    }
+    if (has_m && m_n_cigar) { memcpy(o + n, "\tMC:Z:", 6); n += 6; n += o_add_cigar(o + n, mcg, m_n_cigar, softclip, r->m_is_alt, r->which); }
+    if (r->score >= 0) { memcpy(o + n, "\tAS:i:", 6); n += 6; n += o_putw(o + n, r->score); }
+    if (r->sub >= 0) { memcpy(o + n, "\tXS:i:", 6); n += 6; n += o_putw(o + n, r->sub); }
+    if (rg_id && rg_id[0]) { memcpy(o + n, "\tRG:Z:", 6); n += 6; { const size_t l = strlen(rg_id); memcpy(o + n, rg_id, l); n += (int64_t)l; } }
+    if (r->xa_off >= 0) { const char* xa = (const char*)(blob + r->xa_off); const size_t l = strlen(xa); memcpy(o + n, "\tXA:Z:", 6); n += 6; memcpy(o + n, xa, l); n += (int64_t)l; }
+    o[n++] = '\n';
+    return n;
+}
+
 /* ---- mate-rescue Smith-Waterman of the SAM phase (kswv, reference src/kswv.cpp; driver mem_sam_pe_batch, src/bwamem_pair.cpp:719-818) --------
  * The reference runs 64 (int8) or 32 (int16) pairs per AVX-512 vector, one pair per SIMD lane; what one lane computes does not depend on
  * its neighbours (padding rows / columns never hold a row maximum; the cross-lane loop bounds maxl / minh / limit only widen ranges that

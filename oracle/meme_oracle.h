@@ -58,6 +58,14 @@ int orc_seed_batch(const orc_index* idx, const uint8_t* reads, const int64_t* re
                    uint64_t* hits, int64_t hit_cap_per_read, int64_t* n_hits, orc_counters* ctr,
                    int threads);
 
+/* mem_aln2sam for the only record of a read (reference src/bwamem.cpp:2174-2312); orc_sam_rec = meme_sam_rec of include/meme_hip.h */
+typedef struct {
+    int64_t pos, m_pos, cigar_off, m_cigar_off, xa_off;
+    int32_t read, flag, rid, is_rev, is_alt, mapq, NM, score, sub, n_cigar, has_mate, m_rid, m_is_rev, m_is_alt, m_n_cigar, which;
+} orc_sam_rec;
+int64_t orc_aln2sam(const orc_sam_rec* r, const uint8_t* blob, const char* name, int l_name, const uint8_t* seq, int l_seq, const char* qual,
+                    const char* contig_names, const int32_t* contig_name_off, int softclip, const char* rg_id, char* out);
+
 /* measurement only: census of the searches a diagonal + plcp shortcut could answer (see meme_oracle.c); plcp[u] per TEXT position, out = 4 x 6 counters */
 void orc_diag_census_enable(const uint8_t* plcp);
 void orc_diag_census_get(long long* out);

@@ -8,6 +8,7 @@
 //   ref_flt_chained_seeds  mem_flt_chained_seeds() with mem_seed_sw()      reference src/bwamem.cpp:565-598, 494-520 (ksw_align2, src/ksw.cpp)
 //   ref_kswv_batch      sort_classify() + mem_sam_pe_batch()                reference src/bwamem.cpp:1798-1825, src/bwamem_pair.cpp:719-818
 //                       (the AVX-512 mate-rescue kernels kswv::getScores8 / getScores16, src/kswv.cpp)
+//   ref_aln2sam         mem_aln2sam()                                      reference src/bwamem.cpp:2174-2312
 //   ref_ksw_global2 / ref_gen_cigar2   ksw_global2(), bwa_gen_cigar2() whole (CIGAR + NM + MD)   reference src/ksw.cpp:560-670, src/bwa.cpp:274-362
 //
 // Linked against oracle/_ref/libbwa_pic.so (the reference's objects, built where the sources lie by oracle/Makefile.ref) into
@@ -16,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "bwamem.h"      // reference headers, found via -I$(REF)/src at build time
@@ -303,6 +305,60 @@ int ref_gen_cigar2(const uint8_t* fwd, int64_t l_pac, int a, int b, int o_del, i
     memcpy(md, m, (size_t)l + 1);
     free(cg);
     return 0;
+}
+
+// mem_aln2sam (src/bwamem.cpp:2174-2312) for one record of a read that has `n_list` records (here 1) and, optionally, a mate's record.
+// rec = the fields of meme_sam_rec / orc_sam_rec (16 x int32 after 5 x int64), blob = cigars / MD / XA as the record names them.
+// seq: codes.  out receives the text; returns its length or -1 when cap is too small.
+struct shim_sam_rec {
+    int64_t pos, m_pos, cigar_off, m_cigar_off, xa_off;
+    int32_t read, flag, rid, is_rev, is_alt, mapq, NM, score, sub, n_cigar, has_mate, m_rid, m_is_rev, m_is_alt, m_n_cigar, which;
+};
+int64_t ref_aln2sam(const shim_sam_rec* r, const uint8_t* blob, const char* name, const uint8_t* seq, int l_seq, const char* qual, const char* contig_names,
+                    const int32_t* contig_name_off, int n_contigs, int softclip, const char* rg_id, char* out, int64_t cap) {
+    mem_opt_t* opt = mem_opt_init();
+    if (softclip) opt->flag |= MEM_F_SOFTCLIP;
+    bntseq_t bns;
+    memset(&bns, 0, sizeof(bns));
+    bns.n_seqs = n_contigs;
+    std::vector<bntann1_t> anns((size_t)n_contigs);
+    std::vector<std::string> names((size_t)n_contigs);
+    for (int i = 0; i < n_contigs; ++i) {
+        names[(size_t)i].assign(contig_names + contig_name_off[i], contig_names + contig_name_off[i + 1]);
+        memset(&anns[(size_t)i], 0, sizeof(bntann1_t));
+        anns[(size_t)i].name = (char*)names[(size_t)i].c_str();
+    }
+    bns.anns = anns.data();
+    strncpy(bwa_rg_id, rg_id ? rg_id : "", 255);
+    std::string nm(name), sq((const char*)seq, (size_t)l_seq), ql(qual ? qual : "");
+    bseq1_t s;
+    memset(&s, 0, sizeof(s));
+    s.name = (char*)nm.c_str(); s.seq = (char*)sq.data(); s.qual = qual ? (char*)ql.c_str() : nullptr; s.l_seq = l_seq;
+    mem_aln_t p, m;
+    memset(&p, 0, sizeof(p)); memset(&m, 0, sizeof(m));
+    // (the operations and, behind them, the MD string: one block, as mem_reg2aln leaves it)
+    std::vector<uint32_t> pc((size_t)(r->n_cigar > 0 ? r->n_cigar : 0) + 64), mc((size_t)(r->m_n_cigar > 0 ? r->m_n_cigar : 0) + 1);
+    if (r->n_cigar > 0) {
+        memcpy(pc.data(), blob + r->cigar_off, (size_t)r->n_cigar * 4);
+        const char* md = (const char*)(blob + r->cigar_off + 4 * (int64_t)r->n_cigar);
+        pc.resize((size_t)r->n_cigar + strlen(md) / 4 + 2);
+        strcpy((char*)(pc.data() + r->n_cigar), md);
+    }
+    if (r->m_n_cigar > 0) memcpy(mc.data(), blob + r->m_cigar_off, (size_t)r->m_n_cigar * 4);
+    p.pos = r->pos; p.rid = r->rid; p.flag = r->flag; p.is_rev = r->is_rev; p.is_alt = r->is_alt; p.mapq = r->mapq; p.NM = r->NM; p.n_cigar = r->n_cigar;
+    p.cigar = r->n_cigar > 0 ? pc.data() : nullptr; p.XA = r->xa_off >= 0 ? (char*)(blob + r->xa_off) : nullptr; p.score = r->score; p.sub = r->sub; p.alt_sc = 0;
+    m.pos = r->m_pos; m.rid = r->m_rid; m.is_rev = r->m_is_rev; m.is_alt = r->m_is_alt; m.n_cigar = r->m_n_cigar; m.cigar = r->m_n_cigar > 0 ? mc.data() : nullptr;
+    // `which` > 0: the record is the which-th of its read's list; the others are secondary (0x100), so that no SA tag is written (the device's scope)
+    std::vector<mem_aln_t> list((size_t)r->which + 1);
+    for (auto& x : list) { memset(&x, 0, sizeof(x)); x.flag = 0x100; x.rid = 0; }
+    list[(size_t)r->which] = p;
+    kstring_t str = {0, 0, 0};
+    mem_aln2sam(opt, &bns, &str, &s, r->which + 1, list.data(), r->which, r->has_mate ? &m : nullptr);
+    int64_t n = (int64_t)str.l;
+    if (n > cap) n = -1; else memcpy(out, str.s, (size_t)n);
+    free(str.s); free(opt);
+    bwa_rg_id[0] = 0;
+    return n;
 }
 
 
