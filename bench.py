@@ -500,6 +500,43 @@ def config4_class_leg(ctx, dev, genome, text, sa, l1, l2, l_pac, steps=3):
     return out
 
 
+def live_pmc_traffic(steps=2):
+    """HBM traffic of the SA-search stage measured in THIS run: bench.py re-executes itself (seeding only, `steps` launches, no warm-up) once under
+    `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` -- counters in passes of their own, as the MI355X guide prescribes -- and sums the
+    counters over the stage's kernels (k_seed<G> + k_reseed*).  Returns {"fetch_kb", "write_kb"} per launch, or None when the tool is not there or a
+    pass fails (the caller then keeps the committed pass)."""
+    import glob
+    import sqlite3
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = {}
+    for key, counter in (("fetch_kb", "FETCH_SIZE"), ("write_kb", "WRITE_SIZE")):
+        d = tempfile.mkdtemp(prefix="meme_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", MEME_BENCH_PMC="0", MEME_BENCH_CPU="0", MEME_BENCH_E2E="0", MEME_BENCH_BSW="0", MEME_BENCH_KSWV="0", MEME_BENCH_CHAIN="0",
+                       MEME_BENCH_EXT="0", MEME_BENCH_C4="0", MEME_BENCH_PARITY_READS="0")
+            r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "0"],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            dbs = glob.glob(os.path.join(d, "**", "*results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                log("pmc pass %s failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-300:]))
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
+            stage = [x for x in rows if ("k_seed" in x[0] or "k_reseed" in x[0])]
+            if not stage:
+                return None
+            out[key] = sum(x[1] for x in stage) / steps
+            out[key + "_kernels"] = {x[0][:48]: x[1] / steps for x in stage}
+        except Exception as e:
+            log("pmc pass %s failed: %r" % (counter, e))
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def sam_md5(path):
     """md5 and line count of a SAM file without its @PG line (it holds the command line).  Header lines are read one by one, the records in blocks."""
     import hashlib
@@ -681,6 +718,9 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
                     "chain_kernels_s": float(m.group(2)), "ext_kernels_s": float(m.group(3)), "bsw_kernel_s": float(m.group(4)),
                     "alignment_records": int(m.group(5)), "bsw_pairs": int(m.group(6)), "bsw_pairs_doubled_band": int(m.group(7)),
                     "reads_chained_on_host": int(m.group(9))})
+            for m in re.finditer(r"SAM text on the device: (\d+) records formatted there so far \(kernels ([0-9.]+) s, whole stage ([0-9.]+) s\), (\d+) by the reference's mem_aln2sam", err):
+                info.setdefault("backend", {}).update({"sam_records_on_device": int(m.group(1)), "sam_kernels_s": float(m.group(2)), "sam_stage_s": float(m.group(3)),
+                                                        "sam_records_by_reference": int(m.group(4))})
             prof = re.findall(r"\[meme-dropin-prof\]   (.+?)\s+([0-9.]+) s\s+(\d+) calls", err)
             if prof:
                 info["sam_phase_thread_seconds"] = {k.strip(): {"s": float(v), "calls": int(c)} for k, v, c in prof}
@@ -689,6 +729,15 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
                 refcache.put(ckey, info)
             log("e2e: %s wall %.1f s, process %.1f s (CPU %.1f s), %d SAM lines" % (spec, wall, proc, proc_cpu, nlines))
         ref, drop = out.get("bwa-meme_mode3"), out[dropin_exe]
+        # what bounds the bound aligner (for reading an N-GPU curve: the device stages of a chunk run on its GPUs side by side -- one slice each -- and,
+        # from the second chunk on, beside the previous chunk's host phases; mem_process_seqs is the host's own time)
+        dev_s = drop.get("backend", {}).get("device_stages_s")
+        if dev_s is not None and drop["process_s"] > 0:
+            drop["bound"] = {"device_stages_wall_s": dev_s, "device_stages_wall_s_per_gpu_if_split_evenly": dev_s, "gpus": devices, "host_process_s": drop["process_s"],
+                             "host_process_cpu_s": drop["process_cpu_s"], "host_cpu_quota": host_cpu_quota(),
+                             "reading": ("host-bound: mem_process_seqs (%.2f s) exceeds the device stages (%.2f s wall, every GPU working on its slice at once); more GPUs "
+                                         "shorten only the device stages" % (drop["process_s"], dev_s)) if drop["process_s"] >= dev_s else
+                                        ("device-bound: the device stages (%.2f s) exceed mem_process_seqs (%.2f s); more GPUs shorten the run" % (dev_s, drop["process_s"]))}
         return {"metric": "e2e_reads_per_sec", "value": drop["reads_per_s_wall"], "unit": "reads/s",
                 "workload": "mem -7 (reference: -t %s, its best of a 32-256 sweep; with the backend bound: -t %d), %d pairs of %d-bp reads (%g %% substitutions, %g %% indels, "
                             "300-500 bp inserts%s) vs the benchmark genome (%d bp), wall time incl. index loading"
@@ -1140,6 +1189,23 @@ def main():
                         except Exception as e:
                             log("config4_class e2e failed: %r" % (e,))
                             c4["e2e"] = {"failed": repr(e)[:300]}
+        # ---- roofline.traffic measured in this run (the committed pass stays as the fall-back, labelled as such) -----------------------
+        if single and os.environ.get("MEME_BENCH_PMC", "1") != "0" and time.time() - T_START < budget - 200:
+            try:
+                if ctx is not None:               # (the passes build the index again: the HBM has to be free)
+                    ctx.close()
+                    ctx = None
+                    keep = d_reads = d_off = None
+                    torch.cuda.empty_cache()
+                live = live_pmc_traffic()
+                if live:
+                    out["roofline"]["traffic"] = (2 * live["fetch_kb"] + live["write_kb"]) * 1024.0
+                    out["roofline"]["traffic_source"] = ("this run: bench.py re-executed under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, 2 launches of the "
+                                                         "stage each, counters summed over k_seed + k_reseed*); (2 x FETCH_SIZE + WRITE_SIZE) x 1024 as the MI355X guide prescribes")
+                    out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / (bpr * nreads)
+                    out["roofline"]["traffic_counters_kb_per_launch"] = {"FETCH_SIZE": live["fetch_kb"], "WRITE_SIZE": live["write_kb"]}
+            except Exception as e:
+                log("live pmc passes skipped: %r" % (e,))
         print(json.dumps(out), flush=True)
         if not sample_parity:
             rc_exit = 1

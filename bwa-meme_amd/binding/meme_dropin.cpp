@@ -38,6 +38,32 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }
 bool verbose() { static const bool v = getenv("MEME_DROPIN_VERBOSE") != nullptr; return v; }
 
+// ---- the reference's functions behind the interposed ones (see meme_dropin.h) ---------------------------------------------------------------
+namespace {
+struct RefEntry { const char* what; const char* symbol; void* p; };
+RefEntry g_ref[R_N_SYMS] = {
+    {"mem_process_seqs (src/bwamem.cpp:1920)", "_Z16mem_process_seqsP9mem_opt_tliP7bseq1_tPK12mem_pestat_tR8worker_t", nullptr},
+    {"mem_chain2aln_across_reads_V2 (src/bwamem.cpp:2573)", "_Z29mem_chain2aln_across_reads_V2PK9mem_opt_tPK8bntseq_tPKhP7bseq1_tiP11mem_chain_vP12mem_alnreg_vP9mem_cachePhi", nullptr},
+    {"bseq_read_orig (src/bwa.cpp:184)", "bseq_read_orig", nullptr},
+    {"kt_pipeline, the step function (src/fastmap.cpp:843)", "_Z11kt_pipelinePviS_P9mem_opt_tR8worker_t", nullptr},
+    {"mem_sam_pe_batch (src/bwamem_pair.cpp:719)", "_Z16mem_sam_pe_batchPK9mem_opt_tP9mem_cacheRlS4_P6kswr_tiii", nullptr},
+    {"bwa_gen_cigar2 (src/bwa.cpp:274)", "bwa_gen_cigar2", nullptr},
+    {"mem_aln2sam (src/bwamem.cpp:2174)", "_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_", nullptr},
+    {"mem_pestat (src/bwamem_pair.cpp:81)", "_Z10mem_pestatPK9mem_opt_tliPK12mem_alnreg_vP12mem_pestat_t", nullptr},
+    {"kt_for (src/kthread.cpp:79)", "_Z6kt_forPFvPvlliES_i", nullptr},
+};
+__attribute__((constructor)) void resolve_reference_symbols() {
+    int missing = 0;
+    for (RefEntry& e : g_ref) if (!(e.p = dlsym(RTLD_NEXT, e.symbol))) ++missing;
+    if (!missing) return;
+    fprintf(stderr, "[meme-dropin] the reference library does not export %d of the %d functions the binding stands in front of:\n", missing, (int)R_N_SYMS);
+    for (const RefEntry& e : g_ref) if (!e.p) fprintf(stderr, "[meme-dropin]   %s as %s\n", e.what, e.symbol);
+    fprintf(stderr, "[meme-dropin] (check with: nm -D libbwa_pic.so | grep -E 'mem_process_seqs|kt_for|...'; C++ names are mangled from the signatures in the reference's headers)\n");
+    exit(1);
+}
+}  // namespace
+void* ref_sym(RefSym which) { return g_ref[which].p; }
+
 // ---- the helper team (see meme_dropin.h) ----------------------------------------------------------------------------------------
 namespace {
 struct TeamJob { const std::function<void(int)>* f; int nt; std::atomic<int> next{0}, done{0}; };
@@ -285,6 +311,7 @@ namespace dropin {
 
 Chunk g_chunks[2];
 Chunk* g_cur_chunk = &g_chunks[0];
+int64_t g_cur_chunk_seq = -1;
 
 const bntseq_t* g_bns = nullptr;               // of the run (set by mem_process_seqs)
 std::vector<meme_contig> g_contigs;
@@ -423,6 +450,27 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
             P.ext = tot;
             P.reads_on_ctx = false;                       // (the CIGAR stage names reads of the batch resident on the ctx: not for this part)
         } else if (rc) die("chunk-level device stages (meme_seed_batch_resident_ascii / meme_extend_last_batch_host)");
+        // names and qualities of the slice beside its bases, for the SAM text kernel (the whole slice on the ctx, every read with qualities or none)
+        P.sam_staged = false;
+        if (sam_on_device() && P.reads_on_ctx) {
+            int64_t nb = 0, with_q = 0;
+            if (P.count + 1 > P.name_off_cap) { meme_host_free(P.name_off); P.name_off_cap = P.count + P.count / 4 + 64; if (!(P.name_off = (int64_t*)meme_host_alloc(P.name_off_cap * 8))) die("meme_host_alloc"); }
+            for (int64_t i = 0; i < P.count; ++i) { P.name_off[i] = nb; nb += (int64_t)strlen(seqs[P.first + i].name); with_q += seqs[P.first + i].qual != nullptr; }
+            P.name_off[P.count] = nb;
+            if (with_q == 0 || with_q == P.count) {
+                if (nb + 16 > P.names_cap) { meme_host_free(P.names); P.names_cap = nb + nb / 4 + 4096; if (!(P.names = (char*)meme_host_alloc(P.names_cap))) die("meme_host_alloc"); }
+                if (with_q && bytes + 16 > P.quals_cap) { meme_host_free(P.quals); P.quals_cap = bytes + bytes / 4 + 4096; if (!(P.quals = (char*)meme_host_alloc(P.quals_cap))) die("meme_host_alloc"); }
+                team_for(P.count, cig_threads(), [&](int64_t i0, int64_t i1, int) {
+                    for (int64_t i = i0; i < i1; ++i) {
+                        const bseq1_t& s = seqs[P.first + i];
+                        memcpy(P.names + P.name_off[i], s.name, (size_t)(P.name_off[i + 1] - P.name_off[i]));
+                        if (with_q) memcpy(P.quals + P.off[i], s.qual, (size_t)s.l_seq);
+                    }
+                });
+                if (meme_sam_stage_text(ctx, P.names, P.name_off, with_q ? P.quals : nullptr)) die("meme_sam_stage_text");
+                P.sam_staged = true;
+            }
+        }
         g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
         g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
         g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
@@ -492,7 +540,7 @@ struct Prefetcher {
     std::condition_variable cv;
     struct Job { bseq1_t* seqs; int64_t n, seq; int state; };   // state: 1 queued, 2 running, 3 done
     std::deque<Job> jobs;                                       // in chunk order
-    int64_t processed = -1;                                     // highest chunk number that has left mem_process_seqs
+    int64_t done[2] = {-1, -1};                                 // per slot: highest chunk number whose reads, seeds and staged text nobody needs any more
     mem_opt_t opt;                                              // the run's options BY VALUE (mem -p hands mem_process_seqs a stack-local copy, src/fastmap.cpp:790-828)
     bool has_opt = false;
     bool started = false;
@@ -531,7 +579,7 @@ void prefetch_submit(bseq1_t* seqs, int64_t n) {
                     F.cv.wait(lk, [&] {
                         if (!F.has_opt || F.disabled || !g_ext_on_device || g_dev.empty()) return false;
                         for (Prefetcher::Job& J : F.jobs)
-                            if (J.state == 1) { if (F.processed < J.seq - 2) return false; J.state = 2; seqs = J.seqs; n = J.n; seq = J.seq; return true; }
+                            if (J.state == 1) { if (F.done[J.seq & 1] < J.seq - 2) return false; J.state = 2; seqs = J.seqs; n = J.n; seq = J.seq; return true; }
                         return false;
                     });
                 }
@@ -562,10 +610,11 @@ bool prefetch_take(bseq1_t* seqs, int64_t n, int* slot) {
     F.jobs.erase(F.jobs.begin() + i);
     return true;
 }
-// chunk number `seq` has left mem_process_seqs: its slot may be seeded again
+// chunk number `seq` has left mem_process_seqs -- and, when the device writes its SAM text, the output step has taken that text: its slot
+// may be seeded again
 void prefetch_processed(int64_t seq) {
     Prefetcher& F = *g_pf;
-    { std::lock_guard<std::mutex> lk(F.m); if (seq > F.processed) F.processed = seq; }
+    { std::lock_guard<std::mutex> lk(F.m); if (seq > F.done[seq & 1]) F.done[seq & 1] = seq; }
     F.cv.notify_all();
 }
 
@@ -593,11 +642,7 @@ typedef void (*process_fn)(mem_opt_t*, int64_t, int, bseq1_t*, const mem_pestat_
 }  // namespace dropin
 
 void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs, const mem_pestat_t* pes0, worker_t& w) {
-    static process_fn next = nullptr;
-    if (!next) {
-        next = (process_fn)dlsym(RTLD_NEXT, "_Z16mem_process_seqsP9mem_opt_tliP7bseq1_tPK12mem_pestat_tR8worker_t");
-        if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_process_seqs was not found: %s\n", dlerror()); exit(1); }
-    }
+    static const process_fn next = (process_fn)ref_sym(R_MEM_PROCESS_SEQS);
     const double t_enter = now_s();
     int64_t chunk_seq = -1;                                      // the chunk's number when it came from the binding's reader
     g_team = opt->n_threads > 0 ? opt->n_threads : 1;
@@ -627,12 +672,13 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
         else if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
         g_cur_chunk = &g_chunks[slot];
+        g_cur_chunk_seq = chunk_seq;
         ++g_chunk_gen;
     }
     const double t_body = now_s();
     next(opt, n_processed, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
-    if (chunk_seq >= 0) prefetch_processed(chunk_seq);
+    if (chunk_seq >= 0 && !sam_release_deferred(chunk_seq)) prefetch_processed(chunk_seq);      // (a chunk with SAM text to format is released by the output step)
     if (verbose()) fprintf(stderr, "[meme-dropin] mem_process_seqs of this chunk: %.3f s until its device records were there, %.3f s in the reference's body\n", t_body - t_enter, now_s() - t_body);
     if (verbose() && (double)g_t_prefetched > 0) fprintf(stderr, "[meme-dropin] device stages run ahead of their chunk's turn (beside the previous chunk's SAM phase): %.3f s so far\n", (double)g_t_prefetched);
     if (verbose())
@@ -653,6 +699,7 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
     if (verbose()) meme_dropin_report_matesw();
     if (verbose()) meme_dropin_report_cigar();
     if (verbose()) meme_dropin_report_mate();
+    if (verbose()) meme_dropin_report_sam();
 }
 
 namespace dropin {

@@ -42,6 +42,12 @@ void mem_flt_chained_seeds(const mem_opt_t* opt, const bntseq_t* bns, const uint
 
 namespace dropin {
 
+// The reference's own functions behind the ones the binding interposes: ONE table (meme_dropin.cpp), every entry looked up when the binding
+// is loaded, one message naming everything that is missing -- a reference built with another compiler or other signatures stops at start-up,
+// not in the middle of a run.  (C++ functions are found by their mangled names: the Itanium ABI spelling of the signatures in the reference's headers.)
+enum RefSym { R_MEM_PROCESS_SEQS, R_CHAIN2ALN_V2, R_BSEQ_READ_ORIG, R_KT_PIPELINE, R_MEM_SAM_PE_BATCH, R_BWA_GEN_CIGAR2, R_MEM_ALN2SAM, R_MEM_PESTAT, R_KT_FOR, R_N_SYMS };
+void* ref_sym(RefSym which);
+
 double now_s();
 [[noreturn]] void die(const char* what);
 bool verbose();
@@ -69,12 +75,25 @@ struct ChunkPart {                     // the slice of a chunk one GPU seeded
     std::vector<meme_alnreg> own_regs; std::vector<int64_t> own_reg_off; bool reads_on_ctx = true;
     uint8_t* flat = nullptr; int64_t flat_cap = 0;       // pinned staging (grow-only)
     int64_t* off = nullptr; int64_t off_cap = 0;
+    // SAM text on the device: names and qualities of the slice staged beside its bases (meme_sam_stage_text)
+    bool sam_staged = false;
+    char* names = nullptr; int64_t names_cap = 0; int64_t* name_off = nullptr; int64_t name_off_cap = 0; char* quals = nullptr; int64_t quals_cap = 0;
 };
 struct Chunk {
     const bseq1_t* seqs = nullptr;
     int64_t n = 0;
     std::vector<ChunkPart> part;
 };
+// SAM text on the device (meme_dropin_sam.cpp): the worker threads of a chunk note descriptors, the OUTPUT step of that chunk -- the pipeline's
+// other thread, beside the next chunk's processing -- sends them through the device and writes the text from the ctxs' pinned result buffers.
+struct SamPart { const char* text = nullptr; const int64_t* text_off = nullptr; int64_t first = 0, count = 0; };     // reads [first, first + count): text of read g at text_off[g - first]
+struct SamText { std::vector<SamPart> part; };
+SamText* sam_format_for_output(const bseq1_t* seqs);  // formats the chunk's noted records (null: none); the text is valid until sam_output_done
+void sam_output_done(const bseq1_t* seqs);            // the chunk's text has been written: its slot may take the next chunk
+bool sam_release_deferred(int64_t chunk_seq);         // true: the chunk has records noted, the output step will release its slot
+void prefetch_processed(int64_t seq);
+bool sam_on_device();                                  // MEME_DROPIN_SAM (default on; needs the binding's reader and output step)
+extern int64_t g_cur_chunk_seq;                        // number of the chunk being processed when it came from the binding's reader, else -1
 extern Chunk* g_cur_chunk;                     // the chunk mem_process_seqs is working on (one of two slots)
 #define g_chunk (*dropin::g_cur_chunk)
 // the device stages of a chunk ahead of its turn (started when the FASTQ reader hands the chunk out; meme_dropin.cpp)
@@ -92,6 +111,7 @@ std::atomic<int>& ktfor_calls();               // kt_for calls of the chunk so f
 extern mem_chain_v* g_chunk_chain_ar;          // w.chain_ar of the chunk being processed
 extern uint64_t g_chunk_gen;                   // counts the chunks seeded
 int cig_threads();                             // helper threads of the binding's own host loops
+bool fast_out();                               // MEME_DROPIN_OUT: the binding's output step (writev from the records)
 
 // The binding's own host loops (gathering reads, posing jobs, taking results, the output step) run on a team of helper threads that SLEEP
 // between jobs.  They were OpenMP regions until round 5: libgomp's idle threads spin before they sleep, and under the CPU quota of the
@@ -123,4 +143,5 @@ template <class T, class Less> inline void team_sort(std::vector<T>& v, int nt, 
 void meme_dropin_report_matesw();
 void meme_dropin_report_cigar();
 void meme_dropin_report_mate();
+void meme_dropin_report_sam();
 #endif

@@ -196,8 +196,7 @@ typedef void (*chain2aln_fn)(const mem_opt_t*, const bntseq_t*, const uint8_t*, 
 void mem_chain2aln_across_reads_V2(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int nseq,
                                    mem_chain_v* chain_ar, mem_alnreg_v* av_v, mem_cache* mmc, uint8_t* ref_string, int tid) {
     if (ext_mode() == 0 || !g_chunk.seqs) {
-        static chain2aln_fn next = (chain2aln_fn)dlsym(RTLD_NEXT, "_Z29mem_chain2aln_across_reads_V2PK9mem_opt_tPK8bntseq_tPKhP7bseq1_tiP11mem_chain_vP12mem_alnreg_vP9mem_cachePhi");
-        if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_chain2aln_across_reads_V2 was not found\n"); exit(1); }
+        static const chain2aln_fn next = (chain2aln_fn)ref_sym(R_CHAIN2ALN_V2);
         next(opt, bns, pac, seq_, nseq, chain_ar, av_v, mmc, ref_string, tid);
         return;
     }

@@ -156,7 +156,7 @@ Ahead& g_ahead = *new Ahead;        // (on the heap for good: a run that stops e
 
 extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void* ks2_, int64_t* s) {
     static const bool on = !(getenv("MEME_DROPIN_IO") && atoi(getenv("MEME_DROPIN_IO")) == 0);
-    static bseq_read_fn next = (bseq_read_fn)dlsym(RTLD_NEXT, "bseq_read_orig");
+    static const bseq_read_fn next = (bseq_read_fn)ref_sym(R_BSEQ_READ_ORIG);
     // only the run's read files (the first streams seen); any other caller gets the reference's function
     if (on && !g_rq[0] && ks1_) {
         for (int k = 0; k < 2; ++k) {
@@ -208,8 +208,7 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
 // threads), name / bases / qualities released with their text arenas.  Steps 0 and 1 are the reference's.  MEME_DROPIN_OUT=0: all of it.
 typedef ktp_data_t* (*ktp_step_fn)(void*, int, void*, mem_opt_t*, worker_t&);
 ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, worker_t& w) {
-    static ktp_step_fn next = (ktp_step_fn)dlsym(RTLD_NEXT, "_Z11kt_pipelinePviS_P9mem_opt_tR8worker_t");
-    if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_pipeline step function was not found\n"); exit(1); }
+    static const ktp_step_fn next = (ktp_step_fn)ref_sym(R_KT_PIPELINE);
     if (step != 2 || !fast_out()) return next(shared, step, data, opt, w);
     ktp_aux_t* aux = (ktp_aux_t*)shared;
     ktp_data_t* ret = (ktp_data_t*)data;
@@ -228,10 +227,28 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
     const double t0 = now_s();
     std::vector<struct iovec> iov((size_t)n);
     size_t n_iov = 0;
+    // a read whose record the device formatted (meme_dropin_sam.cpp) has its text in the chunk's arena, in read order: neighbours are adjacent
+    // there and leave as one piece; everybody else's s->sam is the text
+    SamText* dev_text = sam_format_for_output(seqs);
     team_for(n, nt, [&](int64_t i0, int64_t i1, int) {
-        for (int64_t i = i0; i < i1; ++i) { iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0; }
+        size_t d = 0;
+        for (int64_t i = i0; i < i1; ++i) {
+            const char* t = nullptr;
+            int64_t l = 0;
+            if (dev_text) {
+                while (d + 1 < dev_text->part.size() && i >= dev_text->part[d].first + dev_text->part[d].count) ++d;
+                const SamPart& P = dev_text->part[d];
+                if (P.text && i >= P.first && i < P.first + P.count) { l = P.text_off[i - P.first + 1] - P.text_off[i - P.first]; t = P.text + P.text_off[i - P.first]; }
+            }
+            if (l > 0) { iov[(size_t)i].iov_base = (void*)t; iov[(size_t)i].iov_len = (size_t)l; }
+            else { iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0; }
+        }
     });
-    for (int i = 0; i < n; ++i) if (iov[(size_t)i].iov_len) iov[n_iov++] = iov[(size_t)i];
+    for (int i = 0; i < n; ++i) {
+        if (!iov[(size_t)i].iov_len) continue;
+        if (n_iov && (char*)iov[n_iov - 1].iov_base + iov[n_iov - 1].iov_len == (char*)iov[(size_t)i].iov_base) iov[n_iov - 1].iov_len += iov[(size_t)i].iov_len;
+        else iov[n_iov++] = iov[(size_t)i];
+    }
     const double t1 = now_s();
     fflush(aux->fp);                                                // (whatever stdio still holds goes first)
     const int fd = fileno(aux->fp);
@@ -245,6 +262,7 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
         }
     }
     const double t2 = now_s();
+    sam_output_done(seqs);                                          // (the device's text has left: the chunk's slot is free for the next chunk's device stages)
     team_for(n, nt, [&](int64_t i0, int64_t i1, int) {
         for (int64_t i = i0; i < i1; ++i) {
             free(seqs[i].sam); free(seqs[i].comment);

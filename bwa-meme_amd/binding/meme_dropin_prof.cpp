@@ -116,9 +116,3 @@ int mem_approx_mapq_se(const mem_opt_t* opt, const mem_alnreg_t* a) {
     PROF_SCOPE(P_APPROX_MAPQ);
     return next(opt, a);
 }
-void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
-    typedef void (*fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
-    static fn next = next_of<fn>("_Z11mem_aln2samPK9mem_opt_tPK8bntseq_tP11__kstring_tP7bseq1_tiPK9mem_aln_tiSB_");
-    PROF_SCOPE(P_ALN2SAM);
-    next(opt, bns, str, s, n, list, which, m);
-}

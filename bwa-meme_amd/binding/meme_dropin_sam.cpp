@@ -1,6 +1,7 @@
 // Part of the reference-side binding of the MI355X backend (see meme_dropin.h / meme_dropin.cpp).
 #include "meme_dropin.h"
 #include "meme_dropin_prof.h"
+#include <string>
 
 using namespace dropin;
 
@@ -164,8 +165,7 @@ bool matesw_prepass() {                          // false: too few jobs for the 
 // (with the stage off: the reference's batch, timed)
 typedef int (*sam_pe_batch_fn)(const mem_opt_t*, mem_cache*, int64_t&, int64_t&, kswr_t*, int32_t, int32_t, int);
 int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_t& pcnt8, kswr_t* aln, int32_t maxRefLen, int32_t maxQerLen, int tid) {
-    static sam_pe_batch_fn next = (sam_pe_batch_fn)dlsym(RTLD_NEXT, "_Z16mem_sam_pe_batchPK9mem_opt_tP9mem_cacheRlS4_P6kswr_tiii");
-    if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_sam_pe_batch was not found\n"); exit(1); }
+    static const sam_pe_batch_fn next = (sam_pe_batch_fn)ref_sym(R_MEM_SAM_PE_BATCH);
     g_mate_miss.fetch_add(pcnt, std::memory_order_relaxed);
     const double t0 = now_s();
     const int64_t n = pcnt;
@@ -417,8 +417,7 @@ typedef uint32_t* (*gen_cigar2_fn)(const int8_t*, int, int, int, int, int, int64
 
 extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac, const uint8_t* pac, int l_query,
                                     uint8_t* query, int64_t rb, int64_t re, int* score, int* n_cigar, int* NM) {
-    static gen_cigar2_fn next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
-    if (!next) { fprintf(stderr, "[meme-dropin] the reference's bwa_gen_cigar2 was not found\n"); exit(1); }
+    static const gen_cigar2_fn next = (gen_cigar2_fn)ref_sym(R_BWA_GEN_CIGAR2);
     PROF_SCOPE(P_GEN_CIGAR2_HOOK);
     const mem_opt_t* opt = g_opt;
     const CigTable& T = g_cig;
@@ -452,6 +451,214 @@ void meme_dropin_report_cigar() {
             (long long)g_cig.n_jobs, g_cig.t_kernel_ms * 1e-3, g_cig.t_prepass, (long long)g_cig_hits.load(), (long long)g_cig_miss.load());
 }
 
+// ---- SAM text on the device ----------------------------------------------------------------------------------------------
+// mem_aln2sam (src/bwamem.cpp:2174-2312) is what was left of the SAM phase on the host after pairing: 28 % of worker_sam's third step
+// (profiles/r05_sam_phase_split.md) -- kputw / kputc by the dozen, SEQ and QUAL copied base by base -- and behind it an output step that
+// handles one string per read.  The function is interposed: for a record that needs nothing but itself, its mate's record and the read
+// (the only record of its read, no comment, no pa / XR tag: all but the chimeric reads) the hook notes a descriptor -- the numbers, the
+// final CIGAR with its MD string, the mate's CIGAR, the XA string -- in the calling thread's arena and leaves a one-byte marker in the
+// kstring (the caller makes s->sam of it as of any text).  When worker_sam has joined, the chunk's descriptors go to the GPU(s) in one
+// meme_sam_format_batch_host call each (names, qualities and bases are in HBM since the seeding call) and the text comes back as one
+// arena per device, in read order; the output step writes it from there.  Everything else goes to the reference's function as before.
+// MEME_DROPIN_SAM=0: off.  MEME_DROPIN_SAM_CHECK=1 (tests): every such record is ALSO formatted by the reference's function and compared.
+namespace dropin {
+bool sam_on_device() {
+    static const bool v = !(getenv("MEME_DROPIN_SAM") && atoi(getenv("MEME_DROPIN_SAM")) == 0) && fast_out() && ext_mode() == 2;
+    return v;
+}
+bool sam_check() { static const bool v = getenv("MEME_DROPIN_SAM_CHECK") != nullptr; return v; }
+// What the worker threads of one chunk noted: arenas handed out per thread and chunk, owned by the chunk's slot (the threads end with
+// their kt_for call; the arenas stay until the output step has formatted them).
+struct SamArena { std::vector<meme_sam_rec> recs; std::vector<uint8_t> blob; std::vector<std::pair<int64_t, std::string>> check; };
+struct SamSlot {
+    std::mutex mu;
+    std::vector<std::unique_ptr<SamArena>> arenas;   // in use by the chunk being processed / waiting for the output step
+    size_t used = 0;
+    const bseq1_t* seqs = nullptr;                   // the chunk whose records these are (set when its worker_sam has joined)
+    int64_t chunk_seq = -1, n = 0;
+    Chunk* chunk = nullptr;
+    int softclip = 0;
+    std::string rg;
+    // pinned staging of the device calls (grow-only), one set per device slice
+    struct Stage { meme_sam_rec* recs = nullptr; int64_t recs_cap = 0; uint8_t* blob = nullptr; int64_t blob_cap = 0; };
+    std::vector<Stage> stage;
+    SamText text;
+} g_sam_slot[2];
+thread_local SamArena* tl_sam_arena = nullptr;
+thread_local uint64_t tl_sam_gen = 0;
+SamArena& sam_arena() {                               // the calling thread's arena for the chunk being processed
+    if (tl_sam_arena && tl_sam_gen == g_chunk_gen) return *tl_sam_arena;
+    SamSlot& S = g_sam_slot[g_cur_chunk_seq & 1];
+    std::lock_guard<std::mutex> lk(S.mu);
+    if (S.used == S.arenas.size()) S.arenas.emplace_back(new SamArena);
+    tl_sam_arena = S.arenas[S.used++].get();
+    tl_sam_gen = g_chunk_gen;
+    return *tl_sam_arena;
+}
+std::atomic<int64_t> g_sam_dev_recs{0}, g_sam_ref_recs{0};
+double g_sam_kernel_ms = 0, g_sam_stage_s = 0;
+struct SamTally { int64_t dev = 0, ref = 0; ~SamTally() { if (dev) g_sam_dev_recs += dev; if (ref) g_sam_ref_recs += ref; } };
+thread_local SamTally tl_sam_tally;
+std::vector<char> g_contig_names; std::vector<int32_t> g_contig_name_off;
+typedef void (*aln2sam_fn)(const mem_opt_t*, const bntseq_t*, kstring_t*, bseq1_t*, int, const mem_aln_t*, int, const mem_aln_t*);
+
+// worker_sam of the chunk has joined: what its threads noted now belongs to the chunk's output step
+void sam_chunk_closed() {
+    SamSlot& S = g_sam_slot[g_cur_chunk_seq & 1];
+    std::lock_guard<std::mutex> lk(S.mu);
+    S.seqs = nullptr;
+    bool any = false;
+    for (size_t a = 0; a < S.used; ++a) any = any || !S.arenas[a]->recs.empty();
+    if (!any) { S.used = 0; return; }
+    S.seqs = g_chunk.seqs; S.chunk_seq = g_cur_chunk_seq; S.n = g_chunk.n; S.chunk = g_cur_chunk;
+    S.softclip = (g_opt->flag & MEM_F_SOFTCLIP) ? 1 : 0; S.rg = bwa_rg_id;
+    if (g_contig_name_off.empty()) {
+        g_contig_name_off.push_back(0);
+        for (int i = 0; i < g_bns->n_seqs; ++i) { const char* nm = g_bns->anns[i].name; g_contig_names.insert(g_contig_names.end(), nm, nm + strlen(nm)); g_contig_name_off.push_back((int32_t)g_contig_names.size()); }
+        g_contig_names.push_back(0);
+    }
+}
+bool sam_release_deferred(int64_t chunk_seq) {
+    SamSlot& S = g_sam_slot[chunk_seq & 1];
+    std::lock_guard<std::mutex> lk(S.mu);
+    return S.seqs != nullptr && S.chunk_seq == chunk_seq;
+}
+
+// The output step's part (kt_pipeline step 2, meme_dropin_io.cpp): the chunk's noted records through the device.  One record slot per read
+// of a device slice, in read order (a read without a noted record keeps read = -1: no text), assembled in pinned memory by the helper team;
+// the text stays in the ctxs' pinned result buffers until sam_output_done().
+SamText* sam_format_for_output(const bseq1_t* seqs) {
+    SamSlot* Sp = nullptr;
+    for (SamSlot& X : g_sam_slot) { std::lock_guard<std::mutex> lk(X.mu); if (X.seqs && X.seqs == seqs) Sp = &X; }
+    if (!Sp) return nullptr;
+    SamSlot& S = *Sp;
+    const double t0 = now_s();
+    Chunk& C = *S.chunk;
+    const int nd = (int)C.part.size();
+    if ((int)S.stage.size() < nd) S.stage.resize((size_t)nd);
+    // where every arena's blob goes in the concatenation
+    std::vector<int64_t> base(S.used + 1, 0);
+    for (size_t a = 0; a < S.used; ++a) base[a + 1] = base[a] + (((int64_t)S.arenas[a]->blob.size() + 3) & ~(int64_t)3);
+    const int64_t blob_bytes = base[S.used];
+    for (int d = 0; d < nd; ++d) {
+        SamSlot::Stage& G = S.stage[(size_t)d];
+        const int64_t cnt = C.part[(size_t)d].count;
+        if (cnt > G.recs_cap) { meme_host_free(G.recs); G.recs_cap = cnt + cnt / 4 + 64; if (!(G.recs = (meme_sam_rec*)meme_host_alloc(G.recs_cap * (int64_t)sizeof(meme_sam_rec)))) die("meme_host_alloc"); }
+        if (d == 0 && blob_bytes + 64 > G.blob_cap) { meme_host_free(G.blob); G.blob_cap = blob_bytes + blob_bytes / 4 + 4096; if (!(G.blob = (uint8_t*)meme_host_alloc(G.blob_cap))) die("meme_host_alloc"); }
+        team_for(cnt, cig_threads(), [&](int64_t i0, int64_t i1, int) { for (int64_t i = i0; i < i1; ++i) G.recs[i].read = -1; });
+    }
+    uint8_t* const blob = S.stage[0].blob;               // (one blob for all slices: a slice's call ships it whole -- tens of MB)
+    team_for((int64_t)S.used, cig_threads(), [&](int64_t a0, int64_t a1, int) {
+        for (int64_t a = a0; a < a1; ++a) {
+            const SamArena& A = *S.arenas[(size_t)a];
+            if (!A.blob.empty()) memcpy(blob + base[(size_t)a], A.blob.data(), A.blob.size());
+            for (meme_sam_rec r : A.recs) {
+                const int64_t g = r.read;
+                int d = 0;
+                while (d + 1 < nd && g >= C.part[(size_t)d].first + C.part[(size_t)d].count) ++d;
+                if (r.n_cigar > 0) r.cigar_off += base[(size_t)a];
+                if (r.m_n_cigar > 0) r.m_cigar_off += base[(size_t)a];
+                if (r.xa_off >= 0) r.xa_off += base[(size_t)a];
+                r.read = (int32_t)(g - C.part[(size_t)d].first);
+                S.stage[(size_t)d].recs[r.read] = r;
+            }
+        }
+    });
+    S.text.part.assign((size_t)nd, SamPart());
+    std::vector<double> kms((size_t)nd, 0.0);
+    auto run = [&](int d) {
+        const ChunkPart& P = C.part[(size_t)d];
+        if (P.count == 0 || !P.sam_staged) return;
+        meme_sam_host_result R;
+        if (meme_sam_format_batch_host(P.ctx, S.stage[(size_t)d].recs, P.count, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), &R))
+            die("meme_sam_format_batch_host");
+        SamPart& T = S.text.part[(size_t)d];
+        T.text = R.text; T.text_off = R.text_off; T.first = P.first; T.count = P.count;
+        kms[(size_t)d] = R.kernel_ms;
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < nd; ++d) th.emplace_back(run, d);
+    run(0);
+    for (auto& x : th) x.join();
+    for (size_t a = 0; a < S.used; ++a)
+        for (const auto& c : S.arenas[a]->check) {
+            const int64_t g = c.first;
+            int d = 0;
+            while (d + 1 < nd && g >= C.part[(size_t)d].first + C.part[(size_t)d].count) ++d;
+            const SamPart& T = S.text.part[(size_t)d];
+            const char* t = T.text ? T.text + T.text_off[g - T.first] : nullptr;
+            const int64_t l = T.text ? T.text_off[g - T.first + 1] - T.text_off[g - T.first] : 0;
+            if (!t || (size_t)l != c.second.size() || memcmp(t, c.second.data(), c.second.size()) != 0) {
+                fprintf(stderr, "[meme-dropin] SAM text of read %s differs between the device and the reference's mem_aln2sam:\n  device   : %.*s  reference: %s", seqs[g].name, (int)l, t ? t : "",
+                        c.second.c_str());
+                exit(1);
+            }
+        }
+    double km = 0;
+    for (double v : kms) km = km > v ? km : v;
+    g_sam_kernel_ms += km; g_sam_stage_s += now_s() - t0;
+    return &S.text;
+}
+void sam_output_done(const bseq1_t* seqs) {
+    for (SamSlot& S : g_sam_slot) {
+        int64_t seq = -1;
+        {
+            std::lock_guard<std::mutex> lk(S.mu);
+            if (!S.seqs || S.seqs != seqs) continue;
+            for (size_t a = 0; a < S.used; ++a) { S.arenas[a]->recs.clear(); S.arenas[a]->blob.clear(); S.arenas[a]->check.clear(); }
+            S.used = 0; S.seqs = nullptr; seq = S.chunk_seq;
+        }
+        if (seq >= 0) prefetch_processed(seq);           // the slot's reads, seeds and staged text may be overwritten now
+    }
+}
+}  // namespace dropin
+
+void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq1_t* s, int n, const mem_aln_t* list, int which, const mem_aln_t* m) {
+    static const aln2sam_fn next = (aln2sam_fn)ref_sym(R_MEM_ALN2SAM);
+    PROF_SCOPE(P_ALN2SAM);
+    const mem_aln_t& p = list[which];
+    const int64_t g = (g_chunk.seqs && g_cur_chunk_seq >= 0) ? s - g_chunk.seqs : -1;
+    bool dev = sam_on_device() && n == 1 && which == 0 && g >= 0 && g < g_chunk.n && opt == g_opt && bns == g_bns && !s->comment && !(opt->flag & MEM_F_REF_HDR) && p.alt_sc <= 0 &&
+               p.rid < bns->n_seqs && (!m || m->rid < bns->n_seqs) && p.n_cigar >= 0 && (!m || m->n_cigar >= 0) && (p.n_cigar == 0 || p.cigar) && (!m || m->n_cigar == 0 || m->cigar);
+    if (dev) {
+        int d = 0;
+        const int nd = (int)g_chunk.part.size();
+        while (d + 1 < nd && g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
+        dev = g_chunk.part[(size_t)d].sam_staged;
+    }
+    if (!dev) { ++tl_sam_tally.ref; next(opt, bns, str, s, n, list, which, m); return; }
+    SamArena& A = sam_arena();
+    meme_sam_rec r;
+    memset(&r, 0, sizeof(r));
+    r.read = (int32_t)g; r.flag = p.flag; r.rid = p.rid; r.pos = p.pos; r.is_rev = p.is_rev; r.is_alt = p.is_alt; r.mapq = p.mapq; r.NM = p.NM; r.score = p.score; r.sub = p.sub;
+    r.n_cigar = p.n_cigar; r.which = which; r.xa_off = -1;
+    if (p.n_cigar > 0) {                                   // the operations, the MD string right behind them (as mem_reg2aln leaves the block)
+        const char* md = (const char*)(p.cigar + p.n_cigar);
+        const size_t bytes = (size_t)p.n_cigar * 4 + strlen(md) + 1;
+        r.cigar_off = (int64_t)A.blob.size();
+        A.blob.insert(A.blob.end(), (const uint8_t*)p.cigar, (const uint8_t*)p.cigar + bytes);
+    }
+    if (m) {
+        r.has_mate = 1; r.m_rid = m->rid; r.m_pos = m->pos; r.m_is_rev = m->is_rev; r.m_is_alt = m->is_alt; r.m_n_cigar = m->n_cigar;
+        if (m->n_cigar > 0) { r.m_cigar_off = (int64_t)A.blob.size(); A.blob.insert(A.blob.end(), (const uint8_t*)m->cigar, (const uint8_t*)m->cigar + (size_t)m->n_cigar * 4); }
+    }
+    if (p.XA) { r.xa_off = (int64_t)A.blob.size(); A.blob.insert(A.blob.end(), (const uint8_t*)p.XA, (const uint8_t*)p.XA + strlen(p.XA) + 1); }
+    A.recs.push_back(r);
+    ++tl_sam_tally.dev;
+    if (sam_check()) {
+        kstring_t t = {0, 0, 0};
+        next(opt, bns, &t, s, n, list, which, m);
+        A.check.emplace_back(g, std::string(t.s, t.l));
+        free(t.s);
+    }
+    kputc('\x01', str);                                    // the caller makes s->sam of the kstring: one byte that says "the text is the device's"
+}
+void meme_dropin_report_sam() {
+    if (!sam_on_device()) return;
+    fprintf(stderr, "[meme-dropin] SAM text on the device: %lld records formatted there so far (kernels %.3f s, whole stage %.3f s), %lld by the reference's mem_aln2sam "
+            "(reads with several records, comments, pa tags)\n", (long long)g_sam_dev_recs.load(), g_sam_kernel_ms * 1e-3, g_sam_stage_s, (long long)g_sam_ref_recs.load());
+}
+
 // ---- insert-size statistics: mem_pestat (src/bwamem_pair.cpp:81-148) ------------------------------------------------------------------
 // Between worker_aln and worker_sam the reference walks the alignment records of every pair of the chunk in ONE thread -- 667 k scattered
 // heap records, a cache miss each -- collects the insert sizes of the uniquely aligned pairs and sorts them: 0.03-0.045 s of a chunk's
@@ -478,8 +685,7 @@ inline int pestat_cal_sub(const mem_opt_t* opt, const mem_alnreg_v* r) {        
 typedef void (*pestat_fn)(const mem_opt_t*, int64_t, int, const mem_alnreg_v*, mem_pestat_t*);
 }  // namespace dropin
 void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* regs, mem_pestat_t pes[4]) {
-    static pestat_fn next = (pestat_fn)dlsym(RTLD_NEXT, "_Z10mem_pestatPK9mem_opt_tliPK12mem_alnreg_vP12mem_pestat_t");
-    if (!next) { fprintf(stderr, "[meme-dropin] the reference's mem_pestat was not found\n"); exit(1); }
+    static const pestat_fn next = (pestat_fn)ref_sym(R_MEM_PESTAT);
     const int np = n >> 1;
     if (!pestat_fast() || np < 64) { next(opt, l_pac, n, regs, pes); return; }
     struct Key { uint64_t k; int32_t i; };                       // (orientation << 60 | insert size, pair): the order of the stand-ins
@@ -529,8 +735,7 @@ void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* 
 namespace dropin { std::atomic<int> g_ktfor_calls{0}; std::atomic<int>& ktfor_calls() { return g_ktfor_calls; } }
 typedef void (*kt_for_fn)(void (*)(void*, long, long, int), void*, int);
 void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
-    static kt_for_fn next = (kt_for_fn)dlsym(RTLD_NEXT, "_Z6kt_forPFvPvlliES_i");
-    if (!next) { fprintf(stderr, "[meme-dropin] the reference's kt_for was not found\n"); exit(1); }
+    static const kt_for_fn next = (kt_for_fn)ref_sym(R_KT_FOR);
     // (verbose runs: where a chunk's time inside mem_process_seqs goes -- the three worker phases and what lies between them)
     // (wall seconds and, in brackets, CPU seconds of the whole process -- helper threads of the binding included: what a host with a CPU quota is short of)
     static double t_ph[8], c_ph[8];
@@ -544,7 +749,16 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
                     t[1] - t[0], u[1] - u[0], t[3] - t[2], u[3] - u[2], t[4] - t[3], u[4] - u[3], t[5] - t[4], u[5] - u[4]);
     } } phase{call, t_ph, c_ph, +cpu_s};
     if (call >= 0 && call <= 2) { t_ph[2 * call] = now_s(); c_ph[2 * call] = cpu_s(); }
-    if (g_chunk.seqs && data == (void*)g_worker && g_ktfor_calls.fetch_add(1) == 2) {
+    // worker_sam is the third worker function a chunk's mem_process_seqs hands to kt_for; the first chunk tells which pointer that is, later
+    // calls are recognised by it (another kt_for call somewhere does not shift the count)
+    static void (*fn_sam)(void*, long, long, int) = nullptr;
+    bool is_sam = false;
+    if (g_chunk.seqs && data == (void*)g_worker) {
+        const int c = g_ktfor_calls.fetch_add(1);
+        if (!fn_sam && c == 2) fn_sam = func;
+        is_sam = fn_sam != nullptr && func == fn_sam;
+    }
+    if (is_sam) {
         bool mate = false;
 #if __AVX512BW__          // (only this build of the reference batches mate rescue: src/bwamem.cpp:1838)
         mate = matesw_on_device() && (g_opt->flag & MEM_F_PE) && !(g_opt->flag & MEM_F_NO_RESCUE) && !g_dev.empty();
@@ -564,10 +778,9 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
         }
         if (mate_th.joinable()) mate_th.join();
         else if (mate) mate_ok = matesw_prepass();
-        if (mate_ok) {
-            next(sam_worker_dev, data, n);
-            return;
-        }
+        next(mate_ok ? sam_worker_dev : func, data, n);
+        if (sam_on_device() && g_cur_chunk_seq >= 0) sam_chunk_closed();      // the worker threads have joined: their descriptors are the output step's now
+        return;
     }
     next(func, data, n);
 }

@@ -63,9 +63,9 @@ struct meme_ctx {
     void* plcp_aux = nullptr;                      // the plcp table of an attached index (meme_index_attach: the arrays are the caller's, this is ours)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[15], gcig[11], kswv[7];
+           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[15], gcig[11], kswv[7], sam[9];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
-    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[3], h_kswv;
+    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[3], h_kswv, h_sam[2];
     i64 last_seed_max_len = 0;         // longest read of that batch
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
     bool reads_resident = false;       // ctx->reads holds the bases of that batch (false after meme_chain_batch_host: seeds brought by the caller)
@@ -77,6 +77,7 @@ struct meme_ctx {
     i64 seed_blocks_per_cu = 5;
     i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
                                        // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
+    i64 seed_r3_table = 0;             // 1: third-round pivots inside a unique SMEM are answered from windows of the plcp table (k_seed, PH_PLCP)
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches
     i64 ext_census = 0;                // 1: the extension stage counts its exact-prefix jobs (a measurement, profiles/r05_bsw.md)
     i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched
@@ -92,6 +93,9 @@ struct meme_ctx {
     hipEvent_t ev_ext[2] = {nullptr, nullptr};
     hipEvent_t ev_gcig[2] = {nullptr, nullptr};
     hipEvent_t ev_kswv[2] = {nullptr, nullptr};
+    hipEvent_t ev_sam[2] = {nullptr, nullptr};
+    i64 sam_text_reads = 0;            // reads of the batch whose names / qualities meme_sam_stage_text staged (0: none)
+    bool sam_has_quals = false;
     hipStream_t stream_side[3] = {nullptr, nullptr, nullptr};   // the routed chaining tiers run beside the lane-per-read tier
     hipEvent_t ev_side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_aux = nullptr;

@@ -104,10 +104,12 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (DevBuf& b : ctx->chain) free_buf(b);
     for (DevBuf& b : ctx->ext) free_buf(b);
     for (DevBuf& b : ctx->gcig) free_buf(b);
+    for (DevBuf& b : ctx->sam) free_buf(b);
     for (DevBuf& b : ctx->kswv) free_buf(b);
     for (meme_ctx::HostBuf& h : ctx->h_chain) if (h.p) (void)hipHostFree(h.p);
     for (meme_ctx::HostBuf& h : ctx->h_ext) if (h.p) (void)hipHostFree(h.p);
     for (meme_ctx::HostBuf& h : ctx->h_gcig) if (h.p) (void)hipHostFree(h.p);
+    for (meme_ctx::HostBuf& h : ctx->h_sam) if (h.p) (void)hipHostFree(h.p);
     if (ctx->h_kswv.p) (void)hipHostFree(ctx->h_kswv.p);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     if (ctx->plcp_aux) (void)hipFree(ctx->plcp_aux);
@@ -117,6 +119,7 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (auto& e : ctx->ev_chain) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_ext) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_gcig) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_sam) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev_kswv) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
     for (auto& e : ctx->ev_emit) if (e) (void)hipEventDestroy(e);
@@ -149,6 +152,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "max_batch")) ctx->max_batch = value;
     else if (!strcmp(key, "ext_census")) ctx->ext_census = value;
     else if (!strcmp(key, "seed_early_tier")) ctx->seed_early_tier = value;
+    else if (!strcmp(key, "seed_r3_table")) ctx->seed_r3_table = value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
     else if (!strcmp(key, "chain_wave_tiers")) ctx->chain_wave_tiers = value;
@@ -440,7 +444,7 @@ static int index_build_from(meme_ctx* ctx, int64_t n, int64_t l1_bytes, int64_t 
     HIP_TRY(hipFree(d_tmp));
     lap("free of the staging buffer");
     void* d_plcp = nullptr;
-    if ((rc = own_alloc(ctx, &d_plcp, (size_t)n + 64))) return rc;
+    if ((rc = own_alloc(ctx, &d_plcp, (size_t)n + 256))) return rc;
     if ((rc = meme_stage_build_plcp(ctx, d_ent, n, d_pac, d_plcp))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     lap("plcp table");
@@ -592,7 +596,7 @@ extern "C" int meme_index_attach(meme_ctx* ctx, const meme_index_arrays* a) {
     ctx->idx.l1 = (const Rmi32*)a->d_l1;
     // the plcp table is derived data: built here into memory of the ctx (the caller's arrays stay the caller's)
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc(&ctx->plcp_aux, (size_t)a->sa_num + 64));
+    HIP_TRY(hipMalloc(&ctx->plcp_aux, (size_t)a->sa_num + 256));
     if ((rc = meme_stage_build_plcp(ctx, a->d_sa_ent, a->sa_num, a->d_pac64, ctx->plcp_aux))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->idx.plcp = (const uint8_t*)ctx->plcp_aux;

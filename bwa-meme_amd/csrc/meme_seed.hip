@@ -189,6 +189,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     unsigned long long h_counters[16];
     int rc;
     ctx->last_seed_reads = 0;          // whatever batch meme_chain_last_batch_host could have chained is being overwritten
+    ctx->sam_text_reads = 0;           // ... and the names / qualities staged for it belong to the previous batch
     if ((rc = meme_buf_reserve(ctx, ctx->slot_cnt, (size_t)nreads * sizeof(int)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_hits, (size_t)nreads * sizeof(i64)))) return rc;
     if ((rc = meme_buf_reserve(ctx, ctx->slot_loc, (size_t)nreads * sizeof(i64)))) return rc;
@@ -268,6 +269,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.tier = tier;
         A.counters = counters;
         A.defer = defer ? 1 : 0;
+        A.r3_table = (ctx->seed_r3_table != 0 && ctx->idx.plcp != nullptr) ? 1 : 0;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
         while (G < 32 && seed_lds_bytes(G, geo, lcap) > (size_t)160 * 1024) G *= 2;   // long reads: fewer reads per workgroup

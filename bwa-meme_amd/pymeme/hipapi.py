@@ -93,6 +93,16 @@ class CresHost(C.Structure):
                 ("kernel_ms", C.c_float)]
 
 
+SAM_REC = np.dtype([("pos", "<i8"), ("m_pos", "<i8"), ("cigar_off", "<i8"), ("m_cigar_off", "<i8"), ("xa_off", "<i8")] +
+                   [(n, "<i4") for n in ("read", "flag", "rid", "is_rev", "is_alt", "mapq", "NM", "score", "sub", "n_cigar", "has_mate", "m_rid", "m_is_rev", "m_is_alt",
+                                         "m_n_cigar", "which")])
+assert SAM_REC.itemsize == 104
+
+
+class SamHost(C.Structure):
+    _fields_ = [("nrecs", C.c_int64), ("text_off", C.c_void_p), ("text", C.c_void_p), ("text_bytes", C.c_int64), ("kernel_ms", C.c_float)]
+
+
 class KswvHost(C.Structure):
     _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("kernel_ms", C.c_float)]
 
@@ -130,7 +140,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries", "meme_stage_build_plcp",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_gen_cigar_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_gen_cigar_batch_host", "meme_sam_stage_text", "meme_sam_format_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -370,6 +380,34 @@ class Context:
             buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
             return np.frombuffer(buf, dtype=dtype, count=count).copy()
         return view(res.res, res.njobs, CRES), view(res.cigars, res.total_ops, np.uint32), view(res.md, res.md_bytes, np.uint8), float(res.kernel_ms)
+
+    def sam_stage_text(self, names, quals=None):
+        """meme_sam_stage_text: names (list of bytes, one per read of the resident batch) and qualities (one bytes object laid out like the
+        reads' bases, or None)."""
+        blob = np.frombuffer(b"".join(names), dtype=np.uint8).copy() if names else np.zeros(1, np.uint8)
+        if blob.shape[0] == 0:
+            blob = np.zeros(1, np.uint8)
+        off = np.zeros(len(names) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in names])
+        q = np.frombuffer(quals, dtype=np.uint8).copy() if quals is not None else None
+        _check(lib().meme_sam_stage_text(C.c_void_p(self.h), _p(blob), _p(off), _p(q) if q is not None else C.c_void_p(0)))
+
+    def sam_format_batch_host(self, recs, blob, contig_names, softclip=0, rg_id=b""):
+        """meme_sam_format_batch_host: SAM text of the records (SAM_REC).  Returns (text bytes, text_off int64 array, kernel_ms)."""
+        recs = np.ascontiguousarray(recs, dtype=SAM_REC)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        cn = b"".join(n.encode() if isinstance(n, str) else n for n in contig_names)
+        cb = np.frombuffer(cn, dtype=np.uint8).copy() if cn else np.zeros(1, np.uint8)
+        co = np.zeros(len(contig_names) + 1, np.int32)
+        co[1:] = np.cumsum([len(n) for n in contig_names])
+        res = SamHost()
+        _check(lib().meme_sam_format_batch_host(C.c_void_p(self.h), _p(recs), C.c_int64(recs.shape[0]), _p(blob), C.c_int64(blob.shape[0]), _p(cb), _p(co),
+                                                 C.c_int32(len(contig_names)), C.c_int32(int(softclip)), C.c_char_p(rg_id), C.byref(res)))
+        if res.nrecs == 0:
+            return b"", np.zeros(1, np.int64), 0.0
+        off = np.frombuffer((C.c_char * ((res.nrecs + 1) * 8)).from_address(res.text_off), dtype=np.int64).copy()
+        text = bytes((C.c_char * res.text_bytes).from_address(res.text)) if res.text_bytes else b""
+        return text, off, float(res.kernel_ms)
 
     def kswv_batch_host(self, jobs, ref, qer, opt=None):
         """meme_kswv_batch_host: the mate-rescue Smith-Waterman batch (mem_sam_pe_batch with the kswv kernels).  jobs: KSWV_JOB records over the

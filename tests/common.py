@@ -358,3 +358,93 @@ def gencig_workload(n=2500, seed=177):
         tlen = max(1, min(tlen, (l_pac - rb) if rb < l_pac else 2 * l_pac - rb))
         calls[k] = (rb, int(J["read"]), int(J["qb"]), qlen, tlen, w_, 0)
     return g, reads, calls
+
+
+def sam_workload(n=1500, seed=301, read_len=(30, 251)):
+    """Inputs of the SAM-text tests (tests/golden/sam_golden.npz): records the way mem_reg2aln / mem_sam_pe leave them for mem_aln2sam -- mapped and
+    unmapped ends, mates mapped / unmapped / on another contig / absent (single-end), both strands, CIGARs with clipping, insertions, deletions
+    and their MD strings, secondary (0x100 and 0x10000) flags, supplementary records (which > 0: hard clipping unless is_alt or soft clipping is
+    asked for), XA strings, with and without qualities.  Returns (recs SAM_REC_DTYPE, blob uint8, names list, reads list (codes), quals list
+    (bytes or None), contig names)."""
+    from oracle_py import SAM_REC_DTYPE
+    rng = np.random.default_rng(seed)
+    contigs = ["chr1", "chr2_random", "HLA-A*01:01", "c"]
+    recs = np.zeros(n, SAM_REC_DTYPE)
+    blob = bytearray()
+    names, reads, quals = [], [], []
+
+    def pad():
+        while len(blob) % 4:
+            blob.append(0)
+
+    def cigar(L, clip_ok=True):
+        ops, left = [], L
+        if clip_ok and rng.random() < 0.4:
+            c = int(rng.integers(1, max(2, L // 4))); ops.append((c, 3 if rng.random() < 0.8 else 4)); left -= c
+        tail = None
+        if clip_ok and rng.random() < 0.4 and left > 4:
+            c = int(rng.integers(1, max(2, left // 4))); tail = (c, 3 if rng.random() < 0.8 else 4); left -= c
+        while left > 0:
+            m = int(rng.integers(1, left + 1)); ops.append((m, 0)); left -= m
+            if left > 0 and rng.random() < 0.5:
+                if rng.random() < 0.5:
+                    i = int(rng.integers(1, min(left, 12) + 1)); ops.append((i, 1)); left -= i
+                else:
+                    ops.append((int(rng.integers(1, 40)), 2))
+        if ops and ops[-1][1] == 2:
+            ops.pop()
+        if tail:
+            ops.append(tail)
+        return np.array([l << 4 | o for l, o in ops], np.uint32)
+
+    def md_string():
+        parts = []
+        for _ in range(int(rng.integers(1, 6))):
+            parts.append(str(int(rng.integers(0, 120))))
+            parts.append("ACGT"[int(rng.integers(0, 4))] if rng.random() < 0.7 else "^" + "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(1, 5)))))
+        parts.append(str(int(rng.integers(0, 120))))
+        return "".join(parts).encode()
+
+    for k in range(n):
+        L = int(rng.integers(*read_len))
+        reads.append(rng.choice(np.array([0, 1, 2, 3, 4], np.uint8), size=L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        quals.append(None if k % 11 == 0 else bytes(rng.integers(33, 74, size=L).astype(np.uint8)))
+        names.append(("read_%d:%d/x" % (k, int(rng.integers(0, 10 ** 9)))).encode()[:int(rng.integers(1, 40))] or b"r")
+        r = recs[k]
+        r["read"] = k
+        mapped = rng.random() < 0.9
+        r["rid"] = int(rng.integers(0, len(contigs))) if mapped else -1
+        r["pos"] = int(rng.integers(0, 3 * 10 ** 9)) if mapped else -1
+        r["is_rev"] = int(rng.integers(0, 2)) if mapped else 0
+        r["is_alt"] = int(rng.random() < 0.1)
+        r["mapq"] = int(rng.integers(0, 61)) if mapped else 0
+        r["flag"] = (0x40 if k & 1 else 0x80) | (2 if rng.random() < 0.6 else 0) | (0x100 if rng.random() < 0.05 else 0) | (0x10000 if rng.random() < 0.05 else 0) | \
+                    (0x800 if rng.random() < 0.05 else 0) | (0x4 if not mapped else 0)
+        r["which"] = int(rng.integers(1, 3)) if rng.random() < 0.15 else 0
+        r["score"] = int(rng.integers(0, 251)) if mapped else -1 + int(rng.random() < 0.2)
+        r["sub"] = int(rng.integers(-1, 200))
+        r["NM"] = int(rng.integers(0, 40))
+        if mapped:
+            cg = cigar(L)
+            pad(); r["cigar_off"] = len(blob); r["n_cigar"] = cg.shape[0]
+            blob.extend(cg.tobytes()); blob.extend(md_string()); blob.append(0)
+        u = rng.random()
+        if u < 0.85:
+            r["has_mate"] = 1
+            m_mapped = rng.random() < 0.9
+            r["m_rid"] = (int(r["rid"]) if (mapped and rng.random() < 0.8) else int(rng.integers(0, len(contigs)))) if m_mapped else -1
+            r["m_pos"] = int(rng.integers(0, 3 * 10 ** 9)) if m_mapped else -1
+            if m_mapped and mapped and rng.random() < 0.5:
+                r["m_pos"] = int(r["pos"]) + int(rng.integers(-600, 600))
+            r["m_is_rev"] = int(rng.integers(0, 2)) if m_mapped else 0
+            r["m_is_alt"] = int(rng.random() < 0.1)
+            if m_mapped and rng.random() < 0.95:
+                mc = cigar(int(rng.integers(30, 251)))
+                pad(); r["m_cigar_off"] = len(blob); r["m_n_cigar"] = mc.shape[0]
+                blob.extend(mc.tobytes())
+        r["xa_off"] = -1
+        if mapped and rng.random() < 0.2:
+            r["xa_off"] = len(blob)
+            blob.extend(b"chr2_random,-%d,100M50S,%d;c,+17,150M,0;" % (int(rng.integers(1, 10 ** 8)), int(rng.integers(0, 30)))); blob.append(0)
+    pad()
+    return recs, np.frombuffer(bytes(blob), dtype=np.uint8).copy(), names, reads, quals, contigs

@@ -359,6 +359,33 @@ def gen_cigar2(text, l_pac, query, rb, re, w_, a=1, b=4, o_del=6, e_del=1, o_ins
     return sc.value, cig[:nc.value].copy(), nm.value, md[:int(np.argmin(md != 0))].tobytes()
 
 
+SAM_REC_DTYPE = np.dtype([("pos", "<i8"), ("m_pos", "<i8"), ("cigar_off", "<i8"), ("m_cigar_off", "<i8"), ("xa_off", "<i8")] +
+                         [(n, "<i4") for n in ("read", "flag", "rid", "is_rev", "is_alt", "mapq", "NM", "score", "sub", "n_cigar", "has_mate", "m_rid", "m_is_rev", "m_is_alt",
+                                               "m_n_cigar", "which")])
+assert SAM_REC_DTYPE.itemsize == 104
+
+
+def contig_table(names):
+    blob = b"".join(n.encode() if isinstance(n, str) else n for n in names)
+    off = np.zeros(len(names) + 1, np.int32)
+    off[1:] = np.cumsum([len(n) for n in names])
+    return np.frombuffer(blob, dtype=np.uint8).copy(), off
+
+
+def aln2sam(rec, blob, name, seq, qual, contig_blob, contig_off, softclip=0, rg_id=b""):
+    """orc_aln2sam: the SAM text of one record (SAM_REC_DTYPE scalar), bytes."""
+    L = lib()
+    L.orc_aln2sam.restype = C.c_int64
+    rec = np.ascontiguousarray(rec, dtype=SAM_REC_DTYPE).reshape(1)
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    out = np.zeros(len(name) + 2 * seq.shape[0] + blob.shape[0] * 4 + 512, np.uint8)
+    q = C.c_char_p(qual) if qual is not None else C.c_char_p(None)
+    n = L.orc_aln2sam(C.c_void_p(rec.ctypes.data), C.c_void_p(blob.ctypes.data), C.c_char_p(name), C.c_int(len(name)), C.c_void_p(seq.ctypes.data), C.c_int(seq.shape[0]), q,
+                      C.c_void_p(contig_blob.ctypes.data), C.c_void_p(contig_off.ctypes.data), C.c_int(int(softclip)), C.c_char_p(rg_id), C.c_void_p(out.ctypes.data))
+    return out[:n].tobytes()
+
+
 KSWV_JOB_DTYPE = np.dtype([("idr", "<i8"), ("idq", "<i8"), ("len1", "<i4"), ("len2", "<i4"), ("xtra", "<i4"), ("pad", "<i4")])
 KSWR_DTYPE = np.dtype([(n, "<i4") for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")])
 KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000

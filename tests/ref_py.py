@@ -189,6 +189,24 @@ def gen_cigar2(fwd, query, rb, re, w_, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_in
     return int(out[0]), cig[:int(out[1])].copy(), int(out[2]), md[:int(out[3])].tobytes()
 
 
+def aln2sam(rec, blob, name, seq, qual, contig_blob, contig_off, softclip=0, rg_id=b""):
+    """mem_aln2sam of the compiled reference for one record (oracle_py.SAM_REC_DTYPE scalar): the SAM text, bytes."""
+    from oracle_py import SAM_REC_DTYPE
+    L = stage_lib()
+    L.ref_aln2sam.restype = C.c_int64
+    rec = np.ascontiguousarray(rec, dtype=SAM_REC_DTYPE).reshape(1)
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    cap = len(name) + 2 * seq.shape[0] + blob.shape[0] * 4 + 512
+    out = np.zeros(cap, np.uint8)
+    q = C.c_char_p(qual) if qual is not None else C.c_char_p(None)
+    n = L.ref_aln2sam(C.c_void_p(rec.ctypes.data), C.c_void_p(blob.ctypes.data), C.c_char_p(name), C.c_void_p(seq.ctypes.data), C.c_int(seq.shape[0]), q,
+                      C.c_void_p(contig_blob.ctypes.data), C.c_void_p(contig_off.ctypes.data), C.c_int(contig_off.shape[0] - 1), C.c_int(int(softclip)), C.c_char_p(rg_id),
+                      C.c_void_p(out.ctypes.data), C.c_int64(cap))
+    assert n >= 0
+    return out[:n].tobytes()
+
+
 def kswv_batch(jobs, ref, qer, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
     """sort_classify + mem_sam_pe_batch of the compiled reference (its AVX-512 kswv kernels) on the jobs: KSWR_DTYPE records."""
     from oracle_py import KSWV_JOB_DTYPE, KSWR_DTYPE

@@ -19,6 +19,8 @@ REF = R.REF_DIR
 # thousands of Smith-Waterman jobs: here every paired-end run uses it
 os.environ.setdefault("MEME_DROPIN_MATESW", "1")
 os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
+# every record the device formats (SAM text) is also formatted by the reference's mem_aln2sam and compared inside the aligner
+os.environ.setdefault("MEME_DROPIN_SAM_CHECK", "1")
 
 
 def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000, opts=(), stderr=None):
@@ -69,7 +71,7 @@ def test_sam_identical_to_reference(tmp_path, paired):
     # Round 4: the device stages of chunk k+1 run beside the SAM phase of chunk k (prefetch; also switched off), and a backend that refuses
     # a batch for want of memory (MEME_DROPIN_MAX_BATCH: max_batch of the ctxs) is fed in pieces -- extension stage and CIGAR stage alike.
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}), (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
-                                  (8, 400000, {"MEME_DROPIN_PREFETCH": "0"}), (8, 100000000, {"MEME_DROPIN_MAX_BATCH": "1500"}),
+                                  (8, 400000, {"MEME_DROPIN_PREFETCH": "0"}), (8, 400000, {"MEME_DROPIN_SAM": "0"}), (8, 100000000, {"MEME_DROPIN_MAX_BATCH": "1500"}),
                                   (8, 400000, {"MEME_DROPIN_MAX_BATCH": "700", "MEME_DROPIN_VIRTUAL": "2"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
                                   (4, 100000000, {"MEME_DROPIN_EXT": "0", "MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
@@ -314,10 +316,12 @@ def test_sam_identical_mixed_250bp_high_error_paired(tmp_path):
     m = list(re.finditer(r"bwa_gen_cigar2 calls answered from the table (\d+), computed by the reference's function (\d+)", err))
     assert m and int(m[-1].group(1)) > 5000 and int(m[-1].group(1)) > 20 * int(m[-1].group(2)), err[-1500:]   # the CIGAR table answers (nearly) all calls
     assert re.search(r"0 reads chained on the host", err)
+    m = list(re.finditer(r"SAM text on the device: (\d+) records formatted there so far .*?, (\d+) by the reference's mem_aln2sam", err))
+    assert m and int(m[-1].group(1)) > 10000 and int(m[-1].group(1)) > 10 * int(m[-1].group(2)), err[-1500:]       # (only reads with supplementary records stay with the host)
     m = list(re.finditer(r"mate rescue on the device: (\d+) Smith-Waterman jobs posed.*took from the table (\d+), run by the reference's kernels (\d+)", err))
     assert m and int(m[-1].group(1)) > 200 and int(m[-1].group(2)) == int(m[-1].group(1)) and int(m[-1].group(3)) == 0, err[-1500:]
     # and with the CIGAR stage / the mate-rescue stage off the same SAM comes out (the tables only ever replace identical answers)
-    got2 = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CIGAR="0", MEME_DROPIN_MATESW="0"), threads=8, chunk=700000)
+    got2 = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CIGAR="0", MEME_DROPIN_MATESW="0", MEME_DROPIN_SAM="0"), threads=8, chunk=700000)
     assert got2 == got
 
 

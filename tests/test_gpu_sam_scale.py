@@ -12,6 +12,7 @@ import ref_py as R
 from pymeme import hostapi, synth, workload
 
 pytestmark = pytest.mark.gpu
+os.environ.setdefault("MEME_DROPIN_SAM_CHECK", "1")
 os.environ.setdefault("MEME_DROPIN_MATESW", "1")          # (the opt-in mate-rescue stage too, whatever the number of jobs)
 os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
 

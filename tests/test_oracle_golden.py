@@ -258,6 +258,22 @@ def test_gen_cigar2_oracle_equals_reference_golden():
     assert O.gen_cigar2(text, l_pac, reads[0][:50], 100, 100, 10) is None
 
 
+def test_aln2sam_oracle_equals_reference_golden():
+    """orc_aln2sam against the text the compiled reference's mem_aln2sam wrote (tests/golden/sam_golden.npz: 1 500 records -- mapped / unmapped ends and
+    mates, both strands, clipping styles, secondary flags, XA, with and without qualities -- hard and soft clipping, without and with a read group)."""
+    import numpy as np
+    from common import sam_workload
+    recs, blob, names, reads, quals, contigs = sam_workload()
+    cb, co = O.contig_table(contigs)
+    G = np.load(os.path.join(GOLDEN, "sam_golden.npz"))
+    for softclip, rg in ((0, b""), (1, b"grp1")):
+        text, off = G["text_%d" % softclip].tobytes(), G["off_%d" % softclip]
+        assert off.shape[0] == recs.shape[0] + 1
+        for k in range(recs.shape[0]):
+            got = O.aln2sam(recs[k], blob, names[k], reads[k], quals[k], cb, co, softclip, rg)
+            assert got == text[off[k]:off[k + 1]], (k, softclip, got, text[off[k]:off[k + 1]])
+
+
 def test_kswv_oracle_equals_reference_golden():
     """orc_kswv_batch against the kswr_t records of the compiled reference's mate-rescue batch (sort_classify + mem_sam_pe_batch with the AVX-512
     kswv kernels; tests/golden/kswv_golden.npz): 5 500 jobs in three sets -- int8 and int16 classes, reads inside / hanging over / missing
