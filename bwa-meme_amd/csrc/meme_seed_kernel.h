@@ -529,7 +529,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
     for (;;) {
         // ================= control: reads without a request in flight produce the next one =========================
         bool newreq = false;
-        int want_pl = -1;                       // >= 0: the request is a plcp window for unique SMEM number want_pl
         if (phase == PH_CTRL) {
             // One pass over the states in the order reads usually flow through them, so a read takes several hops per
             // pass (a switch in a loop costs the wavefront one full pass per hop of its slowest read); the outer
@@ -615,16 +614,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         const int valid = first_n(nfw, has_n, pivot, l_seq) - pivot;
                         if (valid < msl) { pivot = pivot + valid; continue; }
                         q_kind = K_R3; have = true;
-                        // Inside an SMEM of the read with ONE occurrence at a known text position T the query is a piece of the text, and
-                        // the pivots of this round that fall into it (20 bases apart) are settled by the plcp bytes at T + (pivot - start):
-                        // one window of the table for all of them instead of a search each (PH_PLCP below).
-                        if (A.r3_table && min_intv > 1 && st[ST_R3_NOPL] != pivot + 1) {
-#pragma unroll
-                            for (int k = 0; k < N_USMEM; ++k) {
-                                const int se = st[ST_U_SE + k];
-                                if (se != 0 && (se & 0xffff) <= pivot && pivot < (int)((unsigned)se >> 16)) want_pl = k;
-                            }
-                        }
                         break;
                     }
                 }
@@ -721,7 +710,18 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             newreq = true;
         }
         PROF_MARK(0);
-        if (newreq && want_pl >= 0) {
+        // Third round: inside an SMEM of the read with ONE occurrence at a known text position T the query is a piece of the text, and the
+        // pivots that fall into it (msl bases apart) are settled by the plcp bytes at T + (pivot - start): one window of the table for up to
+        // four of them instead of a search each (PH_PLCP below).
+        int want_pl = -1;
+        if (newreq && q_kind == K_R3 && A.r3_table && min_intv > 1 && st[ST_R3_NOPL] != pivot + 1) {
+#pragma unroll
+            for (int k = 0; k < N_USMEM; ++k) {
+                const int se = st[ST_U_SE + k];
+                if (se != 0 && (se & 0xffff) <= pivot && pivot < (int)((unsigned)se >> 16)) want_pl = k;
+            }
+        }
+        if (want_pl >= 0) {
             // ---- a window of the plcp table: W x 16 bytes from the text position of the pivot (16-byte aligned)
             const int se = st[ST_U_SE + want_pl];
             const i64 u = LD64(ST_U_T + 2 * want_pl) + (i64)(pivot - (se & 0xffff));
@@ -796,15 +796,13 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 //   L_d >= msl, plcp[u] < msl    the seed [p, p + msl) with its one hit u, pivot += msl   (:1252-1277: the next level is below msl)
                 // Anything else -- a saturated byte, plcp[u] >= L_d, a next level of msl bases or more -- is searched: the pivot is marked and
                 // control issues the model search for it.
-                int kk = 0;
+                int u_end = 0;
 #pragma unroll
-                for (int k = 0; k < N_USMEM; ++k) { const int se = st[ST_U_SE + k]; if (se != 0 && (se & 0xffff) <= pivot && pivot < (int)((unsigned)se >> 16)) kk = k; }
-                const int se = st[ST_U_SE + kk];
-                const int u_start = se & 0xffff, u_end = (int)((unsigned)se >> 16);
-                const i64 T0 = LD64(ST_U_T + 2 * kk) - (i64)u_start;             // text position of read base 0 on this diagonal
+                for (int k = 0; k < N_USMEM; ++k) { const int se = st[ST_U_SE + k]; if (se != 0 && (se & 0xffff) <= pivot && pivot < (int)((unsigned)se >> 16)) u_end = (int)((unsigned)se >> 16); }
+                const int p0 = pivot;                                            // (its text position is in ST_CB)
                 int handled = 0;
                 for (;;) {
-                    if (handled == 4 || !(pivot < l_seq - msl + 1) || pivot < u_start || pivot >= u_end) break;
+                    if (handled == 4 || !(pivot < l_seq - msl + 1) || pivot >= u_end) break;
                     const int pl = (int)((plb >> (8 * handled)) & 0xffu);
                     const int Ld = u_end - pivot;
                     if (pl == 255 || pl >= Ld || (Ld >= msl && pl >= msl)) { if (handled == 0 || pl != 255) st[ST_R3_NOPL] = pivot + 1; break; }
@@ -814,7 +812,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                         if (ns < cap && t == 0) {
                             const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
                             SlotRec sr;
-                            sr.start = pivot; sr.end = pivot + msl; sr.count = 1; sr.sa_start = SLOT_POS | (T0 + pivot);
+                            sr.start = pivot; sr.end = pivot + msl; sr.count = 1; sr.sa_start = SLOT_POS | (LD64(ST_CB_LO) + (i64)(pivot - p0));
                             A.slots[(i64)ticket * cap + ns] = sr;
                         }
                         st[ST_N_SMEMS] = ns + 1;

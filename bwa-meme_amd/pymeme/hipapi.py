@@ -211,6 +211,10 @@ class Context:
         if not self.h:
             raise MemeError(L.meme_last_error().decode())
         self.device = device
+        # MEME_TUNING="key=value,key=value": tuning switches for every ctx of the process (probes and A/B runs of the tests and bench.py)
+        for kv in filter(None, os.environ.get("MEME_TUNING", "").split(",")):
+            k, v = kv.split("=")
+            self.set_tuning(k.strip(), int(v))
 
     def close(self):
         if getattr(self, "h", None):
