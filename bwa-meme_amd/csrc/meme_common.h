@@ -77,7 +77,6 @@ struct meme_ctx {
     i64 seed_blocks_per_cu = 5;
     i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
                                        // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
-    i64 seed_r3_table = 0;             // 1: third-round pivots inside a unique SMEM are answered from windows of the plcp table (k_seed, PH_PLCP)
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches
     i64 ext_census = 0;                // 1: the extension stage counts its exact-prefix jobs (a measurement, profiles/r05_bsw.md)
     i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched

@@ -152,7 +152,6 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "max_batch")) ctx->max_batch = value;
     else if (!strcmp(key, "ext_census")) ctx->ext_census = value;
     else if (!strcmp(key, "seed_early_tier")) ctx->seed_early_tier = value;
-    else if (!strcmp(key, "seed_r3_table")) ctx->seed_r3_table = value;
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
     else if (!strcmp(key, "chain_wave_tiers")) ctx->chain_wave_tiers = value;

@@ -269,7 +269,6 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
         A.tier = tier;
         A.counters = counters;
         A.defer = defer ? 1 : 0;
-        A.r3_table = (ctx->seed_r3_table != 0 && ctx->idx.plcp != nullptr) ? 1 : 0;
         tiers.base[tier] = (const SlotRec*)sb.p;
         tiers.cap[tier] = cap;
         while (G < 32 && seed_lds_bytes(G, geo, lcap) > (size_t)160 * 1024) G *= 2;   // long reads: fewer reads per workgroup

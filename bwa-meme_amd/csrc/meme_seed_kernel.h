@@ -83,7 +83,6 @@ struct SeedArgs {
     int cap, lcap, tier;
     unsigned long long* counters;   // [0] ticket, [1] searches, [2] overflowed reads, [3] window loads, [4..11] SEED_PROF, [12] lane searches of k_reseed
     int defer;                      // 1: re-seeding regions of unique SMEMs are left to k_reseed (tier 0 only)
-    int r3_table;                   // 1: third-round pivots inside a unique SMEM of the read are answered from a window of the plcp table
 };
 
 // ---- read packing -------------------------------------------------------------------------------------
@@ -224,7 +223,7 @@ enum Pc : int {
 enum Kind : int { K_S1_RIGHT, K_ZZ_LEFT, K_ZZ_RIGHT, K_OP_MEM, K_OP_SMEM, K_R3 };
 // what the next window is for: the partition point of the query (first window at the model's prediction, later ones
 // gallop/bisect), or the lower / upper end of the run of suffixes sharing >= L bases with it
-enum Phase : int { PH_CTRL, PH_PART, PH_EDGE_DN, PH_EDGE_UP, PH_PLCP };
+enum Phase : int { PH_CTRL, PH_PART, PH_EDGE_DN, PH_EDGE_UP };
 
 // explicit address spaces: LDS (3) for the staged read, global (1) for the index.  Generic pointers would
 // compile to FLAT loads whose waits serialise LDS and HBM traffic.
@@ -278,10 +277,7 @@ enum StIdx : int { ST_BEFORE, ST_AFTER, ST_R2_K, ST_R2_NEXT, ST_R2_SAVED, ST_ZZ_
                    ST_LAST_S_LO, ST_LAST_S_HI, ST_WINDOWS,
                    // the level walk of the search in flight (do not survive a search)
                    ST_L, ST_SE_LO, ST_SE_HI, ST_EE_LO, ST_EE_HI, ST_NB_LO, ST_NB_HI, ST_LF, ST_CB_LO, ST_CB_HI,
-                   ST_TICKET_LO, ST_TICKET_HI,
-                   // the read's last N_USMEM SMEMs with one occurrence whose text position is known: start | end << 16 (0: none), position
-                   ST_U_SE, ST_U_T = ST_U_SE + 3, ST_U_NEXT = ST_U_T + 6, ST_R3_NOPL, ST_WORDS };
-constexpr int N_USMEM = 3;
+                   ST_TICKET_LO, ST_TICKET_HI, ST_WORDS };
 // per-read words are cleared when a read is staged; the group's running totals live in registers
 enum StFlag : int { F_ZZ_CHECK = 1, F_ZZ_RET_ONEPOS = 2, F_REC = 4, F_LDS_OVF = 8 };
 enum LevelFlag : int { LF_NEED_LO = 1, LF_NEED_HI = 2, LF_HAVE_LAST = 4 };
@@ -710,26 +706,7 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             newreq = true;
         }
         PROF_MARK(0);
-        // Third round: inside an SMEM of the read with ONE occurrence at a known text position T the query is a piece of the text, and the
-        // pivots that fall into it (msl bases apart) are settled by the plcp bytes at T + (pivot - start): one window of the table for up to
-        // four of them instead of a search each (PH_PLCP below).
-        int want_pl = -1;
-        if (newreq && q_kind == K_R3 && A.r3_table && min_intv > 1 && st[ST_R3_NOPL] != pivot + 1) {
-#pragma unroll
-            for (int k = 0; k < N_USMEM; ++k) {
-                const int se = st[ST_U_SE + k];
-                if (se != 0 && (se & 0xffff) <= pivot && pivot < (int)((unsigned)se >> 16)) want_pl = k;
-            }
-        }
-        if (want_pl >= 0) {
-            // ---- a window of the plcp table: W x 16 bytes from the text position of the pivot (16-byte aligned)
-            const int se = st[ST_U_SE + want_pl];
-            const i64 u = LD64(ST_U_T + 2 * want_pl) + (i64)(pivot - (se & 0xffff));
-            ST64(ST_CB_LO, u);                    // (a level-walk word: free while no search is in flight)
-            base = u & ~15ll;
-            q_rc = false;
-            phase = PH_PLCP;
-        } else if (newreq) {
+        if (newreq) {
             // ---- the request: query = bases [off, off+vlen) of one strand; first window at the model's prediction
             q_rc = q_kind == K_ZZ_LEFT;
             off = q_rc ? l_seq - 1 - pivot : pivot;
@@ -764,66 +741,11 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         bool less[E];
         u64 ep[E];
         {
-            // (a plcp window is the same E loads of 16 bytes per lane, from the byte table instead of the entry array: `base` is a byte offset then)
-            const bool plw = phase == PH_PLCP;
-            const glb_ent wp = plw ? (glb_ent)((const __attribute__((address_space(1))) unsigned char*)A.I.plcp + base) + t : sa + base + t;
             u64 ek[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) { ek[e] = wp[e * G].key; ep[e] = wp[e * G].pos; }
+            for (int e = 0; e < E; ++e) { ek[e] = sa[base + e * G + t].key; ep[e] = sa[base + e * G + t].pos; }
             st[ST_WINDOWS] = st[ST_WINDOWS] + 1;
-            if (!plw) window_compare<E>(pac, n, s, wq, off, capc, ek, ep, lcp, less);
-            else {
-                // byte j of the window: slot j >> 4, i.e. lane (j >> 4) % G, register (j >> 4) / G, byte j & 15 of {key, pos}
-#pragma unroll
-                for (int e = 0; e < E; ++e) { lcp[e] = 0; less[e] = false; }
-                unsigned plb = 0;                // the table's bytes for this pivot and the next three (msl apart), byte i in bits 8i..
-                const int j0 = (int)(LD64(ST_CB_LO) - base);                  // (the first pivot's byte; ST_CB holds its text position)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = j0 + i * msl;
-                    const int slot = j >> 4, bsel = j & 15;
-                    u64 wsel = 0;
-#pragma unroll
-                    for (int e = 0; e < E; ++e) if (slot / G == e) wsel = bsel < 8 ? ek[e] : ep[e];
-                    const int mine = (j < W * 16 && slot % G == t) ? (int)((wsel >> (8 * (bsel & 7))) & 0xffull) : 0;
-                    plb |= (unsigned)(j < W * 16 ? group_or<G>(mine) : 255) << (8 * i);      // (beyond the window: "saturated", the pivot is searched or asked again)
-                }
-                // ---- third-round pivots inside a unique SMEM, from the table window in ek / ep (byte j of the window: slot j >> 4, i.e. lane
-                // (j >> 4) % G, register (j >> 4) / G, byte j & 15 of {key, pos}).  For the pivot p at text position u = T + (p - start) the query
-                // shares L_d = end - p bases with the text there; plcp[u] < L_d proves that no other suffix reaches L_d (profiles/r05_diag_census.md):
-                // the search's answer is (L_d, one occurrence, u), and the round's rule (:1199-1281) makes of it
-                //   L_d < msl                    no seed, pivot += msl              (:1204-1208)
-                //   L_d >= msl, plcp[u] < msl    the seed [p, p + msl) with its one hit u, pivot += msl   (:1252-1277: the next level is below msl)
-                // Anything else -- a saturated byte, plcp[u] >= L_d, a next level of msl bases or more -- is searched: the pivot is marked and
-                // control issues the model search for it.
-                int u_end = 0;
-#pragma unroll
-                for (int k = 0; k < N_USMEM; ++k) { const int se = st[ST_U_SE + k]; if (se != 0 && (se & 0xffff) <= pivot && pivot < (int)((unsigned)se >> 16)) u_end = (int)((unsigned)se >> 16); }
-                const int p0 = pivot;                                            // (its text position is in ST_CB)
-                int handled = 0;
-                for (;;) {
-                    if (handled == 4 || !(pivot < l_seq - msl + 1) || pivot >= u_end) break;
-                    const int pl = (int)((plb >> (8 * handled)) & 0xffu);
-                    const int Ld = u_end - pivot;
-                    if (pl == 255 || pl >= Ld || (Ld >= msl && pl >= msl)) { if (handled == 0 || pl != 255) st[ST_R3_NOPL] = pivot + 1; break; }
-                    ++handled;
-                    if (Ld >= msl) {                                               // kv_push of the seed (:1266-1277)
-                        const int ns = st[ST_N_SMEMS];
-                        if (ns < cap && t == 0) {
-                            const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
-                            SlotRec sr;
-                            sr.start = pivot; sr.end = pivot + msl; sr.count = 1; sr.sa_start = SLOT_POS | (LD64(ST_CB_LO) + (i64)(pivot - p0));
-                            A.slots[(i64)ticket * cap + ns] = sr;
-                        }
-                        st[ST_N_SMEMS] = ns + 1;
-                        ST64(ST_HITS_LO, LD64(ST_HITS_LO) + 1);
-                    }
-                    pivot = pivot + msl;
-                    // the checks PC_R3_TOP makes before a search (:982-1012): an N cannot lie inside the SMEM, but the distance to the next one counts
-                    if (has_n && pivot < l_seq && first_n(nfw, has_n, pivot, l_seq) - pivot < msl) break;
-                }
-                st[ST_SEARCHES] = st[ST_SEARCHES] + handled;
-            }
+            window_compare<E>(pac, n, s, wq, off, capc, ek, ep, lcp, less);
         }
         PROF_MARK(2);
         u64 m = 0;
@@ -850,9 +772,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
         bool r_emit = false;
         int cl[E];                       // LCPs of the cached partition window (this lane's slots)
         bool cache_in_lds = phase != PH_PART;
-        if (phase == PH_PLCP) {
-            // (settled in the window section above)
-        } else
         if (found) {
             // LCPs of the two slots around the flip
             const int v2 = slot_pair<G, E>(lcp, t, P - 1, P);
@@ -1018,12 +937,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
                 // array: there the table would send nearly every search of the region back, and the searches are better done here.)
                 const bool defer = have_pos && A.defer != 0 && FLAG(F_REC) && ns < DEFER_MAX_K && ns < cap && A.opt.rounds >= 2 &&
                                    e_end - e_start >= A.opt.split_len && A.opt.split_width >= 1 && nb_lo < msl && nb_hi < msl;
-                if (have_pos && q_kind != K_R3 && A.r3_table) {            // what the third round may settle from the table
-                    const int k = st[ST_U_NEXT];
-                    st[ST_U_SE + k] = e_start | (e_end << 16);
-                    ST64(ST_U_T + 2 * k, r_T);
-                    st[ST_U_NEXT] = k + 1 == N_USMEM ? 0 : k + 1;
-                }
                 if (ns < cap && t == 0) {
                     const unsigned long long ticket = ((unsigned long long)(unsigned)st[ST_TICKET_HI] << 32) | (unsigned)st[ST_TICKET_LO];
                     SlotRec sr;
@@ -1054,7 +967,6 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             }
             phase = PH_CTRL;
         }
-        if (phase == PH_PLCP) phase = PH_CTRL;                       // (pc is still PC_R3_TOP: the next pass goes on behind the pivots settled)
         PROF_MARK(5);
     }
 #undef PROF_MARK
