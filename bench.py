@@ -272,6 +272,22 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
            # cells of the jobs' band-limited matrices (first attempts; the kernel trims rows and stops at z-drop, so it evaluates fewer)
            "band_cells_per_job": C3["census_band_cells"] / first, "gcups_band_cells": (C3["census_band_cells"] / 1e9) / (R["bsw_ms"] * 1e-3) if R["bsw_ms"] > 0 else None,
            "jobs_by_lds_class": {"query<=%d" % q: cls[i] / first for i, q in enumerate((30, 62, 94, 126, 158, 222, 318, 600))} | {"query>600": cls[8] / first}}
+    # the stage as the bound aligner runs it (tuning "ext_live_only": extension in rounds, surviving records only): must be the records above minus the
+    # purged ones -- which were just compared with the oracle one by one
+    ctx.set_tuning("ext_live_only", 1)
+    RL = ctx.extend_last_batch_host(contigs, copt)
+    RL = ctx.extend_last_batch_host(contigs, copt)
+    ctx.set_tuning("ext_live_only", 0)
+    keep = R["regs"]["qe"] > R["regs"]["qb"]
+    same_l = same and np.array_equal(RL["reg_off"], np.concatenate([[0], np.cumsum(keep.astype(np.int64))])[R["reg_off"]]) and RL["regs"].tobytes() == R["regs"][keep].tobytes()
+    out["all_seeds_at_once"] = {"value": out["value"], "ext_ms": R["ext_ms"], "bsw_ms": R["bsw_ms"], "extension_jobs": R["n_pairs"]}
+    out["in_rounds"] = {"value": n / ((RL["chain_ms"] + RL["ext_ms"]) * 1e-3) if same_l else None, "chain_ms": RL["chain_ms"], "ext_ms": RL["ext_ms"], "bsw_ms": RL["bsw_ms"],
+                        "extension_jobs": RL["n_pairs"], "jobs_with_doubled_band": RL["n_retried"], "bsw_launches": RL["n_bsw_calls"], "chained_seeds": RL["total_seeds"],
+                        "seeds_extended": RL["n_ext_seeds"], "records_handed_to_the_host": int(RL["regs"].shape[0]),
+                        "equals_the_checked_records_minus_the_purged_ones": bool(same_l)}
+    if same_l:
+        out["value"] = out["in_rounds"]["value"]
+        out["what"] = "chaining + extension in rounds (surviving records only), as the bound aligner calls the stage; all_seeds_at_once = the reference's batch order, every record checked"
     # bwa_gen_cigar2 for every read's best live record, called as mem_reg2aln calls it first (src/bwamem.cpp:2333-2342 with a 1, o 6, e 1, w 100)
     regs, ro = R["regs"], R["reg_off"]
     rid = np.repeat(np.arange(n), np.diff(ro))

@@ -341,7 +341,7 @@ int ext_mode() {
 }
 bool g_ext_on_device = false;           // decided per run in mem_process_seqs (needs opt)
 std::atomic<double> g_t_ext_dev{0}, g_t_ext_chain_ms{0}, g_t_ext_ms{0}, g_t_ext_bsw_ms{0};
-std::atomic<int64_t> g_n_ext_pairs{0}, g_n_ext_retried{0}, g_n_ext_regs{0}, g_n_ext_tier2{0}, g_n_flt_jobs{0}, g_n_flt_dropped{0};
+std::atomic<int64_t> g_n_ext_pairs{0}, g_n_ext_retried{0}, g_n_ext_regs{0}, g_n_ext_live{0}, g_n_ext_tier2{0}, g_n_flt_jobs{0}, g_n_flt_dropped{0};
 bool chain_on_device() { static const bool v = !(getenv("MEME_DROPIN_CHAIN") && atoi(getenv("MEME_DROPIN_CHAIN")) == 0); return v; }
 bool chain_check() { static const bool v = getenv("MEME_DROPIN_CHAIN_CHECK") != nullptr; return v; }
 // MEME_DROPIN_CHAIN_DUMP=<file> (fixture generation, tests/golden/make_chain_golden.py): every read's seeds and the chains the
@@ -421,6 +421,9 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
             const double tc0 = now_s();
             int rc = meme_seed_batch_resident_ascii(ctx, P.flat + P.off[first], poff, count, &so, nullptr, nullptr);
             g_t_seed_call = g_t_seed_call + (now_s() - tc0);
+            // (only the records mem_kernel2_core keeps cross to the host, src/bwamem.cpp:1680-1693; MEME_DROPIN_EXT_LIVE=0: all of them, as the reference's stage leaves them)
+            static const int64_t live_only = getenv("MEME_DROPIN_EXT_LIVE") ? atoll(getenv("MEME_DROPIN_EXT_LIVE")) : 1;
+            if (rc == MEME_OK) rc = meme_set_tuning(ctx, "ext_live_only", live_only);
             if (rc == MEME_OK) rc = meme_extend_last_batch_host(ctx, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, R);
             return rc;
         };
@@ -441,7 +444,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
                 const int64_t base = (int64_t)P.own_regs.size();
                 P.own_regs.insert(P.own_regs.end(), R.regs, R.regs + R.total_regs);
                 for (int64_t i = 1; i <= m; ++i) P.own_reg_off.push_back(base + R.reg_off[i]);
-                tot.total_regs += R.total_regs; tot.total_chains += R.total_chains; tot.n_pairs += R.n_pairs; tot.n_retried += R.n_retried; tot.n_bsw_calls += R.n_bsw_calls;
+                tot.total_regs += R.total_regs; tot.total_seeds += R.total_seeds; tot.total_chains += R.total_chains; tot.n_pairs += R.n_pairs; tot.n_retried += R.n_retried; tot.n_bsw_calls += R.n_bsw_calls;
                 tot.n_tier2 += R.n_tier2; tot.chain_ms += R.chain_ms; tot.ext_ms += R.ext_ms; tot.bsw_ms += R.bsw_ms;
                 tot.n_flt_jobs += R.n_flt_jobs; tot.n_flt_dropped += R.n_flt_dropped;
                 done += m;
@@ -473,7 +476,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         }
         g_t_ext_dev = g_t_ext_dev + (now_s() - t0);
         g_t_ext_chain_ms = g_t_ext_chain_ms + P.ext.chain_ms; g_t_ext_ms = g_t_ext_ms + P.ext.ext_ms; g_t_ext_bsw_ms = g_t_ext_bsw_ms + P.ext.bsw_ms;
-        g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
+        g_n_ext_pairs += P.ext.n_pairs; g_n_ext_retried += P.ext.n_retried; g_n_ext_regs += P.ext.total_seeds; g_n_ext_live += P.ext.total_regs; g_n_ext_tier2 += P.ext.n_tier2;
         g_n_flt_jobs += P.ext.n_flt_jobs; g_n_flt_dropped += P.ext.n_flt_dropped;
         P.has_ext = true;
         return;
@@ -689,8 +692,8 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
     if (verbose() && g_ext_on_device)
         fprintf(stderr, "[meme-dropin] chaining + extension on the device: %.3f s in the backend calls so far (HIP events: chaining %.3f s, extension stage %.3f s of "
                 "which banded SW %.3f s); %lld alignment records, %lld extension jobs (%lld of them again with the doubled band), %lld reads chained by the "
-                "wavefront-per-read tier, 0 reads chained on the host\n", (double)g_t_ext_dev, (double)g_t_ext_chain_ms * 1e-3, (double)g_t_ext_ms * 1e-3,
-                (double)g_t_ext_bsw_ms * 1e-3, (long long)g_n_ext_regs, (long long)g_n_ext_pairs, (long long)g_n_ext_retried, (long long)g_n_ext_tier2);
+                "wavefront-per-read tier, 0 reads chained on the host; %lld records handed to the host\n", (double)g_t_ext_dev, (double)g_t_ext_chain_ms * 1e-3, (double)g_t_ext_ms * 1e-3,
+                (double)g_t_ext_bsw_ms * 1e-3, (long long)g_n_ext_regs, (long long)g_n_ext_pairs, (long long)g_n_ext_retried, (long long)g_n_ext_tier2, (long long)g_n_ext_live);
     if (verbose() && g_ext_on_device && g_n_flt_jobs > 0)
         fprintf(stderr, "[meme-dropin] seed filter (mem_flt_chained_seeds) on the device: %lld alignments, %lld chained seeds removed\n", (long long)g_n_flt_jobs, (long long)g_n_flt_dropped);
     if (verbose() && !g_ext_on_device && chain_on_device())

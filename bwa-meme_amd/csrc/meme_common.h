@@ -63,7 +63,7 @@ struct meme_ctx {
     void* plcp_aux = nullptr;                      // the plcp table of an attached index (meme_index_attach: the arrays are the caller's, this is ours)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[15], gcig[11], kswv[7], sam[9];
+           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[18], gcig[11], kswv[7], sam[9];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[3], h_kswv, h_sam[2];
     i64 last_seed_max_len = 0;         // longest read of that batch
@@ -78,6 +78,8 @@ struct meme_ctx {
     i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
                                        // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches
+    i64 ext_live_only = 0;             // 1: meme_extend_last_batch_host hands over the surviving records only (qe > qb: what src/bwamem.cpp:1680-1693 keeps)
+    i64 ext_rounds = 2;                // with ext_live_only: rounds of one seed per read before everything still ahead is extended at once (0: the reference's batch, then compaction)
     i64 ext_census = 0;                // 1: the extension stage counts its exact-prefix jobs (a measurement, profiles/r05_bsw.md)
     i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched
     i64 chain_light_hits = 32;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it

@@ -38,6 +38,9 @@ struct ExtArgs {
     const i64 *offL, *offR, *offB;    // their exclusive scans over the batch (pointing at read g0)
     i64 job0L, job0R, byte0;          // offsets of this slab's first job / byte (subtracted: SeqPair offsets are 32-bit)
     meme_seqpair* L; meme_seqpair* R; uint8_t* seq;
+    // extension in rounds (tuning "ext_rounds"): mode 0 = every chained seed at once (the reference's batch, :2573-3388); 1 = records and the extension
+    // order only, no jobs; 2 = jobs of the seeds k_ext_advance selected (sel: per chained seed; act: per read, any selected)
+    int mode; const uint8_t* sel; const uint8_t* act; int4* state;
 };
 
 __device__ __forceinline__ int cal_max_gap(const meme_ext_opt& o, int qlen) {       // src/bwamem.cpp:85-95
@@ -75,7 +78,11 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
     const int S = (int)(A.seed_off[r + 1] - s0);
     const int l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
     const meme_ext_opt& o = A.o;
-    if (!WRITE) {
+    if (A.mode == 2 && !A.act[r]) {                  // nothing of this read in the round
+        if (!WRITE && lane == 0) { A.cntL[rl] = 0; A.cntR[rl] = 0; A.cntB[rl] = 0; }
+        return;
+    }
+    if (WRITE ? A.mode == 1 : A.mode == 0) {
         // ---- reference span of every chain: the widest any of its seeds may reach (:2648-2690)
         for (int c = 0; c < nc; ++c) {
             const meme_chain ch = A.chains[c0 + c];
@@ -105,8 +112,9 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
     }
     // ---- one lane per chained seed: its place in the extension order, its two jobs
     i64 nL = 0, nR = 0, nB = 0;                       // running totals of the read (uniform)
-    const i64 jobL0 = WRITE ? A.offL[rl] - A.job0L : 0, jobR0 = WRITE ? A.offR[rl] - A.job0R : 0;
-    const i64 byte0 = WRITE ? A.offB[rl] - A.byte0 : 0;
+    const bool posing = WRITE && A.mode != 1;
+    const i64 jobL0 = posing ? A.offL[rl] - A.job0L : 0, jobR0 = posing ? A.offR[rl] - A.job0R : 0;
+    const i64 byte0 = posing ? A.offB[rl] - A.byte0 : 0;
     for (int jb = 0; jb < S; jb += 64) {
         const int j = jb + lane;
         const bool valid = j < S;
@@ -121,7 +129,9 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
         const int il = valid ? j - ch.seed_beg : 0;
         const meme_chain_seed t = sd[il];
         const i64 rmax0 = A.rmax[2 * (c0 + c)], rmax1 = A.rmax[2 * (c0 + c) + 1];
-        const bool hasL = valid && t.qbeg > 0, hasR = valid && t.qbeg + t.len != l_query;
+        const bool pick = valid && A.mode != 1 && (A.mode == 0 || A.sel[s0 + j]);              // its jobs are posed by this launch
+        const bool sideL = valid && t.qbeg > 0, sideR = valid && t.qbeg + t.len != l_query;   // the seed has a left / right flank at all
+        const bool hasL = pick && sideL, hasR = pick && sideR;
         const int qe = t.qbeg + t.len;
         const int l2L = t.qbeg, l1L = (int)(t.rbeg - rmax0);
         const int l2R = l_query - qe, l1R = (int)(rmax1 - (t.rbeg + t.len));
@@ -135,7 +145,7 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
             bex = x - bsum;
             bsum = __shfl(x, 63);
         }
-        if (WRITE && valid) {
+        if (WRITE && valid && (A.mode != 2 || pick)) {
             // rank among the chain's seeds by (score, index): ks_introsort_64 on score << 32 | index, keys unique (:2692-2699)
             int rank = 0;
             if (A.seed_score) {
@@ -144,29 +154,29 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
                 for (int k = 0; k < ch.n_seeds; ++k) { const int lk = ss[k]; rank += (lk < mine || (lk == mine && k < il)) ? 1 : 0; }
             } else
                 for (int k = 0; k < ch.n_seeds; ++k) { const int lk = sd[k].len; rank += (lk < t.len || (lk == t.len && k < il)) ? 1 : 0; }
-            A.order[s0 + ch.seed_beg + rank] = il;
+            if (A.mode != 2) A.order[s0 + ch.seed_beg + rank] = il;
             const i64 reg = s0 + ch.seed_beg + (ch.n_seeds - 1 - rank);        // best seed first
             meme_alnreg a;
             memset(&a, 0, sizeof(a));
             a.w = o.w; a.score = a.truesc = -1; a.rid = ch.rid; a.frac_rep = A.frac_rep[r]; a.seedlen0 = t.len; a.c = (u64)(c0 + c);
             a.rb = a.re = H0; a.qb = a.qe = H0;
+            if (sideL) { a.qb = t.qbeg; a.rb = t.rbeg; } else { a.score = a.truesc = t.len * o.a; a.qb = 0; a.rb = t.rbeg; }
+            if (sideR) { a.qe = qe; a.re = t.rbeg + t.len; } else { a.qe = l_query; a.re = t.rbeg + t.len; seedcov(&a, sd, ch.n_seeds); }
+            if (A.mode != 2) A.regs[reg] = a;
             if (hasL) {
                 meme_seqpair sp;
                 memset(&sp, 0, sizeof(sp));
                 sp.h0 = t.len * o.a; sp.seqid = (int32_t)r; sp.regid = (int32_t)reg; sp.len1 = l1L; sp.len2 = l2L;
                 sp.idr = (int32_t)(byte0 + nB + bex); sp.idq = sp.idr + pad4(l1L);
                 A.L[jobL0 + nL + __popcll(mL & below)] = sp;
-                a.qb = t.qbeg; a.rb = t.rbeg;
-            } else { a.score = a.truesc = t.len * o.a; a.qb = 0; a.rb = t.rbeg; }
+            }
             if (hasR) {
                 meme_seqpair sp;
                 memset(&sp, 0, sizeof(sp));
                 sp.h0 = H0; sp.seqid = (int32_t)r; sp.regid = (int32_t)reg; sp.len1 = l1R; sp.len2 = l2R;
                 sp.idr = (int32_t)(byte0 + nB + bex + bytesL); sp.idq = sp.idr + pad4(l1R);
                 A.R[jobR0 + nR + __popcll(mR & below)] = sp;
-                a.qe = qe; a.re = t.rbeg + t.len;
-            } else { a.qe = l_query; a.re = t.rbeg + t.len; seedcov(&a, sd, ch.n_seeds); }
-            A.regs[reg] = a;
+            }
         }
         if (WRITE) {
             // the sequences, job after job, 64 lanes x 4 bases per step: left jobs reversed (both sequences run away from the seed)
@@ -206,6 +216,7 @@ __global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
         nL += __popcll(mL); nR += __popcll(mR); nB += bsum;
     }
     if (!WRITE && lane == 0) { A.cntL[rl] = nL; A.cntR[rl] = nR; A.cntB[rl] = nB; }
+    if (WRITE && A.mode == 1 && lane == 0) A.state[r] = make_int4(0, nc ? A.chains[c0].n_seeds - 1 : 0, 0, 0);   // k_ext_advance starts at the best seed of the first chain
 }
 
 // ---- mem_flt_chained_seeds (src/bwamem.cpp:565-598) ---------------------------------------------------------------------------------
@@ -424,7 +435,134 @@ __global__ void __launch_bounds__(64) k_ext_purge(PurgeArgs P) {
     }
 }
 
+// ---- extension in rounds ------------------------------------------------------------------------------------------------------------------
+// The reference extends every chained seed of a batch and then drops, read by read and in extension order, the alignments of seeds that an
+// earlier SURVIVING alignment of the read covers (:3389-3485); mem_kernel2_core deletes the dropped records at once (src/bwamem.cpp:1680-1693).
+// A dropped seed's extension is therefore never looked at, and whether a seed is dropped depends on the survivors before it only: the same
+// records come out when a read's seeds are taken in that order, tested first, and extended only if they survive.  k_ext_advance walks a read
+// from where it stands: dropped seeds are marked, the first survivor is selected for this round's jobs (ADV_ONE); in the last round every seed
+// from the next survivor on is selected at once (ADV_REST: repeat-rich reads have tens of survivors, one round each would be launches without work) and
+// ADV_FINISH walks to the end over alignments that then all exist -- which is the reference's own pass from that point on.
+enum { ADV_ONE = 0, ADV_REST = 1, ADV_FINISH = 2 };
+struct AdvArgs { PurgeArgs P; int4* state; uint8_t* sel; uint8_t* act; unsigned long long* n_sel; int mode; };
+
+__global__ void __launch_bounds__(64) k_ext_advance(AdvArgs V) {
+    const PurgeArgs& P = V.P;
+    const i64 r = blockIdx.x;
+    if (r >= P.nreads) return;
+    const int lane = threadIdx.x;
+    const i64 c0 = P.chain_off[r];
+    const int nc = (int)(P.chain_off[r + 1] - c0);
+    const i64 s0 = P.seed_off[r];
+    int4 st = V.state[r];                              // x chain, y rank of the next seed in it (-1: the chain is done), z seeds met so far
+    if (V.mode != ADV_FINISH && lane == 0) V.act[r] = 0;
+    if (st.x >= nc) return;
+    const int l_query = (int)(P.read_off[r + 1] - P.read_off[r]);
+    meme_alnreg* av = P.regs + s0;
+    int cur = st.z;
+    for (int c = st.x; c < nc; ++c) {
+        const meme_chain ch = P.chains[c0 + c];
+        const meme_chain_seed* sd = P.seeds + s0 + ch.seed_beg;
+        int* ord = P.order + s0 + ch.seed_beg;
+        for (int k = c == st.x ? st.y : ch.n_seeds - 1; k >= 0; --k, ++cur) {
+            const meme_chain_seed s = sd[ord[k]];
+            bool found = false;
+            for (int ib = 0; ib < cur && !found; ib += 64) {
+                const int i = ib + lane;
+                bool hit = false;
+                if (i < cur) {
+                    const meme_alnreg* p = &av[i];
+                    const i64 prb = p->rb, pre = p->re;
+                    const int pqb = p->qb, pqe = p->qe;
+                    if (!(pqb == -1 && pqe == -1) && !(s.rbeg < prb || s.rbeg + s.len > pre || s.qbeg < pqb || s.qbeg + s.len > pqe) &&
+                        !(s.len - p->seedlen0 > .1 * l_query)) {
+                        const int pw = p->w;
+                        int qd = s.qbeg - pqb;
+                        i64 rd = s.rbeg - prb;
+                        int max_gap = cal_max_gap(P.o, qd < rd ? qd : (int)rd);
+                        int band = max_gap < pw ? max_gap : pw;
+                        if (qd - rd < band && rd - qd < band) hit = true;
+                        else {
+                            qd = pqe - (s.qbeg + s.len);
+                            rd = pre - (s.rbeg + s.len);
+                            max_gap = cal_max_gap(P.o, qd < rd ? qd : (int)rd);
+                            band = max_gap < pw ? max_gap : pw;
+                            if (qd - rd < band && rd - qd < band) hit = true;
+                        }
+                    }
+                }
+                found = __ballot(hit) != 0;
+            }
+            bool drop = false;
+            if (found) {
+                bool other = false;
+                for (int ub = k + 1; ub < ch.n_seeds && !other; ub += 64) {
+                    const int u = ub + lane;
+                    bool hit = false;
+                    if (u < ch.n_seeds && ord[u] >= 0) {
+                        const meme_chain_seed t = sd[ord[u]];
+                        if (!(t.len < s.len * .95)) {
+                            if (s.qbeg <= t.qbeg && s.qbeg + s.len - t.qbeg >= s.len >> 2 && t.qbeg - s.qbeg != t.rbeg - s.rbeg) hit = true;
+                            else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
+                        }
+                    }
+                    other = __ballot(hit) != 0;
+                }
+                drop = !other;
+            }
+            if (drop) { av[cur].qb = -1; av[cur].qe = -1; ord[k] = -1; continue; }
+            if (V.mode == ADV_FINISH) continue;        // a survivor whose alignment exists
+            if (V.mode == ADV_REST) {                  // this survivor and everything behind it go into the round; ADV_FINISH walks on from here
+                unsigned long long cnt = 0;
+                for (int c2 = c; c2 < nc; ++c2) {
+                    const meme_chain ch2 = P.chains[c0 + c2];
+                    const int* ord2 = P.order + s0 + ch2.seed_beg;
+                    const int k1 = c2 == c ? k : ch2.n_seeds - 1;
+                    for (int k2 = k1 - lane; k2 >= 0; k2 -= 64) V.sel[s0 + ch2.seed_beg + ord2[k2]] = 1;
+                    cnt += k1 + 1;
+                }
+                if (lane == 0) { V.act[r] = 1; V.state[r] = make_int4(c, k, cur, 0); atomicAdd(V.n_sel, cnt); }
+                return;
+            }
+            if (lane == 0) {                           // this round's seed of the read
+                V.sel[s0 + ch.seed_beg + ord[k]] = 1;
+                V.act[r] = 1;
+                V.state[r] = make_int4(c, k - 1, cur + 1, 0);
+                atomicAdd(V.n_sel, 1ull);
+            }
+            return;
+        }
+        st.y = 0;                                      // (later chains start at their best seed; st.x no longer equals c)
+    }
+    if (lane == 0) V.state[r] = make_int4(nc, 0, cur, 0);
+}
+
 unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
+
+// tuning "ext_live_only": what mem_kernel2_core does first with the stage's records (src/bwamem.cpp:1680-1693: every record with qe <= qb -- the purged
+// ones -- is dropped, the others keep their order) done before the records cross to the host: a read's surviving records counted, then packed.
+__global__ void __launch_bounds__(256) k_ext_live_count(const i64* __restrict__ seed_off, const meme_alnreg* __restrict__ regs, i64 n, i64* __restrict__ cnt) {
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < n; r += (i64)gridDim.x * 256) {
+        int m = 0;
+        for (i64 i = seed_off[r]; i < seed_off[r + 1]; ++i) m += regs[i].qe > regs[i].qb;
+        cnt[r] = m;
+    }
+}
+__global__ void __launch_bounds__(256) k_ext_live_pack(const i64* __restrict__ seed_off, const meme_alnreg* __restrict__ regs, i64 n, const i64* __restrict__ live_off,
+                                                       meme_alnreg* __restrict__ out) {
+    static_assert(sizeof(meme_alnreg) == 7 * 16, "record copied as seven 16-byte words");
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < n; r += (i64)gridDim.x * 256) {
+        i64 o = live_off[r];
+        if (o == live_off[r + 1]) continue;
+        for (i64 i = seed_off[r]; i < seed_off[r + 1]; ++i) {
+            if (!(regs[i].qe > regs[i].qb)) continue;
+            const uint4* s = (const uint4*)&regs[i];
+            uint4* d = (uint4*)&out[o++];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) d[k] = s[k];
+        }
+    }
+}
 
 // measurement (tuning "ext_census"): jobs whose query equals the first len2 bases of the target (no ambiguous base) -- the jobs a closed form
 // could answer without the DP (score = h0 + len2 * a).  SMEM seeds end on a mismatch or at a read end, so few are expected.
@@ -480,7 +618,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     DevBuf* B = ctx->chain;
     DevBuf* E = ctx->ext;       // 0 rmax, 1 regs, 2 order, 3 counts + scans, 4 L pairs, 5 R pairs, 6 retry pairs (two halves), 7 sequences, 8 counters,
-                                // 9 .. 14 the seed filter's: scores, jobs, counts + new seed offsets, kept seeds, their scores, thresholds
+                                // 9 .. 14 the seed filter's: scores, jobs, counts + new seed offsets, kept seeds, their scores, thresholds; 15, 16 surviving records: counts + scan, packed
     const i64* d_choff = (const i64*)B[5].p;
     const i64* d_sdoff = d_choff + (n + 1);
     const i64 n_chains = tot[0];
@@ -538,22 +676,6 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     i64* d_cnt = (i64*)E[3].p;
     i64* d_off = d_cnt + 3 * (n + 1);
     A.cntL = d_cnt; A.cntR = d_cnt + (n + 1); A.cntB = d_cnt + 2 * (n + 1);
-    // ---- plan: spans, job and byte counts of every read, their scans
-    hipLaunchKernelGGL((k_ext_jobs<false>), dim3((unsigned)n), dim3(64), 0, ctx->stream, A);
-    for (int k = 0; k < 3; ++k) if ((rc = meme_scan_exclusive(ctx, d_cnt + k * (n + 1), d_off + k * (n + 1), n))) return rc;
-    std::vector<i64> h_off((size_t)(3 * (n + 1)));
-    HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, h_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    i64 h_flt[2] = {n_seeds, 0};                    // chained seeds after the filter, alignments it ran
-    if (flt) {
-        HIP_TRY(hipMemcpyAsync(&h_flt[0], d_sdoff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(&h_flt[1], d_fltcnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const i64 n_flt_dropped = n_seeds - h_flt[0];
-    n_seeds = h_flt[0];
-    const i64* oL = h_off.data();
-    const i64* oR = oL + (n + 1);
-    const i64* oB = oR + (n + 1);
     meme_bsw_opt bl, br;
     memset(&bl, 0, sizeof(bl));
     bl.o_del = eopt->o_del; bl.e_del = eopt->e_del; bl.o_ins = eopt->o_ins; bl.e_ins = eopt->e_ins; bl.zdrop = eopt->zdrop; bl.a = eopt->a; bl.b = eopt->b;
@@ -561,74 +683,157 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     bl.end_bonus = eopt->pen_clip5;                   // bswLeft / bswRight, src/bwamem.cpp:2953-2959
     br.end_bonus = eopt->pen_clip3;
     unsigned long long* d_nretry = (unsigned long long*)E[8].p;
+    unsigned long long* d_nsel = (unsigned long long*)E[8].p + 1;
     unsigned long long* d_census = (unsigned long long*)E[8].p + 8;
     if (ctx->ext_census) HIP_TRY(hipMemsetAsync(d_census, 0, 11 * 8, ctx->stream));
     i64 n_pairs = 0, n_retried = 0, n_calls = 0;
     float bsw_ms = 0.f;
-    // ---- slabs of reads whose jobs' sequences fit 32-bit offsets (SeqPair::idr / idq)
-    const i64 SLAB_BYTES = (i64)3 << 29, SLAB_JOBS = 8 << 20;
-    for (i64 g0 = 0; g0 < n;) {
-        i64 g1 = g0 + 1;
-        while (g1 < n && oB[g1 + 1] - oB[g0] <= SLAB_BYTES && oL[g1 + 1] - oL[g0] <= SLAB_JOBS && oR[g1 + 1] - oR[g0] <= SLAB_JOBS) {
-            i64 step = 1;                               // gallop to the slab's end
-            while (g1 + 2 * step < n && oB[g1 + 2 * step + 1] - oB[g0] <= SLAB_BYTES && oL[g1 + 2 * step + 1] - oL[g0] <= SLAB_JOBS &&
-                   oR[g1 + 2 * step + 1] - oR[g0] <= SLAB_JOBS) step *= 2;
-            g1 += step;
+    i64 h_flt[2] = {n_seeds, 0};                    // chained seeds after the filter, alignments it ran
+    bool flt_read = !flt;
+    std::vector<i64> h_off;
+    // ---- the jobs of the seeds `A.mode` / `A.sel` name: plan (job and byte counts of every read, their scans), sequences, banded SW left then right
+    // with the band doubled once where the reference doubles it, results folded into the records.  *n_sel_out: what k_ext_advance selected for this round.
+    auto run_jobs = [&](unsigned long long* n_sel_out) -> int {
+        int rc;
+        hipLaunchKernelGGL((k_ext_jobs<false>), dim3((unsigned)n), dim3(64), 0, ctx->stream, A);
+        for (int k = 0; k < 3; ++k) if ((rc = meme_scan_exclusive(ctx, d_cnt + k * (n + 1), d_off + k * (n + 1), n))) return rc;
+        i64 tot3[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(&tot3[k], d_off + k * (n + 1) + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_sel_out) HIP_TRY(hipMemcpyAsync(n_sel_out, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (!flt_read) {
+            HIP_TRY(hipMemcpyAsync(&h_flt[0], d_sdoff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(&h_flt[1], d_fltcnt, 8, hipMemcpyDeviceToHost, ctx->stream));
         }
-        if (oB[g1] - oB[g0] >= ((i64)1 << 31)) { meme_set_error("a read's extension jobs need more than 2 GiB of sequence"); return MEME_E_CAPACITY; }
-        const i64 nL = oL[g1] - oL[g0], nR = oR[g1] - oR[g0], nB = oB[g1] - oB[g0];
-        const i64 nmax = nL > nR ? nL : nR;
-        if ((rc = meme_buf_reserve(ctx, E[4], (size_t)(nL + 1) * sizeof(meme_seqpair))) || (rc = meme_buf_reserve(ctx, E[5], (size_t)(nR + 1) * sizeof(meme_seqpair))) ||
-            (rc = meme_buf_reserve(ctx, E[6], (size_t)(2 * nmax + 2) * sizeof(meme_seqpair))) || (rc = meme_buf_reserve(ctx, E[7], (size_t)nB + 256))) return rc;
-        ExtArgs S = A;
-        S.g0 = g0; S.ns = g1 - g0;
-        // (the scans cover the whole batch: a slab's first read has its own offsets to subtract)
-        S.offL = d_off + g0; S.offR = d_off + (n + 1) + g0; S.offB = d_off + 2 * (n + 1) + g0;
-        S.job0L = oL[g0]; S.job0R = oR[g0]; S.byte0 = oB[g0];
-        S.L = (meme_seqpair*)E[4].p; S.R = (meme_seqpair*)E[5].p; S.seq = (uint8_t*)E[7].p;
-        hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)(g1 - g0)), dim3(64), 0, ctx->stream, S);
-        HIP_TRY(hipGetLastError());
-        if (ctx->ext_census) {
-            if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, eopt->w, d_census);
-            if (nR) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nR, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.R, nR, (const uint8_t*)S.seq, eopt->w, d_census);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        flt_read = true;
+        // ---- slabs of reads whose jobs' sequences fit 32-bit offsets (SeqPair::idr / idq); the per-read offsets cross to the host only when one slab is not enough
+        const i64 SLAB_BYTES = (i64)3 << 29, SLAB_JOBS = 8 << 20;
+        const bool one_slab = tot3[2] <= SLAB_BYTES && tot3[0] <= SLAB_JOBS && tot3[1] <= SLAB_JOBS;
+        if (tot3[0] + tot3[1] == 0) return MEME_OK;
+        if (!one_slab) {
+            h_off.resize((size_t)(3 * (n + 1)));
+            HIP_TRY(hipMemcpyAsync(h_off.data(), d_off, h_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-        for (int dir = 0; dir < 2; ++dir) {
-            meme_seqpair* P = dir == 0 ? S.L : S.R;
-            i64 np = dir == 0 ? nL : nR;
-            if (dir == 1 && np > 0) hipLaunchKernelGGL(k_ext_h0, dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, P, np, (const meme_alnreg*)A.regs);
-            for (int attempt = 0; attempt < EXT_BAND_TRIES && np > 0; ++attempt) {
-                const int w = eopt->w << attempt;
-                if ((rc = meme_bsw_launch(ctx, P, S.seq, S.seq, (int)np, w, dir == 0 ? &bl : &br, (int)ctx->last_seed_max_len))) return rc;
-                HIP_TRY(hipMemsetAsync(d_nretry, 0, 8, ctx->stream));
-                FoldArgs F;
-                F.pairs = P; F.n = np; F.regs = A.regs; F.chains = A.chains; F.seed_off = A.seed_off; F.seeds = A.seeds; F.read_off = A.read_off;
-                F.o = *eopt; F.w = w; F.last = attempt + 1 == EXT_BAND_TRIES;
-                F.retry = (meme_seqpair*)E[6].p + (size_t)(attempt & 1) * (size_t)(nmax + 1); F.n_retry = d_nretry;
-                if (dir == 0) hipLaunchKernelGGL((k_ext_fold<true>), dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, F);
-                else hipLaunchKernelGGL((k_ext_fold<false>), dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, F);
-                unsigned long long h_retry = 0;
-                HIP_TRY(hipMemcpyAsync(&h_retry, d_nretry, 8, hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) bsw_ms += ms; }
-                n_pairs += np; ++n_calls;
-                if (attempt > 0) n_retried += np;
-                P = F.retry;
-                np = (i64)h_retry;
+        const i64* oL = one_slab ? nullptr : h_off.data();
+        const i64* oR = one_slab ? nullptr : oL + (n + 1);
+        const i64* oB = one_slab ? nullptr : oR + (n + 1);
+        for (i64 g0 = 0; g0 < n;) {
+            i64 g1 = n, nL = tot3[0], nR = tot3[1], nB = tot3[2], j0L = 0, j0R = 0, b0 = 0;
+            if (!one_slab) {
+                g1 = g0 + 1;
+                while (g1 < n && oB[g1 + 1] - oB[g0] <= SLAB_BYTES && oL[g1 + 1] - oL[g0] <= SLAB_JOBS && oR[g1 + 1] - oR[g0] <= SLAB_JOBS) {
+                    i64 step = 1;                               // gallop to the slab's end
+                    while (g1 + 2 * step < n && oB[g1 + 2 * step + 1] - oB[g0] <= SLAB_BYTES && oL[g1 + 2 * step + 1] - oL[g0] <= SLAB_JOBS &&
+                           oR[g1 + 2 * step + 1] - oR[g0] <= SLAB_JOBS) step *= 2;
+                    g1 += step;
+                }
+                if (oB[g1] - oB[g0] >= ((i64)1 << 31)) { meme_set_error("a read's extension jobs need more than 2 GiB of sequence"); return MEME_E_CAPACITY; }
+                nL = oL[g1] - oL[g0]; nR = oR[g1] - oR[g0]; nB = oB[g1] - oB[g0];
+                j0L = oL[g0]; j0R = oR[g0]; b0 = oB[g0];
             }
+            const i64 nmax = nL > nR ? nL : nR;
+            if ((rc = meme_buf_reserve(ctx, E[4], (size_t)(nL + 1) * sizeof(meme_seqpair))) || (rc = meme_buf_reserve(ctx, E[5], (size_t)(nR + 1) * sizeof(meme_seqpair))) ||
+                (rc = meme_buf_reserve(ctx, E[6], (size_t)(2 * nmax + 2) * sizeof(meme_seqpair))) || (rc = meme_buf_reserve(ctx, E[7], (size_t)nB + 256))) return rc;
+            ExtArgs S = A;
+            S.g0 = g0; S.ns = g1 - g0;
+            // (the scans cover the whole batch: a slab's first read has its own offsets to subtract)
+            S.offL = d_off + g0; S.offR = d_off + (n + 1) + g0; S.offB = d_off + 2 * (n + 1) + g0;
+            S.job0L = j0L; S.job0R = j0R; S.byte0 = b0;
+            S.L = (meme_seqpair*)E[4].p; S.R = (meme_seqpair*)E[5].p; S.seq = (uint8_t*)E[7].p;
+            hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)(g1 - g0)), dim3(64), 0, ctx->stream, S);
+            HIP_TRY(hipGetLastError());
+            if (ctx->ext_census) {
+                if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, eopt->w, d_census);
+                if (nR) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nR, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.R, nR, (const uint8_t*)S.seq, eopt->w, d_census);
+            }
+            for (int dir = 0; dir < 2; ++dir) {
+                meme_seqpair* P = dir == 0 ? S.L : S.R;
+                i64 np = dir == 0 ? nL : nR;
+                if (dir == 1 && np > 0) hipLaunchKernelGGL(k_ext_h0, dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, P, np, (const meme_alnreg*)A.regs);
+                for (int attempt = 0; attempt < EXT_BAND_TRIES && np > 0; ++attempt) {
+                    const int w = eopt->w << attempt;
+                    if ((rc = meme_bsw_launch(ctx, P, S.seq, S.seq, (int)np, w, dir == 0 ? &bl : &br, (int)ctx->last_seed_max_len))) return rc;
+                    HIP_TRY(hipMemsetAsync(d_nretry, 0, 8, ctx->stream));
+                    FoldArgs F;
+                    F.pairs = P; F.n = np; F.regs = A.regs; F.chains = A.chains; F.seed_off = A.seed_off; F.seeds = A.seeds; F.read_off = A.read_off;
+                    F.o = *eopt; F.w = w; F.last = attempt + 1 == EXT_BAND_TRIES;
+                    F.retry = (meme_seqpair*)E[6].p + (size_t)(attempt & 1) * (size_t)(nmax + 1); F.n_retry = d_nretry;
+                    if (dir == 0) hipLaunchKernelGGL((k_ext_fold<true>), dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, F);
+                    else hipLaunchKernelGGL((k_ext_fold<false>), dim3(grid_of(np, 256)), dim3(256), 0, ctx->stream, F);
+                    unsigned long long h_retry = 0;
+                    HIP_TRY(hipMemcpyAsync(&h_retry, d_nretry, 8, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    { float ms = 0.f; if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) bsw_ms += ms; }
+                    n_pairs += np; ++n_calls;
+                    if (attempt > 0) n_retried += np;
+                    P = F.retry;
+                    np = (i64)h_retry;
+                }
+            }
+            g0 = g1;
         }
-        g0 = g1;
-    }
-    // ---- purge, then the records to the host
+        return MEME_OK;
+    };
     PurgeArgs P;
     P.read_off = A.read_off; P.nreads = n; P.chain_off = A.chain_off; P.chains = A.chains; P.seed_off = A.seed_off; P.seeds = A.seeds;
     P.regs = A.regs; P.order = A.order; P.o = *eopt;
-    hipLaunchKernelGGL(k_ext_purge, dim3((unsigned)n), dim3(64), 0, ctx->stream, P);
-    HIP_TRY(hipGetLastError());
+    const i64 rounds = ctx->ext_live_only ? ctx->ext_rounds : 0;
+    i64 n_seeds_ext = 0;                                // chained seeds whose extension jobs ran
+    if (rounds <= 0) {
+        // ---- the reference's batch: every chained seed extended, then the purge
+        A.mode = 0;
+        if ((rc = run_jobs(nullptr))) return rc;
+        hipLaunchKernelGGL(k_ext_purge, dim3((unsigned)n), dim3(64), 0, ctx->stream, P);
+        HIP_TRY(hipGetLastError());
+        n_seeds_ext = h_flt[0];
+    } else {
+        // ---- in rounds (see k_ext_advance): records + extension order first, then `rounds` rounds of one seed per read, one round with everything still ahead
+        if ((rc = meme_buf_reserve(ctx, E[17], (size_t)(n + 1) * 16 + (size_t)(n + 1) + (size_t)n_seeds + 64))) return rc;
+        AdvArgs V;
+        V.P = P; V.state = (int4*)E[17].p; V.act = (uint8_t*)(V.state + (n + 1)); V.sel = V.act + (n + 1); V.n_sel = d_nsel;
+        A.mode = 1; A.state = V.state;
+        hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)n), dim3(64), 0, ctx->stream, A);
+        A.sel = V.sel; A.act = V.act;
+        for (i64 t = 0; t <= rounds; ++t) {
+            HIP_TRY(hipMemsetAsync(V.sel, 0, (size_t)n_seeds, ctx->stream));
+            HIP_TRY(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
+            V.mode = t < rounds ? ADV_ONE : ADV_REST;
+            hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)n), dim3(64), 0, ctx->stream, V);
+            A.mode = 2;
+            unsigned long long h_sel = 0;
+            if ((rc = run_jobs(&h_sel))) return rc;
+            n_seeds_ext += (i64)h_sel;
+            if (h_sel == 0) break;                      // every read has been walked to its end
+        }
+        V.mode = ADV_FINISH;
+        hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)n), dim3(64), 0, ctx->stream, V);
+        HIP_TRY(hipGetLastError());
+    }
+    const i64 n_flt_dropped = n_seeds - h_flt[0];
+    n_seeds = h_flt[0];
     HIP_TRY(hipEventRecord(ev[1], ctx->stream));
     meme_ctx::HostBuf* Hb = ctx->h_ext;
-    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8)) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg)))) return rc;
-    HIP_TRY(hipMemcpyAsync(Hb[0].p, d_sdoff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_seeds) HIP_TRY(hipMemcpyAsync(Hb[1].p, A.regs, (size_t)n_seeds * sizeof(meme_alnreg), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)(n + 1) * 8))) return rc;
+    i64 n_out = n_seeds;                                // records that cross to the host
+    if (ctx->ext_live_only) {
+        if ((rc = meme_buf_reserve(ctx, E[15], (size_t)(n + 1) * 16))) return rc;
+        i64* d_lcnt = (i64*)E[15].p;
+        i64* d_loff = d_lcnt + (n + 1);
+        hipLaunchKernelGGL(k_ext_live_count, dim3(grid_of(n, 256)), dim3(256), 0, ctx->stream, d_sdoff, (const meme_alnreg*)A.regs, n, d_lcnt);
+        if ((rc = meme_scan_exclusive(ctx, d_lcnt, d_loff, n))) return rc;
+        HIP_TRY(hipMemcpyAsync(Hb[0].p, d_loff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        n_out = ((const i64*)Hb[0].p)[n];
+        if ((rc = meme_buf_reserve(ctx, E[16], (size_t)(n_out + 1) * sizeof(meme_alnreg))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(n_out + 1) * sizeof(meme_alnreg)))) return rc;
+        hipLaunchKernelGGL(k_ext_live_pack, dim3(grid_of(n, 256)), dim3(256), 0, ctx->stream, d_sdoff, (const meme_alnreg*)A.regs, n, (const i64*)d_loff, (meme_alnreg*)E[16].p);
+        HIP_TRY(hipGetLastError());
+        if (n_out) HIP_TRY(hipMemcpyAsync(Hb[1].p, E[16].p, (size_t)n_out * sizeof(meme_alnreg), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        if ((rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg)))) return rc;
+        HIP_TRY(hipMemcpyAsync(Hb[0].p, d_sdoff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_seeds) HIP_TRY(hipMemcpyAsync(Hb[1].p, A.regs, (size_t)n_seeds * sizeof(meme_alnreg), hipMemcpyDeviceToHost, ctx->stream));
+    }
     unsigned long long h_census[11] = {0};
     if (ctx->ext_census) HIP_TRY(hipMemcpyAsync(h_census, d_census, 11 * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -637,7 +842,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     for (int c = 0; c < 9; ++c) out->census_class[c] = ctx->ext_census ? (int64_t)h_census[2 + c] : -1;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
-    out->nreads = n; out->reg_off = (const int64_t*)Hb[0].p; out->regs = (const meme_alnreg*)Hb[1].p; out->total_regs = n_seeds;
+    out->nreads = n; out->reg_off = (const int64_t*)Hb[0].p; out->regs = (const meme_alnreg*)Hb[1].p; out->total_regs = n_out; out->total_seeds = n_seeds; out->n_ext_seeds = n_seeds_ext;
     out->total_chains = n_chains; out->n_pairs = n_pairs; out->n_retried = n_retried; out->n_bsw_calls = n_calls;
     out->n_flt_jobs = h_flt[1]; out->n_flt_dropped = n_flt_dropped;
     out->n_tier2 = ctx->chain_tier2_reads; out->chain_ms = ctx->tm.chain_kernel_ms; out->ext_ms = ms; out->bsw_ms = bsw_ms;

@@ -60,7 +60,7 @@ class ExtHostResult(C.Structure):
     _fields_ = [("nreads", C.c_int64), ("reg_off", C.c_void_p), ("regs", C.c_void_p), ("total_regs", C.c_int64), ("total_chains", C.c_int64),
                 ("n_pairs", C.c_int64), ("n_retried", C.c_int64), ("n_bsw_calls", C.c_int64), ("n_tier2", C.c_int64), ("chain_ms", C.c_float),
                 ("ext_ms", C.c_float), ("bsw_ms", C.c_float), ("n_flt_jobs", C.c_int64), ("n_flt_dropped", C.c_int64), ("n_exact_prefix", C.c_int64),
-                ("census_band_cells", C.c_int64), ("census_class", C.c_int64 * 9)]
+                ("census_band_cells", C.c_int64), ("census_class", C.c_int64 * 9), ("total_seeds", C.c_int64), ("n_ext_seeds", C.c_int64)]
 
 
 def default_ext_opt(w=100):
@@ -353,7 +353,7 @@ class Context:
                 "n_pairs": int(res.n_pairs), "n_retried": int(res.n_retried), "n_bsw_calls": int(res.n_bsw_calls), "n_tier2": int(res.n_tier2),
                 "chain_ms": float(res.chain_ms), "ext_ms": float(res.ext_ms), "bsw_ms": float(res.bsw_ms),
                 "n_flt_jobs": int(res.n_flt_jobs), "n_flt_dropped": int(res.n_flt_dropped), "n_exact_prefix": int(res.n_exact_prefix),
-                "census_band_cells": int(res.census_band_cells), "census_class": [int(x) for x in res.census_class]}
+                "census_band_cells": int(res.census_band_cells), "census_class": [int(x) for x in res.census_class], "total_seeds": int(res.total_seeds), "n_ext_seeds": int(res.n_ext_seeds)}
 
     def global_batch_host(self, jobs, opt=None):
         """meme_global_batch_host: banded global alignments with traceback (ksw_global2) of query spans of the batch's reads against

@@ -247,7 +247,7 @@ typedef struct {
     int64_t nreads;
     const int64_t* reg_off;          /* nreads+1 */
     const meme_alnreg* regs;
-    int64_t total_regs, total_chains;
+    int64_t total_regs, total_chains;   /* records handed over (= reg_off[nreads]), chains */
     int64_t n_pairs, n_retried, n_bsw_calls;   /* extension jobs run, of which with the doubled band; backend launches */
     int64_t n_tier2;                 /* reads chained by the wavefront-per-read tier */
     float chain_ms, ext_ms, bsw_ms;  /* HIP-event times: chaining kernels; the extension stage (incl. its host round trips); of which banded SW */
@@ -255,6 +255,8 @@ typedef struct {
     int64_t n_exact_prefix;          /* measurement (tuning "ext_census" = 1, else -1): first-attempt jobs whose query equals the first qlen target bases */
     int64_t census_band_cells;       /* ... the DP cells of their band-limited matrices (no trimming, no z-drop: an upper bound of the cells evaluated) */
     int64_t census_class[9];         /* ... jobs per LDS size class of the lane-per-pair kernel (query <= 30, 62, 94, 126, 158, 222, 318, 600 bases), [8]: longer queries */
+    int64_t total_seeds;             /* chained seeds behind the seed filter = records made on the device (== total_regs unless tuning "ext_live_only" is set) */
+    int64_t n_ext_seeds;             /* of them, seeds whose extension jobs ran (== total_seeds unless the stage ran in rounds, tuning "ext_rounds") */
 } meme_ext_host_result;
 int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* chain_opt,
                                 const meme_ext_opt* ext_opt, meme_ext_host_result* out);
@@ -376,7 +378,7 @@ typedef struct {
     int64_t seed_lane_searches;   /* searches k_reseed did itself, one lane each (what the table cannot answer) */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "seed_early_tier" (0: overflow tiers strictly behind the re-seeding kernels), "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY) */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "seed_early_tier" (0: overflow tiers strictly behind the re-seeding kernels), "ext_live_only" (1: meme_extend_last_batch_host hands over only the records mem_kernel2_core keeps, src/bwamem.cpp:1680-1693 -- qe > qb, in order -- instead of one per chained seed with the purged ones marked; the stage then also runs in rounds -- "ext_rounds" (default 2; 0: off): a read's seeds are taken in extension order, tested against the read's surviving alignments first and extended only if they survive, one seed per read and round, after that many rounds everything still ahead at once: the same surviving records, without the banded SW of seeds the purge drops), "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY) */
 
 #ifdef __cplusplus
 }

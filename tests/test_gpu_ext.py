@@ -12,13 +12,17 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
-def _device_records(tmp_path, I, ext_opt=None, ascii=False, chain_opt=None):
+def _device_records(tmp_path, I, ext_opt=None, ascii=False, chain_opt=None, live_only=False, rounds=None):
     fa = str(tmp_path / "c.fa")
     synth.write_fasta(fa, I["genome"], name="cg", contigs=3)
     prefix = build_index(fa, bits=14)
     ctx = hipapi.Context(0)
     try:
         ctx.load_index_files(prefix)
+        if live_only:
+            ctx.set_tuning("ext_live_only", 1)
+        if rounds is not None:
+            ctx.set_tuning("ext_rounds", rounds)
         if ascii:       # the reads as FASTQ letters (mixed case, N and other IUPAC letters for ambiguous bases): converted on the device
             letters = np.frombuffer(b"ACGTN", np.uint8)[np.minimum(I["reads"], 4)].copy()
             rng = np.random.default_rng(3)
@@ -55,6 +59,33 @@ def test_device_records_equal_reference_golden(tmp_path):
     assert int(purged.sum()) == int(((G["regs"][:, 2] == -1) & (G["regs"][:, 3] == -1)).sum()) > 5000
 
 
+def _live_of(reg_off, qb, qe):
+    """what mem_kernel2_core keeps of the stage's records (src/bwamem.cpp:1680-1693): the mask and the offsets of the kept ones"""
+    keep = np.asarray(qe) > np.asarray(qb)
+    cs = np.concatenate([[0], np.cumsum(keep.astype(np.int64))])
+    return keep, cs[np.asarray(reg_off)]
+
+
+@pytest.mark.parametrize("rounds", [0, 1, 2, 6])
+def test_live_only_hand_over_is_the_golden_records_minus_the_purged_ones(tmp_path, rounds):
+    """Tuning "ext_live_only": the compaction mem_kernel2_core runs first on the stage's records (src/bwamem.cpp:1680-1693: qe > qb kept,
+    order kept) done on the device -- what the bound aligner asks for, so that purged records do not cross to the host.  With "ext_rounds" > 0
+    the stage also stops extending seeds the purge drops (extension in rounds, k_ext_advance): the surviving records are the compiled reference's."""
+    I = ext_golden_inputs()
+    G = np.load(os.path.join(GOLDEN, "ext_golden.npz"))
+    R = _device_records(tmp_path, I, live_only=True, rounds=rounds)
+    keep, want_off = _live_of(G["reg_off"], G["regs"][:, 2], G["regs"][:, 3])
+    assert 0 < int(keep.sum()) < keep.shape[0] and R["total_seeds"] == keep.shape[0]
+    assert np.array_equal(R["reg_off"], want_off)
+    _assert_same(R["regs"], G["regs"][keep], G["frac_rep_bits"][keep])
+    if rounds == 0:
+        assert R["n_ext_seeds"] == keep.shape[0]
+    else:
+        assert int(keep.sum()) <= R["n_ext_seeds"] < keep.shape[0]          # fewer seeds extended than chained, at least the survivors
+    if rounds == 6:
+        assert R["n_ext_seeds"] < 0.62 * keep.shape[0]
+
+
 def test_reads_as_fastq_letters_give_the_same_records(tmp_path):
     """meme_seed_batch_resident_ascii: the base-code conversion of mem_kernel1_core_Learned (src/bwamem.cpp:1277-1279) on the device."""
     I = ext_golden_inputs()
@@ -78,6 +109,10 @@ def test_device_records_equal_oracle_with_other_options(tmp_path, w, clip, zdrop
                              I["contig_off"], I["contig_len"], oo)
     assert np.array_equal(R["reg_off"], I["seed_off"])
     _assert_same(R["regs"], want, want["frac_rep"].view(np.uint32))
+    keep, want_off = _live_of(I["seed_off"], want["qb"], want["qe"])        # ... and in rounds: the survivors only
+    R2 = _device_records(tmp_path, I, eo, live_only=True, rounds=2)
+    assert np.array_equal(R2["reg_off"], want_off)
+    _assert_same(R2["regs"], want[keep], want["frac_rep"].view(np.uint32)[keep])
 
 
 @pytest.mark.parametrize("W,penalties", [(5, None), (10, None), (20, None), (20, (2, 9, 3, 2, 5, 1))])
@@ -104,6 +139,10 @@ def test_seed_filter_on_the_device_equals_oracle(tmp_path, W, penalties):
     _assert_same(R["regs"], want, want["frac_rep"].view(np.uint32))
     assert R["n_flt_jobs"] == n_sw > 500 and R["n_flt_dropped"] == int(I["seed_off"][-1] - soff[-1])
     assert W < 20 or R["n_flt_dropped"] > 0
+    keep, want_off = _live_of(soff, want["qb"], want["qe"])                 # the same behind the filter in rounds (seed scores decide the order)
+    R2 = _device_records(tmp_path, I, eo, chain_opt=co, live_only=True, rounds=1)
+    assert np.array_equal(R2["reg_off"], want_off) and R2["n_flt_dropped"] == R["n_flt_dropped"] and R2["total_seeds"] == int(soff[-1])
+    _assert_same(R2["regs"], want[keep], want["frac_rep"].view(np.uint32)[keep])
 
 
 def test_seed_filter_is_off_for_short_reads(tmp_path):
