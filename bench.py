@@ -277,6 +277,15 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
     ctx.set_tuning("ext_live_only", 1)
     RL = ctx.extend_last_batch_host(contigs, copt)
     RL = ctx.extend_last_batch_host(contigs, copt)
+    sweep = {}
+    for t in [int(x) for x in os.environ.get("MEME_BENCH_EXT_ROUNDS", "").split(",") if x]:        # (probe: other numbers of one-seed rounds)
+        ctx.set_tuning("ext_rounds", t)
+        ctx.extend_last_batch_host(contigs, copt)
+        X = ctx.extend_last_batch_host(contigs, copt)
+        sweep[str(t)] = {"ext_ms": X["ext_ms"], "bsw_ms": X["bsw_ms"], "extension_jobs": X["n_pairs"], "seeds_extended": X["n_ext_seeds"], "bsw_launches": X["n_bsw_calls"],
+                         "same_records": X["regs"].tobytes() == RL["regs"].tobytes()}
+    if sweep:
+        ctx.set_tuning("ext_rounds", 1)
     ctx.set_tuning("ext_live_only", 0)
     keep = R["regs"]["qe"] > R["regs"]["qb"]
     same_l = same and np.array_equal(RL["reg_off"], np.concatenate([[0], np.cumsum(keep.astype(np.int64))])[R["reg_off"]]) and RL["regs"].tobytes() == R["regs"][keep].tobytes()
@@ -284,7 +293,7 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
     out["in_rounds"] = {"value": n / ((RL["chain_ms"] + RL["ext_ms"]) * 1e-3) if same_l else None, "chain_ms": RL["chain_ms"], "ext_ms": RL["ext_ms"], "bsw_ms": RL["bsw_ms"],
                         "extension_jobs": RL["n_pairs"], "jobs_with_doubled_band": RL["n_retried"], "bsw_launches": RL["n_bsw_calls"], "chained_seeds": RL["total_seeds"],
                         "seeds_extended": RL["n_ext_seeds"], "records_handed_to_the_host": int(RL["regs"].shape[0]),
-                        "equals_the_checked_records_minus_the_purged_ones": bool(same_l)}
+                        "equals_the_checked_records_minus_the_purged_ones": bool(same_l)} | ({"other_round_counts": sweep} if sweep else {})
     if same_l:
         out["value"] = out["in_rounds"]["value"]
         out["what"] = "chaining + extension in rounds (surviving records only), as the bound aligner calls the stage; all_seeds_at_once = the reference's batch order, every record checked"

@@ -67,11 +67,11 @@ __device__ inline void seedcov(meme_alnreg* a, const meme_chain_seed* sd, int n)
 }
 
 template <bool WRITE>
-__global__ void __launch_bounds__(64) k_ext_jobs(ExtArgs A) {
-    const i64 rl = blockIdx.x;                       // read of the slab
+__global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
+    const i64 rl = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);      // read of the slab: a wavefront each, four to a workgroup (2 M one-wave workgroups take 4 ms to dispatch)
     if (rl >= A.ns) return;
     const i64 r = A.g0 + rl;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const i64 c0 = A.chain_off[r];
     const int nc = (int)(A.chain_off[r + 1] - c0);
     const i64 s0 = A.seed_off[r];
@@ -369,10 +369,10 @@ struct PurgeArgs {
 };
 
 // (:3389-3485) in the order the one-read-at-a-time aligner would have met the seeds: chain after chain, best seed first
-__global__ void __launch_bounds__(64) k_ext_purge(PurgeArgs P) {
-    const i64 r = blockIdx.x;
+__global__ void __launch_bounds__(256) k_ext_purge(PurgeArgs P) {
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= P.nreads) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const i64 c0 = P.chain_off[r];
     const int nc = (int)(P.chain_off[r + 1] - c0);
     const i64 s0 = P.seed_off[r];
@@ -444,18 +444,27 @@ __global__ void __launch_bounds__(64) k_ext_purge(PurgeArgs P) {
 // from the next survivor on is selected at once (ADV_REST: repeat-rich reads have tens of survivors, one round each would be launches without work) and
 // ADV_FINISH walks to the end over alignments that then all exist -- which is the reference's own pass from that point on.
 enum { ADV_ONE = 0, ADV_REST = 1, ADV_FINISH = 2 };
-struct AdvArgs { PurgeArgs P; int4* state; uint8_t* sel; uint8_t* act; unsigned long long* n_sel; int mode; };
+struct AdvArgs {
+    PurgeArgs P; int4* state; uint8_t* sel; uint8_t* act; i64* cntS; int mode;     // cntS: seeds selected per read (summed by a scan: an atomic per read on one address costs 12 ns each)
+    const i64* rmax; i64 *cntL, *cntR, *cntB;        // the round's plan as k_ext_jobs<false> would count it: left / right jobs and sequence bytes of the read's selected seeds
+};
+// jobs and bytes of one selected seed (the arithmetic of k_ext_jobs)
+__device__ __forceinline__ void adv_count(const meme_chain_seed& t, i64 rmax0, i64 rmax1, int l_query, i64& nL, i64& nR, i64& nB) {
+    const int qe = t.qbeg + t.len;
+    if (t.qbeg > 0) { ++nL; nB += pad4((int)(t.rbeg - rmax0)) + pad4(t.qbeg); }
+    if (qe != l_query) { ++nR; nB += pad4((int)(rmax1 - (t.rbeg + t.len))) + pad4(l_query - qe); }
+}
 
-__global__ void __launch_bounds__(64) k_ext_advance(AdvArgs V) {
+__global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
     const PurgeArgs& P = V.P;
-    const i64 r = blockIdx.x;
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= P.nreads) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const i64 c0 = P.chain_off[r];
     const int nc = (int)(P.chain_off[r + 1] - c0);
     const i64 s0 = P.seed_off[r];
     int4 st = V.state[r];                              // x chain, y rank of the next seed in it (-1: the chain is done), z seeds met so far
-    if (V.mode != ADV_FINISH && lane == 0) V.act[r] = 0;
+    if (V.mode != ADV_FINISH && lane == 0) { V.act[r] = 0; V.cntL[r] = 0; V.cntR[r] = 0; V.cntB[r] = 0; V.cntS[r] = 0; }
     if (st.x >= nc) return;
     const int l_query = (int)(P.read_off[r + 1] - P.read_off[r]);
     meme_alnreg* av = P.regs + s0;
@@ -514,21 +523,31 @@ __global__ void __launch_bounds__(64) k_ext_advance(AdvArgs V) {
             if (V.mode == ADV_FINISH) continue;        // a survivor whose alignment exists
             if (V.mode == ADV_REST) {                  // this survivor and everything behind it go into the round; ADV_FINISH walks on from here
                 unsigned long long cnt = 0;
+                i64 nL = 0, nR = 0, nB = 0;
                 for (int c2 = c; c2 < nc; ++c2) {
                     const meme_chain ch2 = P.chains[c0 + c2];
                     const int* ord2 = P.order + s0 + ch2.seed_beg;
                     const int k1 = c2 == c ? k : ch2.n_seeds - 1;
-                    for (int k2 = k1 - lane; k2 >= 0; k2 -= 64) V.sel[s0 + ch2.seed_beg + ord2[k2]] = 1;
+                    const i64 rmax0 = V.rmax[2 * (c0 + c2)], rmax1 = V.rmax[2 * (c0 + c2) + 1];
+                    for (int k2 = k1 - lane; k2 >= 0; k2 -= 64) {
+                        const int il = ord2[k2];
+                        V.sel[s0 + ch2.seed_beg + il] = 1;
+                        adv_count(P.seeds[s0 + ch2.seed_beg + il], rmax0, rmax1, l_query, nL, nR, nB);
+                    }
                     cnt += k1 + 1;
                 }
-                if (lane == 0) { V.act[r] = 1; V.state[r] = make_int4(c, k, cur, 0); atomicAdd(V.n_sel, cnt); }
+                for (int d = 32; d >= 1; d >>= 1) { nL += __shfl_xor(nL, d); nR += __shfl_xor(nR, d); nB += __shfl_xor(nB, d); }
+                if (lane == 0) { V.act[r] = 1; V.state[r] = make_int4(c, k, cur, 0); V.cntS[r] = (i64)cnt; V.cntL[r] = nL; V.cntR[r] = nR; V.cntB[r] = nB; }
                 return;
             }
             if (lane == 0) {                           // this round's seed of the read
                 V.sel[s0 + ch.seed_beg + ord[k]] = 1;
                 V.act[r] = 1;
                 V.state[r] = make_int4(c, k - 1, cur + 1, 0);
-                atomicAdd(V.n_sel, 1ull);
+                V.cntS[r] = 1;
+                i64 nL = 0, nR = 0, nB = 0;
+                adv_count(s, V.rmax[2 * (c0 + c)], V.rmax[2 * (c0 + c) + 1], l_query, nL, nR, nB);
+                V.cntL[r] = nL; V.cntR[r] = nR; V.cntB[r] = nB;
             }
             return;
         }
@@ -664,7 +683,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
         } else flt = false;
     }
     if ((rc = meme_buf_reserve(ctx, E[0], (size_t)(n_chains + 1) * 16)) || (rc = meme_buf_reserve(ctx, E[1], (size_t)(n_seeds + 1) * sizeof(meme_alnreg))) ||
-        (rc = meme_buf_reserve(ctx, E[2], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[3], (size_t)(n + 1) * 8 * 6))) return rc;
+        (rc = meme_buf_reserve(ctx, E[2], (size_t)(n_seeds + 1) * 4)) || (rc = meme_buf_reserve(ctx, E[3], (size_t)(n + 1) * 8 * 8))) return rc;
     ExtArgs A;
     memset(&A, 0, sizeof(A));
     A.reads = (const uint8_t*)ctx->reads.p; A.read_off = (const i64*)ctx->read_off.p; A.g0 = 0; A.ns = n;
@@ -683,7 +702,8 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     bl.end_bonus = eopt->pen_clip5;                   // bswLeft / bswRight, src/bwamem.cpp:2953-2959
     br.end_bonus = eopt->pen_clip3;
     unsigned long long* d_nretry = (unsigned long long*)E[8].p;
-    unsigned long long* d_nsel = (unsigned long long*)E[8].p + 1;
+    i64* d_cntS = d_cnt + 6 * (n + 1);              // seeds selected per read in a round, and its scan
+    i64* d_offS = d_cnt + 7 * (n + 1);
     unsigned long long* d_census = (unsigned long long*)E[8].p + 8;
     if (ctx->ext_census) HIP_TRY(hipMemsetAsync(d_census, 0, 11 * 8, ctx->stream));
     i64 n_pairs = 0, n_retried = 0, n_calls = 0;
@@ -693,13 +713,16 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     std::vector<i64> h_off;
     // ---- the jobs of the seeds `A.mode` / `A.sel` name: plan (job and byte counts of every read, their scans), sequences, banded SW left then right
     // with the band doubled once where the reference doubles it, results folded into the records.  *n_sel_out: what k_ext_advance selected for this round.
-    auto run_jobs = [&](unsigned long long* n_sel_out) -> int {
+    auto run_jobs = [&](i64* n_sel_out) -> int {
         int rc;
-        hipLaunchKernelGGL((k_ext_jobs<false>), dim3((unsigned)n), dim3(64), 0, ctx->stream, A);
+        if (A.mode != 2) hipLaunchKernelGGL((k_ext_jobs<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, A);      // (in rounds k_ext_advance has counted)
         for (int k = 0; k < 3; ++k) if ((rc = meme_scan_exclusive(ctx, d_cnt + k * (n + 1), d_off + k * (n + 1), n))) return rc;
         i64 tot3[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(&tot3[k], d_off + k * (n + 1) + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (n_sel_out) HIP_TRY(hipMemcpyAsync(n_sel_out, d_nsel, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_sel_out) {
+            if ((rc = meme_scan_exclusive(ctx, d_cntS, d_offS, n))) return rc;
+            HIP_TRY(hipMemcpyAsync(n_sel_out, d_offS + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
         if (!flt_read) {
             HIP_TRY(hipMemcpyAsync(&h_flt[0], d_sdoff + n, 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync(&h_flt[1], d_fltcnt, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -741,7 +764,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
             S.offL = d_off + g0; S.offR = d_off + (n + 1) + g0; S.offB = d_off + 2 * (n + 1) + g0;
             S.job0L = j0L; S.job0R = j0R; S.byte0 = b0;
             S.L = (meme_seqpair*)E[4].p; S.R = (meme_seqpair*)E[5].p; S.seq = (uint8_t*)E[7].p;
-            hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)(g1 - g0)), dim3(64), 0, ctx->stream, S);
+            hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)((g1 - g0 + 3) / 4)), dim3(256), 0, ctx->stream, S);
             HIP_TRY(hipGetLastError());
             if (ctx->ext_census) {
                 if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, eopt->w, d_census);
@@ -784,30 +807,30 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
         // ---- the reference's batch: every chained seed extended, then the purge
         A.mode = 0;
         if ((rc = run_jobs(nullptr))) return rc;
-        hipLaunchKernelGGL(k_ext_purge, dim3((unsigned)n), dim3(64), 0, ctx->stream, P);
+        hipLaunchKernelGGL(k_ext_purge, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, P);
         HIP_TRY(hipGetLastError());
         n_seeds_ext = h_flt[0];
     } else {
         // ---- in rounds (see k_ext_advance): records + extension order first, then `rounds` rounds of one seed per read, one round with everything still ahead
         if ((rc = meme_buf_reserve(ctx, E[17], (size_t)(n + 1) * 16 + (size_t)(n + 1) + (size_t)n_seeds + 64))) return rc;
         AdvArgs V;
-        V.P = P; V.state = (int4*)E[17].p; V.act = (uint8_t*)(V.state + (n + 1)); V.sel = V.act + (n + 1); V.n_sel = d_nsel;
+        V.P = P; V.state = (int4*)E[17].p; V.act = (uint8_t*)(V.state + (n + 1)); V.sel = V.act + (n + 1); V.cntS = d_cntS;
+        V.rmax = A.rmax; V.cntL = A.cntL; V.cntR = A.cntR; V.cntB = A.cntB;
         A.mode = 1; A.state = V.state;
-        hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)n), dim3(64), 0, ctx->stream, A);
+        hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, A);
         A.sel = V.sel; A.act = V.act;
         for (i64 t = 0; t <= rounds; ++t) {
             HIP_TRY(hipMemsetAsync(V.sel, 0, (size_t)n_seeds, ctx->stream));
-            HIP_TRY(hipMemsetAsync(d_nsel, 0, 8, ctx->stream));
             V.mode = t < rounds ? ADV_ONE : ADV_REST;
-            hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)n), dim3(64), 0, ctx->stream, V);
+            hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, V);
             A.mode = 2;
-            unsigned long long h_sel = 0;
+            i64 h_sel = 0;
             if ((rc = run_jobs(&h_sel))) return rc;
-            n_seeds_ext += (i64)h_sel;
+            n_seeds_ext += h_sel;
             if (h_sel == 0) break;                      // every read has been walked to its end
         }
         V.mode = ADV_FINISH;
-        hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)n), dim3(64), 0, ctx->stream, V);
+        hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, V);
         HIP_TRY(hipGetLastError());
     }
     const i64 n_flt_dropped = n_seeds - h_flt[0];

@@ -54,10 +54,10 @@ __device__ long long ref_len(int n_cigar, const uint8_t* cg) {      // get_rlen
     return l;
 }
 
-__global__ void __launch_bounds__(64) k_sam_format(SamArgs A) {
-    const i64 k = blockIdx.x;
+__global__ void __launch_bounds__(256) k_sam_format(SamArgs A) {
+    const i64 k = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);         // a wavefront per record, four to a workgroup (one-wave workgroups are dispatch-bound)
     if (k >= A.nrecs) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const meme_sam_rec R = A.recs[k];
     if (R.read < 0) { if (lane == 0) A.len[k] = 0; return; }        // an empty slot (the caller submits one per read, in read order)
     char* o = A.scratch + A.soff[k];
@@ -204,13 +204,13 @@ __global__ void __launch_bounds__(256) k_sam_bounds(const meme_sam_rec* __restri
         bound[k] = (b + 15) & ~(i64)15;
     }
 }
-__global__ void __launch_bounds__(64) k_sam_pack(const i64* __restrict__ soff, const char* __restrict__ scratch, const i64* __restrict__ toff, i64 n, char* __restrict__ out) {
-    const i64 k = blockIdx.x;
+__global__ void __launch_bounds__(256) k_sam_pack(const i64* __restrict__ soff, const char* __restrict__ scratch, const i64* __restrict__ toff, i64 n, char* __restrict__ out) {
+    const i64 k = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n) return;
     const i64 l = toff[k + 1] - toff[k];
     const char* src = scratch + soff[k];
     char* dst = out + toff[k];
-    for (i64 i = threadIdx.x; i < l; i += 64) dst[i] = src[i];
+    for (i64 i = threadIdx.x & 63; i < l; i += 64) dst[i] = src[i];
 }
 
 unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
@@ -311,13 +311,13 @@ extern "C" int meme_sam_format_batch_host(meme_ctx* ctx, const meme_sam_rec* rec
     A.contig_name_off = (const int32_t*)d_tab; A.contig_names = d_tab + off_bytes; A.softclip = softclip ? 1 : 0;
     A.rg = d_tab + off_bytes + contig_name_off[n_contigs]; A.rg_len = rg_len;
     A.soff = d_soff; A.scratch = (char*)S[6].p; A.len = d_len;
-    hipLaunchKernelGGL(k_sam_format, dim3((unsigned)nrecs), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_sam_format, dim3((unsigned)((nrecs + 3) / 4)), dim3(256), 0, ctx->stream, A);
     if ((rc = meme_scan_exclusive(ctx, d_len, d_toff, nrecs))) return rc;
     i64 total = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_toff + nrecs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if ((rc = meme_buf_reserve(ctx, S[7], (size_t)total + 64))) return rc;
-    hipLaunchKernelGGL(k_sam_pack, dim3((unsigned)nrecs), dim3(64), 0, ctx->stream, (const i64*)d_soff, (const char*)S[6].p, (const i64*)d_toff, (i64)nrecs, (char*)S[7].p);
+    hipLaunchKernelGGL(k_sam_pack, dim3((unsigned)((nrecs + 3) / 4)), dim3(256), 0, ctx->stream, (const i64*)d_soff, (const char*)S[6].p, (const i64*)d_toff, (i64)nrecs, (char*)S[7].p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev_sam[1], ctx->stream));
     meme_ctx::HostBuf* Hb = ctx->h_sam;
