@@ -430,7 +430,15 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
         const double t0 = now_s();
         int rc = run_piece(0, P.count, &P.ext);
         if (rc == MEME_E_CAPACITY) {
-            fprintf(stderr, "[meme-dropin] the backend cannot take %lld reads at once (%s): in pieces\n", (long long)P.count, meme_last_error());
+            // (said twice, not per chunk: the first time with the backend's reason, and once more when it turns out to be the run's normal state --
+            // a card with too little free HBM beside the index and the second slot's ctx runs every chunk this way, CIGAR stage on the host included)
+            static std::atomic<int> n_pieces{0};
+            const int seen = ++n_pieces;
+            if (seen == 1)
+                fprintf(stderr, "[meme-dropin] the backend cannot take %lld reads at once (%s): in pieces\n", (long long)P.count, meme_last_error());
+            else if (seen == 4)
+                fprintf(stderr, "[meme-dropin] chunks keep running in pieces (%d so far): the device has too little free memory beside the index for a whole -K chunk; "
+                                "a smaller -K, or MEME_DROPIN_PREFETCH=0 (one seeding ctx per GPU instead of two), avoids the split\n", seen);
             P.own_regs.clear(); P.own_reg_off.assign(1, 0);
             meme_ext_host_result tot;
             memset(&tot, 0, sizeof(tot));
