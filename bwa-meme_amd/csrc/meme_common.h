@@ -84,6 +84,7 @@ struct meme_ctx {
     i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched
     i64 chain_light_hits = 32;         // reads with more hits to walk skip the lane-per-read tier: LDS tier at once, beside it
     i64 chain_lane_hits = 256;         // hits per read the lane-per-read chaining tier walks; reads with more go to the wavefront tiers at once
+    i64 chain_side_priority = 0;       // 1: the side streams of the routed chaining tiers are created with the highest stream priority (set before the first chaining call)
     i64 chain_wave_tiers = 1;          // 0: the chaining stage skips the LDS tier (everything beyond the lane tier through the B-tree tier; tests)
     i64 bsw_blocks = 0;
     i64 bsw_lane_min_pairs = 32768;   // batches at least this big use the lane-per-pair kernel (throughput); smaller ones the

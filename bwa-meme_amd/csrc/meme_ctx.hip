@@ -157,6 +157,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "bsw_blocks")) ctx->bsw_blocks = value;
     else if (!strcmp(key, "bsw_lane_min_pairs")) ctx->bsw_lane_min_pairs = value;
     else if (!strcmp(key, "chain_wave_tiers")) ctx->chain_wave_tiers = value;
+    else if (!strcmp(key, "chain_side_priority")) ctx->chain_side_priority = value;
     else if (!strcmp(key, "chain_lane_hits")) ctx->chain_lane_hits = value;
     else if (!strcmp(key, "chain_light_hits")) ctx->chain_light_hits = value;
     else if (!strcmp(key, "group_lanes")) {

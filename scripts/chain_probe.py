@@ -27,6 +27,7 @@ contigs = [(l_pac * k // 8, l_pac * (k + 1) // 8 - l_pac * k // 8, 0) for k in r
 opt = hipapi.default_chain_opt(l_pac)
 if os.environ.get("CHAIN_LIGHT_HITS"): ctx.set_tuning("chain_light_hits", int(os.environ["CHAIN_LIGHT_HITS"]))
 if os.environ.get("CHAIN_WAVE_TIERS"): ctx.set_tuning("chain_wave_tiers", int(os.environ["CHAIN_WAVE_TIERS"]))
+if os.environ.get("CHAIN_SIDE_PRIORITY"): ctx.set_tuning("chain_side_priority", int(os.environ["CHAIN_SIDE_PRIORITY"]))
 for it in range(3 if not os.environ.get("CHAIN_LANE_HITS") else 1):
     t0 = time.time(); smems, so, hits, ho = ctx.seed_batch_host(reads.reshape(-1), off); t1 = time.time()
     res = ctx.chain_last_batch_host(contigs, opt); t2 = time.time()
@@ -70,3 +71,11 @@ for cap in [int(x) for x in os.environ.get("CHAIN_LANE_HITS", "").split(",") if 
     tm = ctx.timings()
     print("[chain probe] lane tier walks <= %d hits: chain kernels %.2f ms, wavefront tiers %.2f ms (%d reads), B-tree tier %.2f ms (%d reads)"
           % (cap, tm.chain_kernel_ms, tm.chain_pass2_ms, tm.chain_tier2_reads, tm.chain_tier3_ms, tm.chain_tier3_reads))
+
+for lh in [int(x) for x in os.environ.get("CHAIN_LIGHT_SWEEP", "").split(",") if x]:
+    ctx.set_tuning("chain_light_hits", lh)
+    for _ in range(3):
+        res = ctx.chain_last_batch_host(contigs, opt)
+    tm = ctx.timings()
+    print("[chain probe] reads with more than %d hits skip the lane tier: chain kernels %.2f ms, after the lane tier %.2f ms (%d reads in the wavefront tiers)"
+          % (lh, tm.chain_kernel_ms, tm.chain_pass2_ms, tm.chain_tier2_reads))
