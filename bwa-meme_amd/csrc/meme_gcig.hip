@@ -28,6 +28,7 @@ struct GcigArgs {
     // bwa_gen_cigar2 whole (meme_gen_cigar_batch_host): NM and the MD string of every job; null for the plain ksw_global2 call
     const i64* mdoff; char* md;              // MD scratch: 2 * (qlen + tlen) + 16 bytes per job
     int32_t* nm; int32_t* mdlen;
+    int zcap;                                // backtrack matrices of at most this many bytes stay in LDS (0: all in global memory)
     const i64* dp_list;                      // jobs that need the kernel below (the rest were answered by k_gcig_nogap), or null: all
     const u64* packed; int pW, pMW, pstride; // the batch's packed reads (2 bits per base + N masks, k_pack_reads): what k_gcig_nogap compares
 };
@@ -45,8 +46,11 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     int* hB = hA + (qlen + 2);
     int* eE = hB + (qlen + 2);
     uint8_t* qs = reinterpret_cast<uint8_t*>(eE + (qlen + 2));
+    uint8_t* ts = qs + ((qlen + 3) & ~3);    // the target bases in row order: a row must not wait for a load from the text (1-2 us each, 250 in a row)
+    uint8_t* zl = ts + ((tlen + 3) & ~3);    // the backtrack matrix, when it fits (A.zcap bytes): the walk back is one dependent load per step
     const uint8_t* rd = A.reads + A.read_off[J.read] + J.qb;
     for (int j = lane; j < qlen; j += 64) qs[j] = J.rev ? rd[qlen - 1 - j] : rd[j];
+    if (w >= 0) for (int i = lane; i < tlen; i += 64) ts[i] = (uint8_t)text_base(A.pac, J.rev ? J.rb + tlen - 1 - i : J.rb + i);
     uint32_t* cg = A.cig + A.coff[jb];
     const int cap = qlen + tlen + 2;
     int n = 0;                               // operations so far; cg[cap - 1 - k] = k-th pushed
@@ -66,7 +70,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     } else {
     const int oe_del = A.o.o_del + A.o.e_del, oe_ins = A.o.o_ins + A.o.e_ins, e_del = A.o.e_del, e_ins = A.o.e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    uint8_t* z = A.z + A.zoff[jb];
+    uint8_t* z = (i64)n_col * tlen <= A.zcap ? zl : A.z + A.zoff[jb];
     // first row (src/ksw.cpp:591-595)
     for (int j = lane; j <= qlen; j += 64) {
         hA[j] = j == 0 ? 0 : (j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF);
@@ -76,7 +80,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     int* hp = hA;                            // H(i-1, j-1) at [j]
     int* hn = hB;
     for (int i = 0; i < tlen; ++i) {
-        const int tb = text_base(A.pac, J.rev ? J.rb + tlen - 1 - i : J.rb + i);
+        const int tb = ts[i];
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
         int f_in = MINUS_INF;                                         // F(i, first column of the chunk)
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
                 const int i = i0 + lane;
                 const bool in = i < l;
                 int tb = 0, qb = 0;
-                if (in) { tb = text_base(A.pac, J.rev ? J.rb + tlen - 1 - (y + i) : J.rb + y + i); qb = qs[x + i]; }
+                if (in) { tb = w >= 0 ? (int)ts[y + i] : text_base(A.pac, J.rev ? J.rb + tlen - 1 - (y + i) : J.rb + y + i); qb = qs[x + i]; }
                 unsigned long long mask = __ballot(in && tb != qb);
                 int pos0 = 0;
                 while (mask) {
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
                 put_num(u);
                 if (lane == 0) out[len] = '^';
                 ++len;
-                for (int i = lane; i < l; i += 64) out[len + i] = b2c[text_base(A.pac, J.rev ? J.rb + tlen - 1 - (y + i) : J.rb + y + i)];
+                for (int i = lane; i < l; i += 64) out[len + i] = b2c[w >= 0 ? (int)ts[y + i] : text_base(A.pac, J.rev ? J.rb + tlen - 1 - (y + i) : J.rb + y + i)];
                 len += l; u = 0; n_gap += l;
             }
             y += l;
@@ -281,13 +285,13 @@ __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__
         for (int k = 0; k < R.n_cigar; ++k) dst[k] = src[k];
     }
 }
-__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, i64* __restrict__ zsz,
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, i64* __restrict__ zsz,
                                                      i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         const meme_gjob J = jobs[jb];
         isdp[jb] = !(fast && nogap_fast(J, read_off));                       // 1: the job goes to k_gcig
         const i64 n_col = J.qlen < 2 * J.w + 1 ? J.qlen : 2 * J.w + 1;
-        zsz[jb] = J.w < 0 ? 0 : (n_col * J.tlen + 15) & ~(i64)15;           // (w < 0: the gap-free shortcut, no matrix)
+        zsz[jb] = J.w < 0 || n_col * J.tlen <= zcap ? 0 : (n_col * J.tlen + 15) & ~(i64)15;   // (w < 0: the gap-free shortcut, no matrix; small matrices stay in LDS)
         csz[jb] = J.qlen + J.tlen + 2;
         if (msz) msz[jb] = 2 * ((i64)J.qlen + J.tlen) + 16;                // an MD string never has more than two characters per base
     }
@@ -354,8 +358,11 @@ unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i6
 // The batch from the jobs in G[0] (device) to packed results: scratch sizes, the alignment kernel, the packed operations (and MD strings).
 // with_md: NM + MD of every job (meme_gen_cigar_batch_host); host_jobs (may be null) only serves the error message of a bad query span.
 struct GcigRun { i64 tops = 0, tmd = 0; };
-int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool with_md, const char* who, GcigRun* out) {
+constexpr int Z_LDS_CAP = 8192;             // a 250-row matrix of up to 32 band columns: the bands bwa_gen_cigar2 computes for reads with a few small indels
+int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* opt, bool with_md, const char* who, GcigRun* out) {
     int rc;
+    const size_t lds_base = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3) + (size_t)((tmax + 3) & ~3);
+    const int zcap = lds_base + Z_LDS_CAP <= 32 * 1024 ? Z_LDS_CAP : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
     if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 13 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     i64* d_zsz = (i64*)G[1].p;
@@ -377,7 +384,7 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool w
     const int pW = (int)((ctx->last_seed_max_len + 31) / 32) + 2, pMW = (int)((ctx->last_seed_max_len + 63) / 64);      // PackGeom of that batch (meme_seed.hip)
     HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
-    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, d_zsz, d_csz,
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, d_zsz, d_csz,
                        with_md ? d_msz : (i64*)nullptr, d_isdp);
     if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs)) || (rc = meme_scan_exclusive(ctx, d_isdp, d_dpoff, njobs))) return rc;
     hipLaunchKernelGGL(k_gcig_dplist, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const i64*)d_isdp, (const i64*)d_dpoff, (i64)njobs, d_dplist);
@@ -410,12 +417,12 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, const meme_bsw_opt* opt, bool w
     A.o = *opt; A.zoff = d_zoff; A.z = (uint8_t*)G[2].p; A.coff = d_coff; A.cig = (uint32_t*)G[3].p; A.res = (meme_gres*)G[4].p;
     A.mdoff = d_moff; A.md = with_md ? (char*)G[6].p : nullptr;
     A.nm = with_md ? (int32_t*)G[7].p : nullptr; A.mdlen = with_md ? (int32_t*)G[7].p + njobs : nullptr;
-    A.dp_list = nullptr; A.packed = (const u64*)ctx->packed.p; A.pW = pW; A.pMW = pMW; A.pstride = 2 * pW + 2 * pMW + 1;
+    A.zcap = zcap; A.dp_list = nullptr; A.packed = (const u64*)ctx->packed.p; A.pW = pW; A.pMW = pMW; A.pstride = 2 * pW + 2 * pMW + 1;
     if (ndp < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
     if (ndp > 0) {
         GcigArgs D = A;
         D.dp_list = d_dplist; D.njobs = ndp;
-        const size_t lds = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3);
+        const size_t lds = lds_base + (size_t)zcap;
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_gcig, dim3((unsigned)ndp), dim3(64), lds, ctx->stream, D);
     }
@@ -465,7 +472,7 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
     memset(out, 0, sizeof(*out));
     if (njobs == 0) return MEME_OK;
     const i64 nreads = ctx->last_seed_reads;
-    int qmax = 0;
+    int qmax = 0, tmax = 0;
     for (i64 k = 0; k < njobs; ++k) {
         const meme_gjob& J = jobs[k];
         // (the band must reach the matrix's last cell, w >= |tlen - qlen|, as every band bwa_gen_cigar2 computes does, src/bwa.cpp:306-316:
@@ -476,13 +483,14 @@ extern "C" int meme_global_batch_host(meme_ctx* ctx, const meme_gjob* jobs, int6
             return MEME_E_ARG;
         }
         qmax = J.qlen > qmax ? J.qlen : qmax;
+        tmax = J.tlen > tmax ? J.tlen : tmax;
     }
     DevBuf* G = ctx->gcig;
     if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob)))) return rc;
     HIP_TRY(hipMemcpyAsync(G[0].p, jobs, (size_t)njobs * sizeof(meme_gjob), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_gcig[0], ctx->stream));
     GcigRun R;
-    if ((rc = gcig_run(ctx, njobs, qmax, opt, false, who, &R))) return rc;
+    if ((rc = gcig_run(ctx, njobs, qmax, tmax, opt, false, who, &R))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_gcig[1], ctx->stream));
     meme_ctx::HostBuf* Hb = ctx->h_gcig;
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)njobs * sizeof(meme_gres))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(R.tops + 1) * 4))) return rc;
@@ -502,7 +510,7 @@ extern "C" int meme_gen_cigar_batch_host(meme_ctx* ctx, const meme_cjob* jobs, i
     memset(out, 0, sizeof(*out));
     if (njobs == 0) return MEME_OK;
     const i64 nreads = ctx->last_seed_reads, l_pac = ctx->idx.n >> 1;
-    int qmax = 0;
+    int qmax = 0, tmax = 0;
     for (i64 k = 0; k < njobs; ++k) {
         const meme_cjob& J = jobs[k];
         // what bwa_gen_cigar2 itself rejects (src/bwa.cpp:285: empty spans, a target bridging the two strands) is not a job
@@ -512,6 +520,7 @@ extern "C" int meme_gen_cigar_batch_host(meme_ctx* ctx, const meme_cjob* jobs, i
             return MEME_E_ARG;
         }
         qmax = J.qlen > qmax ? J.qlen : qmax;
+        tmax = J.tlen > tmax ? J.tlen : tmax;
     }
     DevBuf* G = ctx->gcig;
     if ((rc = meme_buf_reserve(ctx, G[0], (size_t)njobs * sizeof(meme_gjob))) || (rc = meme_buf_reserve(ctx, G[9], (size_t)njobs * sizeof(meme_cjob)))) return rc;
@@ -519,7 +528,7 @@ extern "C" int meme_gen_cigar_batch_host(meme_ctx* ctx, const meme_cjob* jobs, i
     HIP_TRY(hipEventRecord(ctx->ev_gcig[0], ctx->stream));
     hipLaunchKernelGGL(k_cjob_prep, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_cjob*)G[9].p, (i64)njobs, l_pac, *opt, (meme_gjob*)G[0].p);
     GcigRun R;
-    if ((rc = gcig_run(ctx, njobs, qmax, opt, true, who, &R))) return rc;
+    if ((rc = gcig_run(ctx, njobs, qmax, tmax, opt, true, who, &R))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_gcig[1], ctx->stream));
     meme_ctx::HostBuf* Hb = ctx->h_gcig;
     if ((rc = meme_hostbuf_reserve(ctx, Hb[0], (size_t)njobs * sizeof(meme_cres))) || (rc = meme_hostbuf_reserve(ctx, Hb[1], (size_t)(R.tops + 1) * 4)) ||
