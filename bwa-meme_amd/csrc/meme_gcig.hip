@@ -34,6 +34,7 @@ struct GcigArgs {
 };
 
 __device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(pac[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3; }
+#define GCIG_DPP(old_, src_, ctrl_, rowmask_) __builtin_amdgcn_update_dpp((old_), (src_), (ctrl_), (rowmask_), 0xF, false)
 
 __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     extern __shared__ int lds[];             // hA[qlen + 2] | hB[qlen + 2] | e[qlen + 2] | query bytes (as ints, 4 per word)
@@ -100,9 +101,16 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
             // F along the row: F(i,j) = max( f_in - (j-cb)*e_ins , max_{cb <= k < j} (M(i,k) - oe_ins - (j-1-k)*e_ins) )
             // as an inclusive max-scan of G_k = M(i,k) - oe_ins + k*e_ins over the lanes, shifted by one lane
             const int g = in ? m - oe_ins + (j - cb) * e_ins : -2000000000;
-            int sg = g;
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(sg, d); if (lane >= d) sg = sg > y ? sg : y; }
-            int ex = __shfl_up(sg, 1);                                   // max over lanes below
+            // (the scan in the register file: row_shr 1/2/4/8, row_bcast15 into rows 1,3, row_bcast31 into rows 2,3, then wave_shr:1 -- as ds_bpermute
+            // shuffles the eight steps were eight LDS round trips on the row's dependent chain, 1 000 of its 1 200 cycles)
+            int sg = g, y;
+            y = GCIG_DPP(-2000000000, sg, 0x111, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x112, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x114, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x118, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x142, 0xA); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x143, 0xC); sg = sg > y ? sg : y;
+            const int ex = GCIG_DPP(-2000000000, sg, 0x138, 0xF);        // max over lanes below (lane 0: not used)
             // f at this column: from the carry (decayed) or from a column of this chunk
             const int from_carry = f_in - lane * e_ins;
             int f = lane == 0 ? f_in : (ex - (lane - 1) * e_ins > from_carry ? ex - (lane - 1) * e_ins : from_carry);
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
             f2 = f2 > t ? f2 : t;
             if (in) { eE[j] = e2; hn[j + 1] = h; zi[j - beg] = (uint8_t)d; }
             // carry to the next chunk: F(i, cb + 64) = f2 of lane 63
-            f_in = __shfl(f2, 63);
+            f_in = __builtin_amdgcn_readlane(f2, 63);
         }
         if (lane == 0) eE[end] = MINUS_INF;                              // eh[end].e (:647); eh[end].h was stored by the row's last column
         __syncthreads();
@@ -140,10 +148,33 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
             if (last_op == op) cur += (unsigned)len << 4;
             else { if (last_op >= 0) { cg[cap - 1 - n] = cur; ++n; } cur = (unsigned)len << 4 | (unsigned)op; last_op = op; }
         };
+        // A matrix in global memory is walked through a window in LDS: the rows [win_lo, win_hi) the walk is about to cross are fetched by the
+        // whole wavefront at once (a walk straight on HBM is 500 dependent loads of a microsecond each -- ten times the DP above it).
+        const bool windowed = z != zl && A.zcap >= 2 * n_col + 8;
+        const int win_rows = windowed ? (A.zcap - 8) / n_col : 0;
+        i64 win_base = 0, win_b0 = zsize;        // zl[x - win_base] = z[x] for the bytes [win_b0, ..) of the window
         while (i >= 0 && k >= 0) {
             i64 zi = (i64)i * n_col + (k - (i > w ? i - w : 0));
             if (zi < 0) zi = 0;
             if (zi >= zsize) zi = zsize - 1;
+            if (windowed) {
+                if (zi < win_b0) {
+                    __syncthreads();
+                    const int row = (int)(zi / n_col);      // (the clamps above can leave row i)
+                    const int win_lo = row - win_rows + 1 > 0 ? row - win_rows + 1 : 0;
+                    const i64 b0 = (i64)win_lo * n_col, b1 = (i64)(row + 1) * n_col;
+                    win_b0 = b0;
+                    const uint8_t* src = z + b0;
+                    const int shift = (int)(reinterpret_cast<uintptr_t>(src) & 3);      // dword loads from the aligned address below
+                    const unsigned* src4 = reinterpret_cast<const unsigned*>(src - shift);
+                    unsigned* dst4 = reinterpret_cast<unsigned*>(zl);
+                    const int nd = (int)((b1 - b0 + shift + 3) >> 2);
+                    for (int d = lane; d < nd; d += 64) dst4[d] = src4[d];
+                    win_base = b0 - shift;
+                    __syncthreads();
+                }
+                which = zl[zi - win_base] >> (which << 1) & 3;
+            } else
             which = z[zi] >> (which << 1) & 3;
             if (which == 0) { push(0, 1); --i; --k; }
             else if (which == 1) { push(2, 1); --i; }
@@ -362,7 +393,8 @@ constexpr int Z_LDS_CAP = 8192;             // a 250-row matrix of up to 32 band
 int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* opt, bool with_md, const char* who, GcigRun* out) {
     int rc;
     const size_t lds_base = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3) + (size_t)((tmax + 3) & ~3);
-    const int zcap = lds_base + Z_LDS_CAP <= 32 * 1024 ? Z_LDS_CAP : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
+    const int zwant = ctx->gcig_zcap >= 0 ? (int)ctx->gcig_zcap : Z_LDS_CAP;      // (tuning "gcig_zcap": the LDS kept for a job's backtrack matrix or window; 0: none)
+    const int zcap = lds_base + (size_t)zwant <= 32 * 1024 ? zwant : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
     if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 13 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     i64* d_zsz = (i64*)G[1].p;
