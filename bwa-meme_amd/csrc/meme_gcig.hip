@@ -148,6 +148,9 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
             if (last_op == op) cur += (unsigned)len << 4;
             else { if (last_op >= 0) { cg[cap - 1 - n] = cur; ++n; } cur = (unsigned)len << 4 | (unsigned)op; last_op = op; }
         };
+        // The walk is the same on every lane: the byte it reads goes through readfirstlane so that i, k, `which` and the addresses live in scalar
+        // registers.  Measured (profiles/r05_gcig.md): 21-29 % fewer VALU instructions per job and NO change in the kernel's time -- a job's time is its
+        // own serial chain of LDS round trips, not instruction issue.  Kept because it is exact and leaves the vector unit to whatever runs beside it.
         // A matrix in global memory is walked through a window in LDS: the rows [win_lo, win_hi) the walk is about to cross are fetched by the
         // whole wavefront at once (a walk straight on HBM is 500 dependent loads of a microsecond each -- ten times the DP above it).
         const bool windowed = z != zl && A.zcap >= 2 * n_col + 8;
@@ -173,9 +176,9 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
                     win_base = b0 - shift;
                     __syncthreads();
                 }
-                which = zl[zi - win_base] >> (which << 1) & 3;
+                which = __builtin_amdgcn_readfirstlane((int)zl[zi - win_base]) >> (which << 1) & 3;
             } else
-            which = z[zi] >> (which << 1) & 3;
+            which = __builtin_amdgcn_readfirstlane((int)z[zi]) >> (which << 1) & 3;
             if (which == 0) { push(0, 1); --i; --k; }
             else if (which == 1) { push(2, 1); --i; }
             else { push(1, 1); --k; }
@@ -389,11 +392,17 @@ unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i6
 // The batch from the jobs in G[0] (device) to packed results: scratch sizes, the alignment kernel, the packed operations (and MD strings).
 // with_md: NM + MD of every job (meme_gen_cigar_batch_host); host_jobs (may be null) only serves the error message of a bad query span.
 struct GcigRun { i64 tops = 0, tmd = 0; };
+constexpr int Z_LDS_WINDOW = 2048;          // ... and when matrices do not fit anyway: the window the walk back reads them through
 constexpr int Z_LDS_CAP = 8192;             // a 250-row matrix of up to 32 band columns: the bands bwa_gen_cigar2 computes for reads with a few small indels
 int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* opt, bool with_md, const char* who, GcigRun* out) {
     int rc;
     const size_t lds_base = (size_t)(3 * (qmax + 2)) * 4 + (size_t)((qmax + 3) & ~3) + (size_t)((tmax + 3) & ~3);
-    const int zwant = ctx->gcig_zcap >= 0 ? (int)ctx->gcig_zcap : Z_LDS_CAP;      // (tuning "gcig_zcap": the LDS kept for a job's backtrack matrix or window; 0: none)
+    // The LDS kept per job for its backtrack matrix or window (tuning "gcig_zcap" overrides; 0: none).  Measured on two read classes only
+    // (profiles/r05_gcig.md, 400 k calls each): where a typical matrix -- the rows of the longest target x the ~33 band columns bwa_gen_cigar2 computes
+    // for a read with a few small indels -- fits, keeping it whole pays (150 bp: 7.1 ms against 9.8 without); where it does not, only the window is used
+    // and a small one leaves room for more wavefronts (250 bp: 47.5 ms with 2 KB against 52.9 with 8 KB).
+    const int zauto = (size_t)tmax * 33 <= (size_t)Z_LDS_CAP ? Z_LDS_CAP : Z_LDS_WINDOW;
+    const int zwant = ctx->gcig_zcap >= 0 ? (int)ctx->gcig_zcap : zauto;
     const int zcap = lds_base + (size_t)zwant <= 32 * 1024 ? zwant : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
     if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 13 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
