@@ -7,11 +7,20 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_named_r5; mkdir -p $OUT
 export MEME_BENCH_CPU=0 MEME_BENCH_E2E=0 MEME_BENCH_BSW=0 MEME_BENCH_KSWV=0 MEME_BENCH_CHAIN=0 MEME_BENCH_EXT=0 MEME_BENCH_C4=0 MEME_BENCH_PMC=0 MEME_BENCH_PARITY_READS=50000
 export ROCPD_KERNELS=k_seed,k_reseed,k_gather,k_pack_reads ROCPD_ROWS=40
-rocprofv3 --kernel-trace --stats -d $OUT/trace_seed -o seed -- python bench.py --steps 5 --warmup 1 > $OUT/bench_traced_seed.json 2> $OUT/p1.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o seed -- python bench.py --steps 2 --warmup 1 > /dev/null 2> $OUT/p2.err
-rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o seed -- python bench.py --steps 2 --warmup 1 > /dev/null 2> $OUT/p3.err
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq -o seed -- python bench.py --steps 2 --warmup 1 > /dev/null 2> $OUT/p4.err
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2 -o seed -- python bench.py --steps 2 --warmup 1 > /dev/null 2> $OUT/p5.err
-for d in trace_seed pmc_fetch pmc_write pmc_sq pmc_sq2; do python scripts/rocpd_summary.py $OUT/$d/seed_results.db > $OUT/$d.md 2>&1; rm -rf $OUT/$d; done
+# Each pass writes its raw database under /tmp on the box and is summarised and deleted before the next one starts: a call that is cut short then still
+# brings back what it finished (raw databases left under gpurun_out/ exceed the 64 MiB that are merged back -- that lost the counter passes of call R).
+RAW=/tmp/prof_named_r5_raw
+pass() {   # name, output redirection target for the bench line, steps, then the rocprofv3 options
+    local name=$1 line=$2 steps=$3; shift 3
+    rm -rf $RAW; mkdir -p $RAW
+    rocprofv3 "$@" -d $RAW -o seed -- python bench.py --steps $steps --warmup 1 > $line 2> $OUT/$name.err
+    python scripts/rocpd_summary.py $RAW/seed_results.db > $OUT/$name.md 2>&1
+    rm -rf $RAW
+}
+pass trace_seed $OUT/bench_traced_seed.json 5 --kernel-trace --stats
+pass pmc_fetch /dev/null 2 --pmc FETCH_SIZE
+pass pmc_write /dev/null 2 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+pass pmc_sq /dev/null 2 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+pass pmc_sq2 /dev/null 2 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA
 cut -c1-600 $OUT/bench_traced_seed.json
 grep -h "k_seed\|k_reseed\|k_gather\|k_build_plcp" $OUT/trace_seed.md | head -20
