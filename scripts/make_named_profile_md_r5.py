@@ -35,7 +35,7 @@ def trace():
 
 
 traced = json.loads(open(D + "bench_traced_seed.json").read().strip().splitlines()[-1])
-bench_path = os.path.join(REPO, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r05_bench_default_b.json")
+bench_path = os.path.join(REPO, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r05_bench_default_c.json")
 bench = json.loads(open(bench_path).read().strip().splitlines()[-1])
 T = trace()
 launches = 6                                                      # 1 warm-up + 5 timed launches of 10 M reads in the traced run (+ the parity slice)
