@@ -149,8 +149,8 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
             else { if (last_op >= 0) { cg[cap - 1 - n] = cur; ++n; } cur = (unsigned)len << 4 | (unsigned)op; last_op = op; }
         };
         // The walk is the same on every lane: the byte it reads goes through readfirstlane so that i, k, `which` and the addresses live in scalar
-        // registers.  Measured (profiles/r05_gcig.md): 21-29 % fewer VALU instructions per job and NO change in the kernel's time -- a job's time is its
-        // own serial chain of LDS round trips, not instruction issue.  Kept because it is exact and leaves the vector unit to whatever runs beside it.
+        // registers.  Measured (profiles/r05_gcig.md): 21-29 % fewer VALU instructions per job and NO change in the kernel's time -- so the kernel is not
+        // bound by VALU issue; what it IS bound by is open (four explanations refuted, same file).  Kept because it is exact and costs nothing.
         // A matrix in global memory is walked through a window in LDS: the rows [win_lo, win_hi) the walk is about to cross are fetched by the
         // whole wavefront at once (a walk straight on HBM is 500 dependent loads of a microsecond each -- ten times the DP above it).
         const bool windowed = z != zl && A.zcap >= 2 * n_col + 8;
