@@ -38,6 +38,24 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }
 bool verbose() { static const bool v = getenv("MEME_DROPIN_VERBOSE") != nullptr; return v; }
 
+// ---- MEME_DROPIN_VERIFY (see meme_dropin.h) -------------------------------------------------------------------------------------
+bool verify_on() { static const bool v = getenv("MEME_DROPIN_VERIFY") && atoi(getenv("MEME_DROPIN_VERIFY")) != 0; return v; }
+uint64_t verify_hash(const void* p, size_t bytes, uint64_t h) {
+    const uint8_t* b = (const uint8_t*)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t v; memcpy(&v, b + i, 8); h = (h ^ v) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+    if (i < bytes) { uint64_t v = 0; memcpy(&v, b + i, bytes - i); h = (h ^ v) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+    return h;
+}
+void verify_note(int64_t chunk_seq, const char* stage, int dev, uint64_t hash, int64_t items) {
+    fprintf(stderr, "[meme-dropin] verify chunk %lld %s dev %d: %lld items, hash %016llx, identical on two ctxs\n", (long long)chunk_seq, stage, dev, (long long)items, (unsigned long long)hash);
+}
+[[noreturn]] void verify_fail(const char* stage, int64_t item, const char* what) {
+    fprintf(stderr, "[meme-dropin] VERIFY FAILED: the %s stage gave different results on two ctxs of one GPU for the same input (first difference: item %lld%s%s)\n", stage, (long long)item,
+            what && *what ? ", " : "", what ? what : "");
+    exit(3);
+}
+
 // ---- the reference's functions behind the interposed ones (see meme_dropin.h) ---------------------------------------------------------------
 namespace {
 struct RefEntry { const char* what; const char* symbol; void* p; };
@@ -151,6 +169,11 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));   // a memory bound (and the tests' way to the split-and-retry paths)
         // the second slot's ctx (chunks alternate between two, see "the next chunk ahead of its turn"): created and given its buffers
         // now, while the index loads -- its first chunk otherwise pays 0.25 s of allocations in the middle of the run
+        if (verify_on())
+            for (int k = 0; k < 2; ++k) {
+                if (!(g_dev[(size_t)d].vfy[k] = meme_ctx_create(d % n_real))) die("meme_ctx_create");
+                if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].vfy[k], "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));
+            }
         if (prefetch_on() && ext_mode() == 2) {
             if (!(g_dev[(size_t)d].seed2 = meme_ctx_create(d % n_real))) die("meme_ctx_create");
             if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed2, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));
@@ -171,6 +194,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         th.emplace_back([d] { if (meme_index_replicate(g_dev[(size_t)d].seed, g_dev[0].seed)) die("meme_index_replicate"); });
     for (auto& t : th) t.join();
     for (int d = 0; d < n; ++d) if (g_dev[(size_t)d].seed2 && meme_index_share(g_dev[(size_t)d].seed2, g_dev[(size_t)d].seed)) die("meme_index_share");
+    for (int d = 0; d < n; ++d) for (int k = 0; k < 2; ++k) if (g_dev[(size_t)d].vfy[k] && meme_index_share(g_dev[(size_t)d].vfy[k], g_dev[(size_t)d].seed)) die("meme_index_share");
     fprintf(stderr, "[meme-dropin] index staged in HBM in %.2f s, replicated to %d more GPU(s) in %.2f s\n", t1 - t0, n - 1,
             now_s() - t1);
 }
@@ -461,6 +485,32 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
             P.ext = tot;
             P.reads_on_ctx = false;                       // (the CIGAR stage names reads of the batch resident on the ctx: not for this part)
         } else if (rc) die("chunk-level device stages (meme_seed_batch_resident_ascii / meme_extend_last_batch_host)");
+        // MEME_DROPIN_VERIFY: the same stages once more on the slot's verify ctx, the records compared byte for byte
+        P.vfy = nullptr;
+        if (verify_on() && P.reads_on_ctx && g_dev[(size_t)d].vfy[P.ctx == g_dev[(size_t)d].seed2 ? 1 : 0]) {
+            meme_ctx* const v = g_dev[(size_t)d].vfy[P.ctx == g_dev[(size_t)d].seed2 ? 1 : 0];
+            static const int64_t live_only = getenv("MEME_DROPIN_EXT_LIVE") ? atoll(getenv("MEME_DROPIN_EXT_LIVE")) : 1;
+            meme_ext_host_result V;
+            int vr = meme_seed_batch_resident_ascii(v, P.flat, P.off, P.count, &so, nullptr, nullptr);
+            if (vr == MEME_OK) vr = meme_set_tuning(v, "ext_live_only", live_only);
+            if (vr == MEME_OK) vr = meme_extend_last_batch_host(v, g_contigs.data(), (int32_t)g_contigs.size(), &co, &eo, &V);
+            if (vr) die("MEME_DROPIN_VERIFY: the second run of the chunk-level device stages");
+            const meme_ext_host_result& A = P.ext;
+            if (A.total_regs != V.total_regs || A.total_seeds != V.total_seeds || A.total_chains != V.total_chains || A.n_pairs != V.n_pairs || A.n_retried != V.n_retried || A.n_tier2 != V.n_tier2) {
+                char msg[256];
+                snprintf(msg, sizeof(msg), "totals: records %lld / %lld, chained seeds %lld / %lld, chains %lld / %lld, extension jobs %lld / %lld, retried %lld / %lld", (long long)A.total_regs, (long long)V.total_regs,
+                         (long long)A.total_seeds, (long long)V.total_seeds, (long long)A.total_chains, (long long)V.total_chains, (long long)A.n_pairs, (long long)V.n_pairs, (long long)A.n_retried, (long long)V.n_retried);
+                verify_fail("seeding + chaining + extension", -1, msg);
+            }
+            for (int64_t i = 0; i <= P.count; ++i) if (A.reg_off[i] != V.reg_off[i]) verify_fail("seeding + chaining + extension", i, seqs[P.first + (i < P.count ? i : P.count - 1)].name);
+            if (memcmp(A.regs, V.regs, (size_t)A.total_regs * sizeof(meme_alnreg)) != 0)
+                for (int64_t i = 0; i < P.count; ++i)
+                    if (memcmp(A.regs + A.reg_off[i], V.regs + A.reg_off[i], (size_t)(A.reg_off[i + 1] - A.reg_off[i]) * sizeof(meme_alnreg)) != 0) verify_fail("seeding + chaining + extension (alignment records of a read)", i, seqs[P.first + i].name);
+            uint64_t h = verify_hash(A.reg_off, (size_t)(P.count + 1) * 8);
+            h = verify_hash(A.regs, (size_t)A.total_regs * sizeof(meme_alnreg), h);
+            verify_note(P.chunk_seq, "ext-records", d, h, A.total_regs);
+            P.vfy = v;
+        }
         // names and qualities of the slice beside its bases, for the SAM text kernel (the whole slice on the ctx, every read with qualities or none)
         P.sam_staged = false;
         if (sam_on_device() && P.reads_on_ctx) {
@@ -479,6 +529,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
                     }
                 });
                 if (meme_sam_stage_text(ctx, P.names, P.name_off, with_q ? P.quals : nullptr)) die("meme_sam_stage_text");
+                if (P.vfy && meme_sam_stage_text(P.vfy, P.names, P.name_off, with_q ? P.quals : nullptr)) die("meme_sam_stage_text");
                 P.sam_staged = true;
             }
         }
@@ -522,6 +573,7 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n, int slot) {
     for (int d = 0; d < nd; ++d) {
         ChunkPart& P = C.part[(size_t)d];
         P.ctx = slot ? g_dev[(size_t)d].seed2 : g_dev[(size_t)d].seed;
+        P.chunk_seq = C.seq; P.dev = d;
         const int64_t b0 = nb * d / nd, b1 = nb * (d + 1) / nd;
         P.first = b0 * BATCH_SIZE;
         P.count = (b1 * BATCH_SIZE < n ? b1 * BATCH_SIZE : n) - P.first;
@@ -595,6 +647,7 @@ void prefetch_submit(bseq1_t* seqs, int64_t n) {
                     });
                 }
                 const double t0 = now_s();
+                g_chunks[seq & 1].seq = seq;
                 seed_chunk(&F.opt, seqs, n, (int)(seq & 1));
                 g_t_prefetched = g_t_prefetched + (now_s() - t0);
                 {
@@ -680,8 +733,8 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
             { std::lock_guard<std::mutex> lk(g_pf->m); if (!g_pf->has_opt) { g_pf->opt = *opt; g_pf->has_opt = true; } }
             g_pf->cv.notify_all();                               // (chunks submitted before the options were known may go ahead now)
         }
-        if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
-        else if (!prefetch_take(seqs, n, &slot)) seed_chunk(opt, seqs, n, slot);
+        if (slot < 0) { slot = g_next_slot; g_next_slot ^= 1; g_chunks[slot].seq = -1; seed_chunk(opt, seqs, n, slot); }      // not from our reader: nothing is ahead
+        else if (!prefetch_take(seqs, n, &slot)) { g_chunks[slot].seq = chunk_seq; seed_chunk(opt, seqs, n, slot); }
         g_cur_chunk = &g_chunks[slot];
         g_cur_chunk_seq = chunk_seq;
         ++g_chunk_gen;

@@ -57,7 +57,17 @@ struct Device {
     meme_ctx* seed2 = nullptr;    // shares seed's index: chunks alternate between the two, so that the next chunk's device stages can run
                                   // while this chunk's reads, seeds and alignment records are still in use (created with the first prefetch)
     meme_ctx* bsw = nullptr;      // second ctx of the GPU: BandedPairWiseSW calls (host extension stage), mate rescue
+    meme_ctx* vfy[2] = {nullptr, nullptr};   // MEME_DROPIN_VERIFY: per chunk slot a ctx with buffers (and a history) of its own on which every device stage runs once more
 };
+// MEME_DROPIN_VERIFY=1 (round 6, the determinism question): every device stage of every chunk -- seeding + chaining + extension records, the CIGAR
+// table, the mate-rescue table, the SAM text -- runs a second time on another ctx of the same GPU (same index, other workspaces with another
+// history: what a kernel reads without having written it differs between the two) and the two outputs are compared byte for byte in the aligner;
+// a difference stops the run with the first differing item.  One line per chunk carries a 64-bit hash of each stage's output, so that two RUNS
+// can be compared stage by stage as well.
+bool verify_on();
+uint64_t verify_hash(const void* p, size_t bytes, uint64_t h = 0x9e3779b97f4a7c15ull);
+void verify_note(int64_t chunk_seq, const char* stage, int dev, uint64_t hash, int64_t items);   // one line on stderr: "[meme-dropin] verify chunk <seq> <stage> dev <d>: <items> items, hash <h>, identical on two ctxs"
+[[noreturn]] void verify_fail(const char* stage, int64_t item, const char* what);
 // (reached through an accessor: the early-start thread may run before the dynamic initialisers of meme_dropin.cpp)
 std::vector<Device>& device_slots();
 #define g_dev (dropin::device_slots())
@@ -67,6 +77,8 @@ extern std::atomic<int64_t> g_n_bsw_calls, g_n_bsw_pairs, g_n_seed_reads;
 struct ChunkPart {                     // the slice of a chunk one GPU seeded
     int64_t first = 0, count = 0;
     meme_ctx* ctx = nullptr;                             // the ctx that holds the slice's reads (the CIGAR stage names them)
+    meme_ctx* vfy = nullptr;                             // MEME_DROPIN_VERIFY: the ctx the slice's stages ran on once more (holds the same reads, seeds and staged text)
+    int64_t chunk_seq = -1; int dev = 0;                 // for the verify lines
     meme_seed_host_result res;
     meme_chain_host_result chains;                       // valid when g_chain_on_device (host extension stage)
     meme_ext_host_result ext;                            // valid in device-extension mode: alignment records of the part's reads
@@ -82,6 +94,7 @@ struct ChunkPart {                     // the slice of a chunk one GPU seeded
 struct Chunk {
     const bseq1_t* seqs = nullptr;
     int64_t n = 0;
+    int64_t seq = -1;                                    // the chunk's number when it came from the binding's reader (verify lines name it)
     std::vector<ChunkPart> part;
 };
 // SAM text on the device (meme_dropin_sam.cpp): the worker threads of a chunk note descriptors, the OUTPUT step of that chunk -- the pipeline's

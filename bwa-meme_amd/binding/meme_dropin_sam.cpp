@@ -148,6 +148,12 @@ bool matesw_prepass() {                          // false: too few jobs for the 
         static_assert(sizeof(kswr_t) == sizeof(meme_kswr) && offsetof(kswr_t, score) == 0 && offsetof(kswr_t, te) == 4 && offsetof(kswr_t, qe) == 8 &&
                       offsetof(kswr_t, score2) == 12 && offsetof(kswr_t, te2) == 16 && offsetof(kswr_t, tb) == 20 && offsetof(kswr_t, qb) == 24, "kswr_t layout");
         memcpy(&T.aln[(size_t)j0], R.res, (size_t)nj * sizeof(kswr_t));
+        if (verify_on() && g_chunk.part[(size_t)d].vfy) {              // MEME_DROPIN_VERIFY: the same jobs on another ctx of the GPU
+            meme_kswv_host_result V;
+            if (meme_kswv_batch_host(g_chunk.part[(size_t)d].vfy, jobs.data(), nj, ref.data(), rtot, qer.data(), qtot, &bo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
+            for (int64_t k = 0; k < nj; ++k) if (memcmp(&T.aln[(size_t)(j0 + k)], &V.res[k], sizeof(kswr_t)) != 0) verify_fail("mate-rescue Smith-Waterman", k, "");
+            verify_note(g_chunk.seq, "mate-rescue", d, verify_hash(V.res, (size_t)nj * sizeof(kswr_t)), nj);
+        }
         kms[(size_t)d] = R.kernel_ms;
     };
     std::vector<std::thread> th;
@@ -324,6 +330,20 @@ void cig_prepass() {
                     if (!warned) fprintf(stderr, "[meme-dropin] CIGAR stage: %lld of this chunk's alignments stay with the host (%s)\n", (long long)(nj - P.done), meme_last_error());
                     warned = true;
                     break;
+                }
+                if (verify_on() && g_chunk.part[(size_t)d].vfy) {          // MEME_DROPIN_VERIFY: the same calls on the ctx that holds the same reads
+                    const uint64_t h = verify_hash(R.md, (size_t)R.md_bytes, verify_hash(R.cigars, (size_t)R.total_ops * 4, verify_hash(R.res, (size_t)m * sizeof(meme_cres))));
+                    meme_cres_host V;
+                    if (meme_gen_cigar_batch_host(g_chunk.part[(size_t)d].vfy, Jv.data() + P.done, m, &bo, &V)) die("MEME_DROPIN_VERIFY: the second run of the CIGAR stage");
+                    if (V.total_ops != R.total_ops || V.md_bytes != R.md_bytes) verify_fail("CIGAR", -1, "totals of operations / MD bytes");
+                    if (memcmp(V.res, R.res, (size_t)m * sizeof(meme_cres)) != 0)
+                        for (int64_t k = 0; k < m; ++k) if (memcmp(&V.res[k], &R.res[k], sizeof(meme_cres)) != 0) verify_fail("CIGAR (score / NM / lengths of a call)", P.done + k, g_chunk.seqs[g_chunk.part[(size_t)d].first + Jv[(size_t)(P.done + k)].read].name);
+                    if (memcmp(V.cigars, R.cigars, (size_t)R.total_ops * 4) != 0 || memcmp(V.md, R.md, (size_t)R.md_bytes) != 0)
+                        for (int64_t k = 0; k < m; ++k)
+                            if (memcmp(V.cigars + R.res[k].cigar_off, R.cigars + R.res[k].cigar_off, (size_t)R.res[k].n_cigar * 4) != 0 || memcmp(V.md + R.res[k].md_off, R.md + R.res[k].md_off, (size_t)R.res[k].md_len + 1) != 0)
+                                verify_fail("CIGAR (operations / MD string of a call)", P.done + k, g_chunk.seqs[g_chunk.part[(size_t)d].first + Jv[(size_t)(P.done + k)].read].name);
+                    char st[48]; snprintf(st, sizeof(st), "cigar-round-%d", round);
+                    verify_note(g_chunk.seq, st, d, h, m);
                 }
                 // operations and MD string of every job back to back: the device packs both in job order, so 4 x cigar_off + md_off is a packing too
                 const int64_t b0 = (int64_t)P.blob.size();
@@ -572,6 +592,15 @@ SamText* sam_format_for_output(const bseq1_t* seqs) {
         meme_sam_host_result R;
         if (meme_sam_format_batch_host(P.ctx, S.stage[(size_t)d].recs, P.count, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), &R))
             die("meme_sam_format_batch_host");
+        if (verify_on() && P.vfy) {                                    // MEME_DROPIN_VERIFY: the same records on the ctx that holds the same reads, names and qualities
+            meme_sam_host_result V;
+            if (meme_sam_format_batch_host(P.vfy, S.stage[(size_t)d].recs, P.count, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), &V))
+                die("MEME_DROPIN_VERIFY: the second run of the SAM text stage");
+            if (V.text_bytes != R.text_bytes) verify_fail("SAM text", -1, "total bytes");
+            for (int64_t k = 0; k < P.count; ++k)
+                if (V.text_off[k + 1] != R.text_off[k + 1] || memcmp(V.text + R.text_off[k], R.text + R.text_off[k], (size_t)(R.text_off[k + 1] - R.text_off[k])) != 0) verify_fail("SAM text", k, seqs[P.first + k].name);
+            verify_note(C.seq, "sam-text", d, verify_hash(R.text, (size_t)R.text_bytes), P.count);
+        }
         SamPart& T = S.text.part[(size_t)d];
         T.text = R.text; T.text_off = R.text_off; T.first = P.first; T.count = P.count;
         kms[(size_t)d] = R.kernel_ms;
