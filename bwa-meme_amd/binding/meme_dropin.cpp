@@ -169,6 +169,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));   // a memory bound (and the tests' way to the split-and-retry paths)
         // the second slot's ctx (chunks alternate between two, see "the next chunk ahead of its turn"): created and given its buffers
         // now, while the index loads -- its first chunk otherwise pays 0.25 s of allocations in the middle of the run
+        if (getenv("MEME_DROPIN_SAM_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed, "sam_max_batch", atoll(getenv("MEME_DROPIN_SAM_MAX_BATCH")));   // (tests: the SAM text stage in pieces / by the reference's function)
         if (verify_on())
             for (int k = 0; k < 2; ++k) {
                 if (!(g_dev[(size_t)d].vfy[k] = meme_ctx_create(d % n_real))) die("meme_ctx_create");
@@ -177,6 +178,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         if (prefetch_on() && ext_mode() == 2) {
             if (!(g_dev[(size_t)d].seed2 = meme_ctx_create(d % n_real))) die("meme_ctx_create");
             if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed2, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));
+            if (getenv("MEME_DROPIN_SAM_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed2, "sam_max_batch", atoll(getenv("MEME_DROPIN_SAM_MAX_BATCH")));
         }
     }
     // while the index streams in: the seeding / chaining buffers of a chunk on every device slot (pinned memory is slow to allocate)
@@ -566,6 +568,7 @@ void seed_chunk(const mem_opt_t* opt, bseq1_t* seqs, int64_t n, int slot) {
                 { int nreal = meme_device_count(); dev_id = nreal > 0 ? d % nreal : 0; }
                 if (!(D.seed2 = meme_ctx_create(dev_id)) || meme_index_share(D.seed2, D.seed)) die("second seeding ctx");
                 if (getenv("MEME_DROPIN_MAX_BATCH")) meme_set_tuning(D.seed2, "max_batch", atoll(getenv("MEME_DROPIN_MAX_BATCH")));
+                if (getenv("MEME_DROPIN_SAM_MAX_BATCH")) meme_set_tuning(D.seed2, "sam_max_batch", atoll(getenv("MEME_DROPIN_SAM_MAX_BATCH")));
             }
     // consecutive 512-read batches of the chunk go to consecutive GPUs: contiguous ranges, batch-aligned
     const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;

@@ -241,7 +241,12 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
                 if (P.text && i >= P.first && i < P.first + P.count) { l = P.text_off[i - P.first + 1] - P.text_off[i - P.first]; t = P.text + P.text_off[i - P.first]; }
             }
             if (l > 0) { iov[(size_t)i].iov_base = (void*)t; iov[(size_t)i].iov_len = (size_t)l; }
-            else { iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0; }
+            else {
+                // (a read the mem_aln2sam hook handled carries the one-byte marker instead of text: it must have come back from the device stage --
+                // a marker reaching the output would be a 0x01 byte in the SAM stream; advisor, round 5)
+                if (seqs[i].sam && seqs[i].sam[0] == '\x01') { fprintf(stderr, "[meme-dropin] read %s: its SAM record was left to the device's text stage, which returned nothing for it\n", seqs[i].name); exit(1); }
+                iov[(size_t)i].iov_base = seqs[i].sam; iov[(size_t)i].iov_len = seqs[i].sam ? strlen(seqs[i].sam) : 0;
+            }
         }
     });
     for (int i = 0; i < n; ++i) {

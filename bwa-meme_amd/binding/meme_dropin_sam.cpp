@@ -482,9 +482,11 @@ void meme_dropin_report_cigar() {
 // arena per device, in read order; the output step writes it from there.  Everything else goes to the reference's function as before.
 // MEME_DROPIN_SAM=0: off.  MEME_DROPIN_SAM_CHECK=1 (tests): every such record is ALSO formatted by the reference's function and compared.
 namespace dropin {
+std::atomic<bool> g_sam_dev_failed{false};            // a device call of the stage failed for good: later chunks keep the reference's mem_aln2sam
 bool sam_on_device() {
-    static const bool v = !(getenv("MEME_DROPIN_SAM") && atoi(getenv("MEME_DROPIN_SAM")) == 0) && fast_out() && ext_mode() == 2;
-    return v;
+    // (only the environment is cached: ext_mode() may still be overridden by ext_mode_decide() when the first call comes early -- advisor, round 5)
+    static const bool env_on = !(getenv("MEME_DROPIN_SAM") && atoi(getenv("MEME_DROPIN_SAM")) == 0);
+    return env_on && fast_out() && ext_mode() == 2 && !g_sam_dev_failed.load(std::memory_order_relaxed);
 }
 bool sam_check() { static const bool v = getenv("MEME_DROPIN_SAM_CHECK") != nullptr; return v; }
 // What the worker threads of one chunk noted: arenas handed out per thread and chunk, owned by the chunk's slot (the threads end with
@@ -500,7 +502,9 @@ struct SamSlot {
     int softclip = 0;
     std::string rg;
     // pinned staging of the device calls (grow-only), one set per device slice
-    struct Stage { meme_sam_rec* recs = nullptr; int64_t recs_cap = 0; uint8_t* blob = nullptr; int64_t blob_cap = 0; };
+    struct Stage { meme_sam_rec* recs = nullptr; int64_t recs_cap = 0; uint8_t* blob = nullptr; int64_t blob_cap = 0;
+                   std::vector<char> own_text; std::vector<int64_t> own_off; };      // own_*: a slice formatted in pieces / by the reference's function (the device refused it whole)
+    const mem_opt_t* opt = nullptr;
     std::vector<Stage> stage;
     SamText text;
 } g_sam_slot[2];
@@ -515,7 +519,7 @@ SamArena& sam_arena() {                               // the calling thread's ar
     tl_sam_gen = g_chunk_gen;
     return *tl_sam_arena;
 }
-std::atomic<int64_t> g_sam_dev_recs{0}, g_sam_ref_recs{0};
+std::atomic<int64_t> g_sam_dev_recs{0}, g_sam_ref_recs{0}, g_sam_ref_fallback{0};
 double g_sam_kernel_ms = 0, g_sam_stage_s = 0;
 struct SamTally { int64_t dev = 0, ref = 0; ~SamTally() { if (dev) g_sam_dev_recs += dev; if (ref) g_sam_ref_recs += ref; } };
 thread_local SamTally tl_sam_tally;
@@ -531,7 +535,7 @@ void sam_chunk_closed() {
     for (size_t a = 0; a < S.used; ++a) any = any || !S.arenas[a]->recs.empty();
     if (!any) { S.used = 0; return; }
     S.seqs = g_chunk.seqs; S.chunk_seq = g_cur_chunk_seq; S.n = g_chunk.n; S.chunk = g_cur_chunk;
-    S.softclip = (g_opt->flag & MEM_F_SOFTCLIP) ? 1 : 0; S.rg = bwa_rg_id;
+    S.softclip = (g_opt->flag & MEM_F_SOFTCLIP) ? 1 : 0; S.rg = bwa_rg_id; S.opt = g_opt;
     if (g_contig_name_off.empty()) {
         g_contig_name_off.push_back(0);
         for (int i = 0; i < g_bns->n_seqs; ++i) { const char* nm = g_bns->anns[i].name; g_contig_names.insert(g_contig_names.end(), nm, nm + strlen(nm)); g_contig_name_off.push_back((int32_t)g_contig_names.size()); }
@@ -586,24 +590,90 @@ SamText* sam_format_for_output(const bseq1_t* seqs) {
     });
     S.text.part.assign((size_t)nd, SamPart());
     std::vector<double> kms((size_t)nd, 0.0);
+    // A slice the device cannot format whole is formatted in pieces (MEME_E_CAPACITY: halves, as the CIGAR stage does), and whatever the device
+    // cannot format at all by the REFERENCE's own mem_aln2sam from the noted descriptors -- the hook left only a marker in s->sam, so the text must
+    // come from somewhere; the stage is an optimisation, never a reason to stop after all the alignment work is done (advisor, round 5).
+    static const aln2sam_fn ref_aln2sam = (aln2sam_fn)ref_sym(R_MEM_ALN2SAM);
+    auto by_reference = [&](int d, int64_t k0, int64_t k1, std::vector<char>& text, std::vector<int64_t>& off) {
+        const ChunkPart& P = C.part[(size_t)d];
+        const meme_sam_rec* recs = S.stage[(size_t)d].recs;
+        std::vector<std::string> tmp((size_t)(k1 - k0));
+        team_for(k1 - k0, cig_threads(), [&](int64_t i0, int64_t i1, int) {
+            std::vector<uint32_t> cg, mcg;
+            for (int64_t i = i0; i < i1; ++i) {
+                const meme_sam_rec& r = recs[k0 + i];
+                if (r.read < 0) continue;
+                mem_aln_t a, m;
+                memset(&a, 0, sizeof(a)); memset(&m, 0, sizeof(m));
+                a.pos = r.pos; a.rid = r.rid; a.flag = r.flag; a.is_rev = (uint32_t)r.is_rev; a.is_alt = (uint32_t)r.is_alt; a.mapq = (uint32_t)r.mapq; a.NM = (uint32_t)r.NM;
+                a.n_cigar = r.n_cigar; a.score = r.score; a.sub = r.sub; a.alt_sc = 0;
+                if (r.n_cigar > 0) {                                  // (blob offsets need not be aligned: the operations are copied, the MD string behind them with them)
+                    const uint8_t* b = blob + r.cigar_off;
+                    const size_t bytes = (size_t)r.n_cigar * 4 + strlen((const char*)b + (size_t)r.n_cigar * 4) + 1;
+                    cg.resize((bytes + 3) / 4); memcpy(cg.data(), b, bytes); a.cigar = cg.data();
+                }
+                a.XA = r.xa_off >= 0 ? (char*)(blob + r.xa_off) : nullptr;
+                if (r.has_mate) {
+                    m.pos = r.m_pos; m.rid = r.m_rid; m.is_rev = (uint32_t)r.m_is_rev; m.is_alt = (uint32_t)r.m_is_alt; m.n_cigar = r.m_n_cigar;
+                    if (r.m_n_cigar > 0) { mcg.resize((size_t)r.m_n_cigar); memcpy(mcg.data(), blob + r.m_cigar_off, (size_t)r.m_n_cigar * 4); m.cigar = mcg.data(); }
+                }
+                kstring_t t = {0, 0, 0};
+                ref_aln2sam(S.opt, g_bns, &t, const_cast<bseq1_t*>(&seqs[P.first + k0 + i]), 1, &a, r.which, r.has_mate ? &m : nullptr);
+                tmp[(size_t)i].assign(t.s, t.l);
+                free(t.s);
+            }
+        });
+        for (int64_t i = 0; i < k1 - k0; ++i) { text.insert(text.end(), tmp[(size_t)i].begin(), tmp[(size_t)i].end()); off[(size_t)(k0 + i + 1)] = (int64_t)text.size(); }
+    };
     auto run = [&](int d) {
         const ChunkPart& P = C.part[(size_t)d];
         if (P.count == 0 || !P.sam_staged) return;
-        meme_sam_host_result R;
-        if (meme_sam_format_batch_host(P.ctx, S.stage[(size_t)d].recs, P.count, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), &R))
-            die("meme_sam_format_batch_host");
-        if (verify_on() && P.vfy) {                                    // MEME_DROPIN_VERIFY: the same records on the ctx that holds the same reads, names and qualities
-            meme_sam_host_result V;
-            if (meme_sam_format_batch_host(P.vfy, S.stage[(size_t)d].recs, P.count, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), &V))
-                die("MEME_DROPIN_VERIFY: the second run of the SAM text stage");
-            if (V.text_bytes != R.text_bytes) verify_fail("SAM text", -1, "total bytes");
-            for (int64_t k = 0; k < P.count; ++k)
-                if (V.text_off[k + 1] != R.text_off[k + 1] || memcmp(V.text + R.text_off[k], R.text + R.text_off[k], (size_t)(R.text_off[k + 1] - R.text_off[k])) != 0) verify_fail("SAM text", k, seqs[P.first + k].name);
-            verify_note(C.seq, "sam-text", d, verify_hash(R.text, (size_t)R.text_bytes), P.count);
-        }
+        SamSlot::Stage& G = S.stage[(size_t)d];
         SamPart& T = S.text.part[(size_t)d];
-        T.text = R.text; T.text_off = R.text_off; T.first = P.first; T.count = P.count;
-        kms[(size_t)d] = R.kernel_ms;
+        T.first = P.first; T.count = P.count;
+        auto call = [&](int64_t k0, int64_t m, meme_sam_host_result* R) {
+            return meme_sam_format_batch_host(P.ctx, G.recs + k0, m, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), R);
+        };
+        meme_sam_host_result R;
+        int rc = g_sam_dev_failed.load() ? MEME_E_STATE : call(0, P.count, &R);
+        if (rc == MEME_OK) {
+        if (verify_on() && P.vfy) {                                    // MEME_DROPIN_VERIFY: the same records on the ctx that holds the same reads, names and qualities
+                meme_sam_host_result V;
+                if (meme_sam_format_batch_host(P.vfy, S.stage[(size_t)d].recs, P.count, blob, blob_bytes, g_contig_names.data(), g_contig_name_off.data(), g_bns->n_seqs, S.softclip, S.rg.c_str(), &V))
+                    die("MEME_DROPIN_VERIFY: the second run of the SAM text stage");
+                if (V.text_bytes != R.text_bytes) verify_fail("SAM text", -1, "total bytes");
+                for (int64_t k = 0; k < P.count; ++k)
+                    if (V.text_off[k + 1] != R.text_off[k + 1] || memcmp(V.text + R.text_off[k], R.text + R.text_off[k], (size_t)(R.text_off[k + 1] - R.text_off[k])) != 0) verify_fail("SAM text", k, seqs[P.first + k].name);
+                verify_note(C.seq, "sam-text", d, verify_hash(R.text, (size_t)R.text_bytes), P.count);
+            }
+            T.text = R.text; T.text_off = R.text_off;
+            kms[(size_t)d] = R.kernel_ms;
+            return;
+        }
+        {
+            static std::atomic<int> said{0};
+            if (said.fetch_add(1) < 2) fprintf(stderr, "[meme-dropin] SAM text stage: the device does not take a slice of %lld records whole (%s): in pieces, the rest by the reference's mem_aln2sam\n", (long long)P.count, meme_last_error());
+        }
+        G.own_text.clear(); G.own_off.assign((size_t)P.count + 1, 0);
+        int64_t done = 0, piece = (P.count + 1) / 2;
+        while (done < P.count) {
+            const int64_t m = piece < P.count - done ? piece : P.count - done;
+            int prc = rc == MEME_E_CAPACITY ? call(done, m, &R) : rc;
+            if (prc == MEME_E_CAPACITY && m > 1024) { piece = (m + 1) / 2; continue; }
+            if (prc == MEME_OK) {
+                const int64_t base = (int64_t)G.own_text.size();
+                G.own_text.insert(G.own_text.end(), R.text, R.text + R.text_bytes);
+                for (int64_t i = 0; i < m; ++i) G.own_off[(size_t)(done + i + 1)] = base + R.text_off[i + 1];
+                kms[(size_t)d] += R.kernel_ms;
+                done += m;
+                continue;
+            }
+            if (prc != MEME_E_CAPACITY) g_sam_dev_failed = true;      // (not a question of size: the chunks that follow are not staged for the device at all)
+            g_sam_ref_fallback += P.count - done;
+            by_reference(d, done, P.count, G.own_text, G.own_off);
+            done = P.count;
+        }
+        T.text = G.own_text.data(); T.text_off = G.own_off.data();
     };
     std::vector<std::thread> th;
     for (int d = 1; d < nd; ++d) th.emplace_back(run, d);
@@ -685,7 +755,8 @@ void mem_aln2sam(const mem_opt_t* opt, const bntseq_t* bns, kstring_t* str, bseq
 void meme_dropin_report_sam() {
     if (!sam_on_device()) return;
     fprintf(stderr, "[meme-dropin] SAM text on the device: %lld records formatted there so far (kernels %.3f s, whole stage %.3f s), %lld by the reference's mem_aln2sam "
-            "(reads with several records, comments, pa tags)\n", (long long)g_sam_dev_recs.load(), g_sam_kernel_ms * 1e-3, g_sam_stage_s, (long long)g_sam_ref_recs.load());
+            "(reads with several records, comments, pa tags); record slots the device refused and the reference's function formatted from the descriptors: %lld\n", (long long)g_sam_dev_recs.load(),
+            g_sam_kernel_ms * 1e-3, g_sam_stage_s, (long long)g_sam_ref_recs.load(), (long long)g_sam_ref_fallback.load());
 }
 
 // ---- insert-size statistics: mem_pestat (src/bwamem_pair.cpp:81-148) ------------------------------------------------------------------

@@ -1431,14 +1431,7 @@ int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs,
     hipEvent_t* ev = ctx->ev_chain;
     for (int i = 0; i < 5; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
     for (int i = 0; i < 3; ++i) {
-        if (!ctx->stream_side[i]) {
-            // (tuning "chain_side_priority": the routed tiers' streams above the lane tier's in the hardware queues -- their 40 k reads decide when the stage ends)
-            int lo = 0, hi = 0;
-            if (ctx->chain_side_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-                HIP_TRY(hipStreamCreateWithPriority(&ctx->stream_side[i], hipStreamNonBlocking, hi));
-            else
-                HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_side[i], hipStreamNonBlocking));
-        }
+        { const int src = meme_side_stream(ctx, i); if (src) return src; }     // (tuning "chain_side_priority": the routed tiers' streams above the lane tier's in the hardware queues)
         if (!ctx->ev_side[i]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming));
     }
     if (!ctx->ev_aux) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));

@@ -77,6 +77,7 @@ struct meme_ctx {
     i64 seed_blocks_per_cu = 5;
     i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
                                        // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
+    i64 sam_max_batch = 0;             // > 0: meme_sam_format_batch_host refuses more record slots than this with MEME_E_CAPACITY (the caller then formats in pieces)
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches
     i64 ext_live_only = 0;             // 1: meme_extend_last_batch_host hands over the surviving records only (qe > qb: what src/bwamem.cpp:1680-1693 keeps)
     i64 ext_rounds = 1;                // with ext_live_only: rounds of one seed per read before everything still ahead is extended at once (0: the reference's batch, then compaction)
@@ -110,6 +111,9 @@ struct meme_ctx {
 
 void meme_set_error(const char* fmt, ...);
 int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes);
+// side stream i of the ctx (the routed chaining tiers, the early overflow tier of seeding), created on first use -- ONE place, so that the tuning
+// "chain_side_priority" applies to all three whichever stage touches a stream first (advisor, round 5)
+int meme_side_stream(meme_ctx* ctx, int i);
 int meme_hostbuf_reserve(meme_ctx* ctx, meme_ctx::HostBuf& b, size_t bytes);
 // exclusive prefix sum of n 64-bit counts into out[0..n] (out[n] = total), asynchronous on ctx->stream (meme_scan.hip)
 int meme_scan_exclusive(meme_ctx* ctx, const i64* d_in, i64* d_out, i64 n);

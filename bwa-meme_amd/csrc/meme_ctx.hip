@@ -36,6 +36,16 @@ int meme_buf_reserve(meme_ctx* ctx, DevBuf& b, size_t bytes) {
     return MEME_OK;
 }
 
+int meme_side_stream(meme_ctx* ctx, int i) {
+    if (ctx->stream_side[i]) return MEME_OK;
+    int lo = 0, hi = 0;
+    if (ctx->chain_side_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        HIP_TRY(hipStreamCreateWithPriority(&ctx->stream_side[i], hipStreamNonBlocking, hi));
+    else
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_side[i], hipStreamNonBlocking));
+    return MEME_OK;
+}
+
 int meme_hostbuf_reserve(meme_ctx* ctx, meme_ctx::HostBuf& b, size_t bytes) {
     if (bytes <= b.cap) return MEME_OK;
     if (b.p) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
@@ -150,6 +160,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "smem_cap")) ctx->smem_cap = value < 8 ? 8 : value;
     else if (!strcmp(key, "seed_defer")) ctx->seed_defer = value;
     else if (!strcmp(key, "max_batch")) ctx->max_batch = value;
+    else if (!strcmp(key, "sam_max_batch")) ctx->sam_max_batch = value;
     else if (!strcmp(key, "ext_census")) ctx->ext_census = value;
     else if (!strcmp(key, "gcig_zcap")) ctx->gcig_zcap = value;
     else if (!strcmp(key, "ext_live_only")) ctx->ext_live_only = value;

@@ -23,6 +23,7 @@ struct SamArgs {
     const char* rg; int rg_len;
     const i64* soff; char* scratch;                      // per record: its scratch slot
     i64* len;                                           // per record: bytes written
+    i64* over;                                          // smallest record index whose text did not fit its scratch slot (a formatter / bound mismatch: fails the call)
 };
 
 __device__ __forceinline__ int put_num(char* o, long long v) {        // kputw / kputl
@@ -176,7 +177,12 @@ __global__ void __launch_bounds__(256) k_sam_format(SamArgs A) {
         for (int i = lane; i < l; i += 64) o[n + i] = (char)xa[i];
         n += l;
     }
-    if (lane == 0) { o[n] = '\n'; A.len[k] = n + 1; }
+    if (lane == 0) {
+        o[n] = '\n'; A.len[k] = n + 1;
+        // k_sam_bounds sized the slot from the record's parts + a fixed allowance for the numeric fields and tags: a text beyond it has
+        // written into the next record's slot -- never silently (advisor, round 5)
+        if ((i64)n + 1 > A.soff[k + 1] - A.soff[k]) atomicMin((unsigned long long*)A.over, (unsigned long long)k);
+    }
 }
 
 // upper bound of a record's text: name + SEQ + QUAL + 12 bytes per CIGAR operation (its own, the mate's in MC) + the strings + the fixed parts
@@ -253,6 +259,7 @@ extern "C" int meme_sam_format_batch_host(meme_ctx* ctx, const meme_sam_rec* rec
     HIP_TRY(hipSetDevice(ctx->device));
     memset(out, 0, sizeof(*out));
     if (nrecs == 0) return MEME_OK;
+    if (ctx->sam_max_batch > 0 && nrecs > ctx->sam_max_batch) { meme_set_error("%s: %lld record slots exceed the ctx's sam_max_batch of %lld", who, (long long)nrecs, (long long)ctx->sam_max_batch); return MEME_E_CAPACITY; }
     const i64 nreads = ctx->last_seed_reads;
     if (nreads <= 0 || !ctx->reads_resident || !ctx->reads.p || ctx->sam_text_reads != nreads) {
         meme_set_error("%s: the batch on this ctx has no names / qualities staged (meme_sam_stage_text after the seeding call)", who);
@@ -310,12 +317,14 @@ extern "C" int meme_sam_format_batch_host(meme_ctx* ctx, const meme_sam_rec* rec
     A.names = (const char*)S[0].p; A.name_off = (const i64*)S[1].p; A.quals = ctx->sam_has_quals ? (const char*)S[2].p : nullptr;
     A.contig_name_off = (const int32_t*)d_tab; A.contig_names = d_tab + off_bytes; A.softclip = softclip ? 1 : 0;
     A.rg = d_tab + off_bytes + contig_name_off[n_contigs]; A.rg_len = rg_len;
-    A.soff = d_soff; A.scratch = (char*)S[6].p; A.len = d_len;
+    A.soff = d_soff; A.scratch = (char*)S[6].p; A.len = d_len; A.over = d_bad;            // (d_bad is all-ones again: the bounds kernel found nothing)
     hipLaunchKernelGGL(k_sam_format, dim3((unsigned)((nrecs + 3) / 4)), dim3(256), 0, ctx->stream, A);
     if ((rc = meme_scan_exclusive(ctx, d_len, d_toff, nrecs))) return rc;
-    i64 total = 0;
+    i64 total = 0, over = -1;
     HIP_TRY(hipMemcpyAsync(&total, d_toff + nrecs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&over, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (over >= 0) { meme_set_error("%s: the text of record %lld is longer than the slot k_sam_bounds gave it (formatter and bound disagree)", who, (long long)over); return MEME_E_STATE; }
     if ((rc = meme_buf_reserve(ctx, S[7], (size_t)total + 64))) return rc;
     hipLaunchKernelGGL(k_sam_pack, dim3((unsigned)((nrecs + 3) / 4)), dim3(256), 0, ctx->stream, (const i64*)d_soff, (const char*)S[6].p, (const i64*)d_toff, (i64)nrecs, (char*)S[7].p);
     HIP_TRY(hipGetLastError());

@@ -310,7 +310,7 @@ int launch_seed(meme_ctx* ctx, const uint8_t* d_reads, const i64* d_read_off, i6
     if (defer && (rc = meme_buf_reserve(ctx, ctx->blk, (size_t)nreads * BLK_PER_READ * 2 * sizeof(BlkRec)))) return rc;
     if ((rc = launch_tier(0, nreads, nullptr, 0, ctx->stream, defer))) return rc;
     i64 n_early = -1;                  // reads of the tier-1 launch that ran beside the re-seeding kernels (-1: none did)
-    if (!ctx->stream_side[0]) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream_side[0], hipStreamNonBlocking));
+    { const int src = meme_side_stream(ctx, 0); if (src) return src; }
     if (!ctx->ev_side[0]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_side[0], hipEventDisableTiming));
     if (!ctx->ev_aux) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
     if (defer) {
