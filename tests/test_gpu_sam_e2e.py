@@ -72,6 +72,9 @@ def test_sam_identical_to_reference(tmp_path, paired):
     # a batch for want of memory (MEME_DROPIN_MAX_BATCH: max_batch of the ctxs) is fed in pieces -- extension stage and CIGAR stage alike.
     for threads, chunk, extra in ((4, 100000000, {}), (16, 400000, {}), (8, 400000, {"MEME_DROPIN_VIRTUAL": "3"}),
                                   (8, 400000, {"MEME_DROPIN_PREFETCH": "0"}), (8, 400000, {"MEME_DROPIN_SAM": "0"}), (8, 100000000, {"MEME_DROPIN_MAX_BATCH": "1500"}),
+                                  # round 6 (advisor): a SAM-text call the device refuses is repeated in halves (3 000-slot pieces of a 6 000 / 12 000-read chunk) and what
+                                  # it refuses even in pieces of 1 024 is formatted by the reference's own mem_aln2sam from the noted descriptors -- same SAM either way
+                                  (8, 100000000, {"MEME_DROPIN_SAM_MAX_BATCH": "3000"}), (8, 400000, {"MEME_DROPIN_SAM_MAX_BATCH": "500", "MEME_DROPIN_VIRTUAL": "2"}),
                                   (8, 400000, {"MEME_DROPIN_MAX_BATCH": "700", "MEME_DROPIN_VIRTUAL": "2"}),
                                   (16, 400000, {"MEME_DROPIN_EXT": "0"}),
                                   (4, 100000000, {"MEME_DROPIN_EXT": "0", "MEME_DROPIN_CHAIN": "0", "MEME_DROPIN_IO": "1"})):
