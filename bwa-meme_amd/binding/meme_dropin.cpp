@@ -365,7 +365,7 @@ int ext_mode() {
     }();
     return v;
 }
-bool g_ext_on_device = false;           // decided per run in mem_process_seqs (needs opt)
+std::atomic<bool> g_ext_on_device{false};           // decided per run in mem_process_seqs (needs opt)
 std::atomic<double> g_t_ext_dev{0}, g_t_ext_chain_ms{0}, g_t_ext_ms{0}, g_t_ext_bsw_ms{0};
 std::atomic<int64_t> g_n_ext_pairs{0}, g_n_ext_retried{0}, g_n_ext_regs{0}, g_n_ext_live{0}, g_n_ext_tier2{0}, g_n_flt_jobs{0}, g_n_flt_dropped{0};
 bool chain_on_device() { static const bool v = !(getenv("MEME_DROPIN_CHAIN") && atoi(getenv("MEME_DROPIN_CHAIN")) == 0); return v; }
@@ -743,7 +743,29 @@ void mem_process_seqs(mem_opt_t* opt, int64_t n_processed, int n, bseq1_t* seqs,
         ++g_chunk_gen;
     }
     const double t_body = now_s();
-    next(opt, n_processed, n, seqs, pes0, w);
+    // ---- the read counter the chunk is processed with (round 6: the cause of the one differing SAM md5 of round 5, found by ThreadSanitizer) --------
+    // The reference's pipeline adds a chunk's reads to aux->n_processed in its OUTPUT step (src/fastmap.cpp:845) and reads the counter in the
+    // PROCESS step of the next chunk (:805, :818, :832) -- two threads, no ordering between them.  The value becomes w.n_processed and from there the
+    // `id` of every read (src/bwamem.cpp:1844-1909), which seeds hash_64(id + i) -- the tie-breaker between equally good alignments
+    // (mem_mark_primary_se :2010) and equally good pairs (mem_pair, src/bwamem_pair.cpp:412).  Nearly always the output step's thread gets there
+    // first (it continues straight on, the other thread has to wake up), so the counter holds all earlier chunks; when it does not -- a thread
+    // descheduled at the wrong moment, e.g. 64 workers under a 16-CPU quota -- the chunk is processed with the previous chunk's ids and reads with tied
+    // placements come out differently: same number of lines, another md5.  The calls of this function ARE ordered (the pipeline runs one PROCESS
+    // step at a time), so the binding counts for itself: every call gets the number of reads all earlier calls were given, which is what the
+    // reference computes whenever its two threads run in their usual order (-p: the two calls of a chunk get S and S + n_sep[0], as there).
+    // MEME_DROPIN_NPROC=ref: the argument as the pipeline read it.
+    static int64_t s_before = 0;
+    static int64_t n_stale = 0;
+    static const bool nproc_ref = getenv("MEME_DROPIN_NPROC") && !strcmp(getenv("MEME_DROPIN_NPROC"), "ref");
+    const int64_t n_det = s_before;
+    s_before += n;
+    if (n_det != n_processed) {
+        ++n_stale;
+        if (n_stale <= 3 || verbose())
+            fprintf(stderr, "[meme-dropin] note: the pipeline's read counter says %lld where %lld reads have been handed to mem_process_seqs (the reference's unordered update, src/fastmap.cpp:832 / 845; "
+                    "%lld chunk(s) so far): %s\n", (long long)n_processed, (long long)n_det, (long long)n_stale, nproc_ref ? "used as given (MEME_DROPIN_NPROC=ref)" : "the ordered count is used");
+    }
+    next(opt, nproc_ref ? n_processed : n_det, n, seqs, pes0, w);
     g_chunk.seqs = nullptr;
     if (chunk_seq >= 0 && !sam_release_deferred(chunk_seq)) prefetch_processed(chunk_seq);      // (a chunk with SAM text to format is released by the output step)
     if (verbose()) fprintf(stderr, "[meme-dropin] mem_process_seqs of this chunk: %.3f s until its device records were there, %.3f s in the reference's body\n", t_body - t_enter, now_s() - t_body);

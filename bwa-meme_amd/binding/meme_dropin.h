@@ -116,7 +116,7 @@ extern std::vector<meme_contig> g_contigs;
 int ext_mode();                                // MEME_DROPIN_EXT: 2 device (default), 0 the reference's per-batch functions (the cross-check)
 void ext_mode_decide(const mem_opt_t* opt);    // options beyond the device seed filter's limits: mode 0 for the run
 bool prefetch_on();                            // MEME_DROPIN_PREFETCH: chunks go through the device stages ahead of their turn
-extern bool g_ext_on_device;
+extern std::atomic<bool> g_ext_on_device;           // (written by every mem_process_seqs call with the same value, read by the helper that runs chunks ahead)
 extern int g_team;                             // kt_for worker threads of the run (opt->n_threads)
 extern worker_t* g_worker;                     // of the chunk being processed
 extern const mem_opt_t* g_opt;

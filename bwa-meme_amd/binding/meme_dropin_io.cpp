@@ -212,6 +212,10 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
     if (step != 2 || !fast_out()) return next(shared, step, data, opt, w);
     ktp_aux_t* aux = (ktp_aux_t*)shared;
     ktp_data_t* ret = (ktp_data_t*)data;
+    // (tests: MEME_DROPIN_TEST_OUTPUT_DELAY_MS holds this step back before it touches the pipeline's read counter, so that the next chunk's PROCESS step reads
+    // the counter first -- the order the reference's own race allows and a loaded host produces now and then; see mem_process_seqs in meme_dropin.cpp)
+    static const int delay_ms = getenv("MEME_DROPIN_TEST_OUTPUT_DELAY_MS") ? atoi(getenv("MEME_DROPIN_TEST_OUTPUT_DELAY_MS")) : 0;
+    if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
     aux->n_processed += ret->n_seqs;
     const uint64_t tim = __rdtsc();
     const int n = ret->n_seqs;

@@ -62,8 +62,11 @@ def run(exe, threads, K, extra, stderr_path=None, timeout=1800):
     assert p.returncode == 0 and b"FATAL: ThreadSanitizer" not in p.stderr, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.split(b"\n") if not l.startswith(b"@PG")]
     vl = sorted(re.findall(rb"verify chunk (-?\d+) (\S+) dev (\d+): (\d+) items, hash ([0-9a-f]+)", p.stderr))
+    global last_stale
+    last_stale = max([int(x) for x in re.findall(rb"(\d+) chunk\(s\) so far", p.stderr)] or [0])     # chunks whose pipeline read counter was stale (the reference's own race)
     return lines, vl
 
+last_stale = 0
 first, verify_ref, summary = {}, {}, {"mbp": mbp, "pairs": npairs, "K": K_CLASSES, "runs": [], "differing_runs": 0, "verify_lines": 0, "verify_hash_mismatch": 0}
 # the unmodified reference per -K class (what "identical" is measured against)
 ref_lines = {}
@@ -90,11 +93,12 @@ for k, threads, kname, extra in variants():
             verify_ref[split] = vl
         else:
             hm = sum(1 for a, b in zip(verify_ref[split], vl) if a != b) + abs(len(verify_ref[split]) - len(vl))
-    rec = {"run": k, "threads": threads, "K": kname, "env": extra, "lines": len(lines), "differing_lines": ndiff, "verify_lines": len(vl), "verify_hash_mismatch": hm, "s": round(time.time() - t, 2)}
+    rec = {"run": k, "threads": threads, "K": kname, "env": extra, "lines": len(lines), "differing_lines": ndiff, "verify_lines": len(vl), "verify_hash_mismatch": hm, "stale_counter_chunks": last_stale, "s": round(time.time() - t, 2)}
     summary["runs"].append(rec)
     summary["differing_runs"] += ndiff > 0
     summary["verify_lines"] += len(vl)
     summary["verify_hash_mismatch"] += hm
+    summary["stale_counter_chunks"] = summary.get("stale_counter_chunks", 0) + last_stale
     print(json.dumps(rec), flush=True)
     if ndiff:
         bad = [(i, a, b) for i, (a, b) in enumerate(zip(ref, lines)) if a != b][:4]

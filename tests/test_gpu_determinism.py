@@ -65,3 +65,36 @@ def test_sam_identical_under_varied_arrangements_and_stage_verify(tmp_path):
                     key = (kname, extra.get("MEME_DROPIN_VIRTUAL", "1"))
                     assert hashes.setdefault(key, vl) == vl, "per-stage hashes differ between two runs of %r" % (key,)
     assert n_runs == 30 and n_verify_lines > 0
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()), reason="compiled reference (oracle/_ref) not available on this box")
+def test_read_counter_race_of_the_reference_pipeline_is_pinned(tmp_path):
+    """The cause of round 5's one differing SAM md5 (found by ThreadSanitizer, profiles/r06_determinism.md): the reference's output step adds a chunk's
+    reads to aux->n_processed (src/fastmap.cpp:845) while the next chunk's process step reads it (:832) -- unordered; the value seeds the tie-breaking hash
+    of equally good alignments and pairs (src/bwamem.cpp:2010, src/bwamem_pair.cpp:412).  MEME_DROPIN_TEST_OUTPUT_DELAY_MS forces the rare order (the output
+    step late): the binding, which counts the reads itself, must still print the reference's SAM; with MEME_DROPIN_NPROC=ref (the counter as the pipeline
+    read it) the same run shows what the race does -- the same number of lines, other placements of reads that have two equally good ones."""
+    g = synth.make_genome(1_500_000, seed=151, repeat_frac=0.05, n_families=6, n_dups=12, dup_len=2500)      # exact duplicates: tied placements
+    fa = str(tmp_path / "race.fa")
+    synth.write_fasta(fa, g, contigs=2)
+    prefix = build_index(fa, bits=16)
+    n = 16000
+    r1, pos, _ = synth.make_reads(g, n, 150, seed=152, n_frac=0.0, exact_frac=0.5)
+    rng = np.random.default_rng(153)
+    p2 = np.clip(pos + rng.integers(300, 500, size=n) - 150, 0, g.shape[0] - 160)
+    r2 = (3 - g[p2[:, None] + np.arange(150)[None, :]][:, ::-1]).astype(np.uint8)
+    fqs = [str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")]
+    synth.write_fastq(fqs[0], r1, prefix="p")
+    synth.write_fastq(fqs[1], r2, prefix="p")
+    chunk = 600000                                                   # eight chunks
+    want, _ = _run("bwa-meme_mode3", prefix, fqs, 8, chunk, dict(os.environ))
+    base = dict(os.environ, MEME_INDEX_PREFIX=prefix)
+    got, err = _run("bwa-meme_dropin", prefix, fqs, 8, chunk, dict(base, MEME_DROPIN_TEST_OUTPUT_DELAY_MS="120"))
+    assert "the ordered count is used" in err, "the delay did not produce the stale counter:\n" + err[-1500:]
+    assert got == want, "the binding's output depends on the order of the pipeline's two threads"
+    racy, err = _run("bwa-meme_dropin", prefix, fqs, 8, chunk, dict(base, MEME_DROPIN_TEST_OUTPUT_DELAY_MS="120", MEME_DROPIN_NPROC="ref"))
+    assert "used as given" in err
+    ndiff = sum(1 for a, b in zip(racy, want) if a != b)
+    assert len(racy) == len(want) and ndiff > 0, "expected the stale counter to move tied placements (it is what the reference's own race does); %d differing lines" % ndiff
+    # ... and only reads with equally good alternatives move: every differing record is a mapping-quality-0..few record or its mate
+    print("stale read counter: %d of %d SAM lines differ" % (ndiff, len(want)))
