@@ -249,6 +249,10 @@ typedef const __attribute__((address_space(1))) Rmi32* glb_rmi;
 #ifndef SEED_USE_ERR
 #define SEED_USE_ERR 1
 #endif
+// 1: first windows start on a 64-byte boundary of the entry array (exactly two 128-byte lines per 12-entry window)
+#ifndef SEED_ALIGN_WIN
+#define SEED_ALIGN_WIN 0
+#endif
 #if SEED_QUERY_LDS
 typedef lds_u64 q_u64;
 #else
@@ -727,6 +731,12 @@ __global__ void __launch_bounds__(BLOCK, (G >= 4 ? SEED_MIN_WAVES : G)) k_seed(S
             base = span <= W ? pos - below - (W - span) / 2 : pos - (below * W) / span;
 #else
             base = pos - W / 2;
+#endif
+#if SEED_ALIGN_WIN
+            // Round 6: the first window starts on a multiple of four entries (64 bytes): 12 entries = 192 bytes from such a start lie in exactly two
+            // 128-byte lines (start % 128 is 0 or 64), where an arbitrary start touches three in 3 of 8 cases (2.375 on average); the placement
+            // moves by at most two entries.  Any base is a correct base (the window is a hint: a miss costs another window).
+            if constexpr (W % 4 == 0) base = (base + 2) & ~3ll;
 #endif
             if (base < 0) base = 0;
             if (base > n - W) base = n - W;
