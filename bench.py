@@ -69,7 +69,7 @@ def host_cpu_quota():
 
 
 def log(msg):
-    print("[bench r%s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+    print("[bench r%s +%.0fs] %s" % (os.environ.get("RANK", "0"), time.time() - T_START, msg), file=sys.stderr, flush=True)
 
 
 def fastq_bytes(reads: np.ndarray) -> np.ndarray:
@@ -534,6 +534,77 @@ def config4_class_leg(ctx, dev, genome, text, sa, l1, l2, l_pac, steps=3):
     return out
 
 
+def repeat_dense_leg(device_index, steps=3):
+    """Every stage of the path on a REPEAT-DENSE genome: seeding (the overflow tiers, max_occ subsampling of hit lists, src/bwamem.cpp:1154-1160),
+    chaining (the wavefront-per-read tiers and the B-tree tier carry load here), extension (jobs per read), each checked against the oracle.
+    Own index (built on the device in seconds) on a ctx of its own beside the benchmark's."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_py as O
+    mbp = float(os.environ.get("MEME_BENCH_RD_MBP", "128"))
+    nreads = int(os.environ.get("MEME_BENCH_RD_READS", "1000000"))
+    nsub = int(os.environ.get("MEME_BENCH_RD_STAGE_READS", "200000"))
+    l_pac = int(mbp * 1e6) & ~1
+    n = 2 * l_pac
+    t0 = time.time()
+    g = workload.repeat_dense_genome(l_pac)
+    c = hipapi.Context(device_index)
+    text = hipapi.fwd_rc_text(g)
+    d_text, d_sa = hipapi.build_sa_device(c, text)
+    d_pos5 = hipapi.pos5_from_sa_torch(c, d_sa, n)
+    sa = d_sa.cpu().numpy().view(np.uint64)
+    del d_sa
+    d_pac, d_ent = hipapi.stage_entries_torch(c, n, d_text, d_pos5)
+    bits = 26 if 8.0 * n + 8 > 1.0e9 else 24
+    d_l2, n_l2, d_l1, n_l1 = hipapi.train_prmi_device(c, d_ent, n, bits)
+    l2 = d_l2.cpu().numpy().view(hostapi.RMI_DTYPE)
+    l1 = d_l1.cpu().numpy().view(hostapi.RMI_DTYPE)[:n_l1]
+    keep = (d_pac, d_ent) + hipapi.attach_index_torch(c, n, d_pac, d_ent, d_l2, n_l2, d_l1, n_l1)
+    del d_text, d_pos5
+    log("repeat-dense leg: %.0f Mbp genome + index (2^%d leaves, %d partial) on the device in %.1f s" % (mbp, bits, n_l1, time.time() - t0))
+    reads = workload.make_reads_fast(g, nreads, READ_LEN, seed=78)
+    dev = torch.device("cuda", device_index)
+    d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
+    d_off = torch.arange(0, (nreads + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
+    opt = hipapi.default_seed_opt(rounds=3)
+    res = c.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), nreads, nreads * READ_LEN, opt)
+    c.sync()
+    k_ms, wall = [], []
+    for _ in range(steps):
+        t1 = time.perf_counter()
+        res = c.seed_batch_device(d_reads.data_ptr(), d_off.data_ptr(), nreads, nreads * READ_LEN, opt)
+        c.sync()
+        wall.append(time.perf_counter() - t1)
+        tm = c.timings()
+        k_ms.append((tm.seed_kernel_ms, tm.seed_gather_ms + tm.seed_pack_ms, tm.seed_reseed_ms, tm.seed_windows))
+    del d_reads, d_off
+    stage_ms = float(np.mean([k[0] for k in k_ms]))
+    bpr, per_read = algorithmic_bytes_per_read(text, sa, l1, l2, reads[:8000])
+    o_idx = O.Index(text, sa)
+    npar = min(nreads, int(os.environ.get("MEME_BENCH_RD_PARITY_READS", "40000")))
+    parity = all(seeds_equal_oracle(c, O, o_idx, reads[p0:p0 + 10000], opt) for p0 in range(0, npar, 10000))
+    achieved = bpr * nreads / (stage_ms * 1e-3) / 1e9
+    out = {"workload": "%d reads of %d bp (1 %% substitutions) vs a %d-bp genome with 42 %% interspersed 300-bp repeats (24 families, 12 %% divergence), 8 satellites (171-bp monomer x 300), "
+                       "24 exact 3-kb duplications; index of its own, 2^%d leaves" % (nreads, READ_LEN, l_pac, bits),
+           "seeding": {"metric": "seeding_reads_per_sec", "value": nreads / float(np.mean(wall)) if parity else None, "unit": "reads/s", "reads": nreads, "steps": steps,
+                       "ms_per_step": float(np.mean(wall)) * 1e3, "search_stage_ms": stage_ms, "of_which_reseed_kernels_ms": float(np.mean([k[2] for k in k_ms])),
+                       "pack_gather_ms": float(np.mean([k[1] for k in k_ms])), "smems_per_read": res.total_smems / nreads, "hits_per_read": res.total_hits / nreads,
+                       "searches_per_read": res.searches / nreads, "windows_per_read": k_ms[-1][3] / nreads, "algorithmic_bytes_per_read": bpr, "work_per_read": per_read,
+                       "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0},
+                       "matches_oracle": bool(parity), "checked_reads": npar}}
+    del o_idx
+    out["chain"] = chain_leg(c, reads, l_pac, nsub=nsub)
+    out["ext"] = ext_leg(c, reads, g, l_pac, nsub=min(nsub, int(os.environ.get("MEME_BENCH_RD_EXT_READS", "100000"))), ncig=20000)
+    e = out["ext"]
+    if isinstance(e, dict) and e.get("reads"):
+        e["extension_jobs_per_read"] = e["extension_jobs"] / e["reads"]
+        e["alignment_records_per_read"] = e["alignment_records"] / e["reads"]
+    out["all_checks_true"] = bool(parity and out["chain"].get("matches_oracle") and e.get("matches_oracle") and e.get("in_rounds", {}).get("equals_the_checked_records_minus_the_purged_ones") and e.get("cigar", {}).get("matches_oracle"))
+    c.close()
+    del keep
+    torch.cuda.empty_cache()
+    return out
+
+
 def live_pmc_traffic(steps=2):
     """HBM traffic of the SA-search stage measured in THIS run: bench.py re-executes itself (seeding only, `steps` launches, no warm-up) once under
     `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` -- counters in passes of their own, as the MI355X guide prescribes -- and sums the
@@ -549,7 +620,7 @@ def live_pmc_traffic(steps=2):
         d = tempfile.mkdtemp(prefix="meme_pmc_", dir="/tmp")
         try:
             env = dict(os.environ, TMPDIR="/tmp", MEME_BENCH_PMC="0", MEME_BENCH_CPU="0", MEME_BENCH_E2E="0", MEME_BENCH_BSW="0", MEME_BENCH_KSWV="0", MEME_BENCH_CHAIN="0",
-                       MEME_BENCH_EXT="0", MEME_BENCH_C4="0", MEME_BENCH_PARITY_READS="0")
+                       MEME_BENCH_EXT="0", MEME_BENCH_C4="0", MEME_BENCH_RD="0", MEME_BENCH_PARITY_READS="0")
             r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "0"],
                                cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             dbs = glob.glob(os.path.join(d, "**", "*results.db"), recursive=True)
@@ -1191,6 +1262,16 @@ def main():
                 except Exception as e:
                     log("config4_class leg failed: %r" % (e,))
                     out["config4_class"] = {"failed": repr(e)[:300]}
+        # ---- every stage on a repeat-dense genome (round 6: the headline's genome is 98 % unique; this one carries the overflow tiers, max_occ and the heavy chaining tiers) ----
+        if single and os.environ.get("MEME_BENCH_RD", "1") != "0":
+            if time.time() - T_START > budget - 650:
+                out["repeat_dense"] = {"skipped": "wall budget (%d s) nearly used up after %.0f s" % (budget, time.time() - T_START)}
+            else:
+                try:
+                    out["repeat_dense"] = repeat_dense_leg(local)
+                except Exception as e:
+                    log("repeat_dense leg failed: %r" % (e,))
+                    out["repeat_dense"] = {"failed": repr(e)[:300]}
         # ---- e2e: BASELINE.json's second metric, the drop-in next to the unmodified reference (last: it needs the HBM) --------
         if single and os.environ.get("MEME_BENCH_E2E", "1") != "0":
             if not ref_prefix:

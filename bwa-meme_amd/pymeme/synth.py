@@ -21,8 +21,11 @@ _ALPHA = np.frombuffer(b"ACGTN", dtype=np.uint8)
 
 def make_genome(n_bases: int, seed: int = 11, repeat_frac: float = 0.02, repeat_len: int = 300,
                 n_families: int = 20, divergence: float = 0.03, n_dups: int = 8,
-                dup_len: int = 2000, poly_runs: int = 4) -> np.ndarray:
-    """Return a uint8 array of codes 0..3 of length ``n_bases``."""
+                dup_len: int = 2000, poly_runs: int = 4, satellites: int = 0, sat_unit: int = 171,
+                sat_copies: int = 300, sat_divergence: float = 0.02) -> np.ndarray:
+    """Return a uint8 array of codes 0..3 of length ``n_bases``.  ``satellites`` > 0 (the repeat-dense workloads) plants that many
+    tandem arrays -- ``sat_copies`` copies of a ``sat_unit``-base monomer, each copy diverged by ``sat_divergence`` -- AFTER everything
+    else, so that the genomes of existing seeds do not change."""
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
     if n_bases < 4 * repeat_len:
@@ -49,6 +52,17 @@ def make_genome(n_bases: int, seed: int = 11, repeat_frac: float = 0.02, repeat_
         L = int(rng.integers(20, 60))
         s = int(rng.integers(0, n_bases - L))
         g[s:s + L] = k & 3
+    # satellites: tandem arrays of a short monomer (alpha-satellite-like: hundreds of near-identical copies side by side)
+    for _ in range(satellites):
+        L = sat_unit * sat_copies
+        if n_bases < 4 * L:
+            break
+        mono = rng.integers(0, 4, size=sat_unit, dtype=np.uint8)
+        arr = np.tile(mono, sat_copies)
+        mut = rng.random(L) < sat_divergence
+        arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        s = int(rng.integers(0, n_bases - L))
+        g[s:s + L] = arr
     return g
 
 
