@@ -833,6 +833,28 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
             if exe == "bwa-meme_mode3" and refcache is not None:
                 refcache.put(ckey, info)
             log("e2e: %s wall %.1f s, process %.1f s (CPU %.1f s), %d SAM lines" % (spec, wall, proc, proc_cpu, nlines))
+        # ---- the device-stage floor per slice (round 6): with N GPUs the binding hands every GPU 1/N of a -K chunk, so what an N-GPU run's
+        # device stages take is decided by how the stages of a 667 k / N-read slice scale.  The bound aligner once more per slice size (-K = slice x read length,
+        # one GPU, no reference run): seconds of device stages per slice -> the predicted device-stage wall of this workload at 2, 4, 8 GPUs.
+        slices = None
+        if os.environ.get("MEME_BENCH_E2E_SLICES", "1") != "0" and devices == 1 and read_len == READ_LEN:
+            slices = {}
+            chunk_reads = 100000000 // read_len // 2 * 2 + 2
+            for div in (8, 4, 2):
+                k_bases = 100000000 // div
+                env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_DEVICES="1")
+                env.setdefault("GLIBC_TUNABLES", MALLOC_TUNABLES)
+                t0 = time.time()
+                r = subprocess.run([os.path.join(ref_dir, dropin_exe.split("@")[0]), "mem", "-7", "-Y", "-K", str(k_bases), "-t", str(min(threads, 64)), prefix] + fqs,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=1200)
+                err = r.stderr.decode(errors="replace")
+                mm = re.findall(r"totals: chunk-level device stages \(gather \+ seeding \+ chaining \+ extension\) ([0-9.]+) s for (\d+) reads", err)
+                pr = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
+                if r.returncode == 0 and mm:
+                    dev_s, nr = float(mm[-1][0]), int(mm[-1][1])
+                    slices[str(div)] = {"slice_reads": chunk_reads // div, "device_stages_s_total": dev_s, "device_stages_ms_per_slice": 1e3 * dev_s / max(nr, 1) * (chunk_reads // div),
+                                        "process_s": pr, "wall_s": time.time() - t0}
+            log("e2e: device stages per slice of 1/8, 1/4, 1/2 chunk: %s" % {k: round(v["device_stages_ms_per_slice"], 1) for k, v in slices.items()})
         ref, drop = out.get("bwa-meme_mode3"), out[dropin_exe]
         # what bounds the bound aligner (for reading an N-GPU curve: the device stages of a chunk run on its GPUs side by side -- one slice each -- and,
         # from the second chunk on, beside the previous chunk's host phases; mem_process_seqs is the host's own time)
@@ -840,6 +862,13 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
         if dev_s is not None and drop["process_s"] > 0:
             drop["bound"] = {"device_stages_wall_s": dev_s, "device_stages_wall_s_per_gpu_if_split_evenly": dev_s, "gpus": devices, "host_process_s": drop["process_s"],
                              "host_process_cpu_s": drop["process_cpu_s"], "host_cpu_quota": host_cpu_quota(),
+                             "device_stage_floor_per_slice": (dict(slices, **{"1": {"slice_reads": 100000000 // read_len // 2 * 2 + 2, "device_stages_s_total": dev_s,
+                                                                                  "device_stages_ms_per_slice": 1e3 * dev_s / (2.0 * npairs) * (100000000 // read_len // 2 * 2 + 2)}})
+                                                              if slices else None),
+                             "predicted_device_stages_wall_s_by_gpus": ({g: (slices[g]["device_stages_s_total"] / int(g) if g in slices else None) for g in ("2", "4", "8")} | {"1": dev_s}
+                                                                        if slices else None),
+                             "prediction": "N GPUs: every GPU takes 1/N of a chunk; the device-stage wall of this workload is then (seconds per slice of that size) x (number of chunks) = "
+                                           "the one-GPU total at -K/N divided by N",
                              "reading": ("host-bound: mem_process_seqs (%.2f s) exceeds the device stages (%.2f s wall, every GPU working on its slice at once); more GPUs "
                                          "shorten only the device stages" % (drop["process_s"], dev_s)) if drop["process_s"] >= dev_s else
                                         ("device-bound: the device stages (%.2f s) exceed mem_process_seqs (%.2f s); more GPUs shorten the run" % (dev_s, drop["process_s"]))}
@@ -1319,6 +1348,13 @@ def main():
                                                          "stage each, counters summed over k_seed + k_reseed*); (2 x FETCH_SIZE + WRITE_SIZE) x 1024 as the MI355X guide prescribes")
                     out["roofline"]["traffic_over_algorithmic"] = out["roofline"]["traffic"] / (bpr * nreads)
                     out["roofline"]["traffic_counters_kb_per_launch"] = {"FETCH_SIZE": live["fetch_kb"], "WRITE_SIZE": live["write_kb"]}
+                    # The stage's accesses are random 128-byte lines of which a few dozen bytes are used: the memory system delivers ~50 G such lines per second
+                    # whatever is used of them (scripts/microbench/gather_roofline.hip, profiles/r01_gather_roofline.md), which -- not 8 TB/s of useful bytes -- is
+                    # the ceiling of this access pattern (frac 0.17-0.20 of the byte roofline).  Lines fetched per second against that ceiling:
+                    lines_per_s = 2.0 * live["fetch_kb"] * 1024.0 / 128.0 / (k_ms * 1e-3)
+                    out["roofline"]["random_line_ceiling_lines_per_s"] = 50e9
+                    out["roofline"]["lines_fetched_per_s"] = lines_per_s
+                    out["roofline"]["frac_of_random_line_ceiling"] = lines_per_s / 50e9
             except Exception as e:
                 log("live pmc passes skipped: %r" % (e,))
         print(json.dumps(out), flush=True)
