@@ -445,6 +445,191 @@ __global__ void __launch_bounds__(64) k_bsw_lane(LaneArgs A) {
     }
 }
 
+// ---- lane-per-pair kernel with a CIRCULAR band buffer (round 6) -----------------------------------------------------------------
+// Row i of the function touches columns [beg, end] with i - w <= beg and end <= i + w + 1 (:151-156, :171-175): at most 2w + 2 columns, and
+// beg never decreases.  The linear kernel above keeps a word for every column of the query -- (q + 2) * 256 bytes of LDS per wavefront: 57 KB
+// for queries up to 222 bases (two wavefronts per CU), 82 KB up to 318 and 154 KB up to 600 (ONE per CU): the classes that hold 36 % of the
+// extension jobs of 250-bp reads.  Here column j lives in slot j mod C of a ring of C >= 2w + 2 columns (C = 208 for w = 100: 53 KB, three
+// wavefronts per CU whatever the query length).  What makes that exact:
+//   * a slot is reused for column j + C only at a row where i + w + 1 >= j + C, i.e. beg >= i - w > j: column j has left the band for good;
+//   * a column the band reaches for the first time must hold the FIRST ROW's value (the "stale cells" the function reads when its band grows,
+//     :143-145 with :183-201): columns enter in increasing order, one per row (end <= i + w + 1), so the ring is topped up with
+//     {H(-1, j), E = 0, query base j} for j = i + w + 1 at the head of row i -- the query byte requested a row ahead;
+//   * columns the band re-reads after shrinking (end = jt + 2 can fall and rise again) are still in the ring: they are above beg.
+// The cell, the row bookkeeping, the trimming and the tie rules are the linear kernel's, statement for statement; only addresses differ.  A
+// row's columns are walked in runs that do not cross the ring's seam (at most one seam per row: one cell computed on its own).
+struct LaneCircArgs { LaneArgs L; int C; };
+
+__global__ void __launch_bounds__(64) k_bsw_lane_circ(LaneCircArgs AC) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int he_raw[];
+    typedef __attribute__((address_space(3))) unsigned int* lds_u32;
+    LaneArgs& A = AC.L;
+    const int C = AC.C;
+    const int lane = threadIdx.x;
+    const lds_u32 he = (lds_u32)he_raw + lane;           // slot s of this lane's pair: he[s * 64]
+    const int o_del = A.o.o_del, e_del = A.o.e_del, o_ins = A.o.o_ins, e_ins = A.o.e_ins;
+    const int oe_del = o_del + e_del, oe_ins = o_ins + e_ins, zdrop = A.o.zdrop;
+    const int sa = A.o.a, sb = -A.o.b;
+    constexpr unsigned HE_MASK = 0xffffff00u, QMASK = 0xffu;
+    if (A.offs) { A.first = A.offs[A.key_first]; A.count = A.offs[A.key_last] - A.first; }
+    for (;;) {
+        unsigned int tk = 0;
+        if (lane == 0) tk = atomicAdd(A.ticket, 64u);
+        tk = __shfl(tk, 0);
+        if (tk >= (unsigned)A.count) break;
+        const bool active = tk + lane < (unsigned)A.count;
+        meme_seqpair* P = &A.pairs[A.order[A.first + (active ? tk + lane : tk)]];
+        const int qlen = active ? P->len2 : 0, tlen = active ? P->len1 : 0, h0 = P->h0;
+        const uint8_t* query = A.qer + P->idq;
+        const uint8_t* target = A.ref + P->idr;
+        const int first = h0 > oe_ins ? h0 - oe_ins : 0;
+        // H(-1, j) of the first row (:143-145)
+#define BSW_ROW0(j_) ((j_) == 0 ? h0 : ((j_) == 1 ? first : ((first - ((j_) - 2) * e_ins) > e_ins ? (first - ((j_) - 2) * e_ins) - e_ins : 0)))
+        int hi = qlen < C - 1 ? qlen : C - 1;                 // highest column the ring holds so far
+        for (int j0 = 0; j0 <= hi; j0 += 8) {
+            unsigned qb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) qb[u] = j0 + u < qlen ? (unsigned)query[j0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j > hi) break;
+                he[j * 64] = he_pack(BSW_ROW0(j), 0, qb[u] > 4u ? 4u : qb[u]);
+            }
+        }
+        int w = A.w;
+        {
+            const int mx = sa > 0 ? sa : 0;
+            int max_ins = (int)((double)(qlen * mx + A.o.end_bonus - o_ins) / e_ins + 1.);
+            if (max_ins < 1) max_ins = 1;
+            if (w > max_ins) w = max_ins;
+            int max_del = (int)((double)(qlen * mx + A.o.end_bonus - o_del) / e_del + 1.);
+            if (max_del < 1) max_del = 1;
+            if (w > max_del) w = max_del;
+        }
+        int max = h0, max_i = -1, max_j = -1, max_ie = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+        int cb = 0;                                           // multiple of C with cb <= beg < cb + C: column j sits in slot j - cb (- C beyond the seam)
+#define BSW_SLOT(j_) (((j_) - cb) >= C ? ((j_) - cb - C) : ((j_) - cb))
+        int tb_next = tlen > 0 ? (int)target[0] : 4;
+        unsigned q_next = hi + 1 < qlen ? (unsigned)query[hi + 1] : 0u;        // base of the next column to enter the ring
+        for (int i = 0; i < tlen; ++i) {
+            const int tb = tb_next;
+            if (i + 1 < tlen) tb_next = target[i + 1];
+            int f = 0, h1, m = 0, mj = -1;
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            while (beg - cb >= C) cb += C;
+            // the column the band may reach for the first time in this row enters the ring with the first row's value
+            {
+                const int need = i + w + 1 < qlen ? i + w + 1 : qlen;
+                if (hi < need) {
+                    ++hi;
+                    he[BSW_SLOT(hi) * 64] = he_pack(BSW_ROW0(hi), 0, q_next > 4u ? 4u : q_next);
+                    q_next = hi + 1 < qlen ? (unsigned)query[hi + 1] : 0u;      // in flight during the row
+                }
+            }
+            if (beg == 0) { h1 = h0 - (o_del + e_del * (i + 1)); if (h1 < 0) h1 = 0; }
+            else h1 = 0;
+            const unsigned sb4 = (unsigned)(sb & 0xff) * 0x01010101u;
+            const unsigned tab_lo = tb > 3 ? 0xffffffffu : (sb4 & ~(0xffu << (8 * tb))) | ((unsigned)(sa & 0xff) << (8 * tb));
+            const unsigned tab_hi = 0xffffffffu;
+            // one cell: `cur_` holds the word of the cell's slot (pc_), the next slot's word (pn_) is requested first
+#define BSW_CELLC(cur_, nxt_, pc_, pn_, mk_, jb_)                                                             \
+            {                                                                                                  \
+                nxt_ = *(pn_);                                                                                 \
+                int M = (int)((cur_ >> 8) & 0xfffu), e = (int)(cur_ >> 20);                                     \
+                const int sc = (int)(signed char)(__builtin_amdgcn_perm(tab_hi, tab_lo, cur_) & 0xffu);         \
+                M = M ? M + sc : 0;                                                                            \
+                const int h = max3_i32(M, e, f);                                                               \
+                const int key = (h << 10) + (jb_);                                                             \
+                mk_ = mk_ > key ? mk_ : key;                                                                   \
+                e = max3_i32(M - oe_del, e - e_del, 0);                                                        \
+                *(pc_) = he_repack(h1, e, cur_);                                                               \
+                h1 = h;                                                                                        \
+                f = max3_i32(M - oe_ins, f - e_ins, 0);                                                        \
+            }
+            int s = BSW_SLOT(beg);
+            unsigned wa = beg < end ? he[s * 64] : 0u, wb = 0u, wc = 0u, wd = 0u;
+            int mk0 = -8, mk1 = -8, mk2 = -8, mk3 = -8;
+            int j = beg;
+            while (j < end) {
+                // cells whose next slot is s + 1 (the run up to the ring's seam), four per trip
+                int run = end - j < C - 1 - s ? end - j : C - 1 - s;
+                lds_u32 p = he + s * 64;
+                const int j_run = j + run;
+                for (; j + 3 < j_run; j += 4, p += 256) {
+                    BSW_CELLC(wa, wb, p, p + 64, mk0, j)
+                    BSW_CELLC(wb, wc, p + 64, p + 128, mk1, j)
+                    BSW_CELLC(wc, wd, p + 128, p + 192, mk2, j)
+                    BSW_CELLC(wd, wa, p + 192, p + 256, mk3, j)
+                }
+                for (; j < j_run; ++j, p += 64) {
+                    BSW_CELLC(wa, wb, p, p + 64, mk0, j)
+                    wa = wb;
+                }
+                s += run;
+                if (j < end) {                                 // the cell in the ring's last slot: its right neighbour is slot 0
+                    BSW_CELLC(wa, wb, he + (C - 1) * 64, he, mk0, j)
+                    wa = wb;
+                    ++j; s = 0;
+                }
+            }
+#undef BSW_CELLC
+            {
+                mk1 += 1; mk2 += 2; mk3 += 3;
+                const int ka = mk0 > mk1 ? mk0 : mk1, kb = mk2 > mk3 ? mk2 : mk3;
+                const int key = ka > kb ? ka : kb;
+                m = key < 0 ? 0 : key >> 10;
+                mj = key < 0 ? -1 : key & 1023;
+            }
+            const int s_end = BSW_SLOT(end);
+            he[s_end * 64] = he_pack(h1, 0, he[s_end * 64] & QMASK);    // :201
+            const unsigned w_front = he[BSW_SLOT(beg) * 64];
+            if ((beg < end ? end : beg) == qlen) {
+                max_ie = gscore > h1 ? max_ie : i;
+                gscore = gscore > h1 ? gscore : h1;
+            }
+            if (m == 0) break;
+            if (m > max) {
+                max = m; max_i = i; max_j = mj;
+                int off = mj - i;
+                if (off < 0) off = -off;
+                max_off = max_off > off ? max_off : off;
+            } else if (zdrop > 0) {
+                if (i - max_i > mj - max_j) {
+                    if (max - m - ((i - max_i) - (mj - max_j)) * e_del > zdrop) break;
+                } else {
+                    if (max - m - ((mj - max_j) - (i - max_i)) * e_ins > zdrop) break;
+                }
+            }
+            int jt = beg;
+            if (jt < end && (w_front & HE_MASK) == 0u) {
+                ++jt;
+                while (jt < end && (he[BSW_SLOT(jt) * 64] & HE_MASK) == 0u) ++jt;
+            }
+            beg = jt;
+            jt = end;
+            if (h1 == 0) {
+                --jt;
+                while (jt >= beg && (he[BSW_SLOT(jt) * 64] & HE_MASK) == 0u) --jt;
+            }
+            end = jt + 2 < qlen ? jt + 2 : qlen;
+        }
+#undef BSW_SLOT
+#undef BSW_ROW0
+        if (active) {
+            P->score = max;
+            P->qle = max_j + 1;
+            P->tle = max_i + 1;
+            P->gtle = max_ie + 1;
+            P->gscore = gscore;
+            P->max_off = max_off;
+        }
+    }
+}
+
 // ---- counting sort of the pairs by query length (the lanes of a wavefront should finish together) -------------------------
 // Sort key: query length first (LDS size class, column-loop length), then the surplus of target rows over query columns
 // in steps of 8, so that the 64 pairs of a wavefront also run about the same number of rows.
@@ -602,13 +787,25 @@ int launch_bsw(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, const
                 if (qhi < host_maxq && c + 1 < N_LANE_CLS) continue;           // not the top class of this batch yet
                 L.key_first = 0;
             }
-            const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
-            if (lds > 64 * 1024)
-                HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             i64 want = ((i64)npairs + 63) / 64;
             i64 blocks = ctx->bsw_blocks > 0 ? ctx->bsw_blocks : dev_cus * 16;
             if (blocks > want) blocks = want;
-            hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
+            // classes whose queries are longer than the band is wide keep 2w + 2 columns in a ring instead of one word per query column
+            // (round 6: 53 KB per wavefront at w = 100 -- three wavefronts per CU -- where the 222 / 318 / 600-column classes hold two / one / one)
+            const int ring = ((2 * (w > 0 ? w : 0) + 4 + 3) / 4) * 4;        // >= 2w + 2 columns (w = 100: 204 columns = 52 224 bytes, three wavefronts in a CU's 160 KB)
+            if (ctx->bsw_circ != 0 && ring < qhi + 2) {
+                const size_t lds = (size_t)ring * 64 * sizeof(unsigned int);
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane_circ, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                LaneCircArgs LC;
+                LC.L = L; LC.C = ring;
+                hipLaunchKernelGGL(k_bsw_lane_circ, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, LC);
+            } else {
+                const size_t lds = (size_t)(qhi + 2) * 64 * sizeof(unsigned int);
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void*)k_bsw_lane, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_bsw_lane, dim3((unsigned)blocks), dim3(64), lds, ctx->stream, L);
+            }
             HIP_TRY(hipGetLastError());
             if (one_launch) break;
         }

@@ -77,6 +77,7 @@ struct meme_ctx {
     i64 seed_blocks_per_cu = 5;
     i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
                                        // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
+    i64 bsw_circ = 1;                  // 1: lane-per-pair banded SW of queries longer than 2w + 2 columns keeps its columns in a ring (k_bsw_lane_circ); 0: a word per query column
     i64 sam_max_batch = 0;             // > 0: meme_sam_format_batch_host refuses more record slots than this with MEME_E_CAPACITY (the caller then formats in pieces)
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches
     i64 ext_live_only = 0;             // 1: meme_extend_last_batch_host hands over the surviving records only (qe > qb: what src/bwamem.cpp:1680-1693 keeps)

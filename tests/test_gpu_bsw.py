@@ -107,3 +107,25 @@ def test_hip_bsw_queries_beyond_the_lds_resident_limit(ctx):
         got = pairs.copy()
         ctx.bsw_batch(got, ref, qer, w, _opt(5))
         assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want)), w
+
+
+@pytest.mark.parametrize("w", [100, 40, 200, 7])
+def test_ring_of_band_columns_equals_a_word_per_query_column(w):
+    """Round 6: queries longer than the band is wide keep 2w + 2 columns in a ring (k_bsw_lane_circ, tuning "bsw_circ", the default) instead of one LDS word
+    per query column: same six outputs as the oracle and as the linear kernel, for every class the ring replaces -- long targets (the band slides the
+    whole query length), large h0 (first-row values beyond the ring's first fill), gaps that re-grow the band, unrelated pairs (early exits)."""
+    c = hipapi.Context(0)
+    try:
+        c.set_tuning("bsw_lane_min_pairs", 0)
+        for kw in (dict(max_q=600, min_q=150), dict(max_q=600, min_q=230, sub=0.06, indel=0.03), dict(max_q=420, min_q=200, h0_max=900),
+                   dict(max_q=320, min_q=100, sub=0.3, unrelated_frac=0.5), dict(max_q=600, min_q=1, h0_max=60)):
+            pairs, ref, qer = bsw_gen.make_pairs(3000, seed=61 + w, **kw)
+            want = pairs.copy()
+            O.bsw_batch(want, ref, qer, w, O.default_bsw_params(5), threads=0)
+            for circ in (1, 0):
+                c.set_tuning("bsw_circ", circ)
+                got = pairs.copy()
+                c.bsw_batch(got, ref, qer, w, _opt(5))
+                assert np.array_equal(bsw_gen.outputs(got), bsw_gen.outputs(want)), (kw, w, circ)
+    finally:
+        c.close()
