@@ -74,7 +74,13 @@ ALNREG = np.dtype({"names": ["rb", "re", "qb", "qe", "rid", "c", "score", "trues
                    "formats": ["<i8", "<i8", "<i4", "<i4", "<i4", "<u8"] + ["<i4"] * 12 + ["<f4", "<u8", "<i4"],
                    "offsets": [0, 8, 16, 20, 24, 32] + [40 + 4 * k for k in range(12)] + [88, 96, 104], "itemsize": 112})
 
-GJOB = np.dtype([("rb", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("rev", "<i4")])
+def records_equal(a, b):
+    """Field-by-field equality of two arrays of one structured dtype (numpy does not copy the padding bytes of a padded record type, so the
+    raw bytes of two equal arrays differ in whatever the allocator left there)."""
+    return a.dtype == b.dtype and a.shape == b.shape and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+GJOB = np.dtype([(""rb", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("rev", "<i4")])
 GRES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar_off", "<i8")])
 assert GJOB.itemsize == 32 and GRES.itemsize == 16
 

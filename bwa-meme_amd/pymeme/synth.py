@@ -22,7 +22,8 @@ _ALPHA = np.frombuffer(b"ACGTN", dtype=np.uint8)
 def make_genome(n_bases: int, seed: int = 11, repeat_frac: float = 0.02, repeat_len: int = 300,
                 n_families: int = 20, divergence: float = 0.03, n_dups: int = 8,
                 dup_len: int = 2000, poly_runs: int = 4, satellites: int = 0, sat_unit: int = 171,
-                sat_copies: int = 300, sat_divergence: float = 0.02) -> np.ndarray:
+                sat_copies: int = 300, sat_divergence: float = 0.02, young_frac: float = 0.0,
+                young_families: int = 6, young_divergence: float = 0.03) -> np.ndarray:
     """Return a uint8 array of codes 0..3 of length ``n_bases``.  ``satellites`` > 0 (the repeat-dense workloads) plants that many
     tandem arrays -- ``sat_copies`` copies of a ``sat_unit``-base monomer, each copy diverged by ``sat_divergence`` -- AFTER everything
     else, so that the genomes of existing seeds do not change."""
@@ -63,6 +64,18 @@ def make_genome(n_bases: int, seed: int = 11, repeat_frac: float = 0.02, repeat_
         arr[mut] = (arr[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
         s = int(rng.integers(0, n_bases - L))
         g[s:s + L] = arr
+    # young repeat families (the repeat-dense workloads): copies a few per cent from their consensus, so that 19-mers ARE shared between
+    # hundreds of copies -- seeds with hit lists beyond max_occ, reads whose SMEM slots overflow (planted last: existing seeds unchanged)
+    if young_frac > 0:
+        yf = rng.integers(0, 4, size=(young_families, repeat_len), dtype=np.uint8)
+        n_copies = int(n_bases * young_frac / repeat_len)
+        starts = rng.integers(0, n_bases - repeat_len, size=n_copies)
+        fam_id = rng.integers(0, young_families, size=n_copies)
+        mut = rng.random((n_copies, repeat_len)) < young_divergence
+        shift = rng.integers(1, 4, size=(n_copies, repeat_len), dtype=np.uint8)
+        copies = np.where(mut, (yf[fam_id] + shift) & 3, yf[fam_id]).astype(np.uint8)
+        for k in range(n_copies):
+            g[starts[k]:starts[k] + repeat_len] = copies[k]
     return g
 
 

@@ -34,7 +34,7 @@ for rounds in [int(x) for x in os.environ.get("PROBE_ROUNDS", "1,0,2").split(","
     want_off = np.concatenate([[0], np.cumsum(keepm.astype(np.int64))])[ro]
     same_off = np.array_equal(lro, want_off)
     want = regs[keepm]
-    print("ext_rounds=%d: records %d (expected %d), offsets equal %s, bytes equal %s" % (rounds, lregs.shape[0], want.shape[0], same_off, lregs.tobytes() == want.tobytes()), flush=True)
+    print("ext_rounds=%d: records %d (expected %d), offsets equal %s, bytes equal %s" % (rounds, lregs.shape[0], want.shape[0], same_off, hipapi.records_equal(lregs, want)), flush=True)
     bad = np.nonzero(np.diff(lro) != np.diff(want_off))[0]
     print("  reads whose number of surviving records differs: %d" % bad.shape[0])
     if same_off:
