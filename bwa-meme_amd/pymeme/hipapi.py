@@ -80,7 +80,7 @@ def records_equal(a, b):
     return a.dtype == b.dtype and a.shape == b.shape and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
 
 
-GJOB = np.dtype([(""rb", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("rev", "<i4")])
+GJOB = np.dtype([("rb", "<i8"), ("read", "<i4"), ("qb", "<i4"), ("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("rev", "<i4")])
 GRES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("cigar_off", "<i8")])
 assert GJOB.itemsize == 32 and GRES.itemsize == 16
 
