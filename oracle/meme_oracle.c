@@ -1696,3 +1696,84 @@ int orc_kswv_batch(const orc_kswv_job* jobs, int64_t n, const uint8_t* ref, cons
     if (cells) *cells = total;
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Mate rescue, the posing step (see meme_oracle.h): mem_sam_pe_batch_pre (src/bwamem_pair.cpp:660-716) + mem_matesw_batch_pre (:1060-1223).
+ * ------------------------------------------------------------------------------------------------ */
+static int o_infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t* dist) {      /* mem_infer_dir, :58-65 */
+    const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+    const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+    *dist = p2 > b1 ? p2 - b1 : b1 - p2;
+    return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+int64_t orc_matesw_pose(const orc_mate_reg* regs, const int64_t* reg_off, int64_t first, int64_t count, const int32_t* read_len, const orc_pestat* pes,
+                        int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs, const orc_mate_opt* opt,
+                        int32_t* gar, int64_t gar_cap, int64_t* n_gar, orc_mate_job* jobs, int64_t job_cap) {
+    int64_t pcnt = 0, gcnt = 0;
+    for (int64_t p = first; p + 1 < first + count; p += 2) {                /* worker_sam's loop over the batch's pairs (src/bwamem.cpp:1855-1866) */
+        for (int i = 0; i < 2; ++i) {                                        /* :694-706 */
+            const int64_t r = p + i, m = p + (1 - i);
+            const orc_mate_reg* a = regs + reg_off[r];
+            const int64_t na = reg_off[r + 1] - reg_off[r];
+            const orc_mate_reg* ma = regs + reg_off[m];
+            const int64_t nm = reg_off[m + 1] - reg_off[m];
+            const int l_ms = read_len[m];
+            int taken = 0;
+            for (int64_t j = 0; j < na && taken < opt->max_matesw; ++j) {     /* b[i] = the records within pen_unpaired of the best (:688-692), the first max_matesw of them (:696) */
+                if (!(a[j].score >= a[0].score - opt->pen_unpaired)) continue;
+                ++taken;
+                if (gcnt + 4 > gar_cap) return -1;
+                int skip[4];
+                for (int o = 0; o < 4; ++o) skip[o] = pes[o].failed ? 1 : 0;            /* :1081-1083 */
+                for (int64_t k = 0; k < nm; ++k) {                                      /* :1085-1091 */
+                    int64_t dist;
+                    const int o = o_infer_dir(l_pac, a[j].rb, ma[k].rb, &dist);
+                    if (dist >= pes[o].low && dist <= pes[o].high) skip[o] = 1;
+                }
+                if (skip[0] + skip[1] + skip[2] + skip[3] == 4) { for (int o = 0; o < 4; ++o) gar[gcnt + o] = -1; gcnt += 4; continue; }   /* :1094-1098 */
+                int rid = -1;                                                           /* (kept across the orientations, as in the reference: :1080) */
+                for (int o = 0; o < 4; ++o) {
+                    if (skip[o]) { gar[gcnt + o] = -1; continue; }
+                    const int is_rev = (o >> 1) != (o & 1), is_larger = !(o >> 1);      /* :1108-1109 */
+                    int64_t rb, re;
+                    if (!is_rev) {                                                      /* :1118-1125 */
+                        rb = is_larger ? a[j].rb + pes[o].low : a[j].rb - pes[o].high;
+                        re = (is_larger ? a[j].rb + pes[o].high : a[j].rb - pes[o].low) + l_ms;
+                    } else {
+                        rb = (is_larger ? a[j].rb + pes[o].low : a[j].rb - pes[o].high) - l_ms;
+                        re = is_larger ? a[j].rb + pes[o].high : a[j].rb - pes[o].low;
+                    }
+                    if (rb < 0) rb = 0;
+                    if (re > l_pac << 1) re = l_pac << 1;
+                    if (rb < re) {                                                      /* bns_fetch_seq (:1129; src/bntseq.cpp:541-570) */
+                        const int64_t mid = (rb + re) >> 1;
+                        const int mrev = mid >= l_pac;
+                        rid = o_pos2rid(contig_off, n_contigs, l_pac, mrev ? (l_pac << 1) - 1 - mid : mid);
+                        int64_t far_beg = contig_off[rid], far_end = far_beg + contig_len[rid];
+                        if (mrev) { const int64_t t = far_beg; far_beg = (l_pac << 1) - far_end; far_end = (l_pac << 1) - t; }
+                        rb = rb > far_beg ? rb : far_beg;
+                        re = re < far_end ? re : far_end;
+                    }
+                    if (a[j].rid == rid && re - rb >= opt->min_seed_len) {              /* :1131-1218 */
+                        if (pcnt >= job_cap) return -1;
+                        orc_mate_job J;
+                        J.rb = rb; J.read = (int32_t)m; J.len1 = (int32_t)(re - rb); J.len2 = l_ms; J.is_rev = is_rev; J.pad = 0;
+                        J.xtra = 0x40000 | 0x80000 | (l_ms * opt->a < 250 ? 0x10000 : 0) | (opt->min_seed_len * opt->a);     /* KSW_XSUBO | KSW_XSTART | KSW_XBYTE | threshold, :1135 */
+                        gar[gcnt + o] = (int32_t)pcnt;
+                        jobs[pcnt++] = J;
+                    } else gar[gcnt + o] = -1;     /* (the reference leaves the entry as it was -- mem_sam_pe_batch_post only looks at entries of orientations it knows were posed; -1 here so that the arrays compare) */
+                }
+                gcnt += 4;
+            }
+        }
+    }
+    *n_gar = gcnt;
+    return pcnt;
+}
+
+void orc_matesw_job_seqs(const orc_mate_job* j, const uint8_t* text, const uint8_t* reads, const int64_t* read_off, uint8_t* ref, uint8_t* qer) {
+    for (int l = 0; l < j->len1; ++l) ref[l] = text[j->rb + l];                       /* bns_get_seq: bases [rb, re) of the fwd+rc text */
+    const uint8_t* ms = reads + read_off[j->read];
+    for (int l = 0; l < j->len2; ++l) qer[l] = j->is_rev ? (ms[j->len2 - 1 - l] < 4 ? 3 - ms[j->len2 - 1 - l] : 4) : ms[l];      /* :1111-1116 */
+}

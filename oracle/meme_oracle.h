@@ -171,6 +171,27 @@ void orc_kswv_pair(const uint8_t* target, int tlen, const uint8_t* query, int ql
 int orc_kswv_batch(const orc_kswv_job* jobs, int64_t n, const uint8_t* ref, const uint8_t* qer, int a, int b, int o_del, int e_del, int o_ins, int e_ins,
                    orc_kswr* out, int threads, int64_t* cells);
 
+
+/* ---- mate rescue, the posing step: mem_sam_pe_batch_pre (reference src/bwamem_pair.cpp:660-716) with mem_matesw_batch_pre (:1060-1223) --------
+ * For the read pairs of one worker batch (reads [first, first + count), count even; pair = two consecutive reads): which Smith-Waterman jobs
+ * worker_sam's first step poses -- per end i of a pair its alignment records with score >= (best score - pen_unpaired), at most max_matesw of them,
+ * each against the windows of the four orientations that the insert-size statistics allow and no record of the mate already explains
+ * (mem_infer_dir :58-65, skip[] :1082-1097), the window clamped to the strand and the reference sequence of its midpoint (bns_fetch_seq,
+ * src/bntseq.cpp:541-570), kept when it lies on the record's sequence and holds at least min_seed_len bases (:1134).
+ * regs[reg_off[r] .. reg_off[r+1]): the fields of read r's mem_alnreg_t records the step reads.  Outputs in the step's own order:
+ *   gar[4 * q + o]   for the q-th (end, record) the step looks at: index of the job of orientation o among the BATCH's jobs, or -1
+ *   jobs[k]          len1 (window), len2 (mate length), xtra (:1135), rb (window start in fwd+rc coordinates), read (the mate's index), is_rev
+ * Returns the number of jobs; *n_gar receives the number of gar entries (4 per (end, record)).  text = fwd+rc bases (1 byte each). */
+typedef struct { int64_t rb; int32_t rid, score; } orc_mate_reg;
+typedef struct { int32_t low, high, failed, pad; } orc_pestat;
+typedef struct { int32_t a, pen_unpaired, max_matesw, min_seed_len; } orc_mate_opt;
+typedef struct { int64_t rb; int32_t read, len1, len2, xtra, is_rev, pad; } orc_mate_job;
+int64_t orc_matesw_pose(const orc_mate_reg* regs, const int64_t* reg_off, int64_t first, int64_t count, const int32_t* read_len, const orc_pestat* pes /* 4 */,
+                        int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs, const orc_mate_opt* opt,
+                        int32_t* gar, int64_t gar_cap, int64_t* n_gar, orc_mate_job* jobs, int64_t job_cap);
+/* the sequences of one posed job as the step stores them: `ref` = text[rb, rb + len1), `qer` = the mate (reversed and complemented when is_rev) */
+void orc_matesw_job_seqs(const orc_mate_job* j, const uint8_t* text, const uint8_t* reads, const int64_t* read_off, uint8_t* ref, uint8_t* qer);
+
 #ifdef __cplusplus
 }
 #endif

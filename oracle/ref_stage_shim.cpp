@@ -33,6 +33,8 @@ void mem_chain_Learned(const mem_opt_t* opt, const bntseq_t* bns, int len, mem_t
                        mem_seed_t* seedBuf, int64_t seedBufSize, int64_t& seedBufCount, int tid);
 int mem_chain_flt(const mem_opt_t* opt, int n_chn_, mem_chain_t* a_, int tid);
 int64_t sort_classify(mem_cache* mmc, int64_t pcnt, int tid);
+int mem_sam_pe_batch_pre(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, const mem_pestat_t pes[4], uint64_t id, bseq1_t s[2], mem_alnreg_v a[2], mem_cache* mmc,
+                         int64_t& pcnt, int32_t& gcnt, int32_t& maxRefLen, int32_t& maxQerLen, int tid);
 void mem_flt_chained_seeds(const mem_opt_t* opt, const bntseq_t* bns, const uint8_t* pac, bseq1_t* seq_, int n_chn, mem_chain_t* a);
 
 #define shim_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
@@ -407,6 +409,74 @@ int ref_kswv_batch(const shim_kswv_job* jobs, int64_t n, const uint8_t* ref, int
     (void)jobs; (void)n; (void)ref; (void)ref_bytes; (void)qer; (void)qer_bytes; (void)a; (void)b; (void)o_del; (void)e_del; (void)o_ins; (void)e_ins; (void)out;
     return -1;          // the batched kernels only exist in the AVX-512 build (src/bwamem.cpp:1838: other builds run mem_sam_pe / ksw_align2)
 #endif
+}
+
+
+// ---- the posing step of mate rescue exactly as worker_sam runs it for one worker batch (src/bwamem.cpp:1855-1866): mem_sam_pe_batch_pre
+// (src/bwamem_pair.cpp:660-716) -> mem_matesw_batch_pre (:1060-1223) per pair, into a mem_cache of the shim's own.  regs: the fields of the
+// reads' alignment records the step reads.  Outputs: gar (the step's job index array, -1 where it wrote nothing), the SeqPair jobs it posed
+// (idr, idq, len1, len2, h0 as xtra) and the two sequence buffers.
+struct shim_mate_reg { int64_t rb; int32_t rid, score; };
+int64_t ref_matesw_pose(const uint8_t* fwd, int64_t l_pac, const int64_t* contig_off, const int32_t* contig_len, int n_contigs, const uint8_t* reads,
+                        const int64_t* read_off, int64_t first, int64_t count, const shim_mate_reg* regs, const int64_t* reg_off, const int32_t* pes_lhf /* 4 x {low, high, failed} */,
+                        int a, int pen_unpaired, int max_matesw, int min_seed_len, int32_t* gar, int64_t gar_cap, int64_t* n_gar, shim_kswv_job* jobs, int64_t job_cap,
+                        uint8_t* ref_out, int64_t ref_cap, int64_t* ref_bytes, uint8_t* qer_out, int64_t qer_cap, int64_t* qer_bytes) {
+    Bns bns(contig_off, contig_len, nullptr, n_contigs, l_pac);
+    std::vector<uint8_t> pac((size_t)(l_pac / 4 + 1), 0);
+    for (int64_t i = 0; i < l_pac; ++i) pac[(size_t)(i >> 2)] |= (uint8_t)((fwd[i] & 3) << ((~i & 3) << 1));
+    mem_opt_t* opt = mem_opt_init();
+    opt->a = a; opt->pen_unpaired = pen_unpaired; opt->max_matesw = max_matesw; opt->min_seed_len = min_seed_len;
+    bwa_fill_scmat(opt->a, opt->b, opt->mat);
+    mem_pestat_t pes[4];
+    memset(pes, 0, sizeof(pes));
+    for (int r = 0; r < 4; ++r) { pes[r].low = pes_lhf[3 * r]; pes[r].high = pes_lhf[3 * r + 1]; pes[r].failed = pes_lhf[3 * r + 2]; }
+    mem_cache* mmc = (mem_cache*)calloc(1, sizeof(mem_cache));
+    const size_t cap = (size_t)job_cap + 2 * MAX_LINE_LEN + 128;
+    mmc->seqPairArrayLeft128[0] = (SeqPair*)calloc(cap, sizeof(SeqPair));
+    mmc->seqPairArrayRight128[0] = (SeqPair*)calloc(cap, sizeof(SeqPair));
+    const size_t gar_pairs = ((size_t)gar_cap * 4 + sizeof(SeqPair) - 1) / sizeof(SeqPair) + cap;
+    mmc->seqPairArrayAux[0] = (SeqPair*)malloc(gar_pairs * sizeof(SeqPair));
+    memset(mmc->seqPairArrayAux[0], 0xff, gar_pairs * sizeof(SeqPair));                  // (-1 wherever the step does not write)
+    uint8_t* r = (uint8_t*)_mm_malloc((size_t)ref_cap + 4096, 64);
+    uint8_t* q = (uint8_t*)_mm_malloc((size_t)qer_cap + 4096, 64);
+    mmc->seqBufLeftRef[0] = r; mmc->seqBufLeftQer[0] = q;
+    mmc->seqBufRightRef[0] = (uint8_t*)_mm_malloc(64, 64); mmc->seqBufRightQer[0] = (uint8_t*)_mm_malloc(64, 64);
+    mmc->wsize[0] = (int64_t)job_cap; mmc->wsize_buf_ref[0] = ref_cap; mmc->wsize_buf_qer[0] = qer_cap;     // (sized by the caller so that the step never reallocates)
+    int64_t pcnt = 0;
+    int32_t gcnt = 0, maxRef = 0, maxQer = 0;
+    for (int64_t p = first; p + 1 < first + count; p += 2) {
+        bseq1_t s[2];
+        mem_alnreg_v av[2];
+        memset(s, 0, sizeof(s));
+        for (int i = 0; i < 2; ++i) {
+            const int64_t rd = p + i;
+            s[i].seq = (char*)(reads + read_off[rd]);
+            s[i].l_seq = (int)(read_off[rd + 1] - read_off[rd]);
+            const int64_t n = reg_off[rd + 1] - reg_off[rd];
+            kv_init(av[i]);
+            av[i].n = av[i].m = (size_t)n;
+            av[i].a = (mem_alnreg_t*)calloc((size_t)(n ? n : 1), sizeof(mem_alnreg_t));
+            for (int64_t k = 0; k < n; ++k) { av[i].a[k].rb = regs[reg_off[rd] + k].rb; av[i].a[k].rid = regs[reg_off[rd] + k].rid; av[i].a[k].score = regs[reg_off[rd] + k].score; }
+        }
+        mem_sam_pe_batch_pre(opt, &bns.b, pac.data(), pes, (uint64_t)(p >> 1), s, av, mmc, pcnt, gcnt, maxRef, maxQer, 0);
+        free(av[0].a); free(av[1].a);
+        if (pcnt > job_cap || gcnt > gar_cap) return -1;
+    }
+    const int32_t* g = (const int32_t*)mmc->seqPairArrayAux[0];
+    for (int32_t k = 0; k < gcnt; ++k) gar[k] = g[k];
+    *n_gar = gcnt;
+    const SeqPair* sp = mmc->seqPairArrayLeft128[0];
+    int64_t rb = 0, qb = 0;
+    for (int64_t k = 0; k < pcnt; ++k) {
+        jobs[k].idr = sp[k].idr; jobs[k].idq = sp[k].idq; jobs[k].len1 = sp[k].len1; jobs[k].len2 = sp[k].len2; jobs[k].xtra = sp[k].h0; jobs[k].pad = 0;
+        rb = sp[k].idr + sp[k].len1; qb = sp[k].idq + sp[k].len2;
+    }
+    memcpy(ref_out, mmc->seqBufLeftRef[0], (size_t)rb); memcpy(qer_out, mmc->seqBufLeftQer[0], (size_t)qb);
+    *ref_bytes = rb; *qer_bytes = qb;
+    _mm_free(mmc->seqBufLeftRef[0]); _mm_free(mmc->seqBufLeftQer[0]); _mm_free(mmc->seqBufRightRef[0]); _mm_free(mmc->seqBufRightQer[0]);
+    free(mmc->seqPairArrayLeft128[0]); free(mmc->seqPairArrayRight128[0]); free(mmc->seqPairArrayAux[0]);
+    free(mmc); free(opt);
+    return pcnt;
 }
 
 }  // extern "C"

@@ -448,3 +448,70 @@ def sam_workload(n=1500, seed=301, read_len=(30, 251)):
             blob.extend(b"chr2_random,-%d,100M50S,%d;c,+17,150M,0;" % (int(rng.integers(1, 10 ** 8)), int(rng.integers(0, 30)))); blob.append(0)
     pad()
     return recs, np.frombuffer(bytes(blob), dtype=np.uint8).copy(), names, reads, quals, contigs
+
+
+def matesw_pose_workload(seed=301, n_pairs=600, l_pac=240_000, n_contigs=3, read_len=(100, 251), pes=None):
+    """Read pairs with alignment records the way worker_sam's first step meets them (after mem_sort_dedup_patch: best score first): most ends have a
+    record at their origin, some have several (a near-best second one within pen_unpaired, low-scoring ones beyond it), some none; mates are
+    consistent with the insert-size statistics, or on the wrong strand / too far / on another sequence / missing -- so that every branch of
+    mem_matesw_batch_pre (src/bwamem_pair.cpp:1060-1223) is taken: orientations skipped because a mate record explains them, all four skipped,
+    windows clipped at a sequence end or the strand boundary, windows that end up on another sequence (no job), windows shorter than min_seed_len.
+    Returns dict(genome, text, contig_off, contig_len, reads, read_off, read_len, regs, reg_off, pes)."""
+    from oracle_py import MATE_REG_DTYPE
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size=l_pac, dtype=np.uint8)
+    text = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+    cuts = np.sort(rng.choice(np.arange(2000, l_pac - 2000), size=n_contigs - 1, replace=False))
+    contig_off = np.concatenate([[0], cuts]).astype(np.int64)
+    contig_len = np.diff(np.concatenate([contig_off, [l_pac]])).astype(np.int32)
+    if pes is None:
+        pes = [(0, 0, 1), (120, 680, 0), (0, 0, 1), (0, 0, 1)]                 # the usual paired-end library: only FR passes
+    reads, lens, regs, reg_off = [], [], [], [0]
+    for p in range(n_pairs):
+        L1, L2 = int(rng.integers(*read_len)), int(rng.integers(*read_len))
+        ins = int(rng.integers(150, 650))
+        kind = p % 12
+        pos = int(rng.integers(0, l_pac - 1500))
+        if kind == 9:
+            pos = int(rng.choice([0, 30, l_pac - 400, int(contig_off[1]) - 200, int(contig_off[1]) + 5]))       # windows clipped at sequence ends
+            pos = max(0, min(pos, l_pac - 300))
+        strand = int(rng.integers(0, 2))
+        ends = []
+        for e, Lr in ((0, L1), (1, L2)):
+            fpos = pos if e == 0 else min(l_pac - Lr - 1, pos + ins)
+            rd = g[fpos:fpos + Lr].copy()
+            m = rng.random(Lr) < 0.02
+            rd[m] = (rd[m] + 1) & 3
+            if rng.random() < 0.05:
+                rd[rng.integers(0, Lr)] = 4
+            rev = (e == 1) ^ (strand == 1)
+            if rev:
+                rd = np.where(rd < 4, 3 - rd, 4)[::-1].astype(np.uint8)
+            rb = (2 * l_pac - (fpos + Lr)) if rev else fpos
+            ends.append((rd, rb, Lr, fpos))
+        for e, (rd, rb, Lr, fpos) in enumerate(ends):
+            reads.append(rd); lens.append(Lr)
+            recs = []
+            rid = int(np.searchsorted(contig_off, fpos, side="right") - 1)
+            if not (kind == 1 and e == 1) and not (kind == 2):                   # kind 1: the mate has no record; kind 2: neither end has
+                recs.append((rb, rid, int(Lr - rng.integers(0, 12))))
+            if kind == 3 and e == 1:                                             # the mate lies on the wrong strand / far away / on another sequence
+                far = int(rng.integers(0, 2 * l_pac - 300))
+                frid = int(np.searchsorted(contig_off, far if far < l_pac else 2 * l_pac - 1 - far, side="right") - 1)
+                recs = [(far, frid, int(Lr - 5))]
+            if kind in (4, 5, 6):                                                # several records: near-best ones are looked at too, the rest are not
+                for _ in range(int(rng.integers(1, 5))):
+                    far = int(rng.integers(0, 2 * l_pac - 300))
+                    frid = int(np.searchsorted(contig_off, far if far < l_pac else 2 * l_pac - 1 - far, side="right") - 1)
+                    recs.append((far, frid, int(Lr - rng.integers(0, 40))))
+            if kind == 7 and recs:
+                recs[0] = (recs[0][0], (recs[0][1] + 1) % n_contigs, recs[0][2])     # a record whose rid is not the window's sequence: no job
+            recs.sort(key=lambda x: -x[2])
+            regs += recs
+            reg_off.append(len(regs))
+    read_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    R = np.zeros(len(regs), MATE_REG_DTYPE)
+    for k, (rb, rid, sc) in enumerate(regs):
+        R[k] = (rb, rid, sc)
+    return dict(genome=g, text=text, l_pac=l_pac, contig_off=contig_off, contig_len=contig_len, reads=np.concatenate(reads).astype(np.uint8), read_off=read_off,
+                read_len=np.array(lens, np.int32), regs=R, reg_off=np.array(reg_off, np.int64), pes=np.array(pes, np.int32))

@@ -403,3 +403,52 @@ def kswv_batch(jobs, ref, qer, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, thr
                      C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_void_p(out.ctypes.data), C.c_int(threads or (os.cpu_count() or 1)),
                      C.byref(cells))
     return out, cells.value
+
+
+# ---- mate rescue, the posing step (orc_matesw_pose: mem_sam_pe_batch_pre + mem_matesw_batch_pre, reference src/bwamem_pair.cpp:660-716, 1060-1223) ----
+MATE_REG_DTYPE = np.dtype([("rb", "<i8"), ("rid", "<i4"), ("score", "<i4")])
+MATE_JOB_DTYPE = np.dtype([("rb", "<i8"), ("read", "<i4"), ("len1", "<i4"), ("len2", "<i4"), ("xtra", "<i4"), ("is_rev", "<i4"), ("pad", "<i4")])
+assert MATE_REG_DTYPE.itemsize == 16 and MATE_JOB_DTYPE.itemsize == 32
+
+
+def matesw_pose(regs, reg_off, first, count, read_len, pes, l_pac, contig_off, contig_len, a=1, pen_unpaired=17, max_matesw=50, min_seed_len=19):
+    """One worker batch: reads [first, first + count).  pes: 4 x (low, high, failed).  Returns (gar int32 array, jobs MATE_JOB_DTYPE)."""
+    L = lib()
+    L.orc_matesw_pose.restype = C.c_int64
+    regs = np.ascontiguousarray(regs, dtype=MATE_REG_DTYPE)
+    reg_off = np.ascontiguousarray(reg_off, dtype=np.int64)
+    read_len = np.ascontiguousarray(read_len, dtype=np.int32)
+    pes4 = np.zeros((4, 4), np.int32)
+    pes4[:, :3] = np.asarray(pes, np.int32).reshape(4, 3)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+    opt = np.array([a, pen_unpaired, max_matesw, min_seed_len], np.int32)
+    nrec = int(reg_off[first + count] - reg_off[first])
+    gar = np.full(4 * nrec + 8, -7, np.int32)
+    jobs = np.zeros(4 * nrec + 8, MATE_JOB_DTYPE)
+    n_gar = C.c_int64(0)
+    n = L.orc_matesw_pose(C.c_void_p(regs.ctypes.data), C.c_void_p(reg_off.ctypes.data), C.c_int64(first), C.c_int64(count), C.c_void_p(read_len.ctypes.data),
+                          C.c_void_p(pes4.ctypes.data), C.c_int64(l_pac), C.c_void_p(contig_off.ctypes.data), C.c_void_p(contig_len.ctypes.data), C.c_int(contig_off.shape[0]),
+                          C.c_void_p(opt.ctypes.data), C.c_void_p(gar.ctypes.data), C.c_int64(gar.shape[0]), C.byref(n_gar), C.c_void_p(jobs.ctypes.data), C.c_int64(jobs.shape[0]))
+    assert n >= 0
+    return gar[:n_gar.value].copy(), jobs[:n].copy()
+
+
+def matesw_job_seqs(jobs, text, reads, read_off):
+    """The jobs' sequences back to back, as the step stores them: (KSWV_JOB_DTYPE jobs with idr / idq, ref bytes, query bytes)."""
+    L = lib()
+    L.orc_matesw_job_seqs.restype = None
+    jobs = np.ascontiguousarray(jobs, dtype=MATE_JOB_DTYPE)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    kj = np.zeros(jobs.shape[0], KSWV_JOB_DTYPE)
+    kj["len1"], kj["len2"], kj["xtra"] = jobs["len1"], jobs["len2"], jobs["xtra"]
+    kj["idr"][1:] = np.cumsum(jobs["len1"].astype(np.int64))[:-1]
+    kj["idq"][1:] = np.cumsum(jobs["len2"].astype(np.int64))[:-1]
+    ref = np.zeros(int(jobs["len1"].astype(np.int64).sum()) + 8, np.uint8)
+    qer = np.zeros(int(jobs["len2"].astype(np.int64).sum()) + 8, np.uint8)
+    for k in range(jobs.shape[0]):
+        L.orc_matesw_job_seqs(C.c_void_p(jobs[k:k + 1].ctypes.data), C.c_void_p(text.ctypes.data), C.c_void_p(reads.ctypes.data), C.c_void_p(read_off.ctypes.data),
+                              C.c_void_p(ref.ctypes.data + int(kj["idr"][k])), C.c_void_p(qer.ctypes.data + int(kj["idq"][k])))
+    return kj, ref[:-8], qer[:-8]

@@ -220,3 +220,32 @@ def kswv_batch(jobs, ref, qer, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1):
                           C.c_int64(qer.shape[0]), C.c_int(a), C.c_int(b), C.c_int(o_del), C.c_int(e_del), C.c_int(o_ins), C.c_int(e_ins), C.c_void_p(out.ctypes.data))
     assert rc == 0
     return out
+
+
+def matesw_pose(fwd, l_pac, contig_off, contig_len, reads, read_off, first, count, regs, reg_off, pes, a=1, pen_unpaired=17, max_matesw=50, min_seed_len=19):
+    """The compiled reference's mem_sam_pe_batch_pre over one worker batch (oracle/ref_stage_shim.cpp ref_matesw_pose): (gar, jobs KSWV_JOB_DTYPE, ref bytes, query bytes)."""
+    from oracle_py import KSWV_JOB_DTYPE, MATE_REG_DTYPE
+    L = stage_lib()
+    L.ref_matesw_pose.restype = C.c_int64
+    fwd = np.ascontiguousarray(fwd, dtype=np.uint8)
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+    regs = np.ascontiguousarray(regs, dtype=MATE_REG_DTYPE)
+    reg_off = np.ascontiguousarray(reg_off, dtype=np.int64)
+    contig_off = np.ascontiguousarray(contig_off, dtype=np.int64)
+    contig_len = np.ascontiguousarray(contig_len, dtype=np.int32)
+    pes = np.ascontiguousarray(np.asarray(pes, np.int32).reshape(4, 3))
+    nrec = int(reg_off[first + count] - reg_off[first])
+    cap = 4 * nrec + 64
+    gar = np.zeros(cap, np.int32)
+    jobs = np.zeros(cap, KSWV_JOB_DTYPE)
+    ref = np.zeros(cap * 1400 + 4096, np.uint8)
+    qer = np.zeros(cap * 520 + 4096, np.uint8)
+    n_gar, rbytes, qbytes = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    n = L.ref_matesw_pose(C.c_void_p(fwd.ctypes.data), C.c_int64(l_pac), C.c_void_p(contig_off.ctypes.data), C.c_void_p(contig_len.ctypes.data), C.c_int(contig_off.shape[0]),
+                          C.c_void_p(reads.ctypes.data), C.c_void_p(read_off.ctypes.data), C.c_int64(first), C.c_int64(count), C.c_void_p(regs.ctypes.data),
+                          C.c_void_p(reg_off.ctypes.data), C.c_void_p(pes.ctypes.data), C.c_int(a), C.c_int(pen_unpaired), C.c_int(max_matesw), C.c_int(min_seed_len),
+                          C.c_void_p(gar.ctypes.data), C.c_int64(cap), C.byref(n_gar), C.c_void_p(jobs.ctypes.data), C.c_int64(cap), C.c_void_p(ref.ctypes.data),
+                          C.c_int64(ref.shape[0] - 4096), C.byref(rbytes), C.c_void_p(qer.ctypes.data), C.c_int64(qer.shape[0] - 4096), C.byref(qbytes))
+    assert n >= 0
+    return gar[:n_gar.value].copy(), jobs[:n].copy(), ref[:rbytes.value].copy(), qer[:qbytes.value].copy()

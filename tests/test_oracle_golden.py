@@ -289,3 +289,28 @@ def test_kswv_oracle_equals_reference_golden():
         bad = np.nonzero((got != G[name]).any(axis=1))[0]
         assert bad.size == 0, (name, int(bad[0]), got[bad[0]].tolist(), G[name][bad[0]].tolist())
         assert cells > 0
+
+
+def test_matesw_pose_oracle_equals_reference_golden():
+    """The posing step of mate rescue (orc_matesw_pose: mem_sam_pe_batch_pre + mem_matesw_batch_pre, reference src/bwamem_pair.cpp:660-716, 1060-1223) against
+    tests/golden/matesw_golden.npz -- the compiled reference's own function over the same alignment records, worker batch by worker batch: the job index
+    array, the jobs' window / query lengths and flags, their sequences (checksums), and the reference's kswv results for them through the oracle's kswv."""
+    import zlib
+    z = np.load(os.path.join(GOLDEN, "matesw_golden.npz"))
+    for tag in ("a", "b"):
+        g = z[tag + "_genome"]
+        text = np.concatenate([g, (3 - g[::-1]).astype(np.uint8)])
+        n = z[tag + "_read_len"].shape[0]
+        for b, first in enumerate(range(0, n, 512)):
+            count = min(512, n - first)
+            gar, jobs = O.matesw_pose(z[tag + "_regs"], z[tag + "_reg_off"], first, count, z[tag + "_read_len"], z[tag + "_pes"], int(z[tag + "_l_pac"]), z[tag + "_contig_off"], z[tag + "_contig_len"])
+            g0, g1 = z[tag + "_gar_off"][b], z[tag + "_gar_off"][b + 1]
+            j0, j1 = z[tag + "_job_off"][b], z[tag + "_job_off"][b + 1]
+            assert np.array_equal(gar, z[tag + "_gar"][g0:g1]), (tag, b)
+            assert jobs.shape[0] == j1 - j0
+            assert np.array_equal(jobs["len1"], z[tag + "_len1"][j0:j1]) and np.array_equal(jobs["len2"], z[tag + "_len2"][j0:j1]) and np.array_equal(jobs["xtra"], z[tag + "_xtra"][j0:j1])
+            kj, ref, qer = O.matesw_job_seqs(jobs, text, z[tag + "_reads"], z[tag + "_read_off"])
+            assert (zlib.crc32(ref.tobytes()), zlib.crc32(qer.tobytes())) == tuple(int(x) for x in z[tag + "_seq_crc"][b]), (tag, b)
+            if jobs.shape[0]:
+                got, _ = O.kswv_batch(kj, ref, qer)
+                assert np.array_equal(got, z[tag + "_kswr"][j0:j1].view(got.dtype).reshape(got.shape) if z[tag + "_kswr"].dtype != got.dtype else z[tag + "_kswr"][j0:j1]), (tag, b)

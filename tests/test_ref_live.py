@@ -287,3 +287,27 @@ def test_refpath_work_counters_match_the_reference_own_counters(tmp_path):
     assert ctr["compares"] - cmp1 <= 8 * (ctr["lookups"] - lines1), (ctr, got)
     assert got[3][1] < cmp1                         # the ISA shortcut saves compares, not searches
     print("MODE 3 / MODE 1 compares: %.3f; restatement / MODE 1: %.4f" % (got[3][1] / cmp1, ctr["compares"] / cmp1))
+
+
+@pytest.mark.skipif(not (ref_py.have("libstage_ref.so") and ref_py.cpu_can_run()), reason="compiled reference (oracle/_ref) not available on this box")
+def test_matesw_pose_oracle_equals_reference_live():
+    """orc_matesw_pose against the compiled reference's mem_sam_pe_batch_pre on other workloads than the fixture's: every orientation allowed, none allowed,
+    narrow and wide insert-size bounds, short reads (windows below min_seed_len), other max_matesw / pen_unpaired / min_seed_len."""
+    import oracle_py as O
+    from common import matesw_pose_workload
+    cases = [(311, [(10, 2000, 0)] * 4, {}), (312, [(0, 0, 1)] * 4, {}), (313, [(0, 0, 1), (200, 260, 0), (0, 0, 1), (150, 151, 0)], {}),
+             (314, [(50, 500, 0), (120, 680, 0), (100, 900, 0), (0, 0, 1)], dict(max_matesw=2, pen_unpaired=40)),
+             (315, None, dict(min_seed_len=40, a=2)), (316, [(0, 30, 0), (0, 25, 0), (0, 0, 1), (5, 35, 0)], dict(read_len=(20, 60)))]
+    for seed, pes, kw in cases:
+        rl = kw.pop("read_len", (100, 251))
+        W = matesw_pose_workload(seed=seed, pes=pes, n_pairs=300, read_len=rl)
+        n = W["read_len"].shape[0]
+        for first in range(0, n, 512):
+            count = min(512, n - first)
+            g1, j1 = O.matesw_pose(W["regs"], W["reg_off"], first, count, W["read_len"], W["pes"], W["l_pac"], W["contig_off"], W["contig_len"], **kw)
+            g2, j2, ref2, qer2 = ref_py.matesw_pose(W["genome"], W["l_pac"], W["contig_off"], W["contig_len"], W["reads"], W["read_off"], first, count, W["regs"], W["reg_off"], W["pes"], **kw)
+            assert np.array_equal(g1, g2), (seed, first)
+            kj, ref1, qer1 = O.matesw_job_seqs(j1, W["text"], W["reads"], W["read_off"])
+            for f in ("len1", "len2", "xtra", "idr", "idq"):
+                assert np.array_equal(kj[f], j2[f]), (seed, f)
+            assert np.array_equal(ref1, ref2) and np.array_equal(qer1, qer2), seed
