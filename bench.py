@@ -583,7 +583,7 @@ def repeat_dense_leg(device_index, steps=3):
     npar = min(nreads, int(os.environ.get("MEME_BENCH_RD_PARITY_READS", "40000")))
     parity = all(seeds_equal_oracle(c, O, o_idx, reads[p0:p0 + 10000], opt) for p0 in range(0, npar, 10000))
     achieved = bpr * nreads / (stage_ms * 1e-3) / 1e9
-    out = {"workload": "%d reads of %d bp (1 %% substitutions) vs a %d-bp genome with 42 %% interspersed 300-bp repeats (30 %% in 24 families at 12 %% divergence, 12 %% in 6 young families at 3 %%), "
+    out = {"workload": "%d reads of %d bp (1 %% substitutions) vs a %d-bp genome with 42 %% interspersed 300-bp repeats (30 %% in 24 families at 12 %% divergence, 12 %% in 2 young families at 2 %%), "
                        "8 satellites (171-bp monomer x 300), 24 exact 3-kb duplications; index of its own, 2^%d leaves" % (nreads, READ_LEN, l_pac, bits),
            "seeding": {"metric": "seeding_reads_per_sec", "value": nreads / float(np.mean(wall)) if parity else None, "unit": "reads/s", "reads": nreads, "steps": steps,
                        "ms_per_step": float(np.mean(wall)) * 1e3, "search_stage_ms": stage_ms, "of_which_reseed_kernels_ms": float(np.mean([k[2] for k in k_ms])),

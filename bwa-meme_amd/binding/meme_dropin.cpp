@@ -197,6 +197,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
     for (auto& t : th) t.join();
     for (int d = 0; d < n; ++d) if (g_dev[(size_t)d].seed2 && meme_index_share(g_dev[(size_t)d].seed2, g_dev[(size_t)d].seed)) die("meme_index_share");
     for (int d = 0; d < n; ++d) for (int k = 0; k < 2; ++k) if (g_dev[(size_t)d].vfy[k] && meme_index_share(g_dev[(size_t)d].vfy[k], g_dev[(size_t)d].seed)) die("meme_index_share");
+    for (int d = 0; d < n; ++d) if (meme_index_share(g_dev[(size_t)d].bsw, g_dev[(size_t)d].seed)) die("meme_index_share");      // (mate rescue poses its jobs from the text: round 6)
     fprintf(stderr, "[meme-dropin] index staged in HBM in %.2f s, replicated to %d more GPU(s) in %.2f s\n", t1 - t0, n - 1,
             now_s() - t1);
 }

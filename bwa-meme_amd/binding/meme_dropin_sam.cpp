@@ -82,7 +82,140 @@ void mate_cache_init(int slots) {
     g_mate.cache = C; g_mate.slots = slots;
 }
 
+// ---- the posing step on the device too (round 6): meme_matesw_batch_host poses the chunk's jobs from the records' (rb, rid, score) -- gathered here in
+// one parallel walk -- and the bases in HBM, runs them, and returns what the third step needs per worker batch: gar and the kswr_t records.  The host
+// keeps mem_sam_pe_batch_post only.  MEME_DROPIN_MATE_POSE=0: the reference's mem_sam_pe_batch_pre per batch on the host, sequences shipped (rounds 3-5).
+// MEME_DROPIN_MATE_CHECK=1 (tests): both, compared entry by entry -- a difference is fatal.
+bool mate_pose_on_device() { static const bool v = !(getenv("MEME_DROPIN_MATE_POSE") && atoi(getenv("MEME_DROPIN_MATE_POSE")) == 0); return v; }
+bool mate_check() { static const bool v = getenv("MEME_DROPIN_MATE_CHECK") != nullptr; return v; }
+struct MateStage { meme_mate_reg* regs = nullptr; int64_t regs_cap = 0; int64_t* off = nullptr; int64_t off_cap = 0; };      // pinned, grow-only
+MateStage g_mate_stage;
+std::atomic<int64_t> g_mate_posed_dev{0};
+double g_mate_pose_ms = 0;
+
+// 1: the table is filled, 0: too few jobs (worker_sam runs as it is), -1: the device stage is not available for this chunk (the host poses)
+int matesw_prepass_device() {
+    const double t0 = now_s();
+    worker_t* w = g_worker;
+    const mem_opt_t* opt = g_opt;
+    const int64_t n = g_chunk.n;
+    const int nd = (int)g_dev.size();
+    if (n & 1) return -1;
+    for (int d = 0; d < nd; ++d) { const ChunkPart& P = g_chunk.part[(size_t)d]; if (P.count > 0 && (!P.reads_on_ctx || (P.first % BATCH_SIZE) != 0)) return -1; }
+    MateStage& G = g_mate_stage;
+    if (n + 1 > G.off_cap) { meme_host_free(G.off); G.off_cap = n + n / 4 + 64; if (!(G.off = (int64_t*)meme_host_alloc(G.off_cap * 8))) die("meme_host_alloc"); }
+    const int nt = cig_threads();
+    team_for(n, nt, [&](int64_t g0, int64_t g1, int) { for (int64_t g = g0; g < g1; ++g) G.off[g + 1] = (int64_t)w->regs[g].n; });
+    G.off[0] = 0;
+    for (int64_t g = 0; g < n; ++g) G.off[g + 1] += G.off[g];
+    const int64_t nrec = G.off[n];
+    if (nrec + 1 > G.regs_cap) { meme_host_free(G.regs); G.regs_cap = nrec + nrec / 4 + 4096; if (!(G.regs = (meme_mate_reg*)meme_host_alloc(G.regs_cap * (int64_t)sizeof(meme_mate_reg)))) die("meme_host_alloc"); }
+    team_for(n, nt, [&](int64_t g0, int64_t g1, int) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const mem_alnreg_v& av = w->regs[g];
+            meme_mate_reg* o = G.regs + G.off[g];
+            for (size_t k = 0; k < av.n; ++k) { o[k].rb = av.a[k].rb; o[k].rid = av.a[k].rid; o[k].score = av.a[k].score; }
+        }
+    });
+    meme_pestat pes[4];
+    for (int r = 0; r < 4; ++r) { pes[r].low = w->pes[r].low; pes[r].high = w->pes[r].high; pes[r].failed = w->pes[r].failed; pes[r].pad = 0; }
+    meme_mate_opt mo;
+    mo.a = opt->a; mo.b = opt->b; mo.o_del = opt->o_del; mo.e_del = opt->e_del; mo.o_ins = opt->o_ins; mo.e_ins = opt->e_ins;
+    mo.pen_unpaired = opt->pen_unpaired; mo.max_matesw = opt->max_matesw; mo.min_seed_len = opt->min_seed_len; mo.batch_reads = BATCH_SIZE;
+    const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
+    struct PartRes { std::vector<int32_t> gar; std::vector<int64_t> gar_off, job_off; std::vector<kswr_t> aln; double pose_ms = 0, kernel_ms = 0; int rc = 0; };
+    std::vector<PartRes> PR((size_t)nd);
+    auto run_part = [&](int d) {
+        const ChunkPart& P = g_chunk.part[(size_t)d];
+        PartRes& R = PR[(size_t)d];
+        if (P.count == 0) return;
+        std::vector<int64_t> off((size_t)P.count + 1);
+        const int64_t base = G.off[P.first];
+        for (int64_t i = 0; i <= P.count; ++i) off[(size_t)i] = G.off[P.first + i] - base;
+        meme_mate_host_result H;
+        // (the GPU's second ctx executes; the bases are read where the slice's seeding ctx holds them -- that ctx is busy with the CIGAR stage meanwhile)
+        R.rc = meme_matesw_batch_host(g_dev[(size_t)d].bsw, P.ctx, G.regs + base, off.data(), P.count, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &H);
+        if (R.rc) return;
+        static_assert(sizeof(kswr_t) == sizeof(meme_kswr), "kswr_t layout");
+        R.gar.assign(H.gar, H.gar + H.n_gar);
+        R.gar_off.assign(H.gar_off, H.gar_off + H.nbatches + 1);
+        R.job_off.assign(H.job_off, H.job_off + H.nbatches + 1);
+        R.aln.resize((size_t)H.njobs);
+        if (H.njobs) memcpy(R.aln.data(), H.res, (size_t)H.njobs * sizeof(kswr_t));
+        R.pose_ms = H.pose_ms; R.kernel_ms = H.kernel_ms;
+        if (verify_on() && P.vfy) {                              // MEME_DROPIN_VERIFY: the same on the ctx that holds the same reads
+            meme_mate_host_result V;
+            if (meme_matesw_batch_host(P.vfy, nullptr, G.regs + base, off.data(), P.count, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
+            if (V.njobs != H.njobs || V.n_gar != (int64_t)R.gar.size() || (V.n_gar && memcmp(V.gar, R.gar.data(), (size_t)V.n_gar * 4) != 0)) verify_fail("mate rescue (jobs posed)", -1, "");
+            for (int64_t k = 0; k < V.njobs; ++k) if (memcmp(&V.res[k], &R.aln[(size_t)k], sizeof(kswr_t)) != 0) verify_fail("mate-rescue Smith-Waterman", k, "");
+            verify_note(g_chunk.seq, "mate-rescue", d, verify_hash(R.aln.data(), R.aln.size() * sizeof(kswr_t), verify_hash(R.gar.data(), R.gar.size() * 4)), V.njobs);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int d = 1; d < nd; ++d) th.emplace_back(run_part, d);
+    run_part(0);
+    for (auto& x : th) x.join();
+    for (int d = 0; d < nd; ++d)
+        if (PR[(size_t)d].rc) {
+            static std::atomic<int> said{0};
+            if (said.fetch_add(1) < 2) fprintf(stderr, "[meme-dropin] mate rescue: the device stage is not available for this chunk (%s): the reference's posing function on the host\n", meme_last_error());
+            return -1;
+        }
+    MateTable& T = g_mate;
+    T.off.assign((size_t)nb + 1, 0);
+    T.gar.assign((size_t)nb, std::vector<int32_t>());
+    int64_t total = 0;
+    for (int d = 0; d < nd; ++d) total += (int64_t)PR[(size_t)d].aln.size();
+    g_mate_jobs_per_read = n > 0 ? (double)total / (double)n : 0;
+    if (total < matesw_min_jobs() && !mate_check()) { T.t_prepass += now_s() - t0; T.gen = 0; return 0; }
+    T.aln.resize((size_t)total);
+    int64_t jbase = 0;
+    double km = 0, pm = 0;
+    for (int d = 0; d < nd; ++d) {
+        const ChunkPart& P = g_chunk.part[(size_t)d];
+        const PartRes& R = PR[(size_t)d];
+        if (P.count == 0) continue;
+        const int64_t b0 = P.first / BATCH_SIZE, nbl = (int64_t)R.gar_off.size() - 1;
+        for (int64_t b = 0; b < nbl; ++b) {
+            T.off[(size_t)(b0 + b)] = jbase + R.job_off[(size_t)b];
+            T.gar[(size_t)(b0 + b)].assign(R.gar.begin() + R.gar_off[(size_t)b], R.gar.begin() + R.gar_off[(size_t)b + 1]);
+        }
+        if (!R.aln.empty()) memcpy(&T.aln[(size_t)jbase], R.aln.data(), R.aln.size() * sizeof(kswr_t));
+        jbase += (int64_t)R.aln.size();
+        km = km > R.kernel_ms ? km : R.kernel_ms; pm = pm > R.pose_ms ? pm : R.pose_ms;
+    }
+    T.off[(size_t)nb] = total;
+    T.t_kernel_ms += km; g_mate_pose_ms += pm; T.n_jobs += total; g_mate_posed_dev += total;
+    T.t_prepass += now_s() - t0;
+    T.gen = g_chunk_gen;
+    return 1;
+}
+
+bool matesw_prepass_host();
 bool matesw_prepass() {                          // false: too few jobs for the device, worker_sam runs as it is
+    if (mate_pose_on_device()) {
+        const int r = matesw_prepass_device();
+        if (r >= 0 && !mate_check()) return r == 1;
+        if (r >= 0) {                            // MEME_DROPIN_MATE_CHECK: the reference's own posing function over the same records, then its jobs on the device as before
+            MateTable dev;
+            dev.off = g_mate.off; dev.aln = g_mate.aln; dev.gar = g_mate.gar;
+            const int64_t dev_jobs = (int64_t)dev.aln.size();
+            g_mate.n_jobs -= dev_jobs;           // (counted again below)
+            const bool ok = matesw_prepass_host();
+            const MateTable& H = g_mate;
+            if (!ok) { if (dev_jobs >= matesw_min_jobs()) { fprintf(stderr, "[meme-dropin] MATE_CHECK: the host poses fewer jobs than the threshold, the device %lld\n", (long long)dev_jobs); exit(1); } return false; }
+            bool same = dev.off == H.off && dev.gar.size() == H.gar.size() && dev.aln.size() == H.aln.size();
+            // (the host path pre-fills its job index buffer with -1 in this mode: the reference leaves entries it does not pose unwritten, the device writes -1)
+            for (size_t b = 0; same && b < dev.gar.size(); ++b) same = dev.gar[b] == H.gar[b];
+            for (size_t k = 0; same && k < dev.aln.size(); ++k) same = memcmp(&dev.aln[k], &H.aln[k], sizeof(kswr_t)) == 0;
+            if (!same) { fprintf(stderr, "[meme-dropin] MATE_CHECK: mate rescue posed on the device differs from the reference's mem_sam_pe_batch_pre (jobs %zu vs %zu)\n", dev.aln.size(), H.aln.size()); exit(1); }
+            return true;
+        }
+    }
+    return matesw_prepass_host();
+}
+
+bool matesw_prepass_host() {
     const double t0 = now_s();
     worker_t* w = g_worker;
     const mem_opt_t* opt = g_opt;
@@ -100,6 +233,7 @@ bool matesw_prepass() {                          // false: too few jobs for the 
         int64_t pcnt = 0;
         int32_t gcnt = 0, maxRef = 0, maxQer = 0;
         int64_t pos = st >> 1;
+        if (mate_check()) memset(g_mate.cache->seqPairArrayAux[t], 0xff, (size_t)BATCH_SIZE * 50 * 4 * sizeof(int32_t));     // (entries the step does not write compare as -1)
         for (int64_t i = st; i + 1 < ed; i += 2)                  // worker_sam's loop (src/bwamem.cpp:1855-1866)
             mem_sam_pe_batch_pre(opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], g_mate.cache,
                                  pcnt, gcnt, maxRef, maxQer, t);
@@ -183,8 +317,8 @@ int mem_sam_pe_batch(const mem_opt_t* opt, mem_cache* mmc, int64_t& pcnt, int64_
 void meme_dropin_report_mate() {
     if (!matesw_on_device()) return;
     fprintf(stderr, "[meme-dropin] mate rescue on the device: %lld Smith-Waterman jobs posed so far (kernels %.3f s, whole pre-pass %.3f s); jobs whose results worker_sam's third step took from the table "
-            "%lld, run by the reference's kernels %lld\n", (long long)g_mate.n_jobs, g_mate.t_kernel_ms * 1e-3, g_mate.t_prepass, (long long)g_mate_hits.load(),
-            (long long)g_mate_miss.load());
+            "%lld, run by the reference's kernels %lld; jobs posed by the device's own posing step %lld (posing kernels %.3f s)\n", (long long)g_mate.n_jobs, g_mate.t_kernel_ms * 1e-3, g_mate.t_prepass,
+            (long long)g_mate_hits.load(), (long long)g_mate_miss.load(), (long long)g_mate_posed_dev.load(), g_mate_pose_ms * 1e-3);
 }
 void meme_dropin_report_matesw() {
     fprintf(stderr, "[meme-dropin] mate rescue by the reference's kernels (chunks below the job threshold): %.3f thread-seconds for %lld pairs\n", (double)g_t_matesw, (long long)g_n_matesw);

@@ -63,9 +63,9 @@ struct meme_ctx {
     void* plcp_aux = nullptr;                      // the plcp table of an attached index (meme_index_attach: the arrays are the caller's, this is ours)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[18], gcig[11], kswv[7], sam[9];
+           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[18], gcig[11], kswv[7], sam[9], mate[8];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
-    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[3], h_kswv, h_sam[2];
+    struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[3], h_kswv, h_sam[2], h_mate[4];
     i64 last_seed_max_len = 0;         // longest read of that batch
     i64 last_seed_reads = 0;           // reads of the batch whose seeds are in smems / hits (input of meme_chain_last_batch_host)
     bool reads_resident = false;       // ctx->reads holds the bases of that batch (false after meme_chain_batch_host: seeds brought by the caller)
@@ -126,6 +126,10 @@ int meme_bsw_launch(meme_ctx* ctx, meme_seqpair* d_pairs, const uint8_t* d_ref, 
 constexpr int MEME_SEEDSW_MAX = 200;    // MEM_SHORT_LEN, src/bwamem.cpp:250: windows are shorter
 struct meme_seedsw_job { i64 rb; i64 qoff; int seed; short tlen, qlen; };
 int meme_seedsw_launch(meme_ctx* ctx, const meme_seedsw_job* d_jobs, const unsigned long long* d_njobs, i64 max_jobs, int* d_sc, const meme_ext_opt* o);
+// the mate-rescue kernels on jobs whose sequences are already in ctx->kswv[2] / [3] and whose records are in ctx->kswv[0] (meme_kswv.hip; the jobs also on the host,
+// for the sort into LDS classes); staged = false: meme_kswv_batch_host's own path (sequences and jobs come from the host)
+int meme_kswv_run(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer, int64_t qer_bytes, const meme_bsw_opt* opt,
+                  bool staged, meme_kswv_host_result* out);
 // chains of the batch just seeded, left in HBM (meme_chain.hip); totals[0..1] = chains, chained seeds
 int meme_chain_run(meme_ctx* ctx, const meme_contig* contigs, int32_t n_contigs, const meme_chain_opt* opt, i64* totals);
 

@@ -116,10 +116,12 @@ extern "C" void meme_ctx_destroy(meme_ctx* ctx) {
     for (DevBuf& b : ctx->gcig) free_buf(b);
     for (DevBuf& b : ctx->sam) free_buf(b);
     for (DevBuf& b : ctx->kswv) free_buf(b);
+    for (DevBuf& b : ctx->mate) free_buf(b);
     for (meme_ctx::HostBuf& h : ctx->h_chain) if (h.p) (void)hipHostFree(h.p);
     for (meme_ctx::HostBuf& h : ctx->h_ext) if (h.p) (void)hipHostFree(h.p);
     for (meme_ctx::HostBuf& h : ctx->h_gcig) if (h.p) (void)hipHostFree(h.p);
     for (meme_ctx::HostBuf& h : ctx->h_sam) if (h.p) (void)hipHostFree(h.p);
+    for (meme_ctx::HostBuf& h : ctx->h_mate) if (h.p) (void)hipHostFree(h.p);
     if (ctx->h_kswv.p) (void)hipHostFree(ctx->h_kswv.p);
     if (ctx->owns_index) for (auto& o : ctx->owned) (void)hipFree(o.first);
     if (ctx->plcp_aux) (void)hipFree(ctx->plcp_aux);

@@ -296,7 +296,12 @@ int meme_seedsw_launch(meme_ctx* ctx, const meme_seedsw_job* d_jobs, const unsig
 
 extern "C" int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer,
                                     int64_t qer_bytes, const meme_bsw_opt* opt, meme_kswv_host_result* out) {
-    if (!ctx || !opt || !out || njobs < 0 || (njobs > 0 && (!jobs || !ref || !qer))) { meme_set_error("meme_kswv_batch_host: null argument"); return MEME_E_ARG; }
+    return meme_kswv_run(ctx, jobs, njobs, ref, ref_bytes, qer, qer_bytes, opt, false, out);
+}
+
+int meme_kswv_run(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer, int64_t qer_bytes, const meme_bsw_opt* opt,
+                  bool staged, meme_kswv_host_result* out) {
+    if (!ctx || !opt || !out || njobs < 0 || (njobs > 0 && (!jobs || (!staged && (!ref || !qer))))) { meme_set_error("meme_kswv_batch_host: null argument"); return MEME_E_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     memset(out, 0, sizeof(*out));
     if (njobs == 0) return MEME_OK;
@@ -355,10 +360,12 @@ extern "C" int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, in
         (rc = meme_buf_reserve(ctx, K[6], rm_off.size() * 8 + 8))) return rc;
     hipEvent_t* ev = ctx->ev_kswv;
     for (int i = 0; i < 2; ++i) if (!ev[i]) HIP_TRY(hipEventCreate(&ev[i]));
-    HIP_TRY(hipMemcpyAsync(K[0].p, jobs, (size_t)n * sizeof(meme_kswv_job), hipMemcpyHostToDevice, ctx->stream));
+    if (!staged) HIP_TRY(hipMemcpyAsync(K[0].p, jobs, (size_t)n * sizeof(meme_kswv_job), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(K[1].p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(K[2].p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(K[3].p, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!staged) {                                     // (staged: the caller's kernels have written the jobs and both sequence buffers where they are read)
+        HIP_TRY(hipMemcpyAsync(K[2].p, ref, (size_t)ref_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(K[3].p, qer, (size_t)qer_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIP_TRY(hipMemcpyAsync(K[6].p, rm_off.data(), rm_off.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     for (const Launch& L : launches) {

@@ -113,6 +113,16 @@ class KswvHost(C.Structure):
     _fields_ = [("njobs", C.c_int64), ("res", C.c_void_p), ("kernel_ms", C.c_float)]
 
 
+class MateHost(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("nbatches", C.c_int64), ("njobs", C.c_int64), ("n_gar", C.c_int64), ("gar", C.c_void_p), ("gar_off", C.c_void_p), ("job_off", C.c_void_p),
+                ("jobs", C.c_void_p), ("res", C.c_void_p), ("pose_ms", C.c_float), ("kernel_ms", C.c_float)]
+
+
+class MateOpt(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unpaired", "max_matesw", "min_seed_len", "batch_reads")]
+
+
+MATE_REG = np.dtype([("rb", "<i8"), ("rid", "<i4"), ("score", "<i4")])
 KSWV_JOB = np.dtype([("idr", "<i8"), ("idq", "<i8"), ("len1", "<i4"), ("len2", "<i4"), ("xtra", "<i4"), ("pad", "<i4")])
 KSWR = np.dtype([(n, "<i4") for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")])
 CHAIN = np.dtype({"names": ["pos", "rid", "n_seeds", "w", "first", "kept", "is_alt", "seed_beg"],
@@ -146,7 +156,7 @@ EXPORTS = ["meme_device_count", "meme_ctx_create", "meme_ctx_destroy", "meme_las
            "meme_index_pos5_bytes",
            "meme_index_attach", "meme_index_describe", "meme_index_share", "meme_index_replicate", "meme_host_alloc",
            "meme_host_free", "meme_stage_pack_text", "meme_stage_pos5_from_sa", "meme_stage_build_entries", "meme_stage_build_plcp",
-           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_gen_cigar_batch_host", "meme_sam_stage_text", "meme_sam_format_batch_host", "meme_kswv_batch_host", "meme_seed_batch_device",
+           "meme_stage_entries_from_sa", "meme_stage_rmi32", "meme_sa_build_device", "meme_prmi_train_device", "meme_seed_batch", "meme_seed_batch_host", "meme_seed_batch_resident", "meme_seed_batch_resident_ascii", "meme_seed_reserve", "meme_chain_last_batch_host", "meme_chain_batch_host", "meme_extend_last_batch_host", "meme_global_batch_host", "meme_gen_cigar_batch_host", "meme_sam_stage_text", "meme_sam_format_batch_host", "meme_kswv_batch_host", "meme_matesw_batch_host", "meme_seed_batch_device",
            "meme_bsw_batch", "meme_bsw_batch_device", "meme_get_timings", "meme_set_tuning"]
 
 _lib = None
@@ -433,6 +443,29 @@ class Context:
             return np.zeros(0, KSWR), float(res.kernel_ms)
         buf = (C.c_char * (res.njobs * KSWR.itemsize)).from_address(res.res)
         return np.frombuffer(buf, dtype=KSWR, count=res.njobs).copy(), float(res.kernel_ms)
+
+    def matesw_batch_host(self, regs, reg_off, pes, contigs, l_pac, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, pen_unpaired=17, max_matesw=50, min_seed_len=19,
+                          batch_reads=512, reads_of=None):
+        """meme_matesw_batch_host: mate rescue whole for the pairs of the batch resident on the ctx -- the posing step (mem_sam_pe_batch_pre) and the
+        Smith-Waterman jobs (mem_sam_pe_batch).  regs: MATE_REG records of all reads, reg_off per read; pes: 4 x (low, high, failed).
+        Returns dict(gar, gar_off, job_off, jobs KSWV_JOB, res KSWR, pose_ms, kernel_ms)."""
+        regs = np.ascontiguousarray(regs, dtype=MATE_REG)
+        reg_off = np.ascontiguousarray(reg_off, dtype=np.int64)
+        pes4 = np.zeros((4, 4), np.int32)
+        pes4[:, :3] = np.asarray(pes, np.int32).reshape(4, 3)
+        arr = (Contig * len(contigs))(*[Contig(int(o), int(l), int(al)) for o, l, al in contigs])
+        opt = MateOpt(a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, max_matesw, min_seed_len, batch_reads)
+        res = MateHost()
+        _check(lib().meme_matesw_batch_host(C.c_void_p(self.h), C.c_void_p(reads_of.h if reads_of is not None else None), _p(regs), _p(reg_off), C.c_int64(reg_off.shape[0] - 1), _p(pes4), arr, C.c_int32(len(contigs)), C.c_int64(l_pac),
+                                            C.byref(opt), C.byref(res)))
+
+        def view(ptr, count, dtype):
+            if count == 0 or not ptr:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return {"gar": view(res.gar, res.n_gar, np.int32), "gar_off": view(res.gar_off, res.nbatches + 1, np.int64), "job_off": view(res.job_off, res.nbatches + 1, np.int64),
+                "jobs": view(res.jobs, res.njobs, KSWV_JOB), "res": view(res.res, res.njobs, KSWR), "pose_ms": float(res.pose_ms), "kernel_ms": float(res.kernel_ms)}
 
     def chain_batch_host(self, smems, smem_off, hits, hit_off, read_len, contigs, opt):
         """meme_chain_batch_host: chains of seeds the caller brings (numpy arrays laid out as seed_batch_host returns them)."""

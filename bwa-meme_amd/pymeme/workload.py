@@ -234,7 +234,7 @@ def make_pairs_chunk(genome: np.ndarray, m: int, read_len: int, rng, sub_rate: f
 def repeat_dense_genome(l_pac, seed=77):
     """A genome at human-like repeat density (round 6; SURVEY 8(d) realises its configs on a 98 %-unique text): 42 % of the bases are copies of 300-bp
     interspersed repeat families -- 30 % old ones at 12 % divergence from their consensus (24 families, thousands of copies each: they share few 19-mers)
-    and 12 % young ones at 3 % (6 families: most 19-mers shared by hundreds of copies -> hit lists beyond max_occ, SMEM slots that overflow) --, eight
+    and 12 % young ones at 2 % (2 families of ten thousand copies and more: 30-mers shared by thousands of them -> hit lists beyond max_occ) --, eight
     tandem satellites of a 171-bp monomer (300 copies each, 2 % divergence), two dozen 3-kb exact duplications and a dozen homopolymer runs."""
     return synth.make_genome(l_pac, seed=seed, repeat_frac=0.30, repeat_len=300, n_families=24, divergence=0.12, n_dups=24, dup_len=3000, poly_runs=12, satellites=8,
-                             young_frac=0.12, young_families=6, young_divergence=0.03)
+                             young_frac=0.12, young_families=2, young_divergence=0.02)

@@ -16,6 +16,7 @@
  *   meme_global_batch_host          <- ksw_global2() under bwa_gen_cigar2()         src/ksw.cpp:560-670, src/bwa.cpp:274-362
  *   meme_gen_cigar_batch_host       <- bwa_gen_cigar2() whole: CIGAR + NM + MD       src/bwa.cpp:274-362
  *   meme_sam_format_batch_host      <- mem_aln2sam() for a chunk's plain records     src/bwamem.cpp:2174-2312
+ *   meme_matesw_batch_host          <- mem_sam_pe_batch_pre() + mem_sam_pe_batch()   src/bwamem_pair.cpp:660-716, 1060-1223, 719-818
  *   meme_bsw_batch                  <- BandedPairWiseSW::getScores8 / getScores16 /
  *                                      scalarBandedSWAWrapper                 src/bandedSWA.h:118-135,257-297
  *
@@ -360,6 +361,32 @@ typedef struct { int32_t score, te, qe, score2, te2, tb, qb; } meme_kswr;
 typedef struct { int64_t njobs; const meme_kswr* res; /* pinned, owned by the ctx, valid until its next kswv call */ float kernel_ms; } meme_kswv_host_result;
 int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs, const uint8_t* ref, int64_t ref_bytes, const uint8_t* qer, int64_t qer_bytes,
                          const meme_bsw_opt* opt, meme_kswv_host_result* out);
+
+/* ---- mate rescue whole: the posing step in front of the Smith-Waterman kernel -------------------------------------------------------------
+ * What worker_sam's first two steps compute for the read pairs of a chunk (reference src/bwamem.cpp:1855-1877): mem_sam_pe_batch_pre
+ * (src/bwamem_pair.cpp:660-716) with mem_matesw_batch_pre (:1060-1223) poses, per worker batch of `batch_reads` reads, the Smith-Waterman jobs
+ * of mate rescue -- for each end's alignment records within pen_unpaired of its best (at most max_matesw), the orientations that pes[] allows
+ * and no record of the mate explains, a window of the reference clamped to the strand and sequence of its midpoint -- and mem_sam_pe_batch
+ * runs them (meme_kswv_batch_host above).  The reads are the batch resident on the ctx (pair p = reads 2p, 2p + 1; nreads must equal the
+ * batch's), the text is the index's; regs[reg_off[r] .. reg_off[r+1]) = the fields of read r's mem_alnreg_t records the step reads, in the
+ * records' order (best score first, as mem_sort_dedup_patch leaves them).  Results, in pinned memory of the ctx until its next call:
+ *   gar[gar_off[b] .. gar_off[b+1])   worker batch b's job index array as mem_matesw_batch_pre fills it: four entries per (end, record) looked at,
+ *                                     the job's index AMONG THE BATCH'S JOBS or -1 (not posed: mem_sam_pe_batch_post computes it itself)
+ *   res[job_off[b] .. job_off[b+1])   kswr_t records of the batch's jobs in posing order (what mem_sam_pe_batch leaves in `aln`)
+ *   jobs[]                            the jobs (len1 window, len2 query, xtra) for inspection; idr / idq index device buffers
+ * MEME_E_STATE when the ctx does not hold the batch.  opt: a, b, o_del, e_del, o_ins, e_ins = mem_opt_t fields of the same names. */
+typedef struct { int64_t rb; int32_t rid, score; } meme_mate_reg;
+typedef struct { int32_t low, high, failed, pad; } meme_pestat;      /* mem_pestat_t::low, high, failed (src/bwamem.h:175-179) */
+typedef struct { int32_t a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, max_matesw, min_seed_len, batch_reads; } meme_mate_opt;
+typedef struct {
+    int64_t nreads, nbatches, njobs, n_gar;
+    const int32_t* gar; const int64_t* gar_off; const int64_t* job_off;     /* nbatches + 1 offsets each */
+    const meme_kswv_job* jobs; const meme_kswr* res;
+    float pose_ms, kernel_ms;        /* HIP events: the posing kernels (+ scans, sequence unpacking); the Smith-Waterman launches */
+} meme_mate_host_result;
+int meme_matesw_batch_host(meme_ctx* ctx, meme_ctx* reads_of /* NULL: ctx itself; else another ctx of the same GPU whose resident batch is read (not written) */,
+                           const meme_mate_reg* regs, const int64_t* reg_off /* nreads + 1 */, int64_t nreads, const meme_pestat* pes /* 4 */,
+                           const meme_contig* contigs, int32_t n_contigs, int64_t l_pac, const meme_mate_opt* opt, meme_mate_host_result* out);
 
 /* ---- measurement ---------------------------------------------------------------------------------
  * HIP-event timings of the kernels of the last *_device call, measured on the ctx's stream.          */
