@@ -21,6 +21,8 @@ os.environ.setdefault("MEME_DROPIN_MATESW", "1")
 os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
 # every record the device formats (SAM text) is also formatted by the reference's mem_aln2sam and compared inside the aligner
 os.environ.setdefault("MEME_DROPIN_SAM_CHECK", "1")
+# round 6: mate rescue is posed on the device; in the tests the reference's own posing function runs over the same records as well and every job index / result is compared in the aligner
+os.environ.setdefault("MEME_DROPIN_MATE_CHECK", "1")
 
 
 def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000, opts=(), stderr=None):

@@ -13,6 +13,8 @@ from pymeme import hostapi, synth, workload
 
 pytestmark = pytest.mark.gpu
 os.environ.setdefault("MEME_DROPIN_SAM_CHECK", "1")
+# round 6: mate rescue is posed on the device; in the tests the reference's own posing function runs over the same records as well and every job index / result is compared in the aligner
+os.environ.setdefault("MEME_DROPIN_MATE_CHECK", "1")
 os.environ.setdefault("MEME_DROPIN_MATESW", "1")          # (the opt-in mate-rescue stage too, whatever the number of jobs)
 os.environ.setdefault("MEME_DROPIN_MATESW_MIN", "0")
 
