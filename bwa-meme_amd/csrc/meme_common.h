@@ -63,7 +63,7 @@ struct meme_ctx {
     void* plcp_aux = nullptr;                      // the plcp table of an attached index (meme_index_attach: the arrays are the caller's, this is ours)
     // workspaces
     DevBuf reads, read_off, slots[3], ovf[2], slot_cnt, slot_hits, slot_loc, smem_off, hit_off, smems, hits,
-           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[18], gcig[11], kswv[7], sam[9], mate[8];
+           scan_tmp, counters, pend, blk, pairs, refb, qerb, packed, bsw_order, bsw_ws, chain[14], ext[19], gcig[11], kswv[7], sam[9], mate[8];
     // pinned host staging owned by the ctx (results of meme_seed_batch_host, inputs of meme_bsw_batch)
     struct HostBuf { void* p = nullptr; size_t cap = 0; } h_smems, h_hits, h_smem_off, h_hit_off, h_misc, h_chain[7], h_ext[2], h_gcig[3], h_kswv, h_sam[2], h_mate[4];
     i64 last_seed_max_len = 0;         // longest read of that batch
@@ -77,6 +77,7 @@ struct meme_ctx {
     i64 seed_blocks_per_cu = 5;
     i64 max_batch = 0;                 // > 0: the batch calls behind seeding (extension, global alignment) refuse more reads / jobs than this with
                                        // MEME_E_CAPACITY, as they do when their scratch would not fit: a caller's memory bound, and how the tests reach that path
+    i64 ext_split = 1;                 // 1: the extension stage's read-walking kernels run eight lanes per read for reads with at most 8 chained seeds, a wavefront per read for the rest; 0: a wavefront per read
     i64 bsw_circ = 1;                  // 1: lane-per-pair banded SW of queries longer than 2w + 2 columns keeps its columns in a ring (k_bsw_lane_circ); 0: a word per query column
     i64 sam_max_batch = 0;             // > 0: meme_sam_format_batch_host refuses more record slots than this with MEME_E_CAPACITY (the caller then formats in pieces)
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches

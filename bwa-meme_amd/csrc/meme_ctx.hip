@@ -164,6 +164,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "max_batch")) ctx->max_batch = value;
     else if (!strcmp(key, "sam_max_batch")) ctx->sam_max_batch = value;
     else if (!strcmp(key, "bsw_circ")) ctx->bsw_circ = value;
+    else if (!strcmp(key, "ext_split")) ctx->ext_split = value;
     else if (!strcmp(key, "ext_census")) ctx->ext_census = value;
     else if (!strcmp(key, "gcig_zcap")) ctx->gcig_zcap = value;
     else if (!strcmp(key, "ext_live_only")) ctx->ext_live_only = value;

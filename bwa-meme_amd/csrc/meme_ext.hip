@@ -41,7 +41,12 @@ struct ExtArgs {
     // extension in rounds (tuning "ext_rounds"): mode 0 = every chained seed at once (the reference's batch, :2573-3388); 1 = records and the extension
     // order only, no jobs; 2 = jobs of the seeds k_ext_advance selected (sel: per chained seed; act: per read, any selected)
     int mode; const uint8_t* sel; const uint8_t* act; int4* state;
+    // round 6: the kernels that walk a read's chains exist in two widths -- a wavefront per read (G = 64) for the reads in `list` (more than
+    // EXT_LIGHT chained seeds), and EIGHT LANES per read (G = 8: eight reads per wavefront) for the others, which are the many: a 150-bp read
+    // has four chained seeds on average and a wavefront's life is a chain of dependent loads, not work.  list == nullptr: every read of the slab.
+    const i64* list; i64 nlist; int light;           // light: G = 8 launch -- reads with more than EXT_LIGHT seeds are skipped (they are in the other launch's list)
 };
+constexpr int EXT_LIGHT = 8;
 
 __device__ __forceinline__ int cal_max_gap(const meme_ext_opt& o, int qlen) {       // src/bwamem.cpp:85-95
     const int l_del = (int)((double)(qlen * o.a - o.o_del) / o.e_del + 1.);
@@ -54,6 +59,10 @@ __device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(p
 __device__ __forceinline__ i64 wave_min(i64 v) { for (int d = 32; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y < v ? y : v; } return v; }
 __device__ __forceinline__ i64 wave_max(i64 v) { for (int d = 32; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y > v ? y : v; } return v; }
 __device__ __forceinline__ int pad4(int x) { return (x + 3) & ~3; }
+// sub-wavefront groups of G lanes (G = 64: the wavefront): ballots, broadcasts and reductions that stay inside the group
+template <int G> __device__ __forceinline__ u64 gballot(bool p, int gbase) { const u64 b = __ballot(p); return G == 64 ? b : (b >> gbase) & (((u64)1 << (G & 63)) - 1); }
+template <int G> __device__ __forceinline__ i64 group_min(i64 v) { for (int d = G / 2; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y < v ? y : v; } return v; }
+template <int G> __device__ __forceinline__ i64 group_max(i64 v) { for (int d = G / 2; d >= 1; d >>= 1) { const i64 y = __shfl_xor(v, d); v = y > v ? y : v; } return v; }
 
 // seeds of the chain fully inside the alignment (src/bwamem.cpp:2907-2917 and after every fold)
 __device__ inline void seedcov(meme_alnreg* a, const meme_chain_seed* sd, int n) {
@@ -66,16 +75,19 @@ __device__ inline void seedcov(meme_alnreg* a, const meme_chain_seed* sd, int n)
     a->seedcov = cov;
 }
 
-template <bool WRITE>
+template <bool WRITE, int G>
 __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
-    const i64 rl = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);      // read of the slab: a wavefront each, four to a workgroup (2 M one-wave workgroups take 4 ms to dispatch)
-    if (rl >= A.ns) return;
-    const i64 r = A.g0 + rl;
-    const int lane = threadIdx.x & 63;
+    const i64 it = (i64)blockIdx.x * (256 / G) + threadIdx.x / G;  // a group of G lanes per read (G = 64: a wavefront each, four to a workgroup -- 2 M one-wave workgroups take 4 ms to dispatch)
+    if (it >= (A.list ? A.nlist : A.ns)) return;
+    const i64 r = A.list ? A.list[it] : A.g0 + it;
+    const i64 rl = r - A.g0;                          // read of the slab
+    const int lane = threadIdx.x & (G - 1);           // lane of the group
+    const int gbase = (threadIdx.x & 63) & ~(G - 1);  // the group's first lane in its wavefront
     const i64 c0 = A.chain_off[r];
     const int nc = (int)(A.chain_off[r + 1] - c0);
     const i64 s0 = A.seed_off[r];
     const int S = (int)(A.seed_off[r + 1] - s0);
+    if (A.light && S > EXT_LIGHT) return;             // (the wavefront-per-read launch has it)
     const int l_query = (int)(A.read_off[r + 1] - A.read_off[r]);
     const meme_ext_opt& o = A.o;
     if (A.mode == 2 && !A.act[r]) {                  // nothing of this read in the round
@@ -88,7 +100,7 @@ __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
             const meme_chain ch = A.chains[c0 + c];
             const meme_chain_seed* sd = A.seeds + s0 + ch.seed_beg;
             i64 b_min = A.l_pac << 1, e_max = 0;
-            for (int i = lane; i < ch.n_seeds; i += 64) {
+            for (int i = lane; i < ch.n_seeds; i += G) {
                 const meme_chain_seed t = sd[i];
                 const i64 b = t.rbeg - (t.qbeg + cal_max_gap(o, t.qbeg));
                 const int tail = l_query - t.qbeg - t.len;
@@ -96,7 +108,7 @@ __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
                 b_min = b < b_min ? b : b_min;
                 e_max = e > e_max ? e : e_max;
             }
-            i64 rmax0 = wave_min(b_min), rmax1 = wave_max(e_max);
+            i64 rmax0 = group_min<G>(b_min), rmax1 = group_max<G>(e_max);
             if (rmax0 < 0) rmax0 = 0;
             if (rmax1 > A.l_pac << 1) rmax1 = A.l_pac << 1;
             const i64 mid = sd[0].rbeg;
@@ -115,7 +127,7 @@ __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
     const bool posing = WRITE && A.mode != 1;
     const i64 jobL0 = posing ? A.offL[rl] - A.job0L : 0, jobR0 = posing ? A.offR[rl] - A.job0R : 0;
     const i64 byte0 = posing ? A.offB[rl] - A.byte0 : 0;
-    for (int jb = 0; jb < S; jb += 64) {
+    for (int jb = 0; jb < S; jb += G) {
         const int j = jb + lane;
         const bool valid = j < S;
         int c = 0;
@@ -136,14 +148,14 @@ __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
         const int l2L = t.qbeg, l1L = (int)(t.rbeg - rmax0);
         const int l2R = l_query - qe, l1R = (int)(rmax1 - (t.rbeg + t.len));
         const int bytesL = hasL ? pad4(l1L) + pad4(l2L) : 0, bytesR = hasR ? pad4(l1R) + pad4(l2R) : 0;
-        const u64 mL = __ballot(hasL), mR = __ballot(hasR), below = ((u64)1 << lane) - 1;
+        const u64 mL = gballot<G>(hasL, gbase), mR = gballot<G>(hasR, gbase), below = ((u64)1 << lane) - 1;
         // exclusive scan of the bytes over the lanes
         int bsum = bytesL + bytesR, bex;
         {
             int x = bsum;
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
+            for (int d = 1; d < G; d <<= 1) { const int y = __shfl_up(x, d); if (lane >= d) x += y; }
             bex = x - bsum;
-            bsum = __shfl(x, 63);
+            bsum = __shfl(x, gbase + G - 1);
         }
         if (WRITE && valid && (A.mode != 2 || pick)) {
             // rank among the chain's seeds by (score, index): ks_introsort_64 on score << 32 | index, keys unique (:2692-2699)
@@ -186,13 +198,13 @@ __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
                 while (m) {
                     const int jl = __builtin_ctzll(m);
                     m &= m - 1;
-                    const i64 rbeg = __shfl(t.rbeg, jl);
-                    const int qb = __shfl(t.qbeg, jl), ln = __shfl(t.len, jl);
-                    const int l1 = __shfl(side ? l1R : l1L, jl), l2 = __shfl(side ? l2R : l2L, jl);
-                    const i64 dst = byte0 + nB + __shfl(bex, jl) + (side ? __shfl(bytesL, jl) : 0);
+                    const i64 rbeg = __shfl(t.rbeg, gbase + jl);
+                    const int qb = __shfl(t.qbeg, gbase + jl), ln = __shfl(t.len, gbase + jl);
+                    const int l1 = __shfl(side ? l1R : l1L, gbase + jl), l2 = __shfl(side ? l2R : l2L, gbase + jl);
+                    const i64 dst = byte0 + nB + __shfl(bex, gbase + jl) + (side ? __shfl(bytesL, gbase + jl) : 0);
                     uint8_t* dr = A.seq + dst;
                     uint8_t* dq = dr + pad4(l1);
-                    for (int i = lane * 4; i < l1; i += 256) {
+                    for (int i = lane * 4; i < l1; i += 4 * G) {
                         unsigned v = 0;
                         for (int b = 0; b < 4; ++b) {
                             const int k = i + b;
@@ -201,7 +213,7 @@ __global__ void __launch_bounds__(256) k_ext_jobs(ExtArgs A) {
                         }
                         *reinterpret_cast<unsigned*>(dr + i) = v;
                     }
-                    for (int i = lane * 4; i < l2; i += 256) {
+                    for (int i = lane * 4; i < l2; i += 4 * G) {
                         unsigned v = 0;
                         for (int b = 0; b < 4; ++b) {
                             const int k = i + b;
@@ -447,6 +459,7 @@ enum { ADV_ONE = 0, ADV_REST = 1, ADV_FINISH = 2 };
 struct AdvArgs {
     PurgeArgs P; int4* state; uint8_t* sel; uint8_t* act; i64* cntS; int mode;     // cntS: seeds selected per read (summed by a scan: an atomic per read on one address costs 12 ns each)
     const i64* rmax; i64 *cntL, *cntR, *cntB;        // the round's plan as k_ext_jobs<false> would count it: left / right jobs and sequence bytes of the read's selected seeds
+    const i64* list; i64 nlist; int light;           // as in ExtArgs: the wavefront-per-read launch walks `list`, the eight-lanes-per-read launch everything with at most EXT_LIGHT seeds
 };
 // jobs and bytes of one selected seed (the arithmetic of k_ext_jobs)
 __device__ __forceinline__ void adv_count(const meme_chain_seed& t, i64 rmax0, i64 rmax1, int l_query, i64& nL, i64& nR, i64& nB) {
@@ -455,14 +468,18 @@ __device__ __forceinline__ void adv_count(const meme_chain_seed& t, i64 rmax0, i
     if (qe != l_query) { ++nR; nB += pad4((int)(rmax1 - (t.rbeg + t.len))) + pad4(l_query - qe); }
 }
 
+template <int G>
 __global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
     const PurgeArgs& P = V.P;
-    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= P.nreads) return;
-    const int lane = threadIdx.x & 63;
+    const i64 it = (i64)blockIdx.x * (256 / G) + threadIdx.x / G;
+    if (it >= (V.list ? V.nlist : P.nreads)) return;
+    const i64 r = V.list ? V.list[it] : it;
+    const int lane = threadIdx.x & (G - 1);
+    const int gbase = (threadIdx.x & 63) & ~(G - 1);
     const i64 c0 = P.chain_off[r];
     const int nc = (int)(P.chain_off[r + 1] - c0);
     const i64 s0 = P.seed_off[r];
+    if (V.light && P.seed_off[r + 1] - s0 > EXT_LIGHT) return;
     int4 st = V.state[r];                              // x chain, y rank of the next seed in it (-1: the chain is done), z seeds met so far
     if (V.mode != ADV_FINISH && lane == 0) { V.act[r] = 0; V.cntL[r] = 0; V.cntR[r] = 0; V.cntB[r] = 0; V.cntS[r] = 0; }
     if (st.x >= nc) return;
@@ -476,7 +493,7 @@ __global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
         for (int k = c == st.x ? st.y : ch.n_seeds - 1; k >= 0; --k, ++cur) {
             const meme_chain_seed s = sd[ord[k]];
             bool found = false;
-            for (int ib = 0; ib < cur && !found; ib += 64) {
+            for (int ib = 0; ib < cur && !found; ib += G) {
                 const int i = ib + lane;
                 bool hit = false;
                 if (i < cur) {
@@ -500,12 +517,12 @@ __global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
                         }
                     }
                 }
-                found = __ballot(hit) != 0;
+                found = gballot<G>(hit, gbase) != 0;
             }
             bool drop = false;
             if (found) {
                 bool other = false;
-                for (int ub = k + 1; ub < ch.n_seeds && !other; ub += 64) {
+                for (int ub = k + 1; ub < ch.n_seeds && !other; ub += G) {
                     const int u = ub + lane;
                     bool hit = false;
                     if (u < ch.n_seeds && ord[u] >= 0) {
@@ -515,7 +532,7 @@ __global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
                             else if (t.qbeg <= s.qbeg && t.qbeg + t.len - s.qbeg >= s.len >> 2 && s.qbeg - t.qbeg != s.rbeg - t.rbeg) hit = true;
                         }
                     }
-                    other = __ballot(hit) != 0;
+                    other = gballot<G>(hit, gbase) != 0;
                 }
                 drop = !other;
             }
@@ -529,14 +546,14 @@ __global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
                     const int* ord2 = P.order + s0 + ch2.seed_beg;
                     const int k1 = c2 == c ? k : ch2.n_seeds - 1;
                     const i64 rmax0 = V.rmax[2 * (c0 + c2)], rmax1 = V.rmax[2 * (c0 + c2) + 1];
-                    for (int k2 = k1 - lane; k2 >= 0; k2 -= 64) {
+                    for (int k2 = k1 - lane; k2 >= 0; k2 -= G) {
                         const int il = ord2[k2];
                         V.sel[s0 + ch2.seed_beg + il] = 1;
                         adv_count(P.seeds[s0 + ch2.seed_beg + il], rmax0, rmax1, l_query, nL, nR, nB);
                     }
                     cnt += k1 + 1;
                 }
-                for (int d = 32; d >= 1; d >>= 1) { nL += __shfl_xor(nL, d); nR += __shfl_xor(nR, d); nB += __shfl_xor(nB, d); }
+                for (int d = G / 2; d >= 1; d >>= 1) { nL += __shfl_xor(nL, d); nR += __shfl_xor(nR, d); nB += __shfl_xor(nB, d); }
                 if (lane == 0) { V.act[r] = 1; V.state[r] = make_int4(c, k, cur, 0); V.cntS[r] = (i64)cnt; V.cntL[r] = nL; V.cntR[r] = nR; V.cntB[r] = nB; }
                 return;
             }
@@ -554,6 +571,22 @@ __global__ void __launch_bounds__(256) k_ext_advance(AdvArgs V) {
         st.y = 0;                                      // (later chains start at their best seed; st.x no longer equals c)
     }
     if (lane == 0) V.state[r] = make_int4(nc, 0, cur, 0);
+}
+
+// reads with more than EXT_LIGHT chained seeds: the list the wavefront-per-read launches walk (order is irrelevant: everything is indexed by read)
+__global__ void __launch_bounds__(256) k_ext_split(const i64* __restrict__ seed_off, i64 n, i64* __restrict__ list, unsigned long long* __restrict__ cnt) {
+    for (i64 r0 = (i64)blockIdx.x * 256; r0 < n; r0 += (i64)gridDim.x * 256) {
+        const i64 r = r0 + threadIdx.x;
+        const bool heavy = r < n && seed_off[r + 1] - seed_off[r] > EXT_LIGHT;
+        const u64 m = __ballot(heavy);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned long long base = 0;
+            if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(cnt, (unsigned long long)__popcll(m));
+            base = __shfl(base, (int)__builtin_ctzll(m));
+            if (heavy) list[base + __popcll(m & (((u64)1 << lane) - 1))] = r;
+        }
+    }
 }
 
 unsigned grid_of(i64 items, int per) { i64 b = (items + per - 1) / per; const i64 cap = 256 * 64; return (unsigned)(b < cap ? (b < 1 ? 1 : b) : cap); }
@@ -706,6 +739,38 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     i64* d_offS = d_cnt + 7 * (n + 1);
     unsigned long long* d_census = (unsigned long long*)E[8].p + 8;
     if (ctx->ext_census) HIP_TRY(hipMemsetAsync(d_census, 0, 11 * 8, ctx->stream));
+    // ---- light and heavy reads (round 6): the list of reads with more than EXT_LIGHT chained seeds; everything else runs eight lanes per read
+    i64 n_heavy = 0;
+    const i64* d_heavy = nullptr;
+    const bool split = ctx->ext_split != 0;
+    if (split) {
+        if ((rc = meme_buf_reserve(ctx, E[18], (size_t)(n + 1) * 8))) return rc;
+        unsigned long long* d_nheavy = (unsigned long long*)E[8].p + 24;
+        HIP_TRY(hipMemsetAsync(d_nheavy, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_ext_split, dim3(grid_of(n, 256)), dim3(256), 0, ctx->stream, d_sdoff, n, (i64*)E[18].p, d_nheavy);
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpyAsync(&h, d_nheavy, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        n_heavy = (i64)h; d_heavy = (const i64*)E[18].p;
+    }
+    // a kernel that walks the reads of [X.g0, X.g0 + X.ns): one launch of wavefronts, or -- split, and the range is the whole batch -- eight lanes per light read + a wavefront per listed read
+    auto launch_jobs = [&](ExtArgs X, bool write) {
+        const bool two = split && X.g0 == 0 && X.ns == n;
+        X.list = nullptr; X.nlist = 0; X.light = 0;
+        if (!two) {
+            if (write) hipLaunchKernelGGL((k_ext_jobs<true, 64>), dim3((unsigned)((X.ns + 3) / 4)), dim3(256), 0, ctx->stream, X);
+            else hipLaunchKernelGGL((k_ext_jobs<false, 64>), dim3((unsigned)((X.ns + 3) / 4)), dim3(256), 0, ctx->stream, X);
+            return;
+        }
+        X.light = 1;
+        if (write) hipLaunchKernelGGL((k_ext_jobs<true, 8>), dim3((unsigned)((X.ns + 31) / 32)), dim3(256), 0, ctx->stream, X);
+        else hipLaunchKernelGGL((k_ext_jobs<false, 8>), dim3((unsigned)((X.ns + 31) / 32)), dim3(256), 0, ctx->stream, X);
+        if (n_heavy > 0) {
+            X.light = 0; X.list = d_heavy; X.nlist = n_heavy;
+            if (write) hipLaunchKernelGGL((k_ext_jobs<true, 64>), dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, ctx->stream, X);
+            else hipLaunchKernelGGL((k_ext_jobs<false, 64>), dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, ctx->stream, X);
+        }
+    };
     i64 n_pairs = 0, n_retried = 0, n_calls = 0;
     float bsw_ms = 0.f;
     i64 h_flt[2] = {n_seeds, 0};                    // chained seeds after the filter, alignments it ran
@@ -715,7 +780,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
     // with the band doubled once where the reference doubles it, results folded into the records.  *n_sel_out: what k_ext_advance selected for this round.
     auto run_jobs = [&](i64* n_sel_out) -> int {
         int rc;
-        if (A.mode != 2) hipLaunchKernelGGL((k_ext_jobs<false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, A);      // (in rounds k_ext_advance has counted)
+        if (A.mode != 2) launch_jobs(A, false);      // (in rounds k_ext_advance has counted)
         for (int k = 0; k < 3; ++k) if ((rc = meme_scan_exclusive(ctx, d_cnt + k * (n + 1), d_off + k * (n + 1), n))) return rc;
         i64 tot3[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) HIP_TRY(hipMemcpyAsync(&tot3[k], d_off + k * (n + 1) + n, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -764,7 +829,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
             S.offL = d_off + g0; S.offR = d_off + (n + 1) + g0; S.offB = d_off + 2 * (n + 1) + g0;
             S.job0L = j0L; S.job0R = j0R; S.byte0 = b0;
             S.L = (meme_seqpair*)E[4].p; S.R = (meme_seqpair*)E[5].p; S.seq = (uint8_t*)E[7].p;
-            hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)((g1 - g0 + 3) / 4)), dim3(256), 0, ctx->stream, S);
+            launch_jobs(S, true);
             HIP_TRY(hipGetLastError());
             if (ctx->ext_census) {
                 if (nL) hipLaunchKernelGGL(k_ext_census, dim3(grid_of(nL, 256)), dim3(256), 0, ctx->stream, (const meme_seqpair*)S.L, nL, (const uint8_t*)S.seq, eopt->w, d_census);
@@ -817,12 +882,19 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
         V.P = P; V.state = (int4*)E[17].p; V.act = (uint8_t*)(V.state + (n + 1)); V.sel = V.act + (n + 1); V.cntS = d_cntS;
         V.rmax = A.rmax; V.cntL = A.cntL; V.cntR = A.cntR; V.cntB = A.cntB;
         A.mode = 1; A.state = V.state;
-        hipLaunchKernelGGL((k_ext_jobs<true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, A);
+        launch_jobs(A, true);
         A.sel = V.sel; A.act = V.act;
+        auto launch_advance = [&](AdvArgs X) {
+            X.list = nullptr; X.nlist = 0; X.light = 0;
+            if (!split) { hipLaunchKernelGGL((k_ext_advance<64>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, X); return; }
+            X.light = 1;
+            hipLaunchKernelGGL((k_ext_advance<8>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, ctx->stream, X);
+            if (n_heavy > 0) { X.light = 0; X.list = d_heavy; X.nlist = n_heavy; hipLaunchKernelGGL((k_ext_advance<64>), dim3((unsigned)((n_heavy + 3) / 4)), dim3(256), 0, ctx->stream, X); }
+        };
         for (i64 t = 0; t <= rounds; ++t) {
             HIP_TRY(hipMemsetAsync(V.sel, 0, (size_t)n_seeds, ctx->stream));
             V.mode = t < rounds ? ADV_ONE : ADV_REST;
-            hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, V);
+            launch_advance(V);
             A.mode = 2;
             i64 h_sel = 0;
             if ((rc = run_jobs(&h_sel))) return rc;
@@ -830,7 +902,7 @@ extern "C" int meme_extend_last_batch_host(meme_ctx* ctx, const meme_contig* con
             if (h_sel == 0) break;                      // every read has been walked to its end
         }
         V.mode = ADV_FINISH;
-        hipLaunchKernelGGL(k_ext_advance, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, V);
+        launch_advance(V);
         HIP_TRY(hipGetLastError());
     }
     const i64 n_flt_dropped = n_seeds - h_flt[0];

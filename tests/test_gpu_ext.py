@@ -12,6 +12,13 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["eight-lanes-per-light-read", "wavefront-per-read"])
+def _ext_split(request, monkeypatch):
+    """Round 6: the stage's read-walking kernels run eight lanes per read for reads with at most 8 chained seeds (tuning "ext_split", the default) and a
+    wavefront per read for the rest -- every test of this file both ways."""
+    monkeypatch.setenv("MEME_TUNING", "ext_split=%d" % request.param)
+
+
 def _device_records(tmp_path, I, ext_opt=None, ascii=False, chain_opt=None, live_only=False, rounds=None):
     fa = str(tmp_path / "c.fa")
     synth.write_fasta(fa, I["genome"], name="cg", contigs=3)

@@ -46,7 +46,7 @@ def _check(ctx, W, gold=None, **kw):
         assert np.array_equal(dj["len1"], jobs["len1"]) and np.array_equal(dj["len2"], jobs["len2"]) and np.array_equal(dj["xtra"], jobs["xtra"])
         if jobs.shape[0]:
             kj, ref, qer = O.matesw_job_seqs(jobs, W["text"], W["reads"], W["read_off"])
-            want, _ = O.kswv_batch(kj, ref, qer, a=kw.get("a", 1))
+            want, _ = O.kswv_batch(kj, ref, qer, a=kw.get("a", 1), b=kw.get("b", 4))
             got = R["res"][j0:j1]
             for f in want.dtype.names:
                 assert np.array_equal(got[f], want[f]), ("kswr field", f, "batch", b)
