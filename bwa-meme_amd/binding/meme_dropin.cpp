@@ -170,6 +170,7 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
         // the second slot's ctx (chunks alternate between two, see "the next chunk ahead of its turn"): created and given its buffers
         // now, while the index loads -- its first chunk otherwise pays 0.25 s of allocations in the middle of the run
         if (getenv("MEME_DROPIN_SAM_MAX_BATCH")) meme_set_tuning(g_dev[(size_t)d].seed, "sam_max_batch", atoll(getenv("MEME_DROPIN_SAM_MAX_BATCH")));   // (tests: the SAM text stage in pieces / by the reference's function)
+        if (verify_on() && !(g_dev[(size_t)d].vfy_bsw = meme_ctx_create(d % n_real))) die("meme_ctx_create");
         if (verify_on())
             for (int k = 0; k < 2; ++k) {
                 if (!(g_dev[(size_t)d].vfy[k] = meme_ctx_create(d % n_real))) die("meme_ctx_create");
@@ -197,7 +198,8 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
     for (auto& t : th) t.join();
     for (int d = 0; d < n; ++d) if (g_dev[(size_t)d].seed2 && meme_index_share(g_dev[(size_t)d].seed2, g_dev[(size_t)d].seed)) die("meme_index_share");
     for (int d = 0; d < n; ++d) for (int k = 0; k < 2; ++k) if (g_dev[(size_t)d].vfy[k] && meme_index_share(g_dev[(size_t)d].vfy[k], g_dev[(size_t)d].seed)) die("meme_index_share");
-    for (int d = 0; d < n; ++d) if (meme_index_share(g_dev[(size_t)d].bsw, g_dev[(size_t)d].seed)) die("meme_index_share");      // (mate rescue poses its jobs from the text: round 6)
+    for (int d = 0; d < n; ++d) if (meme_index_share(g_dev[(size_t)d].bsw, g_dev[(size_t)d].seed)) die("meme_index_share");
+    for (int d = 0; d < n; ++d) if (g_dev[(size_t)d].vfy_bsw && meme_index_share(g_dev[(size_t)d].vfy_bsw, g_dev[(size_t)d].seed)) die("meme_index_share");      // (mate rescue poses its jobs from the text: round 6)
     fprintf(stderr, "[meme-dropin] index staged in HBM in %.2f s, replicated to %d more GPU(s) in %.2f s\n", t1 - t0, n - 1,
             now_s() - t1);
 }

@@ -57,6 +57,7 @@ struct Device {
     meme_ctx* seed2 = nullptr;    // shares seed's index: chunks alternate between the two, so that the next chunk's device stages can run
                                   // while this chunk's reads, seeds and alignment records are still in use (created with the first prefetch)
     meme_ctx* bsw = nullptr;      // second ctx of the GPU: BandedPairWiseSW calls (host extension stage), mate rescue
+    meme_ctx* vfy_bsw = nullptr;  // MEME_DROPIN_VERIFY: the second run of mate rescue (its pre-pass runs beside the CIGAR pre-pass, which verifies on vfy[slot]: a ctx is one thread's)
     meme_ctx* vfy[2] = {nullptr, nullptr};   // MEME_DROPIN_VERIFY: per chunk slot a ctx with buffers (and a history) of its own on which every device stage runs once more
 };
 // MEME_DROPIN_VERIFY=1 (round 6, the determinism question): every device stage of every chunk -- seeding + chaining + extension records, the CIGAR

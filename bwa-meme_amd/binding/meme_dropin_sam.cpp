@@ -143,9 +143,9 @@ int matesw_prepass_device() {
         R.aln.resize((size_t)H.njobs);
         if (H.njobs) memcpy(R.aln.data(), H.res, (size_t)H.njobs * sizeof(kswr_t));
         R.pose_ms = H.pose_ms; R.kernel_ms = H.kernel_ms;
-        if (verify_on() && P.vfy) {                              // MEME_DROPIN_VERIFY: the same on the ctx that holds the same reads
+        if (verify_on() && g_dev[(size_t)d].vfy_bsw) {           // MEME_DROPIN_VERIFY: the same once more on a ctx of its own (the slot's verify ctx belongs to the CIGAR pre-pass running beside this one)
             meme_mate_host_result V;
-            if (meme_matesw_batch_host(P.vfy, nullptr, G.regs + base, off.data(), P.count, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
+            if (meme_matesw_batch_host(g_dev[(size_t)d].vfy_bsw, P.ctx, G.regs + base, off.data(), P.count, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
             if (V.njobs != H.njobs || V.n_gar != (int64_t)R.gar.size() || (V.n_gar && memcmp(V.gar, R.gar.data(), (size_t)V.n_gar * 4) != 0)) verify_fail("mate rescue (jobs posed)", -1, "");
             for (int64_t k = 0; k < V.njobs; ++k) if (memcmp(&V.res[k], &R.aln[(size_t)k], sizeof(kswr_t)) != 0) verify_fail("mate-rescue Smith-Waterman", k, "");
             verify_note(g_chunk.seq, "mate-rescue", d, verify_hash(R.aln.data(), R.aln.size() * sizeof(kswr_t), verify_hash(R.gar.data(), R.gar.size() * 4)), V.njobs);
@@ -282,9 +282,9 @@ bool matesw_prepass_host() {
         static_assert(sizeof(kswr_t) == sizeof(meme_kswr) && offsetof(kswr_t, score) == 0 && offsetof(kswr_t, te) == 4 && offsetof(kswr_t, qe) == 8 &&
                       offsetof(kswr_t, score2) == 12 && offsetof(kswr_t, te2) == 16 && offsetof(kswr_t, tb) == 20 && offsetof(kswr_t, qb) == 24, "kswr_t layout");
         memcpy(&T.aln[(size_t)j0], R.res, (size_t)nj * sizeof(kswr_t));
-        if (verify_on() && g_chunk.part[(size_t)d].vfy) {              // MEME_DROPIN_VERIFY: the same jobs on another ctx of the GPU
+        if (verify_on() && g_dev[(size_t)d].vfy_bsw) {                 // MEME_DROPIN_VERIFY: the same jobs on another ctx of the GPU
             meme_kswv_host_result V;
-            if (meme_kswv_batch_host(g_chunk.part[(size_t)d].vfy, jobs.data(), nj, ref.data(), rtot, qer.data(), qtot, &bo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
+            if (meme_kswv_batch_host(g_dev[(size_t)d].vfy_bsw, jobs.data(), nj, ref.data(), rtot, qer.data(), qtot, &bo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
             for (int64_t k = 0; k < nj; ++k) if (memcmp(&T.aln[(size_t)(j0 + k)], &V.res[k], sizeof(kswr_t)) != 0) verify_fail("mate-rescue Smith-Waterman", k, "");
             verify_note(g_chunk.seq, "mate-rescue", d, verify_hash(V.res, (size_t)nj * sizeof(kswr_t)), nj);
         }

@@ -43,7 +43,7 @@ def test_seeding_chaining_extension_equal_the_oracle_on_a_repeat_dense_genome():
         sm, ns, oh, nh, _ = O.seed_batch(idx, reads, off, smem_cap=4096, hit_cap=1 << 18, threads=0)
         assert O.format_seed_dump(slots, counts, hl) == O.format_seed_dump(sm, ns, oh)
         hits_per_read = hits.shape[0] / nreads
-        assert hits_per_read > 40 and int(smems["hitcount"].max()) > 500, ("the genome is not repeat-dense for these reads: %.1f hits per read, longest hit list %d (max_occ 500)"
+        assert hits_per_read > 25 and int(smems["hitcount"].max()) > 500, ("the genome is not repeat-dense for these reads: %.1f hits per read, longest hit list %d (max_occ 500)"
                                                                             % (hits_per_read, int(smems["hitcount"].max())))
         # the same with 8 SMEM slots per read in the first tier: most reads go through the overflow tiers
         ctx.set_tuning("smem_cap", 8)
