@@ -36,17 +36,22 @@ struct MateTable {
     std::vector<kswr_t> aln;                     // records, batch after batch, in the order the jobs were posed (= regid)
     std::vector<std::vector<int32_t>> gar;       // per batch: job index (or -1) of every (alignment, orientation) mem_matesw_batch_pre looked at
     uint64_t gen = 0;                            // chunk the table belongs to
+    int64_t lo = 0, hi = 0;                      // the reads it covers: [lo, hi) of the chunk, lo a multiple of BATCH_SIZE (round 6: a chunk's SAM phase runs in two halves)
+};
+MateTable g_mate_tab[2];
+struct MateShared {                              // (the halves' pre-passes never run at the same time)
     double t_prepass = 0, t_kernel_ms = 0;
     int64_t n_jobs = 0;
-    mem_cache* cache = nullptr;                  // the pre-pass's own buffers, one slot per helper thread
+    mem_cache* cache = nullptr;                  // the host pre-pass's own buffers, one slot per helper thread
     int slots = 0;
 } g_mate;
+struct HalfRange { int64_t lo = 0, hi = 0; } g_half[2];          // of the chunk being processed; [1] empty when the chunk is not split
 std::atomic<int64_t> g_mate_hits{0}, g_mate_miss{0};
 // worker_sam's paired-end branch after its first two steps (src/bwamem.cpp:1879-1900), the results of those coming from the table
 void sam_worker_dev(void* data, long seqid, long batch_size, int tid) {
     worker_t* w = (worker_t*)data;
-    const MateTable& T = g_mate;
-    const size_t b = (size_t)(seqid / BATCH_SIZE);
+    const MateTable& T = g_mate_tab[(g_half[1].hi > g_half[1].lo && seqid >= g_half[1].lo) ? 1 : 0];      // (g_half is fixed before the phase's threads start)
+    const size_t b = (size_t)((seqid - T.lo) / BATCH_SIZE);
     const std::vector<int32_t>& gar = T.gar[b];
     if (!gar.empty()) memcpy(w->mmc.seqPairArrayAux[tid], gar.data(), gar.size() * sizeof(int32_t));     // where mem_sam_pe_batch_post reads it
     kswr_t* myaln = const_cast<kswr_t*>(T.aln.data()) + T.off[b];
@@ -94,25 +99,25 @@ std::atomic<int64_t> g_mate_posed_dev{0};
 double g_mate_pose_ms = 0;
 
 // 1: the table is filled, 0: too few jobs (worker_sam runs as it is), -1: the device stage is not available for this chunk (the host poses)
-int matesw_prepass_device() {
+int matesw_prepass_device(int h) {
     const double t0 = now_s();
     worker_t* w = g_worker;
     const mem_opt_t* opt = g_opt;
-    const int64_t n = g_chunk.n;
+    const int64_t lo = g_half[h].lo, n = g_half[h].hi - lo;     // the half's reads are [lo, lo + n) of the chunk; index g below is relative to lo
     const int nd = (int)g_dev.size();
-    if (n & 1) return -1;
+    if ((n & 1) || (lo % BATCH_SIZE) != 0) return -1;
     for (int d = 0; d < nd; ++d) { const ChunkPart& P = g_chunk.part[(size_t)d]; if (P.count > 0 && (!P.reads_on_ctx || (P.first % BATCH_SIZE) != 0)) return -1; }
     MateStage& G = g_mate_stage;
     if (n + 1 > G.off_cap) { meme_host_free(G.off); G.off_cap = n + n / 4 + 64; if (!(G.off = (int64_t*)meme_host_alloc(G.off_cap * 8))) die("meme_host_alloc"); }
     const int nt = cig_threads();
-    team_for(n, nt, [&](int64_t g0, int64_t g1, int) { for (int64_t g = g0; g < g1; ++g) G.off[g + 1] = (int64_t)w->regs[g].n; });
+    team_for(n, nt, [&](int64_t g0, int64_t g1, int) { for (int64_t g = g0; g < g1; ++g) G.off[g + 1] = (int64_t)w->regs[lo + g].n; });
     G.off[0] = 0;
     for (int64_t g = 0; g < n; ++g) G.off[g + 1] += G.off[g];
     const int64_t nrec = G.off[n];
     if (nrec + 1 > G.regs_cap) { meme_host_free(G.regs); G.regs_cap = nrec + nrec / 4 + 4096; if (!(G.regs = (meme_mate_reg*)meme_host_alloc(G.regs_cap * (int64_t)sizeof(meme_mate_reg)))) die("meme_host_alloc"); }
     team_for(n, nt, [&](int64_t g0, int64_t g1, int) {
         for (int64_t g = g0; g < g1; ++g) {
-            const mem_alnreg_v& av = w->regs[g];
+            const mem_alnreg_v& av = w->regs[lo + g];
             meme_mate_reg* o = G.regs + G.off[g];
             for (size_t k = 0; k < av.n; ++k) { o[k].rb = av.a[k].rb; o[k].rid = av.a[k].rid; o[k].score = av.a[k].score; }
         }
@@ -125,16 +130,25 @@ int matesw_prepass_device() {
     const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
     struct PartRes { std::vector<int32_t> gar; std::vector<int64_t> gar_off, job_off; std::vector<kswr_t> aln; double pose_ms = 0, kernel_ms = 0; int rc = 0; };
     std::vector<PartRes> PR((size_t)nd);
+    // the half's reads on device slice d: [s0, s1) of the chunk
+    auto part_range = [&](int d, int64_t& s0, int64_t& s1) {
+        const ChunkPart& P = g_chunk.part[(size_t)d];
+        s0 = P.first > lo ? P.first : lo;
+        s1 = P.first + P.count < lo + n ? P.first + P.count : lo + n;
+    };
     auto run_part = [&](int d) {
         const ChunkPart& P = g_chunk.part[(size_t)d];
         PartRes& R = PR[(size_t)d];
-        if (P.count == 0) return;
-        std::vector<int64_t> off((size_t)P.count + 1);
-        const int64_t base = G.off[P.first];
-        for (int64_t i = 0; i <= P.count; ++i) off[(size_t)i] = G.off[P.first + i] - base;
+        int64_t s0, s1;
+        part_range(d, s0, s1);
+        if (s1 <= s0) return;
+        const int64_t cnt = s1 - s0;
+        std::vector<int64_t> off((size_t)cnt + 1);
+        const int64_t base = G.off[s0 - lo];
+        for (int64_t i = 0; i <= cnt; ++i) off[(size_t)i] = G.off[s0 - lo + i] - base;
         meme_mate_host_result H;
         // (the GPU's second ctx executes; the bases are read where the slice's seeding ctx holds them -- that ctx is busy with the CIGAR stage meanwhile)
-        R.rc = meme_matesw_batch_host(g_dev[(size_t)d].bsw, P.ctx, G.regs + base, off.data(), P.count, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &H);
+        R.rc = meme_matesw_batch_host(g_dev[(size_t)d].bsw, P.ctx, G.regs + base, off.data(), s0 - P.first, cnt, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &H);
         if (R.rc) return;
         static_assert(sizeof(kswr_t) == sizeof(meme_kswr), "kswr_t layout");
         R.gar.assign(H.gar, H.gar + H.n_gar);
@@ -145,7 +159,7 @@ int matesw_prepass_device() {
         R.pose_ms = H.pose_ms; R.kernel_ms = H.kernel_ms;
         if (verify_on() && g_dev[(size_t)d].vfy_bsw) {           // MEME_DROPIN_VERIFY: the same once more on a ctx of its own (the slot's verify ctx belongs to the CIGAR pre-pass running beside this one)
             meme_mate_host_result V;
-            if (meme_matesw_batch_host(g_dev[(size_t)d].vfy_bsw, P.ctx, G.regs + base, off.data(), P.count, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
+            if (meme_matesw_batch_host(g_dev[(size_t)d].vfy_bsw, P.ctx, G.regs + base, off.data(), s0 - P.first, cnt, pes, g_contigs.data(), (int32_t)g_contigs.size(), g_bns->l_pac, &mo, &V)) die("MEME_DROPIN_VERIFY: the second run of the mate-rescue stage");
             if (V.njobs != H.njobs || V.n_gar != (int64_t)R.gar.size() || (V.n_gar && memcmp(V.gar, R.gar.data(), (size_t)V.n_gar * 4) != 0)) verify_fail("mate rescue (jobs posed)", -1, "");
             for (int64_t k = 0; k < V.njobs; ++k) if (memcmp(&V.res[k], &R.aln[(size_t)k], sizeof(kswr_t)) != 0) verify_fail("mate-rescue Smith-Waterman", k, "");
             verify_note(g_chunk.seq, "mate-rescue", d, verify_hash(R.aln.data(), R.aln.size() * sizeof(kswr_t), verify_hash(R.gar.data(), R.gar.size() * 4)), V.njobs);
@@ -161,21 +175,23 @@ int matesw_prepass_device() {
             if (said.fetch_add(1) < 2) fprintf(stderr, "[meme-dropin] mate rescue: the device stage is not available for this chunk (%s): the reference's posing function on the host\n", meme_last_error());
             return -1;
         }
-    MateTable& T = g_mate;
+    MateTable& T = g_mate_tab[h];
+    T.lo = lo; T.hi = lo + n;
     T.off.assign((size_t)nb + 1, 0);
     T.gar.assign((size_t)nb, std::vector<int32_t>());
     int64_t total = 0;
     for (int d = 0; d < nd; ++d) total += (int64_t)PR[(size_t)d].aln.size();
     g_mate_jobs_per_read = n > 0 ? (double)total / (double)n : 0;
-    if (total < matesw_min_jobs() && !mate_check()) { T.t_prepass += now_s() - t0; T.gen = 0; return 0; }
+    if (total * (g_chunk.n / (n > 0 ? n : 1)) < matesw_min_jobs() && !mate_check()) { g_mate.t_prepass += now_s() - t0; T.gen = 0; return 0; }
     T.aln.resize((size_t)total);
     int64_t jbase = 0;
     double km = 0, pm = 0;
     for (int d = 0; d < nd; ++d) {
-        const ChunkPart& P = g_chunk.part[(size_t)d];
         const PartRes& R = PR[(size_t)d];
-        if (P.count == 0) continue;
-        const int64_t b0 = P.first / BATCH_SIZE, nbl = (int64_t)R.gar_off.size() - 1;
+        int64_t s0, s1;
+        part_range(d, s0, s1);
+        if (s1 <= s0) continue;
+        const int64_t b0 = (s0 - lo) / BATCH_SIZE, nbl = (int64_t)R.gar_off.size() - 1;
         for (int64_t b = 0; b < nbl; ++b) {
             T.off[(size_t)(b0 + b)] = jbase + R.job_off[(size_t)b];
             T.gar[(size_t)(b0 + b)].assign(R.gar.begin() + R.gar_off[(size_t)b], R.gar.begin() + R.gar_off[(size_t)b + 1]);
@@ -185,24 +201,24 @@ int matesw_prepass_device() {
         km = km > R.kernel_ms ? km : R.kernel_ms; pm = pm > R.pose_ms ? pm : R.pose_ms;
     }
     T.off[(size_t)nb] = total;
-    T.t_kernel_ms += km; g_mate_pose_ms += pm; T.n_jobs += total; g_mate_posed_dev += total;
-    T.t_prepass += now_s() - t0;
+    g_mate.t_kernel_ms += km; g_mate_pose_ms += pm; g_mate.n_jobs += total; g_mate_posed_dev += total;
+    g_mate.t_prepass += now_s() - t0;
     T.gen = g_chunk_gen;
     return 1;
 }
 
-bool matesw_prepass_host();
-bool matesw_prepass() {                          // false: too few jobs for the device, worker_sam runs as it is
+bool matesw_prepass_host(int h);
+bool matesw_prepass(int h) {                     // false: too few jobs for the device, worker_sam runs as it is (for this half of the chunk)
     if (mate_pose_on_device()) {
-        const int r = matesw_prepass_device();
+        const int r = matesw_prepass_device(h);
         if (r >= 0 && !mate_check()) return r == 1;
         if (r >= 0) {                            // MEME_DROPIN_MATE_CHECK: the reference's own posing function over the same records, then its jobs on the device as before
             MateTable dev;
-            dev.off = g_mate.off; dev.aln = g_mate.aln; dev.gar = g_mate.gar;
+            dev.off = g_mate_tab[h].off; dev.aln = g_mate_tab[h].aln; dev.gar = g_mate_tab[h].gar;
             const int64_t dev_jobs = (int64_t)dev.aln.size();
             g_mate.n_jobs -= dev_jobs;           // (counted again below)
-            const bool ok = matesw_prepass_host();
-            const MateTable& H = g_mate;
+            const bool ok = matesw_prepass_host(h);
+            const MateTable& H = g_mate_tab[h];
             if (!ok) { if (dev_jobs >= matesw_min_jobs()) { fprintf(stderr, "[meme-dropin] MATE_CHECK: the host poses fewer jobs than the threshold, the device %lld\n", (long long)dev_jobs); exit(1); } return false; }
             bool same = dev.off == H.off && dev.gar.size() == H.gar.size() && dev.aln.size() == H.aln.size();
             // (the host path pre-fills its job index buffer with -1 in this mode: the reference leaves entries it does not pose unwritten, the device writes -1)
@@ -212,24 +228,26 @@ bool matesw_prepass() {                          // false: too few jobs for the 
             return true;
         }
     }
-    return matesw_prepass_host();
+    return matesw_prepass_host(h);
 }
 
-bool matesw_prepass_host() {
+bool matesw_prepass_host(int h) {
     const double t0 = now_s();
     worker_t* w = g_worker;
     const mem_opt_t* opt = g_opt;
-    const int64_t n = g_chunk.n;
+    const int64_t lo = g_half[h].lo, n = g_half[h].hi - lo;     // the half's reads: [lo, lo + n) of the chunk
     const int64_t nb = (n + BATCH_SIZE - 1) / BATCH_SIZE;
     const int nt = cig_threads();
     if (!g_mate.cache) mate_cache_init(nt);
     struct BatchJobs { std::vector<meme_kswv_job> jobs; std::vector<uint8_t> ref, qer; };
     std::vector<BatchJobs> B((size_t)nb);
-    g_mate.gar.assign((size_t)nb, std::vector<int32_t>());
+    MateTable& T = g_mate_tab[h];
+    T.lo = lo; T.hi = lo + n;
+    T.gar.assign((size_t)nb, std::vector<int32_t>());
     std::atomic<int64_t> next_b{0};
     team_run(g_mate.slots, [&](int t) {                             // (one buffer slot per share; batches handed out one by one)
     for (int64_t b = next_b.fetch_add(1); b < nb; b = next_b.fetch_add(1)) {
-        const int64_t st = b * BATCH_SIZE, ed = (b + 1) * BATCH_SIZE < n ? (b + 1) * BATCH_SIZE : n;
+        const int64_t st = lo + b * BATCH_SIZE, ed = lo + ((b + 1) * BATCH_SIZE < n ? (b + 1) * BATCH_SIZE : n);
         int64_t pcnt = 0;
         int32_t gcnt = 0, maxRef = 0, maxQer = 0;
         int64_t pos = st >> 1;
@@ -238,7 +256,7 @@ bool matesw_prepass_host() {
             mem_sam_pe_batch_pre(opt, w->fmi->idx->bns, w->fmi->idx->pac, w->pes, (uint64_t)((w->n_processed >> 1) + pos++), &w->seqs[i], &w->regs[i], g_mate.cache,
                                  pcnt, gcnt, maxRef, maxQer, t);
         BatchJobs& J = B[(size_t)b];
-        g_mate.gar[(size_t)b].assign((const int32_t*)g_mate.cache->seqPairArrayAux[t], (const int32_t*)g_mate.cache->seqPairArrayAux[t] + gcnt);
+        T.gar[(size_t)b].assign((const int32_t*)g_mate.cache->seqPairArrayAux[t], (const int32_t*)g_mate.cache->seqPairArrayAux[t] + gcnt);
         if (pcnt == 0) continue;
         const SeqPair* sp = g_mate.cache->seqPairArrayLeft128[t];
         const int64_t rbytes = (int64_t)sp[pcnt - 1].idr + sp[pcnt - 1].len1, qbytes = (int64_t)sp[pcnt - 1].idq + sp[pcnt - 1].len2;
@@ -248,12 +266,11 @@ bool matesw_prepass_host() {
         for (int64_t k = 0; k < pcnt; ++k) { meme_kswv_job& j = J.jobs[(size_t)k]; j.idr = sp[k].idr; j.idq = sp[k].idq; j.len1 = sp[k].len1; j.len2 = sp[k].len2; j.xtra = sp[k].h0; j.pad = 0; }
     }
     });
-    MateTable& T = g_mate;
     T.off.assign((size_t)nb + 1, 0);
     for (int64_t b = 0; b < nb; ++b) T.off[(size_t)b + 1] = T.off[(size_t)b] + (int64_t)B[(size_t)b].jobs.size();
     const int64_t total = T.off[(size_t)nb];
     g_mate_jobs_per_read = n > 0 ? (double)total / (double)n : 0;
-    if (total < matesw_min_jobs()) { T.t_prepass += now_s() - t0; T.gen = 0; return false; }
+    if (total * (g_chunk.n / (n > 0 ? n : 1)) < matesw_min_jobs()) { g_mate.t_prepass += now_s() - t0; T.gen = 0; return false; }
     T.aln.resize((size_t)total);
     // the chunk's batches in contiguous runs over the GPUs, one call each
     const int nd = (int)g_dev.size();
@@ -296,7 +313,7 @@ bool matesw_prepass_host() {
     for (auto& x : th) x.join();
     double km = 0;
     for (double v : kms) km = km > v ? km : v;
-    T.t_kernel_ms += km; T.n_jobs += total; T.t_prepass += now_s() - t0;
+    g_mate.t_kernel_ms += km; g_mate.n_jobs += total; g_mate.t_prepass += now_s() - t0;
     T.gen = g_chunk_gen;
     return true;
 }
@@ -341,14 +358,15 @@ namespace dropin {
 struct CigEntry { int64_t rb; int64_t blob; int32_t g, qb, qlen, tlen, w_, score, n_cigar, nm, md_len, pad; };     // blob: the entry's n_cigar operations, then its MD string + NUL
 struct CigTable {
     std::mutex mu;
-    uint64_t gen = 0;
+    std::atomic<uint64_t> gen{0};                        // chunk the table belongs to; published (release) when the table is complete: the other half's workers may be looking
     std::vector<CigEntry> e;
     std::vector<char> blob;                              // per entry what the hook returns: operations + MD, back to back
     std::vector<uint32_t> slot;                          // open addressing: entry + 1, 0 = empty; size a power of two
     uint64_t mask = 0;
     double t_prepass = 0, t_kernel_ms = 0;
     int64_t n_jobs = 0;
-} g_cig;
+} g_cig_tab[2];                                      // one table per half of the chunk (round 6); the totals are kept in [0]
+#define g_cig g_cig_tab[0]
 std::atomic<int64_t> g_cig_hits{0}, g_cig_miss{0};
 // (the hook's counters per thread, added to the totals when a worker thread ends: two shared atomics touched four million times per
 // 4 M reads by 64 threads cost more than the look-ups they count)
@@ -368,13 +386,13 @@ inline int infer_bw_(int l1, int l2, int score, int a, int q, int r) {        //
 // helper threads of the pre-pass's host loops: a few dozen are enough, and an OpenMP team of 256 would still be spinning when worker_sam starts
 int cig_threads() { static const int m = (int)std::thread::hardware_concurrency(); return m < 1 ? 1 : (m < 32 ? m : 32); }
 
-void cig_prepass() {
+void cig_prepass(int h) {
     const double t0 = now_s();
     double cpu0; { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); cpu0 = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
-    CigTable& T = g_cig;
+    CigTable& T = g_cig_tab[h];
     T.e.clear(); T.blob.clear();
     const mem_opt_t* opt = g_opt;
-    const int64_t n = g_chunk.n, l_pac = g_bns->l_pac;
+    const int64_t h_lo = g_half[h].lo, n = g_half[h].hi - h_lo, l_pac = g_bns->l_pac;      // the half's reads: [h_lo, h_lo + n) of the chunk
     // per alignment record: where mem_reg2aln's loop stands (band argument of the next call, score of the last one)
     struct Cand { int64_t g; int32_t reg, w2, last_sc, tries; };
     std::vector<Cand> cand;
@@ -383,7 +401,7 @@ void cig_prepass() {
         std::vector<std::vector<Cand>> part((size_t)nt);
         team_for(n, nt, [&](int64_t g_lo, int64_t g_hi, int t) {
             std::vector<Cand>& mine = part[(size_t)t];
-            for (int64_t g = g_lo; g < g_hi; ++g) {
+            for (int64_t g = h_lo + g_lo; g < h_lo + g_hi; ++g) {
                 const mem_alnreg_v& av = g_worker->regs[g];
                 for (size_t i = 0; i < av.n; ++i) {
                     const mem_alnreg_t& p = av.a[i];
@@ -476,7 +494,7 @@ void cig_prepass() {
                         for (int64_t k = 0; k < m; ++k)
                             if (memcmp(V.cigars + R.res[k].cigar_off, R.cigars + R.res[k].cigar_off, (size_t)R.res[k].n_cigar * 4) != 0 || memcmp(V.md + R.res[k].md_off, R.md + R.res[k].md_off, (size_t)R.res[k].md_len + 1) != 0)
                                 verify_fail("CIGAR (operations / MD string of a call)", P.done + k, g_chunk.seqs[g_chunk.part[(size_t)d].first + Jv[(size_t)(P.done + k)].read].name);
-                    char st[48]; snprintf(st, sizeof(st), "cigar-round-%d", round);
+                    char st[48]; snprintf(st, sizeof(st), "cigar-round-%d%s", round, h ? "-half2" : "");
                     verify_note(g_chunk.seq, st, d, h, m);
                 }
                 // operations and MD string of every job back to back: the device packs both in job order, so 4 x cigar_off + md_off is a packing too
@@ -507,8 +525,8 @@ void cig_prepass() {
         for (int d = 0; d < nd; ++d) {
             const Part& R = part[(size_t)d];
             if (R.done == 0) continue;
-            T.t_kernel_ms += R.kernel_ms;
-            T.n_jobs += R.done;
+            g_cig.t_kernel_ms += R.kernel_ms;
+            g_cig.n_jobs += R.done;
             const size_t e0 = T.e.size(), b0 = T.blob.size();
             T.blob.insert(T.blob.end(), R.blob.begin(), R.blob.end());
             T.e.resize(e0 + (size_t)R.done);
@@ -558,7 +576,7 @@ void cig_prepass() {
         }
         });
     }
-    T.t_prepass += now_s() - t0;
+    g_cig.t_prepass += now_s() - t0;
     if (verbose()) {
         timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
         fprintf(stderr, "[meme-dropin] CIGAR pre-pass of this chunk %.3f s (process CPU %.2f s): candidates %.3f, jobs posed %.3f, backend calls %.3f, results taken %.3f, table %.3f\n", now_s() - t0,
@@ -574,12 +592,15 @@ extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, 
     static const gen_cigar2_fn next = (gen_cigar2_fn)ref_sym(R_BWA_GEN_CIGAR2);
     PROF_SCOPE(P_GEN_CIGAR2_HOOK);
     const mem_opt_t* opt = g_opt;
-    const CigTable& T = g_cig;
-    if (!cigar_on_device() || !score || !n_cigar || !NM || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || T.gen != g_chunk_gen || mat != opt->mat || o_del != opt->o_del ||
+    if (!cigar_on_device() || !score || !n_cigar || !NM || !g_chunk.seqs || !g_worker || !opt || g_dev.empty() || mat != opt->mat || o_del != opt->o_del ||
         e_del != opt->e_del || o_ins != opt->o_ins || e_ins != opt->e_ins || !g_bns || l_pac != g_bns->l_pac || l_query <= 0 || rb >= re || re - rb > 0x7fffffff)
         return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
     const int tlen = (int)(re - rb);
-    for (uint64_t h = cig_key(rb, l_query, tlen, w_) & T.mask;; h = (h + 1) & T.mask) {
+    const uint64_t key = cig_key(rb, l_query, tlen, w_);
+    for (int half = 0; half < 2; ++half) {               // (a read's calls are in its own half's table; the other one is looked at for what it may hold, once it is published)
+    const CigTable& T = g_cig_tab[half];
+    if (T.gen.load(std::memory_order_acquire) != g_chunk_gen) continue;
+    for (uint64_t h = key & T.mask;; h = (h + 1) & T.mask) {
         const uint32_t s = T.slot[(size_t)h];
         if (!s) break;
         const CigEntry& E = T.e[s - 1];
@@ -593,6 +614,7 @@ extern "C" uint32_t* bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, 
         *score = E.score; *n_cigar = E.n_cigar; *NM = E.nm;
         ++tl_cig.hits;
         return cg;
+    }
     }
     ++tl_cig.miss;
     return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
@@ -968,6 +990,11 @@ void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* 
 // third call every alignment record of the chunk exists and no worker thread is running: the CIGAR stage's quiescent point.
 namespace dropin { std::atomic<int> g_ktfor_calls{0}; std::atomic<int>& ktfor_calls() { return g_ktfor_calls; } }
 typedef void (*kt_for_fn)(void (*)(void*, long, long, int), void*, int);
+namespace dropin {
+// the second half of a chunk's worker_sam phase through the reference's kt_for, which counts its batches from read 0
+struct HalfShim { void (*func)(void*, long, long, int) = nullptr; long off = 0; } g_half_shim;
+void sam_half_shim(void* data, long seqid, long batch_size, int tid) { g_half_shim.func(data, seqid + g_half_shim.off, batch_size, tid); }
+}
 void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
     static const kt_for_fn next = (kt_for_fn)ref_sym(R_KT_FOR);
     // (verbose runs: where a chunk's time inside mem_process_seqs goes -- the three worker phases and what lies between them)
@@ -1002,17 +1029,41 @@ void kt_for(void (*func)(void*, long, long, int), void* data, int n) {
         // The two pre-passes side by side (they read the same alignment records, write tables of their own and use different ctxs): while
         // one waits for its kernels the other poses its jobs -- host time that nobody used.  MEME_DROPIN_PREPASS_OVERLAP=0: one after the other.
         static const bool overlap = !(getenv("MEME_DROPIN_PREPASS_OVERLAP") && atoi(getenv("MEME_DROPIN_PREPASS_OVERLAP")) == 0);
-        bool mate_ok = false;
-        std::thread mate_th;
-        if (mate && overlap && cigar_on_device()) mate_th = std::thread([&mate_ok] { mate_ok = matesw_prepass(); });
-        if (cigar_on_device()) {
-            std::lock_guard<std::mutex> lk(g_cig.mu);
-            cig_prepass();
-            g_cig.gen = g_chunk_gen;
+        // Round 6: the phase in two halves.  The pre-passes are a chain of waits for the GPU (a chunk's 24 M CIGAR calls and 46 k mate-rescue jobs:
+        // 40-50 ms of which the kernels are 20) in front of worker_sam, which is all host work: with the chunk split at a worker-batch boundary
+        // the second half's pre-passes run BESIDE the first half's worker_sam -- tables per half, the hooks look at both -- and only the first
+        // half's pre-passes stay on the chunk's critical path.  worker_sam itself runs through the reference's kt_for as before, once per half
+        // (the second call through a shim that adds the half's first read).  MEME_DROPIN_HALVES=0: the whole chunk at once.
+        static const bool halves_on = !(getenv("MEME_DROPIN_HALVES") && atoi(getenv("MEME_DROPIN_HALVES")) == 0);
+        const int64_t nb = ((int64_t)n + BATCH_SIZE - 1) / BATCH_SIZE;
+        const bool paired = (g_opt->flag & MEM_F_PE) != 0;
+        const int64_t n1 = (halves_on && nb >= 8 && (cigar_on_device() || mate)) ? (nb / 2) * BATCH_SIZE : (int64_t)n;
+        g_half[0].lo = 0; g_half[0].hi = n1; g_half[1].lo = n1; g_half[1].hi = n;
+        (void)paired;
+        auto prepass = [&](int h) -> bool {
+            bool mate_ok = false;
+            std::thread mate_th;
+            if (mate && overlap && cigar_on_device()) mate_th = std::thread([&mate_ok, h] { mate_ok = matesw_prepass(h); });
+            if (cigar_on_device()) {
+                std::lock_guard<std::mutex> lk(g_cig_tab[h].mu);
+                cig_prepass(h);
+                g_cig_tab[h].gen.store(g_chunk_gen, std::memory_order_release);
+            }
+            if (mate_th.joinable()) mate_th.join();
+            else if (mate) mate_ok = matesw_prepass(h);
+            return mate_ok;
+        };
+        const bool mate0 = prepass(0);
+        if (n1 == (int64_t)n) next(mate0 ? sam_worker_dev : func, data, n);
+        else {
+            bool mate1 = false;
+            std::thread second([&] { mate1 = prepass(1); });
+            next(mate0 ? sam_worker_dev : func, data, (int)n1);
+            second.join();
+            g_half_shim.func = mate1 ? sam_worker_dev : func;
+            g_half_shim.off = (long)n1;
+            next(sam_half_shim, data, (int)(n - n1));
         }
-        if (mate_th.joinable()) mate_th.join();
-        else if (mate) mate_ok = matesw_prepass();
-        next(mate_ok ? sam_worker_dev : func, data, n);
         if (sam_on_device() && g_cur_chunk_seq >= 0) sam_chunk_closed();      // the worker threads have joined: their descriptors are the output step's now
         return;
     }

@@ -26,7 +26,8 @@ namespace {
 struct MateAux { i64 rb; int read, is_rev; };                  // per job: window start (fwd+rc coordinate), the mate's read, reverse-complemented?
 
 struct MateArgs {
-    const meme_mate_reg* regs; const i64* reg_off; i64 n;       // n reads; pair p = reads 2p, 2p + 1
+    const meme_mate_reg* regs; const i64* reg_off; i64 n;       // n reads, the reads [first, first + n) of the resident batch (first even): pair p = reads 2p, 2p + 1
+    i64 first;
     const i64* read_off;                                        // of the batch resident on the ctx
     meme_pestat pes[4];
     i64 l_pac; const i64* contig_off; const int* contig_len; int n_contigs;
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) k_mate_plan(MateArgs A) {
         const int na = (int)(A.reg_off[r + 1] - A.reg_off[r]);
         const meme_mate_reg* ma = A.regs + A.reg_off[m];
         const int nm = (int)(A.reg_off[m + 1] - A.reg_off[m]);
-        const int l_ms = (int)(A.read_off[m + 1] - A.read_off[m]);
+        const int l_ms = (int)(A.read_off[A.first + m + 1] - A.read_off[A.first + m]);
         const int xtra = 0x40000 | 0x80000 | (l_ms * A.a < 250 ? 0x10000 : 0) | (A.min_seed_len * A.a);      // KSW_XSUBO | KSW_XSTART | KSW_XBYTE | threshold (:1135)
         i64 nq = 0, nj = 0, nr = 0;
         i64 q0 = 0, j0 = 0, r0 = 0, y0 = 0, jb = 0;
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) k_mate_plan(MateArgs A) {
                             meme_kswv_job J;
                             J.idr = r0 + nr; J.idq = y0 + nj * l_ms; J.len1 = (int)(re - rb); J.len2 = l_ms; J.xtra = xtra; J.pad = 0;
                             A.jobs[j0 + nj] = J;
-                            MateAux X; X.rb = rb; X.read = (int)m; X.is_rev = is_rev;
+                            MateAux X; X.rb = rb; X.read = (int)(A.first + m); X.is_rev = is_rev;
                             A.aux[j0 + nj] = X;
                             idx = (int)(j0 + nj - jb);                                   // relative to the worker batch's first job: what the third step indexes with
                         }
@@ -151,7 +152,7 @@ unsigned blocks_for(i64 items, int per) { i64 b = (items + per - 1) / per; const
 
 }  // namespace
 
-extern "C" int meme_matesw_batch_host(meme_ctx* ctx, meme_ctx* reads_of, const meme_mate_reg* regs, const int64_t* reg_off, int64_t nreads, const meme_pestat* pes,
+extern "C" int meme_matesw_batch_host(meme_ctx* ctx, meme_ctx* reads_of, const meme_mate_reg* regs, const int64_t* reg_off, int64_t first_read, int64_t nreads, const meme_pestat* pes,
                                       const meme_contig* contigs, int32_t n_contigs, int64_t l_pac, const meme_mate_opt* opt, meme_mate_host_result* out) {
     static const char* const who = "meme_matesw_batch_host";
     if (!ctx || !reg_off || !pes || !contigs || n_contigs < 1 || !opt || !out || nreads < 0) { meme_set_error("%s: null argument", who); return MEME_E_ARG; }
@@ -162,11 +163,12 @@ extern "C" int meme_matesw_batch_host(meme_ctx* ctx, meme_ctx* reads_of, const m
     // on the ctx that seeded the batch: the bases are only read, device pointers are valid across the ctxs of a device)
     meme_ctx* const rc_ = reads_of ? reads_of : ctx;
     if (rc_->device != ctx->device) { meme_set_error("%s: the ctx that holds the reads is on another device", who); return MEME_E_ARG; }
-    if (nreads != rc_->last_seed_reads || !rc_->reads_resident || !rc_->reads.p || !rc_->read_off.p) {
-        meme_set_error("%s: the %lld reads must be the batch resident on the ctx (a seeding call stages it; it holds %lld)", who, (long long)nreads, (long long)rc_->last_seed_reads);
+    if (first_read < 0 || first_read + nreads > rc_->last_seed_reads || !rc_->reads_resident || !rc_->reads.p || !rc_->read_off.p) {
+        meme_set_error("%s: reads [%lld, %lld) must lie in the batch resident on the ctx (a seeding call stages it; it holds %lld)", who, (long long)first_read, (long long)(first_read + nreads),
+                       (long long)rc_->last_seed_reads);
         return MEME_E_STATE;
     }
-    if (nreads & 1) { meme_set_error("%s: an odd number of reads is not a set of pairs", who); return MEME_E_ARG; }
+    if ((nreads & 1) || (first_read & 1)) { meme_set_error("%s: an odd number of reads (or an odd first read) is not a set of pairs", who); return MEME_E_ARG; }
     if (l_pac * 2 != ctx->idx.n) { meme_set_error("%s: l_pac does not match the loaded index", who); return MEME_E_ARG; }
     if (opt->batch_reads < 2 || (opt->batch_reads & 1) || opt->max_matesw < 0 || opt->a < 1 || opt->min_seed_len < 1) { meme_set_error("%s: bad options", who); return MEME_E_ARG; }
     const i64 nrec = reg_off[nreads];
@@ -195,7 +197,7 @@ extern "C" int meme_matesw_batch_host(meme_ctx* ctx, meme_ctx* reads_of, const m
     HIP_TRY(hipMemcpyAsync(M[2].p, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream));
     MateArgs A;
     memset(&A, 0, sizeof(A));
-    A.regs = (const meme_mate_reg*)M[0].p; A.reg_off = (const i64*)M[1].p; A.n = n; A.read_off = (const i64*)rc_->read_off.p;
+    A.regs = (const meme_mate_reg*)M[0].p; A.reg_off = (const i64*)M[1].p; A.n = n; A.first = first_read; A.read_off = (const i64*)rc_->read_off.p;
     for (int o = 0; o < 4; ++o) A.pes[o] = pes[o];
     A.l_pac = l_pac; A.contig_off = (const i64*)M[2].p; A.contig_len = (const int*)((unsigned char*)M[2].p + (size_t)n_contigs * 8); A.n_contigs = n_contigs;
     A.a = opt->a; A.pen_unpaired = opt->pen_unpaired; A.max_matesw = opt->max_matesw; A.min_seed_len = opt->min_seed_len; A.batch_reads = opt->batch_reads;

@@ -445,7 +445,7 @@ class Context:
         return np.frombuffer(buf, dtype=KSWR, count=res.njobs).copy(), float(res.kernel_ms)
 
     def matesw_batch_host(self, regs, reg_off, pes, contigs, l_pac, a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, pen_unpaired=17, max_matesw=50, min_seed_len=19,
-                          batch_reads=512, reads_of=None):
+                          batch_reads=512, reads_of=None, first_read=0):
         """meme_matesw_batch_host: mate rescue whole for the pairs of the batch resident on the ctx -- the posing step (mem_sam_pe_batch_pre) and the
         Smith-Waterman jobs (mem_sam_pe_batch).  regs: MATE_REG records of all reads, reg_off per read; pes: 4 x (low, high, failed).
         Returns dict(gar, gar_off, job_off, jobs KSWV_JOB, res KSWR, pose_ms, kernel_ms)."""
@@ -456,7 +456,7 @@ class Context:
         arr = (Contig * len(contigs))(*[Contig(int(o), int(l), int(al)) for o, l, al in contigs])
         opt = MateOpt(a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, max_matesw, min_seed_len, batch_reads)
         res = MateHost()
-        _check(lib().meme_matesw_batch_host(C.c_void_p(self.h), C.c_void_p(reads_of.h if reads_of is not None else None), _p(regs), _p(reg_off), C.c_int64(reg_off.shape[0] - 1), _p(pes4), arr, C.c_int32(len(contigs)), C.c_int64(l_pac),
+        _check(lib().meme_matesw_batch_host(C.c_void_p(self.h), C.c_void_p(reads_of.h if reads_of is not None else None), _p(regs), _p(reg_off), C.c_int64(first_read), C.c_int64(reg_off.shape[0] - 1), _p(pes4), arr, C.c_int32(len(contigs)), C.c_int64(l_pac),
                                             C.byref(opt), C.byref(res)))
 
         def view(ptr, count, dtype):

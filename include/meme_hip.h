@@ -367,8 +367,8 @@ int meme_kswv_batch_host(meme_ctx* ctx, const meme_kswv_job* jobs, int64_t njobs
  * (src/bwamem_pair.cpp:660-716) with mem_matesw_batch_pre (:1060-1223) poses, per worker batch of `batch_reads` reads, the Smith-Waterman jobs
  * of mate rescue -- for each end's alignment records within pen_unpaired of its best (at most max_matesw), the orientations that pes[] allows
  * and no record of the mate explains, a window of the reference clamped to the strand and sequence of its midpoint -- and mem_sam_pe_batch
- * runs them (meme_kswv_batch_host above).  The reads are the batch resident on the ctx (pair p = reads 2p, 2p + 1; nreads must equal the
- * batch's), the text is the index's; regs[reg_off[r] .. reg_off[r+1]) = the fields of read r's mem_alnreg_t records the step reads, in the
+ * runs them (meme_kswv_batch_host above).  The reads are [first_read, first_read + nreads) of the batch resident on the ctx (both even; pair p = reads
+ * 2p, 2p + 1; worker batches are counted from first_read), the text is the index's; regs[reg_off[r] .. reg_off[r+1]) = the fields of read r's mem_alnreg_t records the step reads, in the
  * records' order (best score first, as mem_sort_dedup_patch leaves them).  Results, in pinned memory of the ctx until its next call:
  *   gar[gar_off[b] .. gar_off[b+1])   worker batch b's job index array as mem_matesw_batch_pre fills it: four entries per (end, record) looked at,
  *                                     the job's index AMONG THE BATCH'S JOBS or -1 (not posed: mem_sam_pe_batch_post computes it itself)
@@ -385,7 +385,7 @@ typedef struct {
     float pose_ms, kernel_ms;        /* HIP events: the posing kernels (+ scans, sequence unpacking); the Smith-Waterman launches */
 } meme_mate_host_result;
 int meme_matesw_batch_host(meme_ctx* ctx, meme_ctx* reads_of /* NULL: ctx itself; else another ctx of the same GPU whose resident batch is read (not written) */,
-                           const meme_mate_reg* regs, const int64_t* reg_off /* nreads + 1 */, int64_t nreads, const meme_pestat* pes /* 4 */,
+                           const meme_mate_reg* regs, const int64_t* reg_off /* nreads + 1 */, int64_t first_read, int64_t nreads, const meme_pestat* pes /* 4 */,
                            const meme_contig* contigs, int32_t n_contigs, int64_t l_pac, const meme_mate_opt* opt, meme_mate_host_result* out);
 
 /* ---- measurement ---------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ def variants():
         for threads in (4, 16, 64):
             for kname in ("Ksmall", "K100M"):
                 for extra in ({}, {"MEME_DROPIN_PREFETCH": "0"}, {"MEME_DROPIN_VIRTUAL": "3"}, {"MEME_DROPIN_VERIFY": "1"}, {"MEME_DROPIN_VIRTUAL": "2", "MEME_DROPIN_VERIFY": "1"},
-                              {"MEME_DROPIN_SAM": "0"}, {"MEME_DROPIN_CIGAR": "0", "MEME_DROPIN_MATESW": "0"}, {"MEME_DROPIN_PREPASS_OVERLAP": "0"}, {"MEME_DROPIN_VIRTUAL": "8"}):
+                              {"MEME_DROPIN_SAM": "0"}, {"MEME_DROPIN_CIGAR": "0", "MEME_DROPIN_MATESW": "0"}, {"MEME_DROPIN_PREPASS_OVERLAP": "0"}, {"MEME_DROPIN_VIRTUAL": "8"},
+                              {"MEME_DROPIN_HALVES": "0"}, {"MEME_DROPIN_MATE_POSE": "0"}, {"MEME_DROPIN_HALVES": "0", "MEME_DROPIN_VERIFY": "1"}, {"MEME_DROPIN_MATE_CHECK": "1", "MEME_DROPIN_VIRTUAL": "3"}):
                     yield k, threads, kname, dict(extra)
                     k += 1
 
@@ -86,7 +87,7 @@ for k, threads, kname, extra in variants():
     ref = ref_lines[kname]
     ndiff = sum(1 for a, b in zip(ref, lines) if a != b) + abs(len(ref) - len(lines))
     # per-stage hashes must agree between runs that split the chunk the same way (same -K, same number of device slots)
-    split = (kname, extra.get("MEME_DROPIN_VIRTUAL", "1"))
+    split = (kname, extra.get("MEME_DROPIN_VIRTUAL", "1"), extra.get("MEME_DROPIN_HALVES", "1"))
     hm = 0
     if vl:
         if split not in verify_ref:

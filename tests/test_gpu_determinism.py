@@ -49,7 +49,8 @@ def test_sam_identical_under_varied_arrangements_and_stage_verify(tmp_path):
     hashes = {}
     for threads in (4, 16, 64):
         for kname, chunk in chunks.items():
-            for extra in ({}, {"MEME_DROPIN_PREFETCH": "0"}, {"MEME_DROPIN_VIRTUAL": "3"}, {"MEME_DROPIN_VERIFY": "1"}, {"MEME_DROPIN_VIRTUAL": "3", "MEME_DROPIN_VERIFY": "1", "MEME_DROPIN_PREFETCH": "0"}):
+            for extra in ({}, {"MEME_DROPIN_PREFETCH": "0"}, {"MEME_DROPIN_VIRTUAL": "3"}, {"MEME_DROPIN_VERIFY": "1"}, {"MEME_DROPIN_VIRTUAL": "3", "MEME_DROPIN_VERIFY": "1", "MEME_DROPIN_PREFETCH": "0"},
+                          {"MEME_DROPIN_HALVES": "0", "MEME_DROPIN_MATE_POSE": "0"}):      # (the SAM phase in one piece, mate rescue posed on the host: round 5's arrangement)
                 got, err = _run("bwa-meme_dropin", prefix, fqs, threads, chunk, dict(base, **extra))
                 assert len(got) == len(want[kname]) and len(got) > 2 * n
                 diff = [(a, b) for a, b in zip(got, want[kname]) if a != b]
@@ -58,13 +59,13 @@ def test_sam_identical_under_varied_arrangements_and_stage_verify(tmp_path):
                 if extra.get("MEME_DROPIN_VERIFY"):
                     assert "VERIFY FAILED" not in err
                     vl = sorted(re.findall(r"verify chunk (-?\d+) (\S+) dev (\d+): (\d+) items, hash ([0-9a-f]+)", err))
-                    stages = {v[1].split("-round")[0] for v in vl}
+                    stages = {v[1].decode().split("-round")[0] if isinstance(v[1], bytes) else v[1].split("-round")[0] for v in vl}
                     assert {"ext-records", "cigar", "mate-rescue", "sam-text"} <= stages, "stages verified: %r" % (stages,)
                     n_verify_lines += len(vl)
                     # the stage outputs themselves (not only the SAM) agree between runs that split the chunks the same way
                     key = (kname, extra.get("MEME_DROPIN_VIRTUAL", "1"))
                     assert hashes.setdefault(key, vl) == vl, "per-stage hashes differ between two runs of %r" % (key,)
-    assert n_runs == 30 and n_verify_lines > 0
+    assert n_runs == 36 and n_verify_lines > 0
 
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()), reason="compiled reference (oracle/_ref) not available on this box")

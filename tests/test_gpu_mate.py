@@ -78,6 +78,11 @@ def test_mate_rescue_on_the_device_equals_the_reference_golden(tag):
         R2 = other.matesw_batch_host(W["regs"], W["reg_off"], W["pes"], contigs, int(W["l_pac"]), reads_of=ctx)
         assert np.array_equal(R2["gar"], R["gar"]) and hipapi.records_equal(R2["res"], R["res"])
         other.close()
+        # a sub-range of the resident batch (the binding runs a chunk's SAM phase in two halves): reads [512, n) as a call of its own = the whole call's batches 1..
+        lo = 512
+        R3 = ctx.matesw_batch_host(W["regs"][W["reg_off"][lo]:], W["reg_off"][lo:] - W["reg_off"][lo], W["pes"], contigs, int(W["l_pac"]), first_read=lo)
+        assert np.array_equal(R3["gar"], R["gar"][R["gar_off"][1]:]) and hipapi.records_equal(R3["res"], R["res"][R["job_off"][1]:])
+        assert np.array_equal(R3["job_off"], R["job_off"][1:] - R["job_off"][1])
         del keep
     finally:
         ctx.close()
