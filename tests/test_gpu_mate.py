@@ -106,9 +106,12 @@ def test_mate_rescue_on_the_device_equals_the_oracle(seed, pes, kw):
                 assert R["job_off"][b + 1] - R["job_off"][b] == jobs.shape[0]
         else:
             _check(ctx, W, **kw)
-        # a batch that is not the one on the ctx is refused
+        # reads beyond the batch on the ctx, or an odd first read, are refused
+        n = W["read_len"].shape[0]
         with pytest.raises(hipapi.MemeError):
-            ctx.matesw_batch_host(W["regs"][:0], W["reg_off"][:3] * 0, W["pes"], [(0, int(W["l_pac"]), 0)], int(W["l_pac"]))
+            ctx.matesw_batch_host(W["regs"][:0], np.zeros(n + 3, np.int64), W["pes"], [(0, int(W["l_pac"]), 0)], int(W["l_pac"]))
+        with pytest.raises(hipapi.MemeError):
+            ctx.matesw_batch_host(W["regs"][:0], np.zeros(3, np.int64), W["pes"], [(0, int(W["l_pac"]), 0)], int(W["l_pac"]), first_read=1)
         del keep
     finally:
         ctx.close()
