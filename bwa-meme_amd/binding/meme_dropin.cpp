@@ -23,6 +23,10 @@
 //                                   call per GPU (group commit) -- the path of MEME_DROPIN_EXT=0
 #include "meme_dropin.h"
 #include <malloc.h>
+#include <dirent.h>
+#include <unistd.h>
+#include <map>
+#include <string>
 
 #define dropin_smem_lt(a, b) ((a).start == (b).start ? (a).end < (b).end : (a).start < (b).start)
 KSORT_INIT(meme_dropin_smem, mem_tl, dropin_smem_lt)
@@ -115,7 +119,7 @@ void team_run(int nt, const std::function<void(int)>& f) {
     {
         std::lock_guard<std::mutex> lk(T.m);
         const int want = nt - 1 < 48 ? nt - 1 : 48;
-        while (T.threads < want) { std::thread([&T] { T.worker(); }).detach(); ++T.threads; }
+        while (T.threads < want) { std::thread([&T] { pthread_setname_np(pthread_self(), "meme-team"); T.worker(); }).detach(); ++T.threads; }
         T.q.push_back(&J);
     }
     T.cv_work.notify_all();
@@ -210,7 +214,57 @@ void init_devices(const char* prefix, int64_t chunk_reads) {
 // (bns, pac, the 6 GB .0123 text: 1.5 s at GRCh38 size) -- instead of when memoryAllocLearned() is reached.  MEME_DROPIN_EARLY=0: off.
 std::thread* g_early = nullptr;
 const char* g_early_prefix = nullptr;
+// MEME_DROPIN_VERBOSE: where the process's CPU seconds went, by thread role, when the run ends (what a host with a CPU quota is short of): the threads that
+// are still alive -- the binding's helper team (every host loop of the binding), its prefetcher (the device stages' submission, HIP runtime included), its
+// FASTQ parsers, the aligner's two pipeline threads (the pre-passes' serial parts, the output step) -- and, as the remainder, the aligner's kt_for workers
+// (they end with their phase: the reference's own worker_aln / worker_sam code and the hooks called from it).
+std::mutex g_role_mu;
+std::map<std::string, std::pair<double, int>>& role_cpu() { static auto* m = new std::map<std::string, std::pair<double, int>>(); return *m; }
+void note_thread_cpu(const char* role) {
+    timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    std::lock_guard<std::mutex> lk(g_role_mu);
+    auto& e = role_cpu()[role];
+    e.first += (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; e.second += 1;
+}
+void report_thread_cpu() {
+    if (!verbose()) return;
+    const double tick = (double)sysconf(_SC_CLK_TCK);
+    std::map<std::string, std::pair<double, int>> by;
+    double live = 0;
+    char path[256], buf[1024];
+    for (int pass = 0; pass < 1; ++pass) {
+        DIR* d = opendir("/proc/self/task");
+        if (!d) return;
+        while (dirent* e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            snprintf(path, sizeof(path), "/proc/self/task/%s/stat", e->d_name);
+            FILE* f = fopen(path, "r");
+            if (!f) continue;
+            const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+            fclose(f);
+            buf[n] = 0;
+            char* l = strchr(buf, '('); char* r = strrchr(buf, ')');
+            if (!l || !r) continue;
+            std::string name(l + 1, r);
+            unsigned long ut = 0, st = 0;
+            // fields after the name: state ppid pgrp session tty tpgid flags minflt cminflt majflt cmajflt utime stime
+            if (sscanf(r + 2, "%*c %*d %*d %*d %*d %*d %*u %*u %*u %*u %*u %lu %lu", &ut, &st) != 2) continue;
+            const double c = (double)(ut + st) / tick;
+            by[name].first += c; by[name].second += 1; live += c;
+        }
+        closedir(d);
+    }
+    timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+    const double total = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    fprintf(stderr, "[meme-dropin] process CPU %.2f s by thread role (threads alive at the end; the remainder = threads that ended, i.e. the aligner's kt_for workers):", total);
+    for (const auto& kv : by) fprintf(stderr, " %s x%d %.2f s;", kv.first.c_str(), kv.second.second, kv.second.first);
+    double noted = 0;
+    { std::lock_guard<std::mutex> lk(g_role_mu); for (const auto& kv : role_cpu()) { fprintf(stderr, " %s x%d (ended) %.2f s;", kv.first.c_str(), kv.second.second, kv.second.first); noted += kv.second.first; } }
+    fprintf(stderr, " other ended threads (kt_for workers) %.2f s\n", total - live - noted);
+}
+
 __attribute__((constructor)) void meme_dropin_early_start() {
+    atexit(report_thread_cpu);
     // The chaining stage runs four kernels side by side on streams of their own; the HIP runtime multiplexes a process's streams onto 4
     // hardware queues unless told otherwise when it initialises (7.9 -> 7.4 ms per 2 M reads with 8).  This is the aligner's own start-up
     // code, before its first HIP call and before it has threads: the place for it (the backend library itself no longer touches the environment).
@@ -639,6 +693,7 @@ void prefetch_submit(bseq1_t* seqs, int64_t n) {
     if (!F.started && prefetch_on()) {
         F.started = true;
         std::thread([] {
+            pthread_setname_np(pthread_self(), "meme-prefetch");
             Prefetcher& F = *g_pf;
             for (;;) {
                 bseq1_t* seqs = nullptr; int64_t n = 0, seq = 0;

@@ -49,6 +49,7 @@ enum RefSym { R_MEM_PROCESS_SEQS, R_CHAIN2ALN_V2, R_BSEQ_READ_ORIG, R_KT_PIPELIN
 void* ref_sym(RefSym which);
 
 double now_s();
+void note_thread_cpu(const char* role);          // (verbose accounting: a binding thread that ends says how much CPU it used)
 [[noreturn]] void die(const char* what);
 bool verbose();
 

@@ -166,10 +166,11 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
             g_rq[k] = new ReadQueue;
             g_rq[k]->ks = (kseq_t*)ks;
             g_rq[k]->LIMIT = chunk_size > 1000000 ? chunk_size : 1000000;
-            g_rq[k]->th = std::thread([k] { g_rq[k]->run(); });
+            g_rq[k]->th = std::thread([k] { pthread_setname_np(pthread_self(), "meme-parser"); g_rq[k]->run(); note_thread_cpu("meme-parser"); });
         }
         g_ahead.chunk_size = chunk_size;
         g_ahead.th = std::thread([] {
+            pthread_setname_np(pthread_self(), "meme-ahead");
             Ahead& A = g_ahead;
             for (;;) {
                 int64_t n = 0, size = 0;
@@ -177,7 +178,7 @@ extern "C" bseq1_t* bseq_read_orig(int64_t chunk_size, int* n_, void* ks1_, void
                 std::unique_lock<std::mutex> lk(A.m);
                 A.seqs = seqs; A.n = n; A.size = size; A.ready = true;
                 A.cv.notify_all();
-                if (size == 0) return;                              // (the end of the input: handed out once, then the thread is joined)
+                if (size == 0) { note_thread_cpu("meme-ahead"); return; }      // (the end of the input: handed out once, then the thread is joined)
                 A.cv.wait(lk, [&] { return !A.ready; });
             }
         });
