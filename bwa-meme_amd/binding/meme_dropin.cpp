@@ -23,6 +23,7 @@
 //                                   call per GPU (group commit) -- the path of MEME_DROPIN_EXT=0
 #include "meme_dropin.h"
 #include <malloc.h>
+#include <immintrin.h>
 #include <dirent.h>
 #include <unistd.h>
 #include <map>
@@ -88,7 +89,18 @@ void* ref_sym(RefSym which) { return g_ref[which].p; }
 
 // ---- the helper team (see meme_dropin.h) ----------------------------------------------------------------------------------------
 namespace {
-struct TeamJob { const std::function<void(int)>* f; int nt; std::atomic<int> next{0}, done{0}; };
+struct TeamJob { const std::function<void(int)>* f; int nt; std::atomic<int> next{0}, done{0}; const char* label = nullptr; };
+std::mutex g_label_mu;
+std::map<std::string, double>& label_cpu() { static auto* m = new std::map<std::string, double>(); return *m; }
+inline double thread_cpu_s() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+inline void run_share(TeamJob* J, int t) {
+    if (!verbose()) { (*J->f)(t); return; }
+    const double c0 = thread_cpu_s();
+    (*J->f)(t);
+    const double c = thread_cpu_s() - c0;
+    std::lock_guard<std::mutex> lk(g_label_mu);
+    label_cpu()[J->label ? J->label : "(unlabelled)"] += c;
+}
 struct Team {
     std::mutex m;
     std::condition_variable cv_work, cv_done;
@@ -103,7 +115,7 @@ struct Team {
             if (t >= J->nt) { if (!q.empty() && q.front() == J) q.pop_front(); continue; }
             if (t + 1 == J->nt && !q.empty() && q.front() == J) q.pop_front();      // the last share is taken: nobody else needs to look at this job
             lk.unlock();
-            (*J->f)(t);
+            run_share(J, t);
             lk.lock();
             if (J->done.fetch_add(1) + 1 == J->nt) cv_done.notify_all();
         }
@@ -111,11 +123,12 @@ struct Team {
 };
 Team& team() { static Team* T = new Team; return *T; }                          // (never destroyed: its threads sleep until the process ends)
 }  // namespace
+thread_local const char* tl_team_label = nullptr;
 void team_run(int nt, const std::function<void(int)>& f) {
     if (nt <= 1) { if (nt == 1) f(0); return; }
     Team& T = team();
     TeamJob J;
-    J.f = &f; J.nt = nt;
+    J.f = &f; J.nt = nt; J.label = tl_team_label;
     {
         std::lock_guard<std::mutex> lk(T.m);
         const int want = nt - 1 < 48 ? nt - 1 : 48;
@@ -126,7 +139,7 @@ void team_run(int nt, const std::function<void(int)>& f) {
     for (;;) {                                                       // the submitter takes shares of its own job
         const int t = J.next.fetch_add(1);
         if (t >= nt) break;
-        f(t);
+        run_share(&J, t);
         J.done.fetch_add(1);
     }
     std::unique_lock<std::mutex> lk(T.m);
@@ -261,6 +274,7 @@ void report_thread_cpu() {
     double noted = 0;
     { std::lock_guard<std::mutex> lk(g_role_mu); for (const auto& kv : role_cpu()) { fprintf(stderr, " %s x%d (ended) %.2f s;", kv.first.c_str(), kv.second.second, kv.second.first); noted += kv.second.first; } }
     fprintf(stderr, " other ended threads (kt_for workers) %.2f s\n", total - live - noted);
+    { std::lock_guard<std::mutex> lk(g_label_mu); fprintf(stderr, "[meme-dropin] the helper team's CPU by host loop (submitters' own shares included):"); for (const auto& kv : label_cpu()) fprintf(stderr, " %s %.2f s;", kv.first.c_str(), kv.second); fprintf(stderr, "\n"); }
 }
 
 __attribute__((constructor)) void meme_dropin_early_start() {
@@ -444,6 +458,35 @@ meme_seed_opt seed_opt_of(const mem_opt_t* opt) {
     return so;
 }
 
+// Letters to base codes in place, as mem_kernel1_core_Learned leaves a read for the later stages (src/bwamem.cpp:1277-1279: c < 4 ? c : nst_nt4_table[c]).  The byte loop
+// was 1.3-1.7 of the binding's 7.6 CPU-seconds per 8 M reads (profiles/r06_host_cpu.md): 64 bytes at a time where the build has AVX-512BW (the reference's
+// own build flag); a block that holds anything but A C G T N (either case) or codes below 4 goes through the table, so every byte gets the table's value.
+static inline void letters_to_codes(char* p, int n) {
+    int k = 0;
+#if defined(__AVX512BW__)
+    const __m512i c_df = _mm512_set1_epi8((char)0xDF), cA = _mm512_set1_epi8('A'), cC = _mm512_set1_epi8('C'), cG = _mm512_set1_epi8('G'), cT = _mm512_set1_epi8('T'),
+                  cN = _mm512_set1_epi8('N'), four = _mm512_set1_epi8(4);
+    for (; k + 64 <= n; k += 64) {
+        const __m512i v = _mm512_loadu_si512((const void*)(p + k));
+        const __m512i u = _mm512_and_si512(v, c_df);
+        const __mmask64 mA = _mm512_cmpeq_epi8_mask(u, cA), mC = _mm512_cmpeq_epi8_mask(u, cC), mG = _mm512_cmpeq_epi8_mask(u, cG), mT = _mm512_cmpeq_epi8_mask(u, cT),
+                        mN = _mm512_cmpeq_epi8_mask(u, cN), mS = _mm512_cmplt_epu8_mask(v, four);
+        if ((mA | mC | mG | mT | mN | mS) != ~(__mmask64)0) {                  // some other byte: the table, byte by byte
+            for (int j = k; j < k + 64; ++j) { const char c = p[j]; p[j] = c < 4 ? c : (char)nst_nt4_table[(int)c]; }
+            continue;
+        }
+        __m512i r = four;                                                       // N
+        r = _mm512_mask_mov_epi8(r, mT, _mm512_set1_epi8(3));
+        r = _mm512_mask_mov_epi8(r, mG, _mm512_set1_epi8(2));
+        r = _mm512_mask_mov_epi8(r, mC, _mm512_set1_epi8(1));
+        r = _mm512_mask_mov_epi8(r, mA, _mm512_setzero_si512());
+        r = _mm512_mask_mov_epi8(r, mS, v);                                     // codes stay what they are
+        _mm512_storeu_si512((void*)(p + k), r);
+    }
+#endif
+    for (; k < n; ++k) { const char c = p[k]; p[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; }
+}
+
 void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     meme_ctx* const ctx = P.ctx;
     if (P.count + 1 > P.off_cap) { meme_host_free(P.off); P.off_cap = P.count + P.count / 4 + 64; if (!(P.off = (int64_t*)meme_host_alloc(P.off_cap * 8))) die("meme_host_alloc"); }
@@ -458,20 +501,22 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
     // (a few dozen helper threads: an OpenMP team of all 256 host threads takes longer to start than the loop runs, and keeps spinning
     // into the worker phases that follow)
     const bool raw = g_ext_on_device;
+    TeamLabel lbl_("seed: gather reads");
     team_for(P.count, cig_threads(), [&](int64_t i0, int64_t i1, int) {
         for (int64_t i = i0; i < i1; ++i) {
             bseq1_t& s = seqs[P.first + i];
             uint8_t* dst = P.flat + P.off[i];
             if (raw) memcpy(dst, s.seq, (size_t)s.l_seq);
-            else for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; dst[k] = (uint8_t)s.seq[k]; }
+            else { letters_to_codes(s.seq, s.l_seq); memcpy(dst, s.seq, (size_t)s.l_seq); }
         }
     });
     std::thread codes;
     if (raw) codes = std::thread([&P, seqs] {
+        TeamLabel l2("seed: letters to codes in place");
         team_for(P.count, cig_threads() / 2 > 0 ? cig_threads() / 2 : 1, [&](int64_t i0, int64_t i1, int) {
             for (int64_t i = i0; i < i1; ++i) {
                 bseq1_t& s = seqs[P.first + i];
-                for (int k = 0; k < s.l_seq; ++k) { const char c = s.seq[k]; s.seq[k] = c < 4 ? c : (char)nst_nt4_table[(int)c]; }
+                letters_to_codes(s.seq, s.l_seq);
             }
         });
     });
@@ -580,6 +625,7 @@ void seed_part(int d, const mem_opt_t* opt, bseq1_t* seqs, ChunkPart& P) {
             if (with_q == 0 || with_q == P.count) {
                 if (nb + 16 > P.names_cap) { meme_host_free(P.names); P.names_cap = nb + nb / 4 + 4096; if (!(P.names = (char*)meme_host_alloc(P.names_cap))) die("meme_host_alloc"); }
                 if (with_q && bytes + 16 > P.quals_cap) { meme_host_free(P.quals); P.quals_cap = bytes + bytes / 4 + 4096; if (!(P.quals = (char*)meme_host_alloc(P.quals_cap))) die("meme_host_alloc"); }
+                TeamLabel l3("seed: names + qualities for the SAM text");
                 team_for(P.count, cig_threads(), [&](int64_t i0, int64_t i1, int) {
                     for (int64_t i = i0; i < i1; ++i) {
                         const bseq1_t& s = seqs[P.first + i];

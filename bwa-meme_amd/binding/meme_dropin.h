@@ -135,6 +135,9 @@ bool fast_out();                               // MEME_DROPIN_OUT: the binding's
 //   team_run(nt, f)             f(t) for t in [0, nt), on up to nt threads at once; returns when all are done
 //   team_for(n, nt, f)          f(lo, hi, t): [0, n) in nt contiguous ranges
 void team_run(int nt, const std::function<void(int)>& f);
+// (verbose accounting: the CPU seconds of the team's shares are summed per label; a submitter names what follows with `TeamLabel l("...")`)
+extern thread_local const char* tl_team_label;
+struct TeamLabel { const char* prev; explicit TeamLabel(const char* l) : prev(tl_team_label) { tl_team_label = l; } ~TeamLabel() { tl_team_label = prev; } };
 template <class F> inline void team_for(int64_t n, int nt, F&& f) {
     if (nt > n) nt = n > 0 ? (int)n : 1;
     if (nt <= 1) { f((int64_t)0, n, 0); return; }

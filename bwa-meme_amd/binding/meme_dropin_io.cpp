@@ -235,6 +235,7 @@ ktp_data_t* kt_pipeline(void* shared, int step, void* data, mem_opt_t* opt, work
     // a read whose record the device formatted (meme_dropin_sam.cpp) has its text in the chunk's arena, in read order: neighbours are adjacent
     // there and leave as one piece; everybody else's s->sam is the text
     SamText* dev_text = sam_format_for_output(seqs);
+    TeamLabel lbl_("output step: lengths + frees");
     team_for(n, nt, [&](int64_t i0, int64_t i1, int) {
         size_t d = 0;
         for (int64_t i = i0; i < i1; ++i) {

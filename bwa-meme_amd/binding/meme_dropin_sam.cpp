@@ -98,6 +98,46 @@ MateStage g_mate_stage;
 std::atomic<int64_t> g_mate_posed_dev{0};
 double g_mate_pose_ms = 0;
 
+// ---- the chunk's alignment records, once (round 6) ----------------------------------------------------------------------------------
+// Between worker_aln and worker_sam three loops of the binding read the alignment records of every read of the chunk -- the insert-size
+// pre-filter (mem_pestat's four tests), the CIGAR stage's candidates (+ its posing and entry loops), the mate-rescue stage's gather --
+// and each record is its own heap block: 0.8-1.7 CPU-seconds per 8 M reads EACH, nearly all of it cache misses (profiles/r06_host_cpu.md).
+// The first of them to run walks the heap once and leaves the fields all three need back to back (48 bytes per record, read order); the
+// others read that.  Nothing writes a record between worker_aln's end and worker_sam's start (src/bwamem.cpp:2003-2036), which is the
+// span the digest is used in; it is tagged with the chunk's number and the array it was taken from.
+struct RecDigest { int64_t rb, re; int32_t qb, qe, rid, score, truesc, w, secondary, sec_score; };
+struct ChunkDigest {
+    uint64_t gen = 0; const mem_alnreg_v* regs = nullptr; int64_t n = 0;
+    std::vector<int64_t> off;                           // read g's records: [off[g], off[g + 1])
+    RecDigest* rec = nullptr; int64_t cap = 0;
+} g_digest;
+const ChunkDigest& chunk_digest(const mem_alnreg_v* regs, int64_t n) {
+    ChunkDigest& D = g_digest;
+    if (D.gen == g_chunk_gen && D.regs == regs && D.n == n) return D;
+    TeamLabel lbl("records: one walk over the heap");
+    const int nt = cig_threads();
+    D.off.resize((size_t)n + 1);
+    int64_t* off = D.off.data();
+    off[0] = 0;
+    team_for(n, nt, [&](int64_t g0, int64_t g1, int) { for (int64_t g = g0; g < g1; ++g) off[g + 1] = (int64_t)regs[g].n; });
+    for (int64_t g = 0; g < n; ++g) off[g + 1] += off[g];
+    if (off[n] + 1 > D.cap) { free(D.rec); D.cap = off[n] + off[n] / 4 + 4096; if (!(D.rec = (RecDigest*)malloc((size_t)D.cap * sizeof(RecDigest)))) { fprintf(stderr, "[meme-dropin] out of memory\n"); exit(1); } }
+    RecDigest* rec = D.rec;
+    team_for(n, nt, [&](int64_t g0, int64_t g1, int) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const mem_alnreg_v& av = regs[g];
+            RecDigest* o = rec + off[g];
+            for (size_t k = 0; k < av.n; ++k) {
+                const mem_alnreg_t& p = av.a[k];
+                o[k].rb = p.rb; o[k].re = p.re; o[k].qb = p.qb; o[k].qe = p.qe; o[k].rid = p.rid; o[k].score = p.score; o[k].truesc = p.truesc; o[k].w = p.w; o[k].secondary = p.secondary;
+            }
+            for (size_t k = 0; k < av.n; ++k) o[k].sec_score = o[k].secondary >= 0 && o[k].secondary < (int)av.n ? o[o[k].secondary].score : 0;
+        }
+    });
+    D.gen = g_chunk_gen; D.regs = regs; D.n = n;
+    return D;
+}
+
 // 1: the table is filled, 0: too few jobs (worker_sam runs as it is), -1: the device stage is not available for this chunk (the host poses)
 int matesw_prepass_device(int h) {
     const double t0 = now_s();
@@ -110,17 +150,15 @@ int matesw_prepass_device(int h) {
     MateStage& G = g_mate_stage;
     if (n + 1 > G.off_cap) { meme_host_free(G.off); G.off_cap = n + n / 4 + 64; if (!(G.off = (int64_t*)meme_host_alloc(G.off_cap * 8))) die("meme_host_alloc"); }
     const int nt = cig_threads();
-    team_for(n, nt, [&](int64_t g0, int64_t g1, int) { for (int64_t g = g0; g < g1; ++g) G.off[g + 1] = (int64_t)w->regs[lo + g].n; });
-    G.off[0] = 0;
-    for (int64_t g = 0; g < n; ++g) G.off[g + 1] += G.off[g];
+    const ChunkDigest& D = chunk_digest(w->regs, g_chunk.n);
+TeamLabel tl_9237("mate: gather records");
+    const int64_t d0 = D.off[(size_t)lo];
+    team_for(n + 1, nt, [&](int64_t g0, int64_t g1, int) { for (int64_t g = g0; g < g1; ++g) G.off[g] = D.off[(size_t)(lo + g)] - d0; });
     const int64_t nrec = G.off[n];
     if (nrec + 1 > G.regs_cap) { meme_host_free(G.regs); G.regs_cap = nrec + nrec / 4 + 4096; if (!(G.regs = (meme_mate_reg*)meme_host_alloc(G.regs_cap * (int64_t)sizeof(meme_mate_reg)))) die("meme_host_alloc"); }
-    team_for(n, nt, [&](int64_t g0, int64_t g1, int) {
-        for (int64_t g = g0; g < g1; ++g) {
-            const mem_alnreg_v& av = w->regs[lo + g];
-            meme_mate_reg* o = G.regs + G.off[g];
-            for (size_t k = 0; k < av.n; ++k) { o[k].rb = av.a[k].rb; o[k].rid = av.a[k].rid; o[k].score = av.a[k].score; }
-        }
+    team_for(nrec, nt, [&](int64_t k0, int64_t k1, int) {
+        const RecDigest* src = D.rec + d0;
+        for (int64_t k = k0; k < k1; ++k) { G.regs[k].rb = src[k].rb; G.regs[k].rid = src[k].rid; G.regs[k].score = src[k].score; }
     });
     meme_pestat pes[4];
     for (int r = 0; r < 4; ++r) { pes[r].low = w->pes[r].low; pes[r].high = w->pes[r].high; pes[r].failed = w->pes[r].failed; pes[r].pad = 0; }
@@ -245,6 +283,7 @@ bool matesw_prepass_host(int h) {
     T.lo = lo; T.hi = lo + n;
     T.gar.assign((size_t)nb, std::vector<int32_t>());
     std::atomic<int64_t> next_b{0};
+TeamLabel tl_46641("mate: host posing (mem_sam_pe_batch_pre)");
     team_run(g_mate.slots, [&](int t) {                             // (one buffer slot per share; batches handed out one by one)
     for (int64_t b = next_b.fetch_add(1); b < nb; b = next_b.fetch_add(1)) {
         const int64_t st = lo + b * BATCH_SIZE, ed = lo + ((b + 1) * BATCH_SIZE < n ? (b + 1) * BATCH_SIZE : n);
@@ -394,26 +433,30 @@ void cig_prepass(int h) {
     const mem_opt_t* opt = g_opt;
     const int64_t h_lo = g_half[h].lo, n = g_half[h].hi - h_lo, l_pac = g_bns->l_pac;      // the half's reads: [h_lo, h_lo + n) of the chunk
     // per alignment record: where mem_reg2aln's loop stands (band argument of the next call, score of the last one)
-    struct Cand { int64_t g; int32_t reg, w2, last_sc, tries; };
+    // (the record's own fields ride along: the posing and entry loops below do not go back to the heap)
+    struct Cand { int64_t g, rb; int32_t reg, w2, last_sc, tries, qb, qlen, tlen, truesc; };
     std::vector<Cand> cand;
     {
         const int nt = cig_threads();
         std::vector<std::vector<Cand>> part((size_t)nt);
+        const ChunkDigest& D = chunk_digest(g_worker->regs, g_chunk.n);
+TeamLabel tl_67525("cigar: candidates");
         team_for(n, nt, [&](int64_t g_lo, int64_t g_hi, int t) {
             std::vector<Cand>& mine = part[(size_t)t];
             for (int64_t g = h_lo + g_lo; g < h_lo + g_hi; ++g) {
-                const mem_alnreg_v& av = g_worker->regs[g];
-                for (size_t i = 0; i < av.n; ++i) {
-                    const mem_alnreg_t& p = av.a[i];
+                const RecDigest* av = D.rec + D.off[(size_t)g];
+                const int avn = (int)(D.off[(size_t)g + 1] - D.off[(size_t)g]);
+                for (int i = 0; i < avn; ++i) {
+                    const RecDigest& p = av[i];
                     if (p.rb < 0 || p.re < 0 || p.score < opt->T) continue;
-                    if (p.secondary >= 0 && p.secondary < (int)av.n && p.score < av.a[p.secondary].score * opt->XA_drop_ratio) continue;
+                    if (p.secondary >= 0 && p.secondary < avn && p.score < p.sec_score * opt->XA_drop_ratio) continue;
                     // what bwa_gen_cigar2 rejects, or would unpack from beyond the text, is left to it (src/bwa.cpp:285-287)
                     if (p.qe <= p.qb || p.rb >= p.re || (p.rb < l_pac && p.re > l_pac) || p.re > 2 * l_pac) continue;
                     const int tmp = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_del, opt->e_del);
                     int w2 = infer_bw_(p.qe - p.qb, (int)(p.re - p.rb), p.truesc, opt->a, opt->o_ins, opt->e_ins);
                     w2 = w2 > tmp ? w2 : tmp;
                     if (w2 > opt->w) w2 = w2 < p.w ? w2 : p.w;
-                    mine.push_back({g, (int32_t)i, w2, -(1 << 30), 0});
+                    mine.push_back({g, p.rb, (int32_t)i, w2, -(1 << 30), 0, p.qb, p.qe - p.qb, (int32_t)(p.re - p.rb), p.truesc});
                 }
             }
         });
@@ -436,17 +479,17 @@ void cig_prepass(int h) {
         const int64_t nc = (int64_t)cand.size();
         std::vector<meme_cjob> posed((size_t)nc);
         std::vector<int8_t> dev_of((size_t)nc);
+TeamLabel tl_22918("cigar: pose");
         team_for(nc, cig_threads(), [&](int64_t c_lo, int64_t c_hi, int) {
         for (int64_t c = c_lo; c < c_hi; ++c) {
             Cand& C = cand[(size_t)c];
-            const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
             C.w2 = C.w2 < opt->w << 2 ? C.w2 : opt->w << 2;                         // (:2342)
             dev_of[(size_t)c] = -1;
             int d = 0;
             while (d + 1 < nd && C.g >= g_chunk.part[(size_t)d].first + g_chunk.part[(size_t)d].count) ++d;
             if (!g_chunk.part[(size_t)d].reads_on_ctx) { C.tries = 99; continue; }       // (a part seeded in pieces: its reads are not all on the ctx; the reference's function computes these)
             meme_cjob& J = posed[(size_t)c];
-            J.rb = p.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = p.qb; J.qlen = p.qe - p.qb; J.tlen = (int32_t)(p.re - p.rb); J.w_ = C.w2; J.pad = 0;
+            J.rb = C.rb; J.read = (int32_t)(C.g - g_chunk.part[(size_t)d].first); J.qb = C.qb; J.qlen = C.qlen; J.tlen = C.tlen; J.w_ = C.w2; J.pad = 0;
             dev_of[(size_t)c] = (int8_t)d;
         }
         });
@@ -503,6 +546,7 @@ void cig_prepass(int h) {
                 const size_t r0 = P.res.size();
                 P.res.resize(r0 + (size_t)m);
                 char* const bl = P.blob.data() + b0;
+TeamLabel tl_72393("cigar: take results");
                 team_for(m, cig_threads() / (nd > 1 ? 2 : 1), [&](int64_t k_lo, int64_t k_hi, int) {
                 for (int64_t k = k_lo; k < k_hi; ++k) {
                     meme_cres g = R.res[k];
@@ -531,6 +575,7 @@ void cig_prepass(int h) {
             T.blob.insert(T.blob.end(), R.blob.begin(), R.blob.end());
             T.e.resize(e0 + (size_t)R.done);
             std::vector<uint8_t> again((size_t)R.done);
+TeamLabel tl_12033("cigar: entries");
             team_for(R.done, cig_threads(), [&](int64_t k_lo, int64_t k_hi, int) {
             for (int64_t k = k_lo; k < k_hi; ++k) {
                 const meme_cjob& J = jobs[(size_t)d][(size_t)k];
@@ -541,14 +586,13 @@ void cig_prepass(int h) {
                 E.score = X.score; E.n_cigar = X.n_cigar; E.nm = X.nm; E.md_len = X.md_len; E.blob = (int64_t)b0 + X.cigar_off;
                 // mem_reg2aln's loop (:2340-2347): again with the doubled band while the global score stays below the local one
                 again[(size_t)k] = 0;
-                const mem_alnreg_t& p = g_worker->regs[C.g].a[C.reg];
                 const int score = E.score;
                 if (score == C.last_sc || C.w2 == opt->w << 2) continue;        // (inside the share's loop: the next alignment)
                 C.last_sc = score;
                 const int prev = C.w2;
                 C.w2 <<= 1;
                 // (a doubled 0 is the same call again: its answer is in the table already, and it ends the loop -- score == last_sc)
-                if (++C.tries < 3 && score < p.truesc - opt->a && (C.w2 < opt->w << 2 ? C.w2 : opt->w << 2) != prev) again[(size_t)k] = 1;
+                if (++C.tries < 3 && score < C.truesc - opt->a && (C.w2 < opt->w << 2 ? C.w2 : opt->w << 2) != prev) again[(size_t)k] = 1;
             }
             });
             for (int64_t k = 0; k < R.done; ++k) if (again[(size_t)k]) next.push_back(cand[who[(size_t)d][(size_t)k]]);
@@ -564,6 +608,7 @@ void cig_prepass(int h) {
         T.slot.assign((size_t)cap, 0u);
         T.mask = cap - 1;
         uint32_t* sl = T.slot.data();
+TeamLabel tl_2052("cigar: hash table");
         team_for((int64_t)T.e.size(), cig_threads(), [&](int64_t k_lo, int64_t k_hi, int) {
         for (int64_t k = k_lo; k < k_hi; ++k) {
             const CigEntry& E = T.e[(size_t)k];
@@ -725,6 +770,7 @@ SamText* sam_format_for_output(const bseq1_t* seqs) {
         const int64_t cnt = C.part[(size_t)d].count;
         if (cnt > G.recs_cap) { meme_host_free(G.recs); G.recs_cap = cnt + cnt / 4 + 64; if (!(G.recs = (meme_sam_rec*)meme_host_alloc(G.recs_cap * (int64_t)sizeof(meme_sam_rec)))) die("meme_host_alloc"); }
         if (d == 0 && blob_bytes + 64 > G.blob_cap) { meme_host_free(G.blob); G.blob_cap = blob_bytes + blob_bytes / 4 + 4096; if (!(G.blob = (uint8_t*)meme_host_alloc(G.blob_cap))) die("meme_host_alloc"); }
+TeamLabel tl_59587("sam text: assemble descriptors");
         team_for(cnt, cig_threads(), [&](int64_t i0, int64_t i1, int) { for (int64_t i = i0; i < i1; ++i) G.recs[i].read = -1; });
     }
     uint8_t* const blob = S.stage[0].blob;               // (one blob for all slices: a slice's call ships it whole -- tens of MB)
@@ -926,17 +972,17 @@ void meme_dropin_report_sam() {
 // same multiset of insert sizes.  MEME_DROPIN_PESTAT=0: the reference's walk.
 namespace dropin {
 bool pestat_fast() { static const bool v = !(getenv("MEME_DROPIN_PESTAT") && atoi(getenv("MEME_DROPIN_PESTAT")) == 0); return v; }
-inline int pestat_cal_sub(const mem_opt_t* opt, const mem_alnreg_v* r) {          // cal_sub, :67-79
+inline int pestat_cal_sub(const mem_opt_t* opt, const RecDigest* a, int n) {          // cal_sub, :67-79
     int j;
-    for (j = 1; j < (int)r->n; ++j) {
-        const int b_max = r->a[j].qb > r->a[0].qb ? r->a[j].qb : r->a[0].qb;
-        const int e_min = r->a[j].qe < r->a[0].qe ? r->a[j].qe : r->a[0].qe;
+    for (j = 1; j < n; ++j) {
+        const int b_max = a[j].qb > a[0].qb ? a[j].qb : a[0].qb;
+        const int e_min = a[j].qe < a[0].qe ? a[j].qe : a[0].qe;
         if (e_min > b_max) {
-            const int min_l = r->a[j].qe - r->a[j].qb < r->a[0].qe - r->a[0].qb ? r->a[j].qe - r->a[j].qb : r->a[0].qe - r->a[0].qb;
+            const int min_l = a[j].qe - a[j].qb < a[0].qe - a[0].qb ? a[j].qe - a[j].qb : a[0].qe - a[0].qb;
             if (e_min - b_max >= min_l * opt->mask_level) break;
         }
     }
-    return j < (int)r->n ? r->a[j].score : opt->min_seed_len * opt->a;
+    return j < n ? a[j].score : opt->min_seed_len * opt->a;
 }
 typedef void (*pestat_fn)(const mem_opt_t*, int64_t, int, const mem_alnreg_v*, mem_pestat_t*);
 }  // namespace dropin
@@ -947,17 +993,21 @@ void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* 
     struct Key { uint64_t k; int32_t i; };                       // (orientation << 60 | insert size, pair): the order of the stand-ins
     const int nt = cig_threads();
     std::vector<std::vector<Key>> part((size_t)nt);
+    const ChunkDigest& D = chunk_digest(regs, n);
+TeamLabel tl_54637("pestat: pre-filter + stand-ins");
     team_for(np, nt, [&](int64_t i_lo, int64_t i_hi, int t) {
         std::vector<Key>& mine = part[(size_t)t];
         for (int i = (int)i_lo; i < (int)i_hi; ++i) {
-            const mem_alnreg_v* r0 = &regs[i << 1 | 0];
-            const mem_alnreg_v* r1 = &regs[i << 1 | 1];
-            if (r0->n == 0 || r1->n == 0) continue;                                       // :96
-            if (pestat_cal_sub(opt, r0) > 0.8 * r0->a[0].score) continue;                 // :97 (MIN_RATIO, :49)
-            if (pestat_cal_sub(opt, r1) > 0.8 * r1->a[0].score) continue;                 // :98
-            if (r0->a[0].rid != r1->a[0].rid) continue;                                   // :99
+            const int64_t o0 = D.off[(size_t)i << 1], o1 = D.off[((size_t)i << 1) + 1], o2 = D.off[((size_t)i << 1) + 2];
+            const RecDigest* r0 = D.rec + o0;
+            const RecDigest* r1 = D.rec + o1;
+            const int n0 = (int)(o1 - o0), n1 = (int)(o2 - o1);
+            if (n0 == 0 || n1 == 0) continue;                                             // :96
+            if (pestat_cal_sub(opt, r0, n0) > 0.8 * r0[0].score) continue;                // :97 (MIN_RATIO, :49)
+            if (pestat_cal_sub(opt, r1, n1) > 0.8 * r1[0].score) continue;                // :98
+            if (r0[0].rid != r1[0].rid) continue;                                         // :99
             // (only the order below depends on these two: mem_infer_dir, :58-65)
-            const int64_t b1 = r0->a[0].rb, b2 = r1->a[0].rb;
+            const int64_t b1 = r0[0].rb, b2 = r1[0].rb;
             const int s1 = b1 >= l_pac, s2 = b2 >= l_pac;
             const int64_t p2 = s1 == s2 ? b2 : (l_pac << 1) - 1 - b2;
             const uint64_t dist = (uint64_t)(p2 > b1 ? p2 - b1 : b1 - p2);
@@ -976,7 +1026,7 @@ void mem_pestat(const mem_opt_t* opt, int64_t l_pac, int n, const mem_alnreg_v* 
     team_for(m, nt, [&](int64_t k_lo, int64_t k_hi, int) {
     for (int64_t k = k_lo; k < k_hi; ++k)
         for (int e = 0; e < 2; ++e) {
-            const mem_alnreg_t& src = regs[keys[(size_t)k].i << 1 | e].a[0];
+            const RecDigest& src = D.rec[D.off[(size_t)(keys[(size_t)k].i << 1 | e)]];
             mem_alnreg_t& d = a[2 * k + e];
             d.rb = src.rb; d.rid = src.rid; d.score = 1 << 28;
             v[2 * k + e].n = v[2 * k + e].m = 1; v[2 * k + e].a = &d;

@@ -118,6 +118,42 @@ def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
                     reason="compiled reference (oracle/_ref) not available on this box")
+@pytest.mark.parametrize("ext_on_device", ["1", "0"])
+def test_sam_identical_with_lower_case_and_ambiguity_letters(tmp_path, ext_on_device):
+    """FASTQ letters other than ACGTN: lower case, IUPAC ambiguity codes, '.', in whole reads, in runs and one at a time (every one but
+    acgtACGT is base 4 to nst_nt4_table, reference src/bntseq.cpp:41-58, applied to the reads in mem_process_seqs' callees, src/bwamem.cpp:1277-1279).
+    The binding converts 64 letters at a time where they are all A C G T N and by the table otherwise; the device converts the raw letters itself."""
+    g = synth.make_genome(300_000, seed=51, repeat_frac=0.05, n_families=4, n_dups=4, dup_len=900)
+    fa = str(tmp_path / "lc.fa")
+    synth.write_fasta(fa, g, contigs=2)
+    prefix = build_index(fa, bits=14)
+    n = 3000
+    r1, _, _ = synth.make_reads(g, n, 151, seed=52, n_frac=0.02, exact_frac=0.3)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, r1, prefix="l")
+    rng = np.random.default_rng(53)
+    lines = open(fq, "rb").read().split(b"\n")
+    for i in range(n):
+        s = bytearray(lines[4 * i + 1])
+        u = i % 6
+        if u == 0: s = bytearray(bytes(s).lower())                                     # a whole read in lower case
+        elif u == 1:                                                                    # a lower-case (soft-masked) run
+            p = int(rng.integers(0, 120)); s[p:p + 30] = bytes(s[p:p + 30]).lower()
+        elif u == 2:                                                                    # single ambiguity letters, either case
+            for p in rng.integers(0, len(s), size=3): s[int(p)] = b"RYKMSWBDHVnryk.-*"[int(rng.integers(0, 17))]
+        elif u == 3:                                                                    # one odd letter in the last (scalar) stretch and one in the first block
+            s[len(s) - 1 - int(rng.integers(0, 20))] = ord("x"); s[int(rng.integers(0, 64))] = ord("u")
+        lines[4 * i + 1] = bytes(s)
+    open(fq, "wb").write(b"\n".join(lines))
+    want = _sam("bwa-meme_mode3", prefix, [fq])
+    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", MEME_DROPIN_EXT=ext_on_device))
+    assert len(got) == len(want) and len(want) > n
+    diff = [(a, b) for a, b in zip(got, want) if a != b]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
 def test_sam_identical_with_long_gaps_and_short_reads(tmp_path):
     """Reads that need the second band width (an 80-95-base deletion or insertion next to the seed: max_off >= 3w/4, so the job
     is run again with w = 200, src/bwamem.cpp:2985-3018), 250-bp reads with 5 % substitutions (BASELINE configs[5]) and reads
