@@ -84,7 +84,7 @@ def fastq_bytes(reads: np.ndarray) -> np.ndarray:
     return row
 
 
-def reference_index_on_disk(fwd, text, sa, l1, l2, l_pac, bits):
+def reference_index_on_disk(fwd, text, sa, l1, l2, l_pac, bits, keep_others=False):
     """The benchmark index in the reference's own file formats (what `bwa-meme index` + the trainer write), kept next to
     the suffix-array cache in /dev/shm: the compiled reference binaries (cpu_baseline and e2e legs) load it from there."""
     root = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
@@ -97,7 +97,7 @@ def reference_index_on_disk(fwd, text, sa, l1, l2, l_pac, bits):
         raise RuntimeError("not enough room in %s for the reference-format index (%.0f GB)" % (root, need / 1e9))
     import glob
     for old in glob.glob(os.path.join(root, "meme_bench_ref_*")):
-        if old != d:
+        if old != d and not keep_others:
             shutil.rmtree(old, ignore_errors=True)
     os.makedirs(d, exist_ok=True)
     t0 = time.time()
@@ -332,7 +332,10 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
         o0, m0 = int(r["cigar_off"]), int(r["md_off"])
         ok = ok and o_sc == int(r["score"]) and o_nm == int(r["nm"]) and np.array_equal(o_cg, cig[o0:o0 + int(r["n_cigar"])]) and o_md == md[m0:m0 + int(r["md_len"])].tobytes()
     nogap = int(np.sum((ql == tl) & (w2 == 0)))
-    out["cigar"] = {"metric": "cigar_alignments_per_sec", "value": J.shape[0] / (ms * 1e-3) if ok and ms > 0 else None, "unit": "alignments/s", "alignments": int(J.shape[0]),
+    cls = list(ctx.timings().gcig_class_jobs)
+    out["cigar"] = {"jobs_by_kernel": {"k_gcig_grp<16> (4 jobs per wavefront)": int(cls[0]), "k_gcig_grp<32> (2 per wavefront)": int(cls[1]), "k_gcig (a wavefront each)": int(cls[2]),
+                                       "k_gcig_nogap (a lane each)": int(cls[3])}}
+    out["cigar"] |= {"metric": "cigar_alignments_per_sec", "value": J.shape[0] / (ms * 1e-3) if ok and ms > 0 else None, "unit": "alignments/s", "alignments": int(J.shape[0]),
                     "what": "bwa_gen_cigar2 whole (meme_gen_cigar_batch_host): CIGAR + NM + MD", "gap_free_shortcut_share": nogap / max(J.shape[0], 1),
                     "kernel_ms": ms, "operations": int(cig.shape[0]), "md_bytes": int(md.shape[0]), "matches_oracle": bool(ok), "checked": int(len(range(0, J.shape[0], step)))}
     return out
@@ -534,7 +537,7 @@ def config4_class_leg(ctx, dev, genome, text, sa, l1, l2, l_pac, steps=3):
     return out
 
 
-def repeat_dense_leg(device_index, steps=3):
+def repeat_dense_leg(device_index, steps=3, want_ref_index=False):
     """Every stage of the path on a REPEAT-DENSE genome: seeding (the overflow tiers, max_occ subsampling of hit lists, src/bwamem.cpp:1154-1160),
     chaining (the wavefront-per-read tiers and the B-tree tier carry load here), extension (jobs per read), each checked against the oracle.
     Own index (built on the device in seconds) on a ctx of its own beside the benchmark's."""
@@ -598,6 +601,12 @@ def repeat_dense_leg(device_index, steps=3):
     if isinstance(e, dict) and e.get("reads"):
         e["extension_jobs_per_read"] = e["extension_jobs"] / e["reads"]
         e["alignment_records_per_read"] = e["alignment_records"] / e["reads"]
+    if want_ref_index:                       # the e2e runs on this genome (main): the reference's own file formats, 2 GB beside the benchmark's
+        try:
+            out["_ref_prefix"] = reference_index_on_disk(g, text, sa, l1, l2, l_pac, bits, keep_others=True)
+            out["_genome"] = g
+        except Exception as e2:
+            log("repeat-dense leg: no reference-format index (%r)" % (e2,))
     out["all_checks_true"] = bool(parity and out["chain"].get("matches_oracle") and e.get("matches_oracle") and e.get("in_rounds", {}).get("equals_the_checked_records_minus_the_purged_ones") and e.get("cigar", {}).get("matches_oracle"))
     c.close()
     del keep
@@ -703,7 +712,7 @@ REF_BEST_THREADS = int(os.environ.get("MEME_BENCH_REF_THREADS", "64"))
 MALLOC_TUNABLES = "glibc.malloc.tcache_count=4000:glibc.malloc.trim_threshold=1073741824:glibc.malloc.top_pad=67108864:glibc.malloc.mmap_threshold=33554432"
 
 
-def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=READ_LEN, sub=0.01, indel=0.0, seed=5):
+def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=READ_LEN, sub=0.01, indel=0.0, seed=5, slices_ok=True):
     """BASELINE.json's end-to-end metric: `mem -7` on paired-end reads through the reference aligner with the HIP
     backend bound in (oracle/_ref/bwa-meme_dropin = reference main + reference objects + bwa-meme_amd/binding) and
     through the unmodified reference (oracle/_ref/bwa-meme_mode3, AVX-512) on the same host cores, same index files,
@@ -736,7 +745,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
             del r1, r2
         log("e2e: %d pairs of %d-bp reads written in %.1f s" % (npairs, read_len, time.time() - t_gen))
         out = {}
-        ckey = "e2e_reference_%d_%d_t%d" % (npairs, read_len, threads)
+        ckey = "e2e_reference_%d_%d_t%d_%s" % (npairs, read_len, threads, os.path.basename(os.path.dirname(prefix)))
         # (an N=1 run times the reference itself -- its line must not lean on another run's baseline -- unless a probe that launches the
         # bound aligner several times on one box asks for the entry explicitly: MEME_BENCH_E2E_REUSE_REF=1; the object then says "cached")
         reuse = devices > 1 or os.environ.get("MEME_BENCH_E2E_REUSE_REF") == "1"
@@ -837,7 +846,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
         # device stages take is decided by how the stages of a 667 k / N-read slice scale.  The bound aligner once more per slice size (-K = slice x read length,
         # one GPU, no reference run): seconds of device stages per slice -> the predicted device-stage wall of this workload at 2, 4, 8 GPUs.
         slices = None
-        if os.environ.get("MEME_BENCH_E2E_SLICES", "1") != "0" and devices == 1 and read_len == READ_LEN:
+        if os.environ.get("MEME_BENCH_E2E_SLICES", "1") != "0" and devices == 1 and read_len == READ_LEN and slices_ok:
             slices = {}
             chunk_reads = 100000000 // read_len // 2 * 2 + 2
             for div in (8, 4, 2):
@@ -1217,6 +1226,7 @@ def main():
             except Exception as e:  # never lose the headline line over an annotation
                 log("pmc annotation skipped: %r" % (e,))
         budget = float(os.environ.get("MEME_BENCH_BUDGET_S", "1500"))
+        rd_prefix = rd_genome = None
         single = True        # (rank 0 is alone from here on at every N: the other ranks have left after the timed region)
         cores = min(256, os.cpu_count() or 1)
         refcache = RefCache(l_pac, bits)
@@ -1260,24 +1270,28 @@ def main():
         if single and os.environ.get("MEME_BENCH_BSW", "1") != "0":
             try:
                 out["bsw"] = bsw_leg(ctx, dev, world)
+                log("bsw leg done")
             except Exception as e:  # a secondary measurement: never lose the headline line over it
                 log("bsw leg failed: %r" % (e,))
                 out["bsw"] = None
         if single and os.environ.get("MEME_BENCH_KSWV", "1") != "0":
             try:
                 out["kswv"] = kswv_leg(ctx)
+                log("kswv leg done")
             except Exception as e:
                 log("kswv leg failed: %r" % (e,))
                 out["kswv"] = None
         if single and os.environ.get("MEME_BENCH_CHAIN", "1") != "0":
             try:
                 out["chain"] = chain_leg(ctx, reads, l_pac)
+                log("chain leg done")
             except Exception as e:
                 log("chain leg failed: %r" % (e,))
                 out["chain"] = None
         if single and os.environ.get("MEME_BENCH_EXT", "1") != "0":
             try:
                 out["ext"] = ext_leg(ctx, reads, fwd, l_pac)
+                log("ext leg done")
             except Exception as e:
                 log("ext leg failed: %r" % (e,))
                 out["ext"] = None
@@ -1288,6 +1302,7 @@ def main():
             else:
                 try:
                     out["config4_class"] = config4_class_leg(ctx, dev, fwd, text, sa, l1, l2, l_pac)
+                    log("config4_class leg done")
                 except Exception as e:
                     log("config4_class leg failed: %r" % (e,))
                     out["config4_class"] = {"failed": repr(e)[:300]}
@@ -1297,7 +1312,8 @@ def main():
                 out["repeat_dense"] = {"skipped": "wall budget (%d s) nearly used up after %.0f s" % (budget, time.time() - T_START)}
             else:
                 try:
-                    out["repeat_dense"] = repeat_dense_leg(local)
+                    out["repeat_dense"] = repeat_dense_leg(local, want_ref_index=bool(ref_prefix) and os.environ.get("MEME_BENCH_E2E", "1") != "0")
+                    rd_prefix, rd_genome = out["repeat_dense"].pop("_ref_prefix", None), out["repeat_dense"].pop("_genome", None)
                 except Exception as e:
                     log("repeat_dense leg failed: %r" % (e,))
                     out["repeat_dense"] = {"failed": repr(e)[:300]}
@@ -1322,14 +1338,26 @@ def main():
                 except Exception as e:
                     log("e2e leg failed: %r" % (e,))
                     out["e2e"] = {"failed": repr(e)[:300]}
+                # the same comparison on the repeat-dense genome (round 6): its own 128-Mbp index, so the reference's start-up is seconds, not minutes
+                rd = out.get("repeat_dense")
+                if isinstance(rd, dict) and rd_prefix and os.environ.get("MEME_BENCH_RD_E2E", "1") != "0":
+                    try:
+                        rd["e2e"] = e2e_leg(rd_prefix, rd_genome, int(os.environ.get("MEME_BENCH_RD_E2E_PAIRS", "1000000")), cores, devices=world, refcache=refcache, seed=79, slices_ok=False)
+                    except Exception as e:
+                        log("repeat_dense e2e failed: %r" % (e,))
+                        rd["e2e"] = {"failed": repr(e)[:300]}
                 c4 = out.get("config4_class")
+                # configs[4]'s read class end to end: on the 128-Mbp index as well unless MEME_BENCH_C4_E2E_INDEX=bench (rounds 4-5: the GRCh38-sized one --
+                # 193 s of wall, 170 of them the reference expanding that index a third time, for 18 s of measurement: VERDICT r05 item 9)
+                c4_on_bench = os.environ.get("MEME_BENCH_C4_E2E_INDEX", "rd") == "bench" or not rd_prefix
                 if isinstance(c4, dict) and "seeding" in c4 and os.environ.get("MEME_BENCH_C4_E2E", "1") != "0":
                     if time.time() - T_START > budget - 450:
                         c4["e2e"] = {"skipped": "wall budget (%d s) nearly used up after %.0f s" % (budget, time.time() - T_START)}
                     else:
                         try:
-                            c4["e2e"] = e2e_leg(ref_prefix, fwd, int(os.environ.get("MEME_BENCH_C4_E2E_PAIRS", "500000")), cores, devices=world, refcache=refcache,
-                                                read_len=250, sub=0.05, indel=0.0075, seed=4005)
+                            c4["e2e"] = e2e_leg(ref_prefix if c4_on_bench else rd_prefix, fwd if c4_on_bench else rd_genome, int(os.environ.get("MEME_BENCH_C4_E2E_PAIRS", "500000")), cores,
+                                                devices=world, refcache=refcache, read_len=250, sub=0.05, indel=0.0075, seed=4005)
+                            c4["e2e"]["index"] = "the benchmark's GRCh38-sized index" if c4_on_bench else "the repeat-dense leg's 128-Mbp index (MEME_BENCH_C4_E2E_INDEX=bench: the GRCh38-sized one, as in rounds 4-5)"
                         except Exception as e:
                             log("config4_class e2e failed: %r" % (e,))
                             c4["e2e"] = {"failed": repr(e)[:300]}

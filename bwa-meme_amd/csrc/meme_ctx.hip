@@ -167,6 +167,7 @@ extern "C" int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "ext_split")) ctx->ext_split = value;
     else if (!strcmp(key, "ext_census")) ctx->ext_census = value;
     else if (!strcmp(key, "gcig_zcap")) ctx->gcig_zcap = value;
+    else if (!strcmp(key, "gcig_groups")) ctx->gcig_groups = value;
     else if (!strcmp(key, "ext_live_only")) ctx->ext_live_only = value;
     else if (!strcmp(key, "ext_rounds")) ctx->ext_rounds = value < 0 ? 0 : value;
     else if (!strcmp(key, "seed_early_tier")) ctx->seed_early_tier = value;

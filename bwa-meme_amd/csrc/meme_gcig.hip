@@ -30,6 +30,8 @@ struct GcigArgs {
     int32_t* nm; int32_t* mdlen;
     int zcap;                                // backtrack matrices of at most this many bytes stay in LDS (0: all in global memory)
     const i64* dp_list;                      // jobs that need the kernel below (the rest were answered by k_gcig_nogap), or null: all
+    i64 list_first;                          // k_gcig / k_gcig_grp: this launch's jobs are dp_list[list_first ..) (the list is ordered by class: 16-lane, 32-lane, whole wavefront)
+    int grp_qcap, grp_tcap, grp_z;           // k_gcig_grp: bytes of LDS per group for the query, the target and the backtrack matrix
     const u64* packed; int pW, pMW, pstride; // the batch's packed reads (2 bits per base + N masks, k_pack_reads): what k_gcig_nogap compares
 };
 
@@ -39,7 +41,7 @@ __device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(p
 __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     extern __shared__ int lds[];             // hA[qlen + 2] | hB[qlen + 2] | e[qlen + 2] | query bytes (as ints, 4 per word)
     if ((i64)blockIdx.x >= A.njobs) return;
-    const i64 jb = A.dp_list ? A.dp_list[blockIdx.x] : (i64)blockIdx.x;
+    const i64 jb = A.dp_list ? A.dp_list[A.list_first + blockIdx.x] : (i64)blockIdx.x;
     const int lane = threadIdx.x;
     const meme_gjob J = A.jobs[jb];
     const int qlen = J.qlen, tlen = J.tlen, w = J.w;
@@ -243,6 +245,173 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     if (lane == 0) { out[len] = 0; A.nm[jb] = n_mm + n_gap; A.mdlen[jb] = len; }
 }
 
+// Several jobs per wavefront (round 6).  k_gcig above gives a job all 64 lanes and runs its rows one after the other; the bands bwa_gen_cigar2
+// computes for short reads are 5-15 columns wide, so ~9 of the 64 lanes work and the kernel's time follows its instruction count
+// (profiles/r05_gcig.md).  Here a job whose band has at most G columns (G = 16 or 32: one or two DPP rows) takes a GROUP of G lanes and a wavefront
+// runs 64 / G jobs side by side: the same instruction stream, 4 or 2 jobs per instruction.  A row is ONE chunk (end - beg <= 2w + 1 <= G), so F's
+// max-plus scan needs the row_shr steps only (+ row_bcast15 for G = 32) and no carry.  H and E live in rings of 2G entries (a row reads what the row
+// before wrote inside its band, never beyond: indices modulo the ring), the backtrack matrix (<= G x tlen bytes) always in LDS; the walk back runs
+// per lane, identical within a group.  Same cell, same direction bytes, same walk as above -- so the same CIGAR, NM and MD.
+template <int G>
+__global__ void __launch_bounds__(64) k_gcig_grp(GcigArgs A) {
+    extern __shared__ int lds[];
+    constexpr int NG = 64 / G, R = 2 * G, RM = R - 1;
+    constexpr unsigned long long GMASK = G == 32 ? 0xffffffffull : 0xffffull;
+    const int lane = threadIdx.x, sub = lane / G, gl = lane % G, gbase = sub * G;
+    const i64 slot = (i64)blockIdx.x * NG + sub;
+    const bool live = slot < A.njobs;
+    const i64 jb = live ? A.dp_list[A.list_first + slot] : 0;
+    meme_gjob J;
+    if (live) J = A.jobs[jb];
+    else { J.rb = 0; J.read = 0; J.qb = 0; J.qlen = 0; J.tlen = 0; J.w = 0; J.rev = 0; }
+    const int qlen = J.qlen, tlen = J.tlen, w = J.w;
+    const int stride = 3 * R + ((A.grp_qcap + A.grp_tcap + A.grp_z) >> 2);          // ints per group
+    int* hA = lds + sub * stride;
+    int* hB = hA + R;
+    int* eE = hB + R;
+    uint8_t* qs = reinterpret_cast<uint8_t*>(eE + R);
+    uint8_t* ts = qs + A.grp_qcap;
+    uint8_t* zl = ts + A.grp_tcap;
+    if (live) {
+        const uint8_t* rd = A.reads + A.read_off[J.read] + J.qb;
+        for (int j = gl; j < qlen; j += G) qs[j] = J.rev ? rd[qlen - 1 - j] : rd[j];
+        for (int i = gl; i < tlen; i += G) ts[i] = (uint8_t)text_base(A.pac, J.rev ? J.rb + tlen - 1 - i : J.rb + i);
+    }
+    uint32_t* cg = A.cig + (live ? A.coff[jb] : 0);
+    const int cap = qlen + tlen + 2;
+    int n = 0;
+    const int oe_del = A.o.o_del + A.o.e_del, oe_ins = A.o.o_ins + A.o.e_ins, e_del = A.o.e_del, e_ins = A.o.e_ins;
+    const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
+    // first row (src/ksw.cpp:591-595): the columns row 0 can read
+    for (int j = gl; j <= qlen && j <= w + 1; j += G) {
+        hA[j & RM] = j == 0 ? 0 : (j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF);
+        eE[j & RM] = MINUS_INF;
+    }
+    int tl_max = tlen;
+    for (int d = 32; d >= G; d >>= 1) { const int o = __shfl_xor(tl_max, d); tl_max = tl_max > o ? tl_max : o; }
+    __syncthreads();
+    int* hp = hA;
+    int* hn = hB;
+    for (int i = 0; i < tl_max; ++i) {
+        const bool row = i < tlen;
+        const int tb = row ? ts[i] : 0;
+        const int beg = i > w ? i - w : 0;
+        const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+        const int h_in = beg == 0 ? -(A.o.o_del + e_del * (i + 1)) : MINUS_INF;
+        if (row && gl == 0) hn[beg & RM] = h_in;
+        const int j = beg + gl;
+        const bool in = row && j < end;
+        int m = MINUS_INF, e = MINUS_INF;
+        if (in) {
+            const int qb = qs[j];
+            const int sc = (tb > 3 || qb > 3) ? -1 : (tb == qb ? A.o.a : -A.o.b);
+            m = hp[j & RM] + sc;
+            e = eE[j & RM];
+        }
+        const int g = in ? m - oe_ins + gl * e_ins : -2000000000;
+        int sg = g, y;
+        y = GCIG_DPP(-2000000000, sg, 0x111, 0xF); sg = sg > y ? sg : y;
+        y = GCIG_DPP(-2000000000, sg, 0x112, 0xF); sg = sg > y ? sg : y;
+        y = GCIG_DPP(-2000000000, sg, 0x114, 0xF); sg = sg > y ? sg : y;
+        y = GCIG_DPP(-2000000000, sg, 0x118, 0xF); sg = sg > y ? sg : y;
+        if (G == 32) { y = GCIG_DPP(-2000000000, sg, 0x142, 0xA); sg = sg > y ? sg : y; }
+        const int ex = GCIG_DPP(-2000000000, sg, 0x138, 0xF);            // the lane below (a group's lane 0 does not use it)
+        const int f = gl == 0 ? MINUS_INF : (ex - (gl - 1) * e_ins > MINUS_INF - gl * e_ins ? ex - (gl - 1) * e_ins : MINUS_INF - gl * e_ins);
+        unsigned d = m >= e ? 0u : 1u;
+        int h = m >= e ? m : e;
+        d = h >= f ? d : 2u;
+        h = h >= f ? h : f;
+        int t = m - oe_del;
+        int e2 = e - e_del;
+        d |= e2 > t ? 1u << 2 : 0u;
+        e2 = e2 > t ? e2 : t;
+        t = m - oe_ins;
+        const int f2 = f - e_ins;
+        d |= f2 > t ? 2u << 4 : 0u;
+        if (in) { eE[j & RM] = e2; hn[(j + 1) & RM] = h; zl[i * n_col + gl] = (uint8_t)d; }
+        if (row && gl == 0) eE[end & RM] = MINUS_INF;
+        __syncthreads();
+        if (row) { int* tsw = hp; hp = hn; hn = tsw; }
+    }
+    const int score = live ? hp[qlen & RM] : 0;
+    // backtrack (src/ksw.cpp:650-664): every lane of the group the same walk
+    {
+        int i = tlen - 1, k = (i + w + 1 < qlen ? i + w + 1 : qlen) - 1, which = 0;
+        const int zsize = n_col * tlen;
+        int last_op = -1;
+        unsigned cur = 0;
+        auto push = [&](int op, int len) {
+            if (last_op == op) cur += (unsigned)len << 4;
+            else { if (last_op >= 0) { if (gl == 0) cg[cap - 1 - n] = cur; ++n; } cur = (unsigned)len << 4 | (unsigned)op; last_op = op; }
+        };
+        while (i >= 0 && k >= 0) {
+            int zi = i * n_col + (k - (i > w ? i - w : 0));
+            if (zi < 0) zi = 0;
+            if (zi >= zsize) zi = zsize - 1;
+            which = (int)zl[zi] >> (which << 1) & 3;
+            if (which == 0) { push(0, 1); --i; --k; }
+            else if (which == 1) { push(2, 1); --i; }
+            else { push(1, 1); --k; }
+        }
+        if (i >= 0) push(2, i + 1);
+        if (k >= 0) push(1, k + 1);
+        if (last_op >= 0) { if (gl == 0) cg[cap - 1 - n] = cur; ++n; }
+    }
+    if (live && gl == 0) { meme_gres Rr; Rr.score = score; Rr.n_cigar = n; Rr.cigar_off = cap - n; A.res[jb] = Rr; }
+    if (!A.md) return;
+    // NM and MD (src/bwa.cpp:322-355), as in k_gcig with the group's G lanes
+    __threadfence();
+    __syncthreads();
+    char* out = A.md + (live ? A.mdoff[jb] : 0);
+    const char* const b2c = J.rev ? "TGCAN" : "ACGTN";
+    int len = 0, x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+    auto put_num = [&](int v) {
+        char buf[12];
+        int l = 0;
+        do { buf[l++] = (char)('0' + v % 10); v /= 10; } while (v);
+        if (gl == 0) for (int i = 0; i < l; ++i) out[len + i] = buf[l - 1 - i];
+        len += l;
+    };
+    for (int k = 0; k < n; ++k) {
+        const unsigned c = cg[cap - n + k];
+        const int op = (int)(c & 0xf), l = (int)(c >> 4);
+        if (op == 0) {
+            for (int i0 = 0; i0 < l; i0 += G) {
+                const int i = i0 + gl;
+                const bool in = i < l;
+                int tb = 0, qb = 0;
+                if (in) { tb = (int)ts[y + i]; qb = qs[x + i]; }
+                unsigned long long mask = (__ballot(in && tb != qb) >> gbase) & GMASK;
+                int pos0 = 0;
+                while (mask) {
+                    const int b = __builtin_ctzll(mask);
+                    u += b - pos0;
+                    put_num(u);
+                    const int t = __shfl(tb, gbase + b);
+                    if (gl == 0) out[len] = b2c[t];
+                    ++len; ++n_mm; u = 0; pos0 = b + 1;
+                    mask &= mask - 1;
+                }
+                u += (l - i0 < G ? l - i0 : G) - pos0;
+            }
+            x += l; y += l;
+        } else if (op == 2) {
+            if (k > 0 && k < n - 1) {
+                put_num(u);
+                if (gl == 0) out[len] = '^';
+                ++len;
+                for (int i = gl; i < l; i += G) out[len + i] = b2c[(int)ts[y + i]];
+                len += l; u = 0; n_gap += l;
+            }
+            y += l;
+        } else { x += l; n_gap += l; }
+    }
+    if (live) {
+        put_num(u);
+        if (gl == 0) { out[len] = 0; A.nm[jb] = n_mm + n_gap; A.mdlen[jb] = len; }
+    }
+}
+
 // bwa_gen_cigar2's gap-free shortcut (src/bwa.cpp:295-304) for the jobs of a batch that take it, ONE LANE per job: the query span against
 // the text 32 bases per XOR on the packed reads k_pack_reads left on the ctx (2 bits per base, N as A with a mask beside it) and the 2-bit
 // text -- score, the one M operation, NM and the MD string (visited mismatch by mismatch, in the reversed order on the reverse strand).
@@ -319,19 +488,32 @@ __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__
         for (int k = 0; k < R.n_cigar; ++k) dst[k] = src[k];
     }
 }
-__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, i64* __restrict__ zsz,
-                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp) {
+// per job: the kernel that takes it -- isdp: k_gcig (a wavefront), is16 / is32: k_gcig_grp<16 / 32> (a group of lanes; z16 / z32 = bytes of LDS a group has for
+// the backtrack matrix, 0: the class is not used), none: k_gcig_nogap -- and the sizes of its scratch
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, int z16, int z32, i64* __restrict__ zsz,
+                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp, i64* __restrict__ is16, i64* __restrict__ is32) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         const meme_gjob J = jobs[jb];
-        isdp[jb] = !(fast && nogap_fast(J, read_off));                       // 1: the job goes to k_gcig
+        const bool dp = !(fast && nogap_fast(J, read_off));
         const i64 n_col = J.qlen < 2 * J.w + 1 ? J.qlen : 2 * J.w + 1;
-        zsz[jb] = J.w < 0 || n_col * J.tlen <= zcap ? 0 : (n_col * J.tlen + 15) & ~(i64)15;   // (w < 0: the gap-free shortcut, no matrix; small matrices stay in LDS)
+        const bool g16 = dp && J.w >= 0 && n_col <= 16 && n_col * J.tlen <= z16;
+        const bool g32 = dp && !g16 && J.w >= 0 && n_col <= 32 && n_col * J.tlen <= z32;
+        is16[jb] = g16; is32[jb] = g32;
+        isdp[jb] = dp && !g16 && !g32;                                       // 1: the job goes to k_gcig
+        zsz[jb] = J.w < 0 || g16 || g32 || n_col * J.tlen <= zcap ? 0 : (n_col * J.tlen + 15) & ~(i64)15;   // (w < 0: the gap-free shortcut, no matrix; small matrices stay in LDS)
         csz[jb] = J.qlen + J.tlen + 2;
         if (msz) msz[jb] = 2 * ((i64)J.qlen + J.tlen) + 16;                // an MD string never has more than two characters per base
     }
 }
-__global__ void __launch_bounds__(256) k_gcig_dplist(const i64* __restrict__ isdp, const i64* __restrict__ dpoff, i64 njobs, i64* __restrict__ list) {
-    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) if (isdp[jb]) list[dpoff[jb]] = jb;
+// the list the three kernels draw from: the 16-lane jobs, then the 32-lane jobs, then the whole-wavefront jobs, each in job order
+__global__ void __launch_bounds__(256) k_gcig_dplist(const i64* __restrict__ isdp, const i64* __restrict__ dpoff, const i64* __restrict__ is16, const i64* __restrict__ o16,
+                                                      const i64* __restrict__ is32, const i64* __restrict__ o32, i64 njobs, i64* __restrict__ list) {
+    const i64 n16 = o16[njobs], n32 = o32[njobs];
+    for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
+        if (is16[jb]) list[o16[jb]] = jb;
+        else if (is32[jb]) list[n16 + o32[jb]] = jb;
+        else if (isdp[jb]) list[n16 + n32 + dpoff[jb]] = jb;
+    }
 }
 __global__ void __launch_bounds__(256) k_gcig_ncig(const meme_gres* __restrict__ res, i64 njobs, i64* __restrict__ ncig) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) ncig[jb] = res[jb].n_cigar;
@@ -405,7 +587,7 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     const int zwant = ctx->gcig_zcap >= 0 ? (int)ctx->gcig_zcap : zauto;
     const int zcap = lds_base + (size_t)zwant <= 32 * 1024 ? zwant : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
-    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 13 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 17 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     i64* d_zsz = (i64*)G[1].p;
     i64* d_csz = d_zsz + (njobs + 1);
     i64* d_zoff = d_csz + (njobs + 1);
@@ -419,19 +601,36 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     i64* d_isdp = d_poff + (njobs + 1);
     i64* d_dpoff = d_isdp + (njobs + 1);
     i64* d_dplist = d_dpoff + (njobs + 1);
-    i64* d_bad = d_dplist + (njobs + 1);
+    i64* d_is16 = d_dplist + (njobs + 1);
+    i64* d_o16 = d_is16 + (njobs + 1);
+    i64* d_is32 = d_o16 + (njobs + 1);
+    i64* d_o32 = d_is32 + (njobs + 1);
+    i64* d_bad = d_o32 + (njobs + 1);
+    // Several jobs per wavefront for narrow bands (k_gcig_grp; tuning "gcig_groups" = 0: every job a wavefront): per group rings for H and E, the query, the
+    // target and a matrix of 16 (32) columns x the longest target, as long as a wavefront's groups stay within 24 KB (six wavefronts per CU and more)
+    const int grp_qcap = (qmax + 3) & ~3, grp_tcap = (tmax + 3) & ~3;
+    auto grp_lds = [&](int g, int z) { return (size_t)(64 / g) * ((size_t)3 * 2 * g * 4 + grp_qcap + grp_tcap + z); };
+    int z16 = ctx->gcig_groups ? ((16 * tmax + 3) & ~3) : 0, z32 = ctx->gcig_groups ? ((32 * tmax + 3) & ~3) : 0;
+    if (z16 > 4096) z16 = 4096;
+    if (z32 > 8192) z32 = 8192;
+    if (grp_lds(16, z16) > 24 * 1024) z16 = 0;
+    if (grp_lds(32, z32) > 24 * 1024) z32 = 0;
     // the gap-free shortcut on the packed reads the seeding call left on the ctx (reads of at most 500 bases)
     const bool fast = ctx->packed.p != nullptr && ctx->last_seed_max_len > 0;
     const int pW = (int)((ctx->last_seed_max_len + 31) / 32) + 2, pMW = (int)((ctx->last_seed_max_len + 63) / 64);      // PackGeom of that batch (meme_seed.hip)
     HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
-    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, d_zsz, d_csz,
-                       with_md ? d_msz : (i64*)nullptr, d_isdp);
-    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs)) || (rc = meme_scan_exclusive(ctx, d_isdp, d_dpoff, njobs))) return rc;
-    hipLaunchKernelGGL(k_gcig_dplist, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const i64*)d_isdp, (const i64*)d_dpoff, (i64)njobs, d_dplist);
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, z16, z32, d_zsz, d_csz,
+                       with_md ? d_msz : (i64*)nullptr, d_isdp, d_is16, d_is32);
+    if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs)) || (rc = meme_scan_exclusive(ctx, d_isdp, d_dpoff, njobs)) ||
+        (rc = meme_scan_exclusive(ctx, d_is16, d_o16, njobs)) || (rc = meme_scan_exclusive(ctx, d_is32, d_o32, njobs))) return rc;
+    hipLaunchKernelGGL(k_gcig_dplist, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const i64*)d_isdp, (const i64*)d_dpoff, (const i64*)d_is16, (const i64*)d_o16,
+                       (const i64*)d_is32, (const i64*)d_o32, (i64)njobs, d_dplist);
     if (with_md && (rc = meme_scan_exclusive(ctx, d_msz, d_moff, njobs))) return rc;
-    i64 tz = 0, tc = 0, tm = 0, ndp = 0;
+    i64 tz = 0, tc = 0, tm = 0, ndp = 0, n16 = 0, n32 = 0;
     HIP_TRY(hipMemcpyAsync(&ndp, d_dpoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&n16, d_o16 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&n32, d_o32 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&tz, d_zoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&tc, d_coff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (with_md) HIP_TRY(hipMemcpyAsync(&tm, d_moff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -459,10 +658,22 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     A.mdoff = d_moff; A.md = with_md ? (char*)G[6].p : nullptr;
     A.nm = with_md ? (int32_t*)G[7].p : nullptr; A.mdlen = with_md ? (int32_t*)G[7].p + njobs : nullptr;
     A.zcap = zcap; A.dp_list = nullptr; A.packed = (const u64*)ctx->packed.p; A.pW = pW; A.pMW = pMW; A.pstride = 2 * pW + 2 * pMW + 1;
-    if (ndp < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
+    A.list_first = 0; A.grp_qcap = grp_qcap; A.grp_tcap = grp_tcap; A.grp_z = 0;
+    if (ndp + n16 + n32 < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
+    if (n16 > 0) {
+        GcigArgs D = A;
+        D.dp_list = d_dplist; D.njobs = n16; D.list_first = 0; D.grp_z = z16;
+        hipLaunchKernelGGL(k_gcig_grp<16>, dim3((unsigned)((n16 + 3) / 4)), dim3(64), grp_lds(16, z16), ctx->stream, D);
+    }
+    if (n32 > 0) {
+        GcigArgs D = A;
+        D.dp_list = d_dplist; D.njobs = n32; D.list_first = n16; D.grp_z = z32;
+        hipLaunchKernelGGL(k_gcig_grp<32>, dim3((unsigned)((n32 + 1) / 2)), dim3(64), grp_lds(32, z32), ctx->stream, D);
+    }
+    ctx->tm.gcig_class_jobs[0] = n16; ctx->tm.gcig_class_jobs[1] = n32; ctx->tm.gcig_class_jobs[2] = ndp; ctx->tm.gcig_class_jobs[3] = njobs - ndp - n16 - n32;
     if (ndp > 0) {
         GcigArgs D = A;
-        D.dp_list = d_dplist; D.njobs = ndp;
+        D.dp_list = d_dplist; D.njobs = ndp; D.list_first = n16 + n32;
         const size_t lds = lds_base + (size_t)zcap;
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_gcig, dim3((unsigned)ndp), dim3(64), lds, ctx->stream, D);

@@ -12,6 +12,13 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["groups", "wavefront-per-job"])
+def _gcig_groups(request, monkeypatch):
+    """Round 6: jobs with bands of at most 16 / 32 columns run 4 / 2 to a wavefront (k_gcig_grp); every test of this file runs with that (the default) and with
+    one wavefront per job (k_gcig alone) -- the same scores, operations, NM and MD either way."""
+    monkeypatch.setenv("MEME_TUNING", "gcig_groups=%d" % request.param)
+
+
 def _ctx_with_reads(tmp_path, g, reads):
     fa = str(tmp_path / "g.fa")
     synth.write_fasta(fa, g, contigs=2)
