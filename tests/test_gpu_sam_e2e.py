@@ -25,9 +25,9 @@ os.environ.setdefault("MEME_DROPIN_SAM_CHECK", "1")
 os.environ.setdefault("MEME_DROPIN_MATE_CHECK", "1")
 
 
-def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000, opts=(), stderr=None):
+def _sam(exe, prefix, fqs, env=None, threads=4, chunk=100000000, opts=(), stderr=None, timeout=900):
     cmd = [os.path.join(REF, exe), "mem", "-7", "-Y", "-K", str(chunk), "-t", str(threads)] + list(opts) + [prefix] + fqs
-    r = subprocess.run(cmd, capture_output=True, env=env, timeout=900)
+    r = subprocess.run(cmd, capture_output=True, env=env, timeout=timeout)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     if stderr is not None:
         stderr.append(r.stderr.decode())
@@ -119,10 +119,13 @@ def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
                     reason="compiled reference (oracle/_ref) not available on this box")
 @pytest.mark.parametrize("ext_on_device", ["1", "0"])
-def test_sam_identical_with_lower_case_and_ambiguity_letters(tmp_path, ext_on_device):
-    """FASTQ letters other than ACGTN: lower case, IUPAC ambiguity codes, '.', in whole reads, in runs and one at a time (every one but
-    acgtACGT is base 4 to nst_nt4_table, reference src/bntseq.cpp:41-58, applied to the reads in mem_process_seqs' callees, src/bwamem.cpp:1277-1279).
-    The binding converts 64 letters at a time where they are all A C G T N and by the table otherwise; the device converts the raw letters itself."""
+def test_sam_identical_with_lower_case_letters(tmp_path, ext_on_device):
+    """FASTQ letters in lower case (soft-masked input): whole reads, runs, single letters, `n` among them -- nst_nt4_table maps both cases (reference
+    src/bntseq.cpp:63-80, applied in src/bwamem.cpp:1277-1279).  The binding converts 64 letters at a time where they are all A C G T N of either case and by the
+    table otherwise; the device converts the raw letters itself.
+    NOT in this test: IUPAC ambiguity letters (R, Y, ...).  The reference decides whether a read has an N by looking for the characters 'N' and 'n'
+    (src/bwamem.cpp:1255-1258) while every other letter becomes base 4 as well: its N-free search path then never ends (observed with `mem -7` on one read
+    with an R: two worker threads spin in worker_bwt for good).  There is no reference output to be identical to; DESIGN 7."""
     g = synth.make_genome(300_000, seed=51, repeat_frac=0.05, n_families=4, n_dups=4, dup_len=900)
     fa = str(tmp_path / "lc.fa")
     synth.write_fasta(fa, g, contigs=2)
@@ -139,14 +142,17 @@ def test_sam_identical_with_lower_case_and_ambiguity_letters(tmp_path, ext_on_de
         if u == 0: s = bytearray(bytes(s).lower())                                     # a whole read in lower case
         elif u == 1:                                                                    # a lower-case (soft-masked) run
             p = int(rng.integers(0, 120)); s[p:p + 30] = bytes(s[p:p + 30]).lower()
-        elif u == 2:                                                                    # single ambiguity letters, either case
-            for p in rng.integers(0, len(s), size=3): s[int(p)] = b"RYKMSWBDHVnryk.-*"[int(rng.integers(0, 17))]
-        elif u == 3:                                                                    # one odd letter in the last (scalar) stretch and one in the first block
-            s[len(s) - 1 - int(rng.integers(0, 20))] = ord("x"); s[int(rng.integers(0, 64))] = ord("u")
+        elif u == 2:                                                                    # single lower-case letters, an n among them
+            for p in rng.integers(0, len(s), size=3): s[int(p)] = bytes(s[int(p):int(p) + 1]).lower()[0]
+            s[int(rng.integers(0, len(s)))] = ord("n")
+        elif u == 3:                                                                    # one in the last (scalar) stretch and one in the first 64-letter block
+            p = len(s) - 1 - int(rng.integers(0, 20)); s[p] = bytes(s[p:p + 1]).lower()[0]
+            s[int(rng.integers(0, 64))] = ord("n")
         lines[4 * i + 1] = bytes(s)
     open(fq, "wb").write(b"\n".join(lines))
-    want = _sam("bwa-meme_mode3", prefix, [fq])
-    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", MEME_DROPIN_EXT=ext_on_device))
+    assert not any(c in b"RYKMSWBDHVryk.-*xu" for l in lines[1::4] for c in l)          # (see above: the reference does not return from such a read)
+    want = _sam("bwa-meme_mode3", prefix, [fq], timeout=240)
+    got = _sam("bwa-meme_dropin", prefix, [fq], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1", MEME_DROPIN_EXT=ext_on_device), timeout=240)
     assert len(got) == len(want) and len(want) > n
     diff = [(a, b) for a, b in zip(got, want) if a != b]
     assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
