@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
 
 // Several jobs per wavefront (round 6).  k_gcig above gives a job all 64 lanes and runs its rows one after the other; the bands bwa_gen_cigar2
 // computes for short reads are 5-15 columns wide, so ~9 of the 64 lanes work and the kernel's time follows its instruction count
-// (profiles/r05_gcig.md).  Here a job whose band has at most G columns (G = 16 or 32: one or two DPP rows) takes a GROUP of G lanes and a wavefront
+// (profiles/r05_gcig.md).  Here a job whose band has at most G columns (G = 16, 32 or 64: one, two or four DPP rows; G = 64 is one job per wavefront again, without the chunk loop and with the rings) takes a GROUP of G lanes and a wavefront
 // runs 64 / G jobs side by side: the same instruction stream, 4 or 2 jobs per instruction.  A row is ONE chunk (end - beg <= 2w + 1 <= G), so F's
 // max-plus scan needs the row_shr steps only (+ row_bcast15 for G = 32) and no carry.  H and E live in rings of 2G entries (a row reads what the row
 // before wrote inside its band, never beyond: indices modulo the ring), the backtrack matrix (<= G x tlen bytes) always in LDS; the walk back runs
@@ -256,7 +256,7 @@ template <int G>
 __global__ void __launch_bounds__(64) k_gcig_grp(GcigArgs A) {
     extern __shared__ int lds[];
     constexpr int NG = 64 / G, R = 2 * G, RM = R - 1;
-    constexpr unsigned long long GMASK = G == 32 ? 0xffffffffull : 0xffffull;
+    constexpr unsigned long long GMASK = G == 64 ? ~0ull : G == 32 ? 0xffffffffull : 0xffffull;
     const int lane = threadIdx.x, sub = lane / G, gl = lane % G, gbase = sub * G;
     const i64 slot = (i64)blockIdx.x * NG + sub;
     const bool live = slot < A.njobs;
@@ -314,7 +314,8 @@ __global__ void __launch_bounds__(64) k_gcig_grp(GcigArgs A) {
         y = GCIG_DPP(-2000000000, sg, 0x112, 0xF); sg = sg > y ? sg : y;
         y = GCIG_DPP(-2000000000, sg, 0x114, 0xF); sg = sg > y ? sg : y;
         y = GCIG_DPP(-2000000000, sg, 0x118, 0xF); sg = sg > y ? sg : y;
-        if (G == 32) { y = GCIG_DPP(-2000000000, sg, 0x142, 0xA); sg = sg > y ? sg : y; }
+        if (G >= 32) { y = GCIG_DPP(-2000000000, sg, 0x142, 0xA); sg = sg > y ? sg : y; }
+        if (G == 64) { y = GCIG_DPP(-2000000000, sg, 0x143, 0xC); sg = sg > y ? sg : y; }
         const int ex = GCIG_DPP(-2000000000, sg, 0x138, 0xF);            // the lane below (a group's lane 0 does not use it)
         const int f = gl == 0 ? MINUS_INF : (ex - (gl - 1) * e_ins > MINUS_INF - gl * e_ins ? ex - (gl - 1) * e_ins : MINUS_INF - gl * e_ins);
         unsigned d = m >= e ? 0u : 1u;
@@ -490,29 +491,32 @@ __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__
 }
 // per job: the kernel that takes it -- isdp: k_gcig (a wavefront), is16 / is32: k_gcig_grp<16 / 32> (a group of lanes; z16 / z32 = bytes of LDS a group has for
 // the backtrack matrix, 0: the class is not used), none: k_gcig_nogap -- and the sizes of its scratch
-__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, int z16, int z32, i64* __restrict__ zsz,
-                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp, i64* __restrict__ is16, i64* __restrict__ is32) {
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, int z16, int z32, int z64, i64* __restrict__ zsz,
+                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp, i64* __restrict__ is16, i64* __restrict__ is32, i64* __restrict__ is64) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         const meme_gjob J = jobs[jb];
         const bool dp = !(fast && nogap_fast(J, read_off));
         const i64 n_col = J.qlen < 2 * J.w + 1 ? J.qlen : 2 * J.w + 1;
         const bool g16 = dp && J.w >= 0 && n_col <= 16 && n_col * J.tlen <= z16;
         const bool g32 = dp && !g16 && J.w >= 0 && n_col <= 32 && n_col * J.tlen <= z32;
-        is16[jb] = g16; is32[jb] = g32;
-        isdp[jb] = dp && !g16 && !g32;                                       // 1: the job goes to k_gcig
-        zsz[jb] = J.w < 0 || g16 || g32 || n_col * J.tlen <= zcap ? 0 : (n_col * J.tlen + 15) & ~(i64)15;   // (w < 0: the gap-free shortcut, no matrix; small matrices stay in LDS)
+        const bool g64 = dp && !g16 && !g32 && J.w >= 0 && n_col <= 64 && n_col * J.tlen <= z64;
+        is16[jb] = g16; is32[jb] = g32; is64[jb] = g64;
+        isdp[jb] = dp && !g16 && !g32 && !g64;                               // 1: the job goes to k_gcig
+        zsz[jb] = J.w < 0 || g16 || g32 || g64 || n_col * J.tlen <= zcap ? 0 : (n_col * J.tlen + 15) & ~(i64)15;   // (w < 0: the gap-free shortcut, no matrix; small matrices stay in LDS)
         csz[jb] = J.qlen + J.tlen + 2;
         if (msz) msz[jb] = 2 * ((i64)J.qlen + J.tlen) + 16;                // an MD string never has more than two characters per base
     }
 }
 // the list the three kernels draw from: the 16-lane jobs, then the 32-lane jobs, then the whole-wavefront jobs, each in job order
 __global__ void __launch_bounds__(256) k_gcig_dplist(const i64* __restrict__ isdp, const i64* __restrict__ dpoff, const i64* __restrict__ is16, const i64* __restrict__ o16,
-                                                      const i64* __restrict__ is32, const i64* __restrict__ o32, i64 njobs, i64* __restrict__ list) {
-    const i64 n16 = o16[njobs], n32 = o32[njobs];
+                                                      const i64* __restrict__ is32, const i64* __restrict__ o32, const i64* __restrict__ is64, const i64* __restrict__ o64, i64 njobs,
+                                                      i64* __restrict__ list) {
+    const i64 n16 = o16[njobs], n32 = o32[njobs], n64 = o64[njobs];
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         if (is16[jb]) list[o16[jb]] = jb;
         else if (is32[jb]) list[n16 + o32[jb]] = jb;
-        else if (isdp[jb]) list[n16 + n32 + dpoff[jb]] = jb;
+        else if (is64[jb]) list[n16 + n32 + o64[jb]] = jb;
+        else if (isdp[jb]) list[n16 + n32 + n64 + dpoff[jb]] = jb;
     }
 }
 __global__ void __launch_bounds__(256) k_gcig_ncig(const meme_gres* __restrict__ res, i64 njobs, i64* __restrict__ ncig) {
@@ -587,7 +591,7 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     const int zwant = ctx->gcig_zcap >= 0 ? (int)ctx->gcig_zcap : zauto;
     const int zcap = lds_base + (size_t)zwant <= 32 * 1024 ? zwant : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
-    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 17 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 19 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     i64* d_zsz = (i64*)G[1].p;
     i64* d_csz = d_zsz + (njobs + 1);
     i64* d_zoff = d_csz + (njobs + 1);
@@ -605,29 +609,35 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     i64* d_o16 = d_is16 + (njobs + 1);
     i64* d_is32 = d_o16 + (njobs + 1);
     i64* d_o32 = d_is32 + (njobs + 1);
-    i64* d_bad = d_o32 + (njobs + 1);
+    i64* d_is64 = d_o32 + (njobs + 1);
+    i64* d_o64 = d_is64 + (njobs + 1);
+    i64* d_bad = d_o64 + (njobs + 1);
     // Several jobs per wavefront for narrow bands (k_gcig_grp; tuning "gcig_groups" = 0: every job a wavefront): per group rings for H and E, the query, the
     // target and a matrix of 16 (32) columns x the longest target, as long as a wavefront's groups stay within 24 KB (six wavefronts per CU and more)
     const int grp_qcap = (qmax + 3) & ~3, grp_tcap = (tmax + 3) & ~3;
     auto grp_lds = [&](int g, int z) { return (size_t)(64 / g) * ((size_t)3 * 2 * g * 4 + grp_qcap + grp_tcap + z); };
     int z16 = ctx->gcig_groups ? ((16 * tmax + 3) & ~3) : 0, z32 = ctx->gcig_groups ? ((32 * tmax + 3) & ~3) : 0;
+    int z64 = ctx->gcig_groups ? ((64 * tmax + 3) & ~3) : 0;
     if (z16 > 4096) z16 = 4096;
     if (z32 > 8192) z32 = 8192;
+    if (z64 > 12288) z64 = 12288;
     if (grp_lds(16, z16) > 24 * 1024) z16 = 0;
     if (grp_lds(32, z32) > 24 * 1024) z32 = 0;
+    if (grp_lds(64, z64) > 16 * 1024) z64 = 0;
     // the gap-free shortcut on the packed reads the seeding call left on the ctx (reads of at most 500 bases)
     const bool fast = ctx->packed.p != nullptr && ctx->last_seed_max_len > 0;
     const int pW = (int)((ctx->last_seed_max_len + 31) / 32) + 2, pMW = (int)((ctx->last_seed_max_len + 63) / 64);      // PackGeom of that batch (meme_seed.hip)
     HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
-    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, z16, z32, d_zsz, d_csz,
-                       with_md ? d_msz : (i64*)nullptr, d_isdp, d_is16, d_is32);
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, z16, z32, z64, d_zsz, d_csz,
+                       with_md ? d_msz : (i64*)nullptr, d_isdp, d_is16, d_is32, d_is64);
     if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs)) || (rc = meme_scan_exclusive(ctx, d_isdp, d_dpoff, njobs)) ||
-        (rc = meme_scan_exclusive(ctx, d_is16, d_o16, njobs)) || (rc = meme_scan_exclusive(ctx, d_is32, d_o32, njobs))) return rc;
+        (rc = meme_scan_exclusive(ctx, d_is16, d_o16, njobs)) || (rc = meme_scan_exclusive(ctx, d_is32, d_o32, njobs)) || (rc = meme_scan_exclusive(ctx, d_is64, d_o64, njobs))) return rc;
     hipLaunchKernelGGL(k_gcig_dplist, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const i64*)d_isdp, (const i64*)d_dpoff, (const i64*)d_is16, (const i64*)d_o16,
-                       (const i64*)d_is32, (const i64*)d_o32, (i64)njobs, d_dplist);
+                       (const i64*)d_is32, (const i64*)d_o32, (const i64*)d_is64, (const i64*)d_o64, (i64)njobs, d_dplist);
     if (with_md && (rc = meme_scan_exclusive(ctx, d_msz, d_moff, njobs))) return rc;
-    i64 tz = 0, tc = 0, tm = 0, ndp = 0, n16 = 0, n32 = 0;
+    i64 tz = 0, tc = 0, tm = 0, ndp = 0, n16 = 0, n32 = 0, n64 = 0;
+    HIP_TRY(hipMemcpyAsync(&n64, d_o64 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ndp, d_dpoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&n16, d_o16 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&n32, d_o32 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -659,7 +669,7 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     A.nm = with_md ? (int32_t*)G[7].p : nullptr; A.mdlen = with_md ? (int32_t*)G[7].p + njobs : nullptr;
     A.zcap = zcap; A.dp_list = nullptr; A.packed = (const u64*)ctx->packed.p; A.pW = pW; A.pMW = pMW; A.pstride = 2 * pW + 2 * pMW + 1;
     A.list_first = 0; A.grp_qcap = grp_qcap; A.grp_tcap = grp_tcap; A.grp_z = 0;
-    if (ndp + n16 + n32 < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
+    if (ndp + n16 + n32 + n64 < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
     if (n16 > 0) {
         GcigArgs D = A;
         D.dp_list = d_dplist; D.njobs = n16; D.list_first = 0; D.grp_z = z16;
@@ -670,10 +680,15 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
         D.dp_list = d_dplist; D.njobs = n32; D.list_first = n16; D.grp_z = z32;
         hipLaunchKernelGGL(k_gcig_grp<32>, dim3((unsigned)((n32 + 1) / 2)), dim3(64), grp_lds(32, z32), ctx->stream, D);
     }
-    ctx->tm.gcig_class_jobs[0] = n16; ctx->tm.gcig_class_jobs[1] = n32; ctx->tm.gcig_class_jobs[2] = ndp; ctx->tm.gcig_class_jobs[3] = njobs - ndp - n16 - n32;
+    if (n64 > 0) {
+        GcigArgs D = A;
+        D.dp_list = d_dplist; D.njobs = n64; D.list_first = n16 + n32; D.grp_z = z64;
+        hipLaunchKernelGGL(k_gcig_grp<64>, dim3((unsigned)n64), dim3(64), grp_lds(64, z64), ctx->stream, D);
+    }
+    ctx->tm.gcig_class_jobs[0] = n16; ctx->tm.gcig_class_jobs[1] = n32; ctx->tm.gcig_class_jobs[2] = ndp; ctx->tm.gcig_class_jobs[3] = njobs - ndp - n16 - n32 - n64; ctx->tm.gcig_class_jobs[4] = n64;
     if (ndp > 0) {
         GcigArgs D = A;
-        D.dp_list = d_dplist; D.njobs = ndp; D.list_first = n16 + n32;
+        D.dp_list = d_dplist; D.njobs = ndp; D.list_first = n16 + n32 + n64;
         const size_t lds = lds_base + (size_t)zcap;
         if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_gcig, dim3((unsigned)ndp), dim3(64), lds, ctx->stream, D);

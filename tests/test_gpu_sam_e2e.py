@@ -118,7 +118,7 @@ def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
                     reason="compiled reference (oracle/_ref) not available on this box")
-@pytest.mark.parametrize("ext_on_device", ["1", "0"])
+@pytest.mark.parametrize("ext_on_device", ["device", "0"])
 def test_sam_identical_with_lower_case_letters(tmp_path, ext_on_device):
     """FASTQ letters in lower case (soft-masked input): whole reads, runs, single letters, `n` among them -- nst_nt4_table maps both cases (reference
     src/bntseq.cpp:63-80, applied in src/bwamem.cpp:1277-1279).  The binding converts 64 letters at a time where they are all A C G T N of either case and by the
