@@ -772,7 +772,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
                 # both binaries at the thread count that is best for them on this box -- 64 for either: the unmodified reference's
                 # mem_process_seqs takes 11.86 / 11.86 / 11.95 / 13.64 s at 32 / 64 / 128 / 256 threads (2 M pairs, 512 Mbp,
                 # profiles/r04_ref_thread_sweeps.md), the drop-in's SAM phase stops scaling at 32
-                nthr = min(threads, REF_BEST_THREADS) if exe == "bwa-meme_mode3" else min(threads, int(os.environ.get("MEME_BENCH_E2E_DROPIN_THREADS", "64")))
+                nthr = min(threads, REF_BEST_THREADS) if exe == "bwa-meme_mode3" else min(threads, int(env.get("MEME_T", os.environ.get("MEME_BENCH_E2E_DROPIN_THREADS", "64"))))   # (a probe entry may say "@MEME_T=24")
                 r = subprocess.run([os.path.join(ref_dir, exe), "mem", "-7", "-Y", "-K", "100000000", "-t", str(nthr),
                                     prefix] + fqs, stdout=fh, stderr=subprocess.PIPE, env=env, timeout=3000)
             wall = time.time() - t0
