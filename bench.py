@@ -239,7 +239,7 @@ def infer_bw(l1, l2, score, a, q, r):
     return np.where((l1 == l2) & (l1 * a - score < ((q + r - a) << 1)), 0, w)
 
 
-def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
+def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000, check_reads=None):
     """The stages behind seeding, on the device: chaining + seed extension of `nsub` of the reads without leaving
     HBM (meme_extend_last_batch_host: the host receives alignment records), then bwa_gen_cigar2 whole (meme_gen_cigar_batch_host: CIGAR, NM,
     MD) for the best record of `ncig` reads, called with the band argument mem_reg2aln would pass first.  Kernel times by HIP events; EVERY
@@ -262,18 +262,22 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000):
     # MEME_BENCH_EXT_CHECK=0 is for kernel probes only (the oracle's pass over 2 M reads takes minutes of host time): the leg then reports NO throughput value
     # and matches_oracle null -- a number that was not checked is not a measurement -- while the CIGAR sub-leg keeps its own sampled check.
     checked = os.environ.get("MEME_BENCH_EXT_CHECK", "1") != "0"
+    # (check_reads: the oracle's pass over the first so many reads of the leg -- reads are extended independently of each other, the arrays are indexed by read;
+    # the 250-bp class poses 15 jobs per read and its full pass was 90 s of the default run's wall -- the timed calls above are over all n reads either way)
+    m = n if check_reads is None else min(n, int(check_reads))
     if checked:
-        want, (jobs, retried) = oracle_py.extend_batch(reads[:n].reshape(-1), off, ch["chain_off"], oracle_py.chains_as_orc(ch["chains"]), ch["seed_off"],
-                                                      ch["seeds"], ch["frac_rep"], text, l_pac, np.array([c[0] for c in contigs], np.int64),
+        want, (jobs, retried) = oracle_py.extend_batch(reads[:m].reshape(-1), off[:m + 1], ch["chain_off"][:m + 1], oracle_py.chains_as_orc(ch["chains"]), ch["seed_off"][:m + 1],
+                                                      ch["seeds"], ch["frac_rep"][:m], text, l_pac, np.array([c[0] for c in contigs], np.int64),
                                                       np.array([c[1] for c in contigs], np.int32))
-        same = np.array_equal(R["reg_off"], ch["seed_off"]) and all(np.array_equal(R["regs"][f].astype(np.int64), want[f].astype(np.int64)) for f in oracle_py.ALNREG_FIELDS)
+        nrec = int(ch["seed_off"][m])
+        same = np.array_equal(R["reg_off"], ch["seed_off"]) and all(np.array_equal(R["regs"][f][:nrec].astype(np.int64), want[f].astype(np.int64)) for f in oracle_py.ALNREG_FIELDS)
     else:
         want, same = np.zeros(0, dtype=R["regs"].dtype), False
     first = max(R["n_pairs"] - R["n_retried"], 1)
     cls = C3["census_class"]
     out = {"metric": "extend_reads_per_sec", "value": n / ((R["chain_ms"] + R["ext_ms"]) * 1e-3) if same else None, "unit": "reads/s", "reads": n, "read_len": rl,
            "chain_ms": R["chain_ms"], "ext_ms": R["ext_ms"], "bsw_ms": R["bsw_ms"], "alignment_records": int(R["regs"].shape[0]), "extension_jobs": R["n_pairs"],
-           "jobs_with_doubled_band": R["n_retried"], "reads_in_wavefront_tiers": R["n_tier2"], "matches_oracle": bool(same) if checked else None, "checked_records": int(want.shape[0]),
+           "jobs_with_doubled_band": R["n_retried"], "reads_in_wavefront_tiers": R["n_tier2"], "matches_oracle": bool(same) if checked else None, "checked_records": int(want.shape[0]), "checked_reads": int(m) if checked else 0,
            "exact_prefix_jobs": int(C3["n_exact_prefix"]), "exact_prefix_share": C3["n_exact_prefix"] / first,
            # cells of the jobs' band-limited matrices (first attempts; the kernel trims rows and stops at z-drop, so it evaluates fewer)
            "band_cells_per_job": C3["census_band_cells"] / first, "gcups_band_cells": (C3["census_band_cells"] / 1e9) / (R["bsw_ms"] * 1e-3) if R["bsw_ms"] > 0 else None,
@@ -533,7 +537,7 @@ def config4_class_leg(ctx, dev, genome, text, sa, l1, l2, l_pac, steps=3):
                        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0},
                        "matches_oracle": bool(parity), "checked_reads": npar}}
     out["chain"] = chain_leg(ctx, reads, l_pac, nsub=nreads)
-    out["ext"] = ext_leg(ctx, reads, genome, l_pac, nsub=nreads, ncig=min(nreads, 400000))
+    out["ext"] = ext_leg(ctx, reads, genome, l_pac, nsub=nreads, ncig=min(nreads, 400000), check_reads=int(os.environ.get("MEME_BENCH_C4_EXT_CHECK_READS", "1000000")))
     return out
 
 
@@ -614,7 +618,17 @@ def repeat_dense_leg(device_index, steps=3, want_ref_index=False):
     return out
 
 
-def live_pmc_traffic(steps=2):
+def live_pmc_traffic(steps=2, reads=None):
+    box = []
+    try:
+        return _live_pmc_traffic(steps, reads, box)
+    finally:
+        for f in box:
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def _live_pmc_traffic(steps, reads, rfile_box):
     """HBM traffic of the SA-search stage measured in THIS run: bench.py re-executes itself (seeding only, `steps` launches, no warm-up) once under
     `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` -- counters in passes of their own, as the MI355X guide prescribes -- and sums the
     counters over the stage's kernels (k_seed<G> + k_reseed*).  Returns {"fetch_kb", "write_kb"} per launch, or None when the tool is not there or a
@@ -625,10 +639,18 @@ def live_pmc_traffic(steps=2):
     if not exe:
         return None
     out = {}
+    rfile = None
+    if reads is not None and os.path.isdir("/dev/shm"):
+        try:
+            rfile = os.path.join("/dev/shm", "meme_bench_reads_%d.npy" % os.getpid())
+            np.save(rfile, reads)
+            rfile_box.append(rfile)
+        except Exception:
+            rfile = None
     for key, counter in (("fetch_kb", "FETCH_SIZE"), ("write_kb", "WRITE_SIZE")):
         d = tempfile.mkdtemp(prefix="meme_pmc_", dir="/tmp")
         try:
-            env = dict(os.environ, TMPDIR="/tmp", MEME_BENCH_PMC="0", MEME_BENCH_CPU="0", MEME_BENCH_E2E="0", MEME_BENCH_BSW="0", MEME_BENCH_KSWV="0", MEME_BENCH_CHAIN="0",
+            env = dict(os.environ, TMPDIR="/tmp", **({"MEME_BENCH_READS_FILE": rfile} if rfile else {}), MEME_BENCH_PMC="0", MEME_BENCH_CPU="0", MEME_BENCH_E2E="0", MEME_BENCH_BSW="0", MEME_BENCH_KSWV="0", MEME_BENCH_CHAIN="0",
                        MEME_BENCH_EXT="0", MEME_BENCH_C4="0", MEME_BENCH_RD="0", MEME_BENCH_PARITY_READS="0")
             r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "0"],
                                cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -846,22 +868,31 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
         # device stages take is decided by how the stages of a 667 k / N-read slice scale.  The bound aligner once more per slice size (-K = slice x read length,
         # one GPU, no reference run): seconds of device stages per slice -> the predicted device-stage wall of this workload at 2, 4, 8 GPUs.
         slices = None
+        s_pairs = npairs
         if os.environ.get("MEME_BENCH_E2E_SLICES", "1") != "0" and devices == 1 and read_len == READ_LEN and slices_ok:
             slices = {}
             chunk_reads = 100000000 // read_len // 2 * 2 + 2
+            # (on the first 4 M pairs: per-slice figures do not depend on how many chunks follow, and three more runs over all 10 M pairs were 50 s of this leg)
+            s_pairs = min(npairs, int(os.environ.get("MEME_BENCH_E2E_SLICE_PAIRS", "4000000")))
+            s_fqs = fqs
+            if s_pairs < npairs:
+                s_fqs = [os.path.join(d, "s1.fq"), os.path.join(d, "s2.fq")]
+                for src, dst in zip(fqs, s_fqs):
+                    with open(dst, "wb") as fh:
+                        subprocess.run(["head", "-n", str(4 * s_pairs), src], stdout=fh, check=True)
             for div in (8, 4, 2):
                 k_bases = 100000000 // div
                 env = dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_VERBOSE="1", MEME_DROPIN_DEVICES="1")
                 env.setdefault("GLIBC_TUNABLES", MALLOC_TUNABLES)
                 t0 = time.time()
-                r = subprocess.run([os.path.join(ref_dir, dropin_exe.split("@")[0]), "mem", "-7", "-Y", "-K", str(k_bases), "-t", str(min(threads, 64)), prefix] + fqs,
+                r = subprocess.run([os.path.join(ref_dir, dropin_exe.split("@")[0]), "mem", "-7", "-Y", "-K", str(k_bases), "-t", str(min(threads, 64)), prefix] + s_fqs,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=1200)
                 err = r.stderr.decode(errors="replace")
                 mm = re.findall(r"totals: chunk-level device stages \(gather \+ seeding \+ chaining \+ extension\) ([0-9.]+) s for (\d+) reads", err)
                 pr = sum(float(m.group(1)) for m in re.finditer(r"Processed \d+ reads in [0-9.]+ CPU sec, ([0-9.]+) real sec", err))
                 if r.returncode == 0 and mm:
                     dev_s, nr = float(mm[-1][0]), int(mm[-1][1])
-                    slices[str(div)] = {"slice_reads": chunk_reads // div, "device_stages_s_total": dev_s, "device_stages_ms_per_slice": 1e3 * dev_s / max(nr, 1) * (chunk_reads // div),
+                    slices[str(div)] = {"slice_reads": chunk_reads // div, "pairs_of_the_run": s_pairs, "device_stages_s_total": dev_s, "device_stages_ms_per_slice": 1e3 * dev_s / max(nr, 1) * (chunk_reads // div),
                                         "process_s": pr, "wall_s": time.time() - t0}
             log("e2e: device stages per slice of 1/8, 1/4, 1/2 chunk: %s" % {k: round(v["device_stages_ms_per_slice"], 1) for k, v in slices.items()})
         ref, drop = out.get("bwa-meme_mode3"), out[dropin_exe]
@@ -874,7 +905,7 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
                              "device_stage_floor_per_slice": (dict(slices, **{"1": {"slice_reads": 100000000 // read_len // 2 * 2 + 2, "device_stages_s_total": dev_s,
                                                                                   "device_stages_ms_per_slice": 1e3 * dev_s / (2.0 * npairs) * (100000000 // read_len // 2 * 2 + 2)}})
                                                               if slices else None),
-                             "predicted_device_stages_wall_s_by_gpus": ({g: (slices[g]["device_stages_s_total"] / int(g) if g in slices else None) for g in ("2", "4", "8")} | {"1": dev_s}
+                             "predicted_device_stages_wall_s_by_gpus": ({g: (slices[g]["device_stages_s_total"] * (npairs / float(s_pairs)) / int(g) if g in slices else None) for g in ("2", "4", "8")} | {"1": dev_s}
                                                                         if slices else None),
                              "prediction": "N GPUs: every GPU takes 1/N of a chunk; the device-stage wall of this workload is then (seconds per slice of that size) x (number of chunks) = "
                                            "the one-GPU total at -K/N divided by N",
@@ -1096,7 +1127,12 @@ def main():
     genome = fwd if rank == 0 else genome_t.cpu().numpy()
     del genome_t
     t0 = time.time()
-    reads = workload.make_reads_fast(genome, nreads, READ_LEN, seed=1000 + rank)
+    rf = os.environ.get("MEME_BENCH_READS_FILE")          # (the counter passes re-execute this file: they take the parent's batch instead of sampling it again)
+    if rf and os.path.exists(rf) and world == 1:
+        reads = np.load(rf)
+        assert reads.shape == (nreads, READ_LEN)
+    else:
+        reads = workload.make_reads_fast(genome, nreads, READ_LEN, seed=1000 + rank)
     d_reads = torch.from_numpy(reads.reshape(-1)).to(dev)
     d_off = torch.arange(0, (nreads + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
@@ -1170,7 +1206,7 @@ def main():
         import oracle_py as O
         # (round 4: 1 M reads instead of 20 000, in slices the oracle's fixed-capacity output arrays can hold; every SMEM and every hit
         # position compared after the dump format's ordering -- SMEMs by (start asc, end desc), hits in suffix-array order)
-        ns = min(nreads, int(os.environ.get("MEME_BENCH_PARITY_READS", "1000000")))
+        ns = min(nreads, int(os.environ.get("MEME_BENCH_PARITY_READS", "600000")))
         t_par = time.time()
         sample_parity, o_idx = True, O.Index(text, sa)
         SL = 50000
@@ -1369,7 +1405,7 @@ def main():
                     ctx = None
                     keep = d_reads = d_off = None
                     torch.cuda.empty_cache()
-                live = live_pmc_traffic()
+                live = live_pmc_traffic(reads=reads)
                 if live:
                     out["roofline"]["traffic"] = (2 * live["fetch_kb"] + live["write_kb"]) * 1024.0
                     out["roofline"]["traffic_source"] = ("this run: bench.py re-executed under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, 2 launches of the "

@@ -282,11 +282,10 @@ __global__ void __launch_bounds__(64) k_gcig_grp(GcigArgs A) {
     int n = 0;
     const int oe_del = A.o.o_del + A.o.e_del, oe_ins = A.o.o_ins + A.o.e_ins, e_del = A.o.e_del, e_ins = A.o.e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
-    // first row (src/ksw.cpp:591-595): the columns row 0 can read
-    for (int j = gl; j <= qlen && j <= w + 1; j += G) {
-        hA[j & RM] = j == 0 ? 0 : (j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF);
-        eE[j & RM] = MINUS_INF;
-    }
+    // first row (src/ksw.cpp:591-595): the columns row 0 can read.  The cells left of the band and E above a column the band has just reached are not kept in the
+    // rings: H(i-1, -1) is arithmetic (-(o_del + e_del * i), 0 for the first row) and E of a column at or beyond the previous row's end is -inf (:647) -- two
+    // single-lane stores per row less, and every load of a row is unconditional (lanes beyond the band compute on whatever the ring holds and store nothing).
+    for (int j = gl + 1; j <= qlen && j <= w + 1; j += G) hA[j & RM] = j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF;
     int tl_max = tlen;
     for (int d = 32; d >= G; d >>= 1) { const int o = __shfl_xor(tl_max, d); tl_max = tl_max > o ? tl_max : o; }
     __syncthreads();
@@ -294,20 +293,17 @@ __global__ void __launch_bounds__(64) k_gcig_grp(GcigArgs A) {
     int* hn = hB;
     for (int i = 0; i < tl_max; ++i) {
         const bool row = i < tlen;
-        const int tb = row ? ts[i] : 0;
+        const int tb = ts[i < tlen ? i : 0];
         const int beg = i > w ? i - w : 0;
         const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
-        const int h_in = beg == 0 ? -(A.o.o_del + e_del * (i + 1)) : MINUS_INF;
-        if (row && gl == 0) hn[beg & RM] = h_in;
+        const int end_prev = i == 0 ? 0 : (i + w < qlen ? i + w : qlen);
         const int j = beg + gl;
         const bool in = row && j < end;
-        int m = MINUS_INF, e = MINUS_INF;
-        if (in) {
-            const int qb = qs[j];
-            const int sc = (tb > 3 || qb > 3) ? -1 : (tb == qb ? A.o.a : -A.o.b);
-            m = hp[j & RM] + sc;
-            e = eE[j & RM];
-        }
+        const int qb = qs[j];
+        const int hprev = hp[j & RM], eprev = eE[j & RM];
+        const int sc = (tb > 3 || qb > 3) ? -1 : (tb == qb ? A.o.a : -A.o.b);
+        const int m = (j == 0 ? (i == 0 ? 0 : -(A.o.o_del + e_del * i)) : hprev) + sc;
+        const int e = j >= end_prev ? MINUS_INF : eprev;
         const int g = in ? m - oe_ins + gl * e_ins : -2000000000;
         int sg = g, y;
         y = GCIG_DPP(-2000000000, sg, 0x111, 0xF); sg = sg > y ? sg : y;
@@ -330,7 +326,6 @@ __global__ void __launch_bounds__(64) k_gcig_grp(GcigArgs A) {
         const int f2 = f - e_ins;
         d |= f2 > t ? 2u << 4 : 0u;
         if (in) { eE[j & RM] = e2; hn[(j + 1) & RM] = h; zl[i * n_col + gl] = (uint8_t)d; }
-        if (row && gl == 0) eE[end & RM] = MINUS_INF;
         __syncthreads();
         if (row) { int* tsw = hp; hp = hn; hn = tsw; }
     }
