@@ -337,7 +337,7 @@ def ext_leg(ctx, reads, genome, l_pac, nsub=2000000, ncig=400000, check_reads=No
         ok = ok and o_sc == int(r["score"]) and o_nm == int(r["nm"]) and np.array_equal(o_cg, cig[o0:o0 + int(r["n_cigar"])]) and o_md == md[m0:m0 + int(r["md_len"])].tobytes()
     nogap = int(np.sum((ql == tl) & (w2 == 0)))
     cls = list(ctx.timings().gcig_class_jobs)
-    out["cigar"] = {"jobs_by_kernel": {"k_gcig_grp<16> (4 jobs per wavefront)": int(cls[0]), "k_gcig_grp<32> (2 per wavefront)": int(cls[1]), "k_gcig_grp<64> (one per wavefront, one chunk per row)": int(cls[4]), "k_gcig (a wavefront each, 64-column chunks)": int(cls[2]),
+    out["cigar"] = {"jobs_by_kernel": {"k_gcig_grp<16> (4 jobs per wavefront)": int(cls[0]), "k_gcig_grp<32> (2 per wavefront)": int(cls[1]), "k_gcig_grp<64> (one per wavefront, one chunk per row)": int(cls[4]), "k_gcig_t<true> (a wavefront each, two columns per lane)": int(cls[5]), "k_gcig_t<false> (a wavefront each, 64-column chunks)": int(cls[2]),
                                        "k_gcig_nogap (a lane each)": int(cls[3])}}
     out["cigar"] |= {"metric": "cigar_alignments_per_sec", "value": J.shape[0] / (ms * 1e-3) if ok and ms > 0 else None, "unit": "alignments/s", "alignments": int(J.shape[0]),
                     "what": "bwa_gen_cigar2 whole (meme_gen_cigar_batch_host): CIGAR + NM + MD", "gap_free_shortcut_share": nogap / max(J.shape[0], 1),

@@ -38,17 +38,22 @@ struct GcigArgs {
 __device__ __forceinline__ int text_base(const u64* pac, i64 p) { return (int)(pac[p >> 5] >> (62 - 2 * (int)(p & 31))) & 3; }
 #define GCIG_DPP(old_, src_, ctrl_, rowmask_) __builtin_amdgcn_update_dpp((old_), (src_), (ctrl_), (rowmask_), 0xF, false)
 
-__global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
-    extern __shared__ int lds[];             // hA[qlen + 2] | hB[qlen + 2] | e[qlen + 2] | query bytes (as ints, 4 per word)
+// TWO (round 6): bands of 65-128 columns as ONE chunk per row, two adjacent columns per lane (the 250-bp / 5 % class: ~117 columns, which the 64-column chunks above ran as
+// two passes per row, the second 53 lanes full); H and E in rings of 256 entries as in k_gcig_grp below, the boundary cells by arithmetic; the matrix, the walk back through
+// the LDS window, NM and MD are this kernel's own code, unchanged.
+template <bool TWO>
+__global__ void __launch_bounds__(64) k_gcig_t(GcigArgs A) {
+    extern __shared__ int lds[];             // hA[qlen + 2] | hB[qlen + 2] | e[qlen + 2] (TWO: 256 each) | query bytes (as ints, 4 per word)
     if ((i64)blockIdx.x >= A.njobs) return;
     const i64 jb = A.dp_list ? A.dp_list[A.list_first + blockIdx.x] : (i64)blockIdx.x;
     const int lane = threadIdx.x;
     const meme_gjob J = A.jobs[jb];
     const int qlen = J.qlen, tlen = J.tlen, w = J.w;
+    constexpr int RM2 = 255;
     int* hA = lds;
-    int* hB = hA + (qlen + 2);
-    int* eE = hB + (qlen + 2);
-    uint8_t* qs = reinterpret_cast<uint8_t*>(eE + (qlen + 2));
+    int* hB = hA + (TWO ? 256 : qlen + 2);
+    int* eE = hB + (TWO ? 256 : qlen + 2);
+    uint8_t* qs = reinterpret_cast<uint8_t*>(eE + (TWO ? 256 : qlen + 2));
     uint8_t* ts = qs + ((qlen + 3) & ~3);    // the target bases in row order: a row must not wait for a load from the text (1-2 us each, 250 in a row)
     uint8_t* zl = ts + ((tlen + 3) & ~3);    // the backtrack matrix, when it fits (A.zcap bytes): the walk back is one dependent load per step
     const uint8_t* rd = A.reads + A.read_off[J.read] + J.qb;
@@ -74,14 +79,65 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
     const int oe_del = A.o.o_del + A.o.e_del, oe_ins = A.o.o_ins + A.o.e_ins, e_del = A.o.e_del, e_ins = A.o.e_ins;
     const int n_col = qlen < 2 * w + 1 ? qlen : 2 * w + 1;
     uint8_t* z = (i64)n_col * tlen <= A.zcap ? zl : A.z + A.zoff[jb];
+    int* hp = hA;                            // H(i-1, j-1) at [j]
+    int* hn = hB;
+    if constexpr (TWO) {
+        for (int j = lane + 1; j <= qlen && j <= w + 1; j += 64) hA[j & RM2] = j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF;
+        __syncthreads();
+        for (int i = 0; i < tlen; ++i) {
+            const int tb = ts[i];
+            const int beg = i > w ? i - w : 0;
+            const int end = i + w + 1 < qlen ? i + w + 1 : qlen;
+            const int end_prev = i == 0 ? 0 : (i + w < qlen ? i + w : qlen);
+            const int j0 = beg + 2 * lane, j1 = j0 + 1;
+            const bool in0 = j0 < end, in1 = j1 < end;
+            const int qb0 = qs[j0], qb1 = qs[j1];
+            const int h0 = hp[j0 & RM2], h1 = hp[j1 & RM2], ep0 = eE[j0 & RM2], ep1 = eE[j1 & RM2];
+            const int sc0 = (tb > 3 || qb0 > 3) ? -1 : (tb == qb0 ? A.o.a : -A.o.b);
+            const int sc1 = (tb > 3 || qb1 > 3) ? -1 : (tb == qb1 ? A.o.a : -A.o.b);
+            const int m0 = (j0 == 0 ? (i == 0 ? 0 : -(A.o.o_del + e_del * i)) : h0) + sc0;
+            const int m1 = h1 + sc1;
+            const int e0 = j0 >= end_prev ? MINUS_INF : ep0, e1 = j1 >= end_prev ? MINUS_INF : ep1;
+            // F along the row (see the one-column form below): G_c = M_c - oe_ins + c * e_ins over the row's columns c = j - beg; F_c = max_{k<c} G_k - (c - 1) * e_ins
+            const int g0 = in0 ? m0 - oe_ins + (2 * lane) * e_ins : -2000000000;
+            const int g1 = in1 ? m1 - oe_ins + (2 * lane + 1) * e_ins : -2000000000;
+            int sg = g0 > g1 ? g0 : g1, y;
+            y = GCIG_DPP(-2000000000, sg, 0x111, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x112, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x114, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x118, 0xF); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x142, 0xA); sg = sg > y ? sg : y;
+            y = GCIG_DPP(-2000000000, sg, 0x143, 0xC); sg = sg > y ? sg : y;
+            const int ex = GCIG_DPP(-2000000000, sg, 0x138, 0xF);        // max over the lanes below (lane 0: not used)
+            const int ex1 = lane == 0 ? g0 : (ex > g0 ? ex : g0);
+            int fa = ex - (2 * lane - 1) * e_ins, fb = MINUS_INF - (2 * lane) * e_ins;
+            const int f0 = lane == 0 ? MINUS_INF : (fa > fb ? fa : fb);
+            fa = ex1 - (2 * lane) * e_ins; fb = MINUS_INF - (2 * lane + 1) * e_ins;
+            const int f1 = fa > fb ? fa : fb;
+            unsigned d0 = m0 >= e0 ? 0u : 1u, d1 = m1 >= e1 ? 0u : 1u;
+            int hh0 = m0 >= e0 ? m0 : e0, hh1 = m1 >= e1 ? m1 : e1;
+            d0 = hh0 >= f0 ? d0 : 2u; d1 = hh1 >= f1 ? d1 : 2u;
+            hh0 = hh0 >= f0 ? hh0 : f0; hh1 = hh1 >= f1 ? hh1 : f1;
+            int t0 = m0 - oe_del, t1 = m1 - oe_del;
+            int ea = e0 - e_del, eb = e1 - e_del;
+            d0 |= ea > t0 ? 1u << 2 : 0u; d1 |= eb > t1 ? 1u << 2 : 0u;
+            ea = ea > t0 ? ea : t0; eb = eb > t1 ? eb : t1;
+            t0 = m0 - oe_ins; t1 = m1 - oe_ins;
+            d0 |= f0 - e_ins > t0 ? 2u << 4 : 0u; d1 |= f1 - e_ins > t1 ? 2u << 4 : 0u;
+            uint8_t* zi = z + (i64)i * n_col;
+            if (in0) { eE[j0 & RM2] = ea; hn[(j0 + 1) & RM2] = hh0; zi[2 * lane] = (uint8_t)d0; }
+            if (in1) { eE[j1 & RM2] = eb; hn[(j1 + 1) & RM2] = hh1; zi[2 * lane + 1] = (uint8_t)d1; }
+            __syncthreads();
+            int* tsw = hp; hp = hn; hn = tsw;
+        }
+        score = hp[qlen & RM2];
+    } else {
     // first row (src/ksw.cpp:591-595)
     for (int j = lane; j <= qlen; j += 64) {
         hA[j] = j == 0 ? 0 : (j <= w ? -(A.o.o_ins + e_ins * j) : MINUS_INF);
         eE[j] = MINUS_INF;
     }
     __syncthreads();
-    int* hp = hA;                            // H(i-1, j-1) at [j]
-    int* hn = hB;
     for (int i = 0; i < tlen; ++i) {
         const int tb = ts[i];
         const int beg = i > w ? i - w : 0;
@@ -138,6 +194,7 @@ __global__ void __launch_bounds__(64) k_gcig(GcigArgs A) {
         int* tsw = hp; hp = hn; hn = tsw;
     }
     score = hp[qlen];
+    }
     // backtrack (src/ksw.cpp:650-664), every lane the same walk; the operations are written from the back of the job's scratch
     {
         __threadfence();
@@ -486,8 +543,9 @@ __global__ void __launch_bounds__(256) k_gcig_pack(const meme_gres* __restrict__
 }
 // per job: the kernel that takes it -- isdp: k_gcig (a wavefront), is16 / is32: k_gcig_grp<16 / 32> (a group of lanes; z16 / z32 = bytes of LDS a group has for
 // the backtrack matrix, 0: the class is not used), none: k_gcig_nogap -- and the sizes of its scratch
-__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, int z16, int z32, int z64, i64* __restrict__ zsz,
-                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp, i64* __restrict__ is16, i64* __restrict__ is32, i64* __restrict__ is64) {
+__global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict__ jobs, i64 njobs, const i64* __restrict__ read_off, bool fast, int zcap, int z16, int z32, int z64, bool two, i64* __restrict__ zsz,
+                                                     i64* __restrict__ csz, i64* __restrict__ msz, i64* __restrict__ isdp, i64* __restrict__ is16, i64* __restrict__ is32, i64* __restrict__ is64,
+                                                     i64* __restrict__ is128) {
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         const meme_gjob J = jobs[jb];
         const bool dp = !(fast && nogap_fast(J, read_off));
@@ -495,8 +553,9 @@ __global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict_
         const bool g16 = dp && J.w >= 0 && n_col <= 16 && n_col * J.tlen <= z16;
         const bool g32 = dp && !g16 && J.w >= 0 && n_col <= 32 && n_col * J.tlen <= z32;
         const bool g64 = dp && !g16 && !g32 && J.w >= 0 && n_col <= 64 && n_col * J.tlen <= z64;
-        is16[jb] = g16; is32[jb] = g32; is64[jb] = g64;
-        isdp[jb] = dp && !g16 && !g32 && !g64;                               // 1: the job goes to k_gcig
+        const bool g128 = two && dp && !g16 && !g32 && !g64 && J.w >= 0 && n_col <= 128;      // k_gcig_t<true>: two columns per lane (matrix in LDS or HBM as for k_gcig)
+        is16[jb] = g16; is32[jb] = g32; is64[jb] = g64; is128[jb] = g128;
+        isdp[jb] = dp && !g16 && !g32 && !g64 && !g128;                      // 1: the job goes to k_gcig
         zsz[jb] = J.w < 0 || g16 || g32 || g64 || n_col * J.tlen <= zcap ? 0 : (n_col * J.tlen + 15) & ~(i64)15;   // (w < 0: the gap-free shortcut, no matrix; small matrices stay in LDS)
         csz[jb] = J.qlen + J.tlen + 2;
         if (msz) msz[jb] = 2 * ((i64)J.qlen + J.tlen) + 16;                // an MD string never has more than two characters per base
@@ -504,14 +563,15 @@ __global__ void __launch_bounds__(256) k_gcig_sizes(const meme_gjob* __restrict_
 }
 // the list the three kernels draw from: the 16-lane jobs, then the 32-lane jobs, then the whole-wavefront jobs, each in job order
 __global__ void __launch_bounds__(256) k_gcig_dplist(const i64* __restrict__ isdp, const i64* __restrict__ dpoff, const i64* __restrict__ is16, const i64* __restrict__ o16,
-                                                      const i64* __restrict__ is32, const i64* __restrict__ o32, const i64* __restrict__ is64, const i64* __restrict__ o64, i64 njobs,
-                                                      i64* __restrict__ list) {
-    const i64 n16 = o16[njobs], n32 = o32[njobs], n64 = o64[njobs];
+                                                      const i64* __restrict__ is32, const i64* __restrict__ o32, const i64* __restrict__ is64, const i64* __restrict__ o64, const i64* __restrict__ is128,
+                                                      const i64* __restrict__ o128, i64 njobs, i64* __restrict__ list) {
+    const i64 n16 = o16[njobs], n32 = o32[njobs], n64 = o64[njobs], n128 = o128[njobs];
     for (i64 jb = (i64)blockIdx.x * blockDim.x + threadIdx.x; jb < njobs; jb += (i64)gridDim.x * blockDim.x) {
         if (is16[jb]) list[o16[jb]] = jb;
         else if (is32[jb]) list[n16 + o32[jb]] = jb;
         else if (is64[jb]) list[n16 + n32 + o64[jb]] = jb;
-        else if (isdp[jb]) list[n16 + n32 + n64 + dpoff[jb]] = jb;
+        else if (is128[jb]) list[n16 + n32 + n64 + o128[jb]] = jb;
+        else if (isdp[jb]) list[n16 + n32 + n64 + n128 + dpoff[jb]] = jb;
     }
 }
 __global__ void __launch_bounds__(256) k_gcig_ncig(const meme_gres* __restrict__ res, i64 njobs, i64* __restrict__ ncig) {
@@ -586,7 +646,7 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     const int zwant = ctx->gcig_zcap >= 0 ? (int)ctx->gcig_zcap : zauto;
     const int zcap = lds_base + (size_t)zwant <= 32 * 1024 ? zwant : 0;          // (long reads: their rows fill the LDS, the matrix stays in global memory)
     DevBuf* G = ctx->gcig;      // 0 jobs, 1 sizes + offsets (8 x (n+1)), 2 z, 3 cigar scratch, 4 results, 5 packed cigars, 6 MD scratch, 7 nm + mdlen, 8 packed MD, 9 cjobs, 10 cres
-    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 19 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
+    if ((rc = meme_buf_reserve(ctx, G[1], (size_t)(njobs + 1) * 8 * 21 + 64)) || (rc = meme_buf_reserve(ctx, G[4], (size_t)njobs * sizeof(meme_gres)))) return rc;
     i64* d_zsz = (i64*)G[1].p;
     i64* d_csz = d_zsz + (njobs + 1);
     i64* d_zoff = d_csz + (njobs + 1);
@@ -606,7 +666,9 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     i64* d_o32 = d_is32 + (njobs + 1);
     i64* d_is64 = d_o32 + (njobs + 1);
     i64* d_o64 = d_is64 + (njobs + 1);
-    i64* d_bad = d_o64 + (njobs + 1);
+    i64* d_is128 = d_o64 + (njobs + 1);
+    i64* d_o128 = d_is128 + (njobs + 1);
+    i64* d_bad = d_o128 + (njobs + 1);
     // Several jobs per wavefront for narrow bands (k_gcig_grp; tuning "gcig_groups" = 0: every job a wavefront): per group rings for H and E, the query, the
     // target and a matrix of 16 (32) columns x the longest target, as long as a wavefront's groups stay within 24 KB (six wavefronts per CU and more)
     const int grp_qcap = (qmax + 3) & ~3, grp_tcap = (tmax + 3) & ~3;
@@ -619,19 +681,23 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     if (grp_lds(16, z16) > 24 * 1024) z16 = 0;
     if (grp_lds(32, z32) > 24 * 1024) z32 = 0;
     if (grp_lds(64, z64) > 16 * 1024) z64 = 0;
+    const size_t lds_two = (size_t)3 * 256 * 4 + (size_t)((qmax + 3) & ~3) + (size_t)((tmax + 3) & ~3) + (size_t)(zcap > 256 ? zcap : 256);
+    const bool two = ctx->gcig_groups && lds_two <= 32 * 1024;
     // the gap-free shortcut on the packed reads the seeding call left on the ctx (reads of at most 500 bases)
     const bool fast = ctx->packed.p != nullptr && ctx->last_seed_max_len > 0;
     const int pW = (int)((ctx->last_seed_max_len + 31) / 32) + 2, pMW = (int)((ctx->last_seed_max_len + 63) / 64);      // PackGeom of that batch (meme_seed.hip)
     HIP_TRY(hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     hipLaunchKernelGGL(k_gcig_check, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, d_bad);
-    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, z16, z32, z64, d_zsz, d_csz,
-                       with_md ? d_msz : (i64*)nullptr, d_isdp, d_is16, d_is32, d_is64);
+    hipLaunchKernelGGL(k_gcig_sizes, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gjob*)G[0].p, (i64)njobs, (const i64*)ctx->read_off.p, fast, zcap, z16, z32, z64, two, d_zsz, d_csz,
+                       with_md ? d_msz : (i64*)nullptr, d_isdp, d_is16, d_is32, d_is64, d_is128);
     if ((rc = meme_scan_exclusive(ctx, d_zsz, d_zoff, njobs)) || (rc = meme_scan_exclusive(ctx, d_csz, d_coff, njobs)) || (rc = meme_scan_exclusive(ctx, d_isdp, d_dpoff, njobs)) ||
-        (rc = meme_scan_exclusive(ctx, d_is16, d_o16, njobs)) || (rc = meme_scan_exclusive(ctx, d_is32, d_o32, njobs)) || (rc = meme_scan_exclusive(ctx, d_is64, d_o64, njobs))) return rc;
+        (rc = meme_scan_exclusive(ctx, d_is16, d_o16, njobs)) || (rc = meme_scan_exclusive(ctx, d_is32, d_o32, njobs)) || (rc = meme_scan_exclusive(ctx, d_is64, d_o64, njobs)) ||
+        (rc = meme_scan_exclusive(ctx, d_is128, d_o128, njobs))) return rc;
     hipLaunchKernelGGL(k_gcig_dplist, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const i64*)d_isdp, (const i64*)d_dpoff, (const i64*)d_is16, (const i64*)d_o16,
-                       (const i64*)d_is32, (const i64*)d_o32, (const i64*)d_is64, (const i64*)d_o64, (i64)njobs, d_dplist);
+                       (const i64*)d_is32, (const i64*)d_o32, (const i64*)d_is64, (const i64*)d_o64, (const i64*)d_is128, (const i64*)d_o128, (i64)njobs, d_dplist);
     if (with_md && (rc = meme_scan_exclusive(ctx, d_msz, d_moff, njobs))) return rc;
-    i64 tz = 0, tc = 0, tm = 0, ndp = 0, n16 = 0, n32 = 0, n64 = 0;
+    i64 tz = 0, tc = 0, tm = 0, ndp = 0, n16 = 0, n32 = 0, n64 = 0, n128 = 0;
+    HIP_TRY(hipMemcpyAsync(&n128, d_o128 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&n64, d_o64 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&ndp, d_dpoff + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&n16, d_o16 + njobs, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -664,7 +730,7 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     A.nm = with_md ? (int32_t*)G[7].p : nullptr; A.mdlen = with_md ? (int32_t*)G[7].p + njobs : nullptr;
     A.zcap = zcap; A.dp_list = nullptr; A.packed = (const u64*)ctx->packed.p; A.pW = pW; A.pMW = pMW; A.pstride = 2 * pW + 2 * pMW + 1;
     A.list_first = 0; A.grp_qcap = grp_qcap; A.grp_tcap = grp_tcap; A.grp_z = 0;
-    if (ndp + n16 + n32 + n64 < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
+    if (ndp + n16 + n32 + n64 + n128 < njobs) hipLaunchKernelGGL(k_gcig_nogap, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, A);
     if (n16 > 0) {
         GcigArgs D = A;
         D.dp_list = d_dplist; D.njobs = n16; D.list_first = 0; D.grp_z = z16;
@@ -680,13 +746,19 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
         D.dp_list = d_dplist; D.njobs = n64; D.list_first = n16 + n32; D.grp_z = z64;
         hipLaunchKernelGGL(k_gcig_grp<64>, dim3((unsigned)n64), dim3(64), grp_lds(64, z64), ctx->stream, D);
     }
-    ctx->tm.gcig_class_jobs[0] = n16; ctx->tm.gcig_class_jobs[1] = n32; ctx->tm.gcig_class_jobs[2] = ndp; ctx->tm.gcig_class_jobs[3] = njobs - ndp - n16 - n32 - n64; ctx->tm.gcig_class_jobs[4] = n64;
+    if (n128 > 0) {
+        GcigArgs D = A;
+        D.dp_list = d_dplist; D.njobs = n128; D.list_first = n16 + n32 + n64;
+        hipLaunchKernelGGL(k_gcig_t<true>, dim3((unsigned)n128), dim3(64), lds_two, ctx->stream, D);
+    }
+    ctx->tm.gcig_class_jobs[5] = n128;
+    ctx->tm.gcig_class_jobs[0] = n16; ctx->tm.gcig_class_jobs[1] = n32; ctx->tm.gcig_class_jobs[2] = ndp; ctx->tm.gcig_class_jobs[3] = njobs - ndp - n16 - n32 - n64 - n128; ctx->tm.gcig_class_jobs[4] = n64;
     if (ndp > 0) {
         GcigArgs D = A;
-        D.dp_list = d_dplist; D.njobs = ndp; D.list_first = n16 + n32 + n64;
+        D.dp_list = d_dplist; D.njobs = ndp; D.list_first = n16 + n32 + n64 + n128;
         const size_t lds = lds_base + (size_t)zcap;
-        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_gcig, dim3((unsigned)ndp), dim3(64), lds, ctx->stream, D);
+        if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_gcig_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_gcig_t<false>, dim3((unsigned)ndp), dim3(64), lds, ctx->stream, D);
     }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_gcig_ncig, dim3(grid_of(njobs, 256)), dim3(256), 0, ctx->stream, (const meme_gres*)G[4].p, (i64)njobs, d_ncig);

@@ -147,7 +147,7 @@ class Timings(C.Structure):
                 ("seed_launches", C.c_int64), ("bsw_launches", C.c_int64), ("seed_pack_ms", C.c_float),
                 ("seed_windows", C.c_int64), ("chain_kernel_ms", C.c_float), ("chain_pass2_ms", C.c_float), ("chain_tier3_ms", C.c_float),
                 ("chain_tier2_reads", C.c_int64), ("chain_tier3_reads", C.c_int64),
-                ("seed_reseed_ms", C.c_float), ("seed_lane_searches", C.c_int64), ("gcig_class_jobs", C.c_int64 * 5)]
+                ("seed_reseed_ms", C.c_float), ("seed_lane_searches", C.c_int64), ("gcig_class_jobs", C.c_int64 * 6)]
 
 
 # every symbol include/meme_hip.h declares (tests/test_abi.py checks the library exports them all)

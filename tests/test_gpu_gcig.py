@@ -47,6 +47,11 @@ def test_device_cigars_equal_reference_golden(tmp_path):
 
 def test_device_cigars_equal_oracle_with_other_penalties(tmp_path):
     g, reads, jobs, seqs = gcig_workload(n=800, seed=91)
+    # (the workload's bands are 1, 3, 10, 30, 100, ...: every third job gets one of 33-63 instead -- 67-127 band columns, the two-columns-per-lane kernel of round 6)
+    jobs = jobs.copy()
+    for k in range(0, jobs.shape[0], 3):
+        need = abs(int(jobs["tlen"][k]) - int(jobs["qlen"][k]))
+        jobs["w"][k] = max(need, 33 + (7 * k) % 31)
     ctx = _ctx_with_reads(tmp_path, g, reads)
     try:
         for a, b, od, ed, oi, ei in ((2, 3, 4, 2, 7, 1), (1, 9, 1, 1, 1, 1)):
