@@ -83,7 +83,7 @@ struct meme_ctx {
     i64 seed_early_tier = 1;           // 1: the overflow tier of the reads known to have overflowed after k_reseed runs beside the re-seeding batches
     i64 ext_live_only = 0;             // 1: meme_extend_last_batch_host hands over the surviving records only (qe > qb: what src/bwamem.cpp:1680-1693 keeps)
     i64 ext_rounds = 1;                // with ext_live_only: rounds of one seed per read before everything still ahead is extended at once (0: the reference's batch, then compaction)
-    i64 gcig_groups = 1;               // 1: CIGAR jobs with bands of at most 16 / 32 columns run 4 / 2 to a wavefront (k_gcig_grp); 0: a wavefront each
+    i64 gcig_groups = 1;               // 1: CIGAR jobs with bands of at most 16 / 32 / 64 columns run 4 / 2 / 1 to a wavefront as one chunk per row (k_gcig_grp); 0: a wavefront each, 64-column chunks; 2: also bands of 65-128 columns as one chunk, two columns per lane (measured slower: off by default)
     i64 gcig_zcap = -1;                // >= 0: bytes of LDS per CIGAR job for its backtrack matrix / window (default: 8192 where a typical matrix of the batch fits, else 2048)
     i64 ext_census = 0;                // 1: the extension stage counts its exact-prefix jobs (a measurement, profiles/r05_bsw.md)
     i64 seed_defer = 1;                // 1: re-seeding regions of unique SMEMs are verified on the plcp table (k_reseed) instead of searched

@@ -682,7 +682,8 @@ int gcig_run(meme_ctx* ctx, i64 njobs, int qmax, int tmax, const meme_bsw_opt* o
     if (grp_lds(32, z32) > 24 * 1024) z32 = 0;
     if (grp_lds(64, z64) > 16 * 1024) z64 = 0;
     const size_t lds_two = (size_t)3 * 256 * 4 + (size_t)((qmax + 3) & ~3) + (size_t)((tmax + 3) & ~3) + (size_t)(zcap > 256 ? zcap : 256);
-    const bool two = ctx->gcig_groups && lds_two <= 32 * 1024;
+    // (measured, profiles/r06_gcig.md: 23 % fewer instructions per job than two 64-column chunks and 6 % MORE time on the 250-bp class -- the class stays opt-in, gcig_groups = 2)
+    const bool two = ctx->gcig_groups >= 2 && lds_two <= 32 * 1024;
     // the gap-free shortcut on the packed reads the seeding call left on the ctx (reads of at most 500 bases)
     const bool fast = ctx->packed.p != nullptr && ctx->last_seed_max_len > 0;
     const int pW = (int)((ctx->last_seed_max_len + 31) / 32) + 2, pMW = (int)((ctx->last_seed_max_len + 63) / 64);      // PackGeom of that batch (meme_seed.hip)

@@ -406,7 +406,7 @@ typedef struct {
     int64_t gcig_class_jobs[6];   /* the last CIGAR call's jobs by kernel: 16-lane groups, 32-lane groups, a wavefront each in 64-column chunks, the gap-free shortcut, 64-lane "groups", two columns per lane */
 } meme_timings;
 int meme_get_timings(meme_ctx* ctx, meme_timings* out);
-int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "seed_early_tier" (0: overflow tiers strictly behind the re-seeding kernels), "ext_live_only" (1: meme_extend_last_batch_host hands over only the records mem_kernel2_core keeps, src/bwamem.cpp:1680-1693 -- qe > qb, in order -- instead of one per chained seed with the purged ones marked; the stage then also runs in rounds -- "ext_rounds" (default 1; 0: off): a read's seeds are taken in extension order, tested against the read's surviving alignments first and extended only if they survive, one seed per read and round, after that many rounds everything still ahead at once: the same surviving records, without the banded SW of seeds the purge drops), "gcig_groups" (1, default: CIGAR jobs whose band has at most 16 / 32 columns run 4 / 2 to a wavefront; 0: one wavefront per job), "gcig_zcap" (>= 0: bytes of LDS a CIGAR job keeps for its backtrack matrix or the window it is walked back through; default: chosen per call, 8192 where a typical matrix of the batch fits, else 2048; results do not depend on it), "chain_side_priority" (1: the routed chaining tiers' streams are created with the highest stream priority -- set before the first chaining call; measured slower, profiles/r05_chain_priority.md; default 0), "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY), "ext_split" (default 1: the extension stage's kernels that walk a read's chains run eight lanes per read for reads with at most 8 chained seeds and a wavefront per read for the others; 0: a wavefront per read throughout; same records), "bsw_circ" (default 1: the lane-per-pair banded-SW kernel keeps the columns of queries longer than its band in a ring of 2w + 2 columns -- same results, more wavefronts per CU; 0: one LDS word per query column as before), "sam_max_batch" (> 0: meme_sam_format_batch_host refuses more record slots than this with MEME_E_CAPACITY; the caller formats in pieces) */
+int meme_set_tuning(meme_ctx* ctx, const char* key, int64_t value);   /* "group_lanes", "seed_blocks_per_cu", "seed_blocks", "smem_cap", "bsw_blocks", "bsw_lane_min_pairs", "chain_wave_tiers", "chain_lane_hits", "chain_light_hits", "seed_defer", "seed_early_tier" (0: overflow tiers strictly behind the re-seeding kernels), "ext_live_only" (1: meme_extend_last_batch_host hands over only the records mem_kernel2_core keeps, src/bwamem.cpp:1680-1693 -- qe > qb, in order -- instead of one per chained seed with the purged ones marked; the stage then also runs in rounds -- "ext_rounds" (default 1; 0: off): a read's seeds are taken in extension order, tested against the read's surviving alignments first and extended only if they survive, one seed per read and round, after that many rounds everything still ahead at once: the same surviving records, without the banded SW of seeds the purge drops), "gcig_groups" (1, default: CIGAR jobs whose band has at most 16 / 32 / 64 columns run 4 / 2 / 1 to a wavefront with one chunk per row; 0: one wavefront per job in 64-column chunks; 2: bands of 65-128 columns as one chunk too, two columns per lane -- measured slower, kept for the record), "gcig_zcap" (>= 0: bytes of LDS a CIGAR job keeps for its backtrack matrix or the window it is walked back through; default: chosen per call, 8192 where a typical matrix of the batch fits, else 2048; results do not depend on it), "chain_side_priority" (1: the routed chaining tiers' streams are created with the highest stream priority -- set before the first chaining call; measured slower, profiles/r05_chain_priority.md; default 0), "ext_census" (1: meme_extend_last_batch_host also counts the extension jobs whose query is a prefix of its target), "max_batch" (> 0: meme_extend_last_batch_host / meme_global_batch_host refuse larger batches with MEME_E_CAPACITY), "ext_split" (default 1: the extension stage's kernels that walk a read's chains run eight lanes per read for reads with at most 8 chained seeds and a wavefront per read for the others; 0: a wavefront per read throughout; same records), "bsw_circ" (default 1: the lane-per-pair banded-SW kernel keeps the columns of queries longer than its band in a ring of 2w + 2 columns -- same results, more wavefronts per CU; 0: one LDS word per query column as before), "sam_max_batch" (> 0: meme_sam_format_batch_host refuses more record slots than this with MEME_E_CAPACITY; the caller formats in pieces) */
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ from pymeme import hipapi, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[1, 0], ids=["groups", "wavefront-per-job"])
+@pytest.fixture(autouse=True, params=[1, 0, 2], ids=["groups", "wavefront-per-job", "groups+two-columns-per-lane"])
 def _gcig_groups(request, monkeypatch):
     """Round 6: jobs with bands of at most 16 / 32 columns run 4 / 2 to a wavefront (k_gcig_grp); every test of this file runs with that (the default) and with
     one wavefront per job (k_gcig alone) -- the same scores, operations, NM and MD either way."""
