@@ -537,7 +537,7 @@ def config4_class_leg(ctx, dev, genome, text, sa, l1, l2, l_pac, steps=3):
                        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0},
                        "matches_oracle": bool(parity), "checked_reads": npar}}
     out["chain"] = chain_leg(ctx, reads, l_pac, nsub=nreads)
-    out["ext"] = ext_leg(ctx, reads, genome, l_pac, nsub=nreads, ncig=min(nreads, 400000), check_reads=int(os.environ.get("MEME_BENCH_C4_EXT_CHECK_READS", "1000000")))
+    out["ext"] = ext_leg(ctx, reads, genome, l_pac, nsub=nreads, ncig=min(nreads, 400000), check_reads=int(os.environ.get("MEME_BENCH_C4_EXT_CHECK_READS", "600000")))
     return out
 
 
@@ -872,8 +872,8 @@ def e2e_leg(prefix, genome, npairs, threads, devices=1, refcache=None, read_len=
         if os.environ.get("MEME_BENCH_E2E_SLICES", "1") != "0" and devices == 1 and read_len == READ_LEN and slices_ok:
             slices = {}
             chunk_reads = 100000000 // read_len // 2 * 2 + 2
-            # (on the first 4 M pairs: per-slice figures do not depend on how many chunks follow, and three more runs over all 10 M pairs were 50 s of this leg)
-            s_pairs = min(npairs, int(os.environ.get("MEME_BENCH_E2E_SLICE_PAIRS", "4000000")))
+            # (on the first four chunks' worth of pairs: per-slice figures do not depend on how many chunks follow, and three more runs over all 10 M pairs were 50 s of this leg)
+            s_pairs = min(npairs, int(os.environ.get("MEME_BENCH_E2E_SLICE_PAIRS", "2666668")))
             s_fqs = fqs
             if s_pairs < npairs:
                 s_fqs = [os.path.join(d, "s1.fq"), os.path.join(d, "s2.fq")]
