@@ -618,17 +618,15 @@ def repeat_dense_leg(device_index, steps=3, want_ref_index=False):
     return out
 
 
-def live_pmc_traffic(steps=2, reads=None):
-    box = []
+def live_pmc_traffic(steps=2, reads_file=None):
     try:
-        return _live_pmc_traffic(steps, reads, box)
+        return _live_pmc_traffic(steps, reads_file)
     finally:
-        for f in box:
-            if os.path.exists(f):
-                os.remove(f)
+        if reads_file and os.path.exists(reads_file):
+            os.remove(reads_file)
 
 
-def _live_pmc_traffic(steps, reads, rfile_box):
+def _live_pmc_traffic(steps, rfile):
     """HBM traffic of the SA-search stage measured in THIS run: bench.py re-executes itself (seeding only, `steps` launches, no warm-up) once under
     `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` -- counters in passes of their own, as the MI355X guide prescribes -- and sums the
     counters over the stage's kernels (k_seed<G> + k_reseed*).  Returns {"fetch_kb", "write_kb"} per launch, or None when the tool is not there or a
@@ -639,14 +637,6 @@ def _live_pmc_traffic(steps, reads, rfile_box):
     if not exe:
         return None
     out = {}
-    rfile = None
-    if reads is not None and os.path.isdir("/dev/shm"):
-        try:
-            rfile = os.path.join("/dev/shm", "meme_bench_reads_%d.npy" % os.getpid())
-            np.save(rfile, reads)
-            rfile_box.append(rfile)
-        except Exception:
-            rfile = None
     for key, counter in (("fetch_kb", "FETCH_SIZE"), ("write_kb", "WRITE_SIZE")):
         d = tempfile.mkdtemp(prefix="meme_pmc_", dir="/tmp")
         try:
@@ -1137,6 +1127,16 @@ def main():
     d_off = torch.arange(0, (nreads + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     log("%d reads sampled and uploaded in %.1f s" % (nreads, time.time() - t0))
+    # the batch as sampled, for the counter passes at the end of the run (they re-execute this file; sampling again was 18 s per pass)
+    reads_file, reads_sum0 = None, int(reads.reshape(-1).view(np.uint64).sum(dtype=np.uint64)) if reads.size % 8 == 0 else None
+    if rank == 0 and world == 1 and not rf and os.environ.get("MEME_BENCH_PMC", "1") != "0" and os.environ.get("MEME_BENCH_PMC_READS_CACHE", "1") != "0" and os.path.isdir("/dev/shm") and shutil.which("rocprofv3"):
+        try:
+            reads_file = os.path.join("/dev/shm", "meme_bench_reads_%d.npy" % os.getpid())
+            np.save(reads_file, reads)
+            import atexit
+            atexit.register(lambda f=reads_file: os.path.exists(f) and os.remove(f))
+        except Exception:
+            reads_file = None
     opt = hipapi.default_seed_opt(rounds=3)
 
     def step():
@@ -1405,7 +1405,10 @@ def main():
                     ctx = None
                     keep = d_reads = d_off = None
                     torch.cuda.empty_cache()
-                live = live_pmc_traffic(reads=reads)
+                if reads_sum0 is not None and int(reads.reshape(-1).view(np.uint64).sum(dtype=np.uint64)) != reads_sum0:
+                    log("the benchmark's batch on the host is no longer what was sampled: a leg changed it in place")
+                live = live_pmc_traffic(reads_file=reads_file)
+                reads_file = None
                 if live:
                     out["roofline"]["traffic"] = (2 * live["fetch_kb"] + live["write_kb"]) * 1024.0
                     out["roofline"]["traffic_source"] = ("this run: bench.py re-executed under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, 2 launches of the "
