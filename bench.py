@@ -618,15 +618,15 @@ def repeat_dense_leg(device_index, steps=3, want_ref_index=False):
     return out
 
 
-def live_pmc_traffic(steps=2, reads_file=None):
+def live_pmc_traffic(steps=2, reads_file=None, expect=None):
     try:
-        return _live_pmc_traffic(steps, reads_file)
+        return _live_pmc_traffic(steps, reads_file, expect)
     finally:
         if reads_file and os.path.exists(reads_file):
             os.remove(reads_file)
 
 
-def _live_pmc_traffic(steps, rfile):
+def _live_pmc_traffic(steps, rfile, expect):
     """HBM traffic of the SA-search stage measured in THIS run: bench.py re-executes itself (seeding only, `steps` launches, no warm-up) once under
     `rocprofv3 --pmc FETCH_SIZE` and once under `--pmc WRITE_SIZE` -- counters in passes of their own, as the MI355X guide prescribes -- and sums the
     counters over the stage's kernels (k_seed<G> + k_reseed*).  Returns {"fetch_kb", "write_kb"} per launch, or None when the tool is not there or a
@@ -641,7 +641,7 @@ def _live_pmc_traffic(steps, rfile):
         d = tempfile.mkdtemp(prefix="meme_pmc_", dir="/tmp")
         try:
             env = dict(os.environ, TMPDIR="/tmp", **({"MEME_BENCH_READS_FILE": rfile} if rfile else {}), MEME_BENCH_PMC="0", MEME_BENCH_CPU="0", MEME_BENCH_E2E="0", MEME_BENCH_BSW="0", MEME_BENCH_KSWV="0", MEME_BENCH_CHAIN="0",
-                       MEME_BENCH_EXT="0", MEME_BENCH_C4="0", MEME_BENCH_RD="0", MEME_BENCH_PARITY_READS="0")
+                       MEME_BENCH_EXT="0", MEME_BENCH_C4="0", MEME_BENCH_RD="0", MEME_BENCH_PARITY_READS="0", MEME_BENCH_NO_FALLBACK="1")
             r = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "0"],
                                cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             dbs = glob.glob(os.path.join(d, "**", "*results.db"), recursive=True)
@@ -660,6 +660,10 @@ def _live_pmc_traffic(steps, rfile):
                 out[key + "_pass_work"] = {k: cl["config"].get(k) for k in ("smems_per_read", "hits_per_read", "searches_per_read")} | {"stage_ms": cl["roofline"].get("kernel_ms")}
             except Exception:
                 pass
+            pw = out.get(key + "_pass_work")
+            if expect and pw and any(abs((pw.get(k) or 0) - v) > 1e-6 * max(abs(v), 1.0) for k, v in expect.items()):
+                log("pmc pass %s did other work than this run (%r against %r): not used" % (counter, pw, expect))
+                return None
         except Exception as e:
             log("pmc pass %s failed: %r" % (counter, e))
             return None
@@ -990,6 +994,11 @@ def main():
             pass
         gpu_free = torch.cuda.mem_get_info(local)[0] // ranks_per_device
         while mbp > 64 and 2 * mbp * 1e6 * 33 + nreads * 3800 > 0.9 * gpu_free:     # (3 KB of SMEM slots + packed read + outputs per read)
+            if os.environ.get("MEME_BENCH_NO_FALLBACK") == "1":
+                # (the counter passes re-execute this file while their parent is still alive: found in round 6 -- what the parent had not freed made every pass of
+                # rounds 5-6 fall back to HALF the genome without a word, and `roofline.traffic` was that configuration's; a pass now stops instead)
+                log("HBM too small for the configured genome (%.0f GB free) and MEME_BENCH_NO_FALLBACK=1: stopping" % (gpu_free / 1e9))
+                sys.exit(3)
             mbp /= 2
             log("HBM too small for the configured genome: falling back to %.0f Mbp" % mbp)
     l_pac_t = torch.tensor([int(mbp * 1e6) & ~1], dtype=torch.int64, device=dev)
@@ -1414,7 +1423,13 @@ def main():
                     torch.cuda.empty_cache()
                 if reads_sum0 is not None and int(reads.reshape(-1).view(np.uint64).sum(dtype=np.uint64)) != reads_sum0:
                     log("the benchmark's batch on the host is no longer what was sampled: a leg changed it in place")
-                live = live_pmc_traffic(reads_file=reads_file)
+                # (the passes build the whole index again next to this process: everything it still holds in HBM goes first)
+                d_text = d_pos5 = d_l2 = d_l1 = d_ent = d_pac = keep = d_reads = d_off = pre = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                log("counter passes: %.0f of %.0f GB of HBM free" % tuple(x / 1e9 for x in torch.cuda.mem_get_info(local)))
+                live = live_pmc_traffic(reads_file=reads_file, expect={k: out["config"][k] for k in ("smems_per_read", "hits_per_read", "searches_per_read") if k in out["config"]})
                 reads_file = None
                 if live:
                     out["roofline"]["traffic"] = (2 * live["fetch_kb"] + live["write_kb"]) * 1024.0
