@@ -1425,6 +1425,7 @@ def main():
                     log("the benchmark's batch on the host is no longer what was sampled: a leg changed it in place")
                 # (the passes build the whole index again next to this process: everything it still holds in HBM goes first)
                 d_text = d_pos5 = d_l2 = d_l1 = d_ent = d_pac = keep = d_reads = d_off = pre = None
+                d_text0 = d_s = d_pos50 = d_pac0 = d_ent0 = d_l2_0 = d_l1_0 = None          # (the device-built index's tensors are names of this function too: 146 GB in call R6)
                 import gc
                 gc.collect()
                 torch.cuda.empty_cache()
