@@ -111,7 +111,12 @@ struct ChunkDigest {
     std::vector<int64_t> off;                           // read g's records: [off[g], off[g + 1])
     RecDigest* rec = nullptr; int64_t cap = 0;
 } g_digest;
+// (When mem_pestat did not run for the chunk -- insert sizes given with -I, fewer than 64 pairs, MEME_DROPIN_PESTAT=0 -- the CIGAR and the mate-rescue pre-pass of a
+// half arrive here side by side: the first builds, the other waits.  A later call for the same chunk returns what is there; the next chunk's build starts only after
+// this chunk's worker_sam, i.e. after every reader.)
+std::mutex g_digest_mu;
 const ChunkDigest& chunk_digest(const mem_alnreg_v* regs, int64_t n) {
+    std::lock_guard<std::mutex> lk(g_digest_mu);
     ChunkDigest& D = g_digest;
     if (D.gen == g_chunk_gen && D.regs == regs && D.n == n) return D;
     TeamLabel lbl("records: one walk over the heap");
