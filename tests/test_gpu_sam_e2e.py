@@ -97,6 +97,28 @@ def test_sam_identical_to_reference(tmp_path, paired):
 
 @pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
                     reason="compiled reference (oracle/_ref) not available on this box")
+def test_sam_identical_with_given_insert_size(tmp_path):
+    """`mem -I mean,sd`: the insert-size distribution is given, mem_pestat is not called (reference src/fastmap.cpp:1430-1450, src/bwamem.cpp:1950-1959) -- the binding's
+    record digest is then built by whichever pre-pass of the SAM phase arrives first (under a lock since round 6), and mate rescue is posed with the given bounds."""
+    g = synth.make_genome(400_000, seed=41, repeat_frac=0.08, n_families=6, n_dups=6, dup_len=1500)
+    fa = str(tmp_path / "ins.fa")
+    synth.write_fasta(fa, g, contigs=3)
+    prefix = build_index(fa, bits=14)
+    n = 5000
+    a, b = _pe_reads(g, n, 150, seed=61, sub=0.02, indel=0.002)
+    f1, f2 = str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq")
+    synth.write_fastq(f1, a, prefix="i")
+    synth.write_fastq(f2, b, prefix="i")
+    opts = ["-I", "400,60"]
+    want = _sam("bwa-meme_mode3", prefix, [f1, f2], threads=8, chunk=400000, opts=opts, timeout=240)
+    got = _sam("bwa-meme_dropin", prefix, [f1, f2], env=dict(os.environ, MEME_INDEX_PREFIX=prefix, MEME_DROPIN_CHAIN_CHECK="1"), threads=8, chunk=400000, opts=opts, timeout=240)
+    assert len(got) == len(want) and len(want) > 2 * n
+    diff = [(x, y) for x, y in zip(got, want) if x != y]
+    assert not diff, "first differing SAM line:\n%s\n%s" % diff[0]
+
+
+@pytest.mark.skipif(not (R.have("bwa-meme_dropin") and R.have("bwa-meme_mode3") and R.cpu_can_run()),
+                    reason="compiled reference (oracle/_ref) not available on this box")
 def test_sam_identical_ecoli_sized_100k_reads(tmp_path):
     """BASELINE.json configs[0]: an E. coli K-12 sized reference (4.64 Mbp, one contig) and 100 k synthetic 150-bp
     single-end reads through `mem -7`: SAM diff == empty."""
